@@ -1,0 +1,678 @@
+/* dmg_oracle.c -- see dmg_oracle.h.  TEST INFRASTRUCTURE ONLY (parity checker).
+ *
+ * Plain C restatement of the reference's GLSL passes.  "Literal" functions walk
+ * the shader text statement by statement through restated texture-unit
+ * semantics; "rows" functions are the hoisted form (per-row tables + integer
+ * neighbour indices) that the HIP kernels implement and must match bit for bit.
+ */
+#include "dmg_oracle.h"
+#define _GNU_SOURCE
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* GLSL `#define M_PI 3.1415926535897932384626433832795` is a float literal (src/Shader.h:30-31) */
+static const float MPI = 3.1415926535897932384626433832795f;
+
+static int g_bilinear = 0;
+static int g_threads = 0;
+void orc_set_linear_taps(int bilinear) { g_bilinear = bilinear; }
+void orc_set_threads(int n) { g_threads = n; }
+static int nthreads(void)
+{
+#ifdef _OPENMP
+    return g_threads > 0 ? g_threads : omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* ---------- GLSL built-ins ---------- */
+static inline float glsl_mod(float x, float y) { return x - y * floorf(x / y); }
+static inline float glsl_sign(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
+typedef struct { float x, y, z; } vec3;
+static inline vec3 v3(float x, float y, float z) { vec3 r = { x, y, z }; return r; }
+static inline vec3 v3_cross(vec3 a, vec3 b)
+{ return v3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y); }
+static inline float v3_dot(vec3 a, vec3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static inline vec3 v3_scale(vec3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+static inline vec3 v3_add(vec3 a, vec3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline vec3 v3_normalize(vec3 a)
+{ float r = 1.0f / sqrtf(v3_dot(a, a)); return v3(a.x * r, a.y * r, a.z * r); }  /* x * inversesqrt(dot) */
+
+/* ---------- texture unit (src/Texture.cpp:29-33: CLAMP_TO_EDGE, NEAREST or LINEAR) ---------- */
+static inline int clampi(int i, int lo, int hi) { return i < lo ? lo : (i > hi ? hi : i); }
+
+static inline float fetch_nearest(const float *t, int W, int H, int nc, int c, float u, float v)
+{
+    int i = clampi((int)floorf(u * (float)W), 0, W - 1);
+    int j = clampi((int)floorf(v * (float)H), 0, H - 1);
+    return t[((size_t)j * W + i) * nc + c];
+}
+
+static inline float fetch_linear(const float *t, int W, int H, int nc, int c, float u, float v)
+{
+    float fu = u * (float)W - 0.5f, fv = v * (float)H - 0.5f;
+    float flu = floorf(fu), flv = floorf(fv);
+    float wx = fu - flu, wy = fv - flv;
+    int i0 = clampi((int)flu, 0, W - 1), i1 = clampi((int)flu + 1, 0, W - 1);
+    int j0 = clampi((int)flv, 0, H - 1), j1 = clampi((int)flv + 1, 0, H - 1);
+    float t00 = t[((size_t)j0 * W + i0) * nc + c], t10 = t[((size_t)j0 * W + i1) * nc + c];
+    float t01 = t[((size_t)j1 * W + i0) * nc + c], t11 = t[((size_t)j1 * W + i1) * nc + c];
+    float a = t00 + wx * (t10 - t00);
+    float b = t01 + wx * (t11 - t01);
+    return a + wy * (b - a);
+}
+
+/* tap of a GL_LINEAR texture at a texel-centre-ish coordinate (see orc_set_linear_taps) */
+static inline float tap_linear(const float *t, int W, int H, int nc, int c, float u, float v)
+{
+    return g_bilinear ? fetch_linear(t, W, H, nc, c, u, v) : fetch_nearest(t, W, H, nc, c, u, v);
+}
+
+/* ---------- cornerCoords library (src/Shader.h:43-99) ---------- */
+void orc_tex_to_spheric(const orc_grid *g, float sx, float sy, float *lon, float *lat)
+{   /* :49-53 */
+    *lon = (sx * (g->coords[3] - g->coords[2]) + g->coords[2]);
+    *lat = (sy * (g->coords[1] - g->coords[0]) + g->coords[0]);
+}
+
+static inline void spheric_to_tex(const orc_grid *g, float lon, float lat, float *sx, float *sy)
+{   /* :55-59 */
+    *sx = (lon - g->coords[2]) / (g->coords[3] - g->coords[2]);
+    *sy = (lat - g->coords[0]) / (g->coords[1] - g->coords[0]);
+}
+
+static inline vec3 spheric_to_cartesian(float lon, float lat)
+{   /* :61-63 */
+    return v3(cosf(lat) * cosf(lon), cosf(lat) * sinf(lon), sinf(lat));
+}
+
+/* pixelsize(st) :71-74 -- `vec2(dlon*cos(lat), dlat)*circumference/(2*M_PI) / textureSize(img,0)` */
+void orc_pixelsize(const orc_grid *g, float sty, float *dx, float *dy)
+{
+    float lon, lat;
+    orc_tex_to_spheric(g, 0.0f, sty, &lon, &lat);
+    float two_pi = 2.0f * MPI;
+    *dx = ((g->coords[3] - g->coords[2]) * cosf(lat)) * g->circumference / two_pi / (float)g->W;
+    *dy = (g->coords[1] - g->coords[0]) * g->circumference / two_pi / (float)g->H;
+}
+
+/* offset(p, dp, resolution) :82-98 (offset_no_globe_wrap is never set by any filter: false) */
+void orc_offset(const orc_grid *g, float px, float py, float dpx, float dpy, float resx, float resy,
+                float *ox, float *oy)
+{
+    const float *c = g->coords;
+    float two_pi = 2.0f * MPI;
+    px = px + dpx / resx;
+    py = py + dpy / resy;
+    int lonwrap = (c[2] < -MPI + 1e-4f) && (c[3] > MPI - 1e-3f);
+    if (lonwrap) px = glsl_mod(px + 1.0f, 1.0f);
+    if (c[0] < -MPI / 2.0f + 1e-4f && py < 0.0f) {
+        py = -py;
+        px = glsl_mod((px * (c[3] - c[2]) + c[2]) + two_pi, two_pi) - MPI;
+        px = (px - c[2]) / (c[3] - c[2]);
+    }
+    if (c[1] > MPI / 2.0f - 1e-4f && py > 1.0f) {
+        py = 2.0f - py;
+        px = glsl_mod((px * (c[3] - c[2]) + c[2]) + two_pi, two_pi) - MPI;
+        px = (px - c[2]) / (c[3] - c[2]);
+    }
+    if (lonwrap) px = glsl_mod(px + 1.0f, 1.0f);
+    *ox = px;
+    *oy = py;
+}
+
+static inline float stx(const orc_grid *g, int x) { return ((float)x + 0.5f) / (float)g->W; }
+static inline float sty(const orc_grid *g, int y) { return ((float)y + 0.5f) / (float)g->H; }
+
+/* ====================================================================== */
+/* Ocean currents                                                          */
+/* ====================================================================== */
+
+/* One Jacobi sweep, literal: OceanCurrents.cpp:450-481.
+ * pressure/divw are GL_LINEAR (:44,54), img is the Layer texture, GL_NEAREST (src/menus/LayerWindow.cpp:78-84). */
+static void jacobi_sweep_literal(const orc_grid *g, const float *img, const float *divw, const float *p, float *out)
+{
+    const int W = g->W, H = g->H;
+    const float rx = (float)W, ry = (float)H;   /* resolution = textureSize(pressure,0) */
+#pragma omp parallel for schedule(static) num_threads(nthreads())
+    for (int y = 0; y < H; y++) {
+        float sy = sty(g, y);
+        float dx, dy;
+        orc_pixelsize(g, sy, &dx, &dy);
+        float wx = dx / 420.0f, wy = dy / 420.0f;
+        float pw2x = wx * wx, pw2y = wy * wy;                 /* pow(v, vec2(2,2)) */
+        float Beta = 2.0f * (1.0f / pw2x + 1.0f / pw2y);      /* :479 */
+        for (int x = 0; x < W; x++) {
+            float sx = stx(g, x);
+            float nx, ny, sx2, sy2, ex, ey, wx2, wy2;
+            orc_offset(g, sx, sy, 0, 1, rx, ry, &nx, &ny);
+            orc_offset(g, sx, sy, 0, -1, rx, ry, &sx2, &sy2);
+            orc_offset(g, sx, sy, 1, 0, rx, ry, &ex, &ey);
+            orc_offset(g, sx, sy, -1, 0, rx, ry, &wx2, &wy2);
+            float pN = tap_linear(p, W, H, 1, 0, nx, ny);
+            float pS = tap_linear(p, W, H, 1, 0, sx2, sy2);
+            float pE = tap_linear(p, W, H, 1, 0, ex, ey);
+            float pW = tap_linear(p, W, H, 1, 0, wx2, wy2);
+            float pC = tap_linear(p, W, H, 1, 0, sx, sy);
+            float oN = fetch_nearest(img, W, H, 1, 0, nx, ny);
+            float oS = fetch_nearest(img, W, H, 1, 0, sx2, sy2);
+            float oE = fetch_nearest(img, W, H, 1, 0, ex, ey);
+            float oW = fetch_nearest(img, W, H, 1, 0, wx2, wy2);
+            float oC = fetch_nearest(img, W, H, 1, 0, sx, sy);
+            if (oN > 0) pN = pC;
+            if (oS > 0) pS = pC;
+            if (oE > 0) pE = pC;
+            if (oW > 0) pW = pC;
+            float bC = tap_linear(divw, W, H, 1, 0, sx, sy);
+            float fc = ((pW + pE) / pw2x + (pS + pN) / pw2y - bC) / Beta;   /* :480 */
+            if (oC > 0) fc = 0;
+            out[(size_t)y * W + x] = fc;
+        }
+    }
+}
+
+/* OceanCurrents::jacobi host loop :500-508 (the caller zeroes p like :495-497 when it wants a full solve) */
+void orc_ocean_jacobi(const orc_grid *g, const float *img, const float *divw, float *p, float *scratch, int iters)
+{
+    float *a = p, *b = scratch;
+    for (int i = 0; i < iters; i++) {
+        jacobi_sweep_literal(g, img, divw, a, b);
+        float *t = a; a = b; b = t;                              /* pressure->swap(scratch) */
+    }
+    if (a != p) memcpy(p, a, sizeof(float) * (size_t)g->W * g->H);
+}
+
+/* ---- row tables + neighbour indices (the HIP kernels' contract) ---- */
+void orc_jacobi_row_tables(const orc_grid *g, float *cx, float *cy, float *beta)
+{
+    for (int y = 0; y < g->H; y++) {
+        float dx, dy;
+        orc_pixelsize(g, sty(g, y), &dx, &dy);
+        float wx = dx / 420.0f, wy = dy / 420.0f;
+        cx[y] = wx * wx;
+        cy[y] = wy * wy;
+        beta[y] = 2.0f * (1.0f / cx[y] + 1.0f / cy[y]);
+    }
+}
+
+void orc_pole_columns(const orc_grid *g, int *polecol)
+{
+    /* literal evaluation of the pole branch of offset() for a tap that leaves the grid through a pole;
+     * south and north branches are the same expression in p.x (src/Shader.h:88-89 == :93-94). */
+    const int W = g->W;
+    for (int x = 0; x < W; x++) {
+        float ox, oy;
+        if (g->coords[0] < -MPI / 2.0f + 1e-4f)
+            orc_offset(g, stx(g, x), sty(g, 0), 0, -1, (float)W, (float)g->H, &ox, &oy);
+        else
+            orc_offset(g, stx(g, x), sty(g, g->H - 1), 0, 1, (float)W, (float)g->H, &ox, &oy);
+        polecol[x] = clampi((int)floorf(ox * (float)W), 0, W - 1);
+    }
+}
+
+/* neighbour index rules equivalent to offset()+NEAREST for integer steps */
+typedef struct { int lonwrap, spole, npole; } orc_topo;
+static orc_topo topo_of(const orc_grid *g)
+{
+    orc_topo t;
+    t.lonwrap = (g->coords[2] < -MPI + 1e-4f) && (g->coords[3] > MPI - 1e-3f);
+    t.spole = g->coords[0] < -MPI / 2.0f + 1e-4f;
+    t.npole = g->coords[1] > MPI / 2.0f - 1e-4f;
+    return t;
+}
+
+void orc_ocean_jacobi_rows(const orc_grid *g, const float *img, const float *divw, float *p, float *scratch,
+                           int iters, int nth)
+{
+    const int W = g->W, H = g->H;
+    float *cx = malloc(sizeof(float) * H), *cy = malloc(sizeof(float) * H), *be = malloc(sizeof(float) * H);
+    int *pc = malloc(sizeof(int) * W);
+    orc_jacobi_row_tables(g, cx, cy, be);
+    orc_pole_columns(g, pc);
+    orc_topo t = topo_of(g);
+    if (nth <= 0) nth = nthreads();
+    float *a = p, *b = scratch;
+    for (int it = 0; it < iters; it++) {
+#pragma omp parallel for schedule(static) num_threads(nth)
+        for (int y = 0; y < H; y++) {
+            const float pw2x = cx[y], pw2y = cy[y], Beta = be[y];
+            const float *rowC = a + (size_t)y * W, *imgC = img + (size_t)y * W;
+            /* north / south rows; pole rows reflect into themselves at column polecol[x] */
+            int yn = y + 1, ys = y - 1, nflip = 0, sflip = 0;
+            if (yn >= H) { yn = H - 1; nflip = t.npole; }
+            if (ys < 0) { ys = 0; sflip = t.spole; }
+            const float *rowN = a + (size_t)yn * W, *imgN = img + (size_t)yn * W;
+            const float *rowS = a + (size_t)ys * W, *imgS = img + (size_t)ys * W;
+            for (int x = 0; x < W; x++) {
+                int xe = x + 1, xw = x - 1;
+                if (t.lonwrap) { if (xe >= W) xe = 0; if (xw < 0) xw = W - 1; }
+                else { if (xe >= W) xe = W - 1; if (xw < 0) xw = 0; }
+                int xn = nflip ? pc[x] : x, xs = sflip ? pc[x] : x;
+                float pC = rowC[x];
+                float pN = imgN[xn] > 0 ? pC : rowN[xn];
+                float pS = imgS[xs] > 0 ? pC : rowS[xs];
+                float pE = imgC[xe] > 0 ? pC : rowC[xe];
+                float pW = imgC[xw] > 0 ? pC : rowC[xw];
+                float fc = ((pW + pE) / pw2x + (pS + pN) / pw2y - divw[(size_t)y * W + x]) / Beta;
+                if (imgC[x] > 0) fc = 0;
+                b[(size_t)y * W + x] = fc;
+            }
+        }
+        float *s = a; a = b; b = s;
+    }
+    if (a != p) memcpy(p, a, sizeof(float) * (size_t)W * H);
+    free(cx); free(cy); free(be); free(pc);
+}
+
+/* get_velocity(st,o) of divergence/diffusion shaders (OceanCurrents.cpp:376-393, :647-661).
+ * Returns v (sign-flipped across a pole) and the neighbour coordinate. */
+static inline void get_velocity(const orc_grid *g, const float *v, float sx, float sy, float ox, float oy,
+                                float *vx, float *vy, float *sox, float *soy)
+{
+    const int W = g->W, H = g->H;
+    float px, py;
+    orc_offset(g, sx, sy, ox, oy, (float)W, (float)H, &px, &py);
+    float lon, lat, lon_o, lat_o;
+    orc_tex_to_spheric(g, sx, sy, &lon, &lat);
+    orc_tex_to_spheric(g, px, py, &lon_o, &lat_o);
+    float a = tap_linear(v, W, H, 2, 0, px, py), b = tap_linear(v, W, H, 2, 1, px, py);
+    if (fabsf(fabsf(lon - lon_o) - 3.14159f) < 0.1f) { a = -a; b = -b; }   /* :389 / :657 */
+    *vx = a; *vy = b; *sox = px; *soy = py;
+}
+
+/* divergence shader :376-420 */
+void orc_ocean_divergence(const orc_grid *g, const float *img, const float *v, float pressurefactor, float *out)
+{
+    const int W = g->W, H = g->H;
+#pragma omp parallel for schedule(static) num_threads(nthreads())
+    for (int y = 0; y < H; y++) {
+        float sy = sty(g, y);
+        float dxc, dyc;
+        orc_pixelsize(g, sy, &dxc, &dyc);
+        float pwx = dxc / 420.0f, pwy = dyc / 420.0f;      /* :419 */
+        for (int x = 0; x < W; x++) {
+            float sx = stx(g, x);
+            float vel[4][2], so[4][2];
+            const float offs[4][2] = { { 0, 1 }, { 0, -1 }, { 1, 0 }, { -1, 0 } };   /* N S E W */
+            float o[4];
+            for (int k = 0; k < 4; k++) {
+                get_velocity(g, v, sx, sy, offs[k][0], offs[k][1], &vel[k][0], &vel[k][1], &so[k][0], &so[k][1]);
+                float ddx, ddy;
+                orc_pixelsize(g, so[k][1], &ddx, &ddy);                 /* d_o = pixelsize(st_o) */
+                float area = ddx * ddy;
+                vel[k][0] = vel[k][0] * area * pressurefactor;          /* :392 */
+                vel[k][1] = vel[k][1] * area * pressurefactor;
+                o[k] = fetch_nearest(img, W, H, 1, 0, so[k][0], so[k][1]);
+            }
+            float vNy = vel[0][1], vSy = vel[1][1], vEx = vel[2][0], vWx = vel[3][0];
+            if (o[0] > 0) vNy = 0;
+            if (o[1] > 0) vSy = 0;
+            if (o[2] > 0) vEx = 0;
+            if (o[3] > 0) vWx = 0;
+            out[(size_t)y * W + x] = 0.5f * ((vEx - vWx) / pwx + (vNy - vSy) / pwy);   /* :420 */
+        }
+    }
+}
+
+/* diffusion shader :664-693, `iters` ping-pong sweeps :701-707 */
+void orc_ocean_diffusion(const orc_grid *g, const float *img, float *v, float *scratch, int iters, int scalar_rhs)
+{
+    const int W = g->W, H = g->H;
+    float *a = v, *b = scratch;
+    for (int it = 0; it < iters; it++) {
+#pragma omp parallel for schedule(static) num_threads(nthreads())
+        for (int y = 0; y < H; y++) {
+            float sy = sty(g, y);
+            float dx, dy;
+            orc_pixelsize(g, sy, &dx, &dy);
+            /* :689  1*1/pow(pixelsize(st),vec2(2,2))*420*420 */
+            float px2 = 1.0f / (dx * dx) * 420.0f * 420.0f;
+            float py2 = 1.0f / (dy * dy) * 420.0f * 420.0f;
+            float s = 2.0f * (px2 + py2);
+            float Beta = s * (1.0f + 1.0f / s);          /* :690 */
+            for (int x = 0; x < W; x++) {
+                float sx = stx(g, x);
+                const float offs[4][2] = { { 0, 1 }, { 0, -1 }, { 1, 0 }, { -1, 0 } };
+                float pv[4][2], so[4][2];
+                float pCx = tap_linear(a, W, H, 2, 0, sx, sy), pCy = tap_linear(a, W, H, 2, 1, sx, sy);
+                for (int k = 0; k < 4; k++) {
+                    get_velocity(g, a, sx, sy, offs[k][0], offs[k][1], &pv[k][0], &pv[k][1], &so[k][0], &so[k][1]);
+                    if (fetch_nearest(img, W, H, 1, 0, so[k][0], so[k][1]) > 0) { pv[k][0] = pCx; pv[k][1] = pCy; }
+                }
+                float bCx = pCx, bCy = scalar_rhs ? pCx : pCy;     /* :687 `float bC = texture(v,st).r` */
+                /* :693  ((pW + pE)*pw2.x + (pS + pN)*pw2.y - (-bC)) / Beta */
+                b[((size_t)y * W + x) * 2 + 0] = ((pv[3][0] + pv[2][0]) * px2 + (pv[1][0] + pv[0][0]) * py2 - (-bCx)) / Beta;
+                b[((size_t)y * W + x) * 2 + 1] = ((pv[3][1] + pv[2][1]) * px2 + (pv[1][1] + pv[0][1]) * py2 - (-bCy)) / Beta;
+            }
+        }
+        float *t = a; a = b; b = t;
+    }
+    if (a != v) memcpy(v, a, sizeof(float) * 2 * (size_t)W * H);
+}
+
+/* v_to_cartesian / cartesian_to_v (OceanCurrents.cpp:251-268) */
+static inline vec3 v_to_cartesian(float vx, float vy, float lon, float lat)
+{
+    vec3 c = spheric_to_cartesian(lon, lat);
+    float il = 1.0f / sqrtf(c.x * c.x + c.y * c.y);
+    float inx = c.x * il, iny = c.y * il;                                   /* normalize(c.xy) */
+    vec3 ycomp = v3(sinf(lat) * (-inx), sinf(lat) * (-iny), cosf(lat));
+    vec3 par = v3_normalize(v3_cross(v3(0, 0, 1), c));
+    return v3_add(v3_scale(par, vx), v3_scale(ycomp, vy));
+}
+static inline void cartesian_to_v(vec3 v, float lon, float lat, float *ox, float *oy)
+{
+    vec3 c = spheric_to_cartesian(lon, lat);
+    float il = 1.0f / sqrtf(c.x * c.x + c.y * c.y);
+    float inx = c.x * il, iny = c.y * il;
+    vec3 ycomp = v3(sinf(lat) * (-inx), sinf(lat) * (-iny), cosf(lat));
+    vec3 par = v3_normalize(v3_cross(v3(0, 0, 1), c));
+    *ox = v3_dot(v, par);
+    *oy = v3_dot(v, ycomp);
+}
+/* rotation_matrix(theta,u)*v (src/Shader.h:35-40): mat3 is column-major, M*v = c0*v.x + c1*v.y + c2*v.z */
+static inline vec3 rotate(float theta, vec3 u, vec3 v)
+{
+    float c = cosf(theta), s = sinf(theta), ic = 1.0f - c;
+    vec3 c0 = v3(c + u.x * u.x * ic, u.y * u.x * ic + u.z * s, u.z * u.x * ic - u.y * s);
+    vec3 c1 = v3(u.x * u.y * ic - u.z * s, c + u.y * u.y * ic, u.z * u.y * ic + u.x * s);
+    vec3 c2 = v3(u.x * u.z * ic + u.y * s, u.y * u.z * ic - u.x * s, c + u.z * u.z * ic);
+    return v3_add(v3_add(v3_scale(c0, v.x), v3_scale(c1, v.y)), v3_scale(c2, v.z));
+}
+
+/* advect shader :282-348 */
+void orc_ocean_advect(const orc_grid *g, const float *img, const float *v, float *out)
+{
+    const int W = g->W, H = g->H;
+    const float k04 = powf(0.4f, 1.0f / 24.0f);          /* pow(vec2(0.4),vec2(1.0/24)) :348 */
+#pragma omp parallel for schedule(static) num_threads(nthreads())
+    for (int y = 0; y < H; y++) {
+        float sy = sty(g, y);
+        for (int x = 0; x < W; x++) {
+            float sx = stx(g, x);
+            float *o = out + ((size_t)y * W + x) * 2;
+            if (fetch_nearest(img, W, H, 1, 0, sx, sy) > 0) { o[0] = 0; o[1] = 0; continue; }   /* :284-288 */
+            float velx = tap_linear(v, W, H, 2, 0, sx, sy), vely = tap_linear(v, W, H, 2, 1, sx, sy);   /* :290 */
+            float timestep = 24.0f;
+            float distance = sqrtf(velx * velx + vely * vely) * timestep;          /* :298 */
+            float arclength = 2.0f * 3.14159f / g->circumference * distance;       /* :299 */
+            float lon, lat;
+            orc_tex_to_spheric(g, sx, sy, &lon, &lat);
+            vec3 cart = spheric_to_cartesian(lon, lat);
+            vec3 v_cart = v_to_cartesian(velx, vely, lon, lat);
+            vec3 rotdir = v3_normalize(v3_cross(cart, v_cart));                    /* :306 */
+            cart = rotate(-arclength, rotdir, cart);                               /* :308 */
+            float lon_n = atan2f(cart.y, cart.x), lat_n = asinf(cart.z);           /* cartesian_to_spheric */
+            float cx, cy;
+            spheric_to_tex(g, lon_n, lat_n, &cx, &cy);
+            float nvx = fetch_linear(v, W, H, 2, 0, cx, cy), nvy = fetch_linear(v, W, H, 2, 1, cx, cy);   /* :315 */
+            vec3 testv = v_to_cartesian(nvx, nvy, lon_n, lat_n);
+            testv = rotate(arclength, rotdir, testv);
+            cartesian_to_v(testv, lon, lat, &nvx, &nvy);
+            if (isnan(nvx) || isnan(nvy)) { nvx = 0; nvy = 0; }                    /* :321 */
+            /* Coriolis term is multiplied by 0.0 (:327); NaN/Inf cannot arise from it once newV is finite */
+            float fcx = 1.0f * nvx, fcy = 1.0f * nvy;                              /* Dissipation :332 */
+            float phi = 2.0f * (sy - 0.5f) * 3.14159f;                             /* :341 */
+            float windx = 10.0f * -cosf(phi * 3.0f / 2.0f), windy = 10.0f * sinf(phi * 3.0f / 2.0f);
+            if (fabsf(phi * 3.0f / 2.0f) > 3.14159f) windx = -windx;
+            if (fabsf(phi) > 3.14159f * 1.0f / 3.0f && fabsf(phi) < 3.1459f * 2.0f / 3.0f) windy = -windy;   /* sic 3.1459 */
+            if (phi < 0) windy = -windy;
+            float ax = fabsf(windx - fcx), ay = fabsf(windy - fcy);
+            float stressx = 1.0f + 0.0001f * (ax * ax), stressy = 1.0f + 0.0001f * (ay * ay);   /* :347 */
+            float e = -1.0f / 24.0f * 2.0f;                                        /* -vec2(1.0)/24.0*2 */
+            o[0] = fcx + windx * (1.0f - powf(stressx, e)) - fcx * (1.0f - k04);    /* :348 */
+            o[1] = fcy + windy * (1.0f - powf(stressy, e)) - fcy * (1.0f - k04);
+        }
+    }
+}
+
+/* subDiv shader :532-606 */
+void orc_ocean_subdiv(const orc_grid *g, const float *img, const float *v, const float *pressure,
+                      float pressurefactor, float *out)
+{
+    const int W = g->W, H = g->H;
+    const float rx = (float)W, ry = (float)H;
+    static const float offsets[8][2] = { { 1, 0 }, { 1, 1 }, { 0, 1 }, { -1, 1 }, { -1, 0 }, { -1, -1 }, { 0, -1 }, { 1, -1 } };  /* :560 */
+#pragma omp parallel for schedule(static) num_threads(nthreads())
+    for (int y = 0; y < H; y++) {
+        float sy = sty(g, y);
+        float dx, dy;
+        orc_pixelsize(g, sy, &dx, &dy);
+        float pwx = dx / 420.0f, pwy = dy / 420.0f;      /* :574 */
+        for (int x = 0; x < W; x++) {
+            float sx = stx(g, x);
+            float *o = out + ((size_t)y * W + x) * 2;
+            if (fetch_nearest(img, W, H, 1, 0, sx, sy) > 0) { o[0] = 0; o[1] = 0; continue; }   /* :536-540 */
+            float c[4][2];
+            const float offs[4][2] = { { 0, 1 }, { 0, -1 }, { 1, 0 }, { -1, 0 } };
+            float pn[4], on[4];
+            float pC = tap_linear(pressure, W, H, 1, 0, sx, sy);
+            for (int k = 0; k < 4; k++) {
+                orc_offset(g, sx, sy, offs[k][0], offs[k][1], rx, ry, &c[k][0], &c[k][1]);
+                pn[k] = tap_linear(pressure, W, H, 1, 0, c[k][0], c[k][1]);
+                on[k] = fetch_nearest(img, W, H, 1, 0, c[k][0], c[k][1]);
+                if (on[k] > 0) pn[k] = pC;                                          /* :566-569 */
+            }
+            float oldx = tap_linear(v, W, H, 2, 0, sx, sy), oldy = tap_linear(v, W, H, 2, 1, sx, sy);
+            /* :575  oldV - 0.5*vec2(pE-pW,pN-pS)/pixelwidth / pixelsize.x / pixelsize.y / pressurefactor */
+            float fx = oldx - 0.5f * (pn[2] - pn[3]) / pwx / dx / dy / pressurefactor;
+            float fy = oldy - 0.5f * (pn[0] - pn[1]) / pwy / dx / dy / pressurefactor;
+            float o_array[8];
+            for (int i = 0; i < 8; i++) {
+                float qx, qy;
+                orc_offset(g, sx, sy, offsets[i][0], offsets[i][1], rx, ry, &qx, &qy);
+                o_array[i] = fetch_nearest(img, W, H, 1, 0, qx, qy);
+            }
+            float ang = (atan2f(fy, fx) / MPI + 1.0f) / 2.0f * 8.0f + 4.0f;
+            float lower = glsl_mod(floorf(ang), 8.0f);
+            float upper = glsl_mod(ceilf(ang), 8.0f);
+            float theta = glsl_mod(ang, 8.0f);
+            int isBorder = o_array[clampi((int)lower, 0, 7)] > 0 || o_array[clampi((int)upper, 0, 7)] > 0;
+            float nx = fx, ny = fy;
+            float difference = 2.0f * MPI;
+            for (int i = 0; i < 8; i++) {
+                float ox = offsets[i][0], oy = offsets[i][1];
+                float thetai = glsl_mod((atan2f(oy, ox) / MPI + 1.0f) / 2.0f * 8.0f + 4.0f, 8.0f);
+                float d = fabsf(thetai - theta);
+                float angleToVel = fminf((2.0f * MPI) - d, d);
+                if (angleToVel < difference && o_array[clampi((int)roundf(thetai), 0, 7)] <= 0) {
+                    difference = angleToVel;
+                    float lo = sqrtf(ox * ox + oy * oy), ln = sqrtf(nx * nx + ny * ny);
+                    nx = ox / lo * ln;
+                    ny = oy / lo * ln;
+                }
+            }
+            if (isBorder) { fx = nx; fy = ny; }
+            o[0] = fx; o[1] = fy;
+        }
+    }
+}
+
+/* ====================================================================== */
+/* Gaussian blur (src/filter/BlurMenu.cpp)                                 */
+/* ====================================================================== */
+int orc_blur_rlist(float radius, float *rlist, int cap)
+{
+    /* :27 radius = radius/2;  :79-94 schedule, fp32 with the reference's implicit double sqrt */
+    radius = radius / 2;
+    float R = radius * radius / 2;
+    int n = 0;
+    float i = 1.0f, incrementer = 0.5f;
+    if (R < 3) {
+        float k = (float)(1 / sqrt((double)(55 / R)));
+        incrementer = k;
+        i = k;
+    }
+    while (R >= i * i) {
+        R -= i * i;
+        if (n < cap) rlist[n] = i;
+        n++;
+        i += incrementer;
+    }
+    if (R > 0.0f) { if (n < cap) rlist[n] = (float)sqrt((double)R); n++; }
+    /* std::sort ascending :94 */
+    int m = n < cap ? n : cap;
+    for (int a = 1; a < m; a++) { float k = rlist[a]; int b = a - 1; while (b >= 0 && rlist[b] > k) { rlist[b + 1] = rlist[b]; b--; } rlist[b + 1] = k; }
+    return n;
+}
+
+/* blur13 :41-62; image is GL_LINEAR (:29-30): genuine bilinear taps at fractional offsets */
+void orc_blur13_pass(const orc_grid *g, const float *src, float dirx, float diry, float *dst)
+{
+    const int W = g->W, H = g->H;
+    const float rx = (float)W, ry = (float)H;
+    const float k1 = 1.411764705882353f, k2 = 3.2941176470588234f, k3 = 5.176470588235294f;
+    const float w0 = 0.1964825501511404f, w1 = 0.2969069646728344f, w2 = 0.09447039785044732f, w3 = 0.010381362401148057f;
+#pragma omp parallel for schedule(static) num_threads(nthreads())
+    for (int y = 0; y < H; y++) {
+        float sy = sty(g, y);
+        float lon, lat;
+        orc_tex_to_spheric(g, 0.0f, sy, &lon, &lat);
+        float phifactor = cosf(fabsf(lat));                                   /* :49 */
+        float o1x = k1 * dirx / phifactor, o2x = k2 * dirx / phifactor, o3x = k3 * dirx / phifactor;
+        float o1y = k1 * diry, o2y = k2 * diry, o3y = k3 * diry;
+        for (int x = 0; x < W; x++) {
+            float sx = stx(g, x);
+            float color = 0.0f, px, py;
+            color += fetch_linear(src, W, H, 1, 0, sx, sy) * w0;
+            orc_offset(g, sx, sy, o1x, o1y, rx, ry, &px, &py);   color += fetch_linear(src, W, H, 1, 0, px, py) * w1;
+            orc_offset(g, sx, sy, -o1x, -o1y, rx, ry, &px, &py); color += fetch_linear(src, W, H, 1, 0, px, py) * w1;
+            orc_offset(g, sx, sy, o2x, o2y, rx, ry, &px, &py);   color += fetch_linear(src, W, H, 1, 0, px, py) * w2;
+            orc_offset(g, sx, sy, -o2x, -o2y, rx, ry, &px, &py); color += fetch_linear(src, W, H, 1, 0, px, py) * w2;
+            orc_offset(g, sx, sy, o3x, o3y, rx, ry, &px, &py);   color += fetch_linear(src, W, H, 1, 0, px, py) * w3;
+            orc_offset(g, sx, sy, -o3x, -o3y, rx, ry, &px, &py); color += fetch_linear(src, W, H, 1, 0, px, py) * w3;
+            dst[(size_t)y * W + x] = color;
+        }
+    }
+}
+
+void orc_blur(const orc_grid *g, float *field, float *scratch, float radius)
+{
+    float rl[4096];
+    int n = orc_blur_rlist(radius, rl, 4096);
+    /* Blur::step :97-117: vertical tex1->tex2 with direction (0,r), horizontal tex2->tex1 with (r,0);
+     * `i>rlist.size()-1` is an unsigned compare: an empty rlist never happens for radius>0 */
+    int i = 0;
+    do {
+        orc_blur13_pass(g, field, 0.0f, rl[i], scratch);
+        orc_blur13_pass(g, scratch, rl[i], 0.0f, field);
+        i++;
+    } while (!(i > n - 1));
+}
+
+/* ====================================================================== */
+/* Climate (src/filter/Temperature.cpp:56-134)                             */
+/* ====================================================================== */
+static float qday(float phi, float M)
+{
+    const float eccentricity = 0.017f;
+    const float gamma = 23.44f / 180.0f * MPI;
+    const float omega = 0.0f, omega2 = 77.05f / 180.0f * MPI;
+    const float S0 = 1365.0f;
+    /* A(M) :73-75 */
+    float e3 = eccentricity * eccentricity * eccentricity;   /* pow(e,3) */
+    float A = M + (2.0f * eccentricity - e3 / 4.0f * sinf(M) + 5.0f / 4.0f * (eccentricity * eccentricity) * sinf(2.0f * M)
+                   + 13.0f / 12.0f * e3 * sinf(3.0f * M));
+    float Ls = A - omega2;
+    float delt = asinf(sinf(gamma) * sinf(Ls));
+    /* h0 :85-89 */
+    float h = glsl_sign(phi) == glsl_sign(delt) ? MPI : 0.0f;
+    if (fabsf(phi) <= MPI / 2.0f - fabsf(delt)) h = acosf(-tanf(phi) * tanf(delt));
+    float S = S0 * (1.0f + 2.0f * eccentricity * cosf(A - omega));
+    return S / MPI * (h * sinf(phi) * sinf(delt) + cosf(phi) * cosf(delt) * sinf(h));
+}
+
+void orc_temperature(const orc_grid *g, float *T, float *scratch, const float *terrain, int first_step, int n_steps)
+{
+    const int W = g->W, H = g->H;
+    const float rx = (float)W, ry = (float)H;
+    float *a = T, *b = scratch;
+    for (int i = first_step; i < first_step + n_steps; i++) {
+        float M = (float)(M_PI * 2 / 15000 * i);          /* :146 glUniform1f(id, M_PI*2/15000*i) */
+#pragma omp parallel for schedule(static) num_threads(nthreads())
+        for (int y = 0; y < H; y++) {
+            float sy = sty(g, y);
+            float lon, phi;
+            orc_tex_to_spheric(g, 0.0f, sy, &lon, &phi);
+            float ASR = (1.0f - 0.30f) * qday(phi, M);     /* :102,:122 */
+            float factor = cosf(phi);                      /* get_texture_laplacian, Shader.h:301-302 */
+            float dx, dy;
+            orc_pixelsize(g, sy, &dx, &dy);
+            float den = 4.0f * (dy * dy);                  /* 4*pow(pixelwidth.y,2) */
+            for (int x = 0; x < W; x++) {
+                float sx = stx(g, x);
+                float Tc = fetch_nearest(a, W, H, 1, 0, sx, sy);
+                float terr = fetch_nearest(terrain, W, H, 1, 0, sx, sy);
+                float s[9];
+                /* Shader.h:304-312: taps offset(st,-vec2(i/factor, j)) for a..i */
+                const float ox[9] = { 1, 0, -1, 1, 0, -1, 1, 0, -1 };
+                const float oy[9] = { 1, 1, 1, 0, 0, 0, -1, -1, -1 };
+                for (int k = 0; k < 9; k++) {
+                    float px, py;
+                    float dpx = ox[k] == 0 ? -0.0f : -(ox[k] / factor);
+                    orc_offset(g, sx, sy, dpx, -oy[k], rx, ry, &px, &py);
+                    s[k] = fetch_nearest(a, W, H, 1, 0, px, py);
+                }
+                float A_ = s[0], B_ = s[1], C_ = s[2], D_ = s[3], E_ = s[4], F_ = s[5], G_ = s[6], H_ = s[7], I_ = s[8];
+                float delta_x = (A_ - 2 * B_ + C_ + 2 * D_ - 4 * E_ + 2 * F_ + G_ - 2 * H_ + I_) / den;
+                float delta_y = (A_ + 2 * B_ + C_ - 2 * D_ - 4 * E_ - 2 * F_ + G_ + 2 * H_ + I_) / den;
+                if (isnan(delta_x)) delta_x = 0;
+                if (isnan(delta_y)) delta_y = 0;
+                float t = Tc + 273.15f;
+                float t2 = t * t, r2 = 273.4f * 273.4f;
+                float OLR = 210.0f * (t2 * t2) / (r2 * r2) * 0.93f;            /* :125 */
+                float change = ASR - OLR + 0.55f * 1e6f * (delta_x + delta_y);   /* :128 */
+                float atmosphere = 1e7f;
+                float C = atmosphere + (terr > 0 ? atmosphere * 0.5f : 4.0f * 1.5f * atmosphere);
+                b[(size_t)y * W + x] = Tc + change * 3.154f * 1e7f / 15000.0f / C;   /* :133 */
+            }
+        }
+        float *t = a; a = b; b = t;
+    }
+    if (a != T) memcpy(T, a, sizeof(float) * (size_t)W * H);
+}
+
+/* ====================================================================== */
+/* Erosion / uplift pass (src/filter/cpufilter.cpp:121-198)                 */
+/* ====================================================================== */
+void orc_erosion_pass(const orc_grid *g, const float *hgt, const float *flow, const float *updrift,
+                      float factor, float slope_exponent, float *out)
+{
+    const int W = g->W, H = g->H;
+    const float rx = (float)W, ry = (float)H;
+    static const float offs[8][2] = { { 1, 1 }, { 0, 1 }, { -1, 1 }, { 1, 0 }, { -1, 0 }, { 1, -1 }, { 0, -1 }, { -1, -1 } };  /* :134-189 order */
+    const float SLOPE = tanf(MPI / 2.0f / 3.0f);          /* :191 */
+#pragma omp parallel for schedule(static) num_threads(nthreads())
+    for (int y = 0; y < H; y++) {
+        float sy = sty(g, y);
+        float psx, psy;
+        orc_pixelsize(g, sy, &psx, &psy);
+        for (int x = 0; x < W; x++) {
+            float sx = stx(g, x);
+            float h = fetch_nearest(hgt, W, H, 1, 0, sx, sy);
+            if (h <= 0) { out[(size_t)y * W + x] = h; continue; }        /* :122-123 */
+            float maxslope = 0;
+            float dist = sqrtf(psx * psx + psy * psy);                    /* length(psize) :128 */
+            for (int k = 0; k < 8; k++) {
+                float px, py;
+                orc_offset(g, sx, sy, offs[k][0], offs[k][1], rx, ry, &px, &py);
+                float h2 = fetch_nearest(hgt, W, H, 1, 0, px, py);
+                float ax = psx * offs[k][0], ay = psy * offs[k][1];
+                float ndist = sqrtf(ax * ax + ay * ay);
+                h2 = (h - h2) / ndist;
+                if (h2 > maxslope) { maxslope = h2; dist = ndist; }
+            }
+            float hdiff = SLOPE * dist - maxslope * dist;                  /* :192 */
+            /* :195 factor*4*flow*pow(maxslope,n)/pow(0.1,n)*0.1 */
+            float fl = factor * 4.0f * fetch_nearest(flow, W, H, 1, 0, sx, sy) * powf(maxslope, slope_exponent)
+                       / powf(0.1f, slope_exponent) * 0.1f;
+            float up = fetch_nearest(updrift, W, H, 1, 0, sx, sy);
+            out[(size_t)y * W + x] = h + fminf(hdiff, fmaxf(0.0f, up - fl));   /* :198 */
+        }
+    }
+}

@@ -1,0 +1,39 @@
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "oracle"))
+GOLDEN = ROOT / "tests" / "golden"
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The CPU restatement (test infrastructure).  Built on demand with plain gcc."""
+    lib = ROOT / "oracle" / "liboracle.so"
+    src = ROOT / "oracle" / "dmg_oracle.c"
+    if not lib.exists() or lib.stat().st_mtime < src.stat().st_mtime:
+        subprocess.check_call(["make", "-C", str(ROOT / "oracle"), "liboracle.so"])
+    import oracle as orc
+    orc.set_linear_taps(False)
+    return orc
+
+
+def load_golden(name):
+    z = np.load(GOLDEN / (name + ".npz"))
+    return {k: z[k] for k in z.files}
+
+
+def relerr(a, ref):
+    """max |a-ref| / max |ref|: the norm every parity tolerance in this suite is stated in."""
+    a = np.asarray(a, np.float64)
+    ref = np.asarray(ref, np.float64)
+    return float(np.abs(a - ref).max() / max(np.abs(ref).max(), 1e-30))

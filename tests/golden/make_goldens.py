@@ -1,0 +1,104 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE'S OWN GLSL (lifted verbatim from
+/root/reference by oracle/refgl) on Mesa llvmpipe.  Runs only in the build container
+(needs /root/reference + Mesa); the fixtures it writes are plain data: inputs and the
+reference's outputs.  Re-run:  make -C oracle && python3 tests/golden/make_goldens.py
+"""
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "oracle" / "refgl"))
+import refgl  # noqa: E402
+from demiurge_amd import synth  # noqa: E402
+
+OUT = Path(__file__).resolve().parent
+f32 = np.float32
+FULL = tuple(f32(x) for x in refgl.FULL_GLOBE)
+REGION = (f32(-0.6), f32(0.9), f32(-1.0), f32(2.0))            # no wrap, no poles
+BELT = (f32(-1.0), f32(1.2), f32(-np.pi), f32(np.pi))          # longitude wrap, no poles
+CIRC = 42000.0
+
+
+def save(name, **arrs):
+    meta = dict(renderer=np.array(refgl.RefGL.get().renderer()))
+    np.savez_compressed(OUT / (name + ".npz"), **arrs, **meta)
+    print("wrote", name, {k: getattr(v, "shape", None) for k, v in arrs.items()})
+
+
+def ocean_inputs(W, H, vscale=1.0):
+    img = synth.terrain(W, H)
+    v = synth.velocity(W, H, scale=vscale)
+    v[img > 0] = 0
+    return img, v
+
+
+def main():
+    # ---- Jacobi (headline) -------------------------------------------------
+    W, H = 256, 128
+    img, b = synth.terrain(W, H), synth.divw(W, H)
+    save("jacobi_256x128_full", coords=np.array(FULL), circ=f32(CIRC), img=img, divw=b,
+         p1=refgl.ocean_jacobi(img, b, 1), p100=refgl.ocean_jacobi(img, b, 100),
+         p5000=refgl.ocean_jacobi(img, b, 5000))
+    W, H = 128, 64
+    img, b = synth.terrain(W, H), synth.divw(W, H)
+    rng = np.random.default_rng(7)
+    p0 = rng.standard_normal((H, W)).astype(f32)
+    for name, c in (("region", REGION), ("belt", BELT), ("full", FULL)):
+        save("jacobi_128x64_" + name, coords=np.array(c), circ=f32(CIRC), img=img, divw=b, p0=p0,
+             p1=refgl.ocean_jacobi(img, b, 1, coords=c, p0=p0),
+             p60=refgl.ocean_jacobi(img, b, 60, coords=c, p0=p0))
+    # non-power-of-two grid: llvmpipe's float-weight bilinear filter blends neighbours
+    W, H = 96, 64
+    img, b = synth.terrain(W, H), synth.divw(W, H)
+    save("jacobi_96x64_full", coords=np.array(FULL), circ=f32(CIRC), img=img, divw=b,
+         p300=refgl.ocean_jacobi(img, b, 300))
+
+    # ---- other ocean passes --------------------------------------------------
+    W, H = 128, 64
+    for name, c in (("full", FULL), ("region", REGION)):
+        img, v = ocean_inputs(W, H)
+        div = refgl.ocean_divergence(img, v, 100.0, coords=c)
+        p = refgl.ocean_jacobi(img, div, 200, coords=c)
+        save("ocean_passes_128x64_" + name, coords=np.array(c), circ=f32(CIRC), img=img, v=v,
+             divergence=div, divergence_pf7=refgl.ocean_divergence(img, v, 7.5, coords=c),
+             diffusion1=refgl.ocean_diffusion(img, v, 1, coords=c),
+             diffusion50=refgl.ocean_diffusion(img, v, 50, coords=c),
+             advect=refgl.ocean_advect(img, v, coords=c),
+             pressure200=p,
+             subdiv=refgl.ocean_subdiv(img, v, p, 100.0, coords=c))
+    img, v = ocean_inputs(W, H, vscale=8.0)      # departure points several texels away
+    save("ocean_advect_fast_128x64_full", coords=np.array(FULL), circ=f32(CIRC), img=img, v=v,
+         advect=refgl.ocean_advect(img, v))
+    img, v = ocean_inputs(W, H)
+    v2, p2, d2 = refgl.ocean_step(img, np.zeros_like(v), n_outer=2, jacobi_iters=150, diffusion_iters=50)
+    save("ocean_step_128x64_full", coords=np.array(FULL), circ=f32(CIRC), img=img,
+         n_outer=np.int32(2), jacobi_iters=np.int32(150), diffusion_iters=np.int32(50), v=v2, pressure=p2, divw=d2)
+
+    # ---- blur (config 1) -----------------------------------------------------
+    img = synth.terrain(W, H)
+    for r in (1.0, 10.0):
+        save("blur_128x64_r%g" % r, coords=np.array(FULL), circ=f32(CIRC), field=img, radius=f32(r),
+             rlist=np.array(refgl.blur_rlist(r), f32), out=refgl.blur(img, r))
+    save("blur_128x64_region_r3", coords=np.array(REGION), circ=f32(CIRC), field=img, radius=f32(3.0),
+         rlist=np.array(refgl.blur_rlist(3.0), f32), out=refgl.blur(img, 3.0, coords=REGION))
+
+    # ---- climate ---------------------------------------------------------------
+    T0 = np.full((H, W), 50, f32)
+    save("temperature_128x64_full", coords=np.array(FULL), circ=f32(CIRC), terrain=img, T0=T0,
+         T1=refgl.temperature(T0, img, 0, 1), T20=refgl.temperature(T0, img, 0, 20),
+         T20_from3000=refgl.temperature(T0, img, 3000, 20))
+
+    # ---- erosion / uplift pass -------------------------------------------------
+    h = (img * 20).astype(f32)
+    flow = (np.abs(synth.divw(W, H)) * 3).astype(f32)
+    up = (np.maximum(h, 0) / 50).astype(f32)
+    save("erosion_128x64_full", coords=np.array(FULL), circ=f32(CIRC), h=h, flow=flow, updrift=up,
+         out=refgl.erosion_shader(h, flow, up, 1.0, 1.0), out_f2_n07=refgl.erosion_shader(h, flow, up, 2.0, 0.7))
+
+
+if __name__ == "__main__":
+    main()
