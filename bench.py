@@ -1,0 +1,243 @@
+#!/usr/bin/env python3
+"""bench.py -- Mcell-steps/s of the ocean-current Jacobi pressure stencil (BASELINE.json metric).
+
+A "step" is one pressure solve of the reference (OceanCurrents::jacobi, src/filter/OceanCurrents.cpp:437-509):
+pressure := 0 then `--sweeps` Jacobi sweeps (reference value 5000) over the synthetic 16384x8192 full-globe
+grid of SURVEY.md section 8d, inputs resident in HBM before the timed region.
+
+    python bench.py [--gpus N --steps K --warmup W]            one process per GPU; N>1 via torch.distributed.run
+
+N>1 splits the SAME grid into N latitude bands (strong scaling), ghost rows refreshed with RCCL send/recv.
+Prints ONE JSON line on rank 0 with `roofline` (algorithmic bytes / measured launch time vs HBM peak) and, at N=1,
+`cpu_baseline` (the reference GLSL on llvmpipe when oracle/_ref + Mesa are usable on this host, else the C port).
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+ALGO_BYTES_PER_CELL_STEP = 16  # read p, read divw, read terrain, write p'
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=16384)
+    ap.add_argument("--height", type=int, default=8192)
+    ap.add_argument("--sweeps", type=int, default=5000, help="Jacobi sweeps per solve (reference: 5000)")
+    ap.add_argument("--ghost", type=int, default=8, help="ghost rows per band side = sweeps between halo exchanges")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    return ap.parse_args()
+
+
+# --------------------------------------------------------------------------------------------------
+# CPU baseline (rank 0, N=1): runs in a child process so a missing/fragile Mesa cannot take the bench down
+# --------------------------------------------------------------------------------------------------
+def cpu_baseline_child(args):
+    """Times a bounded sample of the same workload on the host cores and prints a JSON object."""
+    from demiurge_amd import synth
+    W, H = args.width, args.height
+    img, b = synth.terrain(W, H), synth.divw(W, H)
+    cores = os.cpu_count() or 1
+    res = None
+    sys.path.insert(0, str(ROOT / "oracle" / "refgl"))
+    sys.path.insert(0, str(ROOT / "oracle"))
+    try:
+        os.environ.setdefault("LP_NUM_THREADS", str(min(cores, 32)))
+        import refgl
+        if not refgl.available():
+            raise RuntimeError("oracle/_ref/librefgl.so not built")
+        t = []
+        refgl.ocean_jacobi(img, b, 2, timing=t)                       # includes shader compile + first-touch
+        per = max(t[0] / 2, 1e-3)
+        n = int(max(3, min(40, 15.0 / per)))
+        t = []
+        refgl.ocean_jacobi(img, b, n, timing=t)
+        res = dict(value=W * H * n / t[0] / 1e6, unit="Mcell-steps/s", cores=int(os.environ["LP_NUM_THREADS"]),
+                   kind="reference",
+                   sample="%d sweeps of the reference Jacobi GLSL (OceanCurrents.cpp:450-481) at %dx%d on %s, %.1f s"
+                          % (n, W, H, refgl.RefGL.get().renderer().split("|")[0].strip(), t[0]))
+    except Exception as e:  # Mesa / reference harness unavailable on this host: fall back to the C port
+        note = "llvmpipe reference unavailable (%s)" % str(e)[:80]
+        import oracle
+        g = oracle.grid(W, H)
+        t0 = time.time()
+        oracle.ocean_jacobi(g, img, b, 2, rows=True, nthreads=cores)
+        per = max((time.time() - t0) / 2, 1e-3)
+        n = int(max(3, min(200, 15.0 / per)))
+        t0 = time.time()
+        oracle.ocean_jacobi(g, img, b, n, rows=True, nthreads=cores)
+        dt = time.time() - t0
+        res = dict(value=W * H * n / dt / 1e6, unit="Mcell-steps/s", cores=cores, kind="port",
+                   sample="%d sweeps of oracle/dmg_oracle.c orc_ocean_jacobi_rows (OpenMP) at %dx%d, %.1f s; %s"
+                          % (n, W, H, dt, note))
+    print("CPU_BASELINE_JSON " + json.dumps(res))
+
+
+def cpu_baseline(args):
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--cpu-baseline-only", "--width", str(args.width),
+           "--height", str(args.height)]
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        for line in out.stdout.splitlines():
+            if line.startswith("CPU_BASELINE_JSON "):
+                return json.loads(line[len("CPU_BASELINE_JSON "):])
+        return dict(value=None, unit="Mcell-steps/s", cores=0, kind="port",
+                    sample="cpu baseline failed: " + (out.stderr or out.stdout)[-200:])
+    except Exception as e:
+        return dict(value=None, unit="Mcell-steps/s", cores=0, kind="port", sample="cpu baseline failed: %s" % e)
+
+
+# --------------------------------------------------------------------------------------------------
+# device tensors aliasing library-owned halo slabs (for RCCL send/recv through torch.distributed)
+# --------------------------------------------------------------------------------------------------
+class _DevSlab:
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = dict(shape=(nbytes // 4,), typestr="<f4", data=(int(ptr), False), version=2)
+
+
+_alias_cache = {}
+
+
+def alias(torch, ptr, nbytes, device):
+    key = (ptr, nbytes)
+    if key not in _alias_cache:
+        _alias_cache[key] = torch.as_tensor(_DevSlab(ptr, nbytes), device=device)
+    return _alias_cache[key]
+
+
+def exchange_halos(torch, dist, capi, oc, rank, world, rows, device):
+    """Refresh the pressure ghost rows: band r's top rows <-> band r+1's bottom rows (one RCCL group)."""
+    ops = []
+    for side, peer in ((capi.SIDE_SOUTH, rank - 1), (capi.SIDE_NORTH, rank + 1)):
+        if peer < 0 or peer >= world:
+            continue
+        send, recv, nb = oc.halo(capi.F_PRESSURE, side, rows)
+        ops.append(dist.P2POp(dist.isend, alias(torch, send, nb, device), peer))
+        ops.append(dist.P2POp(dist.irecv, alias(torch, recv, nb, device), peer))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+
+
+def main():
+    args = parse()
+    if args.cpu_baseline_only:
+        cpu_baseline_child(args)
+        return
+    import torch
+    from demiurge_amd import capi, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
+                             % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("no GPU visible: the HIP backend has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    W, H, sweeps = args.width, args.height, args.sweeps
+    ghost = max(1, min(args.ghost, H // world))
+    stream = torch.cuda.current_stream(device)
+    ctx = capi.Context(local_rank, stream=stream.cuda_stream)
+    grid = capi.make_grid(W, H)
+    oc = capi.Ocean(ctx, grid, band_rank=rank, band_count=world, ghost=ghost)
+    img = synth.terrain(W, H)
+    oc.set_terrain(img)
+    del img
+    b = synth.divw(W, H)
+    oc.set_divw(b)
+    del b
+
+    launches = [0]
+
+    def solve():
+        oc.zero_pressure()                       # OceanCurrents.cpp:495-497
+        if world == 1:
+            oc.jacobi_sweeps(sweeps)
+            launches[0] += sweeps
+        else:
+            done = 0
+            while done < sweeps:
+                n = min(ghost, sweeps - done)
+                exchange_halos(torch, dist, capi, oc, rank, world, ghost, device)
+                oc.jacobi_sweeps(n)
+                launches[0] += n
+                done += n
+
+    def fence():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        solve()
+    fence()
+    launches[0] = 0
+    t0 = time.perf_counter()
+    ctx.timer_start()
+    for _ in range(args.steps):
+        solve()
+    ev_ms = ctx.timer_stop()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt, ev_ms], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt, ev_ms = float(tt[0]), float(tt[1])
+
+    if rank == 0:
+        cell_steps = float(W) * H * sweeps * args.steps
+        value = cell_steps / dt / 1e6
+        # dominant kernel = one Jacobi sweep launch over this rank's band; average launch time from HIP events
+        band_cells = float(W) * (H / world)
+        launch_s = (ev_ms / 1e3) / max(launches[0], 1)
+        achieved = ALGO_BYTES_PER_CELL_STEP * band_cells / launch_s / 1e9
+        out = {
+            "metric": "Mcell-steps/s, ocean Jacobi stencil @%dx%d fp32" % (W, H),
+            "value": value, "unit": "Mcell-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "ocean-current Jacobi pressure solve, %dx%d full globe, %d sweeps per step "
+                                   "(pressure zeroed first)" % (W, H, sweeps),
+                       "parallelism": "1 GPU" if world == 1 else "%d latitude bands, %d ghost rows, RCCL halo every %d sweeps"
+                                      % (world, ghost, ghost),
+                       "device": ctx.name()},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_jacobi_sweep", "launch_us": launch_s * 1e6,
+                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_CELL_STEP * band_cells},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out))
+    oc.close()
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,270 @@
+"""ctypes binding of libdemiurge_hip.so (the C ABI in include/demiurge_hip.h).
+
+This module is plumbing for the tests and bench.py; the product is the shared library.  It fails
+loudly when the library is missing or no MI355X is visible -- there is no CPU fallback.
+"""
+import ctypes
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "libdemiurge_hip.so"
+ROOT = _HERE.parent
+
+OK, EINVAL, ENOMEM, EHIP, ENODEVICE, ESTATE = 0, -1, -2, -3, -4, -5
+F_PRESSURE, F_DIVW, F_TERRAIN, F_VX, F_VY = range(5)
+SIDE_SOUTH, SIDE_NORTH = 0, 1
+QUIRK_DIFFUSION_SCALAR_RHS = 1
+FULL_GLOBE = (np.float32(-np.pi / 2), np.float32(np.pi / 2), np.float32(-np.pi), np.float32(np.pi))  # Project.h:97
+
+
+class DmgError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("dmg error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Grid(ctypes.Structure):
+    _fields_ = [("W", ctypes.c_int), ("H", ctypes.c_int), ("coords", ctypes.c_float * 4),
+                ("circumference", ctypes.c_float)]
+
+
+class OceanParams(ctypes.Structure):
+    _fields_ = [("pressurefactor", ctypes.c_float), ("jacobi_iters", ctypes.c_int),
+                ("diffusion_iters", ctypes.c_int), ("timestep_h", ctypes.c_float), ("scale", ctypes.c_float),
+                ("wind", ctypes.c_float), ("quirks", ctypes.c_int)]
+
+
+def make_grid(W, H, coords=FULL_GLOBE, circumference=42000.0):
+    g = Grid()
+    g.W, g.H = int(W), int(H)
+    for i in range(4):
+        g.coords[i] = float(np.float32(coords[i]))
+    g.circumference = float(circumference)
+    return g
+
+
+_lib = None
+
+
+def lib():
+    """Loads the library (raises if it was not built: run __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise FileNotFoundError("%s missing -- build it with `make -C demiurge_amd/csrc` "
+                                "(or __graft_entry__.build()); there is no fallback path" % LIB_PATH)
+    L = ctypes.CDLL(str(LIB_PATH))
+    c_int, c_float, vp, sz = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
+    PG, PP = ctypes.POINTER(Grid), ctypes.POINTER(OceanParams)
+    sig = {
+        "dmg_version": (c_int, []),
+        "dmg_last_error": (ctypes.c_char_p, []),
+        "dmg_create": (c_int, [c_int, vp, ctypes.POINTER(vp)]),
+        "dmg_destroy": (None, [vp]),
+        "dmg_sync": (c_int, [vp]),
+        "dmg_device_name": (c_int, [vp, ctypes.c_char_p, sz]),
+        "dmg_copy_device": (c_int, [vp, vp, vp, sz]),
+        "dmg_timer_start": (c_int, [vp]),
+        "dmg_timer_stop": (c_int, [vp, ctypes.POINTER(c_float)]),
+        "dmg_band_row0": (c_int, [c_int, c_int, c_int]),
+        "dmg_ocean_params_default": (None, [PP]),
+        "dmg_ocean_create": (c_int, [vp, PG, PP, c_int, c_int, c_int, ctypes.POINTER(vp)]),
+        "dmg_ocean_destroy": (None, [vp]),
+        "dmg_ocean_set_terrain": (c_int, [vp, vp]),
+        "dmg_ocean_set_velocity": (c_int, [vp, vp, vp]),
+        "dmg_ocean_set_divw": (c_int, [vp, vp]),
+        "dmg_ocean_set_pressure": (c_int, [vp, vp]),
+        "dmg_ocean_jacobi": (c_int, [vp, c_int, c_int]),
+        "dmg_ocean_jacobi_sweeps": (c_int, [vp, c_int]),
+        "dmg_ocean_zero_pressure": (c_int, [vp]),
+        "dmg_ocean_halo": (c_int, [vp, c_int, c_int, c_int, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(sz)]),
+        "dmg_ocean_step": (c_int, [vp, c_int]),
+        "dmg_ocean_advect": (c_int, [vp]),
+        "dmg_ocean_diffusion": (c_int, [vp, c_int]),
+        "dmg_ocean_divergence": (c_int, [vp]),
+        "dmg_ocean_subdiv": (c_int, [vp]),
+        "dmg_ocean_get": (c_int, [vp, vp, vp, vp, vp]),
+        "dmg_blur": (c_int, [vp, PG, vp, c_float]),
+        "dmg_temperature_steps": (c_int, [vp, PG, vp, vp, c_int, c_int]),
+        "dmg_erosion_pass": (c_int, [vp, PG, vp, vp, vp, c_float, c_float]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)          # AttributeError if the library does not export a declared symbol
+        fn.restype, fn.argtypes = res, args
+    L._dmg_signatures = sig
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise DmgError(rc, lib().dmg_last_error().decode(errors="replace"))
+
+
+def _f32(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data
+
+
+class Context:
+    """dmg_ctx: one per GPU/process."""
+
+    def __init__(self, device=0, stream=None):
+        h = ctypes.c_void_p()
+        check(lib().dmg_create(int(device), stream, ctypes.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            lib().dmg_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        check(lib().dmg_sync(self.h))
+
+    def name(self):
+        b = ctypes.create_string_buffer(160)
+        check(lib().dmg_device_name(self.h, b, 160))
+        return b.value.decode()
+
+    def copy_device(self, dst, src, nbytes):
+        check(lib().dmg_copy_device(self.h, dst, src, nbytes))
+
+    def timer_start(self):
+        check(lib().dmg_timer_start(self.h))
+
+    def timer_stop(self):
+        ms = ctypes.c_float()
+        check(lib().dmg_timer_stop(self.h, ctypes.byref(ms)))
+        return ms.value
+
+    # generic filters ------------------------------------------------------
+    def blur(self, grid, field, radius):
+        f = _f32(field).copy()
+        check(lib().dmg_blur(self.h, ctypes.byref(grid), _p(f), radius))
+        return f
+
+    def temperature_steps(self, grid, T, terrain, first_step, n_steps):
+        T = _f32(T).copy()
+        terrain = _f32(terrain)
+        check(lib().dmg_temperature_steps(self.h, ctypes.byref(grid), _p(T), _p(terrain), first_step, n_steps))
+        return T
+
+    def erosion_pass(self, grid, h, flow, updrift, factor=1.0, slope_exponent=1.0):
+        h = _f32(h).copy()
+        flow, updrift = _f32(flow), _f32(updrift)
+        check(lib().dmg_erosion_pass(self.h, ctypes.byref(grid), _p(h), _p(flow), _p(updrift), factor, slope_exponent))
+        return h
+
+
+def default_ocean_params():
+    p = OceanParams()
+    lib().dmg_ocean_params_default(ctypes.byref(p))
+    return p
+
+
+class Ocean:
+    """dmg_ocean: the OceanCurrents filter state of one latitude band."""
+
+    def __init__(self, ctx, grid, params=None, band_rank=0, band_count=1, ghost=1):
+        self.ctx, self.grid = ctx, grid
+        self.params = params if params is not None else default_ocean_params()
+        self.rank, self.count, self.ghost = band_rank, band_count, ghost
+        h = ctypes.c_void_p()
+        check(lib().dmg_ocean_create(ctx.h, ctypes.byref(grid), ctypes.byref(self.params), band_rank, band_count,
+                                     ghost, ctypes.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            lib().dmg_ocean_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_terrain(self, img):
+        img = _f32(img)
+        assert img.shape == (self.grid.H, self.grid.W)
+        check(lib().dmg_ocean_set_terrain(self.h, _p(img)))
+
+    def set_divw(self, divw):
+        divw = _f32(divw)
+        assert divw.shape == (self.grid.H, self.grid.W)
+        check(lib().dmg_ocean_set_divw(self.h, _p(divw)))
+
+    def set_pressure(self, p):
+        p = _f32(p)
+        assert p.shape == (self.grid.H, self.grid.W)
+        check(lib().dmg_ocean_set_pressure(self.h, _p(p)))
+
+    def set_velocity(self, v):
+        """v: (H, W, 2) interleaved like the reference's RG32F texture, or a (vx, vy) pair of planes."""
+        if isinstance(v, (tuple, list)):
+            vx, vy = _f32(v[0]), _f32(v[1])
+        else:
+            v = np.asarray(v, np.float32)
+            vx, vy = _f32(v[..., 0]), _f32(v[..., 1])
+        check(lib().dmg_ocean_set_velocity(self.h, _p(vx), _p(vy)))
+
+    def zero_pressure(self):
+        check(lib().dmg_ocean_zero_pressure(self.h))
+
+    def jacobi(self, iters, zero_first=True):
+        check(lib().dmg_ocean_jacobi(self.h, int(iters), 1 if zero_first else 0))
+
+    def jacobi_sweeps(self, n):
+        check(lib().dmg_ocean_jacobi_sweeps(self.h, int(n)))
+
+    def halo(self, field, side, rows):
+        """-> (send_ptr, recv_ptr, nbytes) device addresses (ints); nbytes == 0 at a grid edge."""
+        s, r, n = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_size_t()
+        check(lib().dmg_ocean_halo(self.h, field, side, rows, ctypes.byref(s), ctypes.byref(r), ctypes.byref(n)))
+        return s.value, r.value, n.value
+
+    def step(self, n_outer=1):
+        check(lib().dmg_ocean_step(self.h, int(n_outer)))
+
+    def advect(self):
+        check(lib().dmg_ocean_advect(self.h))
+
+    def diffusion(self, iters=None):
+        check(lib().dmg_ocean_diffusion(self.h, int(self.params.diffusion_iters if iters is None else iters)))
+
+    def divergence(self):
+        check(lib().dmg_ocean_divergence(self.h))
+
+    def subdiv(self):
+        check(lib().dmg_ocean_subdiv(self.h))
+
+    def get(self, want=("v", "pressure", "divw"), out=None):
+        """Downloads owned rows into full-grid arrays (zeros elsewhere).  Returns dict of arrays."""
+        H, W = self.grid.H, self.grid.W
+        res = {} if out is None else out
+        arr = {}
+        for k in ("vx", "vy", "pressure", "divw"):
+            need = (k in want) or (k in ("vx", "vy") and "v" in want)
+            arr[k] = res.get(k, np.zeros((H, W), np.float32)) if need else None
+        check(lib().dmg_ocean_get(self.h, _p(arr["vx"]), _p(arr["vy"]), _p(arr["pressure"]), _p(arr["divw"])))
+        for k, a in arr.items():
+            if a is not None:
+                res[k] = a
+        if "v" in want:
+            res["v"] = np.stack([arr["vx"], arr["vy"]], axis=-1)
+        return res

@@ -1,0 +1,123 @@
+// Context, error reporting, timers, band arithmetic.
+#include "dmg_internal.h"
+
+static thread_local std::string g_last_error;
+
+int dmg_fail(int code, const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+int dmg_check_grid(const dmg_grid *g, dmg_topology *t)
+{
+    DMG_CHECK_ARG(g != nullptr);
+    DMG_CHECK_ARG(g->W >= 4 && g->H >= 2);
+    DMG_CHECK_ARG(g->coords[1] > g->coords[0] && g->coords[3] > g->coords[2]);
+    DMG_CHECK_ARG(g->circumference > 0.0f);
+    *t = dmg_topology_of(*g);
+    if ((t->spole || t->npole) && (!t->lonwrap || (g->W & 1)))
+        return dmg_fail(DMG_EINVAL,
+                        "a pole edge needs the full longitude range and an even width: offset()'s pole branch "
+                        "(reference src/Shader.h:86-95) lands between texels otherwise");
+    return DMG_OK;
+}
+
+extern "C" {
+
+int dmg_version(void) { return DMG_VERSION; }
+const char *dmg_last_error(void) { return g_last_error.c_str(); }
+
+int dmg_create(int device_id, void *stream, dmg_ctx **out)
+{
+    DMG_CHECK_ARG(out != nullptr);
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return dmg_fail(DMG_ENODEVICE, "no HIP device visible; this backend has no CPU path");
+    DMG_CHECK_ARG(device_id >= 0 && device_id < n);
+    DMG_HIP(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    DMG_HIP(hipGetDeviceProperties(&prop, device_id));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return dmg_fail(DMG_ENODEVICE, "device %d is %s; the kernels are built for gfx950 (MI355X) only",
+                        device_id, prop.gcnArchName);
+    dmg_ctx *c = new (std::nothrow) dmg_ctx();
+    if (!c) return dmg_fail(DMG_ENOMEM, "out of host memory");
+    c->device = device_id;
+    c->num_cu = prop.multiProcessorCount;
+    snprintf(c->name, sizeof c->name, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    if (stream) {
+        c->stream = (hipStream_t)stream;
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete c; return dmg_fail(DMG_EHIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+        c->own_stream = true;
+    }
+    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+        dmg_destroy(c);
+        return dmg_fail(DMG_EHIP, "hipEventCreate failed");
+    }
+    *out = c;
+    return DMG_OK;
+}
+
+void dmg_destroy(dmg_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int dmg_sync(dmg_ctx *c)
+{
+    DMG_CHECK_ARG(c != nullptr);
+    DMG_HIP(hipStreamSynchronize(c->stream));
+    return DMG_OK;
+}
+
+int dmg_device_name(dmg_ctx *c, char *buf, size_t len)
+{
+    DMG_CHECK_ARG(c != nullptr && buf != nullptr && len > 0);
+    snprintf(buf, len, "%s", c->name);
+    return DMG_OK;
+}
+
+int dmg_copy_device(dmg_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    DMG_CHECK_ARG(c != nullptr && (bytes == 0 || (dst != nullptr && src != nullptr)));
+    if (bytes) DMG_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream));
+    return DMG_OK;
+}
+
+int dmg_timer_start(dmg_ctx *c)
+{
+    DMG_CHECK_ARG(c != nullptr);
+    DMG_HIP(hipEventRecord(c->ev0, c->stream));
+    return DMG_OK;
+}
+
+int dmg_timer_stop(dmg_ctx *c, float *ms)
+{
+    DMG_CHECK_ARG(c != nullptr && ms != nullptr);
+    DMG_HIP(hipEventRecord(c->ev1, c->stream));
+    DMG_HIP(hipEventSynchronize(c->ev1));
+    DMG_HIP(hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return DMG_OK;
+}
+
+int dmg_band_row0(int H, int band_count, int band_rank)
+{
+    if (H <= 0 || band_count <= 0 || band_rank < 0 || band_rank > band_count) return DMG_EINVAL;
+    return (int)(((long long)H * band_rank) / band_count);
+}
+
+}  // extern "C"

@@ -1,0 +1,73 @@
+// Internal declarations shared by the HIP translation units of libdemiurge_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/demiurge_hip.h"
+
+struct dmg_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int num_cu = 0;
+    char name[128] = {0};
+};
+
+// thread-local error string behind dmg_last_error()
+int dmg_fail(int code, const char *fmt, ...);
+
+#define DMG_HIP(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess)                                                               \
+            return dmg_fail(DMG_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                            __FILE__, __LINE__);                                            \
+    } while (0)
+
+#define DMG_CHECK_ARG(cond)                                                                  \
+    do {                                                                                     \
+        if (!(cond)) return dmg_fail(DMG_EINVAL, "invalid argument: %s (%s:%d)", #cond, __FILE__, __LINE__); \
+    } while (0)
+
+// ---- canvas geometry, the GLSL `cornerCoords` library (reference src/Shader.h:43-99) in fp32 ----
+// GLSL's `#define M_PI 3.1415926535897932384626433832795` is a float literal.
+static constexpr float DMG_PI = 3.1415926535897932384626433832795f;
+
+struct dmg_topology {
+    bool lonwrap;   // Shader.h:85  cornerCoords[2] < -M_PI+1e-4 && cornerCoords[3] > M_PI-1e-3
+    bool spole;     // Shader.h:86  cornerCoords[0] < -M_PI/2+1e-4
+    bool npole;     // Shader.h:91  cornerCoords[1] >  M_PI/2-1e-4
+};
+
+inline dmg_topology dmg_topology_of(const dmg_grid &g)
+{
+    dmg_topology t;
+    t.lonwrap = (g.coords[2] < -DMG_PI + 1e-4f) && (g.coords[3] > DMG_PI - 1e-3f);
+    t.spole = g.coords[0] < -DMG_PI / 2.0f + 1e-4f;
+    t.npole = g.coords[1] > DMG_PI / 2.0f - 1e-4f;
+    return t;
+}
+
+// tex_to_spheric(st).y for the texel row y (Shader.h:49-53), st.y = (y+0.5)/H
+inline float dmg_row_lat(const dmg_grid &g, int y)
+{
+    float sy = ((float)y + 0.5f) / (float)g.H;
+    return sy * (g.coords[1] - g.coords[0]) + g.coords[0];
+}
+
+// pixelsize(st) (Shader.h:71-74): vec2(dlon*cos(lat), dlat)*circumference/(2*M_PI)/textureSize
+inline void dmg_row_pixelsize(const dmg_grid &g, int y, float *dx, float *dy)
+{
+    float lat = dmg_row_lat(g, y);
+    float two_pi = 2.0f * DMG_PI;
+    *dx = ((g.coords[3] - g.coords[2]) * cosf(lat)) * g.circumference / two_pi / (float)g.W;
+    *dy = (g.coords[1] - g.coords[0]) * g.circumference / two_pi / (float)g.H;
+}
+
+// Validates the geometry this backend supports; fills topology.
+int dmg_check_grid(const dmg_grid *g, dmg_topology *t);

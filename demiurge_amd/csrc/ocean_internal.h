@@ -1,0 +1,43 @@
+// dmg_ocean: device state of one OceanCurrents instance (one latitude band).
+#pragma once
+#include "dmg_internal.h"
+
+// per-local-row tables, evaluated on the host in fp32 with the GLSL's own operation order
+enum {
+    RT_JCX = 0,     // jacobi pixelwidth2.x = (pixelsize.x/420)^2            OceanCurrents.cpp:478
+    RT_JCY,         // jacobi pixelwidth2.y
+    RT_JBETA,       // 2*(1/pw2.x + 1/pw2.y)                                  :479
+    RT_DX,          // pixelsize(st).x  (km)                                  Shader.h:71-74
+    RT_DY,          // pixelsize(st).y
+    RT_DIFPX,       // diffusion 1*1/pixelsize.x^2*420*420                    :689
+    RT_DIFPY,
+    RT_DIFBETA,     // 2*(px+py)*(1+1/(2*(px+py)))                            :690
+    RT_LAT,         // tex_to_spheric(st).y
+    ROWTAB_FIELDS
+};
+
+struct dmg_ocean {
+    dmg_ctx *ctx = nullptr;
+    dmg_grid grid{};
+    dmg_topology topo{};
+    dmg_ocean_params prm{};
+    int rank = 0, count = 1, ghost = 1;
+    int y0 = 0, y1 = 0;            // owned grid rows [y0, y1)
+    int gs = 0, gn = 0;            // ghost rows towards south / north neighbour band
+    int L = 0;                     // local rows = gs + (y1-y0) + gn
+    float *p[2] = { nullptr, nullptr };
+    int cur = 0;                   // p[cur] holds the current pressure
+    float *divw = nullptr, *img = nullptr;
+    unsigned char *code = nullptr;
+    float *v[2] = { nullptr, nullptr };   // interleaved (vx,vy)
+    int vcur = 0;
+    float *rowtab = nullptr;       // ROWTAB_FIELDS arrays of L floats
+    const float *jac_cx = nullptr, *jac_cy = nullptr, *jac_beta = nullptr;
+    bool have_terrain = false;
+    const float *rt(int field) const { return rowtab + (size_t)field * L; }
+};
+
+int ocean_upload_row_tables(dmg_ocean *o);
+int ocean_build_codes(dmg_ocean *o);
+int ocean_upload_rows(dmg_ocean *o, float *dst, const float *src_full, int comps);
+int ocean_download_rows(dmg_ocean *o, float *dst_full, const float *src, int comps);

@@ -1,0 +1,36 @@
+// Per-row coefficient tables.  The GLSL evaluates these per fragment (pixelsize() has a cos(), the Jacobi
+// shader two pow()s, OceanCurrents.cpp:478-479); they depend on the row only, so they are computed once on
+// the host, in fp32, statement by statement as the shader does, and the kernels read 3 floats per row.
+#include "ocean_internal.h"
+
+int ocean_upload_row_tables(dmg_ocean *o)
+{
+    const int L = o->L;
+    std::vector<float> t((size_t)ROWTAB_FIELDS * L);
+    const float scale = o->prm.scale;
+    for (int l = 0; l < L; l++) {
+        int y = o->y0 - o->gs + l;
+        float dx, dy;
+        dmg_row_pixelsize(o->grid, y, &dx, &dy);
+        float wx = dx / scale, wy = dy / scale;                 // pixelsize(st)/420
+        float cx = wx * wx, cy = wy * wy;                       // pow(.,vec2(2,2))
+        t[(size_t)RT_JCX * L + l] = cx;
+        t[(size_t)RT_JCY * L + l] = cy;
+        t[(size_t)RT_JBETA * L + l] = 2.0f * (1.0f / cx + 1.0f / cy);
+        t[(size_t)RT_DX * L + l] = dx;
+        t[(size_t)RT_DY * L + l] = dy;
+        float px = 1.0f / (dx * dx) * scale * scale;            // 1*1/pow(pixelsize,2)*420*420
+        float py = 1.0f / (dy * dy) * scale * scale;
+        float s = 2.0f * (px + py);
+        t[(size_t)RT_DIFPX * L + l] = px;
+        t[(size_t)RT_DIFPY * L + l] = py;
+        t[(size_t)RT_DIFBETA * L + l] = s * (1.0f + 1.0f / s);
+        t[(size_t)RT_LAT * L + l] = dmg_row_lat(o->grid, y);
+    }
+    DMG_HIP(hipMemcpyAsync(o->rowtab, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice, o->ctx->stream));
+    DMG_HIP(hipStreamSynchronize(o->ctx->stream));
+    o->jac_cx = o->rt(RT_JCX);
+    o->jac_cy = o->rt(RT_JCY);
+    o->jac_beta = o->rt(RT_JBETA);
+    return DMG_OK;
+}

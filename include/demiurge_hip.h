@@ -1,0 +1,163 @@
+/* demiurge_hip.h -- C ABI of the MI355X-native compute backend for Demiurge's
+ * spherical-grid simulation filters.
+ *
+ * This is the drop-in boundary.  The reference has no
+ * FFI; its simulation tools are C++ classes behind Filter/SubFilter
+ * (src/filter/Filter.h:58-130) that reach the GPU through
+ *     Project::apply(ShaderProgram*, Texture* target, ...)   src/Project.cpp:284-292
+ *     Texture::uploadData / downloadDataRAW / swap           src/Texture.cpp:38-93
+ *     Project::getCoords / circumference / getWidth/Height   src/Project.cpp:419-421, src/Project.h:88
+ * Each entry point below names the reference interface it replaces.  A
+ * maintainer-side adapter (HipOceanCurrents : AsyncSubFilter) is shown in
+ * INTEGRATION.md and implemented against a GL-free Project in demiurge_amd/host/.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes, no exceptions cross the boundary.
+ *  - every function returns 0 (DMG_OK) or a negative DMG_E* code;
+ *    dmg_last_error() returns the message of the calling thread's last failure.
+ *  - the caller owns all host buffers; the library owns device memory.
+ *  - a handle may be used by one thread at a time (the reference runs each
+ *    filter on one worker thread, src/filter/Filter.cpp:125-143).
+ *  - field layout = Texture::downloadDataRAW (src/Texture.cpp:56-67): W*H fp32,
+ *    row-major, x (longitude) fastest, row 0 = latitude coords[0].  Velocity is
+ *    handed over as two planes vx, vy (the reference exports it that way:
+ *    scratch1 := v.x, scratch2 := v.y, src/filter/OceanCurrents.cpp:175-205).
+ *  - work is enqueued on the context's HIP stream; calls that return data to the
+ *    host synchronise that stream, the others do not (dmg_sync does).
+ *
+ * Latitude bands (multi-GPU): one process per GPU.  A dmg_ocean created with
+ * band (rank r of n) owns grid rows [dmg_band_row0(H,n,r), dmg_band_row0(H,n,r+1))
+ * plus `ghost` rows towards each neighbouring band.  The host refreshes ghost
+ * rows between sweep blocks with dmg_ocean_halo() slabs (RCCL send/recv over
+ * xGMI, or any transport); the library never communicates by itself.
+ */
+#ifndef DEMIURGE_HIP_H
+#define DEMIURGE_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DMG_VERSION 100            /* 0.1.0 */
+
+enum {
+    DMG_OK = 0,
+    DMG_EINVAL = -1,               /* bad argument (null, size, unsupported geometry) */
+    DMG_ENOMEM = -2,               /* host or device allocation failed */
+    DMG_EHIP = -3,                 /* a HIP runtime call or kernel launch failed */
+    DMG_ENODEVICE = -4,            /* no usable gfx950 device: the backend never falls back to the CPU */
+    DMG_ESTATE = -5                /* call order (e.g. step before set_terrain) */
+};
+
+typedef struct dmg_ctx dmg_ctx;        /* one per GPU / process */
+typedef struct dmg_ocean dmg_ocean;    /* OceanCurrents instance (src/filter/OceanCurrents.h:24-54) */
+
+/* Canvas geometry = Project::getWidth/getHeight/getCoords/circumference. */
+typedef struct {
+    int W, H;                      /* texels: longitude x latitude */
+    float coords[4];               /* lat0, lat1, lon0, lon1 in radians; default {-pi/2, pi/2, -pi, pi} (src/Project.h:97) */
+    float circumference;           /* km; default 42000 (src/Project.h:88) */
+} dmg_grid;
+
+/* Every literal the reference hard-codes in OceanCurrents.cpp, as a field. */
+typedef struct {
+    float pressurefactor;          /* 100   OceanCurrentsMenu::pressure (OceanCurrents.h:21), uniform :430,:618 */
+    int jacobi_iters;              /* 5000  :50 */
+    int diffusion_iters;           /* 50    :701 */
+    float timestep_h;              /* 24    :294 */
+    float scale;                   /* 420   :419,:478,:574,:689 */
+    float wind;                    /* 10    :342 */
+    int quirks;                    /* DMG_QUIRK_* bit set; default = reference behaviour */
+} dmg_ocean_params;
+
+/* the reference's `float bC = texture(v,st).r` adds v.x to BOTH components in velocity diffusion (:687,:693) */
+#define DMG_QUIRK_DIFFUSION_SCALAR_RHS 1
+
+/* field ids for dmg_ocean_halo / dmg_ocean_device_ptr */
+enum { DMG_F_PRESSURE = 0, DMG_F_DIVW = 1, DMG_F_TERRAIN = 2, DMG_F_VX = 3, DMG_F_VY = 4 };
+enum { DMG_SIDE_SOUTH = 0, DMG_SIDE_NORTH = 1 };   /* south = towards row 0 */
+
+/* ---- library / context ------------------------------------------------- */
+int dmg_version(void);
+const char *dmg_last_error(void);
+
+/* Binds HIP device `device_id`.  `stream` may be an existing hipStream_t (e.g. the host
+ * framework's current stream) or NULL to create a private non-blocking stream. */
+int dmg_create(int device_id, void *stream, dmg_ctx **out);
+void dmg_destroy(dmg_ctx *ctx);
+int dmg_sync(dmg_ctx *ctx);                                   /* hipStreamSynchronize */
+int dmg_device_name(dmg_ctx *ctx, char *buf, size_t len);
+
+/* hipEvent timing on the context's stream (the stream the kernels run on). */
+/* hipMemcpyAsync(device -> device) on the context's stream: the single-process halo transport used when
+ * several bands live on one GPU (tests, SURVEY.md section 4 "fake cluster"); multi-GPU runs use RCCL. */
+int dmg_copy_device(dmg_ctx *ctx, void *dst, const void *src, size_t bytes);
+
+int dmg_timer_start(dmg_ctx *ctx);
+int dmg_timer_stop(dmg_ctx *ctx, float *elapsed_ms);          /* records, synchronises, returns ms since start */
+
+/* ---- latitude bands ------------------------------------------------------ */
+int dmg_band_row0(int H, int band_count, int band_rank);      /* first row of a band; band_rank==band_count gives H */
+
+/* ---- ocean currents  (replaces OceanCurrents, src/filter/OceanCurrents.cpp) ---- */
+void dmg_ocean_params_default(dmg_ocean_params *p);
+
+/* OceanCurrents::OceanCurrents (:23-103): allocates v, pressure, scratch, divw for this band; v := 0 (:92,:102).
+ * ghost = rows of halo kept towards each neighbouring band (>= 1; also the largest sweep block
+ * dmg_ocean_jacobi_sweeps accepts between halo refreshes).  band_count == 1: whole grid on this GPU. */
+int dmg_ocean_create(dmg_ctx *ctx, const dmg_grid *grid, const dmg_ocean_params *params,
+                     int band_rank, int band_count, int ghost, dmg_ocean **out);
+void dmg_ocean_destroy(dmg_ocean *o);
+
+/* Texture::downloadDataRAW of the terrain layer -> device (only the sign matters: img > 0 is land,
+ * :284,:467,:536).  `img` is the FULL W*H field; the band (plus ghosts) is sliced out here. */
+int dmg_ocean_set_terrain(dmg_ocean *o, const float *img);
+/* optional: start from a given velocity instead of 0; full-grid planes */
+int dmg_ocean_set_velocity(dmg_ocean *o, const float *vx, const float *vy);
+/* right-hand side of the pressure solve (what OceanCurrents::divergence(p, divw) leaves in `divw`); full grid */
+int dmg_ocean_set_divw(dmg_ocean *o, const float *divw);
+/* starting pressure (the reference always starts from 0, :495-497); full grid */
+int dmg_ocean_set_pressure(dmg_ocean *o, const float *pressure);
+
+/* OceanCurrents::jacobi (:437-509) on one GPU (band_count == 1): pressure := 0 (:495-497) when
+ * zero_first != 0, then `iters` sweeps of the Jacobi shader (:450-481) with the ping-pong of :500-508.
+ * Asynchronous on the context's stream. */
+int dmg_ocean_jacobi(dmg_ocean *o, int iters, int zero_first);
+/* Band form: `n` (<= ghost) sweeps assuming the pressure ghost rows are current; afterwards the owned
+ * rows are n sweeps ahead and the ghost rows are stale until the host refreshes them via dmg_ocean_halo. */
+int dmg_ocean_jacobi_sweeps(dmg_ocean *o, int n);
+int dmg_ocean_zero_pressure(dmg_ocean *o);
+
+/* One exchange slab of a field: `send` = this band's `rows` rows next to `side`, `recv` = the ghost rows
+ * beyond that side; both contiguous device memory of `bytes` bytes.  bytes == 0 when the side is a grid edge. */
+int dmg_ocean_halo(dmg_ocean *o, int field, int side, int rows, void **send, void **recv, size_t *bytes);
+
+/* OceanCurrents::run body (:155-209) n_outer times: advect -> diffusion -> divergence -> jacobi -> subDiv
+ * (the WIP `resize(600,200)` :207 and `while(true)` :212 are not replicated).  band_count == 1 only. */
+int dmg_ocean_step(dmg_ocean *o, int n_outer);
+/* the individual passes (band_count == 1), each leaving its result in the field the reference leaves it in */
+int dmg_ocean_advect(dmg_ocean *o);                            /* :235-360  v <- advect(v) */
+int dmg_ocean_diffusion(dmg_ocean *o, int iters);              /* :625-708  v <- diffuse(v) */
+int dmg_ocean_divergence(dmg_ocean *o);                        /* :363-435  divw <- div(v) */
+int dmg_ocean_subdiv(dmg_ocean *o);                            /* :511-622  v <- v - grad p, coastline snapping */
+
+/* Results back to the host (Texture::uploadData side of the adapter): owned rows only are written,
+ * into FULL-grid arrays at their grid position (so ranks can fill one array); NULL skips a field. */
+int dmg_ocean_get(dmg_ocean *o, float *vx, float *vy, float *pressure, float *divw);
+
+/* ---- generic stencil filters on a whole grid ---------------------------- */
+/* Blur::Blur + Blur::step until finished (src/filter/BlurMenu.cpp:24-117), in place on host data */
+int dmg_blur(dmg_ctx *ctx, const dmg_grid *grid, float *field_inout, float radius);
+/* Temperature::run inner pass (src/filter/Temperature.cpp:140-150) n_steps times from step index first_step */
+int dmg_temperature_steps(dmg_ctx *ctx, const dmg_grid *grid, float *T_inout, const float *terrain,
+                          int first_step, int n_steps);
+/* erosion/uplift pass of cpufilter::run (src/filter/cpufilter.cpp:106-214) */
+int dmg_erosion_pass(dmg_ctx *ctx, const dmg_grid *grid, float *h_inout, const float *flow, const float *updrift,
+                     float factor, float slope_exponent);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEMIURGE_HIP_H */

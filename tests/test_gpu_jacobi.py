@@ -1,0 +1,144 @@
+"""Parity of the HIP Jacobi pressure solve (through the C ABI) against the oracle and the llvmpipe goldens.
+Integer-free fp32 path; contract: the kernels perform the GLSL's operations in the GLSL's order with IEEE
+division, so they match the oracle's row-table form BIT FOR BIT; against the reference's own GLSL output the
+bound is BASELINE.json's 1e-5 relative (max|a-ref|/max|ref|)."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, relerr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from demiurge_amd import capi
+    ctx = capi.Context(0)
+    yield capi, ctx
+    ctx.close()
+
+
+def run_jacobi(capi, ctx, grid, img, divw, iters, p0=None, bands=1, ghost=1, block=1):
+    """Single GPU.  bands > 1 emulates the latitude-band split on one device: one dmg_ocean per band, halo
+    slabs moved with dmg_copy_device between sweep blocks of `block` (<= ghost) sweeps."""
+    oc = [capi.Ocean(ctx, grid, band_rank=r, band_count=bands, ghost=ghost) for r in range(bands)]
+    for o in oc:
+        o.set_terrain(img)
+        o.set_divw(divw)
+        if p0 is None:
+            o.zero_pressure()
+        else:
+            o.set_pressure(p0)
+    done = 0
+    while done < iters:
+        n = min(block, iters - done)
+        if bands > 1:
+            exchange(capi, ctx, oc, ghost)
+        for o in oc:
+            o.jacobi_sweeps(n)
+        done += n
+    out = {"pressure": np.zeros((grid.H, grid.W), np.float32)}
+    for o in oc:
+        o.get(want=("pressure",), out=out)
+        o.close()
+    return out["pressure"]
+
+
+def exchange(capi, ctx, oc, rows):
+    for r in range(len(oc) - 1):
+        s_send, s_recv, nb = oc[r].halo(capi.F_PRESSURE, capi.SIDE_NORTH, rows)
+        n_send, n_recv, nb2 = oc[r + 1].halo(capi.F_PRESSURE, capi.SIDE_SOUTH, rows)
+        assert nb == nb2 and nb > 0
+        ctx.copy_device(n_recv, s_send, nb)      # band r's top rows -> band r+1's south ghosts
+        ctx.copy_device(s_recv, n_send, nb)      # band r+1's bottom rows -> band r's north ghosts
+
+
+def ogrid(oracle, grid):
+    return oracle.grid(grid.W, grid.H, tuple(grid.coords), grid.circumference)
+
+
+def test_headline_golden_and_oracle(dev, oracle):
+    capi, ctx = dev
+    G = load_golden("jacobi_256x128_full")
+    grid = capi.make_grid(256, 128, tuple(G["coords"]), float(G["circ"]))
+    for iters, key in ((1, "p1"), (100, "p100"), (5000, "p5000")):
+        p = run_jacobi(capi, ctx, grid, G["img"], G["divw"], iters)
+        assert relerr(p, G[key]) < 1e-5, (iters, relerr(p, G[key]))                      # vs the reference's GLSL
+        ref = oracle.ocean_jacobi(ogrid(oracle, grid), G["img"], G["divw"], iters, rows=True)
+        assert np.array_equal(p, ref), (iters, relerr(p, ref))                             # vs the oracle: bitwise
+
+
+@pytest.mark.parametrize("name", ["full", "belt", "region"])
+def test_extents_golden_and_oracle(dev, oracle, name):
+    capi, ctx = dev
+    G = load_golden("jacobi_128x64_" + name)
+    grid = capi.make_grid(128, 64, tuple(G["coords"]), float(G["circ"]))
+    for iters, key in ((1, "p1"), (60, "p60")):
+        p = run_jacobi(capi, ctx, grid, G["img"], G["divw"], iters, p0=G["p0"])
+        assert relerr(p, G[key]) < 1e-5
+        ref = oracle.ocean_jacobi(ogrid(oracle, grid), G["img"], G["divw"], iters, p0=G["p0"], rows=True)
+        assert np.array_equal(p, ref)
+
+
+@pytest.mark.parametrize("W,H", [(100, 50), (36, 18), (520, 96), (4, 2), (1024, 512)])
+def test_ragged_sizes_bitwise(dev, oracle, W, H):
+    """widths that are not multiples of the vector width / tile, tiny grids, config-1 size"""
+    capi, ctx = dev
+    from demiurge_amd import synth
+    grid = capi.make_grid(W, H)
+    img, b = synth.terrain(W, H), synth.divw(W, H)
+    p = run_jacobi(capi, ctx, grid, img, b, 23)
+    assert np.array_equal(p, oracle.ocean_jacobi(ogrid(oracle, grid), img, b, 23, rows=True))
+
+
+def test_all_land_and_all_ocean(dev, oracle):
+    capi, ctx = dev
+    from demiurge_amd import synth
+    W, H = 128, 64
+    grid = capi.make_grid(W, H)
+    b = synth.divw(W, H)
+    for img in (np.ones((H, W), np.float32), -np.ones((H, W), np.float32), np.zeros((H, W), np.float32)):
+        p = run_jacobi(capi, ctx, grid, img, b, 9)
+        assert np.array_equal(p, oracle.ocean_jacobi(ogrid(oracle, grid), img, b, 9, rows=True))
+    assert not run_jacobi(capi, ctx, grid, np.ones((H, W), np.float32), b, 3).any()
+
+
+@pytest.mark.parametrize("bands,ghost,block", [(2, 1, 1), (4, 4, 4), (8, 3, 2), (3, 5, 5)])
+def test_band_split_is_bitwise(dev, bands, ghost, block):
+    """latitude bands + ghost-row exchange reproduce the single-band result exactly"""
+    capi, ctx = dev
+    from demiurge_amd import synth
+    W, H = 256, 128
+    grid = capi.make_grid(W, H)
+    img, b = synth.terrain(W, H), synth.divw(W, H)
+    one = run_jacobi(capi, ctx, grid, img, b, 37)
+    split = run_jacobi(capi, ctx, grid, img, b, 37, bands=bands, ghost=ghost, block=block)
+    assert np.array_equal(one, split)
+
+
+def test_full_size_bitwise_vs_oracle(dev, oracle):
+    """BASELINE config: 16384x8192, a few sweeps against the oracle bit for bit, plus band split at full size."""
+    capi, ctx = dev
+    from demiurge_amd import synth
+    W, H = 16384, 8192
+    grid = capi.make_grid(W, H)
+    img, b = synth.terrain(W, H), synth.divw(W, H)
+    p = run_jacobi(capi, ctx, grid, img, b, 6)
+    ref = oracle.ocean_jacobi(ogrid(oracle, grid), img, b, 6, rows=True)
+    assert np.array_equal(p, ref)
+    del ref
+    split = run_jacobi(capi, ctx, grid, img, b, 6, bands=8, ghost=3, block=3)
+    assert np.array_equal(p, split)
+
+
+def test_errors(dev):
+    capi, ctx = dev
+    with pytest.raises(capi.DmgError):
+        capi.Ocean(ctx, capi.make_grid(101, 50))           # odd width with poles
+    with pytest.raises(capi.DmgError):
+        capi.Ocean(ctx, capi.make_grid(2, 1))
+    o = capi.Ocean(ctx, capi.make_grid(64, 32))
+    with pytest.raises(capi.DmgError) as e:
+        o.jacobi(1)                                         # before set_terrain
+    assert e.value.code == capi.ESTATE
+    o.close()
