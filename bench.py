@@ -50,12 +50,13 @@ def cpu_baseline_child(args):
     from demiurge_amd import synth
     W, H = args.width, args.height
     img, b = synth.terrain(W, H), synth.divw(W, H)
-    cores = os.cpu_count() or 1
+    # a one-GPU box grants ~16 cores whatever the host shows; oversubscribed OpenMP/llvmpipe threads crawl
+    cores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
     res = None
     sys.path.insert(0, str(ROOT / "oracle" / "refgl"))
     sys.path.insert(0, str(ROOT / "oracle"))
     try:
-        os.environ.setdefault("LP_NUM_THREADS", str(min(cores, 32)))
+        os.environ.setdefault("LP_NUM_THREADS", str(cores))
         import refgl
         if not refgl.available():
             raise RuntimeError("oracle/_ref/librefgl.so not built")

@@ -51,7 +51,8 @@ int dmg_create(int device_id, void *stream, dmg_ctx **out)
     if (!c) return dmg_fail(DMG_ENOMEM, "out of host memory");
     c->device = device_id;
     c->num_cu = prop.multiProcessorCount;
-    snprintf(c->name, sizeof c->name, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    snprintf(c->name, sizeof c->name, "%s (%s, %d CUs)", prop.name[0] ? prop.name : "AMD Instinct", prop.gcnArchName,
+             prop.multiProcessorCount);
     if (stream) {
         c->stream = (hipStream_t)stream;
     } else {

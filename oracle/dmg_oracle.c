@@ -21,13 +21,25 @@ static int g_bilinear = 0;
 static int g_threads = 0;
 void orc_set_linear_taps(int bilinear) { g_bilinear = bilinear; }
 void orc_set_threads(int n) { g_threads = n; }
+/* Default: at most 16 threads (a one-GPU box's CPU share; the host may show far more cores than the cgroup
+ * grants, and oversubscribed OpenMP barriers crawl).  orc_set_threads() overrides. */
 static int nthreads(void)
 {
 #ifdef _OPENMP
-    return g_threads > 0 ? g_threads : omp_get_max_threads();
+    if (g_threads > 0) return g_threads;
+    int n = omp_get_num_procs();
+    return n > 16 ? 16 : (n < 1 ? 1 : n);
 #else
     return 1;
 #endif
+}
+/* small grids: no more threads than 16-row chunks */
+static int nthreads_rows(int H, int want)
+{
+    int n = want > 0 ? want : nthreads();
+    int cap = H / 16;
+    if (cap < 1) cap = 1;
+    return n < cap ? n : cap;
 }
 
 /* ---------- GLSL built-ins ---------- */
@@ -139,7 +151,7 @@ static void jacobi_sweep_literal(const orc_grid *g, const float *img, const floa
 {
     const int W = g->W, H = g->H;
     const float rx = (float)W, ry = (float)H;   /* resolution = textureSize(pressure,0) */
-#pragma omp parallel for schedule(static) num_threads(nthreads())
+#pragma omp parallel for schedule(static) num_threads(nthreads_rows(H, 0))
     for (int y = 0; y < H; y++) {
         float sy = sty(g, y);
         float dx, dy;
@@ -235,7 +247,7 @@ void orc_ocean_jacobi_rows(const orc_grid *g, const float *img, const float *div
     orc_jacobi_row_tables(g, cx, cy, be);
     orc_pole_columns(g, pc);
     orc_topo t = topo_of(g);
-    if (nth <= 0) nth = nthreads();
+    nth = nthreads_rows(H, nth);
     float *a = p, *b = scratch;
     for (int it = 0; it < iters; it++) {
 #pragma omp parallel for schedule(static) num_threads(nth)
@@ -289,7 +301,7 @@ static inline void get_velocity(const orc_grid *g, const float *v, float sx, flo
 void orc_ocean_divergence(const orc_grid *g, const float *img, const float *v, float pressurefactor, float *out)
 {
     const int W = g->W, H = g->H;
-#pragma omp parallel for schedule(static) num_threads(nthreads())
+#pragma omp parallel for schedule(static) num_threads(nthreads_rows(H, 0))
     for (int y = 0; y < H; y++) {
         float sy = sty(g, y);
         float dxc, dyc;
@@ -325,7 +337,7 @@ void orc_ocean_diffusion(const orc_grid *g, const float *img, float *v, float *s
     const int W = g->W, H = g->H;
     float *a = v, *b = scratch;
     for (int it = 0; it < iters; it++) {
-#pragma omp parallel for schedule(static) num_threads(nthreads())
+#pragma omp parallel for schedule(static) num_threads(nthreads_rows(H, 0))
         for (int y = 0; y < H; y++) {
             float sy = sty(g, y);
             float dx, dy;
@@ -390,7 +402,7 @@ void orc_ocean_advect(const orc_grid *g, const float *img, const float *v, float
 {
     const int W = g->W, H = g->H;
     const float k04 = powf(0.4f, 1.0f / 24.0f);          /* pow(vec2(0.4),vec2(1.0/24)) :348 */
-#pragma omp parallel for schedule(static) num_threads(nthreads())
+#pragma omp parallel for schedule(static) num_threads(nthreads_rows(H, 0))
     for (int y = 0; y < H; y++) {
         float sy = sty(g, y);
         for (int x = 0; x < W; x++) {
@@ -438,7 +450,7 @@ void orc_ocean_subdiv(const orc_grid *g, const float *img, const float *v, const
     const int W = g->W, H = g->H;
     const float rx = (float)W, ry = (float)H;
     static const float offsets[8][2] = { { 1, 0 }, { 1, 1 }, { 0, 1 }, { -1, 1 }, { -1, 0 }, { -1, -1 }, { 0, -1 }, { 1, -1 } };  /* :560 */
-#pragma omp parallel for schedule(static) num_threads(nthreads())
+#pragma omp parallel for schedule(static) num_threads(nthreads_rows(H, 0))
     for (int y = 0; y < H; y++) {
         float sy = sty(g, y);
         float dx, dy;
@@ -528,7 +540,7 @@ void orc_blur13_pass(const orc_grid *g, const float *src, float dirx, float diry
     const float rx = (float)W, ry = (float)H;
     const float k1 = 1.411764705882353f, k2 = 3.2941176470588234f, k3 = 5.176470588235294f;
     const float w0 = 0.1964825501511404f, w1 = 0.2969069646728344f, w2 = 0.09447039785044732f, w3 = 0.010381362401148057f;
-#pragma omp parallel for schedule(static) num_threads(nthreads())
+#pragma omp parallel for schedule(static) num_threads(nthreads_rows(H, 0))
     for (int y = 0; y < H; y++) {
         float sy = sty(g, y);
         float lon, lat;
@@ -594,7 +606,7 @@ void orc_temperature(const orc_grid *g, float *T, float *scratch, const float *t
     float *a = T, *b = scratch;
     for (int i = first_step; i < first_step + n_steps; i++) {
         float M = (float)(M_PI * 2 / 15000 * i);          /* :146 glUniform1f(id, M_PI*2/15000*i) */
-#pragma omp parallel for schedule(static) num_threads(nthreads())
+#pragma omp parallel for schedule(static) num_threads(nthreads_rows(H, 0))
         for (int y = 0; y < H; y++) {
             float sy = sty(g, y);
             float lon, phi;
@@ -647,7 +659,7 @@ void orc_erosion_pass(const orc_grid *g, const float *hgt, const float *flow, co
     const float rx = (float)W, ry = (float)H;
     static const float offs[8][2] = { { 1, 1 }, { 0, 1 }, { -1, 1 }, { 1, 0 }, { -1, 0 }, { 1, -1 }, { 0, -1 }, { -1, -1 } };  /* :134-189 order */
     const float SLOPE = tanf(MPI / 2.0f / 3.0f);          /* :191 */
-#pragma omp parallel for schedule(static) num_threads(nthreads())
+#pragma omp parallel for schedule(static) num_threads(nthreads_rows(H, 0))
     for (int y = 0; y < H; y++) {
         float sy = sty(g, y);
         float psx, psy;

@@ -2,6 +2,7 @@
 importable from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, never from
 the product package."""
 import ctypes
+import os
 from pathlib import Path
 
 import numpy as np
@@ -26,6 +27,7 @@ def grid(W, H, coords=FULL_GLOBE, circumference=42000.0):
 
 
 _lib = None
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")   # shared hosts: do not spin at barriers
 
 
 def lib():
