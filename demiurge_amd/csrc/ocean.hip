@@ -256,6 +256,7 @@ int dmg_ocean_create(dmg_ctx *ctx, const dmg_grid *grid, const dmg_ocean_params 
     alloc((void **)&o->p[0], n * 4); alloc((void **)&o->p[1], n * 4);
     alloc((void **)&o->divw, n * 4); alloc((void **)&o->img, n * 4);
     alloc((void **)&o->code, n);
+    alloc((void **)&o->code8, n);
     alloc((void **)&o->v[0], n * 8); alloc((void **)&o->v[1], n * 8);
     alloc((void **)&o->rowtab, sizeof(float) * ROWTAB_FIELDS * o->L);
     if (e != hipSuccess) {
@@ -281,7 +282,7 @@ void dmg_ocean_destroy(dmg_ocean *o)
     if (!o) return;
     (void)hipSetDevice(o->ctx->device);
     (void)hipStreamSynchronize(o->ctx->stream);
-    for (void *p : { (void *)o->p[0], (void *)o->p[1], (void *)o->divw, (void *)o->img, (void *)o->code,
+    for (void *p : { (void *)o->p[0], (void *)o->p[1], (void *)o->divw, (void *)o->img, (void *)o->code, (void *)o->code8,
                      (void *)o->v[0], (void *)o->v[1], (void *)o->rowtab })
         if (p) (void)hipFree(p);
     delete o;
@@ -293,6 +294,8 @@ int dmg_ocean_set_terrain(dmg_ocean *o, const float *img)
     int rc = ocean_upload_rows(o, o->img, img, 1);
     if (rc) return rc;
     rc = ocean_build_codes(o);
+    if (rc) return rc;
+    rc = ocean_build_codes8(o);
     if (rc) return rc;
     o->have_terrain = true;
     // keep the "land holds exact zeros" invariant for whatever pressure is resident

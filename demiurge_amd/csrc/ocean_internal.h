@@ -28,7 +28,8 @@ struct dmg_ocean {
     float *p[2] = { nullptr, nullptr };
     int cur = 0;                   // p[cur] holds the current pressure
     float *divw = nullptr, *img = nullptr;
-    unsigned char *code = nullptr;
+    unsigned char *code = nullptr;    // Jacobi/diffusion/subDiv 'use centre' bits + centre-solid bit
+    unsigned char *code8 = nullptr;   // 8-neighbour solid bits (divergence, subDiv)
     float *v[2] = { nullptr, nullptr };   // interleaved (vx,vy)
     int vcur = 0;
     float *rowtab = nullptr;       // ROWTAB_FIELDS arrays of L floats
@@ -39,5 +40,6 @@ struct dmg_ocean {
 
 int ocean_upload_row_tables(dmg_ocean *o);
 int ocean_build_codes(dmg_ocean *o);
+int ocean_build_codes8(dmg_ocean *o);
 int ocean_upload_rows(dmg_ocean *o, float *dst, const float *src_full, int comps);
 int ocean_download_rows(dmg_ocean *o, float *dst_full, const float *src, int comps);

@@ -1,0 +1,393 @@
+// The non-Jacobi passes of OceanCurrents::run (reference src/filter/OceanCurrents.cpp:155-209):
+// advect (:235-360), diffusion (:625-708), divergence (:363-435), subDiv (:511-622) and the outer step.
+// One thread per cell, coalesced row-major access; velocity is interleaved (vx,vy) like the reference's RG32F.
+// Arithmetic follows the GLSL statement order with IEEE ops and host-computed per-row tables, so divergence and
+// diffusion match the oracle bit for bit; advect/subDiv call device libm (sin/cos/atan2/asin/pow) and match the
+// oracle to a few ulp.
+#include "ocean_internal.h"
+
+struct pass_args {
+    const float2 *vin;
+    float2 *vout;
+    const float *p;
+    float *out;                      // scalar output (divergence)
+    const float *img;
+    const unsigned char *code;       // bits0-3 N,S,E,W "use centre" (solid or clamped onto self), bit4 centre solid
+    const unsigned char *code8;      // bit i: neighbour offsets[i] is solid, offsets = E,NE,N,NW,W,SW,S,SE (:560)
+    const float *rt;                 // row tables, ROWTAB_FIELDS x L
+    int W, L;
+    int l_south_pole, l_north_pole;  // local row of grid row 0 / H-1 when that edge is a pole, else -1
+    int lonwrap;
+    float pressurefactor, scale, timestep, wind, circumference;
+    float c0, c1, c2, c3;            // cornerCoords
+    int scalar_rhs;
+    int H;                           // full grid height (advect's texture space)
+    int y_first;                     // grid row of local row 0
+};
+
+// resolves the 4-neighbourhood of (x,l): neighbour column/row and whether the tap crossed a pole
+struct nb4 {
+    int xn, ln, xs, ls, xe, xw;
+    bool nflip, sflip;
+};
+__device__ __forceinline__ nb4 neighbours(const pass_args &a, int x, int l)
+{
+    nb4 n;
+    const int W = a.W;
+    n.xe = x + 1; n.xw = x - 1;
+    if (n.xe >= W) n.xe = a.lonwrap ? 0 : W - 1;
+    if (n.xw < 0) n.xw = a.lonwrap ? W - 1 : 0;
+    n.nflip = (l == a.l_north_pole); n.sflip = (l == a.l_south_pole);
+    if (n.nflip) { n.ln = l; n.xn = x + W / 2; if (n.xn >= W) n.xn -= W; }
+    else { n.ln = (l + 1 < a.L) ? l + 1 : l; n.xn = x; }
+    if (n.sflip) { n.ls = l; n.xs = x + W / 2; if (n.xs >= W) n.xs -= W; }
+    else { n.ls = (l >= 1) ? l - 1 : l; n.xs = x; }
+    return n;
+}
+
+__device__ __forceinline__ float2 neg2(float2 v) { return make_float2(-v.x, -v.y); }
+
+// ---------------------------------------------------------------------------------------------
+// divergence (:376-420)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_divergence(pass_args a)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x, l = blockIdx.y;
+    if (x >= a.W) return;
+    const int W = a.W, L = a.L;
+    nb4 n = neighbours(a, x, l);
+    const float *dxr = a.rt + (size_t)RT_DX * L, *dyr = a.rt + (size_t)RT_DY * L;
+    unsigned c8 = a.code8[(size_t)l * W + x];
+    // get_velocity(): v(st_o) [sign-flipped across a pole, :389] * (d_o.x*d_o.y) * pressurefactor (:392)
+    float2 vN = a.vin[(size_t)n.ln * W + n.xn], vS = a.vin[(size_t)n.ls * W + n.xs];
+    float2 vE = a.vin[(size_t)l * W + n.xe], vW = a.vin[(size_t)l * W + n.xw];
+    if (n.nflip) vN = neg2(vN);
+    if (n.sflip) vS = neg2(vS);
+    float aN = __fmul_rn(dxr[n.ln], dyr[n.ln]), aS = __fmul_rn(dxr[n.ls], dyr[n.ls]), aC = __fmul_rn(dxr[l], dyr[l]);
+    float vNy = __fmul_rn(__fmul_rn(vN.y, aN), a.pressurefactor);
+    float vSy = __fmul_rn(__fmul_rn(vS.y, aS), a.pressurefactor);
+    float vEx = __fmul_rn(__fmul_rn(vE.x, aC), a.pressurefactor);
+    float vWx = __fmul_rn(__fmul_rn(vW.x, aC), a.pressurefactor);
+    if (c8 & 4u) vNy = 0.0f;       // oN > 0 (:413)
+    if (c8 & 64u) vSy = 0.0f;
+    if (c8 & 1u) vEx = 0.0f;
+    if (c8 & 16u) vWx = 0.0f;
+    float pwx = __fdiv_rn(dxr[l], a.scale), pwy = __fdiv_rn(dyr[l], a.scale);    // pixelsize(st)/420 (:419)
+    a.out[(size_t)l * W + x] =
+        __fmul_rn(0.5f, __fadd_rn(__fdiv_rn(__fsub_rn(vEx, vWx), pwx), __fdiv_rn(__fsub_rn(vNy, vSy), pwy)));   // :420
+}
+
+// ---------------------------------------------------------------------------------------------
+// velocity diffusion sweep (:664-693)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_diffusion(pass_args a)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x, l = blockIdx.y;
+    if (x >= a.W) return;
+    const int W = a.W, L = a.L;
+    nb4 n = neighbours(a, x, l);
+    unsigned c = a.code[(size_t)l * W + x];
+    float2 pC = a.vin[(size_t)l * W + x];
+    float2 pN = a.vin[(size_t)n.ln * W + n.xn], pS = a.vin[(size_t)n.ls * W + n.xs];
+    float2 pE = a.vin[(size_t)l * W + n.xe], pW = a.vin[(size_t)l * W + n.xw];
+    if (n.nflip) pN = neg2(pN);      // :657
+    if (n.sflip) pS = neg2(pS);
+    if (c & 1u) pN = pC;             // :682-685
+    if (c & 2u) pS = pC;
+    if (c & 4u) pE = pC;
+    if (c & 8u) pW = pC;
+    float px = a.rt[(size_t)RT_DIFPX * L + l], py = a.rt[(size_t)RT_DIFPY * L + l], beta = a.rt[(size_t)RT_DIFBETA * L + l];
+    float bx = pC.x, by = a.scalar_rhs ? pC.x : pC.y;      // `float bC = texture(v,st).r` (:687)
+    float2 o;
+    // ((pW + pE)*pw2.x + (pS + pN)*pw2.y - (-bC)) / Beta   (:693)
+    o.x = __fdiv_rn(__fsub_rn(__fadd_rn(__fmul_rn(__fadd_rn(pW.x, pE.x), px), __fmul_rn(__fadd_rn(pS.x, pN.x), py)), -bx), beta);
+    o.y = __fdiv_rn(__fsub_rn(__fadd_rn(__fmul_rn(__fadd_rn(pW.y, pE.y), px), __fmul_rn(__fadd_rn(pS.y, pN.y), py)), -by), beta);
+    a.vout[(size_t)l * W + x] = o;
+}
+
+// ---------------------------------------------------------------------------------------------
+// subDiv: pressure-gradient subtraction + coastline direction snapping (:532-606)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float glsl_mod(float x, float y) { return __fsub_rn(x, __fmul_rn(y, floorf(__fdiv_rn(x, y)))); }
+
+__global__ __launch_bounds__(256) void k_subdiv(pass_args a)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x, l = blockIdx.y;
+    if (x >= a.W) return;
+    const int W = a.W, L = a.L;
+    size_t i = (size_t)l * W + x;
+    unsigned c = a.code[i];
+    if (c & 16u) { a.vout[i] = make_float2(0.0f, 0.0f); return; }     // :536-540
+    nb4 n = neighbours(a, x, l);
+    float pC = a.p[i];
+    float pN = a.p[(size_t)n.ln * W + n.xn], pS = a.p[(size_t)n.ls * W + n.xs];
+    float pE = a.p[(size_t)l * W + n.xe], pW = a.p[(size_t)l * W + n.xw];
+    if (c & 1u) pN = pC;
+    if (c & 2u) pS = pC;
+    if (c & 4u) pE = pC;
+    if (c & 8u) pW = pC;
+    float2 oldV = a.vin[i];
+    float dx = a.rt[(size_t)RT_DX * L + l], dy = a.rt[(size_t)RT_DY * L + l];
+    float pwx = __fdiv_rn(dx, a.scale), pwy = __fdiv_rn(dy, a.scale);
+    // :575  oldV - 0.5*vec2(pE-pW,pN-pS)/pixelwidth / pixelsize.x / pixelsize.y / pressurefactor
+    float fx = __fsub_rn(oldV.x, __fdiv_rn(__fdiv_rn(__fdiv_rn(__fdiv_rn(__fmul_rn(0.5f, __fsub_rn(pE, pW)), pwx), dx), dy), a.pressurefactor));
+    float fy = __fsub_rn(oldV.y, __fdiv_rn(__fdiv_rn(__fdiv_rn(__fdiv_rn(__fmul_rn(0.5f, __fsub_rn(pN, pS)), pwy), dx), dy), a.pressurefactor));
+    unsigned o8 = a.code8[i];                                             // o_array[k] > 0  <=>  bit k
+    float ang = __fadd_rn(__fmul_rn(__fdiv_rn(__fadd_rn(__fdiv_rn(atan2f(fy, fx), DMG_PI), 1.0f), 2.0f), 8.0f), 4.0f);
+    float lower = glsl_mod(floorf(ang), 8.0f), upper = glsl_mod(ceilf(ang), 8.0f), theta = glsl_mod(ang, 8.0f);
+    int il = min(max((int)lower, 0), 7), iu = min(max((int)upper, 0), 7);
+    bool isBorder = ((o8 >> il) & 1u) || ((o8 >> iu) & 1u);
+    float nx = fx, ny = fy;
+    float difference = 2.0f * DMG_PI;
+    const float offx[8] = { 1, 1, 0, -1, -1, -1, 0, 1 }, offy[8] = { 0, 1, 1, 1, 0, -1, -1, -1 };
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        // thetai = mod((atan(o.y,o.x)/M_PI+1)/2*8+4, 8) is exactly k for the 8 compass offsets (:597)
+        float thetai = (float)k;
+        float d = fabsf(__fsub_rn(thetai, theta));
+        float angleToVel = fminf(__fsub_rn(2.0f * DMG_PI, d), d);          // sic: 2*pi, not 8 (:598)
+        if (angleToVel < difference && !((o8 >> k) & 1u)) {
+            difference = angleToVel;
+            float lo = sqrtf(__fadd_rn(__fmul_rn(offx[k], offx[k]), __fmul_rn(offy[k], offy[k])));
+            float ln = sqrtf(__fadd_rn(__fmul_rn(nx, nx), __fmul_rn(ny, ny)));
+            nx = __fmul_rn(__fdiv_rn(offx[k], lo), ln);
+            ny = __fmul_rn(__fdiv_rn(offy[k], lo), ln);
+        }
+    }
+    if (isBorder) { fx = nx; fy = ny; }
+    a.vout[i] = make_float2(fx, fy);
+}
+
+// ---------------------------------------------------------------------------------------------
+// advect: semi-Lagrangian back-trace along a great circle + parallel transport + wind forcing (:282-348)
+// ---------------------------------------------------------------------------------------------
+struct vec3 { float x, y, z; };
+__device__ __forceinline__ vec3 v3(float x, float y, float z) { vec3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ vec3 cross3(vec3 a, vec3 b)
+{ return v3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y); }
+__device__ __forceinline__ float dot3(vec3 a, vec3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ vec3 norm3(vec3 a) { float r = 1.0f / sqrtf(dot3(a, a)); return v3(a.x * r, a.y * r, a.z * r); }
+__device__ __forceinline__ vec3 sph2cart(float lon, float lat) { return v3(cosf(lat) * cosf(lon), cosf(lat) * sinf(lon), sinf(lat)); }
+// v_to_cartesian / cartesian_to_v (:251-268)
+__device__ __forceinline__ void tangent_basis(float lon, float lat, vec3 *par, vec3 *ycomp)
+{
+    vec3 c = sph2cart(lon, lat);
+    float il = 1.0f / sqrtf(c.x * c.x + c.y * c.y);
+    float inx = c.x * il, iny = c.y * il;
+    *ycomp = v3(sinf(lat) * (-inx), sinf(lat) * (-iny), cosf(lat));
+    *par = norm3(cross3(v3(0, 0, 1), c));
+}
+// rotation_matrix(theta,u)*v (reference src/Shader.h:35-40; mat3 columns)
+__device__ __forceinline__ vec3 rotate3(float theta, vec3 u, vec3 v)
+{
+    float c = cosf(theta), s = sinf(theta), ic = 1.0f - c;
+    vec3 c0 = v3(c + u.x * u.x * ic, u.y * u.x * ic + u.z * s, u.z * u.x * ic - u.y * s);
+    vec3 c1 = v3(u.x * u.y * ic - u.z * s, c + u.y * u.y * ic, u.z * u.y * ic + u.x * s);
+    vec3 c2 = v3(u.x * u.z * ic + u.y * s, u.y * u.z * ic - u.x * s, c + u.z * u.z * ic);
+    return v3(c0.x * v.x + c1.x * v.y + c2.x * v.z, c0.y * v.x + c1.y * v.y + c2.y * v.z, c0.z * v.x + c1.z * v.y + c2.z * v.z);
+}
+// GL_LINEAR + GL_CLAMP_TO_EDGE fetch of the RG32F velocity texture at (u,v) (reference src/Texture.cpp:29-33)
+__device__ __forceinline__ float2 fetch_linear2(const float2 *t, int W, int H, float u, float v)
+{
+    float fu = u * (float)W - 0.5f, fv = v * (float)H - 0.5f;
+    float flu = floorf(fu), flv = floorf(fv);
+    float wx = fu - flu, wy = fv - flv;
+    int i0 = min(max((int)flu, 0), W - 1), i1 = min(max((int)flu + 1, 0), W - 1);
+    int j0 = min(max((int)flv, 0), H - 1), j1 = min(max((int)flv + 1, 0), H - 1);
+    float2 t00 = t[(size_t)j0 * W + i0], t10 = t[(size_t)j0 * W + i1], t01 = t[(size_t)j1 * W + i0], t11 = t[(size_t)j1 * W + i1];
+    float ax = t00.x + wx * (t10.x - t00.x), bx = t01.x + wx * (t11.x - t01.x);
+    float ay = t00.y + wx * (t10.y - t00.y), by = t01.y + wx * (t11.y - t01.y);
+    return make_float2(ax + wy * (bx - ax), ay + wy * (by - ay));
+}
+
+__global__ __launch_bounds__(256) void k_advect(pass_args a, float k04)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x, l = blockIdx.y;
+    if (x >= a.W) return;
+    const int W = a.W;
+    size_t i = (size_t)l * W + x;
+    if (a.code[i] & 16u) { a.vout[i] = make_float2(0.0f, 0.0f); return; }        // :284-288
+    float2 vel = a.vin[i];                                                         // :290
+    float sx = ((float)x + 0.5f) / (float)W, sy = ((float)(a.y_first + l) + 0.5f) / (float)a.H;
+    float distance = sqrtf(vel.x * vel.x + vel.y * vel.y) * a.timestep;           // :298
+    float arclength = 2.0f * 3.14159f / a.circumference * distance;                // :299
+    float lon = sx * (a.c3 - a.c2) + a.c2, lat = sy * (a.c1 - a.c0) + a.c0;        // tex_to_spheric
+    vec3 cart = sph2cart(lon, lat);
+    vec3 par, yc;
+    tangent_basis(lon, lat, &par, &yc);
+    vec3 v_cart = v3(par.x * vel.x + yc.x * vel.y, par.y * vel.x + yc.y * vel.y, par.z * vel.x + yc.z * vel.y);
+    vec3 rotdir = norm3(cross3(cart, v_cart));                                     // :306
+    cart = rotate3(-arclength, rotdir, cart);                                      // :308
+    float lon_n = atan2f(cart.y, cart.x), lat_n = asinf(cart.z);                   // cartesian_to_spheric
+    float cu = (lon_n - a.c2) / (a.c3 - a.c2), cv = (lat_n - a.c0) / (a.c1 - a.c0);   // spheric_to_tex
+    // single-band only: the whole velocity field is local, row index = grid row
+    float2 nv = fetch_linear2(a.vin, W, a.H, cu, cv);                              // :315
+    vec3 par_n, yc_n;
+    tangent_basis(lon_n, lat_n, &par_n, &yc_n);
+    vec3 testv = v3(par_n.x * nv.x + yc_n.x * nv.y, par_n.y * nv.x + yc_n.y * nv.y, par_n.z * nv.x + yc_n.z * nv.y);
+    testv = rotate3(arclength, rotdir, testv);
+    float nvx = dot3(testv, par), nvy = dot3(testv, yc);                           // cartesian_to_v(testv, tex_to_spheric(st))
+    if (isnan(nvx) || isnan(nvy)) { nvx = 0.0f; nvy = 0.0f; }                      // :321 (zero velocity: normalize(0))
+    float fcx = 1.0f * nvx, fcy = 1.0f * nvy;                                      // Dissipation :332; Coriolis x0.0 (:327)
+    float phi = 2.0f * (sy - 0.5f) * 3.14159f;                                     // :341
+    float windx = a.wind * -cosf(phi * 3.0f / 2.0f), windy = a.wind * sinf(phi * 3.0f / 2.0f);
+    if (fabsf(phi * 3.0f / 2.0f) > 3.14159f) windx = -windx;
+    if (fabsf(phi) > 3.14159f * 1.0f / 3.0f && fabsf(phi) < 3.1459f * 2.0f / 3.0f) windy = -windy;   // sic 3.1459 (:344)
+    if (phi < 0.0f) windy = -windy;
+    float ax = fabsf(windx - fcx), ay = fabsf(windy - fcy);
+    float stressx = 1.0f + 0.0001f * (ax * ax), stressy = 1.0f + 0.0001f * (ay * ay);   // :347
+    float e = -1.0f / 24.0f * 2.0f;
+    float2 o;
+    o.x = fcx + windx * (1.0f - powf(stressx, e)) - fcx * (1.0f - k04);            // :348
+    o.y = fcy + windy * (1.0f - powf(stressy, e)) - fcy * (1.0f - k04);
+    a.vout[i] = o;
+}
+
+// neighbour-solid bits for the 8 compass offsets of subDiv (:560), img fetched through offset() + CLAMP_TO_EDGE
+__global__ void k_build_codes8(const float *__restrict__ img, unsigned char *__restrict__ code8, int W, int L,
+                               int y_first, int H, int lonwrap, int spole, int npole)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x, l = blockIdx.y;
+    if (x >= W) return;
+    const int offx[8] = { 1, 1, 0, -1, -1, -1, 0, 1 }, offy[8] = { 0, 1, 1, 1, 0, -1, -1, -1 };
+    int y = y_first + l;
+    unsigned c = 0;
+    for (int k = 0; k < 8; k++) {
+        int xx = x + offx[k], yy = y + offy[k];
+        // offset(): longitude wrap first (Shader.h:85), then pole reflection with lon += pi (:86-95), else clamp
+        if (lonwrap) { if (xx >= W) xx -= W; if (xx < 0) xx += W; }
+        else xx = min(max(xx, 0), W - 1);
+        if (yy < 0) { if (spole) { yy = 0; xx = (xx + W / 2) % W; } else yy = 0; }
+        if (yy >= H) { if (npole) { yy = H - 1; xx = (xx + W / 2) % W; } else yy = H - 1; }
+        int ll = yy - y_first;
+        bool solid = (ll >= 0 && ll < L) ? (img[(size_t)ll * W + xx] > 0.0f) : true;   // beyond the ghost rows: never used
+        if (solid) c |= (1u << k);
+    }
+    code8[(size_t)l * W + x] = (unsigned char)c;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static pass_args make_args(dmg_ocean *o)
+{
+    pass_args a;
+    memset(&a, 0, sizeof a);
+    a.vin = (const float2 *)o->v[o->vcur];
+    a.vout = (float2 *)o->v[o->vcur ^ 1];
+    a.p = o->p[o->cur];
+    a.out = o->divw;
+    a.img = o->img;
+    a.code = o->code;
+    a.code8 = o->code8;
+    a.rt = o->rowtab;
+    a.W = o->grid.W; a.L = o->L; a.H = o->grid.H; a.y_first = o->y0 - o->gs;
+    a.l_south_pole = (o->topo.spole && o->y0 == 0) ? o->gs : -1;
+    a.l_north_pole = (o->topo.npole && o->y1 == o->grid.H) ? o->gs + (o->y1 - o->y0) - 1 : -1;
+    a.lonwrap = o->topo.lonwrap ? 1 : 0;
+    a.pressurefactor = o->prm.pressurefactor; a.scale = o->prm.scale; a.timestep = o->prm.timestep_h;
+    a.wind = o->prm.wind; a.circumference = o->grid.circumference;
+    a.c0 = o->grid.coords[0]; a.c1 = o->grid.coords[1]; a.c2 = o->grid.coords[2]; a.c3 = o->grid.coords[3];
+    a.scalar_rhs = (o->prm.quirks & DMG_QUIRK_DIFFUSION_SCALAR_RHS) ? 1 : 0;
+    return a;
+}
+
+static int require_single_band(dmg_ocean *o, const char *what)
+{
+    if (!o) return dmg_fail(DMG_EINVAL, "%s: null handle", what);
+    if (!o->have_terrain) return dmg_fail(DMG_ESTATE, "%s: dmg_ocean_set_terrain must come first", what);
+    if (o->count != 1) return dmg_fail(DMG_EINVAL, "%s: single-band (band_count == 1) in this build", what);
+    return DMG_OK;
+}
+
+int ocean_build_codes8(dmg_ocean *o)
+{
+    dim3 grid((o->grid.W + 255) / 256, o->L);
+    hipLaunchKernelGGL(k_build_codes8, grid, dim3(256), 0, o->ctx->stream, o->img, o->code8, o->grid.W, o->L,
+                       o->y0 - o->gs, o->grid.H, (int)o->topo.lonwrap, (int)o->topo.spole, (int)o->topo.npole);
+    DMG_HIP(hipGetLastError());
+    return DMG_OK;
+}
+
+extern "C" {
+
+int dmg_ocean_set_velocity(dmg_ocean *o, const float *vx, const float *vy)
+{
+    DMG_CHECK_ARG(o != nullptr && vx != nullptr && vy != nullptr);
+    size_t n = (size_t)o->L * o->grid.W, off = (size_t)(o->y0 - o->gs) * o->grid.W;
+    std::vector<float> tmp(n * 2);
+    for (size_t i = 0; i < n; i++) { tmp[2 * i] = vx[off + i]; tmp[2 * i + 1] = vy[off + i]; }
+    DMG_HIP(hipMemcpyAsync(o->v[o->vcur], tmp.data(), n * 8, hipMemcpyHostToDevice, o->ctx->stream));
+    DMG_HIP(hipStreamSynchronize(o->ctx->stream));
+    return DMG_OK;
+}
+
+int dmg_ocean_divergence(dmg_ocean *o)
+{
+    int rc = require_single_band(o, "dmg_ocean_divergence");
+    if (rc) return rc;
+    pass_args a = make_args(o);
+    dim3 grid((a.W + 255) / 256, a.L);
+    hipLaunchKernelGGL(k_divergence, grid, dim3(256), 0, o->ctx->stream, a);
+    DMG_HIP(hipGetLastError());
+    return DMG_OK;
+}
+
+int dmg_ocean_diffusion(dmg_ocean *o, int iters)
+{
+    int rc = require_single_band(o, "dmg_ocean_diffusion");
+    if (rc) return rc;
+    DMG_CHECK_ARG(iters >= 0);
+    for (int it = 0; it < iters; it++) {                   // :701-707
+        pass_args a = make_args(o);
+        dim3 grid((a.W + 255) / 256, a.L);
+        hipLaunchKernelGGL(k_diffusion, grid, dim3(256), 0, o->ctx->stream, a);
+        DMG_HIP(hipGetLastError());
+        o->vcur ^= 1;                                      // v_scratch->swap(v)
+    }
+    return DMG_OK;
+}
+
+int dmg_ocean_subdiv(dmg_ocean *o)
+{
+    int rc = require_single_band(o, "dmg_ocean_subdiv");
+    if (rc) return rc;
+    pass_args a = make_args(o);
+    dim3 grid((a.W + 255) / 256, a.L);
+    hipLaunchKernelGGL(k_subdiv, grid, dim3(256), 0, o->ctx->stream, a);
+    DMG_HIP(hipGetLastError());
+    o->vcur ^= 1;                                          // v->swap(v_scratch) (:621)
+    return DMG_OK;
+}
+
+int dmg_ocean_advect(dmg_ocean *o)
+{
+    int rc = require_single_band(o, "dmg_ocean_advect");
+    if (rc) return rc;
+    pass_args a = make_args(o);
+    float k04 = powf(0.4f, 1.0f / 24.0f);                  // pow(vec2(0.4),vec2(1.0/24)) (:348), a constant
+    dim3 grid((a.W + 255) / 256, a.L);
+    hipLaunchKernelGGL(k_advect, grid, dim3(256), 0, o->ctx->stream, a, k04);
+    DMG_HIP(hipGetLastError());
+    o->vcur ^= 1;                                          // v->swap(v_scratch) (:359)
+    return DMG_OK;
+}
+
+// OceanCurrents::run body (:155-209)
+int dmg_ocean_step(dmg_ocean *o, int n_outer)
+{
+    int rc = require_single_band(o, "dmg_ocean_step");
+    if (rc) return rc;
+    DMG_CHECK_ARG(n_outer >= 0);
+    for (int j = 0; j < n_outer; j++) {
+        if ((rc = dmg_ocean_advect(o))) return rc;                                  // :158
+        if ((rc = dmg_ocean_diffusion(o, o->prm.diffusion_iters))) return rc;       // :160
+        if ((rc = dmg_ocean_divergence(o))) return rc;                              // :162
+        if ((rc = dmg_ocean_jacobi(o, o->prm.jacobi_iters, 1))) return rc;          // :166
+        if ((rc = dmg_ocean_subdiv(o))) return rc;                                  // :168
+        // :170 divergence(p, divw_showcase) is a display-only field; :175-205 exports are dmg_ocean_get
+    }
+    return DMG_OK;
+}
+
+}  // extern "C"

@@ -3,12 +3,6 @@
 #include "ocean_internal.h"
 #define NOT_YET(name) return dmg_fail(DMG_ESTATE, name ": kernel not implemented in this build")
 extern "C" {
-int dmg_ocean_set_velocity(dmg_ocean *, const float *, const float *) { NOT_YET("dmg_ocean_set_velocity"); }
-int dmg_ocean_step(dmg_ocean *, int) { NOT_YET("dmg_ocean_step"); }
-int dmg_ocean_advect(dmg_ocean *) { NOT_YET("dmg_ocean_advect"); }
-int dmg_ocean_diffusion(dmg_ocean *, int) { NOT_YET("dmg_ocean_diffusion"); }
-int dmg_ocean_divergence(dmg_ocean *) { NOT_YET("dmg_ocean_divergence"); }
-int dmg_ocean_subdiv(dmg_ocean *) { NOT_YET("dmg_ocean_subdiv"); }
 int dmg_blur(dmg_ctx *, const dmg_grid *, float *, float) { NOT_YET("dmg_blur"); }
 int dmg_temperature_steps(dmg_ctx *, const dmg_grid *, float *, const float *, int, int) { NOT_YET("dmg_temperature_steps"); }
 int dmg_erosion_pass(dmg_ctx *, const dmg_grid *, float *, const float *, const float *, float, float) { NOT_YET("dmg_erosion_pass"); }
