@@ -4,6 +4,7 @@ This module is plumbing for the tests and bench.py; the product is the shared li
 loudly when the library is missing or no MI355X is visible -- there is no CPU fallback.
 """
 import ctypes
+import weakref
 from pathlib import Path
 
 import numpy as np
@@ -120,9 +121,12 @@ class Context:
         h = ctypes.c_void_p()
         check(lib().dmg_create(int(device), stream, ctypes.byref(h)))
         self.h = h
+        self._children = weakref.WeakSet()     # handles that must be destroyed before the context
 
     def close(self):
         if self.h:
+            for c in list(self._children):
+                c.close()
             lib().dmg_destroy(self.h)
             self.h = None
 
@@ -187,6 +191,7 @@ class Ocean:
         check(lib().dmg_ocean_create(ctx.h, ctypes.byref(grid), ctypes.byref(self.params), band_rank, band_count,
                                      ghost, ctypes.byref(h)))
         self.h = h
+        ctx._children.add(self)
 
     def close(self):
         if self.h:

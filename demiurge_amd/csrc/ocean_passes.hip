@@ -23,6 +23,10 @@ struct pass_args {
     int scalar_rhs;
     int H;                           // full grid height (advect's texture space)
     int y_first;                     // grid row of local row 0
+    // pixelsize(st_o).x*.y of the virtual rows y = -1 / y = H: on a non-pole edge offset() leaves st_o.y outside
+    // [0,1] (only the texture fetch clamps), so get_velocity()'s d_o is evaluated beyond the grid (:380-381,:392)
+    float area_below, area_above;
+    int l_south_clamp, l_north_clamp;   // local row of grid row 0 / H-1 when that edge is NOT a pole, else -1
 };
 
 // resolves the 4-neighbourhood of (x,l): neighbour column/row and whether the tap crossed a pole
@@ -64,6 +68,8 @@ __global__ __launch_bounds__(256) void k_divergence(pass_args a)
     if (n.nflip) vN = neg2(vN);
     if (n.sflip) vS = neg2(vS);
     float aN = __fmul_rn(dxr[n.ln], dyr[n.ln]), aS = __fmul_rn(dxr[n.ls], dyr[n.ls]), aC = __fmul_rn(dxr[l], dyr[l]);
+    if (l == a.l_north_clamp) aN = a.area_above;
+    if (l == a.l_south_clamp) aS = a.area_below;
     float vNy = __fmul_rn(__fmul_rn(vN.y, aN), a.pressurefactor);
     float vSy = __fmul_rn(__fmul_rn(vS.y, aS), a.pressurefactor);
     float vEx = __fmul_rn(__fmul_rn(vE.x, aC), a.pressurefactor);
@@ -289,6 +295,13 @@ static pass_args make_args(dmg_ocean *o)
     a.wind = o->prm.wind; a.circumference = o->grid.circumference;
     a.c0 = o->grid.coords[0]; a.c1 = o->grid.coords[1]; a.c2 = o->grid.coords[2]; a.c3 = o->grid.coords[3];
     a.scalar_rhs = (o->prm.quirks & DMG_QUIRK_DIFFUSION_SCALAR_RHS) ? 1 : 0;
+    a.l_south_clamp = (!o->topo.spole && o->y0 == 0) ? o->gs : -1;
+    a.l_north_clamp = (!o->topo.npole && o->y1 == o->grid.H) ? o->gs + (o->y1 - o->y0) - 1 : -1;
+    float dx, dy;
+    dmg_row_pixelsize(o->grid, -1, &dx, &dy);
+    a.area_below = dx * dy;
+    dmg_row_pixelsize(o->grid, o->grid.H, &dx, &dy);
+    a.area_above = dx * dy;
     return a;
 }
 
