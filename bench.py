@@ -101,45 +101,13 @@ def cpu_baseline(args):
         return dict(value=None, unit="Mcell-steps/s", cores=0, kind="port", sample="cpu baseline failed: %s" % e)
 
 
-# --------------------------------------------------------------------------------------------------
-# device tensors aliasing library-owned halo slabs (for RCCL send/recv through torch.distributed)
-# --------------------------------------------------------------------------------------------------
-class _DevSlab:
-    def __init__(self, ptr, nbytes):
-        self.__cuda_array_interface__ = dict(shape=(nbytes // 4,), typestr="<f4", data=(int(ptr), False), version=2)
-
-
-_alias_cache = {}
-
-
-def alias(torch, ptr, nbytes, device):
-    key = (ptr, nbytes)
-    if key not in _alias_cache:
-        _alias_cache[key] = torch.as_tensor(_DevSlab(ptr, nbytes), device=device)
-    return _alias_cache[key]
-
-
-def exchange_halos(torch, dist, capi, oc, rank, world, rows, device):
-    """Refresh the pressure ghost rows: band r's top rows <-> band r+1's bottom rows (one RCCL group)."""
-    ops = []
-    for side, peer in ((capi.SIDE_SOUTH, rank - 1), (capi.SIDE_NORTH, rank + 1)):
-        if peer < 0 or peer >= world:
-            continue
-        send, recv, nb = oc.halo(capi.F_PRESSURE, side, rows)
-        ops.append(dist.P2POp(dist.isend, alias(torch, send, nb, device), peer))
-        ops.append(dist.P2POp(dist.irecv, alias(torch, recv, nb, device), peer))
-    if ops:
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
-
-
 def main():
     args = parse()
     if args.cpu_baseline_only:
         cpu_baseline_child(args)
         return
     import torch
-    from demiurge_amd import capi, synth
+    from demiurge_amd import bands, capi, synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -172,20 +140,10 @@ def main():
     del b
 
     launches = [0]
+    exch = bands.HaloExchanger(dist, rank, world, device) if world > 1 else None
 
     def solve():
-        oc.zero_pressure()                       # OceanCurrents.cpp:495-497
-        if world == 1:
-            oc.jacobi_sweeps(sweeps)
-            launches[0] += sweeps
-        else:
-            done = 0
-            while done < sweeps:
-                n = min(ghost, sweeps - done)
-                exchange_halos(torch, dist, capi, oc, rank, world, ghost, device)
-                oc.jacobi_sweeps(n)
-                launches[0] += n
-                done += n
+        launches[0] += bands.jacobi_solve(oc, exch, sweeps, ghost, zero_first=True)   # OceanCurrents.cpp:495-508
 
     def fence():
         torch.cuda.synchronize(device)

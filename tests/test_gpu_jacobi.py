@@ -142,3 +142,35 @@ def test_errors(dev):
         o.jacobi(1)                                         # before set_terrain
     assert e.value.code == capi.ESTATE
     o.close()
+
+
+def test_halo_slabs_alias_as_torch_tensors(dev):
+    """the zero-copy path bench.py uses for RCCL: library-owned device slabs viewed as torch tensors"""
+    import torch
+    capi, ctx = dev
+    from demiurge_amd import bands, synth
+    W, H, G = 256, 128, 4
+    grid = capi.make_grid(W, H)
+    rng = np.random.default_rng(3)
+    p0 = rng.standard_normal((H, W)).astype(np.float32)
+    img = -np.ones((H, W), np.float32)
+    o = capi.Ocean(ctx, grid, band_rank=1, band_count=4, ghost=G)     # owns rows 32..63
+    o.set_terrain(img)
+    o.set_pressure(p0)
+    ctx.sync()
+
+    class _D:   # minimal stand-in for torch.distributed: only get_backend() is consulted here
+        @staticmethod
+        def get_backend():
+            return "nccl"
+    ex = bands.HaloExchanger(_D, 1, 4, torch.device("cuda", 0))
+    for side, send_rows, recv_rows in ((capi.SIDE_SOUTH, slice(32, 36), slice(28, 32)), (capi.SIDE_NORTH, slice(60, 64), slice(64, 68))):
+        s, r, nb = o.halo(capi.F_PRESSURE, side, G)
+        assert nb == G * W * 4
+        ts, tr = ex._tensor(s, nb), ex._tensor(r, nb)
+        assert ts.is_cuda and ts.data_ptr() == s
+        assert np.array_equal(ts.cpu().numpy().reshape(G, W), p0[send_rows])
+        assert np.array_equal(tr.cpu().numpy().reshape(G, W), p0[recv_rows])
+        tr.copy_(torch.full_like(tr, 7.0))                             # writes land in the library's buffer
+    torch.cuda.synchronize()
+    o.close()
