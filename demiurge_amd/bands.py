@@ -9,6 +9,10 @@ sweep, in 1/ghost as many messages (xGMI is latency-bound at 64 KiB).  Results a
 Transport: `torch.distributed` P2P -- backend "nccl" (= RCCL over xGMI) sends straight from / into the library's
 device slabs (zero copy); with backend "gloo" (CPU tests, or several ranks sharing one GPU) slabs are staged
 through host tensors.
+
+Stream contract: create the dmg context on the stream torch issues its copies / collectives on
+(`capi.Context(dev, stream=torch.cuda.current_stream().cuda_stream)`), so kernels, halo sends and halo receives
+are ordered by the stream itself and no host synchronisation is needed between sweep blocks.
 """
 import numpy as np
 

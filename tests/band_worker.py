@@ -69,7 +69,9 @@ def worker(rank, world, port, mode, W, H, sweeps, ghost, outdir):
     else:
         import torch
         from demiurge_amd import capi
-        ctx = capi.Context(0)
+        torch.cuda.set_device(0)
+        # the library must run on the stream torch orders its copies / collectives on (as bench.py does)
+        ctx = capi.Context(0, stream=torch.cuda.current_stream().cuda_stream)
         oc = capi.Ocean(ctx, capi.make_grid(W, H), band_rank=rank, band_count=world, ghost=ghost)
         oc.set_terrain(img)
         oc.set_divw(divw)
