@@ -17,6 +17,7 @@ OK, EINVAL, ENOMEM, EHIP, ENODEVICE, ESTATE = 0, -1, -2, -3, -4, -5
 F_PRESSURE, F_DIVW, F_TERRAIN, F_VX, F_VY = range(5)
 SIDE_SOUTH, SIDE_NORTH = 0, 1
 QUIRK_DIFFUSION_SCALAR_RHS = 1
+PRIVATE_STREAM = 1
 FULL_GLOBE = (np.float32(-np.pi / 2), np.float32(np.pi / 2), np.float32(-np.pi), np.float32(np.pi))  # Project.h:97
 
 
@@ -63,7 +64,7 @@ def lib():
     sig = {
         "dmg_version": (c_int, []),
         "dmg_last_error": (ctypes.c_char_p, []),
-        "dmg_create": (c_int, [c_int, vp, ctypes.POINTER(vp)]),
+        "dmg_create": (c_int, [c_int, vp, c_int, ctypes.POINTER(vp)]),
         "dmg_destroy": (None, [vp]),
         "dmg_sync": (c_int, [vp]),
         "dmg_device_name": (c_int, [vp, ctypes.c_char_p, sz]),
@@ -115,11 +116,15 @@ def _p(a):
 
 
 class Context:
-    """dmg_ctx: one per GPU/process."""
+    """dmg_ctx: one per GPU/process.  stream=None: a private non-blocking stream; stream=<int hipStream_t>
+    (0 = the default stream, e.g. torch.cuda.current_stream().cuda_stream): run on the host program's stream."""
 
     def __init__(self, device=0, stream=None):
         h = ctypes.c_void_p()
-        check(lib().dmg_create(int(device), stream, ctypes.byref(h)))
+        if stream is None:
+            check(lib().dmg_create(int(device), None, PRIVATE_STREAM, ctypes.byref(h)))
+        else:
+            check(lib().dmg_create(int(device), ctypes.c_void_p(int(stream)), 0, ctypes.byref(h)))
         self.h = h
         self._children = weakref.WeakSet()     # handles that must be destroyed before the context
 

@@ -33,7 +33,7 @@ extern "C" {
 int dmg_version(void) { return DMG_VERSION; }
 const char *dmg_last_error(void) { return g_last_error.c_str(); }
 
-int dmg_create(int device_id, void *stream, dmg_ctx **out)
+int dmg_create(int device_id, void *stream, int flags, dmg_ctx **out)
 {
     DMG_CHECK_ARG(out != nullptr);
     *out = nullptr;
@@ -53,8 +53,8 @@ int dmg_create(int device_id, void *stream, dmg_ctx **out)
     c->num_cu = prop.multiProcessorCount;
     snprintf(c->name, sizeof c->name, "%s (%s, %d CUs)", prop.name[0] ? prop.name : "AMD Instinct", prop.gcnArchName,
              prop.multiProcessorCount);
-    if (stream) {
-        c->stream = (hipStream_t)stream;
+    if (!(flags & DMG_PRIVATE_STREAM)) {
+        c->stream = (hipStream_t)stream;       // may be NULL: the default stream
     } else {
         hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
         if (e != hipSuccess) { delete c; return dmg_fail(DMG_EHIP, "hipStreamCreate: %s", hipGetErrorString(e)); }

@@ -83,18 +83,20 @@ enum { DMG_SIDE_SOUTH = 0, DMG_SIDE_NORTH = 1 };   /* south = towards row 0 */
 int dmg_version(void);
 const char *dmg_last_error(void);
 
-/* Binds HIP device `device_id`.  `stream` may be an existing hipStream_t (e.g. the host
- * framework's current stream) or NULL to create a private non-blocking stream. */
-int dmg_create(int device_id, void *stream, dmg_ctx **out);
+/* Binds HIP device `device_id`.  Work is enqueued on `stream`: an existing hipStream_t of the host program
+ * (NULL = the device's default stream, which is what e.g. torch.cuda.current_stream() is unless changed), or,
+ * with DMG_PRIVATE_STREAM in `flags`, a new non-blocking stream owned by the context (`stream` ignored). */
+#define DMG_PRIVATE_STREAM 1
+int dmg_create(int device_id, void *stream, int flags, dmg_ctx **out);
 void dmg_destroy(dmg_ctx *ctx);
 int dmg_sync(dmg_ctx *ctx);                                   /* hipStreamSynchronize */
 int dmg_device_name(dmg_ctx *ctx, char *buf, size_t len);
 
-/* hipEvent timing on the context's stream (the stream the kernels run on). */
 /* hipMemcpyAsync(device -> device) on the context's stream: the single-process halo transport used when
  * several bands live on one GPU (tests, SURVEY.md section 4 "fake cluster"); multi-GPU runs use RCCL. */
 int dmg_copy_device(dmg_ctx *ctx, void *dst, const void *src, size_t bytes);
 
+/* hipEvent timing on the context's stream (the stream the kernels run on). */
 int dmg_timer_start(dmg_ctx *ctx);
 int dmg_timer_stop(dmg_ctx *ctx, float *elapsed_ms);          /* records, synchronises, returns ms since start */
 
