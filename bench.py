@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--width", type=int, default=16384)
     ap.add_argument("--height", type=int, default=8192)
     ap.add_argument("--sweeps", type=int, default=5000, help="Jacobi sweeps per solve (reference: 5000)")
-    ap.add_argument("--ghost", type=int, default=8, help="ghost rows per band side = sweeps between halo exchanges")
+    ap.add_argument("--ghost", type=int, default=16, help="ghost rows per band side = sweeps between halo exchanges")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
