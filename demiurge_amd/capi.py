@@ -18,6 +18,7 @@ F_PRESSURE, F_DIVW, F_TERRAIN, F_VX, F_VY = range(5)
 SIDE_SOUTH, SIDE_NORTH = 0, 1
 QUIRK_DIFFUSION_SCALAR_RHS = 1
 PRIVATE_STREAM = 1
+JACOBI_AUTO, JACOBI_SINGLE, JACOBI_BLOCKED = 0, 1, 2
 FULL_GLOBE = (np.float32(-np.pi / 2), np.float32(np.pi / 2), np.float32(-np.pi), np.float32(np.pi))  # Project.h:97
 
 
@@ -35,7 +36,7 @@ class Grid(ctypes.Structure):
 class OceanParams(ctypes.Structure):
     _fields_ = [("pressurefactor", ctypes.c_float), ("jacobi_iters", ctypes.c_int),
                 ("diffusion_iters", ctypes.c_int), ("timestep_h", ctypes.c_float), ("scale", ctypes.c_float),
-                ("wind", ctypes.c_float), ("quirks", ctypes.c_int)]
+                ("wind", ctypes.c_float), ("quirks", ctypes.c_int), ("jacobi_kernel", ctypes.c_int)]
 
 
 def make_grid(W, H, coords=FULL_GLOBE, circumference=42000.0):

@@ -224,6 +224,7 @@ void dmg_ocean_params_default(dmg_ocean_params *p)
     p->scale = 420.0f;            // :419,:478,:574,:689
     p->wind = 10.0f;              // :342
     p->quirks = DMG_QUIRK_DIFFUSION_SCALAR_RHS;   // :687,:693
+    p->jacobi_kernel = DMG_JACOBI_AUTO;
 }
 
 int dmg_ocean_create(dmg_ctx *ctx, const dmg_grid *grid, const dmg_ocean_params *params, int band_rank,
@@ -332,8 +333,23 @@ int dmg_ocean_jacobi_sweeps(dmg_ocean *o, int n)
     if (o->count > 1 && n > o->ghost)
         return dmg_fail(DMG_EINVAL, "%d sweeps between halo refreshes but only %d ghost rows", n, o->ghost);
     DMG_HIP(hipSetDevice(o->ctx->device));
+    bool blocked = o->prm.jacobi_kernel != DMG_JACOBI_SINGLE && ocean_tb_supported(o);
+    if (o->prm.jacobi_kernel == DMG_JACOBI_BLOCKED && !blocked)
+        return dmg_fail(DMG_EINVAL, "DMG_JACOBI_BLOCKED needs a full-longitude grid with W %% 8 == 0 and W >= 256");
+    // after k sweeps since the last halo refresh the rows still computable lie k rows inside the ghost slabs:
+    // the region shrinks by one row per sweep on every side that has a neighbour band
+    if (blocked) {
+        for (int k = 0; k < n;) {
+            int m = n - k < 8 ? n - k : 8;
+            k += m;
+            int lo = o->gs ? k : 0, hi = o->L - (o->gn ? k : 0);
+            int rc = ocean_launch_tb(o, lo, hi, m);
+            if (rc) return rc;
+            o->cur ^= 1;
+        }
+        return DMG_OK;
+    }
     for (int k = 1; k <= n; k++) {
-        // sweep k can still be computed k rows inside the ghost slab: the region shrinks by one row per sweep
         int lo = o->gs ? k : 0, hi = o->L - (o->gn ? k : 0);
         int rc = launch_sweep(o, lo, hi);
         if (rc) return rc;

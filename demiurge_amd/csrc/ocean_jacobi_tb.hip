@@ -104,6 +104,7 @@ __global__ __launch_bounds__(512) void k_jacobi_tb8(tb_args a)
         rcx[r] = a.cx[l]; rcy[r] = a.cy[l]; rbeta[r] = a.beta[l];
         if (__builtin_amdgcn_ballot_w64((c & 0x1F1F1F1Fu) != 0)) slow_rows |= (1u << r);
     }
+    slow_rows = __builtin_amdgcn_readfirstlane(slow_rows);
 
     for (int s = 0; s < a.nsweeps; s++) {
         // publish this wave's bottom and top rows (values before the sweep), fetch the neighbours' rows

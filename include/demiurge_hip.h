@@ -70,7 +70,10 @@ typedef struct {
     float scale;                   /* 420   :419,:478,:574,:689 */
     float wind;                    /* 10    :342 */
     int quirks;                    /* DMG_QUIRK_* bit set; default = reference behaviour */
+    int jacobi_kernel;             /* DMG_JACOBI_AUTO (default) | _SINGLE (one sweep per launch) | _BLOCKED (8 sweeps
+                                      per launch, temporally blocked on chip); results are bit-identical */
 } dmg_ocean_params;
+enum { DMG_JACOBI_AUTO = 0, DMG_JACOBI_SINGLE = 1, DMG_JACOBI_BLOCKED = 2 };
 
 /* the reference's `float bC = texture(v,st).r` adds v.x to BOTH components in velocity diffusion (:687,:693) */
 #define DMG_QUIRK_DIFFUSION_SCALAR_RHS 1

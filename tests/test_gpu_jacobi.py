@@ -18,10 +18,12 @@ def dev():
     ctx.close()
 
 
-def run_jacobi(capi, ctx, grid, img, divw, iters, p0=None, bands=1, ghost=1, block=1):
+def run_jacobi(capi, ctx, grid, img, divw, iters, p0=None, bands=1, ghost=1, block=1, kernel=0):
     """Single GPU.  bands > 1 emulates the latitude-band split on one device: one dmg_ocean per band, halo
     slabs moved with dmg_copy_device between sweep blocks of `block` (<= ghost) sweeps."""
-    oc = [capi.Ocean(ctx, grid, band_rank=r, band_count=bands, ghost=ghost) for r in range(bands)]
+    prm = capi.default_ocean_params()
+    prm.jacobi_kernel = kernel
+    oc = [capi.Ocean(ctx, grid, params=prm, band_rank=r, band_count=bands, ghost=ghost) for r in range(bands)]
     for o in oc:
         o.set_terrain(img)
         o.set_divw(divw)
@@ -174,3 +176,52 @@ def test_halo_slabs_alias_as_torch_tensors(dev):
         tr.copy_(torch.full_like(tr, 7.0))                             # writes land in the library's buffer
     torch.cuda.synchronize()
     o.close()
+
+
+# ---- temporally blocked kernel (8 sweeps per launch) == single-sweep kernel, bit for bit -----------------------
+@pytest.mark.parametrize("W,H,iters", [(256, 128, 8), (256, 128, 37), (512, 64, 5), (1000, 500, 19), (264, 16, 24), (2048, 1024, 100)])
+def test_blocked_equals_single(dev, oracle, W, H, iters):
+    capi, ctx = dev
+    from demiurge_amd import synth
+    grid = capi.make_grid(W, H)
+    img, b = synth.terrain(W, H), synth.divw(W, H)
+    rng = np.random.default_rng(11)
+    p0 = rng.standard_normal((H, W)).astype(np.float32)
+    single = run_jacobi(capi, ctx, grid, img, b, iters, p0=p0, block=iters, kernel=capi.JACOBI_SINGLE)
+    blocked = run_jacobi(capi, ctx, grid, img, b, iters, p0=p0, block=iters, kernel=capi.JACOBI_BLOCKED)
+    assert np.array_equal(single, blocked)
+    assert np.array_equal(blocked, oracle.ocean_jacobi(ogrid(oracle, grid), img, b, iters, p0=p0, rows=True))
+
+
+def test_blocked_belt_no_poles(dev, oracle):
+    capi, ctx = dev
+    G = load_golden("jacobi_128x64_belt")
+    from demiurge_amd import synth
+    W, H = 512, 96
+    grid = capi.make_grid(W, H, tuple(G["coords"]), float(G["circ"]))
+    img, b = synth.terrain(W, H), synth.divw(W, H)
+    got = run_jacobi(capi, ctx, grid, img, b, 21, block=21, kernel=capi.JACOBI_BLOCKED)
+    assert np.array_equal(got, oracle.ocean_jacobi(ogrid(oracle, grid), img, b, 21, rows=True))
+
+
+@pytest.mark.parametrize("bands,ghost,block", [(2, 8, 8), (4, 16, 16), (3, 16, 11)])
+def test_blocked_band_split_is_bitwise(dev, bands, ghost, block):
+    capi, ctx = dev
+    from demiurge_amd import synth
+    W, H = 512, 384
+    grid = capi.make_grid(W, H)
+    img, b = synth.terrain(W, H), synth.divw(W, H)
+    one = run_jacobi(capi, ctx, grid, img, b, 45, block=45, kernel=capi.JACOBI_SINGLE)
+    split = run_jacobi(capi, ctx, grid, img, b, 45, bands=bands, ghost=ghost, block=block, kernel=capi.JACOBI_BLOCKED)
+    assert np.array_equal(one, split)
+
+
+def test_blocked_full_size_bitwise(dev, oracle):
+    capi, ctx = dev
+    from demiurge_amd import synth
+    W, H = 16384, 8192
+    grid = capi.make_grid(W, H)
+    img, b = synth.terrain(W, H), synth.divw(W, H)
+    blocked = run_jacobi(capi, ctx, grid, img, b, 12, block=12, kernel=capi.JACOBI_BLOCKED)
+    ref = oracle.ocean_jacobi(ogrid(oracle, grid), img, b, 12, rows=True)
+    assert np.array_equal(blocked, ref)
