@@ -83,6 +83,7 @@ def lib():
         "dmg_ocean_jacobi": (c_int, [vp, c_int, c_int]),
         "dmg_ocean_jacobi_sweeps": (c_int, [vp, c_int]),
         "dmg_ocean_zero_pressure": (c_int, [vp]),
+        "dmg_ocean_counters": (c_int, [vp, ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_longlong)]),
         "dmg_ocean_halo": (c_int, [vp, c_int, c_int, c_int, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(sz)]),
         "dmg_ocean_step": (c_int, [vp, c_int]),
         "dmg_ocean_advect": (c_int, [vp]),
@@ -242,6 +243,12 @@ class Ocean:
 
     def jacobi_sweeps(self, n):
         check(lib().dmg_ocean_jacobi_sweeps(self.h, int(n)))
+
+    def counters(self):
+        """-> (jacobi kernel launches, jacobi sweeps) since creation"""
+        a, b = ctypes.c_longlong(), ctypes.c_longlong()
+        check(lib().dmg_ocean_counters(self.h, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
 
     def halo(self, field, side, rows):
         """-> (send_ptr, recv_ptr, nbytes) device addresses (ints); nbytes == 0 at a grid edge."""

@@ -346,6 +346,7 @@ int dmg_ocean_jacobi_sweeps(dmg_ocean *o, int n)
             int rc = ocean_launch_tb(o, lo, hi, m);
             if (rc) return rc;
             o->cur ^= 1;
+            o->n_launches++; o->n_sweeps += m;
         }
         return DMG_OK;
     }
@@ -353,7 +354,16 @@ int dmg_ocean_jacobi_sweeps(dmg_ocean *o, int n)
         int lo = o->gs ? k : 0, hi = o->L - (o->gn ? k : 0);
         int rc = launch_sweep(o, lo, hi);
         if (rc) return rc;
+        o->n_launches++; o->n_sweeps++;
     }
+    return DMG_OK;
+}
+
+int dmg_ocean_counters(dmg_ocean *o, long long *jacobi_launches, long long *jacobi_sweeps)
+{
+    DMG_CHECK_ARG(o != nullptr);
+    if (jacobi_launches) *jacobi_launches = o->n_launches;
+    if (jacobi_sweeps) *jacobi_sweeps = o->n_sweeps;
     return DMG_OK;
 }
 

@@ -35,6 +35,7 @@ struct dmg_ocean {
     float *rowtab = nullptr;       // ROWTAB_FIELDS arrays of L floats
     const float *jac_cx = nullptr, *jac_cy = nullptr, *jac_beta = nullptr;
     bool have_terrain = false;
+    long long n_launches = 0, n_sweeps = 0;   // Jacobi statistics
     const float *rt(int field) const { return rowtab + (size_t)field * L; }
 };
 

@@ -134,6 +134,9 @@ int dmg_ocean_jacobi(dmg_ocean *o, int iters, int zero_first);
  * rows are n sweeps ahead and the ghost rows are stale until the host refreshes them via dmg_ocean_halo. */
 int dmg_ocean_jacobi_sweeps(dmg_ocean *o, int n);
 int dmg_ocean_zero_pressure(dmg_ocean *o);
+/* cumulative counters since creation: Jacobi kernel launches and sweeps performed (a temporally blocked launch
+ * advances up to 8 sweeps) -- what bench.py divides its HIP-event time by */
+int dmg_ocean_counters(dmg_ocean *o, long long *jacobi_launches, long long *jacobi_sweeps);
 
 /* One exchange slab of a field: `send` = this band's `rows` rows next to `side`, `recv` = the ghost rows
  * beyond that side; both contiguous device memory of `bytes` bytes.  bytes == 0 when the side is a grid edge. */
