@@ -65,16 +65,17 @@ __global__ void k_zero_land(float *__restrict__ p, const unsigned char *__restri
 // ------------------------------------------------------------------------------------------------
 // Jacobi sweep, one launch per sweep (general form: any W, any topology, bands)
 // ------------------------------------------------------------------------------------------------
-// Arithmetic contract (bit-exact with oracle/dmg_oracle.c orc_ocean_jacobi_rows and the literal GLSL
-// statement order, OceanCurrents.cpp:480):   fc = ((pW + pE)/pw2.x + (pS + pN)/pw2.y - bC) / Beta
+// Arithmetic contract (shared with ocean_jacobi_tb.hip and bit-exact with oracle/dmg_oracle.c
+// orc_ocean_jacobi_rows): the GLSL statement  fc = ((pW + pE)/pw2.x + (pS + pN)/pw2.y - bC) / Beta
+// (OceanCurrents.cpp:480) in its own order, each division by a row constant evaluated by dmg_div_rc().
 __device__ __forceinline__ float jacobi_cell(float pC, float pN, float pS, float pE, float pW, float b, unsigned c,
-                                             float cx, float cy, float beta)
+                                             const jacobi_row &k)
 {
     if (c & 1u) pN = pC;
     if (c & 2u) pS = pC;
     if (c & 4u) pE = pC;
     if (c & 8u) pW = pC;
-    float r = __fdiv_rn(__fsub_rn(__fadd_rn(__fdiv_rn(__fadd_rn(pW, pE), cx), __fdiv_rn(__fadd_rn(pS, pN), cy)), b), beta);
+    float r = jacobi_value(pN, pS, pE, pW, b, k);
     return (c & 16u) ? 0.0f : r;
 }
 
@@ -83,7 +84,7 @@ struct sweep_args {
     float *pout;
     const float *b;
     const unsigned char *code;
-    const float *cx, *cy, *beta;    // per local row
+    const float *cx, *cy, *beta, *rx, *ry, *rb;    // per local row: divisors and their reciprocals
     int W, L;
     int row_lo, row_hi;             // local rows computed by this sweep
     int l_south_pole, l_north_pole; // local row index of grid row 0 / H-1 when that edge is a pole here, else -1
@@ -114,12 +115,12 @@ __global__ __launch_bounds__(256) void k_jacobi_sweep_v4(sweep_args a)
     float pW = rowC[xw], pE = rowC[xe];
     float4 b = *reinterpret_cast<const float4 *>(a.b + (size_t)l * W + x);
     uchar4 c = *reinterpret_cast<const uchar4 *>(a.code + (size_t)l * W + x);
-    float cx = a.cx[l], cy = a.cy[l], beta = a.beta[l];
+    jacobi_row k = { a.cx[l], a.cy[l], a.beta[l], a.rx[l], a.ry[l], a.rb[l] };
     float4 o;
-    o.x = jacobi_cell(pC.x, pN.x, pS.x, pC.y, pW, b.x, c.x, cx, cy, beta);
-    o.y = jacobi_cell(pC.y, pN.y, pS.y, pC.z, pC.x, b.y, c.y, cx, cy, beta);
-    o.z = jacobi_cell(pC.z, pN.z, pS.z, pC.w, pC.y, b.z, c.z, cx, cy, beta);
-    o.w = jacobi_cell(pC.w, pN.w, pS.w, pE, pC.z, b.w, c.w, cx, cy, beta);
+    o.x = jacobi_cell(pC.x, pN.x, pS.x, pC.y, pW, b.x, c.x, k);
+    o.y = jacobi_cell(pC.y, pN.y, pS.y, pC.z, pC.x, b.y, c.y, k);
+    o.z = jacobi_cell(pC.z, pN.z, pS.z, pC.w, pC.y, b.z, c.z, k);
+    o.w = jacobi_cell(pC.w, pN.w, pS.w, pE, pC.z, b.w, c.w, k);
     *reinterpret_cast<float4 *>(a.pout + (size_t)l * W + x) = o;
 }
 
@@ -141,8 +142,8 @@ __global__ __launch_bounds__(256) void k_jacobi_sweep_s(sweep_args a)
     if (xw < 0) xw = a.lonwrap ? W - 1 : 0;
     if (xe >= W) xe = a.lonwrap ? 0 : W - 1;
     size_t i = (size_t)l * W + x;
-    a.pout[i] = jacobi_cell(rowC[x], rowN[xn], rowS[xs], rowC[xe], rowC[xw], a.b[i], a.code[i],
-                            a.cx[l], a.cy[l], a.beta[l]);
+    jacobi_row k = { a.cx[l], a.cy[l], a.beta[l], a.rx[l], a.ry[l], a.rb[l] };
+    a.pout[i] = jacobi_cell(rowC[x], rowN[xn], rowS[xs], rowC[xe], rowC[xw], a.b[i], a.code[i], k);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -157,6 +158,7 @@ static int launch_sweep(dmg_ocean *o, int row_lo, int row_hi)
     a.b = o->divw;
     a.code = o->code;
     a.cx = o->jac_cx; a.cy = o->jac_cy; a.beta = o->jac_beta;
+    a.rx = o->jac_rx; a.ry = o->jac_ry; a.rb = o->jac_rb;
     a.W = o->grid.W; a.L = o->L;
     a.row_lo = row_lo; a.row_hi = row_hi;
     a.l_south_pole = (o->topo.spole && o->y0 == 0) ? o->gs : -1;

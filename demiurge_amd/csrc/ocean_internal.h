@@ -13,6 +13,9 @@ enum {
     RT_DIFPY,
     RT_DIFBETA,     // 2*(px+py)*(1+1/(2*(px+py)))                            :690
     RT_LAT,         // tex_to_spheric(st).y
+    RT_JRX,         // RN(1/pw2.x), RN(1/pw2.y), RN(1/Beta): reciprocals for the FMA-corrected division
+    RT_JRY,
+    RT_JRB,
     ROWTAB_FIELDS
 };
 
@@ -34,6 +37,7 @@ struct dmg_ocean {
     int vcur = 0;
     float *rowtab = nullptr;       // ROWTAB_FIELDS arrays of L floats
     const float *jac_cx = nullptr, *jac_cy = nullptr, *jac_beta = nullptr;
+    const float *jac_rx = nullptr, *jac_ry = nullptr, *jac_rb = nullptr;
     bool have_terrain = false;
     long long n_launches = 0, n_sweeps = 0;   // Jacobi statistics
     const float *rt(int field) const { return rowtab + (size_t)field * L; }
@@ -46,3 +50,19 @@ int ocean_launch_tb(dmg_ocean *o, int lo, int hi, int n);   // ocean_jacobi_tb.h
 bool ocean_tb_supported(const dmg_ocean *o);
 int ocean_upload_rows(dmg_ocean *o, float *dst, const float *src_full, int comps);
 int ocean_download_rows(dmg_ocean *o, float *dst_full, const float *src, int comps);
+
+// ---- Jacobi cell arithmetic shared by the single-sweep and the temporally blocked kernels ----
+struct jacobi_row { float cx, cy, beta, rx, ry, rb; };     // pw2.x, pw2.y, Beta and their correctly rounded reciprocals
+
+// x / c for a row constant c with r = RN(1/c):  q = x*r ; q' = fma(fma(-c, q, x), r, q)   (Markstein correction).
+// Equals the IEEE quotient unless the remainder underflows (|x| < 2^-100 here); see oracle/dmg_oracle.c div_rc().
+__device__ __forceinline__ float dmg_div_rc(float x, float c, float r)
+{
+    float q = __fmul_rn(x, r);
+    return __fmaf_rn(__fmaf_rn(-c, q, x), r, q);
+}
+__device__ __forceinline__ float jacobi_value(float pN, float pS, float pE, float pW, float b, const jacobi_row &k)
+{
+    float t = __fadd_rn(dmg_div_rc(__fadd_rn(pW, pE), k.cx, k.rx), dmg_div_rc(__fadd_rn(pS, pN), k.cy, k.ry));
+    return dmg_div_rc(__fsub_rn(t, b), k.beta, k.rb);
+}

@@ -16,7 +16,11 @@ int ocean_upload_row_tables(dmg_ocean *o)
         float cx = wx * wx, cy = wy * wy;                       // pow(.,vec2(2,2))
         t[(size_t)RT_JCX * L + l] = cx;
         t[(size_t)RT_JCY * L + l] = cy;
-        t[(size_t)RT_JBETA * L + l] = 2.0f * (1.0f / cx + 1.0f / cy);
+        float beta = 2.0f * (1.0f / cx + 1.0f / cy);
+        t[(size_t)RT_JBETA * L + l] = beta;
+        t[(size_t)RT_JRX * L + l] = 1.0f / cx;               // IEEE division on the host: correctly rounded
+        t[(size_t)RT_JRY * L + l] = 1.0f / cy;
+        t[(size_t)RT_JRB * L + l] = 1.0f / beta;
         t[(size_t)RT_DX * L + l] = dx;
         t[(size_t)RT_DY * L + l] = dy;
         float px = 1.0f / (dx * dx) * scale * scale;            // 1*1/pow(pixelsize,2)*420*420
@@ -32,5 +36,8 @@ int ocean_upload_row_tables(dmg_ocean *o)
     o->jac_cx = o->rt(RT_JCX);
     o->jac_cy = o->rt(RT_JCY);
     o->jac_beta = o->rt(RT_JBETA);
+    o->jac_rx = o->rt(RT_JRX);
+    o->jac_ry = o->rt(RT_JRY);
+    o->jac_rb = o->rt(RT_JRB);
     return DMG_OK;
 }

