@@ -52,7 +52,10 @@ _lib = None
 
 
 def lib():
-    """Loads the library (raises if it was not built: run __graft_entry__.build())."""
+    """Loads the library (raises if it was not built: run __graft_entry__.build()).
+
+    In a process that also uses torch, import torch FIRST: torch ships its own libamdhip64 and the two must
+    resolve to one HIP runtime (device pointers are shared with torch for the RCCL halo exchange)."""
     global _lib
     if _lib is not None:
         return _lib

@@ -5,6 +5,13 @@ from pathlib import Path
 import numpy as np
 import pytest
 
+# torch bundles its own libamdhip64; it must be loaded BEFORE libdemiurge_hip.so so that both resolve to ONE HIP
+# runtime in this process (loading /opt/rocm's first leaves torch unable to see the GPU: "No HIP GPUs are available")
+try:
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    torch = None
+
 ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "oracle"))
