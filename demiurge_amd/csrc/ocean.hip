@@ -341,8 +341,9 @@ int dmg_ocean_jacobi_sweeps(dmg_ocean *o, int n)
     // after k sweeps since the last halo refresh the rows still computable lie k rows inside the ghost slabs:
     // the region shrinks by one row per sweep on every side that has a neighbour band
     if (blocked) {
+        static const int cap = [] { const char *e = getenv("DMG_TB_SWEEPS"); int v = e ? atoi(e) : 8; return v >= 1 && v <= 8 ? v : 8; }();
         for (int k = 0; k < n;) {
-            int m = n - k < 8 ? n - k : 8;
+            int m = n - k < cap ? n - k : cap;   // DMG_TB_SWEEPS (1..8): sweeps per launch, for phase-cost experiments
             k += m;
             int lo = o->gs ? k : 0, hi = o->L - (o->gn ? k : 0);
             int rc = ocean_launch_tb(o, lo, hi, m);
