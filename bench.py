@@ -182,6 +182,13 @@ def main():
         algo_bytes = ALGO_BYTES_PER_CELL_STEP * band_cells * sweeps_per_launch
         achieved = algo_bytes / launch_s / 1e9
         kname = "k_jacobi_tb8" if sweeps_per_launch > 1 else "k_jacobi_sweep_v4"
+        traffic = None                     # measured separately with rocprofv3 --pmc (profiles/README.md)
+        try:
+            t = json.load(open(ROOT / "profiles" / "pmc_traffic.json")).get(kname)
+            if t and world == 1 and (t["W"], t["H"]) == (W, H) and sweeps_per_launch in (1.0, 8.0):
+                traffic = t["hbm_bytes_per_launch"]
+        except Exception:
+            pass
         out = {
             "metric": "Mcell-steps/s, ocean Jacobi stencil @%dx%d fp32" % (W, H),
             "value": value, "unit": "Mcell-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -193,7 +200,7 @@ def main():
                                       % (world, ghost, ghost),
                        "device": ctx.name()},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": kname, "launch_us": launch_s * 1e6, "sweeps_per_launch": sweeps_per_launch,
                          "algorithmic_bytes_per_launch": algo_bytes},
         }
