@@ -34,6 +34,7 @@ struct tb_args {
     int y_first, H;                 // grid row of local row 0; grid height
     int spole, npole;
     int nsweeps;                    // 1..TB_T
+    int tiles_x, tiles_y;
 };
 
 __device__ __forceinline__ float dpp_from_prev_lane(float v)   // lane i <- lane i-1
@@ -44,20 +45,24 @@ __device__ __forceinline__ float dpp_from_next_lane(float v)   // lane i <- lane
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
 }
-__device__ __forceinline__ float lane_value(float v, int lane_const)
+// branch-free land handling for rows that contain coast: a neighbour flagged in the code is replaced by the centre
+// value, a land centre yields 0 (OceanCurrents.cpp:470-473,481).  Bit k of the code byte -> all-ones mask via
+// v_bfe_i32, select via v_bfi_b32: no VCC/SGPR lane masks.
+__device__ __forceinline__ float sel_bits(unsigned code, int bit, float if_set, float if_clear)
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane_const));
+    int m = __builtin_amdgcn_sbfe((int)code, bit, 1);          // 0 or -1
+    int a = __builtin_bit_cast(int, if_set), b = __builtin_bit_cast(int, if_clear);
+    return __builtin_bit_cast(float, (m & a) | (~m & b));
 }
-
-__device__ __forceinline__ float tb_cell(float pC, float pN, float pS, float pE, float pW, float b, unsigned c,
-                                         const jacobi_row &k)
+__device__ __forceinline__ float tb_cell(float pC, float pN, float pS, float pE, float pW, float b, unsigned code,
+                                         int shift, const jacobi_row &k)
 {
-    if (c & 1u) pN = pC;
-    if (c & 2u) pS = pC;
-    if (c & 4u) pE = pC;
-    if (c & 8u) pW = pC;
+    pN = sel_bits(code, shift + 0, pC, pN);
+    pS = sel_bits(code, shift + 1, pC, pS);
+    pE = sel_bits(code, shift + 2, pC, pE);
+    pW = sel_bits(code, shift + 3, pC, pW);
     float r = jacobi_value(pN, pS, pE, pW, b, k);
-    return (c & 16u) ? 0.0f : r;
+    return sel_bits(code, shift + 4, 0.0f, r);
 }
 
 // maps an extended-tile row to its source: local row l, whether it is a mirrored copy, whether it is pole-shifted
@@ -74,18 +79,33 @@ __device__ __forceinline__ tb_row tb_map_row(const tb_args &a, int local_unclamp
     return m;
 }
 
+// second launch-bound argument = waves per SIMD the register allocator must leave room for (R = 8: 128 VGPRs,
+// i.e. two 8-wave workgroups per CU, so one workgroup's load phase overlaps the other's sweeps)
 template <int R, int NW>
-__global__ __launch_bounds__(NW * 64) void k_jacobi_tb8(tb_args a)
+__global__ __launch_bounds__(NW * 64, (R <= 8 ? 4 : (R <= 12 ? 3 : 2))) void k_jacobi_tb8(tb_args a)
 {
     constexpr int EH = R * NW;                      // extended tile rows
     constexpr int OH = EH - 2 * TB_T;               // output rows per tile
     __shared__ float4 halo[2][NW][2][64];           // [sweep parity][wave][0 = row r=0, 1 = row r=R-1][lane]
+    __shared__ float4 coef[EH][2];                  // per extended row: {cx, cy, beta, rx}, {ry, rb, -, -}
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int W = a.W;
-    const int X0 = blockIdx.x * TB_OW;              // first output column of the tile
-    const int Y0 = a.out_lo + blockIdx.y * OH;      // first output local row of the tile
+
+    // tile id -> (tile column, tile row).  Workgroups are dealt round-robin over the 8 XCDs (id % 8); give each XCD a
+    // contiguous run of tiles in column-major order so that vertically adjacent tiles, which share 16 of their rows,
+    // run on the same XCD back to back and find the shared rows in that XCD's L2.  Placement only affects speed.
+    int tx, ty;
+    {
+        const int ntiles = a.tiles_x * a.tiles_y;
+        int id = blockIdx.x;
+        int per = ntiles >> 3;                      // tiles per XCD (the remainder keeps its natural order)
+        int t = (id < per * 8) ? (id & 7) * per + (id >> 3) : id;
+        tx = t / a.tiles_y; ty = t - tx * a.tiles_y;
+    }
+    const int X0 = tx * TB_OW;                      // first output column of the tile
+    const int Y0 = a.out_lo + ty * OH;              // first output local row of the tile
     const int e0 = Y0 - TB_T + wave * R;            // unclamped local row of this wave's register row 0
 
     // this lane's 4 columns (wrapped), plain and pole-shifted
@@ -93,17 +113,15 @@ __global__ __launch_bounds__(NW * 64) void k_jacobi_tb8(tb_args a)
     col %= W; if (col < 0) col += W;
     int colp = col + W / 2; if (colp >= W) colp -= W;
 
-    // per-row coefficients: lane r (< R) of these registers holds row r's value
-    float tcx, tcy, tbe, trx, try_, trb;
-    {
-        tb_row m = tb_map_row(a, e0 + min(lane, R - 1));
-        tcx = a.cx[m.l]; tcy = a.cy[m.l]; tbe = a.beta[m.l];
-        trx = a.rx[m.l]; try_ = a.ry[m.l]; trb = a.rb[m.l];
+    if (threadIdx.x < EH) {                         // one thread per extended row fills the coefficient table
+        tb_row m = tb_map_row(a, Y0 - TB_T + (int)threadIdx.x);
+        coef[threadIdx.x][0] = make_float4(a.cx[m.l], a.cy[m.l], a.beta[m.l], a.rx[m.l]);
+        coef[threadIdx.x][1] = make_float4(a.ry[m.l], a.rb[m.l], 0.0f, 0.0f);
     }
 
     float4 p[R], b[R];
     unsigned code[R];
-    unsigned slow_rows = 0;                         // bit r: some lane of this wave has land/coast in row r
+    unsigned mixed_rows = 0, land_rows = 0;         // bit r: row r of this wave has coast / is entirely land
 #pragma unroll
     for (int r = 0; r < R; r++) {
         tb_row m = tb_map_row(a, e0 + r);
@@ -113,9 +131,12 @@ __global__ __launch_bounds__(NW * 64) void k_jacobi_tb8(tb_args a)
         unsigned c = *reinterpret_cast<const unsigned *>(a.code + off);
         if (m.flip) c = (c & 0xFCFCFCFCu) | ((c & 0x01010101u) << 1) | ((c & 0x02020202u) >> 1);   // swap N/S bits
         code[r] = c;
-        if (__builtin_amdgcn_ballot_w64((c & 0x1F1F1F1Fu) != 0)) slow_rows |= (1u << r);
+        if (__builtin_amdgcn_ballot_w64((c & 0x1F1F1F1Fu) != 0)) mixed_rows |= (1u << r);
+        if (__builtin_amdgcn_ballot_w64((c & 0x10101010u) != 0x10101010u) == 0) land_rows |= (1u << r);
     }
-    slow_rows = __builtin_amdgcn_readfirstlane(slow_rows);
+    mixed_rows = __builtin_amdgcn_readfirstlane(mixed_rows);
+    land_rows = __builtin_amdgcn_readfirstlane(land_rows);
+    // wave-rows that are land everywhere stay exactly 0 (k_zero_land keeps land at 0 on input; :481 on output)
 
     for (int s = 0; s < a.nsweeps; s++) {
         // publish this wave's first and last rows (values before the sweep), fetch the neighbours' rows
@@ -123,8 +144,14 @@ __global__ __launch_bounds__(NW * 64) void k_jacobi_tb8(tb_args a)
         halo[par][wave][0][lane] = p[0];
         halo[par][wave][1][lane] = p[R - 1];
         __syncthreads();
-        float4 south = (wave > 0) ? halo[par][wave - 1][1][lane] : p[0];            // row below r = 0
-        float4 north = (wave < NW - 1) ? halo[par][wave + 1][0][lane] : p[R - 1];   // row above r = R-1
+        // the outermost waves read a slot of their own: those rows are halo, their values never reach the output
+        float4 south = halo[par][wave > 0 ? wave - 1 : 0][1][lane];            // row below r = 0
+        float4 north = halo[par][wave < NW - 1 ? wave + 1 : NW - 1][0][lane];  // row above r = R-1
+
+        // rows closer than s+1 to the top/bottom edge of the extended tile are stale after this sweep whatever we
+        // do (staleness creeps in one row per sweep) and nothing reads them for a valid output: skip them
+        const int skip_lo = (wave == 0) ? s + 1 : 0;                            // rows r < skip_lo
+        const int skip_hi = (wave == NW - 1) ? R - 1 - s : R;                   // rows r >= skip_hi
 
         float4 prev = south;                        // pre-sweep values of row r-1
 #pragma unroll
@@ -132,24 +159,26 @@ __global__ __launch_bounds__(NW * 64) void k_jacobi_tb8(tb_args a)
             float4 C = p[r];
             float4 N = (r < R - 1) ? p[r + 1] : north;
             float4 S = prev;
+            prev = C;
+            if (r < skip_lo || r >= skip_hi) continue;
+            if (land_rows & (1u << r)) continue;    // all land: the row is and stays 0
             float wl = dpp_from_prev_lane(C.w);     // west neighbour of C.x
             float er = dpp_from_next_lane(C.x);     // east neighbour of C.w
-            jacobi_row k = { lane_value(tcx, r), lane_value(tcy, r), lane_value(tbe, r),
-                             lane_value(trx, r), lane_value(try_, r), lane_value(trb, r) };
+            float4 k0 = coef[wave * R + r][0], k1 = coef[wave * R + r][1];
+            jacobi_row k = { k0.x, k0.y, k0.z, k0.w, k1.x, k1.y };
             float4 o;
-            if (!(slow_rows & (1u << r))) {         // wave-uniform: open ocean, no selects needed
+            if (!(mixed_rows & (1u << r))) {        // wave-uniform: open ocean, no selects needed
                 o.x = jacobi_value(N.x, S.x, C.y, wl, b[r].x, k);
                 o.y = jacobi_value(N.y, S.y, C.z, C.x, b[r].y, k);
                 o.z = jacobi_value(N.z, S.z, C.w, C.y, b[r].z, k);
                 o.w = jacobi_value(N.w, S.w, er, C.z, b[r].w, k);
             } else {
                 unsigned c = code[r];
-                o.x = tb_cell(C.x, N.x, S.x, C.y, wl, b[r].x, c & 0xFFu, k);
-                o.y = tb_cell(C.y, N.y, S.y, C.z, C.x, b[r].y, (c >> 8) & 0xFFu, k);
-                o.z = tb_cell(C.z, N.z, S.z, C.w, C.y, b[r].z, (c >> 16) & 0xFFu, k);
-                o.w = tb_cell(C.w, N.w, S.w, er, C.z, b[r].w, (c >> 24) & 0xFFu, k);
+                o.x = tb_cell(C.x, N.x, S.x, C.y, wl, b[r].x, c, 0, k);
+                o.y = tb_cell(C.y, N.y, S.y, C.z, C.x, b[r].y, c, 8, k);
+                o.z = tb_cell(C.z, N.z, S.z, C.w, C.y, b[r].z, c, 16, k);
+                o.w = tb_cell(C.w, N.w, S.w, er, C.z, b[r].w, c, 24, k);
             }
-            prev = C;
             p[r] = o;
         }
     }
@@ -184,11 +213,12 @@ static tb_shape tb_pick_shape()
 }
 
 template <int R, int NW>
-static void tb_launch(const tb_args &a, int W, int rows, hipStream_t stream)
+static void tb_launch(tb_args a, int W, int rows, hipStream_t stream)
 {
     constexpr int OH = R * NW - 2 * TB_T;
-    dim3 grid((W + TB_OW - 1) / TB_OW, (rows + OH - 1) / OH);
-    hipLaunchKernelGGL((k_jacobi_tb8<R, NW>), grid, dim3(NW * 64), 0, stream, a);
+    a.tiles_x = (W + TB_OW - 1) / TB_OW;
+    a.tiles_y = (rows + OH - 1) / OH;
+    hipLaunchKernelGGL((k_jacobi_tb8<R, NW>), dim3(a.tiles_x * a.tiles_y), dim3(NW * 64), 0, stream, a);
 }
 
 // host launcher: `n` (1..8) sweeps over local rows [lo, hi).  The caller flips o->cur.
