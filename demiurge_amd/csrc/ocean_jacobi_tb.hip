@@ -35,6 +35,7 @@ struct tb_args {
     int spole, npole;
     int nsweeps;                    // 1..TB_T
     int tiles_x, tiles_y;
+    int order;                      // tile walk: 0 natural row-major, 1 XCD-chunked 16-column groups, 2 XCD-chunked column-major
 };
 
 __device__ __forceinline__ float dpp_from_prev_lane(float v)   // lane i <- lane i-1
@@ -82,7 +83,7 @@ __device__ __forceinline__ tb_row tb_map_row(const tb_args &a, int local_unclamp
 // second launch-bound argument = waves per SIMD the register allocator must leave room for (R = 8: 128 VGPRs,
 // i.e. two 8-wave workgroups per CU, so one workgroup's load phase overlaps the other's sweeps)
 template <int R, int NW>
-__global__ __launch_bounds__(NW * 64, (R <= 8 ? 4 : (R <= 12 ? 3 : 2))) void k_jacobi_tb8(tb_args a)
+__global__ __launch_bounds__(NW * 64, (R <= 10 ? 4 : (R <= 12 ? 3 : 2))) void k_jacobi_tb8(tb_args a)
 {
     constexpr int EH = R * NW;                      // extended tile rows
     constexpr int OH = EH - 2 * TB_T;               // output rows per tile
@@ -93,16 +94,32 @@ __global__ __launch_bounds__(NW * 64, (R <= 8 ? 4 : (R <= 12 ? 3 : 2))) void k_j
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int W = a.W;
 
-    // tile id -> (tile column, tile row).  Workgroups are dealt round-robin over the 8 XCDs (id % 8); give each XCD a
-    // contiguous run of tiles in column-major order so that vertically adjacent tiles, which share 16 of their rows,
-    // run on the same XCD back to back and find the shared rows in that XCD's L2.  Placement only affects speed.
+    // tile id -> (tile column, tile row).  Workgroups are dealt round-robin over the 8 XCDs (id % 8, observed, not
+    // contractual: placement only affects speed).  order 1: every XCD gets a contiguous run of tiles, walked row by
+    // row inside groups of 16 tile columns, so vertically adjacent tiles (which share 16 of their rows) run on the
+    // same XCD shortly after one another while the tiles in flight still spread over 16 KB of each grid row
+    // (a pure column-major walk puts all concurrent rows 64 KiB apart and hot-spots HBM channels).
     int tx, ty;
     {
         const int ntiles = a.tiles_x * a.tiles_y;
-        int id = blockIdx.x;
-        int per = ntiles >> 3;                      // tiles per XCD (the remainder keeps its natural order)
-        int t = (id < per * 8) ? (id & 7) * per + (id >> 3) : id;
-        tx = t / a.tiles_y; ty = t - tx * a.tiles_y;
+        int t = blockIdx.x;
+        if (a.order != 0) {
+            int per = ntiles >> 3;                  // tiles per XCD (the remainder keeps its natural order)
+            if (t < per * 8) t = (t & 7) * per + (t >> 3);
+        }
+        if (a.order == 1) {
+            const int G = 16;
+            int full = (a.tiles_x / G) * G;         // columns covered by full groups
+            int ingroups = full * a.tiles_y;
+            if (t < ingroups) {
+                int g = t / (G * a.tiles_y), r = t - g * (G * a.tiles_y);
+                ty = r / G; tx = g * G + (r - ty * G);
+            } else {
+                int rem = a.tiles_x - full, r = t - ingroups;
+                ty = r / rem; tx = full + (r - ty * rem);
+            }
+        } else if (a.order == 2) { tx = t / a.tiles_y; ty = t - tx * a.tiles_y; }
+        else { ty = t / a.tiles_x; tx = t - ty * a.tiles_x; }
     }
     const int X0 = tx * TB_OW;                      // first output column of the tile
     const int Y0 = a.out_lo + ty * OH;              // first output local row of the tile
@@ -150,8 +167,10 @@ __global__ __launch_bounds__(NW * 64, (R <= 8 ? 4 : (R <= 12 ? 3 : 2))) void k_j
 
         // rows closer than s+1 to the top/bottom edge of the extended tile are stale after this sweep whatever we
         // do (staleness creeps in one row per sweep) and nothing reads them for a valid output: skip them
-        const int skip_lo = (wave == 0) ? s + 1 : 0;                            // rows r < skip_lo
-        const int skip_hi = (wave == NW - 1) ? R - 1 - s : R;                   // rows r >= skip_hi
+        // ... and rows that are land everywhere are and stay exactly 0: one wave-uniform skip mask per sweep
+        unsigned skip = land_rows;
+        if (wave == 0) skip |= (2u << s) - 1u;                                  // rows r <= s
+        if (wave == NW - 1) skip |= ~((1u << (R - 1 - s)) - 1u);                // rows r >= R-1-s
 
         float4 prev = south;                        // pre-sweep values of row r-1
 #pragma unroll
@@ -160,8 +179,7 @@ __global__ __launch_bounds__(NW * 64, (R <= 8 ? 4 : (R <= 12 ? 3 : 2))) void k_j
             float4 N = (r < R - 1) ? p[r + 1] : north;
             float4 S = prev;
             prev = C;
-            if (r < skip_lo || r >= skip_hi) continue;
-            if (land_rows & (1u << r)) continue;    // all land: the row is and stays 0
+            if (skip & (1u << r)) continue;
             float wl = dpp_from_prev_lane(C.w);     // west neighbour of C.x
             float er = dpp_from_next_lane(C.x);     // east neighbour of C.w
             float4 k0 = coef[wave * R + r][0], k1 = coef[wave * R + r][1];
@@ -205,7 +223,7 @@ static tb_shape tb_pick_shape()
         const char *e = getenv("DMG_TB_SHAPE");
         int r = 0, nw = 0;
         if (e && sscanf(e, "%dx%d", &r, &nw) == 2 &&
-            ((r == 8 && nw == 8) || (r == 16 && nw == 8) || (r == 8 && nw == 16) || (r == 12 && nw == 8)))
+            ((r == 8 && nw == 8) || (r == 16 && nw == 8) || (r == 8 && nw == 16) || (r == 12 && nw == 8) || (r == 10 && nw == 8)))
             d = { r, nw };
         return d;
     }();
@@ -218,6 +236,8 @@ static void tb_launch(tb_args a, int W, int rows, hipStream_t stream)
     constexpr int OH = R * NW - 2 * TB_T;
     a.tiles_x = (W + TB_OW - 1) / TB_OW;
     a.tiles_y = (rows + OH - 1) / OH;
+    static const int order = [] { const char *e = getenv("DMG_TB_ORDER"); return e ? atoi(e) : 0; }();
+    a.order = order;
     hipLaunchKernelGGL((k_jacobi_tb8<R, NW>), dim3(a.tiles_x * a.tiles_y), dim3(NW * 64), 0, stream, a);
 }
 
@@ -240,6 +260,7 @@ int ocean_launch_tb(dmg_ocean *o, int lo, int hi, int n)
     tb_shape sh = tb_pick_shape();
     hipStream_t st = o->ctx->stream;
     if (sh.R == 16) tb_launch<16, 8>(a, a.W, hi - lo, st);
+    else if (sh.R == 10) tb_launch<10, 8>(a, a.W, hi - lo, st);
     else if (sh.R == 12) tb_launch<12, 8>(a, a.W, hi - lo, st);
     else if (sh.NW == 16) tb_launch<8, 16>(a, a.W, hi - lo, st);
     else tb_launch<8, 8>(a, a.W, hi - lo, st);
