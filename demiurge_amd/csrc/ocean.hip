@@ -342,38 +342,11 @@ int dmg_ocean_jacobi_sweeps(dmg_ocean *o, int n)
     // the region shrinks by one row per sweep on every side that has a neighbour band
     if (blocked) {
         static const int cap = [] { const char *e = getenv("DMG_TB_SWEEPS"); int v = e ? atoi(e) : 8; return v >= 1 && v <= 8 ? v : 8; }();
-        // Cache blocking above the tile level (single band only): walk the grid in chunks of `chunk` rows and advance
-        // each chunk `depth` launches (8*depth sweeps) before moving on, so a chunk's p/divw/code stay in the 256 MiB
-        // Infinity Cache between launches.  Launch j of a chunk is shifted 8*j rows towards row 0 (parallelogram
-        // tiling): its inputs are rows the previous launch of the same chunk or the finished previous chunk wrote,
-        // and nothing a later chunk still needs is overwritten -- no redundant rows, plain ping-pong buffers.
-        static const int chunk = [] { const char *e = getenv("DMG_TB_CHUNK"); return e ? atoi(e) : 0; }();
-        static const int depth = [] { const char *e = getenv("DMG_TB_DEPTH"); int v = e ? atoi(e) : 4; return v >= 1 ? v : 1; }();
-        int k = 0;
-        if (o->count == 1 && chunk >= 64 && cap == 8) {
-            const int L = o->L;
-            const int K = (L + chunk - 1) / chunk;
-            while (n - k >= 8) {
-                int J = (n - k) / 8 < depth ? (n - k) / 8 : depth;
-                if (8 * J >= chunk) J = chunk / 8 - 1 > 0 ? chunk / 8 - 1 : 1;
-                for (int c = 0; c < K; c++)
-                    for (int j = 0; j < J; j++) {
-                        int lo = c * chunk - 8 * j, hi = (c == K - 1) ? L : (c + 1) * chunk - 8 * j;
-                        if (lo < 0) lo = 0;
-                        int rc = ocean_launch_tb(o, lo, hi, 8, o->cur ^ (j & 1));
-                        if (rc) return rc;
-                        o->n_launches++;
-                    }
-                o->n_sweeps += 8 * J;
-                o->cur ^= (J & 1);
-                k += 8 * J;
-            }
-        }
-        while (k < n) {
+        for (int k = 0; k < n;) {
             int m = n - k < cap ? n - k : cap;   // DMG_TB_SWEEPS (1..8): sweeps per launch, for phase-cost experiments
             k += m;
             int lo = o->gs ? k : 0, hi = o->L - (o->gn ? k : 0);
-            int rc = ocean_launch_tb(o, lo, hi, m, o->cur);
+            int rc = ocean_launch_tb(o, lo, hi, m);
             if (rc) return rc;
             o->cur ^= 1;
             o->n_launches++; o->n_sweeps += m;

@@ -241,13 +241,13 @@ static void tb_launch(tb_args a, int W, int rows, hipStream_t stream)
     hipLaunchKernelGGL((k_jacobi_tb8<R, NW>), dim3(a.tiles_x * a.tiles_y), dim3(NW * 64), 0, stream, a);
 }
 
-// host launcher: `n` (1..8) sweeps over local rows [lo, hi), reading pressure buffer `src` and writing `src ^ 1`.
-int ocean_launch_tb(dmg_ocean *o, int lo, int hi, int n, int src)
+// host launcher: `n` (1..8) sweeps over local rows [lo, hi).  The caller flips o->cur.
+int ocean_launch_tb(dmg_ocean *o, int lo, int hi, int n)
 {
     if (hi <= lo) return DMG_OK;
     tb_args a;
-    a.pin = o->p[src];
-    a.pout = o->p[src ^ 1];
+    a.pin = o->p[o->cur];
+    a.pout = o->p[o->cur ^ 1];
     a.b = o->divw;
     a.code = o->code;
     a.cx = o->jac_cx; a.cy = o->jac_cy; a.beta = o->jac_beta;
