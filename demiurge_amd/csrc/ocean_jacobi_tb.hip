@@ -219,7 +219,7 @@ struct tb_shape { int R, NW; };
 static tb_shape tb_pick_shape()
 {
     static tb_shape s = [] {
-        tb_shape d = { 8, 8 };
+        tb_shape d = { 10, 8 };
         const char *e = getenv("DMG_TB_SHAPE");
         int r = 0, nw = 0;
         if (e && sscanf(e, "%dx%d", &r, &nw) == 2 &&
