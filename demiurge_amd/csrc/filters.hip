@@ -1,0 +1,350 @@
+// Whole-grid stencil filters behind the generic entry points of include/demiurge_hip.h:
+//   dmg_blur               Blur::Blur + Blur::step          reference src/filter/BlurMenu.cpp:24-117
+//   dmg_temperature_steps  Temperature::run inner pass      reference src/filter/Temperature.cpp:56-150
+//   dmg_erosion_pass       erosion/uplift pass of cpufilter reference src/filter/cpufilter.cpp:106-214
+// One thread per cell, row-major coalesced.  The fractional-offset taps (blur13, the temperature laplacian's
+// 1/cos(lat) x-offsets) go through a literal fp32 restatement of the GLSL offset() (reference src/Shader.h:82-98)
+// and of the texture unit (GL_LINEAR / GL_NEAREST with CLAMP_TO_EDGE, reference src/Texture.cpp:29-33), so the
+// texel each tap hits is the one the reference hits.  Row-constant transcendental factors (cos(lat)) come from the
+// host in fp32, exactly as in the ocean kernels; the per-row insolation of the climate step is evaluated on the
+// device (sin/cos/asin/acos/tan of device libm: a few ulp from glibc).
+#include "dmg_internal.h"
+#include <algorithm>
+
+struct canvas {
+    int W, H;
+    float c0, c1, c2, c3, circumference;
+    int lonwrap, spole, npole;
+};
+
+static canvas make_canvas(const dmg_grid &g, const dmg_topology &t)
+{
+    canvas c;
+    c.W = g.W; c.H = g.H;
+    c.c0 = g.coords[0]; c.c1 = g.coords[1]; c.c2 = g.coords[2]; c.c3 = g.coords[3];
+    c.circumference = g.circumference;
+    c.lonwrap = t.lonwrap; c.spole = t.spole; c.npole = t.npole;
+    return c;
+}
+
+__device__ __forceinline__ float d_mod(float x, float y) { return __fsub_rn(x, __fmul_rn(y, floorf(__fdiv_rn(x, y)))); }
+
+// offset(p, dp, resolution)  (reference src/Shader.h:82-98), statement by statement in fp32
+__device__ __forceinline__ void d_offset(const canvas &c, float px, float py, float dpx, float dpy, float *ox, float *oy)
+{
+    const float two_pi = 2.0f * DMG_PI;
+    px = __fadd_rn(px, __fdiv_rn(dpx, (float)c.W));
+    py = __fadd_rn(py, __fdiv_rn(dpy, (float)c.H));
+    if (c.lonwrap) px = d_mod(__fadd_rn(px, 1.0f), 1.0f);
+    if (c.spole && py < 0.0f) {
+        py = -py;
+        px = __fsub_rn(d_mod(__fadd_rn(__fadd_rn(__fmul_rn(px, __fsub_rn(c.c3, c.c2)), c.c2), two_pi), two_pi), DMG_PI);
+        px = __fdiv_rn(__fsub_rn(px, c.c2), __fsub_rn(c.c3, c.c2));
+    }
+    if (c.npole && py > 1.0f) {
+        py = __fsub_rn(2.0f, py);
+        px = __fsub_rn(d_mod(__fadd_rn(__fadd_rn(__fmul_rn(px, __fsub_rn(c.c3, c.c2)), c.c2), two_pi), two_pi), DMG_PI);
+        px = __fdiv_rn(__fsub_rn(px, c.c2), __fsub_rn(c.c3, c.c2));
+    }
+    if (c.lonwrap) px = d_mod(__fadd_rn(px, 1.0f), 1.0f);
+    *ox = px; *oy = py;
+}
+
+__device__ __forceinline__ float d_fetch_nearest(const float *t, int W, int H, float u, float v)
+{
+    int i = min(max((int)floorf(__fmul_rn(u, (float)W)), 0), W - 1);
+    int j = min(max((int)floorf(__fmul_rn(v, (float)H)), 0), H - 1);
+    return t[(size_t)j * W + i];
+}
+
+__device__ __forceinline__ float d_fetch_linear(const float *t, int W, int H, float u, float v)
+{
+    float fu = __fsub_rn(__fmul_rn(u, (float)W), 0.5f), fv = __fsub_rn(__fmul_rn(v, (float)H), 0.5f);
+    float flu = floorf(fu), flv = floorf(fv);
+    float wx = __fsub_rn(fu, flu), wy = __fsub_rn(fv, flv);
+    int i0 = min(max((int)flu, 0), W - 1), i1 = min(max((int)flu + 1, 0), W - 1);
+    int j0 = min(max((int)flv, 0), H - 1), j1 = min(max((int)flv + 1, 0), H - 1);
+    float t00 = t[(size_t)j0 * W + i0], t10 = t[(size_t)j0 * W + i1], t01 = t[(size_t)j1 * W + i0], t11 = t[(size_t)j1 * W + i1];
+    float a = __fadd_rn(t00, __fmul_rn(wx, __fsub_rn(t10, t00)));
+    float b = __fadd_rn(t01, __fmul_rn(wx, __fsub_rn(t11, t01)));
+    return __fadd_rn(a, __fmul_rn(wy, __fsub_rn(b, a)));
+}
+
+__device__ __forceinline__ float d_stx(const canvas &c, int x) { return __fdiv_rn(__fadd_rn((float)x, 0.5f), (float)c.W); }
+__device__ __forceinline__ float d_sty(const canvas &c, int y) { return __fdiv_rn(__fadd_rn((float)y, 0.5f), (float)c.H); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// blur13 (BlurMenu.cpp:41-62): 7 bilinear taps along `direction`, x offsets divided by cos(|lat|)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_blur13(canvas c, const float *__restrict__ src, float *__restrict__ dst,
+                                                const float *__restrict__ phifactor, float dirx, float diry)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= c.W) return;
+    const float k1 = 1.411764705882353f, k2 = 3.2941176470588234f, k3 = 5.176470588235294f;
+    const float w0 = 0.1964825501511404f, w1 = 0.2969069646728344f, w2 = 0.09447039785044732f, w3 = 0.010381362401148057f;
+    float pf = phifactor[y];
+    float o1x = __fdiv_rn(__fmul_rn(k1, dirx), pf), o2x = __fdiv_rn(__fmul_rn(k2, dirx), pf), o3x = __fdiv_rn(__fmul_rn(k3, dirx), pf);
+    float o1y = __fmul_rn(k1, diry), o2y = __fmul_rn(k2, diry), o3y = __fmul_rn(k3, diry);
+    float sx = d_stx(c, x), sy = d_sty(c, y);
+    float color = 0.0f, px, py;
+    color = __fadd_rn(color, __fmul_rn(d_fetch_linear(src, c.W, c.H, sx, sy), w0));
+    d_offset(c, sx, sy, o1x, o1y, &px, &py);   color = __fadd_rn(color, __fmul_rn(d_fetch_linear(src, c.W, c.H, px, py), w1));
+    d_offset(c, sx, sy, -o1x, -o1y, &px, &py); color = __fadd_rn(color, __fmul_rn(d_fetch_linear(src, c.W, c.H, px, py), w1));
+    d_offset(c, sx, sy, o2x, o2y, &px, &py);   color = __fadd_rn(color, __fmul_rn(d_fetch_linear(src, c.W, c.H, px, py), w2));
+    d_offset(c, sx, sy, -o2x, -o2y, &px, &py); color = __fadd_rn(color, __fmul_rn(d_fetch_linear(src, c.W, c.H, px, py), w2));
+    d_offset(c, sx, sy, o3x, o3y, &px, &py);   color = __fadd_rn(color, __fmul_rn(d_fetch_linear(src, c.W, c.H, px, py), w3));
+    d_offset(c, sx, sy, -o3x, -o3y, &px, &py); color = __fadd_rn(color, __fmul_rn(d_fetch_linear(src, c.W, c.H, px, py), w3));
+    dst[(size_t)y * c.W + x] = color;
+}
+
+// Blur::Blur radius schedule (BlurMenu.cpp:27,79-94), fp32 with the reference's implicit double sqrt
+static std::vector<float> blur_rlist(float radius)
+{
+    std::vector<float> rl;
+    radius = radius / 2;
+    float R = radius * radius / 2;
+    float i = 1.0f, incrementer = 0.5f;
+    if (R < 3) {
+        float k = (float)(1 / sqrt((double)(55 / R)));
+        incrementer = k;
+        i = k;
+    }
+    while (R >= i * i) {
+        R -= i * i;
+        rl.push_back(i);
+        i += incrementer;
+    }
+    if (R > 0.0f) rl.push_back((float)sqrt((double)R));
+    std::sort(rl.begin(), rl.end());
+    return rl;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// climate step (Temperature.cpp:56-134)
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float d_sign(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
+
+// QDay(phi, M) (:69-95) -> absorbed solar radiation of the row, ASR = (1-0.30)*QDay (:102,:122)
+__global__ void k_temperature_rows(canvas c, const float *__restrict__ lat, float M, float *__restrict__ asr)
+{
+    int y = blockIdx.x * blockDim.x + threadIdx.x;
+    if (y >= c.H) return;
+    float phi = lat[y];
+    const float eccentricity = 0.017f;
+    const float gamma = 23.44f / 180.0f * DMG_PI;
+    const float omega = 0.0f, omega2 = 77.05f / 180.0f * DMG_PI;
+    const float S0 = 1365.0f;
+    float e3 = eccentricity * eccentricity * eccentricity;
+    float A = M + (2.0f * eccentricity - e3 / 4.0f * sinf(M) + 5.0f / 4.0f * (eccentricity * eccentricity) * sinf(2.0f * M)
+                   + 13.0f / 12.0f * e3 * sinf(3.0f * M));
+    float Ls = A - omega2;
+    float delt = asinf(sinf(gamma) * sinf(Ls));
+    float h = d_sign(phi) == d_sign(delt) ? DMG_PI : 0.0f;
+    if (fabsf(phi) <= DMG_PI / 2.0f - fabsf(delt)) h = acosf(-tanf(phi) * tanf(delt));
+    float S = S0 * (1.0f + 2.0f * eccentricity * cosf(A - omega));
+    float q = S / DMG_PI * (h * sinf(phi) * sinf(delt) + cosf(phi) * cosf(delt) * sinf(h));
+    asr[y] = (1.0f - 0.30f) * q;
+}
+
+__global__ __launch_bounds__(256) void k_temperature(canvas c, const float *__restrict__ T, float *__restrict__ out,
+                                                     const float *__restrict__ terrain, const float *__restrict__ asr,
+                                                     const float *__restrict__ cosphi, const float *__restrict__ dyrow)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= c.W) return;
+    float sx = d_stx(c, x), sy = d_sty(c, y);
+    float factor = cosphi[y];                        // get_texture_laplacian: cos(geo.y) (Shader.h:301-302)
+    float dy = dyrow[y];
+    float den = __fmul_rn(4.0f, __fmul_rn(dy, dy));  // 4*pow(pixelwidth.y,2)
+    float Tc = T[(size_t)y * c.W + x];
+    float terr = terrain[(size_t)y * c.W + x];
+    float s[9];
+    const float ox[9] = { 1, 0, -1, 1, 0, -1, 1, 0, -1 }, oy[9] = { 1, 1, 1, 0, 0, 0, -1, -1, -1 };
+#pragma unroll
+    for (int k = 0; k < 9; k++) {                    // Shader.h:304-312: offset(st, -vec2(i/factor, j)), NEAREST `img`
+        float px, py;
+        float dpx = ox[k] == 0.0f ? -0.0f : -__fdiv_rn(ox[k], factor);
+        d_offset(c, sx, sy, dpx, -oy[k], &px, &py);
+        s[k] = d_fetch_nearest(T, c.W, c.H, px, py);
+    }
+    float A_ = s[0], B_ = s[1], C_ = s[2], D_ = s[3], E_ = s[4], F_ = s[5], G_ = s[6], H_ = s[7], I_ = s[8];
+    // (a - 2*b + c + 2*d - 4*e + 2*f + g - 2*h + i) and (a + 2*b + c - 2*d - 4*e - 2*f + g + 2*h + i), left to right
+    float nx = __fadd_rn(__fsub_rn(__fadd_rn(__fadd_rn(__fsub_rn(__fadd_rn(__fadd_rn(__fsub_rn(A_, __fmul_rn(2.0f, B_)), C_), __fmul_rn(2.0f, D_)), __fmul_rn(4.0f, E_)), __fmul_rn(2.0f, F_)), G_), __fmul_rn(2.0f, H_)), I_);
+    float ny = __fadd_rn(__fadd_rn(__fadd_rn(__fsub_rn(__fsub_rn(__fsub_rn(__fadd_rn(__fadd_rn(A_, __fmul_rn(2.0f, B_)), C_), __fmul_rn(2.0f, D_)), __fmul_rn(4.0f, E_)), __fmul_rn(2.0f, F_)), G_), __fmul_rn(2.0f, H_)), I_);
+    float delta_x = __fdiv_rn(nx, den), delta_y = __fdiv_rn(ny, den);
+    if (isnan(delta_x)) delta_x = 0.0f;
+    if (isnan(delta_y)) delta_y = 0.0f;
+    float t = __fadd_rn(Tc, 273.15f);
+    float t2 = __fmul_rn(t, t), r2 = __fmul_rn(273.4f, 273.4f);
+    float OLR = __fmul_rn(__fdiv_rn(__fmul_rn(210.0f, __fmul_rn(t2, t2)), __fmul_rn(r2, r2)), 0.93f);          // :125
+    float change = __fadd_rn(__fsub_rn(asr[y], OLR), __fmul_rn(__fmul_rn(0.55f, 1e6f), __fadd_rn(delta_x, delta_y)));   // :128
+    float atmosphere = 1e7f;
+    float Cc = __fadd_rn(atmosphere, terr > 0.0f ? __fmul_rn(atmosphere, 0.5f) : __fmul_rn(__fmul_rn(4.0f, 1.5f), atmosphere));
+    out[(size_t)y * c.W + x] = __fadd_rn(Tc, __fdiv_rn(__fdiv_rn(__fmul_rn(__fmul_rn(change, 3.154f), 1e7f), 15000.0f), Cc));   // :133
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// erosion / uplift pass (cpufilter.cpp:121-198); reads old heights, writes a new buffer
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_erosion(canvas c, const float *__restrict__ hgt, const float *__restrict__ flow,
+                                                 const float *__restrict__ updrift, float *__restrict__ out,
+                                                 const float *__restrict__ dxrow, const float *__restrict__ dyrow,
+                                                 float factor, float slope_exponent, float SLOPE, float pow01)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= c.W) return;
+    const int W = c.W, H = c.H;
+    size_t i = (size_t)y * W + x;
+    float h = hgt[i];
+    if (h <= 0.0f) { out[i] = h; return; }                                   // :122-123
+    float psx = dxrow[y], psy = dyrow[y];
+    float maxslope = 0.0f;
+    float dist = sqrtf(__fadd_rn(__fmul_rn(psx, psx), __fmul_rn(psy, psy)));  // length(psize) :128
+    const int offx[8] = { 1, 0, -1, 1, -1, 1, 0, -1 }, offy[8] = { 1, 1, 1, 0, 0, -1, -1, -1 };   // :134-189 order
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        // offset(st, o) + NEAREST for integer o: wrap, then pole reflection (lon += pi) or CLAMP_TO_EDGE
+        int xx = x + offx[k], yy = y + offy[k];
+        if (c.lonwrap) { if (xx >= W) xx -= W; if (xx < 0) xx += W; }
+        else xx = min(max(xx, 0), W - 1);
+        if (yy < 0) { yy = 0; if (c.spole) { xx += W / 2; if (xx >= W) xx -= W; } }
+        if (yy >= H) { yy = H - 1; if (c.npole) { xx += W / 2; if (xx >= W) xx -= W; } }
+        float h2 = hgt[(size_t)yy * W + xx];
+        float ax = __fmul_rn(psx, (float)offx[k]), ay = __fmul_rn(psy, (float)offy[k]);
+        float ndist = sqrtf(__fadd_rn(__fmul_rn(ax, ax), __fmul_rn(ay, ay)));
+        h2 = __fdiv_rn(__fsub_rn(h, h2), ndist);
+        if (h2 > maxslope) { maxslope = h2; dist = ndist; }
+    }
+    float hdiff = __fsub_rn(__fmul_rn(SLOPE, dist), __fmul_rn(maxslope, dist));   // :192
+    // :195 factor*4*flow*pow(maxslope,n)/pow(0.1,n)*0.1
+    float fl = __fmul_rn(__fdiv_rn(__fmul_rn(__fmul_rn(__fmul_rn(factor, 4.0f), flow[i]), powf(maxslope, slope_exponent)), pow01), 0.1f);
+    float up = updrift[i];
+    out[i] = __fadd_rn(h, fminf(hdiff, fmaxf(0.0f, __fsub_rn(up, fl))));           // :198
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+struct dev_buf {
+    void *p = nullptr;
+    ~dev_buf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc(&p, n); }
+    float *f() const { return (float *)p; }
+};
+}  // namespace
+
+#define DMG_ALLOC(buf, bytes)                                                                      \
+    do {                                                                                           \
+        hipError_t _e = (buf).alloc(bytes);                                                        \
+        if (_e != hipSuccess) return dmg_fail(DMG_ENOMEM, "hipMalloc(%zu) failed: %s", (size_t)(bytes), hipGetErrorString(_e)); \
+    } while (0)
+
+static int upload_rows(dmg_ctx *ctx, dev_buf &d, const std::vector<float> &v)
+{
+    DMG_ALLOC(d, v.size() * sizeof(float));
+    DMG_HIP(hipMemcpyAsync(d.p, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    DMG_HIP(hipStreamSynchronize(ctx->stream));      // `v` is a host temporary
+    return DMG_OK;
+}
+
+extern "C" {
+
+int dmg_blur(dmg_ctx *ctx, const dmg_grid *grid, float *field, float radius)
+{
+    DMG_CHECK_ARG(ctx != nullptr && field != nullptr && radius > 0.0f);
+    dmg_topology topo;
+    int rc = dmg_check_grid(grid, &topo);
+    if (rc) return rc;
+    DMG_HIP(hipSetDevice(ctx->device));
+    canvas c = make_canvas(*grid, topo);
+    const size_t n = (size_t)grid->W * grid->H;
+    std::vector<float> pf(grid->H);
+    for (int y = 0; y < grid->H; y++) pf[y] = cosf(fabsf(dmg_row_lat(*grid, y)));   // BlurMenu.cpp:49
+    dev_buf t1, t2, dpf;
+    DMG_ALLOC(t1, n * 4); DMG_ALLOC(t2, n * 4);
+    if ((rc = upload_rows(ctx, dpf, pf))) return rc;
+    DMG_HIP(hipMemcpyAsync(t1.p, field, n * 4, hipMemcpyHostToDevice, ctx->stream));   // copy target -> tex1 (:36)
+    std::vector<float> rl = blur_rlist(radius);
+    dim3 g((grid->W + 255) / 256, grid->H);
+    size_t i = 0;
+    do {                                             // Blur::step (:97-117)
+        hipLaunchKernelGGL(k_blur13, g, dim3(256), 0, ctx->stream, c, t1.f(), t2.f(), dpf.f(), 0.0f, rl[i]);   // (0, r)
+        hipLaunchKernelGGL(k_blur13, g, dim3(256), 0, ctx->stream, c, t2.f(), t1.f(), dpf.f(), rl[i], 0.0f);   // (r, 0)
+        DMG_HIP(hipGetLastError());
+        i++;
+    } while (!(i > rl.size() - 1));                  // `i>rlist.size()-1` (:111)
+    DMG_HIP(hipMemcpyAsync(field, t1.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));   // copy tex1 -> target (:112)
+    DMG_HIP(hipStreamSynchronize(ctx->stream));
+    return DMG_OK;
+}
+
+int dmg_temperature_steps(dmg_ctx *ctx, const dmg_grid *grid, float *T, const float *terrain, int first_step, int n_steps)
+{
+    DMG_CHECK_ARG(ctx != nullptr && T != nullptr && terrain != nullptr && n_steps >= 0);
+    dmg_topology topo;
+    int rc = dmg_check_grid(grid, &topo);
+    if (rc) return rc;
+    DMG_HIP(hipSetDevice(ctx->device));
+    canvas c = make_canvas(*grid, topo);
+    const int W = grid->W, H = grid->H;
+    const size_t n = (size_t)W * H;
+    std::vector<float> lat(H), cosphi(H), dyr(H);
+    for (int y = 0; y < H; y++) {
+        float dx, dy;
+        dmg_row_pixelsize(*grid, y, &dx, &dy);
+        lat[y] = dmg_row_lat(*grid, y);
+        cosphi[y] = cosf(lat[y]);
+        dyr[y] = dy;
+    }
+    dev_buf a, b, terr, dlat, dcos, ddy, dasr;
+    DMG_ALLOC(a, n * 4); DMG_ALLOC(b, n * 4); DMG_ALLOC(terr, n * 4); DMG_ALLOC(dasr, (size_t)H * 4);
+    if ((rc = upload_rows(ctx, dlat, lat)) || (rc = upload_rows(ctx, dcos, cosphi)) || (rc = upload_rows(ctx, ddy, dyr))) return rc;
+    DMG_HIP(hipMemcpyAsync(a.p, T, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    DMG_HIP(hipMemcpyAsync(terr.p, terrain, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    float *cur = a.f(), *nxt = b.f();
+    dim3 g((W + 255) / 256, H);
+    for (int i = first_step; i < first_step + n_steps; i++) {
+        float M = (float)(M_PI * 2 / 15000 * i);     // glUniform1f(id, M_PI*2/15000*i) (:146)
+        hipLaunchKernelGGL(k_temperature_rows, dim3((H + 255) / 256), dim3(256), 0, ctx->stream, c, dlat.f(), M, dasr.f());
+        hipLaunchKernelGGL(k_temperature, g, dim3(256), 0, ctx->stream, c, cur, nxt, terr.f(), dasr.f(), dcos.f(), ddy.f());
+        DMG_HIP(hipGetLastError());
+        std::swap(cur, nxt);                         // terrain.swap(scratch2) (:148)
+    }
+    DMG_HIP(hipMemcpyAsync(T, cur, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    DMG_HIP(hipStreamSynchronize(ctx->stream));
+    return DMG_OK;
+}
+
+int dmg_erosion_pass(dmg_ctx *ctx, const dmg_grid *grid, float *h, const float *flow, const float *updrift,
+                     float factor, float slope_exponent)
+{
+    DMG_CHECK_ARG(ctx != nullptr && h != nullptr && flow != nullptr && updrift != nullptr);
+    dmg_topology topo;
+    int rc = dmg_check_grid(grid, &topo);
+    if (rc) return rc;
+    DMG_HIP(hipSetDevice(ctx->device));
+    canvas c = make_canvas(*grid, topo);
+    const int W = grid->W, H = grid->H;
+    const size_t n = (size_t)W * H;
+    std::vector<float> dxr(H), dyr(H);
+    for (int y = 0; y < H; y++) dmg_row_pixelsize(*grid, y, &dxr[y], &dyr[y]);
+    dev_buf dh, df, du, dout, ddx, ddy;
+    DMG_ALLOC(dh, n * 4); DMG_ALLOC(df, n * 4); DMG_ALLOC(du, n * 4); DMG_ALLOC(dout, n * 4);
+    if ((rc = upload_rows(ctx, ddx, dxr)) || (rc = upload_rows(ctx, ddy, dyr))) return rc;
+    DMG_HIP(hipMemcpyAsync(dh.p, h, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    DMG_HIP(hipMemcpyAsync(df.p, flow, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    DMG_HIP(hipMemcpyAsync(du.p, updrift, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    float SLOPE = tanf(DMG_PI / 2.0f / 3.0f);        // tan(M_PI/2/3), 30 degrees (:191)
+    float pow01 = powf(0.1f, slope_exponent);        // pow(0.1, slope_exponent): a constant of the pass
+    dim3 g((W + 255) / 256, H);
+    hipLaunchKernelGGL(k_erosion, g, dim3(256), 0, ctx->stream, c, dh.f(), df.f(), du.f(), dout.f(), ddx.f(), ddy.f(),
+                       factor, slope_exponent, SLOPE, pow01);
+    DMG_HIP(hipGetLastError());
+    DMG_HIP(hipMemcpyAsync(h, dout.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    DMG_HIP(hipStreamSynchronize(ctx->stream));
+    return DMG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,75 @@
+"""Parity of the whole-grid filters (blur13, climate step, erosion/uplift pass) through the C ABI."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, relerr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from demiurge_amd import capi
+    ctx = capi.Context(0)
+    yield capi, ctx
+    ctx.close()
+
+
+def grids(capi, oracle, G, shape):
+    H, W = shape
+    c, circ = tuple(G["coords"]), float(G["circ"])
+    return capi.make_grid(W, H, c, circ), oracle.grid(W, H, c, circ)
+
+
+@pytest.mark.parametrize("name", ["blur_128x64_r1", "blur_128x64_r10", "blur_128x64_region_r3"])
+def test_blur(dev, oracle, name):
+    """config 1 plumbing: Blur::Blur + Blur::step; all-IEEE arithmetic + host cos table -> bit-exact vs the oracle"""
+    capi, ctx = dev
+    G = load_golden(name)
+    g, og = grids(capi, oracle, G, G["field"].shape)
+    out = ctx.blur(g, G["field"], float(G["radius"]))
+    assert relerr(out, G["out"]) < 1e-5
+    assert np.array_equal(out, oracle.blur(og, G["field"], float(G["radius"])))
+
+
+def test_blur_config1_size(dev, oracle):
+    """BASELINE config 1: 1024x512 Gaussian blur"""
+    capi, ctx = dev
+    from demiurge_amd import synth
+    W, H = 1024, 512
+    f = synth.terrain(W, H)
+    out = ctx.blur(capi.make_grid(W, H), f, 1.0)
+    assert np.array_equal(out, oracle.blur(oracle.grid(W, H), f, 1.0))
+
+
+def test_temperature(dev, oracle):
+    capi, ctx = dev
+    G = load_golden("temperature_128x64_full")
+    g, og = grids(capi, oracle, G, G["T0"].shape)
+    for first, n, key in ((0, 1, "T1"), (0, 20, "T20"), (3000, 20, "T20_from3000")):
+        out = ctx.temperature_steps(g, G["T0"], G["terrain"], first, n)
+        assert relerr(out, G[key]) < 1e-5                                            # vs the reference's GLSL
+        assert relerr(out, oracle.temperature(og, G["T0"], G["terrain"], first, n)) < 2e-6   # insolation: device vs glibc libm
+
+
+def test_erosion(dev, oracle):
+    capi, ctx = dev
+    G = load_golden("erosion_128x64_full")
+    g, og = grids(capi, oracle, G, G["h"].shape)
+    for (f, n, key) in ((1.0, 1.0, "out"), (2.0, 0.7, "out_f2_n07")):
+        out = ctx.erosion_pass(g, G["h"], G["flow"], G["updrift"], f, n)
+        assert relerr(out, G[key]) < 1e-5
+        assert relerr(out, oracle.erosion_pass(og, G["h"], G["flow"], G["updrift"], f, n)) < 1e-6
+
+
+def test_erosion_config2_size(dev, oracle):
+    """BASELINE config 2 grid (4096x2048): one erosion/uplift pass against the oracle"""
+    capi, ctx = dev
+    from demiurge_amd import synth
+    W, H = 4096, 2048
+    h = (synth.terrain(W, H) * 20).astype(np.float32)
+    flow = (np.abs(synth.divw(W, H)) * 3).astype(np.float32)
+    up = (np.maximum(h, 0) / 50).astype(np.float32)
+    out = ctx.erosion_pass(capi.make_grid(W, H), h, flow, up, 1.0, 1.0)
+    assert relerr(out, oracle.erosion_pass(oracle.grid(W, H), h, flow, up, 1.0, 1.0)) < 1e-6
+    assert np.array_equal(out[h <= 0], h[h <= 0])
