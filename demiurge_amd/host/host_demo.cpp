@@ -1,0 +1,45 @@
+// Drives HipOceanCurrents the way the editor does: ProgressFilter::run calls subFilter->step(p) once per frame
+// until it reports finished (reference src/filter/Filter.cpp:97-115).  Reads a terrain (raw fp32), writes vx, vy.
+//   host_demo <W> <H> <terrain.f32> <n_outer> <jacobi_iters> <diffusion_iters> <out_prefix>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
+#include "HipOceanCurrents.h"
+
+static bool read_f32(const char *path, std::vector<float> &v)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f) return false;
+    size_t n = fread(v.data(), sizeof(float), v.size(), f);
+    fclose(f);
+    return n == v.size();
+}
+static void write_f32(const std::string &path, const std::vector<float> &v)
+{
+    FILE *f = fopen(path.c_str(), "wb");
+    fwrite(v.data(), sizeof(float), v.size(), f);
+    fclose(f);
+}
+
+int main(int argc, char **argv)
+{
+    if (argc != 8) { fprintf(stderr, "usage: host_demo W H terrain.f32 n_outer jacobi_iters diffusion_iters out_prefix\n"); return 2; }
+    Project p;
+    p.width = atoi(argv[1]); p.height = atoi(argv[2]);
+    p.terrain.resize((size_t)p.width * p.height);
+    if (!read_f32(argv[3], p.terrain)) { fprintf(stderr, "cannot read %s\n", argv[3]); return 2; }
+    auto filter = std::make_unique<HipOceanCurrents>(&p, 100.0f, atoi(argv[4]), atoi(argv[5]), atoi(argv[6]));
+    int frames = 0;
+    for (;;) {                                           // one step() per UI frame
+        auto [finished, progress] = filter->step(&p);
+        frames++;
+        if (finished) break;
+        std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    }
+    if (!filter->error().empty()) { fprintf(stderr, "filter failed: %s\n", filter->error().c_str()); return 1; }
+    write_f32(std::string(argv[7]) + "_vx.f32", p.scratch1);
+    write_f32(std::string(argv[7]) + "_vy.f32", p.scratch2);
+    printf("finished after %d frames\n", frames);
+    return 0;
+}
