@@ -77,3 +77,32 @@ def jacobi_solve(ocean, exch, sweeps, ghost, zero_first=True, field=0):
         ocean.jacobi_sweeps(n)
         done += n
     return sweeps
+
+
+F_PRESSURE, F_DIVW, F_TERRAIN, F_V = 0, 1, 2, 3     # DMG_F_* of include/demiurge_hip.h
+
+
+def ocean_step(ocean, exch, n_outer=1):
+    """OceanCurrents::run body (reference OceanCurrents.cpp:155-209) over latitude bands.
+
+    Same passes in the same order as dmg_ocean_step; between them the ghost rows of the field the next pass reads
+    are refreshed (depth = the ocean's `ghost`).  Bit-identical to the single-band step.
+    """
+    prm, g = ocean.params, ocean.ghost
+    if exch is None or exch.world == 1:
+        ocean.step(n_outer)
+        return
+    for _ in range(n_outer):
+        exch.exchange(ocean, F_V, g)                    # advect gathers v up to advect_reach() rows away
+        ocean.advect()                                  # :158
+        done = 0
+        while done < prm.diffusion_iters:               # :160, 50 sweeps in blocks of `ghost`
+            n = min(g, prm.diffusion_iters - done)
+            exch.exchange(ocean, F_V, g)
+            ocean.diffusion(n)
+            done += n
+        exch.exchange(ocean, F_V, g)
+        ocean.divergence()                              # :162  divw valid ghost-1 rows deep
+        jacobi_solve(ocean, exch, prm.jacobi_iters, g - (g % 8) if g >= 8 else g, zero_first=True)   # :166
+        exch.exchange(ocean, F_PRESSURE, g)
+        ocean.subdiv()                                  # :168

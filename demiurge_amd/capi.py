@@ -14,7 +14,7 @@ LIB_PATH = _HERE / "libdemiurge_hip.so"
 ROOT = _HERE.parent
 
 OK, EINVAL, ENOMEM, EHIP, ENODEVICE, ESTATE = 0, -1, -2, -3, -4, -5
-F_PRESSURE, F_DIVW, F_TERRAIN, F_VX, F_VY = range(5)
+F_PRESSURE, F_DIVW, F_TERRAIN, F_V = range(4)
 SIDE_SOUTH, SIDE_NORTH = 0, 1
 QUIRK_DIFFUSION_SCALAR_RHS = 1
 PRIVATE_STREAM = 1
@@ -93,6 +93,7 @@ def lib():
         "dmg_ocean_diffusion": (c_int, [vp, c_int]),
         "dmg_ocean_divergence": (c_int, [vp]),
         "dmg_ocean_subdiv": (c_int, [vp]),
+        "dmg_ocean_advect_reach": (c_int, [vp, ctypes.POINTER(c_int)]),
         "dmg_ocean_get": (c_int, [vp, vp, vp, vp, vp]),
         "dmg_blur": (c_int, [vp, PG, vp, c_float]),
         "dmg_temperature_steps": (c_int, [vp, PG, vp, vp, c_int, c_int]),
@@ -273,6 +274,11 @@ class Ocean:
 
     def subdiv(self):
         check(lib().dmg_ocean_subdiv(self.h))
+
+    def advect_reach(self):
+        r = ctypes.c_int()
+        check(lib().dmg_ocean_advect_reach(self.h, ctypes.byref(r)))
+        return r.value
 
     def get(self, want=("v", "pressure", "divw"), out=None):
         """Downloads owned rows into full-grid arrays (zeros elsewhere).  Returns dict of arrays."""

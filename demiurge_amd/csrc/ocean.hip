@@ -262,6 +262,7 @@ int dmg_ocean_create(dmg_ctx *ctx, const dmg_grid *grid, const dmg_ocean_params 
     alloc((void **)&o->code8, n);
     alloc((void **)&o->v[0], n * 8); alloc((void **)&o->v[1], n * 8);
     alloc((void **)&o->rowtab, sizeof(float) * ROWTAB_FIELDS * o->L);
+    alloc((void **)&o->oob_flag, sizeof(int));
     if (e != hipSuccess) {
         dmg_ocean_destroy(o);
         return dmg_fail(DMG_ENOMEM, "hipMalloc of %zu cells failed: %s", n, hipGetErrorString(e));
@@ -286,7 +287,7 @@ void dmg_ocean_destroy(dmg_ocean *o)
     (void)hipSetDevice(o->ctx->device);
     (void)hipStreamSynchronize(o->ctx->stream);
     for (void *p : { (void *)o->p[0], (void *)o->p[1], (void *)o->divw, (void *)o->img, (void *)o->code, (void *)o->code8,
-                     (void *)o->v[0], (void *)o->v[1], (void *)o->rowtab })
+                     (void *)o->v[0], (void *)o->v[1], (void *)o->rowtab, (void *)o->oob_flag })
         if (p) (void)hipFree(p);
     delete o;
 }
@@ -388,6 +389,7 @@ int dmg_ocean_halo(dmg_ocean *o, int field, int side, int rows, void **send, voi
     case DMG_F_PRESSURE: base = o->p[o->cur]; break;
     case DMG_F_DIVW: base = o->divw; break;
     case DMG_F_TERRAIN: base = o->img; break;
+    case DMG_F_V: base = o->v[o->vcur]; comps = 2; break;
     default: return dmg_fail(DMG_EINVAL, "field %d has no halo", field);
     }
     size_t row = (size_t)o->grid.W * comps;

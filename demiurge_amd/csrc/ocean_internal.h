@@ -35,6 +35,7 @@ struct dmg_ocean {
     unsigned char *code8 = nullptr;   // 8-neighbour solid bits (divergence, subDiv)
     float *v[2] = { nullptr, nullptr };   // interleaved (vx,vy)
     int vcur = 0;
+    int *oob_flag = nullptr;       // device word: advect out-of-band flag / reduction scratch
     float *rowtab = nullptr;       // ROWTAB_FIELDS arrays of L floats
     const float *jac_cx = nullptr, *jac_cy = nullptr, *jac_beta = nullptr;
     const float *jac_rx = nullptr, *jac_ry = nullptr, *jac_rb = nullptr;

@@ -23,6 +23,8 @@ struct pass_args {
     int scalar_rhs;
     int H;                           // full grid height (advect's texture space)
     int y_first;                     // grid row of local row 0
+    int row_lo;                      // first local row computed by the launch (blockIdx.y = 0)
+    int *oob_flag;                   // advect: set to 1 when a departure point needs rows outside the band's storage
     // pixelsize(st_o).x*.y of the virtual rows y = -1 / y = H: on a non-pole edge offset() leaves st_o.y outside
     // [0,1] (only the texture fetch clamps), so get_velocity()'s d_o is evaluated beyond the grid (:380-381,:392)
     float area_below, area_above;
@@ -56,7 +58,7 @@ __device__ __forceinline__ float2 neg2(float2 v) { return make_float2(-v.x, -v.y
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_divergence(pass_args a)
 {
-    int x = blockIdx.x * blockDim.x + threadIdx.x, l = blockIdx.y;
+    int x = blockIdx.x * blockDim.x + threadIdx.x, l = a.row_lo + blockIdx.y;
     if (x >= a.W) return;
     const int W = a.W, L = a.L;
     nb4 n = neighbours(a, x, l);
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(256) void k_divergence(pass_args a)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_diffusion(pass_args a)
 {
-    int x = blockIdx.x * blockDim.x + threadIdx.x, l = blockIdx.y;
+    int x = blockIdx.x * blockDim.x + threadIdx.x, l = a.row_lo + blockIdx.y;
     if (x >= a.W) return;
     const int W = a.W, L = a.L;
     nb4 n = neighbours(a, x, l);
@@ -118,7 +120,7 @@ __device__ __forceinline__ float glsl_mod(float x, float y) { return __fsub_rn(x
 
 __global__ __launch_bounds__(256) void k_subdiv(pass_args a)
 {
-    int x = blockIdx.x * blockDim.x + threadIdx.x, l = blockIdx.y;
+    int x = blockIdx.x * blockDim.x + threadIdx.x, l = a.row_lo + blockIdx.y;
     if (x >= a.W) return;
     const int W = a.W, L = a.L;
     size_t i = (size_t)l * W + x;
@@ -192,14 +194,17 @@ __device__ __forceinline__ vec3 rotate3(float theta, vec3 u, vec3 v)
     vec3 c2 = v3(u.x * u.z * ic + u.y * s, u.y * u.z * ic - u.x * s, c + u.z * u.z * ic);
     return v3(c0.x * v.x + c1.x * v.y + c2.x * v.z, c0.y * v.x + c1.y * v.y + c2.y * v.z, c0.z * v.x + c1.z * v.y + c2.z * v.z);
 }
-// GL_LINEAR + GL_CLAMP_TO_EDGE fetch of the RG32F velocity texture at (u,v) (reference src/Texture.cpp:29-33)
-__device__ __forceinline__ float2 fetch_linear2(const float2 *t, int W, int H, float u, float v)
+// GL_LINEAR + GL_CLAMP_TO_EDGE fetch of the RG32F velocity texture at (u,v) (reference src/Texture.cpp:29-33).
+// (u,v) address the FULL grid; `t` holds the band's L rows starting at grid row y_first.  A tap outside the stored
+// rows raises *oob (the caller needs more ghost rows) and is clamped so that nothing is read out of bounds.
+__device__ __forceinline__ float2 fetch_linear2(const float2 *t, int W, int H, float u, float v, int y_first, int L, int *oob)
 {
     float fu = u * (float)W - 0.5f, fv = v * (float)H - 0.5f;
     float flu = floorf(fu), flv = floorf(fv);
     float wx = fu - flu, wy = fv - flv;
     int i0 = min(max((int)flu, 0), W - 1), i1 = min(max((int)flu + 1, 0), W - 1);
-    int j0 = min(max((int)flv, 0), H - 1), j1 = min(max((int)flv + 1, 0), H - 1);
+    int j0 = min(max((int)flv, 0), H - 1) - y_first, j1 = min(max((int)flv + 1, 0), H - 1) - y_first;
+    if (j0 < 0 || j1 >= L) { *oob = 1; j0 = min(max(j0, 0), L - 1); j1 = min(max(j1, 0), L - 1); }
     float2 t00 = t[(size_t)j0 * W + i0], t10 = t[(size_t)j0 * W + i1], t01 = t[(size_t)j1 * W + i0], t11 = t[(size_t)j1 * W + i1];
     float ax = t00.x + wx * (t10.x - t00.x), bx = t01.x + wx * (t11.x - t01.x);
     float ay = t00.y + wx * (t10.y - t00.y), by = t01.y + wx * (t11.y - t01.y);
@@ -208,7 +213,7 @@ __device__ __forceinline__ float2 fetch_linear2(const float2 *t, int W, int H, f
 
 __global__ __launch_bounds__(256) void k_advect(pass_args a, float k04)
 {
-    int x = blockIdx.x * blockDim.x + threadIdx.x, l = blockIdx.y;
+    int x = blockIdx.x * blockDim.x + threadIdx.x, l = a.row_lo + blockIdx.y;
     if (x >= a.W) return;
     const int W = a.W;
     size_t i = (size_t)l * W + x;
@@ -226,8 +231,7 @@ __global__ __launch_bounds__(256) void k_advect(pass_args a, float k04)
     cart = rotate3(-arclength, rotdir, cart);                                      // :308
     float lon_n = atan2f(cart.y, cart.x), lat_n = asinf(cart.z);                   // cartesian_to_spheric
     float cu = (lon_n - a.c2) / (a.c3 - a.c2), cv = (lat_n - a.c0) / (a.c1 - a.c0);   // spheric_to_tex
-    // single-band only: the whole velocity field is local, row index = grid row
-    float2 nv = fetch_linear2(a.vin, W, a.H, cu, cv);                              // :315
+    float2 nv = fetch_linear2(a.vin, W, a.H, cu, cv, a.y_first, a.L, a.oob_flag);  // :315
     vec3 par_n, yc_n;
     tangent_basis(lon_n, lat_n, &par_n, &yc_n);
     vec3 testv = v3(par_n.x * nv.x + yc_n.x * nv.y, par_n.y * nv.x + yc_n.y * nv.y, par_n.z * nv.x + yc_n.z * nv.y);
@@ -295,6 +299,7 @@ static pass_args make_args(dmg_ocean *o)
     a.wind = o->prm.wind; a.circumference = o->grid.circumference;
     a.c0 = o->grid.coords[0]; a.c1 = o->grid.coords[1]; a.c2 = o->grid.coords[2]; a.c3 = o->grid.coords[3];
     a.scalar_rhs = (o->prm.quirks & DMG_QUIRK_DIFFUSION_SCALAR_RHS) ? 1 : 0;
+    a.oob_flag = o->oob_flag;
     a.l_south_clamp = (!o->topo.spole && o->y0 == 0) ? o->gs : -1;
     a.l_north_clamp = (!o->topo.npole && o->y1 == o->grid.H) ? o->gs + (o->y1 - o->y0) - 1 : -1;
     float dx, dy;
@@ -305,11 +310,22 @@ static pass_args make_args(dmg_ocean *o)
     return a;
 }
 
-static int require_single_band(dmg_ocean *o, const char *what)
+static int require_terrain(dmg_ocean *o, const char *what)
 {
     if (!o) return dmg_fail(DMG_EINVAL, "%s: null handle", what);
     if (!o->have_terrain) return dmg_fail(DMG_ESTATE, "%s: dmg_ocean_set_terrain must come first", what);
-    if (o->count != 1) return dmg_fail(DMG_EINVAL, "%s: single-band (band_count == 1) in this build", what);
+    DMG_HIP(hipSetDevice(o->ctx->device));
+    return DMG_OK;
+}
+
+template <typename K, typename... A>
+static int launch_rows(dmg_ocean *o, K kernel, pass_args a, int lo, int hi, A... extra)
+{
+    if (hi <= lo) return DMG_OK;
+    a.row_lo = lo;
+    dim3 grid((a.W + 255) / 256, hi - lo);
+    hipLaunchKernelGGL(kernel, grid, dim3(256), 0, o->ctx->stream, a, extra...);
+    DMG_HIP(hipGetLastError());
     return DMG_OK;
 }
 
@@ -322,7 +338,40 @@ int ocean_build_codes8(dmg_ocean *o)
     return DMG_OK;
 }
 
+// max |v|^2 over the owned rows (non-negative floats order like their bit patterns)
+__global__ void k_max_speed2(const float2 *__restrict__ v, size_t n, unsigned *__restrict__ out)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float m = 0.0f;
+    for (; i < n; i += (size_t)gridDim.x * blockDim.x) { float2 a = v[i]; m = fmaxf(m, a.x * a.x + a.y * a.y); }
+    for (int d = 32; d > 0; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+
 extern "C" {
+
+// Rows of velocity halo the next dmg_ocean_advect of THIS band needs: the back-trace travels |v|*timestep km
+// (OceanCurrents.cpp:298-299) = that many / (circumference/(2H)) rows (H rows span half the circumference on a
+// full globe; other extents scale by their latitude range), plus the bilinear footprint.
+int dmg_ocean_advect_reach(dmg_ocean *o, int *rows)
+{
+    DMG_CHECK_ARG(o != nullptr && rows != nullptr);
+    DMG_HIP(hipSetDevice(o->ctx->device));
+    DMG_HIP(hipMemsetAsync(o->oob_flag, 0, sizeof(int), o->ctx->stream));
+    size_t n = (size_t)(o->y1 - o->y0) * o->grid.W;
+    hipLaunchKernelGGL(k_max_speed2, dim3(1024), dim3(256), 0, o->ctx->stream,
+                       (const float2 *)o->v[o->vcur] + (size_t)o->gs * o->grid.W, n, (unsigned *)o->oob_flag);
+    DMG_HIP(hipGetLastError());
+    unsigned bits = 0;
+    DMG_HIP(hipMemcpyAsync(&bits, o->oob_flag, sizeof bits, hipMemcpyDeviceToHost, o->ctx->stream));
+    DMG_HIP(hipStreamSynchronize(o->ctx->stream));
+    float m2;
+    memcpy(&m2, &bits, sizeof m2);
+    double km = sqrt((double)m2) * o->prm.timestep_h;
+    double row_km = (double)(o->grid.coords[1] - o->grid.coords[0]) / (2.0 * M_PI) * o->grid.circumference / o->grid.H;
+    *rows = (int)ceil(km / row_km) + 2;
+    return DMG_OK;
+}
 
 int dmg_ocean_set_velocity(dmg_ocean *o, const float *vx, const float *vy)
 {
@@ -335,27 +384,29 @@ int dmg_ocean_set_velocity(dmg_ocean *o, const float *vx, const float *vy)
     return DMG_OK;
 }
 
+// Band semantics of the passes (band_count > 1): a pass computes every local row whose inputs are valid, given that
+// the host has refreshed the ghost rows of the input field(s) to full depth (dmg_ocean_halo) beforehand:
+//   advect      owned rows                (gathers v anywhere inside the stored rows; fails if it needs more)
+//   diffusion   n <= ghost sweeps, region shrinking one row per sweep like dmg_ocean_jacobi_sweeps
+//   divergence  local rows [1, L-1) on interior sides, so divw is valid ghost-1 rows deep for the Jacobi halo
+//   subDiv      owned rows                (needs 1 row of pressure halo)
 int dmg_ocean_divergence(dmg_ocean *o)
 {
-    int rc = require_single_band(o, "dmg_ocean_divergence");
+    int rc = require_terrain(o, "dmg_ocean_divergence");
     if (rc) return rc;
-    pass_args a = make_args(o);
-    dim3 grid((a.W + 255) / 256, a.L);
-    hipLaunchKernelGGL(k_divergence, grid, dim3(256), 0, o->ctx->stream, a);
-    DMG_HIP(hipGetLastError());
-    return DMG_OK;
+    return launch_rows(o, k_divergence, make_args(o), o->gs ? 1 : 0, o->L - (o->gn ? 1 : 0));
 }
 
 int dmg_ocean_diffusion(dmg_ocean *o, int iters)
 {
-    int rc = require_single_band(o, "dmg_ocean_diffusion");
+    int rc = require_terrain(o, "dmg_ocean_diffusion");
     if (rc) return rc;
     DMG_CHECK_ARG(iters >= 0);
-    for (int it = 0; it < iters; it++) {                   // :701-707
-        pass_args a = make_args(o);
-        dim3 grid((a.W + 255) / 256, a.L);
-        hipLaunchKernelGGL(k_diffusion, grid, dim3(256), 0, o->ctx->stream, a);
-        DMG_HIP(hipGetLastError());
+    if (o->count > 1 && iters > o->ghost)
+        return dmg_fail(DMG_EINVAL, "%d diffusion sweeps between halo refreshes but only %d ghost rows", iters, o->ghost);
+    for (int k = 1; k <= iters; k++) {                    // :701-707
+        rc = launch_rows(o, k_diffusion, make_args(o), o->gs ? k : 0, o->L - (o->gn ? k : 0));
+        if (rc) return rc;
         o->vcur ^= 1;                                      // v_scratch->swap(v)
     }
     return DMG_OK;
@@ -363,34 +414,43 @@ int dmg_ocean_diffusion(dmg_ocean *o, int iters)
 
 int dmg_ocean_subdiv(dmg_ocean *o)
 {
-    int rc = require_single_band(o, "dmg_ocean_subdiv");
+    int rc = require_terrain(o, "dmg_ocean_subdiv");
     if (rc) return rc;
-    pass_args a = make_args(o);
-    dim3 grid((a.W + 255) / 256, a.L);
-    hipLaunchKernelGGL(k_subdiv, grid, dim3(256), 0, o->ctx->stream, a);
-    DMG_HIP(hipGetLastError());
+    rc = launch_rows(o, k_subdiv, make_args(o), o->gs, o->gs + (o->y1 - o->y0));
+    if (rc) return rc;
     o->vcur ^= 1;                                          // v->swap(v_scratch) (:621)
     return DMG_OK;
 }
 
 int dmg_ocean_advect(dmg_ocean *o)
 {
-    int rc = require_single_band(o, "dmg_ocean_advect");
+    int rc = require_terrain(o, "dmg_ocean_advect");
     if (rc) return rc;
     pass_args a = make_args(o);
     float k04 = powf(0.4f, 1.0f / 24.0f);                  // pow(vec2(0.4),vec2(1.0/24)) (:348), a constant
-    dim3 grid((a.W + 255) / 256, a.L);
-    hipLaunchKernelGGL(k_advect, grid, dim3(256), 0, o->ctx->stream, a, k04);
-    DMG_HIP(hipGetLastError());
+    if (o->count > 1) DMG_HIP(hipMemsetAsync(o->oob_flag, 0, sizeof(int), o->ctx->stream));
+    rc = launch_rows(o, k_advect, a, o->gs, o->gs + (o->y1 - o->y0), k04);
+    if (rc) return rc;
     o->vcur ^= 1;                                          // v->swap(v_scratch) (:359)
+    if (o->count > 1) {                                    // did a departure point leave the stored rows?
+        int flag = 0;
+        DMG_HIP(hipMemcpyAsync(&flag, o->oob_flag, sizeof(int), hipMemcpyDeviceToHost, o->ctx->stream));
+        DMG_HIP(hipStreamSynchronize(o->ctx->stream));
+        if (flag)
+            return dmg_fail(DMG_EINVAL, "advect: a departure point lies more than %d rows outside the band; create the "
+                                        "ocean with ghost >= dmg_ocean_advect_reach()", o->ghost);
+    }
     return DMG_OK;
 }
 
 // OceanCurrents::run body (:155-209)
 int dmg_ocean_step(dmg_ocean *o, int n_outer)
 {
-    int rc = require_single_band(o, "dmg_ocean_step");
+    int rc = require_terrain(o, "dmg_ocean_step");
     if (rc) return rc;
+    if (o->count != 1)
+        return dmg_fail(DMG_EINVAL, "dmg_ocean_step is the single-band form; with bands the host interleaves the "
+                                    "passes with halo refreshes (demiurge_amd/bands.py ocean_step)");
     DMG_CHECK_ARG(n_outer >= 0);
     for (int j = 0; j < n_outer; j++) {
         if ((rc = dmg_ocean_advect(o))) return rc;                                  // :158

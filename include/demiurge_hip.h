@@ -78,8 +78,8 @@ enum { DMG_JACOBI_AUTO = 0, DMG_JACOBI_SINGLE = 1, DMG_JACOBI_BLOCKED = 2 };
 /* the reference's `float bC = texture(v,st).r` adds v.x to BOTH components in velocity diffusion (:687,:693) */
 #define DMG_QUIRK_DIFFUSION_SCALAR_RHS 1
 
-/* field ids for dmg_ocean_halo / dmg_ocean_device_ptr */
-enum { DMG_F_PRESSURE = 0, DMG_F_DIVW = 1, DMG_F_TERRAIN = 2, DMG_F_VX = 3, DMG_F_VY = 4 };
+/* field ids for dmg_ocean_halo */
+enum { DMG_F_PRESSURE = 0, DMG_F_DIVW = 1, DMG_F_TERRAIN = 2, DMG_F_V = 3 /* interleaved (vx,vy), 8 B per cell */ };
 enum { DMG_SIDE_SOUTH = 0, DMG_SIDE_NORTH = 1 };   /* south = towards row 0 */
 
 /* ---- library / context ------------------------------------------------- */
@@ -143,13 +143,19 @@ int dmg_ocean_counters(dmg_ocean *o, long long *jacobi_launches, long long *jaco
 int dmg_ocean_halo(dmg_ocean *o, int field, int side, int rows, void **send, void **recv, size_t *bytes);
 
 /* OceanCurrents::run body (:155-209) n_outer times: advect -> diffusion -> divergence -> jacobi -> subDiv
- * (the WIP `resize(600,200)` :207 and `while(true)` :212 are not replicated).  band_count == 1 only. */
+ * (the WIP `resize(600,200)` :207 and `while(true)` :212 are not replicated).  band_count == 1 only; with bands the
+ * host interleaves the passes below with halo refreshes (demiurge_amd/bands.py ocean_step shows the order). */
 int dmg_ocean_step(dmg_ocean *o, int n_outer);
-/* the individual passes (band_count == 1), each leaving its result in the field the reference leaves it in */
+/* The individual passes, each leaving its result in the field the reference leaves it in.  With bands a pass
+ * computes every local row whose inputs are valid, assuming the host refreshed the input field's ghost rows:
+ * advect/subDiv -> owned rows; diffusion -> iters <= ghost sweeps with the region shrinking a row per sweep;
+ * divergence -> all local rows but the outermost ghost row (so divw is valid ghost-1 rows deep for the Jacobi). */
 int dmg_ocean_advect(dmg_ocean *o);                            /* :235-360  v <- advect(v) */
 int dmg_ocean_diffusion(dmg_ocean *o, int iters);              /* :625-708  v <- diffuse(v) */
 int dmg_ocean_divergence(dmg_ocean *o);                        /* :363-435  divw <- div(v) */
 int dmg_ocean_subdiv(dmg_ocean *o);                            /* :511-622  v <- v - grad p, coastline snapping */
+/* rows of velocity halo this band's next advect needs (back-trace distance |v|*timestep, :298-299) */
+int dmg_ocean_advect_reach(dmg_ocean *o, int *rows);
 
 /* Results back to the host (Texture::uploadData side of the adapter): owned rows only are written,
  * into FULL-grid arrays at their grid position (so ranks can fill one array); NULL skips a field. */

@@ -54,7 +54,7 @@ class FakeOcean:
         return self.p[self.gs:self.gs + (self.y1 - self.y0)]
 
 
-def worker(rank, world, port, mode, W, H, sweeps, ghost, outdir):
+def worker(rank, world, port, mode, W, H, sweeps, ghost, outdir, step=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist
     from demiurge_amd import bands, synth
@@ -76,9 +76,22 @@ def worker(rank, world, port, mode, W, H, sweeps, ghost, outdir):
         oc.set_terrain(img)
         oc.set_divw(divw)
         exch = bands.HaloExchanger(dist, rank, world, torch.device("cuda", 0))
-        bands.jacobi_solve(oc, exch, sweeps, ghost)
-        full = oc.get(want=("pressure",))["pressure"]
-        mine = full[H * rank // world:H * (rank + 1) // world]
+        lo, hi = H * rank // world, H * (rank + 1) // world
+        if step is None:
+            bands.jacobi_solve(oc, exch, sweeps, ghost)
+            mine = oc.get(want=("pressure",))["pressure"][lo:hi]
+        else:                                           # full outer ocean step(s): (n_outer, jacobi_iters, diffusion_iters)
+            oc.close()
+            prm = capi.default_ocean_params()
+            prm.jacobi_iters, prm.diffusion_iters = step[1], step[2]
+            oc = capi.Ocean(ctx, capi.make_grid(W, H), params=prm, band_rank=rank, band_count=world, ghost=ghost)
+            oc.set_terrain(img)
+            v0 = synth.velocity(W, H)
+            v0[img > 0] = 0
+            oc.set_velocity(v0)
+            bands.ocean_step(oc, exch, step[0])
+            r = oc.get(want=("v", "pressure"))
+            mine = np.concatenate([r["v"][lo:hi], r["pressure"][lo:hi, :, None]], axis=2)
         oc.close()
         ctx.close()
     np.save(os.path.join(outdir, "band%d.npy" % rank), mine)

@@ -16,12 +16,12 @@ def free_port():
     return p
 
 
-def run_bands(mode, world, W, H, sweeps, ghost, tmp_path):
+def run_bands(mode, world, W, H, sweeps, ghost, tmp_path, step=None):
     import torch.multiprocessing as mp
     import sys
     sys.path.insert(0, str(ROOT / "tests"))
     import band_worker
-    mp.spawn(band_worker.worker, args=(world, free_port(), mode, W, H, sweeps, ghost, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(band_worker.worker, args=(world, free_port(), mode, W, H, sweeps, ghost, str(tmp_path), step), nprocs=world, join=True)
     return np.concatenate([np.load(tmp_path / ("band%d.npy" % r)) for r in range(world)], axis=0)
 
 
@@ -42,4 +42,28 @@ def test_bands_gloo_hip_ranks_share_gpu(oracle, tmp_path, world, ghost, sweeps):
     W, H = 512, 256
     got = run_bands("hip", world, W, H, sweeps, ghost, tmp_path)
     ref = oracle.ocean_jacobi(oracle.grid(W, H), synth.terrain(W, H), synth.divw(W, H), sweeps, rows=True)
+    assert np.array_equal(got, ref)
+
+
+@pytest.mark.gpu
+def test_ocean_step_bands_gloo_hip(tmp_path):
+    """the whole outer ocean step (advect, 50x diffusion, divergence, Jacobi, subDiv) on 3 bands = one band, bitwise"""
+    from demiurge_amd import capi, synth
+    W, H, ghost = 512, 192, 16
+    step = (2, 40, 20)
+    got = run_bands("hip", 3, W, H, 0, ghost, tmp_path, step=step)
+    ctx = capi.Context(0)
+    prm = capi.default_ocean_params()
+    prm.jacobi_iters, prm.diffusion_iters = step[1], step[2]
+    o = capi.Ocean(ctx, capi.make_grid(W, H), params=prm)
+    img = synth.terrain(W, H)
+    v0 = synth.velocity(W, H)
+    v0[img > 0] = 0
+    o.set_terrain(img)
+    o.set_velocity(v0)
+    o.step(step[0])
+    r = o.get(want=("v", "pressure"))
+    ref = np.concatenate([r["v"], r["pressure"][:, :, None]], axis=2)
+    o.close()
+    ctx.close()
     assert np.array_equal(got, ref)

@@ -130,3 +130,79 @@ def test_outer_step_config3_size_runs(dev):
     assert not r["v"][img > 0].any() and not r["pressure"][img > 0].any()
     assert np.abs(r["v"]).max() > 0
     o.close()
+
+
+def test_band_passes_fake_cluster(dev):
+    """latitude bands of the full outer step on one GPU (halo slabs moved with dmg_copy_device) == one band, bitwise;
+    and advect reports a departure point beyond its ghost rows instead of reading garbage"""
+    capi, ctx = dev
+    from demiurge_amd import synth
+    W, H, NB, G = 512, 256, 4, 16
+    grid = capi.make_grid(W, H)
+    img = synth.terrain(W, H)
+    v0 = synth.velocity(W, H)
+    v0[img > 0] = 0
+    prm = capi.default_ocean_params()
+    prm.jacobi_iters, prm.diffusion_iters = 24, 20
+
+    one = capi.Ocean(ctx, grid, params=prm)
+    one.set_terrain(img)
+    one.set_velocity(v0)
+    one.step(1)
+    ref = one.get()
+    one.close()
+
+    oc = [capi.Ocean(ctx, grid, params=prm, band_rank=r, band_count=NB, ghost=G) for r in range(NB)]
+    for o in oc:
+        o.set_terrain(img)
+        o.set_velocity(v0)
+
+    def exchange(field, rows=G):
+        for r in range(NB - 1):
+            s_send, s_recv, nb = oc[r].halo(field, capi.SIDE_NORTH, rows)
+            n_send, n_recv, nb2 = oc[r + 1].halo(field, capi.SIDE_SOUTH, rows)
+            assert nb == nb2 and nb == rows * W * (8 if field == capi.F_V else 4)
+            ctx.copy_device(n_recv, s_send, nb)
+            ctx.copy_device(s_recv, n_send, nb)
+
+    assert max(o.advect_reach() for o in oc) <= G
+    exchange(capi.F_V)
+    for o in oc:
+        o.advect()
+    done = 0
+    while done < prm.diffusion_iters:
+        n = min(G, prm.diffusion_iters - done)
+        exchange(capi.F_V)
+        for o in oc:
+            o.diffusion(n)
+        done += n
+    exchange(capi.F_V)
+    for o in oc:
+        o.divergence()
+        o.zero_pressure()
+    done = 0
+    while done < prm.jacobi_iters:
+        n = min(G, prm.jacobi_iters - done)
+        exchange(capi.F_PRESSURE)
+        for o in oc:
+            o.jacobi_sweeps(n)
+        done += n
+    exchange(capi.F_PRESSURE)
+    for o in oc:
+        o.subdiv()
+    got = {}
+    for o in oc:
+        o.get(out=got)
+    for k in ("vx", "vy", "pressure", "divw"):
+        assert np.array_equal(got[k], ref[k]), k
+
+    # a fast current needs more halo than a 2-row ghost: loud error, not silent garbage
+    small = capi.Ocean(ctx, grid, params=prm, band_rank=1, band_count=NB, ghost=2)
+    small.set_terrain(img)
+    small.set_velocity(v0 * 30)
+    assert small.advect_reach() > 2
+    with pytest.raises(capi.DmgError):
+        small.advect()
+    small.close()
+    for o in oc:
+        o.close()
