@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--width", type=int, default=16384)
     ap.add_argument("--height", type=int, default=8192)
     ap.add_argument("--sweeps", type=int, default=5000, help="Jacobi sweeps per solve (reference: 5000)")
-    ap.add_argument("--ghost", type=int, default=16, help="ghost rows per band side = sweeps between halo exchanges")
+    ap.add_argument("--ghost", type=int, default=32, help="ghost rows per band side = sweeps between halo exchanges")
     ap.add_argument("--kernel", choices=["auto", "single", "blocked"], default="auto",
                     help="Jacobi kernel: one sweep per launch, or 8 sweeps per launch temporally blocked (bit-identical)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -98,6 +98,8 @@ def lib():
         "dmg_blur": (c_int, [vp, PG, vp, c_float]),
         "dmg_temperature_steps": (c_int, [vp, PG, vp, vp, c_int, c_int]),
         "dmg_erosion_pass": (c_int, [vp, PG, vp, vp, vp, c_float, c_float]),
+        "dmg_flow_accumulate": (c_int, [vp, PG, vp, vp, c_float, c_float, c_int, vp]),
+        "dmg_erosion_run": (c_int, [vp, PG, vp, c_int, c_int, c_float, c_float, c_float]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)          # AttributeError if the library does not export a declared symbol
@@ -183,6 +185,24 @@ class Context:
         flow, updrift = _f32(flow), _f32(updrift)
         check(lib().dmg_erosion_pass(self.h, ctypes.byref(grid), _p(h), _p(flow), _p(updrift), factor, slope_exponent))
         return h
+
+
+def _ctx_flow_accumulate(self, grid, h, preblur=0.5, exponent=1.0, sel=None, lakes=0):
+    h = _f32(h)
+    sel = None if sel is None else _f32(sel)
+    out = np.empty_like(h)
+    check(lib().dmg_flow_accumulate(self.h, ctypes.byref(grid), _p(h), _p(sel), preblur, exponent, lakes, _p(out)))
+    return out
+
+
+def _ctx_erosion_run(self, grid, h, N=50, iters=150, exponent=0.5, slope_exponent=1.0, factor=1.0):
+    h = _f32(h).copy()
+    check(lib().dmg_erosion_run(self.h, ctypes.byref(grid), _p(h), N, iters, exponent, slope_exponent, factor))
+    return h
+
+
+Context.flow_accumulate = _ctx_flow_accumulate
+Context.erosion_run = _ctx_erosion_run
 
 
 def default_ocean_params():

@@ -1,0 +1,102 @@
+// Device-side restatement of the GLSL canvas helpers shared by filters.hip and flow.hip: offset()
+// (reference src/Shader.h:82-98) and the texture unit (GL_LINEAR / GL_NEAREST + CLAMP_TO_EDGE, src/Texture.cpp:29-33).
+#pragma once
+#include "dmg_internal.h"
+
+struct canvas {
+    int W, H;
+    float c0, c1, c2, c3, circumference;
+    int lonwrap, spole, npole;
+};
+
+static inline canvas make_canvas(const dmg_grid &g, const dmg_topology &t)
+{
+    canvas c;
+    c.W = g.W; c.H = g.H;
+    c.c0 = g.coords[0]; c.c1 = g.coords[1]; c.c2 = g.coords[2]; c.c3 = g.coords[3];
+    c.circumference = g.circumference;
+    c.lonwrap = t.lonwrap; c.spole = t.spole; c.npole = t.npole;
+    return c;
+}
+
+__device__ __forceinline__ float d_mod(float x, float y) { return __fsub_rn(x, __fmul_rn(y, floorf(__fdiv_rn(x, y)))); }
+
+// offset(p, dp, resolution)  (reference src/Shader.h:82-98), statement by statement in fp32
+__device__ __forceinline__ void d_offset(const canvas &c, float px, float py, float dpx, float dpy, float *ox, float *oy)
+{
+    const float two_pi = 2.0f * DMG_PI;
+    px = __fadd_rn(px, __fdiv_rn(dpx, (float)c.W));
+    py = __fadd_rn(py, __fdiv_rn(dpy, (float)c.H));
+    if (c.lonwrap) px = d_mod(__fadd_rn(px, 1.0f), 1.0f);
+    if (c.spole && py < 0.0f) {
+        py = -py;
+        px = __fsub_rn(d_mod(__fadd_rn(__fadd_rn(__fmul_rn(px, __fsub_rn(c.c3, c.c2)), c.c2), two_pi), two_pi), DMG_PI);
+        px = __fdiv_rn(__fsub_rn(px, c.c2), __fsub_rn(c.c3, c.c2));
+    }
+    if (c.npole && py > 1.0f) {
+        py = __fsub_rn(2.0f, py);
+        px = __fsub_rn(d_mod(__fadd_rn(__fadd_rn(__fmul_rn(px, __fsub_rn(c.c3, c.c2)), c.c2), two_pi), two_pi), DMG_PI);
+        px = __fdiv_rn(__fsub_rn(px, c.c2), __fsub_rn(c.c3, c.c2));
+    }
+    if (c.lonwrap) px = d_mod(__fadd_rn(px, 1.0f), 1.0f);
+    *ox = px; *oy = py;
+}
+
+__device__ __forceinline__ float d_fetch_nearest(const float *t, int W, int H, float u, float v)
+{
+    int i = min(max((int)floorf(__fmul_rn(u, (float)W)), 0), W - 1);
+    int j = min(max((int)floorf(__fmul_rn(v, (float)H)), 0), H - 1);
+    return t[(size_t)j * W + i];
+}
+
+__device__ __forceinline__ float d_fetch_linear(const float *t, int W, int H, float u, float v)
+{
+    float fu = __fsub_rn(__fmul_rn(u, (float)W), 0.5f), fv = __fsub_rn(__fmul_rn(v, (float)H), 0.5f);
+    float flu = floorf(fu), flv = floorf(fv);
+    float wx = __fsub_rn(fu, flu), wy = __fsub_rn(fv, flv);
+    int i0 = min(max((int)flu, 0), W - 1), i1 = min(max((int)flu + 1, 0), W - 1);
+    int j0 = min(max((int)flv, 0), H - 1), j1 = min(max((int)flv + 1, 0), H - 1);
+    float t00 = t[(size_t)j0 * W + i0], t10 = t[(size_t)j0 * W + i1], t01 = t[(size_t)j1 * W + i0], t11 = t[(size_t)j1 * W + i1];
+    float a = __fadd_rn(t00, __fmul_rn(wx, __fsub_rn(t10, t00)));
+    float b = __fadd_rn(t01, __fmul_rn(wx, __fsub_rn(t11, t01)));
+    return __fadd_rn(a, __fmul_rn(wy, __fsub_rn(b, a)));
+}
+
+__device__ __forceinline__ float d_stx(const canvas &c, int x) { return __fdiv_rn(__fadd_rn((float)x, 0.5f), (float)c.W); }
+__device__ __forceinline__ float d_sty(const canvas &c, int y) { return __fdiv_rn(__fadd_rn((float)y, 0.5f), (float)c.H); }
+
+
+// device-resident Gaussian blur (Blur::Blur + Blur::step, reference src/filter/BlurMenu.cpp:24-117): blurs d_field
+// (W*H floats) in place, d_tmp is W*H floats of workspace.  Asynchronous on the context's stream.
+int blur_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, float *d_field, float *d_tmp, float radius);
+
+// device-resident flow accumulation (flow.hip) and erosion pass (filters.hip), used by dmg_erosion_run
+int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, const float *d_h, const float *d_sel,
+                float preblur, float exponent, float *d_flow);
+int erosion_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, const float *d_h, const float *d_flow,
+                   const float *d_updrift, float *d_out, const float *d_dx, const float *d_dy, float factor, float slope_exponent);
+
+namespace {
+struct dev_buf {
+    void *p = nullptr;
+    ~dev_buf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc(&p, n); }
+    float *f() const { return (float *)p; }
+    int *i() const { return (int *)p; }
+};
+}  // namespace
+
+#define DMG_ALLOC(buf, bytes)                                                                      \
+    do {                                                                                           \
+        hipError_t _e = (buf).alloc(bytes);                                                        \
+        if (_e != hipSuccess) return dmg_fail(DMG_ENOMEM, "hipMalloc(%zu) failed: %s", (size_t)(bytes), hipGetErrorString(_e)); \
+    } while (0)
+
+template <typename T>
+static inline int upload_vec(dmg_ctx *ctx, dev_buf &d, const std::vector<T> &v)
+{
+    DMG_ALLOC(d, v.size() * sizeof(T) + 16);
+    DMG_HIP(hipMemcpyAsync(d.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    DMG_HIP(hipStreamSynchronize(ctx->stream));      // `v` is a host temporary
+    return DMG_OK;
+}

@@ -8,70 +8,8 @@
 // texel each tap hits is the one the reference hits.  Row-constant transcendental factors (cos(lat)) come from the
 // host in fp32, exactly as in the ocean kernels; the per-row insolation of the climate step is evaluated on the
 // device (sin/cos/asin/acos/tan of device libm: a few ulp from glibc).
-#include "dmg_internal.h"
+#include "canvas.h"
 #include <algorithm>
-
-struct canvas {
-    int W, H;
-    float c0, c1, c2, c3, circumference;
-    int lonwrap, spole, npole;
-};
-
-static canvas make_canvas(const dmg_grid &g, const dmg_topology &t)
-{
-    canvas c;
-    c.W = g.W; c.H = g.H;
-    c.c0 = g.coords[0]; c.c1 = g.coords[1]; c.c2 = g.coords[2]; c.c3 = g.coords[3];
-    c.circumference = g.circumference;
-    c.lonwrap = t.lonwrap; c.spole = t.spole; c.npole = t.npole;
-    return c;
-}
-
-__device__ __forceinline__ float d_mod(float x, float y) { return __fsub_rn(x, __fmul_rn(y, floorf(__fdiv_rn(x, y)))); }
-
-// offset(p, dp, resolution)  (reference src/Shader.h:82-98), statement by statement in fp32
-__device__ __forceinline__ void d_offset(const canvas &c, float px, float py, float dpx, float dpy, float *ox, float *oy)
-{
-    const float two_pi = 2.0f * DMG_PI;
-    px = __fadd_rn(px, __fdiv_rn(dpx, (float)c.W));
-    py = __fadd_rn(py, __fdiv_rn(dpy, (float)c.H));
-    if (c.lonwrap) px = d_mod(__fadd_rn(px, 1.0f), 1.0f);
-    if (c.spole && py < 0.0f) {
-        py = -py;
-        px = __fsub_rn(d_mod(__fadd_rn(__fadd_rn(__fmul_rn(px, __fsub_rn(c.c3, c.c2)), c.c2), two_pi), two_pi), DMG_PI);
-        px = __fdiv_rn(__fsub_rn(px, c.c2), __fsub_rn(c.c3, c.c2));
-    }
-    if (c.npole && py > 1.0f) {
-        py = __fsub_rn(2.0f, py);
-        px = __fsub_rn(d_mod(__fadd_rn(__fadd_rn(__fmul_rn(px, __fsub_rn(c.c3, c.c2)), c.c2), two_pi), two_pi), DMG_PI);
-        px = __fdiv_rn(__fsub_rn(px, c.c2), __fsub_rn(c.c3, c.c2));
-    }
-    if (c.lonwrap) px = d_mod(__fadd_rn(px, 1.0f), 1.0f);
-    *ox = px; *oy = py;
-}
-
-__device__ __forceinline__ float d_fetch_nearest(const float *t, int W, int H, float u, float v)
-{
-    int i = min(max((int)floorf(__fmul_rn(u, (float)W)), 0), W - 1);
-    int j = min(max((int)floorf(__fmul_rn(v, (float)H)), 0), H - 1);
-    return t[(size_t)j * W + i];
-}
-
-__device__ __forceinline__ float d_fetch_linear(const float *t, int W, int H, float u, float v)
-{
-    float fu = __fsub_rn(__fmul_rn(u, (float)W), 0.5f), fv = __fsub_rn(__fmul_rn(v, (float)H), 0.5f);
-    float flu = floorf(fu), flv = floorf(fv);
-    float wx = __fsub_rn(fu, flu), wy = __fsub_rn(fv, flv);
-    int i0 = min(max((int)flu, 0), W - 1), i1 = min(max((int)flu + 1, 0), W - 1);
-    int j0 = min(max((int)flv, 0), H - 1), j1 = min(max((int)flv + 1, 0), H - 1);
-    float t00 = t[(size_t)j0 * W + i0], t10 = t[(size_t)j0 * W + i1], t01 = t[(size_t)j1 * W + i0], t11 = t[(size_t)j1 * W + i1];
-    float a = __fadd_rn(t00, __fmul_rn(wx, __fsub_rn(t10, t00)));
-    float b = __fadd_rn(t01, __fmul_rn(wx, __fsub_rn(t11, t01)));
-    return __fadd_rn(a, __fmul_rn(wy, __fsub_rn(b, a)));
-}
-
-__device__ __forceinline__ float d_stx(const canvas &c, int x) { return __fdiv_rn(__fadd_rn((float)x, 0.5f), (float)c.W); }
-__device__ __forceinline__ float d_sty(const canvas &c, int y) { return __fdiv_rn(__fadd_rn((float)y, 0.5f), (float)c.H); }
 
 // ---------------------------------------------------------------------------------------------------------------
 // blur13 (BlurMenu.cpp:41-62): 7 bilinear taps along `direction`, x offsets divided by cos(|lat|)
@@ -226,26 +164,39 @@ __global__ __launch_bounds__(256) void k_erosion(canvas c, const float *__restri
 // ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
-namespace {
-struct dev_buf {
-    void *p = nullptr;
-    ~dev_buf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t n) { return hipMalloc(&p, n); }
-    float *f() const { return (float *)p; }
-};
-}  // namespace
+static int upload_rows(dmg_ctx *ctx, dev_buf &d, const std::vector<float> &v) { return upload_vec(ctx, d, v); }
 
-#define DMG_ALLOC(buf, bytes)                                                                      \
-    do {                                                                                           \
-        hipError_t _e = (buf).alloc(bytes);                                                        \
-        if (_e != hipSuccess) return dmg_fail(DMG_ENOMEM, "hipMalloc(%zu) failed: %s", (size_t)(bytes), hipGetErrorString(_e)); \
-    } while (0)
-
-static int upload_rows(dmg_ctx *ctx, dev_buf &d, const std::vector<float> &v)
+int blur_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, float *d_field, float *d_tmp, float radius)
 {
-    DMG_ALLOC(d, v.size() * sizeof(float));
-    DMG_HIP(hipMemcpyAsync(d.p, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    DMG_HIP(hipStreamSynchronize(ctx->stream));      // `v` is a host temporary
+    canvas c = make_canvas(grid, topo);
+    std::vector<float> pf(grid.H);
+    for (int y = 0; y < grid.H; y++) pf[y] = cosf(fabsf(dmg_row_lat(grid, y)));   // BlurMenu.cpp:49
+    dev_buf dpf;
+    int rc = upload_rows(ctx, dpf, pf);
+    if (rc) return rc;
+    std::vector<float> rl = blur_rlist(radius);
+    dim3 g((grid.W + 255) / 256, grid.H);
+    size_t i = 0;
+    do {                                             // Blur::step (:97-117)
+        hipLaunchKernelGGL(k_blur13, g, dim3(256), 0, ctx->stream, c, d_field, d_tmp, dpf.f(), 0.0f, rl[i]);   // (0, r)
+        hipLaunchKernelGGL(k_blur13, g, dim3(256), 0, ctx->stream, c, d_tmp, d_field, dpf.f(), rl[i], 0.0f);   // (r, 0)
+        DMG_HIP(hipGetLastError());
+        i++;
+    } while (!(i > rl.size() - 1));                  // `i>rlist.size()-1` (:111)
+    DMG_HIP(hipStreamSynchronize(ctx->stream));      // dpf is released on return
+    return DMG_OK;
+}
+
+int erosion_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, const float *d_h, const float *d_flow,
+                   const float *d_updrift, float *d_out, const float *d_dx, const float *d_dy, float factor, float slope_exponent)
+{
+    canvas c = make_canvas(grid, topo);
+    float SLOPE = tanf(DMG_PI / 2.0f / 3.0f);        // tan(M_PI/2/3), 30 degrees (cpufilter.cpp:191)
+    float pow01 = powf(0.1f, slope_exponent);        // pow(0.1, slope_exponent): a constant of the pass
+    dim3 g((grid.W + 255) / 256, grid.H);
+    hipLaunchKernelGGL(k_erosion, g, dim3(256), 0, ctx->stream, c, d_h, d_flow, d_updrift, d_out, d_dx, d_dy,
+                       factor, slope_exponent, SLOPE, pow01);
+    DMG_HIP(hipGetLastError());
     return DMG_OK;
 }
 
@@ -258,23 +209,11 @@ int dmg_blur(dmg_ctx *ctx, const dmg_grid *grid, float *field, float radius)
     int rc = dmg_check_grid(grid, &topo);
     if (rc) return rc;
     DMG_HIP(hipSetDevice(ctx->device));
-    canvas c = make_canvas(*grid, topo);
     const size_t n = (size_t)grid->W * grid->H;
-    std::vector<float> pf(grid->H);
-    for (int y = 0; y < grid->H; y++) pf[y] = cosf(fabsf(dmg_row_lat(*grid, y)));   // BlurMenu.cpp:49
-    dev_buf t1, t2, dpf;
+    dev_buf t1, t2;
     DMG_ALLOC(t1, n * 4); DMG_ALLOC(t2, n * 4);
-    if ((rc = upload_rows(ctx, dpf, pf))) return rc;
     DMG_HIP(hipMemcpyAsync(t1.p, field, n * 4, hipMemcpyHostToDevice, ctx->stream));   // copy target -> tex1 (:36)
-    std::vector<float> rl = blur_rlist(radius);
-    dim3 g((grid->W + 255) / 256, grid->H);
-    size_t i = 0;
-    do {                                             // Blur::step (:97-117)
-        hipLaunchKernelGGL(k_blur13, g, dim3(256), 0, ctx->stream, c, t1.f(), t2.f(), dpf.f(), 0.0f, rl[i]);   // (0, r)
-        hipLaunchKernelGGL(k_blur13, g, dim3(256), 0, ctx->stream, c, t2.f(), t1.f(), dpf.f(), rl[i], 0.0f);   // (r, 0)
-        DMG_HIP(hipGetLastError());
-        i++;
-    } while (!(i > rl.size() - 1));                  // `i>rlist.size()-1` (:111)
+    if ((rc = blur_device(ctx, *grid, topo, t1.f(), t2.f(), radius))) return rc;
     DMG_HIP(hipMemcpyAsync(field, t1.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));   // copy tex1 -> target (:112)
     DMG_HIP(hipStreamSynchronize(ctx->stream));
     return DMG_OK;
@@ -325,9 +264,8 @@ int dmg_erosion_pass(dmg_ctx *ctx, const dmg_grid *grid, float *h, const float *
     int rc = dmg_check_grid(grid, &topo);
     if (rc) return rc;
     DMG_HIP(hipSetDevice(ctx->device));
-    canvas c = make_canvas(*grid, topo);
-    const int W = grid->W, H = grid->H;
-    const size_t n = (size_t)W * H;
+    const int H = grid->H;
+    const size_t n = (size_t)grid->W * H;
     std::vector<float> dxr(H), dyr(H);
     for (int y = 0; y < H; y++) dmg_row_pixelsize(*grid, y, &dxr[y], &dyr[y]);
     dev_buf dh, df, du, dout, ddx, ddy;
@@ -336,13 +274,50 @@ int dmg_erosion_pass(dmg_ctx *ctx, const dmg_grid *grid, float *h, const float *
     DMG_HIP(hipMemcpyAsync(dh.p, h, n * 4, hipMemcpyHostToDevice, ctx->stream));
     DMG_HIP(hipMemcpyAsync(df.p, flow, n * 4, hipMemcpyHostToDevice, ctx->stream));
     DMG_HIP(hipMemcpyAsync(du.p, updrift, n * 4, hipMemcpyHostToDevice, ctx->stream));
-    float SLOPE = tanf(DMG_PI / 2.0f / 3.0f);        // tan(M_PI/2/3), 30 degrees (:191)
-    float pow01 = powf(0.1f, slope_exponent);        // pow(0.1, slope_exponent): a constant of the pass
-    dim3 g((W + 255) / 256, H);
-    hipLaunchKernelGGL(k_erosion, g, dim3(256), 0, ctx->stream, c, dh.f(), df.f(), du.f(), dout.f(), ddx.f(), ddy.f(),
-                       factor, slope_exponent, SLOPE, pow01);
-    DMG_HIP(hipGetLastError());
+    if ((rc = erosion_device(ctx, *grid, topo, dh.f(), df.f(), du.f(), dout.f(), ddx.f(), ddy.f(), factor, slope_exponent))) return rc;
     DMG_HIP(hipMemcpyAsync(h, dout.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    DMG_HIP(hipStreamSynchronize(ctx->stream));
+    return DMG_OK;
+}
+
+__global__ void k_erosion_prepare(const float *__restrict__ img, float *__restrict__ updrift, float *__restrict__ height, float N, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float v = img[i];
+    updrift[i] = __fdiv_rn(fmaxf(v, 0.0f), N);           // max(texture2D(img,st).r,0)/N  (cpufilter.cpp:52)
+    height[i] = (v <= 0.0f) ? v : __fdiv_rn(v, N);       // :70-72
+}
+
+// cpufilter::run (:41-222), device resident: no readbacks between the flow solve and the erosion pass
+int dmg_erosion_run(dmg_ctx *ctx, const dmg_grid *grid, float *h, int N, int iters, float exponent,
+                    float slope_exponent, float factor)
+{
+    DMG_CHECK_ARG(ctx != nullptr && h != nullptr && N >= 1 && iters >= 0);
+    dmg_topology topo;
+    int rc = dmg_check_grid(grid, &topo);
+    if (rc) return rc;
+    DMG_HIP(hipSetDevice(ctx->device));
+    const int H = grid->H;
+    const size_t n = (size_t)grid->W * H;
+    std::vector<float> dxr(H), dyr(H);
+    for (int y = 0; y < H; y++) dmg_row_pixelsize(*grid, y, &dxr[y], &dyr[y]);
+    dev_buf terrain, height, next, updrift, flow, ddx, ddy;
+    DMG_ALLOC(terrain, n * 4); DMG_ALLOC(height, n * 4); DMG_ALLOC(next, n * 4); DMG_ALLOC(updrift, n * 4); DMG_ALLOC(flow, n * 4);
+    if ((rc = upload_rows(ctx, ddx, dxr)) || (rc = upload_rows(ctx, ddy, dyr))) return rc;
+    DMG_HIP(hipMemcpyAsync(terrain.p, h, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_erosion_prepare, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, terrain.f(), updrift.f(),
+                       height.f(), (float)N, n);
+    DMG_HIP(hipGetLastError());
+    float *cur = height.f(), *nxt = next.f();
+    for (int i = 0; i < iters; i++) {                    // :93
+        // the first FlowFilter sees the unscaled terrain texture, every later one the eroded scaled heights (:95-108)
+        const float *flow_in = (i == 0) ? terrain.f() : cur;
+        if ((rc = flow_device(ctx, *grid, topo, flow_in, nullptr, 0.5f, exponent, flow.f()))) return rc;
+        if ((rc = erosion_device(ctx, *grid, topo, cur, flow.f(), updrift.f(), nxt, ddx.f(), ddy.f(), factor, slope_exponent))) return rc;
+        std::swap(cur, nxt);
+    }
+    DMG_HIP(hipMemcpyAsync(h, cur, n * 4, hipMemcpyDeviceToHost, ctx->stream));
     DMG_HIP(hipStreamSynchronize(ctx->stream));
     return DMG_OK;
 }

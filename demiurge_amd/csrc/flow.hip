@@ -1,0 +1,460 @@
+// Flow accumulation: FlowFilter (reference src/filter/FlowFilter.cpp) rebuilt for the GPU.
+//
+// The reference alternates GLSL passes with a CPU graph walk over downloaded textures (recursive std::function
+// lambdas, per-lake std::set/unordered_map).  Here everything that is per-cell lives on the device:
+//   k_flow_direction   stochastic-D8 direction codes            (:109-244)
+//   k_flow_mask        receiver bitmask + sink / river-mouth bits (:268-303)
+//   k_flow_parent + pointer jumping   catchment label = sink cell, depth = distance to the sink
+//                                     (replaces the recursive flood of assignLakeIds, :360-398)
+//   k_flow_passes      lowest neighbour in another catchment per boundary cell (the per-cell part of
+//                      findAllConnections, :405-492), compacted to a candidate list
+//   k_flow_level       upstream-area sum, one launch per depth level from the leaves down, each cell adding its
+//                      upstream neighbours in the reference's order (calculateflow's recursion, :607-622) so the fp32
+//                      sums are the reference's sums
+// Only the lake graph (which catchment overflows into which: solvingConnections, :533-595) runs on the host, on the
+// compacted candidate list.  Tie-breaking where the reference is container-order dependent follows
+// oracle/flow_oracle.cpp: total order (height, from, tolocation), lakes in ascending cell index.
+#include "canvas.h"
+#include <algorithm>
+#include <map>
+#include <set>
+#include <tuple>
+#include <unordered_map>
+
+// keypad order of FlowFilter::neighbours (:66-73): bits 1,2,3,4,6,7,8,9 <-> (dx,dy)
+__constant__ int c_ndx[8] = { -1, 0, 1, -1, 1, -1, 0, 1 };
+__constant__ int c_ndy[8] = { -1, -1, -1, 0, 0, 1, 1, 1 };
+__constant__ int c_nbit[8] = { 1, 2, 4, 8, 32, 64, 128, 256 };      // value of keypad bit 1,2,3,4,6,7,8,9
+
+struct flow_canvas {
+    canvas c;            // the project's canvas (mask pass)
+    canvas cm;           // cornerCoords moved 1e-3 off the poles (direction pass, :253-256)
+    int wrap;            // FlowFilter::neighbours' own wrap test (:47)
+};
+
+__device__ __forceinline__ float d_fract(float x) { return __fsub_rn(x, floorf(x)); }
+// hash() of the direction shader (:114-118); noise() (:120-131) is only evaluated at integer lattice points
+// (st*resolution*2 = (2x+1, 2y+1)), where it reduces to hash(i): mix(a,b,0) = a*(1-0)+b*0 = a exactly
+__device__ __forceinline__ float d_flow_hash(float px, float py)
+{
+    px = __fmul_rn(50.0f, d_fract(__fadd_rn(__fmul_rn(px, 0.3183099f), 0.71f)));
+    py = __fmul_rn(50.0f, d_fract(__fadd_rn(__fmul_rn(py, 0.3183099f), 0.113f)));
+    return __fadd_rn(-1.0f, __fmul_rn(2.0f, d_fract(__fmul_rn(__fmul_rn(px, py), __fadd_rn(px, py)))));
+}
+
+// nearest texel reached by offset(st,(dx,dy)) for integer steps: wrap or clamp in x, pole reflection or clamp in y
+__device__ __forceinline__ int d_step(const canvas &c, int x, int y, int dx, int dy)
+{
+    int xx = x + dx, yy = y + dy;
+    if (c.lonwrap) { if (xx >= c.W) xx -= c.W; if (xx < 0) xx += c.W; }
+    else xx = min(max(xx, 0), c.W - 1);
+    if (yy < 0) { yy = 0; if (c.spole) { xx += c.W / 2; if (xx >= c.W) xx -= c.W; } }
+    if (yy >= c.H) { yy = c.H - 1; if (c.npole) { xx += c.W / 2; if (xx >= c.W) xx -= c.W; } }
+    return yy * c.W + xx;
+}
+
+// ---- direction codes ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_flow_direction(flow_canvas fc, const float *__restrict__ img, const float *__restrict__ sel,
+                                                        const float *__restrict__ dxrow, const float *__restrict__ dyrow,
+                                                        unsigned char *__restrict__ code)
+{
+    const canvas &c = fc.cm;
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= c.W) return;
+    size_t i = (size_t)y * c.W + x;
+    float a = img[i];
+    if (a <= 0.0f || (sel && sel[i] == 0.0f)) { code[i] = 0; return; }
+    // get_aspect -> get_texture_gradient (reference src/Shader.h:281-297): taps a..i = -vec2(ox,oy)
+    float A = img[d_step(c, x, y, -1, -1)], B = img[d_step(c, x, y, 0, -1)], C = img[d_step(c, x, y, 1, -1)];
+    float D = img[d_step(c, x, y, -1, 0)], F = img[d_step(c, x, y, 1, 0)];
+    float G = img[d_step(c, x, y, -1, 1)], Hh = img[d_step(c, x, y, 0, 1)], I = img[d_step(c, x, y, 1, 1)];
+    float gx = __fdiv_rn(__fadd_rn(-__fadd_rn(__fadd_rn(C, __fmul_rn(2.0f, F)), I), __fadd_rn(__fadd_rn(A, __fmul_rn(2.0f, D)), G)),
+                         __fmul_rn(8.0f, dxrow[y]));
+    float gy = __fdiv_rn(__fsub_rn(__fadd_rn(__fadd_rn(G, __fmul_rn(2.0f, Hh)), I), __fadd_rn(__fadd_rn(A, __fmul_rn(2.0f, B)), C)),
+                         __fmul_rn(8.0f, dyrow[y]));
+    float aspect = __fsub_rn(DMG_PI, atan2f(gy, -gx));
+    const float two_pi = 2.0f * DMG_PI;
+    float lower = __fmul_rn(__fmul_rn(__fdiv_rn(floorf(__fmul_rn(__fdiv_rn(aspect, two_pi), 8.0f)), 8.0f), 2.0f), DMG_PI);
+    float upper = __fmul_rn(__fmul_rn(__fdiv_rn(ceilf(__fmul_rn(__fdiv_rn(aspect, two_pi), 8.0f)), 8.0f), 2.0f), DMG_PI);
+    float prob = __fmul_rn(__fdiv_rn(fabsf(__fsub_rn(aspect, lower)), DMG_PI), 4.0f);
+    float sx = d_stx(c, x), sy = d_sty(c, y);
+    float q = __fadd_rn(__fmul_rn(d_flow_hash(floorf(__fmul_rn(__fmul_rn(sx, (float)c.W), 2.0f)), floorf(__fmul_rn(__fmul_rn(sy, (float)c.H), 2.0f))), 0.5f), 0.5f);
+    aspect = (q < prob) ? upper : lower;
+    int dx = (int)roundf(cosf(aspect)), dy = -(int)roundf(sinf(aspect));
+    int fcode = 5 + dx + 3 * dy;                       // keypad code of (dx,dy): 9=(1,1) 8=(0,1) .. 1=(-1,-1); (0,0) stays 5
+    int n = d_step(c, x, y, dx, dy);
+    float a2 = img[n];
+    float s2 = sel ? sel[n] : 1.0f;
+    if (a2 <= 0.0f) fcode = 5;
+    if (s2 == 0.0f) fcode = 5;
+    if (a2 < a) { code[i] = (unsigned char)fcode; return; }
+    // fallback: the lowest of the 8 neighbours, visited in the shader's order (:134-189)
+    fcode = 5;
+    float s = 1.0f;
+    const int ox[8] = { 1, 0, -1, 1, -1, 1, 0, -1 }, oy[8] = { 1, 1, 1, 0, 0, -1, -1, -1 }, oc[8] = { 9, 8, 7, 6, 4, 3, 2, 1 };
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        int m = d_step(c, x, y, ox[k], oy[k]);
+        a2 = img[m];
+        if (a2 < a) { fcode = oc[k]; a = a2; s = sel ? sel[m] : 1.0f; }
+    }
+    if (a <= 0.0f) fcode = 5;                          // edge of ocean
+    if (s == 0.0f) fcode = 5;
+    code[i] = (unsigned char)fcode;
+}
+
+// ---- receiver bitmask -------------------------------------------------------------------------------------------
+// mask bits: 1,2,4,8,32,64,128,256 = keypad neighbours 1,2,3,4,6,7,8,9 drain into this cell; 16 = sink; 512 = river
+// mouth (some neighbour is ocean/unselected); 0xFFFF = not land (the reference's -1)
+__global__ __launch_bounds__(256) void k_flow_mask(flow_canvas fc, const float *__restrict__ img, const float *__restrict__ sel,
+                                                   const unsigned char *__restrict__ code, unsigned short *__restrict__ mask)
+{
+    const canvas &c = fc.c;
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= c.W) return;
+    size_t i = (size_t)y * c.W + x;
+    if (img[i] <= 0.0f || (sel && sel[i] == 0.0f)) { mask[i] = 0xFFFFu; return; }
+    unsigned v = 0;
+    bool flag = false;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        // keypad neighbour k drains into this cell when its code points back: code == 10 - keypad(k)
+        int kp = (k < 4) ? k + 1 : k + 2;
+        unsigned cc = code[d_step(c, x, y, c_ndx[k], c_ndy[k])];
+        if (cc == (unsigned)(10 - kp)) v |= (unsigned)c_nbit[k];
+        if (cc == 0) flag = true;
+    }
+    if (code[i] == 5) v |= 16u;
+    if (flag) v |= 512u;
+    mask[i] = (unsigned short)v;
+}
+
+// ---- catchments ---------------------------------------------------------------------------------------------------
+// parent = the cell this one drains to under FlowFilter::neighbours' rules (x wraps on a full-longitude canvas, a
+// step out of the grid in y leads nowhere); sinks and dead ends are their own parent.
+__global__ void k_flow_parent(flow_canvas fc, const unsigned char *__restrict__ code, int *__restrict__ parent, int *__restrict__ dist)
+{
+    int W = fc.c.W, H = fc.c.H;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)W * H) return;
+    int cd = code[i];
+    int p = (int)i, d = 0;
+    if (cd != 0 && cd != 5) {
+        int dx = (cd - 1) % 3 - 1, dy = (cd - 1) / 3 - 1;
+        int x = (int)(i % W) + dx, y = (int)(i / W) + dy;
+        bool ok = true;
+        if (fc.wrap) x = (x + W) % W; else if (x < 0 || x >= W) ok = false;
+        if (y < 0 || y >= H) ok = false;
+        if (ok) { p = y * W + x; d = 1; }
+    }
+    parent[i] = p;
+    dist[i] = d;
+}
+
+__global__ void k_flow_jump(const int *__restrict__ pin, const int *__restrict__ din, int *__restrict__ pout, int *__restrict__ dout,
+                            size_t n, int *__restrict__ changed)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int p = pin[i], pp = pin[p];
+    dout[i] = din[i] + din[p];
+    pout[i] = pp;
+    if (pp != p) *changed = 1;
+}
+
+// label = root when the root is a sink, else -1 (ocean, unselected, or a chain that leaves the grid)
+__global__ void k_flow_label(const int *__restrict__ root, const unsigned char *__restrict__ code, int *__restrict__ label, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int r = root[i];
+    label[i] = (code[i] != 0 && code[r] == 5) ? r : -1;
+}
+
+// ---- pass candidates --------------------------------------------------------------------------------------------
+struct flow_cand { int lake, from, s; float h; };
+
+__global__ void k_flow_passes(flow_canvas fc, const float *__restrict__ h, const int *__restrict__ label,
+                              const unsigned short *__restrict__ mask, flow_cand *__restrict__ out, int *__restrict__ count, int cap)
+{
+    int W = fc.c.W, H = fc.c.H;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)W * H) return;
+    int lake = label[i];
+    if (lake < 0) return;
+    int x0 = (int)(i % W), y0 = (int)(i / W);
+    float minpass = INFINITY;
+    int nlake = -1;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {                       // FlowFilter::neighbours order, strict '<' keeps the first
+        int x = x0 + c_ndx[k], y = y0 + c_ndy[k];
+        if (fc.wrap) x = (x + W) % W; else if (x < 0 || x >= W) continue;
+        if (y < 0 || y >= H) continue;
+        int n = y * W + x;
+        int ln = label[n];
+        if (ln < 0 || ln == lake) continue;             // the adjacency pass: another lake's id (:417-439)
+        float bd = h[n];
+        if (bd > 0.0f && bd < minpass) { minpass = bd; nlake = n; }     // :476-481
+    }
+    if (nlake < 0) return;
+    int lid = label[nlake];
+    if (mask[lid] & 512u) return;                       // never towards a river-mouth lake (:484)
+    int slot = atomicAdd(count, 1);
+    if (slot < cap) { flow_cand c; c.lake = lake; c.from = lid; c.s = (int)i; c.h = fmaxf(minpass, h[i]); out[slot] = c; }
+}
+
+// ---- upstream-area accumulation by depth level --------------------------------------------------------------------
+__global__ void k_flow_gdepth(const int *__restrict__ label, const int *__restrict__ dist, const int *__restrict__ lake_off,
+                              int *__restrict__ gdepth, int *__restrict__ hist, size_t n, int max_levels)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int l = label[i], g = -1;
+    if (l >= 0 && lake_off[l] >= 0) g = dist[i] + lake_off[l];
+    gdepth[i] = g;
+    if (g >= 0 && g < max_levels) atomicAdd(&hist[g], 1);
+}
+
+__global__ void k_flow_scatter(const int *__restrict__ gdepth, int *__restrict__ cursor, int *__restrict__ order, size_t n, int max_levels)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int g = gdepth[i];
+    if (g >= 0 && g < max_levels) order[atomicAdd(&cursor[g], 1)] = (int)i;
+}
+
+__global__ void k_flow_level(flow_canvas fc, const int *__restrict__ order, int first, int count,
+                             const unsigned short *__restrict__ mask, const int *__restrict__ conn_from,
+                             const float *__restrict__ own_row, float *__restrict__ acc, float *__restrict__ out, float exponent)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    int W = fc.c.W, H = fc.c.H;
+    int p = order[first + t];
+    int x0 = p % W, y0 = p / W;
+    float sum = own_row[y0];                            // pixelwidthy*pixelwidthx*cos(geoy)*1e-5 (:608-613)
+    unsigned m = mask[p];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {                       // sum += rec(n) in FlowFilter::neighbours order (:614-616)
+        if (!(m & (unsigned)c_nbit[k])) continue;
+        int x = x0 + c_ndx[k], y = y0 + c_ndy[k];
+        if (fc.wrap) x = (x + W) % W; else if (x < 0 || x >= W) continue;
+        if (y < 0 || y >= H) continue;
+        sum = __fadd_rn(sum, acc[y * W + x]);
+    }
+    int from = conn_from[p];
+    if (from >= 0) sum = __fadd_rn(sum, acc[from]);     // sum += rec(connections[p].from) (:617-619)
+    acc[p] = sum;
+    out[p] = powf(sum, exponent);                       // lakeID[p] = pow(sum, exponent) (:620)
+}
+
+__global__ void k_fill_f(float *p, float v, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// ---- host ---------------------------------------------------------------------------------------------------------
+namespace {
+struct Pass { float h; int from; int tolocation; };
+struct PassLess {
+    bool operator()(const Pass &a, const Pass &b) const
+    { return std::tie(a.h, a.from, a.tolocation) < std::tie(b.h, b.from, b.tolocation); }
+};
+}  // namespace
+
+// Device-resident flow accumulation.  d_h: heights (W*H); d_sel: selection mask or nullptr; d_flow: result.
+int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, const float *d_h, const float *d_sel,
+                float preblur, float exponent, float *d_flow)
+{
+    const int W = grid.W, H = grid.H;
+    const size_t N = (size_t)W * H;
+    hipStream_t st = ctx->stream;
+    const unsigned nb = (unsigned)((N + 255) / 256);
+
+    flow_canvas fc;
+    fc.c = make_canvas(grid, topo);
+    dmg_grid gm = grid;                                  // coordsMod (:253-256): float += double literal
+    gm.coords[0] = (float)((double)gm.coords[0] + 1e-3);
+    gm.coords[1] = (float)((double)gm.coords[1] - 1e-3);
+    fc.cm = make_canvas(gm, dmg_topology_of(gm));
+    fc.wrap = fabs(grid.coords[3] - grid.coords[2]) > 2 * M_PI - 1e-4;       // :47
+
+    // per-row tables: pixelsize() of the direction pass, cell area of calculateflow (double arithmetic, :608-613)
+    std::vector<float> dxr(H), dyr(H), own(H);
+    float pwx = (float)(grid.circumference * (grid.coords[3] - grid.coords[2]) / (2 * M_PI) / W);
+    float pwy = (float)(grid.circumference * (grid.coords[1] - grid.coords[0]) / (2 * M_PI) / H);
+    for (int y = 0; y < H; y++) {
+        dmg_row_pixelsize(gm, y, &dxr[y], &dyr[y]);
+        float fy = (float)y / H;
+        float geoy = (fy * (grid.coords[1] - grid.coords[0]) + grid.coords[0]);
+        own[y] = (float)(pwy * pwx * cosf(geoy) * 1e-5);
+    }
+    dev_buf ddx, ddy, down, hb, tmp, code, mask, par[2], dst[2], label, changed, cand, count;
+    int rc;
+    if ((rc = upload_vec(ctx, ddx, dxr)) || (rc = upload_vec(ctx, ddy, dyr)) || (rc = upload_vec(ctx, down, own))) return rc;
+    DMG_ALLOC(hb, N * 4); DMG_ALLOC(tmp, N * 4); DMG_ALLOC(code, N); DMG_ALLOC(mask, N * 2);
+    DMG_ALLOC(par[0], N * 4); DMG_ALLOC(par[1], N * 4); DMG_ALLOC(dst[0], N * 4); DMG_ALLOC(dst[1], N * 4);
+    DMG_ALLOC(label, N * 4); DMG_ALLOC(changed, 4); DMG_ALLOC(count, 4);
+
+    // findMagicNumbers: pre-blur (:90-103) then the two passes on the blurred terrain
+    DMG_HIP(hipMemcpyAsync(hb.p, d_h, N * 4, hipMemcpyDeviceToDevice, st));
+    if (preblur > 0.0f && (rc = blur_device(ctx, grid, topo, hb.f(), tmp.f(), preblur))) return rc;
+    dim3 g2((W + 255) / 256, H);
+    hipLaunchKernelGGL(k_flow_direction, g2, dim3(256), 0, st, fc, hb.f(), d_sel, ddx.f(), ddy.f(), (unsigned char *)code.p);
+    hipLaunchKernelGGL(k_flow_mask, g2, dim3(256), 0, st, fc, hb.f(), d_sel, (const unsigned char *)code.p, (unsigned short *)mask.p);
+    DMG_HIP(hipGetLastError());
+
+    // catchment labels + depth by pointer jumping (log2 of the longest river iterations)
+    hipLaunchKernelGGL(k_flow_parent, dim3(nb), dim3(256), 0, st, fc, (const unsigned char *)code.p, par[0].i(), dst[0].i());
+    int cur = 0;
+    for (int it = 0; it < 40; it++) {
+        DMG_HIP(hipMemsetAsync(changed.p, 0, 4, st));
+        hipLaunchKernelGGL(k_flow_jump, dim3(nb), dim3(256), 0, st, par[cur].i(), dst[cur].i(), par[cur ^ 1].i(), dst[cur ^ 1].i(), N, changed.i());
+        DMG_HIP(hipGetLastError());
+        cur ^= 1;
+        int ch = 0;
+        DMG_HIP(hipMemcpyAsync(&ch, changed.p, 4, hipMemcpyDeviceToHost, st));
+        DMG_HIP(hipStreamSynchronize(st));
+        if (!ch) break;
+    }
+    hipLaunchKernelGGL(k_flow_label, dim3(nb), dim3(256), 0, st, par[cur].i(), (const unsigned char *)code.p, label.i(), N);
+
+    // boundary cells -> pass candidates (compacted), then the lake graph on the host
+    int cap = (int)std::min<size_t>(N, (size_t)1 << 28);
+    DMG_ALLOC(cand, (size_t)cap * sizeof(flow_cand));
+    DMG_HIP(hipMemsetAsync(count.p, 0, 4, st));
+    hipLaunchKernelGGL(k_flow_passes, dim3(nb), dim3(256), 0, st, fc, d_h, label.i(), (const unsigned short *)mask.p,
+                       (flow_cand *)cand.p, count.i(), cap);
+    DMG_HIP(hipGetLastError());
+    int ncand = 0;
+    DMG_HIP(hipMemcpyAsync(&ncand, count.p, 4, hipMemcpyDeviceToHost, st));
+    DMG_HIP(hipStreamSynchronize(st));
+    if (ncand > cap) return dmg_fail(DMG_ENOMEM, "flow: %d pass candidates exceed the buffer", ncand);
+    std::vector<flow_cand> cands(ncand);
+    std::vector<unsigned short> hmask(N);
+    std::vector<int> hlabel(N), hdist(N);
+    if (ncand) DMG_HIP(hipMemcpyAsync(cands.data(), cand.p, (size_t)ncand * sizeof(flow_cand), hipMemcpyDeviceToHost, st));
+    DMG_HIP(hipMemcpyAsync(hmask.data(), mask.p, N * 2, hipMemcpyDeviceToHost, st));
+    DMG_HIP(hipMemcpyAsync(hlabel.data(), label.p, N * 4, hipMemcpyDeviceToHost, st));
+    DMG_HIP(hipMemcpyAsync(hdist.data(), dst[cur].p, N * 4, hipMemcpyDeviceToHost, st));
+    DMG_HIP(hipStreamSynchronize(st));
+
+    // lowest pass per (lake, neighbouring lake), canonical order
+    std::map<int, std::map<int, Pass>> best;
+    for (const flow_cand &c : cands) {
+        Pass p{ c.h, c.from, c.s };
+        auto &m = best[c.lake];
+        auto it = m.find(c.from);
+        if (it == m.end() || PassLess()(p, it->second)) m[c.from] = p;
+    }
+    std::map<int, std::set<Pass, PassLess>> passes;
+    for (auto &kv : best) for (auto &q : kv.second) passes[kv.first].insert(q.second);
+
+    // solvingConnections (:533-595)
+    std::vector<int> mouths;
+    for (size_t i = 0; i < N; i++)
+        if (hmask[i] != 0xFFFFu && (hmask[i] & 16u) && (hmask[i] & 512u)) mouths.push_back((int)i);
+    std::set<Pass, PassLess> candidates;
+    std::set<int> placed(mouths.begin(), mouths.end());
+    std::unordered_map<int, Pass> connections;
+    auto push_next = [&](int lake) {
+        auto it = passes.find(lake);
+        if (it == passes.end()) return;
+        auto &set = it->second;
+        while (!set.empty()) {
+            Pass c = *set.begin();
+            set.erase(set.begin());
+            if (placed.count(c.from)) continue;
+            candidates.insert(c);
+            break;
+        }
+    };
+    for (int lake : mouths) push_next(lake);
+    while (!candidates.empty()) {
+        Pass p = *candidates.begin();
+        candidates.erase(candidates.begin());
+        int to_lake = hlabel[p.tolocation];
+        if (placed.count(p.from)) { push_next(to_lake); continue; }
+        placed.insert(p.from);
+        connections[p.tolocation] = p;                   // a later pass at the same cell replaces an earlier one (:588)
+        push_next(p.from);
+        push_next(to_lake);
+    }
+
+    // depth offset of every lake that calculateflow's recursion reaches: river mouths at 0, a connected lake one
+    // below the cell it drains into
+    std::vector<int> lake_off(N, -1), conn_from(N, -1);
+    std::unordered_map<int, std::vector<std::pair<int, int>>> into;     // lake -> (tolocation, from) of lakes draining into it
+    for (auto &kv : connections) {
+        conn_from[kv.first] = kv.second.from;
+        into[hlabel[kv.first]].push_back({ kv.first, kv.second.from });
+    }
+    std::vector<int> work(mouths.begin(), mouths.end());
+    for (int m : mouths) lake_off[m] = 0;
+    int max_depth = 0;
+    while (!work.empty()) {
+        int lake = work.back(); work.pop_back();
+        auto it = into.find(lake);
+        if (it == into.end()) continue;
+        for (auto &e : it->second) {
+            lake_off[e.second] = lake_off[lake] + hdist[e.first] + 1;
+            work.push_back(e.second);
+        }
+    }
+    for (size_t i = 0; i < N; i++)
+        if (hlabel[i] >= 0 && lake_off[hlabel[i]] >= 0) max_depth = std::max(max_depth, lake_off[hlabel[i]] + hdist[i]);
+    const int levels = max_depth + 1;
+
+    dev_buf dlo, dcf, gdepth, hist, order, acc;
+    if ((rc = upload_vec(ctx, dlo, lake_off)) || (rc = upload_vec(ctx, dcf, conn_from))) return rc;
+    DMG_ALLOC(gdepth, N * 4); DMG_ALLOC(hist, (size_t)levels * 4); DMG_ALLOC(order, N * 4); DMG_ALLOC(acc, N * 4);
+    DMG_HIP(hipMemsetAsync(hist.p, 0, (size_t)levels * 4, st));
+    hipLaunchKernelGGL(k_flow_gdepth, dim3(nb), dim3(256), 0, st, label.i(), dst[cur].i(), dlo.i(), gdepth.i(), hist.i(), N, levels);
+    DMG_HIP(hipGetLastError());
+    std::vector<int> hh(levels), start(levels + 1, 0);
+    DMG_HIP(hipMemcpyAsync(hh.data(), hist.p, (size_t)levels * 4, hipMemcpyDeviceToHost, st));
+    DMG_HIP(hipStreamSynchronize(st));
+    for (int l = 0; l < levels; l++) start[l + 1] = start[l] + hh[l];
+    DMG_HIP(hipMemcpyAsync(hist.p, start.data(), (size_t)levels * 4, hipMemcpyHostToDevice, st));   // hist := scatter cursors
+    hipLaunchKernelGGL(k_flow_scatter, dim3(nb), dim3(256), 0, st, gdepth.i(), hist.i(), order.i(), N, levels);
+    hipLaunchKernelGGL(k_fill_f, dim3(nb), dim3(256), 0, st, d_flow, -1.0f, N);        // unreached cells keep -1 (:598-604)
+    DMG_HIP(hipGetLastError());
+    for (int l = levels - 1; l >= 0; l--) {
+        int cnt = start[l + 1] - start[l];
+        if (!cnt) continue;
+        hipLaunchKernelGGL(k_flow_level, dim3((cnt + 255) / 256), dim3(256), 0, st, fc, order.i(), start[l], cnt,
+                           (const unsigned short *)mask.p, dcf.i(), down.f(), acc.f(), d_flow, exponent);
+    }
+    DMG_HIP(hipGetLastError());
+    DMG_HIP(hipStreamSynchronize(st));                   // the temporaries above are released on return
+    return DMG_OK;
+}
+
+extern "C" {
+
+// FlowFilter::run (:719-786) with lakeflag = 0: flow_out[i] = pow(upstream area, exponent), -1 off the drained land
+int dmg_flow_accumulate(dmg_ctx *ctx, const dmg_grid *grid, const float *h, const float *sel, float preblur,
+                        float exponent, int lakes, float *flow_out)
+{
+    DMG_CHECK_ARG(ctx != nullptr && h != nullptr && flow_out != nullptr && preblur >= 0.0f);
+    if (lakes) return dmg_fail(DMG_EINVAL, "dmg_flow_accumulate: lake drawing (FlowFilter lakeflag, :660-699) is not built yet");
+    dmg_topology topo;
+    int rc = dmg_check_grid(grid, &topo);
+    if (rc) return rc;
+    DMG_HIP(hipSetDevice(ctx->device));
+    const size_t N = (size_t)grid->W * grid->H;
+    dev_buf dh, dsel, dflow;
+    DMG_ALLOC(dh, N * 4); DMG_ALLOC(dflow, N * 4);
+    DMG_HIP(hipMemcpyAsync(dh.p, h, N * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (sel) {
+        DMG_ALLOC(dsel, N * 4);
+        DMG_HIP(hipMemcpyAsync(dsel.p, sel, N * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
+    if ((rc = flow_device(ctx, *grid, topo, dh.f(), sel ? dsel.f() : nullptr, preblur, exponent, dflow.f()))) return rc;
+    DMG_HIP(hipMemcpyAsync(flow_out, dflow.p, N * 4, hipMemcpyDeviceToHost, ctx->stream));
+    DMG_HIP(hipStreamSynchronize(ctx->stream));
+    return DMG_OK;
+}
+
+}  // extern "C"

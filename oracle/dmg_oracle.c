@@ -699,3 +699,153 @@ void orc_erosion_pass(const orc_grid *g, const float *hgt, const float *flow, co
         }
     }
 }
+
+/* ====================================================================== */
+/* Flow accumulation: the GLSL passes of FlowFilter (src/filter/FlowFilter.cpp) */
+/* ====================================================================== */
+static inline float glsl_fract(float x) { return x - floorf(x); }
+/* hash()/noise() of the direction shader (:114-131).  noise() is only ever called at integer lattice points
+ * (st*resolution*2 = (2x+1, 2y+1)), where it reduces to hash(i) exactly; the general form is kept. */
+static inline float flow_hash(float px, float py)
+{
+    px = 50.0f * glsl_fract(px * 0.3183099f + 0.71f);
+    py = 50.0f * glsl_fract(py * 0.3183099f + 0.113f);
+    return -1.0f + 2.0f * glsl_fract(px * py * (px + py));
+}
+static inline float flow_mix(float a, float b, float t) { return a * (1.0f - t) + b * t; }
+static inline float flow_noise(float px, float py)
+{
+    float ix = floorf(px), iy = floorf(py), fx = glsl_fract(px), fy = glsl_fract(py);
+    float ux = fx * fx * (3.0f - 2.0f * fx), uy = fy * fy * (3.0f - 2.0f * fy);
+    return flow_mix(flow_mix(flow_hash(ix, iy), flow_hash(ix + 1.0f, iy), ux),
+                    flow_mix(flow_hash(ix, iy + 1.0f), flow_hash(ix + 1.0f, iy + 1.0f), ux), uy);
+}
+
+void orc_flow_direction(const orc_grid *g0, const float *img, const float *sel, float *codes)
+{
+    orc_grid gm = *g0;                               /* coordsMod (:253-256): float += double literal */
+    gm.coords[0] = (float)((double)gm.coords[0] + 1e-3);
+    gm.coords[1] = (float)((double)gm.coords[1] - 1e-3);
+    const orc_grid *g = &gm;
+    const int W = g->W, H = g->H;
+    const float rx = (float)W, ry = (float)H;
+#pragma omp parallel for schedule(static) num_threads(nthreads_rows(H, 0))
+    for (int y = 0; y < H; y++) {
+        float sy = sty(g, y);
+        float psx, psy;
+        orc_pixelsize(g, sy, &psx, &psy);
+        for (int x = 0; x < W; x++) {
+            float sx = stx(g, x);
+            float *fc = codes + (size_t)y * W + x;
+            float a = fetch_nearest(img, W, H, 1, 0, sx, sy);
+            *fc = 0.0f;
+            if (a <= 0.0f) continue;
+            if (fetch_nearest(sel, W, H, 1, 0, sx, sy) == 0) continue;
+            *fc = 5.0f;
+            /* get_aspect -> get_texture_gradient (src/Shader.h:281-297, :327-330) */
+            float t[9];
+            const float ox[9] = { 1, 0, -1, 1, 0, -1, 1, 0, -1 }, oy[9] = { 1, 1, 1, 0, 0, 0, -1, -1, -1 };  /* a..i = -vec2(ox,oy) */
+            for (int k = 0; k < 9; k++) {
+                float px, py;
+                orc_offset(g, sx, sy, -ox[k], -oy[k], rx, ry, &px, &py);
+                t[k] = fetch_nearest(img, W, H, 1, 0, px, py);
+            }
+            float A = t[0], B = t[1], C = t[2], D = t[3], F = t[5], G = t[6], Hh = t[7], I = t[8];
+            float gx = (-(C + 2 * F + I) + (A + 2 * D + G)) / (8 * psx);
+            float gy = ((G + 2 * Hh + I) - (A + 2 * B + C)) / (8 * psy);
+            float aspect = MPI - atan2f(gy, -gx);
+            float lower_aspect = floorf(aspect / (2 * MPI) * 8) / 8 * 2 * MPI;
+            float upper_aspect = ceilf(aspect / (2 * MPI) * 8) / 8 * 2 * MPI;
+            float prob = fabsf(aspect - lower_aspect) / MPI * 4;
+            float q = flow_noise(sx * rx * 2, sy * ry * 2) * 0.5f + 0.5f;
+            aspect = (q < prob) ? upper_aspect : lower_aspect;
+            float dx = roundf(cosf(aspect)), dy = -roundf(sinf(aspect));
+            if (dx == 1 && dy == 1) *fc = 9;
+            if (dx == 0 && dy == 1) *fc = 8;
+            if (dx == -1 && dy == 1) *fc = 7;
+            if (dx == 1 && dy == 0) *fc = 6;
+            if (dx == -1 && dy == 0) *fc = 4;
+            if (dx == 1 && dy == -1) *fc = 3;
+            if (dx == 0 && dy == -1) *fc = 2;
+            if (dx == -1 && dy == -1) *fc = 1;
+            float px, py;
+            orc_offset(g, sx, sy, dx, dy, rx, ry, &px, &py);
+            float a2 = fetch_nearest(img, W, H, 1, 0, px, py);
+            float s2 = fetch_nearest(sel, W, H, 1, 0, px, py);
+            if (a2 <= 0.0f) *fc = 5;
+            if (s2 == 0) *fc = 5;
+            if (a2 < a) continue;
+            *fc = 5;
+            float s = 0.0f;                               /* GLSL leaves `s` undefined when no neighbour is lower; see note */
+            int any = 0;
+            const float nx[8] = { 1, 0, -1, 1, -1, 1, 0, -1 }, ny[8] = { 1, 1, 1, 0, 0, -1, -1, -1 };
+            const float nc[8] = { 9, 8, 7, 6, 4, 3, 2, 1 };
+            for (int k = 0; k < 8; k++) {
+                orc_offset(g, sx, sy, nx[k], ny[k], rx, ry, &px, &py);
+                a2 = fetch_nearest(img, W, H, 1, 0, px, py);
+                s2 = fetch_nearest(sel, W, H, 1, 0, px, py);
+                if (a2 < a) { *fc = nc[k]; a = a2; s = s2; any = 1; }
+            }
+            if (a <= 0.0f) *fc = 5;                       /* edge of ocean */
+            if (any && s == 0) *fc = 5;                   /* `if(s==0) fc=5` with s set; unset s only when fc is already 5 */
+        }
+    }
+}
+
+void orc_flow_mask(const orc_grid *g, const float *img, const float *sel, const float *codes, float *mask)
+{
+    const int W = g->W, H = g->H;
+    const float rx = (float)W, ry = (float)H;
+    const float nx[8] = { 1, 0, -1, 1, -1, 1, 0, -1 }, ny[8] = { 1, 1, 1, 0, 0, -1, -1, -1 };
+    const float want[8] = { 1, 2, 3, 4, 6, 7, 8, 9 }, add[8] = { 256, 128, 64, 32, 8, 4, 2, 1 };
+#pragma omp parallel for schedule(static) num_threads(nthreads_rows(H, 0))
+    for (int y = 0; y < H; y++) {
+        float sy = sty(g, y);
+        for (int x = 0; x < W; x++) {
+            float sx = stx(g, x);
+            float *fc = mask + (size_t)y * W + x;
+            *fc = -1.0f;
+            if (fetch_nearest(img, W, H, 1, 0, sx, sy) <= 0.0f) continue;
+            if (fetch_nearest(sel, W, H, 1, 0, sx, sy) == 0) continue;
+            float v = 0.5f;
+            int flag = 0;
+            for (int k = 0; k < 8; k++) {
+                float px, py;
+                orc_offset(g, sx, sy, nx[k], ny[k], rx, ry, &px, &py);
+                float c = fetch_nearest(codes, W, H, 1, 0, px, py);
+                if (c == want[k]) v += add[k];
+                if (c == 0) flag = 1;
+            }
+            if (fetch_nearest(codes, W, H, 1, 0, sx, sy) == 5) v += 16;
+            /* the reference adds in the order 256,128,64,32,16,8,4,2,1: all exact in fp32, order irrelevant */
+            if (flag) v += 512;
+            *fc = v;
+        }
+    }
+}
+
+void orc_lake_adjacency(const orc_grid *g, const float *lakeid, float *out)
+{
+    const int W = g->W, H = g->H;
+    const float rx = (float)W, ry = (float)H;
+    const float nx[8] = { 1, 0, -1, 1, -1, 1, 0, -1 }, ny[8] = { 1, 1, 1, 0, 0, -1, -1, -1 };
+    const float add[8] = { 256, 128, 64, 32, 8, 4, 2, 1 };
+#pragma omp parallel for schedule(static) num_threads(nthreads_rows(H, 0))
+    for (int y = 0; y < H; y++) {
+        float sy = sty(g, y);
+        for (int x = 0; x < W; x++) {
+            float sx = stx(g, x);
+            float a = fetch_nearest(lakeid, W, H, 1, 0, sx, sy);
+            float v = 0.0f;
+            if (!(a < 0.0f)) {
+                for (int k = 0; k < 8; k++) {
+                    float px, py;
+                    orc_offset(g, sx, sy, nx[k], ny[k], rx, ry, &px, &py);
+                    float a2 = fetch_nearest(lakeid, W, H, 1, 0, px, py);
+                    if (a2 != a && a2 > 0) v += add[k];
+                }
+            }
+            out[(size_t)y * W + x] = v;
+        }
+    }
+}

@@ -52,6 +52,10 @@ def lib():
         L.orc_blur.argtypes = [G, P, P, ctypes.c_float]
         L.orc_temperature.argtypes = [G, P, P, P, ctypes.c_int, ctypes.c_int]
         L.orc_erosion_pass.argtypes = [G, P, P, P, ctypes.c_float, ctypes.c_float, P]
+        L.orc_flow_direction.argtypes = [G, P, P, P]
+        L.orc_flow_mask.argtypes = [G, P, P, P, P]
+        L.orc_lake_adjacency.argtypes = [G, P, P]
+        L.orc_flow_accumulate.argtypes = [G, P, P, ctypes.c_float, ctypes.c_float, P, P, P, P]
         _lib = L
     return _lib
 
@@ -167,3 +171,37 @@ def erosion_pass(g, h, flow, updrift, factor=1.0, slope_exponent=1.0):
     out = np.empty_like(h)
     lib().orc_erosion_pass(ctypes.byref(g), _ptr(h), _ptr(flow), _ptr(updrift), factor, slope_exponent, _ptr(out))
     return out
+
+
+def flow_direction(g, img, sel=None):
+    img = _f32(img)
+    sel = np.ones_like(img) if sel is None else _f32(sel)
+    out = np.empty_like(img)
+    lib().orc_flow_direction(ctypes.byref(g), _ptr(img), _ptr(sel), _ptr(out))
+    return out
+
+
+def flow_mask(g, img, codes, sel=None):
+    img, codes = _f32(img), _f32(codes)
+    sel = np.ones_like(img) if sel is None else _f32(sel)
+    out = np.empty_like(img)
+    lib().orc_flow_mask(ctypes.byref(g), _ptr(img), _ptr(sel), _ptr(codes), _ptr(out))
+    return out
+
+
+def lake_adjacency(g, lakeid):
+    lakeid = _f32(lakeid)
+    out = np.empty_like(lakeid)
+    lib().orc_lake_adjacency(ctypes.byref(g), _ptr(lakeid), _ptr(out))
+    return out
+
+
+def flow_accumulate(g, h, preblur=0.5, exponent=1.0, sel=None):
+    """-> dict(flow, codes, mask, label)"""
+    h = _f32(h)
+    sel = None if sel is None else _f32(sel)
+    flow, codes, mask = (np.empty_like(h) for _ in range(3))
+    label = np.empty(h.shape, np.int32)
+    lib().orc_flow_accumulate(ctypes.byref(g), _ptr(h), None if sel is None else _ptr(sel), preblur, exponent,
+                              _ptr(flow), _ptr(codes), _ptr(mask), _ptr(label))
+    return dict(flow=flow, codes=codes, mask=mask, label=label)

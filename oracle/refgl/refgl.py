@@ -331,3 +331,41 @@ def erosion_shader(h, flow, updrift, factor=1.0, slope_exponent=1.0, coords=FULL
     out = g.download(t_o)
     g.delete(t_h, t_f, t_u, t_o)
     return out
+
+
+def flow_direction_and_mask(img, sel=None, coords=FULL_GLOBE, circ=42000.0):
+    """The two GLSL passes of FlowFilter::findMagicNumbers (FlowFilter.cpp:109-315) on an (already blurred) terrain:
+    direction codes 0..9 -> scratch1 with cornerCoords moved 1e-3 off the poles (:253-256), then the receiver
+    bitmask -> scratch2 with the project's own coords (:304-310).  Returns (codes, mask)."""
+    g = RefGL.get()
+    H, W = img.shape
+    sel = np.ones((H, W), np.float32) if sel is None else sel
+    t_img = g.tex(W, H, 1, False, img)
+    t_sel = g.tex(W, H, 1, False, sel)
+    t_s1 = g.tex(W, H, 1, False)
+    t_s2 = g.tex(W, H, 1, False)
+    cm = [np.float32(c) for c in coords]
+    cm[0] = np.float32(cm[0] + np.float32(1e-3))          # coordsMod[0]+=1e-3 (float vector, double literal)
+    cm[1] = np.float32(cm[1] - np.float32(1e-3))
+    g.set_canvas(cm, circ)
+    g.apply(g.program(K_FLOWDIR), t_s1, {"img": t_img, "sel": t_sel})
+    g.set_canvas(coords, circ)
+    g.apply(g.program(K_FLOWMASK), t_s2, {"img": t_img, "sel": t_sel, "scratch1": t_s1})
+    codes, mask = g.download(t_s1), g.download(t_s2)
+    g.delete(t_img, t_sel, t_s1, t_s2)
+    return codes, mask
+
+
+def lake_adjacency(lake_id_bits, coords=FULL_GLOBE, circ=42000.0):
+    """FlowFilter::findAllConnections GLSL pass (FlowFilter.cpp:405-447): scratch1 = lake ids (int bits + 2^30 read
+    as float, -1 elsewhere) -> scratch2 bitmask of neighbours that belong to another lake."""
+    g = RefGL.get()
+    g.set_canvas(coords, circ)
+    H, W = lake_id_bits.shape
+    t_s1 = g.tex(W, H, 1, False, lake_id_bits)
+    t_img = g.tex(W, H, 1, False, np.zeros((H, W), np.float32))
+    t_s2 = g.tex(W, H, 1, False)
+    g.apply(g.program("FlowFilter.cpp:405"), t_s2, {"img": t_img, "scratch1": t_s1})
+    out = g.download(t_s2)
+    g.delete(t_s1, t_img, t_s2)
+    return out

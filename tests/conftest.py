@@ -27,7 +27,8 @@ def oracle():
     """The CPU restatement (test infrastructure).  Built on demand with plain gcc."""
     lib = ROOT / "oracle" / "liboracle.so"
     src = ROOT / "oracle" / "dmg_oracle.c"
-    if not lib.exists() or lib.stat().st_mtime < src.stat().st_mtime:
+    src2 = ROOT / "oracle" / "flow_oracle.cpp"
+    if not lib.exists() or lib.stat().st_mtime < max(src.stat().st_mtime, src2.stat().st_mtime):
         subprocess.check_call(["make", "-C", str(ROOT / "oracle"), "liboracle.so"])
     import oracle as orc
     orc.set_linear_taps(False)

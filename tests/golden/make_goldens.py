@@ -36,7 +36,41 @@ def ocean_inputs(W, H, vscale=1.0):
     return img, v
 
 
+def flow_goldens():
+    """the GLSL passes of FlowFilter (direction codes, receiver bitmask, lake adjacency) on a pre-blurred terrain"""
+    W, H = 128, 64
+    img = (synth.terrain(W, H) * 100 + synth.lcg_uniform(W * H, 99).reshape(H, W) * 8).astype(f32)
+    hb = refgl.blur(img, 0.5)                                 # FlowFilter's pre-blur (FlowFilter.cpp:90-103)
+    codes, mask = refgl.flow_direction_and_mask(hb)
+    # lake ids for the adjacency pass: label = sink reached by following the codes (computed here in numpy)
+    label = np.full(W * H, -1, np.int64)
+    c = codes.astype(np.int64).ravel()
+    for i in np.nonzero(c > 0)[0]:
+        path, j = [], int(i)
+        while label[j] < 0 and c[j] not in (0, 5):
+            path.append(j)
+            dx, dy = (c[j] - 1) % 3 - 1, (c[j] - 1) // 3 - 1
+            x, y = (j % W + dx) % W, j // W + dy
+            if y < 0 or y >= H:
+                j = -1
+                break
+            j = y * W + x
+        root = -1 if j < 0 else (label[j] if label[j] >= 0 else (j if c[j] == 5 else -1))
+        for k in path + ([j] if j >= 0 and c[j] == 5 else []):
+            label[k] = root
+    lid = np.where(label < 0, f32(-1), (label + 1073741824).astype(np.int32).view(f32)).reshape(H, W).astype(f32)
+    save("flow_passes_128x64_full", coords=np.array(FULL), circ=f32(CIRC), img=img, blurred=hb, codes=codes, mask=mask,
+         label=label.reshape(H, W).astype(np.int32), adjacency=refgl.lake_adjacency(lid))
+    sel = np.ones((H, W), f32)
+    sel[:, 40:60] = 0
+    c2, m2 = refgl.flow_direction_and_mask(hb, sel)
+    save("flow_passes_128x64_sel", coords=np.array(FULL), circ=f32(CIRC), blurred=hb, sel=sel, codes=c2, mask=m2)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "flow":
+        return flow_goldens()
+    flow_goldens()
     # ---- Jacobi (headline) -------------------------------------------------
     W, H = 256, 128
     img, b = synth.terrain(W, H), synth.divw(W, H)
