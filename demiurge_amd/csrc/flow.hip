@@ -33,13 +33,26 @@ struct flow_canvas {
 };
 
 __device__ __forceinline__ float d_fract(float x) { return __fsub_rn(x, floorf(x)); }
-// hash() of the direction shader (:114-118); noise() (:120-131) is only evaluated at integer lattice points
-// (st*resolution*2 = (2x+1, 2y+1)), where it reduces to hash(i): mix(a,b,0) = a*(1-0)+b*0 = a exactly
+// hash() and noise() of the direction shader (:114-131).  noise() is sampled at st*resolution*2 = (2x+1, 2y+1), an
+// integer lattice point in exact arithmetic; in fp32 it can land an ulp below (non-power-of-two sizes), so the full
+// bilinear form is kept.
 __device__ __forceinline__ float d_flow_hash(float px, float py)
 {
     px = __fmul_rn(50.0f, d_fract(__fadd_rn(__fmul_rn(px, 0.3183099f), 0.71f)));
     py = __fmul_rn(50.0f, d_fract(__fadd_rn(__fmul_rn(py, 0.3183099f), 0.113f)));
     return __fadd_rn(-1.0f, __fmul_rn(2.0f, d_fract(__fmul_rn(__fmul_rn(px, py), __fadd_rn(px, py)))));
+}
+__device__ __forceinline__ float d_mix(float a, float b, float t)      // GLSL mix: a*(1-t) + b*t
+{
+    return __fadd_rn(__fmul_rn(a, __fsub_rn(1.0f, t)), __fmul_rn(b, t));
+}
+__device__ __forceinline__ float d_flow_noise(float px, float py)
+{
+    float ix = floorf(px), iy = floorf(py), fx = d_fract(px), fy = d_fract(py);
+    float ux = __fmul_rn(__fmul_rn(fx, fx), __fsub_rn(3.0f, __fmul_rn(2.0f, fx)));
+    float uy = __fmul_rn(__fmul_rn(fy, fy), __fsub_rn(3.0f, __fmul_rn(2.0f, fy)));
+    return d_mix(d_mix(d_flow_hash(ix, iy), d_flow_hash(__fadd_rn(ix, 1.0f), iy), ux),
+                 d_mix(d_flow_hash(ix, __fadd_rn(iy, 1.0f)), d_flow_hash(__fadd_rn(ix, 1.0f), __fadd_rn(iy, 1.0f)), ux), uy);
 }
 
 // nearest texel reached by offset(st,(dx,dy)) for integer steps: wrap or clamp in x, pole reflection or clamp in y
@@ -78,7 +91,7 @@ __global__ __launch_bounds__(256) void k_flow_direction(flow_canvas fc, const fl
     float upper = __fmul_rn(__fmul_rn(__fdiv_rn(ceilf(__fmul_rn(__fdiv_rn(aspect, two_pi), 8.0f)), 8.0f), 2.0f), DMG_PI);
     float prob = __fmul_rn(__fdiv_rn(fabsf(__fsub_rn(aspect, lower)), DMG_PI), 4.0f);
     float sx = d_stx(c, x), sy = d_sty(c, y);
-    float q = __fadd_rn(__fmul_rn(d_flow_hash(floorf(__fmul_rn(__fmul_rn(sx, (float)c.W), 2.0f)), floorf(__fmul_rn(__fmul_rn(sy, (float)c.H), 2.0f))), 0.5f), 0.5f);
+    float q = __fadd_rn(__fmul_rn(d_flow_noise(__fmul_rn(__fmul_rn(sx, (float)c.W), 2.0f), __fmul_rn(__fmul_rn(sy, (float)c.H), 2.0f)), 0.5f), 0.5f);
     aspect = (q < prob) ? upper : lower;
     int dx = (int)roundf(cosf(aspect)), dy = -(int)roundf(sinf(aspect));
     int fcode = 5 + dx + 3 * dy;                       // keypad code of (dx,dy): 9=(1,1) 8=(0,1) .. 1=(-1,-1); (0,0) stays 5
