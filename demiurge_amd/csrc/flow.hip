@@ -20,6 +20,7 @@
 #include <set>
 #include <tuple>
 #include <unordered_map>
+#include <chrono>
 
 // keypad order of FlowFilter::neighbours (:66-73): bits 1,2,3,4,6,7,8,9 <-> (dx,dy)
 __constant__ int c_ndx[8] = { -1, 0, 1, -1, 1, -1, 0, 1 };
@@ -284,6 +285,15 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
     const size_t N = (size_t)W * H;
     hipStream_t st = ctx->stream;
     const unsigned nb = (unsigned)((N + 255) / 256);
+    static const bool timing = getenv("DMG_FLOW_TIMING") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        (void)hipStreamSynchronize(st);
+        auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[flow] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+        t_prev = now;
+    };
 
     flow_canvas fc;
     fc.c = make_canvas(grid, topo);
@@ -318,6 +328,7 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
     hipLaunchKernelGGL(k_flow_mask, g2, dim3(256), 0, st, fc, hb.f(), d_sel, (const unsigned char *)code.p, (unsigned short *)mask.p);
     DMG_HIP(hipGetLastError());
 
+    lap("alloc+blur+direction+mask");
     // catchment labels + depth by pointer jumping (log2 of the longest river iterations)
     hipLaunchKernelGGL(k_flow_parent, dim3(nb), dim3(256), 0, st, fc, (const unsigned char *)code.p, par[0].i(), dst[0].i());
     int cur = 0;
@@ -333,6 +344,7 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
     }
     hipLaunchKernelGGL(k_flow_label, dim3(nb), dim3(256), 0, st, par[cur].i(), (const unsigned char *)code.p, label.i(), N);
 
+    lap("pointer jumping");
     // boundary cells -> pass candidates (compacted), then the lake graph on the host
     int cap = (int)std::min<size_t>(N, (size_t)1 << 28);
     DMG_ALLOC(cand, (size_t)cap * sizeof(flow_cand));
@@ -353,6 +365,8 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
     DMG_HIP(hipMemcpyAsync(hdist.data(), dst[cur].p, N * 4, hipMemcpyDeviceToHost, st));
     DMG_HIP(hipStreamSynchronize(st));
 
+    lap("passes + downloads");
+    if (timing) fprintf(stderr, "[flow] %d pass candidates\n", ncand);
     // lowest pass per (lake, neighbouring lake), canonical order
     std::map<int, std::map<int, Pass>> best;
     for (const flow_cand &c : cands) {
@@ -364,6 +378,7 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
     std::map<int, std::set<Pass, PassLess>> passes;
     for (auto &kv : best) for (auto &q : kv.second) passes[kv.first].insert(q.second);
 
+    lap("host: best passes");
     // solvingConnections (:533-595)
     std::vector<int> mouths;
     for (size_t i = 0; i < N; i++)
@@ -395,6 +410,7 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
         push_next(to_lake);
     }
 
+    lap("host: solve connections");
     // depth offset of every lake that calculateflow's recursion reaches: river mouths at 0, a connected lake one
     // below the cell it drains into
     std::vector<int> lake_off(N, -1), conn_from(N, -1);
@@ -419,6 +435,8 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
         if (hlabel[i] >= 0 && lake_off[hlabel[i]] >= 0) max_depth = std::max(max_depth, lake_off[hlabel[i]] + hdist[i]);
     const int levels = max_depth + 1;
 
+    lap("host: lake offsets");
+    if (timing) fprintf(stderr, "[flow] %d levels, %zu mouths, %zu connections\n", levels, mouths.size(), connections.size());
     dev_buf dlo, dcf, gdepth, hist, order, acc;
     if ((rc = upload_vec(ctx, dlo, lake_off)) || (rc = upload_vec(ctx, dcf, conn_from))) return rc;
     DMG_ALLOC(gdepth, N * 4); DMG_ALLOC(hist, (size_t)levels * 4); DMG_ALLOC(order, N * 4); DMG_ALLOC(acc, N * 4);
@@ -433,6 +451,7 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
     hipLaunchKernelGGL(k_flow_scatter, dim3(nb), dim3(256), 0, st, gdepth.i(), hist.i(), order.i(), N, levels);
     hipLaunchKernelGGL(k_fill_f, dim3(nb), dim3(256), 0, st, d_flow, -1.0f, N);        // unreached cells keep -1 (:598-604)
     DMG_HIP(hipGetLastError());
+    lap("upload + depth sort");
     for (int l = levels - 1; l >= 0; l--) {
         int cnt = start[l + 1] - start[l];
         if (!cnt) continue;
@@ -441,6 +460,7 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
     }
     DMG_HIP(hipGetLastError());
     DMG_HIP(hipStreamSynchronize(st));                   // the temporaries above are released on return
+    lap("level sums");
     return DMG_OK;
 }
 
