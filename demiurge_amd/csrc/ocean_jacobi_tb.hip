@@ -46,24 +46,40 @@ __device__ __forceinline__ float dpp_from_next_lane(float v)   // lane i <- lane
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
 }
-// branch-free land handling for rows that contain coast: a neighbour flagged in the code is replaced by the centre
-// value, a land centre yields 0 (OceanCurrents.cpp:470-473,481).  Bit k of the code byte -> all-ones mask via
-// v_bfe_i32, select via v_bfi_b32: no VCC/SGPR lane masks.
-__device__ __forceinline__ float sel_bits(unsigned code, int bit, float if_set, float if_clear)
+// Land handling for wave-rows that contain coast.  Inside the tile every set neighbour bit means "that neighbour is
+// land" (the clamp-onto-self bits of non-pole edge rows are cleared at load: the mirrored row holds the cell's own
+// value), and land cells hold exactly +0.0 (k_zero_land on input, this kernel on output).  Replacing a land neighbour
+// by the centre value (OceanCurrents.cpp:470-473) is therefore  pN | (pC & mask)  on the bit patterns: v_bfe_i32 for
+// the mask, one v_and_or_b32 for the select -- no lane masks, no VCC traffic.
+// (inline asm: left to itself the compiler turns the pattern back into v_cndmask and hoists 40 lane masks per row
+// out of the sweep loop into VGPR lanes, paying two v_readlane + s_nop per select)
+// `tick` is the sweep counter: an unused asm input that keeps the mask extraction inside the sweep loop.
+template <int BIT>
+__device__ __forceinline__ int code_mask(unsigned code, int tick)        // 0 or -1 from bit BIT
 {
-    int m = __builtin_amdgcn_sbfe((int)code, bit, 1);          // 0 or -1
-    int a = __builtin_bit_cast(int, if_set), b = __builtin_bit_cast(int, if_clear);
-    return __builtin_bit_cast(float, (m & a) | (~m & b));
+    int m;
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(code), "n"(BIT), "s"(tick));
+    return m;
 }
-__device__ __forceinline__ float tb_cell(float pC, float pN, float pS, float pE, float pW, float b, unsigned code,
-                                         int shift, const jacobi_row &k)
+template <int BIT>
+__device__ __forceinline__ float land_to_centre(unsigned code, int tick, float pC, float pK)
 {
-    pN = sel_bits(code, shift + 0, pC, pN);
-    pS = sel_bits(code, shift + 1, pC, pS);
-    pE = sel_bits(code, shift + 2, pC, pE);
-    pW = sel_bits(code, shift + 3, pC, pW);
+    float o;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(o) : "v"(pC), "v"(code_mask<BIT>(code, tick)), "v"(pK));
+    return o;
+}
+template <int SHIFT>
+__device__ __forceinline__ float tb_cell(float pC, float pN, float pS, float pE, float pW, float b, unsigned code,
+                                         int tick, const jacobi_row &k)
+{
+    pN = land_to_centre<SHIFT + 0>(code, tick, pC, pN);
+    pS = land_to_centre<SHIFT + 1>(code, tick, pC, pS);
+    pE = land_to_centre<SHIFT + 2>(code, tick, pC, pE);
+    pW = land_to_centre<SHIFT + 3>(code, tick, pC, pW);
     float r = jacobi_value(pN, pS, pE, pW, b, k);
-    return sel_bits(code, shift + 4, 0.0f, r);
+    float o;                                                     // land centre -> +0.0 (:481):  r & ~mask
+    asm("v_bfi_b32 %0, %1, 0, %2" : "=v"(o) : "v"(code_mask<SHIFT + 4>(code, tick)), "v"(r));
+    return o;
 }
 
 // maps an extended-tile row to its source: local row l, whether it is a mirrored copy, whether it is pole-shifted
@@ -147,6 +163,10 @@ __global__ __launch_bounds__(NW * 64, (R <= 10 ? 4 : (R <= 12 ? 3 : 2))) void k_
         b[r] = *reinterpret_cast<const float4 *>(a.b + off);
         unsigned c = *reinterpret_cast<const unsigned *>(a.code + off);
         if (m.flip) c = (c & 0xFCFCFCFCu) | ((c & 0x01010101u) << 1) | ((c & 0x02020202u) >> 1);   // swap N/S bits
+        // a non-pole edge row's clamp bit only says "the tap lands on the cell itself"; its mirror row is in the tile
+        int yg = a.y_first + e0 + r;
+        if (yg == 0 && !a.spole) c &= ~0x02020202u;
+        if (yg == a.H - 1 && !a.npole) c &= ~0x01010101u;
         code[r] = c;
         if (__builtin_amdgcn_ballot_w64((c & 0x1F1F1F1Fu) != 0)) mixed_rows |= (1u << r);
         if (__builtin_amdgcn_ballot_w64((c & 0x10101010u) != 0x10101010u) == 0) land_rows |= (1u << r);
@@ -192,10 +212,10 @@ __global__ __launch_bounds__(NW * 64, (R <= 10 ? 4 : (R <= 12 ? 3 : 2))) void k_
                 o.w = jacobi_value(N.w, S.w, er, C.z, b[r].w, k);
             } else {
                 unsigned c = code[r];
-                o.x = tb_cell(C.x, N.x, S.x, C.y, wl, b[r].x, c, 0, k);
-                o.y = tb_cell(C.y, N.y, S.y, C.z, C.x, b[r].y, c, 8, k);
-                o.z = tb_cell(C.z, N.z, S.z, C.w, C.y, b[r].z, c, 16, k);
-                o.w = tb_cell(C.w, N.w, S.w, er, C.z, b[r].w, c, 24, k);
+                o.x = tb_cell<0>(C.x, N.x, S.x, C.y, wl, b[r].x, c, s, k);
+                o.y = tb_cell<8>(C.y, N.y, S.y, C.z, C.x, b[r].y, c, s, k);
+                o.z = tb_cell<16>(C.z, N.z, S.z, C.w, C.y, b[r].z, c, s, k);
+                o.w = tb_cell<24>(C.w, N.w, S.w, er, C.z, b[r].w, c, s, k);
             }
             p[r] = o;
         }
@@ -219,7 +239,7 @@ struct tb_shape { int R, NW; };
 static tb_shape tb_pick_shape()
 {
     static tb_shape s = [] {
-        tb_shape d = { 10, 8 };
+        tb_shape d = { 8, 8 };
         const char *e = getenv("DMG_TB_SHAPE");
         int r = 0, nw = 0;
         if (e && sscanf(e, "%dx%d", &r, &nw) == 2 &&
