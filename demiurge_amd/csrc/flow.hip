@@ -15,7 +15,9 @@
 // compacted candidate list.  Tie-breaking where the reference is container-order dependent follows
 // oracle/flow_oracle.cpp: total order (height, from, tolocation), lakes in ascending cell index.
 #include "canvas.h"
+#include <hipcub/hipcub.hpp>
 #include <algorithm>
+#include <queue>
 #include <map>
 #include <set>
 #include <tuple>
@@ -186,10 +188,12 @@ __global__ void k_flow_label(const int *__restrict__ root, const unsigned char *
 }
 
 // ---- pass candidates --------------------------------------------------------------------------------------------
-struct flow_cand { int lake, from, s; float h; };
-
+// One candidate per boundary cell s: the lowest neighbour that belongs to another catchment (:470-492).
+//   key = (lake of s) << 32 | (neighbouring lake)        val = (pass height bits) << 32 | s
+// heights are > 0, so their fp32 bit patterns order like the values.
 __global__ void k_flow_passes(flow_canvas fc, const float *__restrict__ h, const int *__restrict__ label,
-                              const unsigned short *__restrict__ mask, flow_cand *__restrict__ out, int *__restrict__ count, int cap)
+                              const unsigned short *__restrict__ mask, unsigned long long *__restrict__ key,
+                              unsigned long long *__restrict__ val, int *__restrict__ count, int cap)
 {
     int W = fc.c.W, H = fc.c.H;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -214,19 +218,66 @@ __global__ void k_flow_passes(flow_canvas fc, const float *__restrict__ h, const
     int lid = label[nlake];
     if (mask[lid] & 512u) return;                       // never towards a river-mouth lake (:484)
     int slot = atomicAdd(count, 1);
-    if (slot < cap) { flow_cand c; c.lake = lake; c.from = lid; c.s = (int)i; c.h = fmaxf(minpass, h[i]); out[slot] = c; }
+    if (slot < cap) {
+        key[slot] = ((unsigned long long)(unsigned)lake << 32) | (unsigned)lid;
+        val[slot] = ((unsigned long long)__float_as_uint(fmaxf(minpass, h[i])) << 32) | (unsigned)i;
+    }
+}
+
+__global__ void k_flow_heads(const unsigned long long *__restrict__ key, unsigned char *__restrict__ flag, int n)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flag[i] = (i == 0 || key[i] != key[i - 1]) ? 1 : 0;
+}
+
+// per unique (lake, from) pass: sort key (lake << 32 | height bits), payload (from << 32 | s), depth of s
+__global__ void k_flow_pack(const unsigned long long *__restrict__ ukey, const unsigned long long *__restrict__ uval,
+                            unsigned long long *__restrict__ key2, unsigned long long *__restrict__ pay, int n)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned long long k = ukey[i], v = uval[i];
+    key2[i] = (k & 0xFFFFFFFF00000000ull) | (v >> 32);
+    pay[i] = (k << 32) | (v & 0xFFFFFFFFull);
+}
+
+__global__ void k_flow_gather_dist(const unsigned long long *__restrict__ pay, const int *__restrict__ dist, int *__restrict__ out, int n)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = dist[(unsigned)(pay[i] & 0xFFFFFFFFull)];
+}
+
+// river-mouth lakes = sinks (bit 16) next to the ocean (bit 512), compacted
+__global__ void k_flow_mouths(const unsigned short *__restrict__ mask, int *__restrict__ out, int *__restrict__ count, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned m = mask[i];
+    if (m != 0xFFFFu && (m & 16u) && (m & 512u)) out[atomicAdd(count, 1)] = (int)i;
+}
+
+__global__ void k_flow_scatter_pairs(const int *__restrict__ idx, const int *__restrict__ v, int *__restrict__ dst, int n)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[idx[i]] = v[i];
 }
 
 // ---- upstream-area accumulation by depth level --------------------------------------------------------------------
 __global__ void k_flow_gdepth(const int *__restrict__ label, const int *__restrict__ dist, const int *__restrict__ lake_off,
-                              int *__restrict__ gdepth, int *__restrict__ hist, size_t n, int max_levels)
+                              int *__restrict__ gdepth, int *__restrict__ maxd, size_t n)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int l = label[i], g = -1;
     if (l >= 0 && lake_off[l] >= 0) g = dist[i] + lake_off[l];
     gdepth[i] = g;
-    if (g >= 0 && g < max_levels) atomicAdd(&hist[g], 1);
+    if (g > 0) atomicMax(maxd, g);
+}
+
+__global__ void k_flow_hist(const int *__restrict__ gdepth, int *__restrict__ hist, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && gdepth[i] >= 0) atomicAdd(&hist[gdepth[i]], 1);
 }
 
 __global__ void k_flow_scatter(const int *__restrict__ gdepth, int *__restrict__ cursor, int *__restrict__ order, size_t n, int max_levels)
@@ -313,7 +364,7 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
         float geoy = (fy * (grid.coords[1] - grid.coords[0]) + grid.coords[0]);
         own[y] = (float)(pwy * pwx * cosf(geoy) * 1e-5);
     }
-    dev_buf ddx, ddy, down, hb, tmp, code, mask, par[2], dst[2], label, changed, cand, count;
+    dev_buf ddx, ddy, down, hb, tmp, code, mask, par[2], dst[2], label, changed, count;
     int rc;
     if ((rc = upload_vec(ctx, ddx, dxr)) || (rc = upload_vec(ctx, ddy, dyr)) || (rc = upload_vec(ctx, down, own))) return rc;
     DMG_ALLOC(hb, N * 4); DMG_ALLOC(tmp, N * 4); DMG_ALLOC(code, N); DMG_ALLOC(mask, N * 2);
@@ -345,103 +396,151 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
     hipLaunchKernelGGL(k_flow_label, dim3(nb), dim3(256), 0, st, par[cur].i(), (const unsigned char *)code.p, label.i(), N);
 
     lap("pointer jumping");
-    // boundary cells -> pass candidates (compacted), then the lake graph on the host
+    // boundary cells -> pass candidates; reduce to the lowest pass per lake pair on the device:
+    // sort by (height, s), stable sort by (lake, from), keep segment heads, then order each lake's passes by height
     int cap = (int)std::min<size_t>(N, (size_t)1 << 28);
-    DMG_ALLOC(cand, (size_t)cap * sizeof(flow_cand));
+    dev_buf k0, v0, k1, v1, flags, nsel, tmpst, sdist, mouths_d;
+    DMG_ALLOC(k0, (size_t)cap * 8); DMG_ALLOC(v0, (size_t)cap * 8); DMG_ALLOC(k1, (size_t)cap * 8); DMG_ALLOC(v1, (size_t)cap * 8);
+    DMG_ALLOC(nsel, 8);
     DMG_HIP(hipMemsetAsync(count.p, 0, 4, st));
     hipLaunchKernelGGL(k_flow_passes, dim3(nb), dim3(256), 0, st, fc, d_h, label.i(), (const unsigned short *)mask.p,
-                       (flow_cand *)cand.p, count.i(), cap);
+                       (unsigned long long *)k0.p, (unsigned long long *)v0.p, count.i(), cap);
     DMG_HIP(hipGetLastError());
     int ncand = 0;
     DMG_HIP(hipMemcpyAsync(&ncand, count.p, 4, hipMemcpyDeviceToHost, st));
+    // river mouths, compacted (order restored on the host)
+    DMG_ALLOC(mouths_d, N * 4);
+    DMG_HIP(hipMemsetAsync(nsel.p, 0, 8, st));
+    hipLaunchKernelGGL(k_flow_mouths, dim3(nb), dim3(256), 0, st, (const unsigned short *)mask.p, mouths_d.i(), nsel.i(), N);
+    int nmouth = 0;
+    DMG_HIP(hipMemcpyAsync(&nmouth, nsel.p, 4, hipMemcpyDeviceToHost, st));
     DMG_HIP(hipStreamSynchronize(st));
     if (ncand > cap) return dmg_fail(DMG_ENOMEM, "flow: %d pass candidates exceed the buffer", ncand);
-    std::vector<flow_cand> cands(ncand);
-    std::vector<unsigned short> hmask(N);
-    std::vector<int> hlabel(N), hdist(N);
-    if (ncand) DMG_HIP(hipMemcpyAsync(cands.data(), cand.p, (size_t)ncand * sizeof(flow_cand), hipMemcpyDeviceToHost, st));
-    DMG_HIP(hipMemcpyAsync(hmask.data(), mask.p, N * 2, hipMemcpyDeviceToHost, st));
-    DMG_HIP(hipMemcpyAsync(hlabel.data(), label.p, N * 4, hipMemcpyDeviceToHost, st));
-    DMG_HIP(hipMemcpyAsync(hdist.data(), dst[cur].p, N * 4, hipMemcpyDeviceToHost, st));
-    DMG_HIP(hipStreamSynchronize(st));
+    std::vector<int> mouths(nmouth);
+    if (nmouth) DMG_HIP(hipMemcpyAsync(mouths.data(), mouths_d.p, (size_t)nmouth * 4, hipMemcpyDeviceToHost, st));
 
-    lap("passes + downloads");
-    if (timing) fprintf(stderr, "[flow] %d pass candidates\n", ncand);
-    // lowest pass per (lake, neighbouring lake), canonical order
-    std::map<int, std::map<int, Pass>> best;
-    for (const flow_cand &c : cands) {
-        Pass p{ c.h, c.from, c.s };
-        auto &m = best[c.lake];
-        auto it = m.find(c.from);
-        if (it == m.end() || PassLess()(p, it->second)) m[c.from] = p;
+    int nuniq = 0;
+    std::vector<unsigned long long> hkey, hpay;
+    std::vector<int> hsdist;
+    if (ncand) {
+        typedef unsigned long long u64;
+        size_t tb = 0, tb2 = 0;
+        (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb, (u64 *)v0.p, (u64 *)v1.p, (u64 *)k0.p, (u64 *)k1.p, ncand, 0, 64, st);
+        DMG_ALLOC(flags, (size_t)ncand);
+        (void)hipcub::DeviceSelect::Flagged(nullptr, tb2, (u64 *)k0.p, (unsigned char *)flags.p, (u64 *)k1.p, nsel.i(), ncand, st);
+        DMG_ALLOC(tmpst, std::max(tb, tb2) + 256);
+        // 1) by (height, s): (v0,k0) -> (v1,k1)
+        DMG_HIP(hipcub::DeviceRadixSort::SortPairs(tmpst.p, tb, (u64 *)v0.p, (u64 *)v1.p, (u64 *)k0.p, (u64 *)k1.p, ncand, 0, 64, st));
+        // 2) stable by (lake, from): (k1,v1) -> (k0,v0); within a lake pair the lowest (height, s) comes first
+        DMG_HIP(hipcub::DeviceRadixSort::SortPairs(tmpst.p, tb, (u64 *)k1.p, (u64 *)k0.p, (u64 *)v1.p, (u64 *)v0.p, ncand, 0, 64, st));
+        hipLaunchKernelGGL(k_flow_heads, dim3((ncand + 255) / 256), dim3(256), 0, st, (const u64 *)k0.p, (unsigned char *)flags.p, ncand);
+        DMG_HIP(hipcub::DeviceSelect::Flagged(tmpst.p, tb2, (u64 *)k0.p, (unsigned char *)flags.p, (u64 *)k1.p, nsel.i(), ncand, st));
+        DMG_HIP(hipcub::DeviceSelect::Flagged(tmpst.p, tb2, (u64 *)v0.p, (unsigned char *)flags.p, (u64 *)v1.p, nsel.i(), ncand, st));
+        DMG_HIP(hipMemcpyAsync(&nuniq, nsel.p, 4, hipMemcpyDeviceToHost, st));
+        DMG_HIP(hipStreamSynchronize(st));
+        // 3) (lake, height) order with (from, s) payload; stable, so equal heights stay in `from` order
+        hipLaunchKernelGGL(k_flow_pack, dim3((nuniq + 255) / 256), dim3(256), 0, st, (const u64 *)k1.p, (const u64 *)v1.p,
+                           (u64 *)k0.p, (u64 *)v0.p, nuniq);
+        DMG_HIP(hipcub::DeviceRadixSort::SortPairs(tmpst.p, tb, (u64 *)k0.p, (u64 *)k1.p, (u64 *)v0.p, (u64 *)v1.p, nuniq, 0, 64, st));
+        DMG_ALLOC(sdist, (size_t)nuniq * 4);
+        hipLaunchKernelGGL(k_flow_gather_dist, dim3((nuniq + 255) / 256), dim3(256), 0, st, (const u64 *)v1.p, dst[cur].i(), sdist.i(), nuniq);
+        DMG_HIP(hipGetLastError());
+        hkey.resize(nuniq); hpay.resize(nuniq); hsdist.resize(nuniq);
+        DMG_HIP(hipMemcpyAsync(hkey.data(), k1.p, (size_t)nuniq * 8, hipMemcpyDeviceToHost, st));
+        DMG_HIP(hipMemcpyAsync(hpay.data(), v1.p, (size_t)nuniq * 8, hipMemcpyDeviceToHost, st));
+        DMG_HIP(hipMemcpyAsync(hsdist.data(), sdist.p, (size_t)nuniq * 4, hipMemcpyDeviceToHost, st));
     }
-    std::map<int, std::set<Pass, PassLess>> passes;
-    for (auto &kv : best) for (auto &q : kv.second) passes[kv.first].insert(q.second);
+    DMG_HIP(hipStreamSynchronize(st));
+    std::sort(mouths.begin(), mouths.end());
+    lap("passes: sort/reduce/download");
+    if (timing) fprintf(stderr, "[flow] %d pass candidates -> %d lake pairs, %d river mouths\n", ncand, nuniq, nmouth);
 
-    lap("host: best passes");
-    // solvingConnections (:533-595)
-    std::vector<int> mouths;
-    for (size_t i = 0; i < N; i++)
-        if (hmask[i] != 0xFFFFu && (hmask[i] & 16u) && (hmask[i] & 512u)) mouths.push_back((int)i);
-    std::set<Pass, PassLess> candidates;
-    std::set<int> placed(mouths.begin(), mouths.end());
-    std::unordered_map<int, Pass> connections;
+    // solvingConnections (:533-595) on the reduced list: entry i = pass into lake (hkey>>32) at cell s from lake `from`
+    struct Entry { float h; int from, s, lake, sdist; };
+    std::vector<Entry> ent(nuniq);
+    std::unordered_map<int, std::pair<int, int>> range;      // lake -> [cursor, end) into ent
+    for (int i = 0; i < nuniq; i++) {
+        unsigned hb = (unsigned)(hkey[i] & 0xFFFFFFFFull);
+        Entry e;
+        memcpy(&e.h, &hb, 4);
+        e.lake = (int)(hkey[i] >> 32); e.from = (int)(hpay[i] >> 32); e.s = (int)(hpay[i] & 0xFFFFFFFFull); e.sdist = hsdist[i];
+        ent[i] = e;
+        auto it = range.find(e.lake);
+        if (it == range.end()) range[e.lake] = { i, i + 1 }; else it->second.second = i + 1;
+    }
+    auto worse = [&](int a, int b) {                         // priority_queue keeps the LOWEST (h, from, s) on top
+        return std::tie(ent[a].h, ent[a].from, ent[a].s) > std::tie(ent[b].h, ent[b].from, ent[b].s);
+    };
+    std::priority_queue<int, std::vector<int>, decltype(worse)> candidates(worse);
+    std::unordered_map<int, char> placed;
+    placed.reserve(mouths.size() * 4 + 16);
+    for (int m : mouths) placed[m] = 1;
     auto push_next = [&](int lake) {
-        auto it = passes.find(lake);
-        if (it == passes.end()) return;
-        auto &set = it->second;
-        while (!set.empty()) {
-            Pass c = *set.begin();
-            set.erase(set.begin());
-            if (placed.count(c.from)) continue;
-            candidates.insert(c);
+        auto it = range.find(lake);
+        if (it == range.end()) return;
+        int &cursor = it->second.first;
+        while (cursor < it->second.second) {
+            int c = cursor++;
+            if (placed.count(ent[c].from)) continue;
+            candidates.push(c);
             break;
         }
     };
+    std::unordered_map<int, int> connections;                // tolocation -> entry (a later one replaces an earlier one, :588)
     for (int lake : mouths) push_next(lake);
     while (!candidates.empty()) {
-        Pass p = *candidates.begin();
-        candidates.erase(candidates.begin());
-        int to_lake = hlabel[p.tolocation];
-        if (placed.count(p.from)) { push_next(to_lake); continue; }
-        placed.insert(p.from);
-        connections[p.tolocation] = p;                   // a later pass at the same cell replaces an earlier one (:588)
+        int c = candidates.top();
+        candidates.pop();
+        const Entry &p = ent[c];
+        if (placed.count(p.from)) { push_next(p.lake); continue; }
+        placed[p.from] = 1;
+        connections[p.s] = c;
         push_next(p.from);
-        push_next(to_lake);
+        push_next(p.lake);
     }
-
     lap("host: solve connections");
+
     // depth offset of every lake that calculateflow's recursion reaches: river mouths at 0, a connected lake one
     // below the cell it drains into
-    std::vector<int> lake_off(N, -1), conn_from(N, -1);
-    std::unordered_map<int, std::vector<std::pair<int, int>>> into;     // lake -> (tolocation, from) of lakes draining into it
-    for (auto &kv : connections) {
-        conn_from[kv.first] = kv.second.from;
-        into[hlabel[kv.first]].push_back({ kv.first, kv.second.from });
-    }
-    std::vector<int> work(mouths.begin(), mouths.end());
-    for (int m : mouths) lake_off[m] = 0;
-    int max_depth = 0;
+    std::unordered_map<int, std::vector<int>> into;          // lake -> entries of the lakes draining into it
+    for (auto &kv : connections) into[ent[kv.second].lake].push_back(kv.second);
+    std::vector<int> off_idx, off_val, conn_idx, conn_val;
+    std::vector<std::pair<int, int>> work;                    // (lake, offset)
+    for (int m : mouths) work.push_back({ m, 0 });
     while (!work.empty()) {
-        int lake = work.back(); work.pop_back();
+        auto [lake, off] = work.back(); work.pop_back();
+        off_idx.push_back(lake); off_val.push_back(off);
         auto it = into.find(lake);
         if (it == into.end()) continue;
-        for (auto &e : it->second) {
-            lake_off[e.second] = lake_off[lake] + hdist[e.first] + 1;
-            work.push_back(e.second);
+        for (int c : it->second) {
+            conn_idx.push_back(ent[c].s); conn_val.push_back(ent[c].from);
+            work.push_back({ ent[c].from, off + ent[c].sdist + 1 });
         }
     }
-    for (size_t i = 0; i < N; i++)
-        if (hlabel[i] >= 0 && lake_off[hlabel[i]] >= 0) max_depth = std::max(max_depth, lake_off[hlabel[i]] + hdist[i]);
-    const int levels = max_depth + 1;
-
     lap("host: lake offsets");
-    if (timing) fprintf(stderr, "[flow] %d levels, %zu mouths, %zu connections\n", levels, mouths.size(), connections.size());
-    dev_buf dlo, dcf, gdepth, hist, order, acc;
-    if ((rc = upload_vec(ctx, dlo, lake_off)) || (rc = upload_vec(ctx, dcf, conn_from))) return rc;
-    DMG_ALLOC(gdepth, N * 4); DMG_ALLOC(hist, (size_t)levels * 4); DMG_ALLOC(order, N * 4); DMG_ALLOC(acc, N * 4);
+    if (timing) fprintf(stderr, "[flow] %zu connections, %zu lakes reached\n", connections.size(), off_idx.size());
+
+    dev_buf dlo, dcf, gdepth, hist, order, acc, doi, dov, dci, dcv, dmax;
+    DMG_ALLOC(dlo, N * 4); DMG_ALLOC(dcf, N * 4); DMG_ALLOC(gdepth, N * 4); DMG_ALLOC(order, N * 4); DMG_ALLOC(acc, N * 4); DMG_ALLOC(dmax, 4);
+    DMG_HIP(hipMemsetAsync(dlo.p, 0xFF, N * 4, st));         // -1
+    DMG_HIP(hipMemsetAsync(dcf.p, 0xFF, N * 4, st));
+    DMG_HIP(hipMemsetAsync(dmax.p, 0, 4, st));
+    if ((rc = upload_vec(ctx, doi, off_idx)) || (rc = upload_vec(ctx, dov, off_val))) return rc;
+    if (!off_idx.empty())
+        hipLaunchKernelGGL(k_flow_scatter_pairs, dim3(((int)off_idx.size() + 255) / 256), dim3(256), 0, st, doi.i(), dov.i(), dlo.i(), (int)off_idx.size());
+    if (!conn_idx.empty()) {
+        if ((rc = upload_vec(ctx, dci, conn_idx)) || (rc = upload_vec(ctx, dcv, conn_val))) return rc;
+        hipLaunchKernelGGL(k_flow_scatter_pairs, dim3(((int)conn_idx.size() + 255) / 256), dim3(256), 0, st, dci.i(), dcv.i(), dcf.i(), (int)conn_idx.size());
+    }
+    hipLaunchKernelGGL(k_flow_gdepth, dim3(nb), dim3(256), 0, st, label.i(), dst[cur].i(), dlo.i(), gdepth.i(), dmax.i(), N);
+    DMG_HIP(hipGetLastError());
+    int max_depth = 0;
+    DMG_HIP(hipMemcpyAsync(&max_depth, dmax.p, 4, hipMemcpyDeviceToHost, st));
+    DMG_HIP(hipStreamSynchronize(st));
+    const int levels = max_depth + 1;
+    DMG_ALLOC(hist, (size_t)levels * 4);
     DMG_HIP(hipMemsetAsync(hist.p, 0, (size_t)levels * 4, st));
-    hipLaunchKernelGGL(k_flow_gdepth, dim3(nb), dim3(256), 0, st, label.i(), dst[cur].i(), dlo.i(), gdepth.i(), hist.i(), N, levels);
+    hipLaunchKernelGGL(k_flow_hist, dim3(nb), dim3(256), 0, st, gdepth.i(), hist.i(), N);
     DMG_HIP(hipGetLastError());
     std::vector<int> hh(levels), start(levels + 1, 0);
     DMG_HIP(hipMemcpyAsync(hh.data(), hist.p, (size_t)levels * 4, hipMemcpyDeviceToHost, st));
@@ -451,6 +550,7 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
     hipLaunchKernelGGL(k_flow_scatter, dim3(nb), dim3(256), 0, st, gdepth.i(), hist.i(), order.i(), N, levels);
     hipLaunchKernelGGL(k_fill_f, dim3(nb), dim3(256), 0, st, d_flow, -1.0f, N);        // unreached cells keep -1 (:598-604)
     DMG_HIP(hipGetLastError());
+    if (timing) fprintf(stderr, "[flow] %d levels\n", levels);
     lap("upload + depth sort");
     for (int l = levels - 1; l >= 0; l--) {
         int cnt = start[l + 1] - start[l];
