@@ -72,7 +72,7 @@ int blur_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, fl
 
 // device-resident flow accumulation (flow.hip) and erosion pass (filters.hip), used by dmg_erosion_run
 int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, const float *d_h, const float *d_sel,
-                float preblur, float exponent, float *d_flow);
+                float preblur, float exponent, float *d_flow, int lakes = 0);
 int erosion_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, const float *d_h, const float *d_flow,
                    const float *d_updrift, float *d_out, const float *d_dx, const float *d_dy, float factor, float slope_exponent);
 

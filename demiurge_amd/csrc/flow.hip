@@ -313,6 +313,24 @@ __global__ void k_flow_level(flow_canvas fc, const int *__restrict__ order, int 
     out[p] = powf(sum, exponent);                       // lakeID[p] = pow(sum, exponent) (:620)
 }
 
+// lake drawing (:660-699): cells of a reached lake's catchment at or below the lake's water level become 0
+__global__ void k_flow_lakefill(const float *__restrict__ h, const int *__restrict__ label, const float *__restrict__ level,
+                                float *__restrict__ flow, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int l = label[i];
+    if (l < 0) return;
+    float wl = level[l];                                // NaN for lakes the walk from the river mouths never reaches
+    if (h[i] <= wl) flow[i] = 0.0f;
+}
+
+__global__ void k_flow_scatter_f(const int *__restrict__ idx, const float *__restrict__ v, float *__restrict__ dst, int n)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[idx[i]] = v[i];
+}
+
 __global__ void k_fill_f(float *p, float v, size_t n)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -330,7 +348,7 @@ struct PassLess {
 
 // Device-resident flow accumulation.  d_h: heights (W*H); d_sel: selection mask or nullptr; d_flow: result.
 int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, const float *d_h, const float *d_sel,
-                float preblur, float exponent, float *d_flow)
+                float preblur, float exponent, float *d_flow, int lakes)
 {
     const int W = grid.W, H = grid.H;
     const size_t N = (size_t)W * H;
@@ -505,16 +523,18 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
     std::unordered_map<int, std::vector<int>> into;          // lake -> entries of the lakes draining into it
     for (auto &kv : connections) into[ent[kv.second].lake].push_back(kv.second);
     std::vector<int> off_idx, off_val, conn_idx, conn_val;
-    std::vector<std::pair<int, int>> work;                    // (lake, offset)
-    for (int m : mouths) work.push_back({ m, 0 });
+    std::vector<float> off_level;                             // water level of the lake: highest pass on the way down (:683-690)
+    struct Work { int lake, off; float level; };
+    std::vector<Work> work;
+    for (int m : mouths) work.push_back({ m, 0, 0.0f });
     while (!work.empty()) {
-        auto [lake, off] = work.back(); work.pop_back();
-        off_idx.push_back(lake); off_val.push_back(off);
-        auto it = into.find(lake);
+        Work w = work.back(); work.pop_back();
+        off_idx.push_back(w.lake); off_val.push_back(w.off); off_level.push_back(w.level);
+        auto it = into.find(w.lake);
         if (it == into.end()) continue;
         for (int c : it->second) {
             conn_idx.push_back(ent[c].s); conn_val.push_back(ent[c].from);
-            work.push_back({ ent[c].from, off + ent[c].sdist + 1 });
+            work.push_back({ ent[c].from, w.off + ent[c].sdist + 1, w.level > ent[c].h ? w.level : ent[c].h });
         }
     }
     lap("host: lake offsets");
@@ -559,6 +579,16 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
                            (const unsigned short *)mask.p, dcf.i(), down.f(), acc.f(), d_flow, exponent);
     }
     DMG_HIP(hipGetLastError());
+    if (lakes && !off_idx.empty()) {
+        dev_buf dlevel, dlv;
+        DMG_ALLOC(dlevel, N * 4);
+        DMG_HIP(hipMemsetAsync(dlevel.p, 0xFF, N * 4, st));                          // NaN: compares false
+        if ((rc = upload_vec(ctx, dlv, off_level))) return rc;
+        hipLaunchKernelGGL(k_flow_scatter_f, dim3(((int)off_idx.size() + 255) / 256), dim3(256), 0, st, doi.i(), dlv.f(), dlevel.f(), (int)off_idx.size());
+        hipLaunchKernelGGL(k_flow_lakefill, dim3(nb), dim3(256), 0, st, d_h, label.i(), dlevel.f(), d_flow, N);
+        DMG_HIP(hipGetLastError());
+        DMG_HIP(hipStreamSynchronize(st));
+    }
     DMG_HIP(hipStreamSynchronize(st));                   // the temporaries above are released on return
     lap("level sums");
     return DMG_OK;
@@ -566,12 +596,12 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
 
 extern "C" {
 
-// FlowFilter::run (:719-786) with lakeflag = 0: flow_out[i] = pow(upstream area, exponent), -1 off the drained land
+// FlowFilter::run (:719-786): flow_out[i] = pow(upstream area, exponent), -1 off the drained land; lakes != 0 also
+// draws the lakes (lakeflag, :660-699)
 int dmg_flow_accumulate(dmg_ctx *ctx, const dmg_grid *grid, const float *h, const float *sel, float preblur,
                         float exponent, int lakes, float *flow_out)
 {
     DMG_CHECK_ARG(ctx != nullptr && h != nullptr && flow_out != nullptr && preblur >= 0.0f);
-    if (lakes) return dmg_fail(DMG_EINVAL, "dmg_flow_accumulate: lake drawing (FlowFilter lakeflag, :660-699) is not built yet");
     dmg_topology topo;
     int rc = dmg_check_grid(grid, &topo);
     if (rc) return rc;
@@ -584,7 +614,7 @@ int dmg_flow_accumulate(dmg_ctx *ctx, const dmg_grid *grid, const float *h, cons
         DMG_ALLOC(dsel, N * 4);
         DMG_HIP(hipMemcpyAsync(dsel.p, sel, N * 4, hipMemcpyHostToDevice, ctx->stream));
     }
-    if ((rc = flow_device(ctx, *grid, topo, dh.f(), sel ? dsel.f() : nullptr, preblur, exponent, dflow.f()))) return rc;
+    if ((rc = flow_device(ctx, *grid, topo, dh.f(), sel ? dsel.f() : nullptr, preblur, exponent, dflow.f(), lakes))) return rc;
     DMG_HIP(hipMemcpyAsync(flow_out, dflow.p, N * 4, hipMemcpyDeviceToHost, ctx->stream));
     DMG_HIP(hipStreamSynchronize(ctx->stream));
     return DMG_OK;

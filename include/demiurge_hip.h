@@ -174,7 +174,7 @@ int dmg_erosion_pass(dmg_ctx *ctx, const dmg_grid *grid, float *h_inout, const f
 /* FlowFilter::run (src/filter/FlowFilter.cpp:719-786): pre-blur, stochastic-D8 directions, catchments, lake graph,
  * upstream area.  flow_out[i] = pow(area, exponent), -1 where no river mouth is reached (what the reference uploads
  * into the terrain texture, :714-716).  sel = selection mask or NULL (all ones, src/Project.cpp:102-104).
- * lakes != 0 (the lake-drawing pass, :660-699) is not implemented yet and is refused. */
+ * lakes != 0 = FlowFilter's lakeflag (:660-699): cells at or below their lake's water level are set to 0. */
 int dmg_flow_accumulate(dmg_ctx *ctx, const dmg_grid *grid, const float *h, const float *sel_or_null, float preblur,
                         float exponent, int lakes, float *flow_out);
 /* cpufilter::run (src/filter/cpufilter.cpp:41-222): uplift = max(h,0)/N, heights scaled by 1/N on land, then

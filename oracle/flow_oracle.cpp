@@ -48,8 +48,8 @@ inline int neighbours(const Topo &t, int pos, int dat, int out[8])
 }
 }  // namespace
 
-extern "C" void orc_flow_accumulate(const orc_grid *g, const float *h, const float *sel_in, float preblur, float exponent,
-                                    float *flow, float *codes_out, float *mask_out, int *label_out)
+static void flow_accumulate(const orc_grid *g, const float *h, const float *sel_in, float preblur, float exponent,
+                            int lakeflag, float *flow, float *codes_out, float *mask_out, int *label_out)
 {
     const int W = g->W, H = g->H;
     const size_t N = (size_t)W * H;
@@ -182,8 +182,42 @@ extern "C" void orc_flow_accumulate(const orc_grid *g, const float *h, const flo
             st.pop_back();
         }
     }
+    // lake drawing (:660-699): walking the lake tree from every river mouth, a lake's water level is the highest
+    // pass on the way down to it; cells of the lake's catchment at or below that level are marked 0
+    if (lakeflag) {
+        struct Job { int lake; float waterheight; };
+        std::vector<Job> jobs;
+        for (int lake : lakes)
+            if (nthbit((int)data[lake], 10)) jobs.push_back({ lake, 0.0f });
+        while (!jobs.empty()) {
+            Job j = jobs.back(); jobs.pop_back();
+            stack.assign(1, j.lake);
+            while (!stack.empty()) {
+                int p = stack.back(); stack.pop_back();
+                if (h[p] <= j.waterheight) out[p] = 0;
+                int n = neighbours(topo, p, (int)data[p], nb);
+                for (int k = 0; k < n; k++) stack.push_back(nb[k]);
+                auto it = connections.find(p);
+                if (it != connections.end()) {
+                    const Pass &c = it->second;
+                    jobs.push_back({ c.from, j.waterheight > c.h ? j.waterheight : c.h });
+                }
+            }
+        }
+    }
     std::memcpy(flow, out.data(), N * sizeof(float));
     if (codes_out) std::memcpy(codes_out, codes.data(), N * sizeof(float));
     if (mask_out) std::memcpy(mask_out, data.data(), N * sizeof(float));
     if (label_out) std::memcpy(label_out, label.data(), N * sizeof(int));
+}
+
+extern "C" void orc_flow_accumulate(const orc_grid *g, const float *h, const float *sel, float preblur, float exponent,
+                                    float *flow, float *codes, float *mask, int *label)
+{
+    flow_accumulate(g, h, sel, preblur, exponent, 0, flow, codes, mask, label);
+}
+extern "C" void orc_flow_accumulate_lakes(const orc_grid *g, const float *h, const float *sel, float preblur, float exponent,
+                                          float *flow)
+{
+    flow_accumulate(g, h, sel, preblur, exponent, 1, flow, nullptr, nullptr, nullptr);
 }

@@ -56,6 +56,7 @@ def lib():
         L.orc_flow_mask.argtypes = [G, P, P, P, P]
         L.orc_lake_adjacency.argtypes = [G, P, P]
         L.orc_flow_accumulate.argtypes = [G, P, P, ctypes.c_float, ctypes.c_float, P, P, P, P]
+        L.orc_flow_accumulate_lakes.argtypes = [G, P, P, ctypes.c_float, ctypes.c_float, P]
         _lib = L
     return _lib
 
@@ -205,3 +206,11 @@ def flow_accumulate(g, h, preblur=0.5, exponent=1.0, sel=None):
     lib().orc_flow_accumulate(ctypes.byref(g), _ptr(h), None if sel is None else _ptr(sel), preblur, exponent,
                               _ptr(flow), _ptr(codes), _ptr(mask), _ptr(label))
     return dict(flow=flow, codes=codes, mask=mask, label=label)
+
+
+def flow_accumulate_lakes(g, h, preblur=0.5, exponent=1.0, sel=None):
+    h = _f32(h)
+    sel = None if sel is None else _f32(sel)
+    flow = np.empty_like(h)
+    lib().orc_flow_accumulate_lakes(ctypes.byref(g), _ptr(h), None if sel is None else _ptr(sel), preblur, exponent, _ptr(flow))
+    return flow

@@ -130,3 +130,17 @@ def test_erosion_run_matches_oracle(dev, oracle):
     got = ctx.erosion_run(capi.make_grid(W, H), h0, N, iters, 0.5, 1.0, 1.0)
     assert relerr(got, hd) < 1e-3
     assert np.median(np.abs(got - hd)) < 1e-6 * np.abs(hd).max()
+
+
+@pytest.mark.gpu
+def test_flow_lake_drawing(dev, oracle):
+    """FlowFilter lakeflag (the standalone Flow tool passes true, FlowFilter.cpp:24-27): lake surfaces are 0"""
+    capi, ctx = dev
+    from demiurge_amd import synth
+    W, H = 256, 128
+    h = (synth.terrain(W, H) * 100 + synth.lcg_uniform(W * H, 99).reshape(H, W) * 8).astype(np.float32)
+    ref = oracle.flow_accumulate_lakes(oracle.grid(W, H), h, 0.5, 1.0)
+    got = ctx.flow_accumulate(capi.make_grid(W, H), h, 0.5, 1.0, lakes=1)
+    assert (ref == 0).sum() > 50                          # the case has lakes
+    assert ((got == 0) != (ref == 0)).mean() < 2e-3
+    assert (~np.isclose(got, ref, rtol=2e-6, atol=0)).mean() < 4e-3
