@@ -302,8 +302,10 @@ int dmg_ocean_set_terrain(dmg_ocean *o, const float *img)
     rc = ocean_build_codes8(o);
     if (rc) return rc;
     o->have_terrain = true;
-    // keep the "land holds exact zeros" invariant for whatever pressure is resident
-    return zero_land(o, o->p[o->cur]);
+    // keep the "land holds exact +0 in BOTH ping-pong buffers" invariant (the blocked kernel neither loads nor
+    // stores wave-rows that are land everywhere)
+    if ((rc = zero_land(o, o->p[0]))) return rc;
+    return zero_land(o, o->p[1]);
 }
 
 int dmg_ocean_set_divw(dmg_ocean *o, const float *divw)
@@ -318,7 +320,7 @@ int dmg_ocean_set_pressure(dmg_ocean *o, const float *pressure)
     if (!o->have_terrain) return dmg_fail(DMG_ESTATE, "dmg_ocean_set_terrain must come first");
     int rc = ocean_upload_rows(o, o->p[o->cur], pressure, 1);
     if (rc) return rc;
-    return zero_land(o, o->p[o->cur]);
+    return zero_land(o, o->p[o->cur]);      // the other buffer already holds 0 on land
 }
 
 int dmg_ocean_zero_pressure(dmg_ocean *o)

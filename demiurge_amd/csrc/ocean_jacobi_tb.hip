@@ -155,12 +155,12 @@ __global__ __launch_bounds__(NW * 64, (R <= 10 ? 4 : (R <= 12 ? 3 : 2))) void k_
     float4 p[R], b[R];
     unsigned code[R];
     unsigned mixed_rows = 0, land_rows = 0;         // bit r: row r of this wave has coast / is entirely land
+    // codes first: a wave-row that is land everywhere needs neither its pressure (exactly 0 in both ping-pong
+    // buffers, see k_zero_land) nor its right-hand side, and is not stored either
 #pragma unroll
     for (int r = 0; r < R; r++) {
         tb_row m = tb_map_row(a, e0 + r);
         size_t off = (size_t)m.l * W + (m.shift ? colp : col);
-        p[r] = *reinterpret_cast<const float4 *>(a.pin + off);
-        b[r] = *reinterpret_cast<const float4 *>(a.b + off);
         unsigned c = *reinterpret_cast<const unsigned *>(a.code + off);
         if (m.flip) c = (c & 0xFCFCFCFCu) | ((c & 0x01010101u) << 1) | ((c & 0x02020202u) >> 1);   // swap N/S bits
         // a non-pole edge row's clamp bit only says "the tap lands on the cell itself"; its mirror row is in the tile
@@ -168,11 +168,23 @@ __global__ __launch_bounds__(NW * 64, (R <= 10 ? 4 : (R <= 12 ? 3 : 2))) void k_
         if (yg == 0 && !a.spole) c &= ~0x02020202u;
         if (yg == a.H - 1 && !a.npole) c &= ~0x01010101u;
         code[r] = c;
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        unsigned c = code[r];
         if (__builtin_amdgcn_ballot_w64((c & 0x1F1F1F1Fu) != 0)) mixed_rows |= (1u << r);
         if (__builtin_amdgcn_ballot_w64((c & 0x10101010u) != 0x10101010u) == 0) land_rows |= (1u << r);
     }
-    mixed_rows = __builtin_amdgcn_readfirstlane(mixed_rows);
     land_rows = __builtin_amdgcn_readfirstlane(land_rows);
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        if (land_rows & (1u << r)) { p[r] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); b[r] = p[r]; continue; }
+        tb_row m = tb_map_row(a, e0 + r);
+        size_t off = (size_t)m.l * W + (m.shift ? colp : col);
+        p[r] = *reinterpret_cast<const float4 *>(a.pin + off);
+        b[r] = *reinterpret_cast<const float4 *>(a.b + off);
+    }
+    mixed_rows = __builtin_amdgcn_readfirstlane(mixed_rows);
     // wave-rows that are land everywhere stay exactly 0 (k_zero_land keeps land at 0 on input; :481 on output)
 
     for (int s = 0; s < a.nsweeps; s++) {
@@ -229,7 +241,12 @@ __global__ __launch_bounds__(NW * 64, (R <= 10 ? 4 : (R <= 12 ? 3 : 2))) void k_
         int e = wave * R + r;
         int l = e0 + r;                             // the row itself (mirrored / clamped copies fail the range test)
         bool row_ok = (e >= TB_T) && (e < EH - TB_T) && (l >= a.out_lo) && (l < a.out_hi);
-        if (row_ok && lane_ok) *reinterpret_cast<float4 *>(a.pout + (size_t)l * W + xcol) = p[r];
+        if (row_ok && lane_ok && !(land_rows & (1u << r)))
+        {
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            v4f q = { p[r].x, p[r].y, p[r].z, p[r].w };
+            __builtin_nontemporal_store(q, reinterpret_cast<v4f *>(a.pout + (size_t)l * W + xcol));   // never re-read in this launch
+        }
     }
 }
 
