@@ -100,6 +100,9 @@ def lib():
         "dmg_erosion_pass": (c_int, [vp, PG, vp, vp, vp, c_float, c_float]),
         "dmg_flow_accumulate": (c_int, [vp, PG, vp, vp, c_float, c_float, c_int, vp]),
         "dmg_erosion_run": (c_int, [vp, PG, vp, c_int, c_int, c_float, c_float, c_float]),
+        "dmg_thermal_erosion": (c_int, [vp, PG, vp]),
+        "dmg_morphological": (c_int, [vp, PG, vp, c_float, c_int]),
+        "dmg_morphological_gradient": (c_int, [vp, PG, vp, c_float]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)          # AttributeError if the library does not export a declared symbol
@@ -201,6 +204,27 @@ def _ctx_erosion_run(self, grid, h, N=50, iters=150, exponent=0.5, slope_exponen
     return h
 
 
+def _ctx_thermal_erosion(self, grid, h):
+    h = _f32(h).copy()
+    check(lib().dmg_thermal_erosion(self.h, ctypes.byref(grid), _p(h)))
+    return h
+
+
+def _ctx_morphological(self, grid, field, radius, op):
+    f = _f32(field).copy()
+    check(lib().dmg_morphological(self.h, ctypes.byref(grid), _p(f), radius, 1 if op in (1, "max", "dilate") else 0))
+    return f
+
+
+def _ctx_morphological_gradient(self, grid, field, radius):
+    f = _f32(field).copy()
+    check(lib().dmg_morphological_gradient(self.h, ctypes.byref(grid), _p(f), radius))
+    return f
+
+
+Context.thermal_erosion = _ctx_thermal_erosion
+Context.morphological = _ctx_morphological
+Context.morphological_gradient = _ctx_morphological_gradient
 Context.flow_accumulate = _ctx_flow_accumulate
 Context.erosion_run = _ctx_erosion_run
 

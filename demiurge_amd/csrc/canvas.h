@@ -66,6 +66,17 @@ __device__ __forceinline__ float d_stx(const canvas &c, int x) { return __fdiv_r
 __device__ __forceinline__ float d_sty(const canvas &c, int y) { return __fdiv_rn(__fadd_rn((float)y, 0.5f), (float)c.H); }
 
 
+// nearest texel reached by offset(st,(dx,dy)) for integer steps: wrap or clamp in x, pole reflection or clamp in y
+__device__ __forceinline__ int d_step(const canvas &c, int x, int y, int dx, int dy)
+{
+    int xx = x + dx, yy = y + dy;
+    if (c.lonwrap) { if (xx >= c.W) xx -= c.W; if (xx < 0) xx += c.W; }
+    else xx = min(max(xx, 0), c.W - 1);
+    if (yy < 0) { yy = 0; if (c.spole) { xx += c.W / 2; if (xx >= c.W) xx -= c.W; } }
+    if (yy >= c.H) { yy = c.H - 1; if (c.npole) { xx += c.W / 2; if (xx >= c.W) xx -= c.W; } }
+    return yy * c.W + xx;
+}
+
 // device-resident Gaussian blur (Blur::Blur + Blur::step, reference src/filter/BlurMenu.cpp:24-117): blurs d_field
 // (W*H floats) in place, d_tmp is W*H floats of workspace.  Asynchronous on the context's stream.
 int blur_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, float *d_field, float *d_tmp, float radius);

@@ -162,6 +162,82 @@ __global__ __launch_bounds__(256) void k_erosion(canvas c, const float *__restri
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// thermal erosion (reference src/filter/ThermalErosion.cpp:25-142) and the 64-tap ring
+// erode/dilate (reference src/filter/Morphological.cpp:45-85)
+// ---------------------------------------------------------------------------------------------------------------
+// get_slope(1,st) = atan(|get_texture_gradient|) (reference src/Shader.h:281-297,338-341)
+__device__ __forceinline__ float d_slope(const canvas &c, const float *img, int x, int y, float psx, float psy)
+{
+    float A = img[d_step(c, x, y, -1, -1)], B = img[d_step(c, x, y, 0, -1)], C = img[d_step(c, x, y, 1, -1)];
+    float D = img[d_step(c, x, y, -1, 0)], F = img[d_step(c, x, y, 1, 0)];
+    float G = img[d_step(c, x, y, -1, 1)], Hh = img[d_step(c, x, y, 0, 1)], I = img[d_step(c, x, y, 1, 1)];
+    float gx = __fdiv_rn(__fadd_rn(-__fadd_rn(__fadd_rn(C, __fmul_rn(2.0f, F)), I), __fadd_rn(__fadd_rn(A, __fmul_rn(2.0f, D)), G)), __fmul_rn(8.0f, psx));
+    float gy = __fdiv_rn(__fsub_rn(__fadd_rn(__fadd_rn(G, __fmul_rn(2.0f, Hh)), I), __fadd_rn(__fadd_rn(A, __fmul_rn(2.0f, B)), C)), __fmul_rn(8.0f, psy));
+    return atanf(__fmul_rn(1.0f, sqrtf(__fadd_rn(__fmul_rn(gx, gx), __fmul_rn(gy, gy)))));
+}
+
+// talus "loss" pass (:30-72)
+__global__ __launch_bounds__(256) void k_thermal_loss(canvas c, const float *__restrict__ img, const float *__restrict__ dxrow,
+                                                      const float *__restrict__ dyrow, float *__restrict__ loss)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= c.W) return;
+    size_t i = (size_t)y * c.W + x;
+    float h = img[i];
+    float fc = 0.0f;
+    if (d_slope(c, img, x, y, dxrow[y], dyrow[y]) > DMG_PI / 6.0f && h > 0.0f) {
+        float count = 1.0f, minh = h;
+        const int ox[8] = { -1, 0, 1, 1, -1, 1, 0, -1 }, oy[8] = { 1, 1, 1, 0, 0, -1, -1, -1 };      // :41-63
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            float h2 = img[d_step(c, x, y, ox[k], oy[k])];
+            if (h2 < minh) minh = h2;
+            if (h2 < h) count = __fadd_rn(count, 1.0f);
+        }
+        fc = __fmul_rn(__fdiv_rn(__fsub_rn(h, minh), count), 0.3f);                                    // :69
+    }
+    loss[i] = fc;
+}
+
+// "gain" pass (:84-128): material lost by higher neighbours lands on cells flatter than pi/60
+__global__ __launch_bounds__(256) void k_thermal_gain(canvas c, const float *__restrict__ img, const float *__restrict__ loss,
+                                                      const float *__restrict__ dxrow, const float *__restrict__ dyrow, float *__restrict__ out)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= c.W) return;
+    size_t i = (size_t)y * c.W + x;
+    float h = img[i], gain = 0.0f;
+    const int ox[8] = { -1, 0, 1, -1, 1, -1, 0, 1 }, oy[8] = { 1, 1, 1, 0, 0, -1, -1, -1 };           // :92-113
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        int n = d_step(c, x, y, ox[k], oy[k]);
+        if (img[n] > h) gain = __fadd_rn(gain, loss[n]);
+    }
+    bool steep = d_slope(c, img, x, y, dxrow[y], dyrow[y]) > DMG_PI / 6.0f / 10.0f && h > 0.0f;       // :121
+    out[i] = steep ? h : __fadd_rn(h, gain);
+}
+
+struct ring64 { float cs[64], sn[64]; };      // cos/sin(2*3.14159*i/64) evaluated on the host in fp32 (Morphological.cpp:57)
+
+// one Morphological::step (:49-60, :75-85): min or max over the cell and 64 ring taps, x offsets scaled by 1/cos|lat|
+__global__ __launch_bounds__(256) void k_morph(canvas c, const float *__restrict__ src, float *__restrict__ dst,
+                                               const float *__restrict__ factor_row, float radius, int use_max, ring64 ring)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= c.W) return;
+    float sx = d_stx(c, x), sy = d_sty(c, y);
+    float factor = factor_row[y];
+    float a = src[(size_t)y * c.W + x];
+    for (int i = 0; i < 64; i++) {
+        float px, py;
+        d_offset(c, sx, sy, __fmul_rn(__fmul_rn(ring.cs[i], radius), factor), __fmul_rn(ring.sn[i], radius), &px, &py);
+        float v = d_fetch_nearest(src, c.W, c.H, px, py);
+        a = use_max ? fmaxf(a, v) : fminf(a, v);
+    }
+    dst[(size_t)y * c.W + x] = a;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
 static int upload_rows(dmg_ctx *ctx, dev_buf &d, const std::vector<float> &v) { return upload_vec(ctx, d, v); }
@@ -318,6 +394,121 @@ int dmg_erosion_run(dmg_ctx *ctx, const dmg_grid *grid, float *h, int N, int ite
         std::swap(cur, nxt);
     }
     DMG_HIP(hipMemcpyAsync(h, cur, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    DMG_HIP(hipStreamSynchronize(ctx->stream));
+    return DMG_OK;
+}
+
+// ThermalErosion::step (reference src/filter/ThermalErosion.cpp:25-142): 10 rounds of loss + gain, in place
+int dmg_thermal_erosion(dmg_ctx *ctx, const dmg_grid *grid, float *h)
+{
+    DMG_CHECK_ARG(ctx != nullptr && h != nullptr);
+    dmg_topology topo;
+    int rc = dmg_check_grid(grid, &topo);
+    if (rc) return rc;
+    DMG_HIP(hipSetDevice(ctx->device));
+    canvas c = make_canvas(*grid, topo);
+    const int H = grid->H;
+    const size_t n = (size_t)grid->W * H;
+    std::vector<float> dxr(H), dyr(H);
+    for (int y = 0; y < H; y++) dmg_row_pixelsize(*grid, y, &dxr[y], &dyr[y]);
+    dev_buf a, b, loss, ddx, ddy;
+    DMG_ALLOC(a, n * 4); DMG_ALLOC(b, n * 4); DMG_ALLOC(loss, n * 4);
+    if ((rc = upload_rows(ctx, ddx, dxr)) || (rc = upload_rows(ctx, ddy, dyr))) return rc;
+    DMG_HIP(hipMemcpyAsync(a.p, h, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    float *cur = a.f(), *nxt = b.f();
+    dim3 g((grid->W + 255) / 256, H);
+    for (int i = 0; i < 10; i++) {                    // :26
+        hipLaunchKernelGGL(k_thermal_loss, g, dim3(256), 0, ctx->stream, c, cur, ddx.f(), ddy.f(), loss.f());
+        hipLaunchKernelGGL(k_thermal_gain, g, dim3(256), 0, ctx->stream, c, cur, loss.f(), ddx.f(), ddy.f(), nxt);
+        DMG_HIP(hipGetLastError());
+        std::swap(cur, nxt);                          // scratch2.swap(terrain) (:134)
+    }
+    DMG_HIP(hipMemcpyAsync(h, cur, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    DMG_HIP(hipStreamSynchronize(ctx->stream));
+    return DMG_OK;
+}
+
+// Morphological radius schedule (reference src/filter/Morphological.cpp:31-43)
+static std::vector<float> morph_rlist(float radius)
+{
+    std::vector<float> r;
+    int x = 1;
+    while (radius >= 0) {
+        if (x < radius) { radius -= x; r.push_back((float)x); x *= 2; }
+        else { r.push_back(radius); break; }
+    }
+    std::sort(r.begin(), r.end());
+    return r;
+}
+
+static int morph_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, float *d_field, float *d_tmp, float radius,
+                        int use_max, float **result)
+{
+    canvas c = make_canvas(grid, topo);
+    std::vector<float> fac(grid.H);
+    for (int y = 0; y < grid.H; y++) fac[y] = 1 / cosf(fabsf(dmg_row_lat(grid, y)));     // :53-54
+    ring64 ring;
+    for (int i = 0; i < 64; i++) { float a = 2 * 3.14159f * (float)i / 64.0f; ring.cs[i] = cosf(a); ring.sn[i] = sinf(a); }
+    dev_buf dfac;
+    int rc = upload_rows(ctx, dfac, fac);
+    if (rc) return rc;
+    float *cur = d_field, *nxt = d_tmp;
+    dim3 g((grid.W + 255) / 256, grid.H);
+    for (float r : morph_rlist(radius)) {             // Morphological::step (:75-85)
+        hipLaunchKernelGGL(k_morph, g, dim3(256), 0, ctx->stream, c, cur, nxt, dfac.f(), r, use_max, ring);
+        DMG_HIP(hipGetLastError());
+        std::swap(cur, nxt);                          // scratch1.swap(target)
+    }
+    DMG_HIP(hipStreamSynchronize(ctx->stream));
+    *result = cur;
+    return DMG_OK;
+}
+
+// Erode (op 0, "min") / Dilate (op 1, "max"): MorphologicalMenu::makeFilter (:24-27) + Morphological::step
+int dmg_morphological(dmg_ctx *ctx, const dmg_grid *grid, float *field, float radius, int op)
+{
+    DMG_CHECK_ARG(ctx != nullptr && field != nullptr && radius >= 0.0f && (op == 0 || op == 1));
+    dmg_topology topo;
+    int rc = dmg_check_grid(grid, &topo);
+    if (rc) return rc;
+    DMG_HIP(hipSetDevice(ctx->device));
+    const size_t n = (size_t)grid->W * grid->H;
+    dev_buf a, b;
+    DMG_ALLOC(a, n * 4); DMG_ALLOC(b, n * 4);
+    DMG_HIP(hipMemcpyAsync(a.p, field, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    float *res = nullptr;
+    if ((rc = morph_device(ctx, *grid, topo, a.f(), b.f(), radius, op, &res))) return rc;
+    DMG_HIP(hipMemcpyAsync(field, res, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    DMG_HIP(hipStreamSynchronize(ctx->stream));
+    return DMG_OK;
+}
+
+__global__ void k_sub(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ o, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) o[i] = __fsub_rn(a[i], b[i]);
+}
+
+// MorphologicalGradient (:87-131): dilate((radius+1)/2) - erode(radius/2) of the same input
+int dmg_morphological_gradient(dmg_ctx *ctx, const dmg_grid *grid, float *field, float radius)
+{
+    DMG_CHECK_ARG(ctx != nullptr && field != nullptr && radius >= 0.0f);
+    dmg_topology topo;
+    int rc = dmg_check_grid(grid, &topo);
+    if (rc) return rc;
+    DMG_HIP(hipSetDevice(ctx->device));
+    const size_t n = (size_t)grid->W * grid->H;
+    dev_buf e0, e1, d0, d1;
+    DMG_ALLOC(e0, n * 4); DMG_ALLOC(e1, n * 4); DMG_ALLOC(d0, n * 4); DMG_ALLOC(d1, n * 4);
+    DMG_HIP(hipMemcpyAsync(e0.p, field, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    DMG_HIP(hipMemcpyAsync(d0.p, e0.p, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    float *er = nullptr, *di = nullptr;
+    if ((rc = morph_device(ctx, *grid, topo, e0.f(), e1.f(), radius / 2, 0, &er))) return rc;          // :89
+    if ((rc = morph_device(ctx, *grid, topo, d0.f(), d1.f(), (radius + 1) / 2, 1, &di))) return rc;    // :88
+    float *out = (er == e0.f()) ? e1.f() : e0.f();
+    hipLaunchKernelGGL(k_sub, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, di, er, out, n);   // :115-117
+    DMG_HIP(hipGetLastError());
+    DMG_HIP(hipMemcpyAsync(field, out, n * 4, hipMemcpyDeviceToHost, ctx->stream));
     DMG_HIP(hipStreamSynchronize(ctx->stream));
     return DMG_OK;
 }

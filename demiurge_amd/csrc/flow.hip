@@ -58,17 +58,6 @@ __device__ __forceinline__ float d_flow_noise(float px, float py)
                  d_mix(d_flow_hash(ix, __fadd_rn(iy, 1.0f)), d_flow_hash(__fadd_rn(ix, 1.0f), __fadd_rn(iy, 1.0f)), ux), uy);
 }
 
-// nearest texel reached by offset(st,(dx,dy)) for integer steps: wrap or clamp in x, pole reflection or clamp in y
-__device__ __forceinline__ int d_step(const canvas &c, int x, int y, int dx, int dy)
-{
-    int xx = x + dx, yy = y + dy;
-    if (c.lonwrap) { if (xx >= c.W) xx -= c.W; if (xx < 0) xx += c.W; }
-    else xx = min(max(xx, 0), c.W - 1);
-    if (yy < 0) { yy = 0; if (c.spole) { xx += c.W / 2; if (xx >= c.W) xx -= c.W; } }
-    if (yy >= c.H) { yy = c.H - 1; if (c.npole) { xx += c.W / 2; if (xx >= c.W) xx -= c.W; } }
-    return yy * c.W + xx;
-}
-
 // ---- direction codes ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_flow_direction(flow_canvas fc, const float *__restrict__ img, const float *__restrict__ sel,
                                                         const float *__restrict__ dxrow, const float *__restrict__ dyrow,

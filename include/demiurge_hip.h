@@ -183,6 +183,14 @@ int dmg_flow_accumulate(dmg_ctx *ctx, const dmg_grid *grid, const float *h, cons
 int dmg_erosion_run(dmg_ctx *ctx, const dmg_grid *grid, float *h_inout, int N, int iters, float exponent,
                     float slope_exponent, float factor);
 
+/* ---- SURVEY.md section 8(f) "next" rows: adjacent Filter-menu tools on the same stencil skeleton ---- */
+/* ThermalErosion::step (src/filter/ThermalErosion.cpp:25-142): 10 rounds of talus loss + gain, in place */
+int dmg_thermal_erosion(dmg_ctx *ctx, const dmg_grid *grid, float *h_inout);
+/* Morphological (src/filter/Morphological.cpp:28-85): 64-tap ring erode (op 0) / dilate (op 1), radius schedule :31-43 */
+int dmg_morphological(dmg_ctx *ctx, const dmg_grid *grid, float *field_inout, float radius, int op);
+/* MorphologicalGradient (:87-131): dilate((radius+1)/2) - erode(radius/2) */
+int dmg_morphological_gradient(dmg_ctx *ctx, const dmg_grid *grid, float *field_inout, float radius);
+
 #ifdef __cplusplus
 }
 #endif

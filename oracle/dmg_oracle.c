@@ -849,3 +849,125 @@ void orc_lake_adjacency(const orc_grid *g, const float *lakeid, float *out)
         }
     }
 }
+
+/* ====================================================================== */
+/* ThermalErosion and Morphological                        */
+/* ====================================================================== */
+/* get_slope(1, st) (src/Shader.h:338-341) over get_texture_gradient (:281-297) */
+static float orc_slope(const orc_grid *g, const float *img, float sx, float sy, float psx, float psy)
+{
+    const int W = g->W, H = g->H;
+    float t[9];
+    const float ox[9] = { 1, 0, -1, 1, 0, -1, 1, 0, -1 }, oy[9] = { 1, 1, 1, 0, 0, 0, -1, -1, -1 };   /* a..i = -vec2(ox,oy) */
+    for (int k = 0; k < 9; k++) {
+        float px, py;
+        orc_offset(g, sx, sy, -ox[k], -oy[k], (float)W, (float)H, &px, &py);
+        t[k] = fetch_nearest(img, W, H, 1, 0, px, py);
+    }
+    float A = t[0], B = t[1], C = t[2], D = t[3], F = t[5], G = t[6], Hh = t[7], I = t[8];
+    float gx = (-(C + 2 * F + I) + (A + 2 * D + G)) / (8 * psx);
+    float gy = ((G + 2 * Hh + I) - (A + 2 * B + C)) / (8 * psy);
+    return atanf(1.0f * sqrtf(gx * gx + gy * gy));
+}
+
+/* ThermalErosion::step (src/filter/ThermalErosion.cpp:25-142): 10 x { loss pass :30-72, gain pass :84-128 } in place */
+void orc_thermal_erosion(const orc_grid *g, float *h, float *scratch, float *scratch2)
+{
+    const int W = g->W, H = g->H;
+    const float rx = (float)W, ry = (float)H;
+    float *img = h, *loss = scratch, *out = scratch2;
+    static const float l1x[8] = { -1, 0, 1, 1, -1, 1, 0, -1 }, l1y[8] = { 1, 1, 1, 0, 0, -1, -1, -1 };     /* :41-63 */
+    static const float l2x[8] = { -1, 0, 1, -1, 1, -1, 0, 1 }, l2y[8] = { 1, 1, 1, 0, 0, -1, -1, -1 };     /* :92-113 */
+    for (int it = 0; it < 10; it++) {
+#pragma omp parallel for schedule(static) num_threads(nthreads_rows(H, 0))
+        for (int y = 0; y < H; y++) {
+            float sy = sty(g, y), psx, psy;
+            orc_pixelsize(g, sy, &psx, &psy);
+            for (int x = 0; x < W; x++) {
+                float sx = stx(g, x);
+                float slope = orc_slope(g, img, sx, sy, psx, psy);
+                float hh = fetch_nearest(img, W, H, 1, 0, sx, sy);
+                float fc = 0;
+                if (slope > MPI / 6 && hh > 0) {
+                    float count = 1, minh = hh;
+                    for (int k = 0; k < 8; k++) {
+                        float px, py;
+                        orc_offset(g, sx, sy, l1x[k], l1y[k], rx, ry, &px, &py);
+                        float h2 = fetch_nearest(img, W, H, 1, 0, px, py);
+                        if (h2 < minh) minh = h2;
+                        if (h2 < hh) count += 1;
+                    }
+                    fc = (hh - minh) / count * 0.3f;
+                }
+                loss[(size_t)y * W + x] = fc;
+            }
+        }
+#pragma omp parallel for schedule(static) num_threads(nthreads_rows(H, 0))
+        for (int y = 0; y < H; y++) {
+            float sy = sty(g, y), psx, psy;
+            orc_pixelsize(g, sy, &psx, &psy);
+            for (int x = 0; x < W; x++) {
+                float sx = stx(g, x);
+                float hh = fetch_nearest(img, W, H, 1, 0, sx, sy);
+                float gain = 0;
+                for (int k = 0; k < 8; k++) {
+                    float px, py;
+                    orc_offset(g, sx, sy, l2x[k], l2y[k], rx, ry, &px, &py);
+                    float h2 = fetch_nearest(img, W, H, 1, 0, px, py);
+                    if (h2 > hh) gain += fetch_nearest(loss, W, H, 1, 0, px, py);
+                }
+                float slope = orc_slope(g, img, sx, sy, psx, psy);
+                out[(size_t)y * W + x] = (slope > MPI / 6 / 10 && hh > 0) ? hh : hh + gain;      /* :121-125 */
+            }
+        }
+        float *t = img; img = out; out = t;          /* scratch2.swap(terrain) (:134) */
+    }
+    if (img != h) memcpy(h, img, sizeof(float) * (size_t)W * H);
+}
+
+/* Morphological radius schedule (src/filter/Morphological.cpp:31-43) */
+int orc_morph_rlist(float radius, float *r, int cap)
+{
+    int n = 0, x = 1;
+    while (radius >= 0) {
+        if (x < radius) { radius -= x; if (n < cap) r[n] = (float)x; n++; x *= 2; }
+        else { if (n < cap) r[n] = radius; n++; break; }
+    }
+    int m = n < cap ? n : cap;
+    for (int a = 1; a < m; a++) { float k = r[a]; int b = a - 1; while (b >= 0 && r[b] > k) { r[b + 1] = r[b]; b--; } r[b + 1] = k; }
+    return n;
+}
+
+/* one Morphological::step (:75-85): 64-tap ring min (use_max = 0) or max (:49-60), NEAREST target */
+void orc_morph_pass(const orc_grid *g, const float *src, float radius, int use_max, float *dst)
+{
+    const int W = g->W, H = g->H;
+    float cs[64], sn[64];
+    for (int i = 0; i < 64; i++) { float a = 2 * 3.14159f * (float)i / 64.0f; cs[i] = cosf(a); sn[i] = sinf(a); }
+#pragma omp parallel for schedule(static) num_threads(nthreads_rows(H, 0))
+    for (int y = 0; y < H; y++) {
+        float sy = sty(g, y), lon, phi;
+        orc_tex_to_spheric(g, 0.0f, sy, &lon, &phi);
+        float factor = 1 / cosf(fabsf(phi));
+        for (int x = 0; x < W; x++) {
+            float sx = stx(g, x);
+            float a = fetch_nearest(src, W, H, 1, 0, sx, sy);
+            for (int i = 0; i < 64; i++) {
+                float px, py;
+                orc_offset(g, sx, sy, cs[i] * radius * factor, sn[i] * radius, (float)W, (float)H, &px, &py);
+                float v = fetch_nearest(src, W, H, 1, 0, px, py);
+                a = use_max ? fmaxf(a, v) : fminf(a, v);
+            }
+            dst[(size_t)y * W + x] = a;
+        }
+    }
+}
+
+void orc_morphological(const orc_grid *g, float *field, float *scratch, float radius, int use_max)
+{
+    float r[64];
+    int n = orc_morph_rlist(radius, r, 64);
+    float *a = field, *b = scratch;
+    for (int i = 0; i < n; i++) { orc_morph_pass(g, a, r[i], use_max, b); float *t = a; a = b; b = t; }
+    if (a != field) memcpy(field, a, sizeof(float) * (size_t)g->W * g->H);
+}

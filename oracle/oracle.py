@@ -52,6 +52,10 @@ def lib():
         L.orc_blur.argtypes = [G, P, P, ctypes.c_float]
         L.orc_temperature.argtypes = [G, P, P, P, ctypes.c_int, ctypes.c_int]
         L.orc_erosion_pass.argtypes = [G, P, P, P, ctypes.c_float, ctypes.c_float, P]
+        L.orc_thermal_erosion.argtypes = [G, P, P, P]
+        L.orc_morph_rlist.argtypes = [ctypes.c_float, P, ctypes.c_int]
+        L.orc_morph_rlist.restype = ctypes.c_int
+        L.orc_morphological.argtypes = [G, P, P, ctypes.c_float, ctypes.c_int]
         L.orc_flow_direction.argtypes = [G, P, P, P]
         L.orc_flow_mask.argtypes = [G, P, P, P, P]
         L.orc_lake_adjacency.argtypes = [G, P, P]
@@ -214,3 +218,29 @@ def flow_accumulate_lakes(g, h, preblur=0.5, exponent=1.0, sel=None):
     flow = np.empty_like(h)
     lib().orc_flow_accumulate_lakes(ctypes.byref(g), _ptr(h), None if sel is None else _ptr(sel), preblur, exponent, _ptr(flow))
     return flow
+
+
+def thermal_erosion(g, h):
+    h = _f32(h).copy()
+    a, b = np.empty_like(h), np.empty_like(h)
+    lib().orc_thermal_erosion(ctypes.byref(g), _ptr(h), _ptr(a), _ptr(b))
+    return h
+
+
+def morph_rlist(radius):
+    buf = np.empty(64, np.float32)
+    n = lib().orc_morph_rlist(radius, _ptr(buf), 64)
+    return buf[:n].copy()
+
+
+def morphological(g, field, radius, op):
+    f = _f32(field).copy()
+    s = np.empty_like(f)
+    lib().orc_morphological(ctypes.byref(g), _ptr(f), _ptr(s), radius, 1 if op == "max" else 0)
+    return f
+
+
+def morphological_gradient(g, field, radius):
+    er = morphological(g, field, np.float32(radius) / np.float32(2), "min")
+    di = morphological(g, field, (np.float32(radius) + np.float32(1)) / np.float32(2), "max")
+    return (di - er).astype(np.float32)

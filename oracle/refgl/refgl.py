@@ -369,3 +369,62 @@ def lake_adjacency(lake_id_bits, coords=FULL_GLOBE, circ=42000.0):
     out = g.download(t_s2)
     g.delete(t_s1, t_img, t_s2)
     return out
+
+
+def thermal_erosion(img, coords=FULL_GLOBE, circ=42000.0):
+    """ThermalErosion::step (ThermalErosion.cpp:25-142): 10 x { talus loss -> scratch1 ; gain pass -> scratch2 ;
+    scratch2.swap(terrain) }.  All textures NEAREST."""
+    g = RefGL.get()
+    g.set_canvas(coords, circ)
+    H, W = img.shape
+    t_img = g.tex(W, H, 1, False, img)
+    t_s1 = g.tex(W, H, 1, False)
+    t_s2 = g.tex(W, H, 1, False)
+    p1, p2 = g.program("ThermalErosion.cpp:27"), g.program("ThermalErosion.cpp:84")
+    for _ in range(10):
+        g.apply(p1, t_s1, {"img": t_img})
+        g.apply(p2, t_s2, {"img": t_img, "scratch1": t_s1})
+        g.swap(t_s2, t_img)
+    out = g.download(t_img)
+    g.delete(t_img, t_s1, t_s2)
+    return out
+
+
+def morph_rlist(radius):
+    """Morphological::Morphological radius schedule (Morphological.cpp:31-43), float arithmetic"""
+    f = np.float32
+    radius = f(radius)
+    r, x = [], 1
+    while radius >= 0:
+        if x < radius:
+            radius = f(radius - f(x))
+            r.append(f(x))
+            x *= 2
+        else:
+            r.append(radius)
+            break
+    return sorted(r)
+
+
+def morphological(field, radius, op, coords=FULL_GLOBE, circ=42000.0):
+    """Morphological::step until finished (Morphological.cpp:75-85); op = "min" (Erode) or "max" (Dilate)."""
+    g = RefGL.get()
+    g.set_canvas(coords, circ)
+    H, W = field.shape
+    t_t = g.tex(W, H, 1, False, field)
+    t_s = g.tex(W, H, 1, False)
+    prog = g.program("Morphological.cpp:63#" + op)
+    for r in morph_rlist(radius):
+        g.uniform1f(prog, "radius", r)
+        g.apply(prog, t_s, {"target": t_t})
+        g.swap(t_s, t_t)
+    out = g.download(t_t)
+    g.delete(t_t, t_s)
+    return out
+
+
+def morphological_gradient(field, radius, coords=FULL_GLOBE, circ=42000.0):
+    """MorphologicalGradient (Morphological.cpp:87-131): dilate((radius+1)/2) - erode(radius/2) of the same input"""
+    er = morphological(field, np.float32(radius) / np.float32(2), "min", coords, circ)
+    di = morphological(field, (np.float32(radius) + np.float32(1)) / np.float32(2), "max", coords, circ)
+    return (di - er).astype(np.float32)

@@ -67,10 +67,30 @@ def flow_goldens():
     save("flow_passes_128x64_sel", coords=np.array(FULL), circ=f32(CIRC), blurred=hb, sel=sel, codes=c2, mask=m2)
 
 
+def next_goldens():
+    """ThermalErosion and Morphological"""
+    W, H = 128, 64
+    # relief of hundreds of height units per 328-km texel so that slopes exceed the 30 degree talus angle somewhere,
+    # with flat shelves (rounded heights) where the gain pass deposits
+    h = np.round(synth.terrain(W, H) * 2) * 150 + np.where(synth.lcg_uniform(W * H, 3).reshape(H, W) > 0.3, 260, 0)
+    h = h.astype(f32)
+    save("thermal_128x64_full", coords=np.array(FULL), circ=f32(CIRC), h=h, out=refgl.thermal_erosion(h))
+    save("thermal_128x64_region", coords=np.array(REGION), circ=f32(CIRC), h=h, out=refgl.thermal_erosion(h, coords=REGION))
+    f = synth.terrain(W, H)
+    save("morph_128x64_full", coords=np.array(FULL), circ=f32(CIRC), field=f,
+         rlist_r1=np.array(refgl.morph_rlist(1.0), f32), rlist_r5=np.array(refgl.morph_rlist(5.5), f32),
+         erode_r1=refgl.morphological(f, 1.0, "min"), dilate_r1=refgl.morphological(f, 1.0, "max"),
+         erode_r5=refgl.morphological(f, 5.5, "min"), dilate_r5=refgl.morphological(f, 5.5, "max"),
+         gradient_r3=refgl.morphological_gradient(f, 3.0))
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "flow":
         return flow_goldens()
+    if len(sys.argv) > 1 and sys.argv[1] == "next":
+        return next_goldens()
     flow_goldens()
+    next_goldens()
     # ---- Jacobi (headline) -------------------------------------------------
     W, H = 256, 128
     img, b = synth.terrain(W, H), synth.divw(W, H)
