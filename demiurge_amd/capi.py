@@ -95,6 +95,8 @@ def lib():
         "dmg_ocean_subdiv": (c_int, [vp]),
         "dmg_ocean_advect_reach": (c_int, [vp, ctypes.POINTER(c_int)]),
         "dmg_ocean_get": (c_int, [vp, vp, vp, vp, vp]),
+        "dmg_ocean_checkpoint": (c_int, [vp, ctypes.c_char_p]),
+        "dmg_ocean_restore": (c_int, [vp, ctypes.c_char_p]),
         "dmg_blur": (c_int, [vp, PG, vp, c_float]),
         "dmg_temperature_steps": (c_int, [vp, PG, vp, vp, c_int, c_int]),
         "dmg_erosion_pass": (c_int, [vp, PG, vp, vp, vp, c_float, c_float]),
@@ -323,6 +325,12 @@ class Ocean:
         r = ctypes.c_int()
         check(lib().dmg_ocean_advect_reach(self.h, ctypes.byref(r)))
         return r.value
+
+    def checkpoint(self, prefix):
+        check(lib().dmg_ocean_checkpoint(self.h, str(prefix).encode()))
+
+    def restore(self, prefix):
+        check(lib().dmg_ocean_restore(self.h, str(prefix).encode()))
 
     def get(self, want=("v", "pressure", "divw"), out=None):
         """Downloads owned rows into full-grid arrays (zeros elsewhere).  Returns dict of arrays."""

@@ -161,6 +161,11 @@ int dmg_ocean_advect_reach(dmg_ocean *o, int *rows);
  * into FULL-grid arrays at their grid position (so ranks can fill one array); NULL skips a field. */
 int dmg_ocean_get(dmg_ocean *o, float *vx, float *vy, float *pressure, float *divw);
 
+/* Checkpoint / resume (the reference has none; its solve runs 10000 outer steps, :155): the band's owned rows of
+ * v, pressure and divw as NumPy files <prefix>.v.npy (rows,W,2), <prefix>.pressure.npy, <prefix>.divw.npy. */
+int dmg_ocean_checkpoint(dmg_ocean *o, const char *prefix);
+int dmg_ocean_restore(dmg_ocean *o, const char *prefix);      /* after dmg_ocean_set_terrain, same grid and band */
+
 /* ---- generic stencil filters on a whole grid ---------------------------- */
 /* Blur::Blur + Blur::step until finished (src/filter/BlurMenu.cpp:24-117), in place on host data */
 int dmg_blur(dmg_ctx *ctx, const dmg_grid *grid, float *field_inout, float radius);

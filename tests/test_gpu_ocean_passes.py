@@ -206,3 +206,41 @@ def test_band_passes_fake_cluster(dev):
     small.close()
     for o in oc:
         o.close()
+
+
+def test_checkpoint_resume(dev, tmp_path):
+    """run 2 outer steps in one go == run 1, checkpoint to .npy, restore into a fresh ocean, run 1 more"""
+    capi, ctx = dev
+    from demiurge_amd import synth
+    W, H = 256, 128
+    grid = capi.make_grid(W, H)
+    img = synth.terrain(W, H)
+    prm = capi.default_ocean_params()
+    prm.jacobi_iters, prm.diffusion_iters = 40, 10
+    a = capi.Ocean(ctx, grid, params=prm)
+    a.set_terrain(img)
+    a.step(2)
+    ref = a.get()
+    a.close()
+    b = capi.Ocean(ctx, grid, params=prm)
+    b.set_terrain(img)
+    b.step(1)
+    b.checkpoint(tmp_path / "ck")
+    mid = b.get()
+    b.close()
+    v = np.load(tmp_path / "ck.v.npy")                      # plain NumPy files
+    assert v.shape == (H, W, 2) and v.dtype == np.float32 and np.array_equal(v, mid["v"])
+    assert np.array_equal(np.load(tmp_path / "ck.pressure.npy"), mid["pressure"])
+    c = capi.Ocean(ctx, grid, params=prm)
+    c.set_terrain(img)
+    c.restore(tmp_path / "ck")
+    c.step(1)
+    got = c.get()
+    c.close()
+    for k in ("vx", "vy", "pressure", "divw"):
+        assert np.array_equal(got[k], ref[k]), k
+    d = capi.Ocean(ctx, capi.make_grid(128, 128), params=prm)
+    d.set_terrain(synth.terrain(128, 128))
+    with pytest.raises(capi.DmgError):
+        d.restore(tmp_path / "ck")                          # shape mismatch is refused
+    d.close()
