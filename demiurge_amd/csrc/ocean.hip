@@ -194,6 +194,12 @@ static int zero_land(dmg_ocean *o, float *p)
     return DMG_OK;
 }
 
+int ocean_zero_land(dmg_ocean *o)
+{
+    int rc = zero_land(o, o->p[0]);
+    return rc ? rc : zero_land(o, o->p[1]);
+}
+
 // fills a local (band + ghosts) device array from a FULL-grid host array
 int ocean_upload_rows(dmg_ocean *o, float *dst, const float *src_full, int comps)
 {

@@ -47,6 +47,7 @@ struct dmg_ocean {
 int ocean_upload_row_tables(dmg_ocean *o);
 int ocean_build_codes(dmg_ocean *o);
 int ocean_build_codes8(dmg_ocean *o);
+int ocean_zero_land(dmg_ocean *o);            // p := +0 on land in BOTH ping-pong buffers (invariant of the blocked kernel)
 int ocean_launch_tb(dmg_ocean *o, int lo, int hi, int n);   // ocean_jacobi_tb.hip
 bool ocean_tb_supported(const dmg_ocean *o);
 int ocean_upload_rows(dmg_ocean *o, float *dst, const float *src_full, int comps);

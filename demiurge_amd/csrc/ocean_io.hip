@@ -96,7 +96,7 @@ int dmg_ocean_restore(dmg_ocean *o, const char *prefix)
     if ((rc = read_npy(p + ".divw.npy", buf.data(), own, W, 1))) return rc;
     DMG_HIP(hipMemcpyAsync(o->divw + off, buf.data(), n * 4, hipMemcpyHostToDevice, st));
     DMG_HIP(hipStreamSynchronize(st));
-    return DMG_OK;
+    return ocean_zero_land(o);                       // whatever the file held: land keeps exactly +0 in both pressure buffers
 }
 
 }  // extern "C"

@@ -225,3 +225,32 @@ def test_blocked_full_size_bitwise(dev, oracle):
     blocked = run_jacobi(capi, ctx, grid, img, b, 12, block=12, kernel=capi.JACOBI_BLOCKED)
     ref = oracle.ocean_jacobi(ogrid(oracle, grid), img, b, 12, rows=True)
     assert np.array_equal(blocked, ref)
+
+
+def test_blocked_randomised_geometries(dev, oracle):
+    """many small random cases: widths that are multiples of 8 from 256 up, heights down to 2 tile rows or less, land
+    fractions from none to nearly all, sweep counts that are not multiples of 8, pole and belt canvases, band splits"""
+    capi, ctx = dev
+    rng = np.random.default_rng(20261003)
+    belt = (np.float32(-1.0), np.float32(1.2), np.float32(-np.pi), np.float32(np.pi))
+    for case in range(24):
+        W = int(rng.choice([256, 264, 320, 488, 512, 1000]))
+        H = int(rng.choice([2, 6, 16, 47, 48, 49, 64, 97, 130]))
+        iters = int(rng.integers(1, 21))
+        coords = belt if case % 3 == 2 else capi.FULL_GLOBE
+        grid = capi.make_grid(W, H, coords)
+        land = rng.random()
+        img = np.where(rng.random((H, W)) < land * 0.5, 1.0, -1.0).astype(np.float32)
+        if case % 4 == 0:                                  # blocky continents: whole wave-rows of land
+            img = np.repeat(np.repeat(np.where(rng.random((H // 2 + 1, W // 64 + 1)) < land, 1.0, -1.0), 2, 0), 64, 1)[:H, :W].astype(np.float32)
+        b = rng.standard_normal((H, W)).astype(np.float32)
+        p0 = rng.standard_normal((H, W)).astype(np.float32)
+        ref = oracle.ocean_jacobi(ogrid(oracle, grid), img, b, iters, p0=p0, rows=True)
+        got = run_jacobi(capi, ctx, grid, img, b, iters, p0=p0, block=iters, kernel=capi.JACOBI_BLOCKED)
+        assert np.array_equal(got, ref), (case, W, H, iters)
+        if H >= 48 and case % 2 == 0:
+            bands = 2 if H < 97 else 3
+            ghost = min(16, H // bands)
+            got = run_jacobi(capi, ctx, grid, img, b, iters, p0=p0, bands=bands, ghost=ghost, block=min(ghost, iters),
+                             kernel=capi.JACOBI_BLOCKED)
+            assert np.array_equal(got, ref), ("bands", case, W, H, iters)
