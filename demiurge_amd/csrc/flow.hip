@@ -176,11 +176,25 @@ __global__ void k_flow_label(const int *__restrict__ root, const unsigned char *
     label[i] = (code[i] != 0 && code[r] == 5) ? r : -1;
 }
 
+// ---- dense lake numbering -------------------------------------------------------------------------------------------
+// A lake is a sink cell that labels itself.  dense[c] (exclusive scan of the flags) numbers the lakes 0..L-1 in cell
+// order, so the host side of the lake graph works on flat arrays instead of hash maps keyed by cell index.
+__global__ void k_flow_sinkflag(const int *__restrict__ label, int *__restrict__ flag, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flag[i] = (label[i] == (int)i) ? 1 : 0;
+}
+__global__ void k_flow_sinkcells(const int *__restrict__ label, const int *__restrict__ dense, int *__restrict__ sink_cell, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && label[i] == (int)i) sink_cell[dense[i]] = (int)i;
+}
+
 // ---- pass candidates --------------------------------------------------------------------------------------------
 // One candidate per boundary cell s: the lowest neighbour that belongs to another catchment (:470-492).
-//   key = (lake of s) << 32 | (neighbouring lake)        val = (pass height bits) << 32 | s
-// heights are > 0, so their fp32 bit patterns order like the values.
-__global__ void k_flow_passes(flow_canvas fc, const float *__restrict__ h, const int *__restrict__ label,
+//   key = (dense id of the lake of s) << 32 | (dense id of the neighbouring lake)     val = (pass height bits) << 32 | s
+// heights are > 0, so their fp32 bit patterns order like the values; dense ids order like the sink cell indices.
+__global__ void k_flow_passes(flow_canvas fc, const float *__restrict__ h, const int *__restrict__ label, const int *__restrict__ dense,
                               const unsigned short *__restrict__ mask, unsigned long long *__restrict__ key,
                               unsigned long long *__restrict__ val, int *__restrict__ count, int cap)
 {
@@ -208,7 +222,7 @@ __global__ void k_flow_passes(flow_canvas fc, const float *__restrict__ h, const
     if (mask[lid] & 512u) return;                       // never towards a river-mouth lake (:484)
     int slot = atomicAdd(count, 1);
     if (slot < cap) {
-        key[slot] = ((unsigned long long)(unsigned)lake << 32) | (unsigned)lid;
+        key[slot] = ((unsigned long long)(unsigned)dense[lake] << 32) | (unsigned)dense[lid];
         val[slot] = ((unsigned long long)__float_as_uint(fmaxf(minpass, h[i])) << 32) | (unsigned)i;
     }
 }
@@ -237,12 +251,13 @@ __global__ void k_flow_gather_dist(const unsigned long long *__restrict__ pay, c
 }
 
 // river-mouth lakes = sinks (bit 16) next to the ocean (bit 512), compacted
-__global__ void k_flow_mouths(const unsigned short *__restrict__ mask, int *__restrict__ out, int *__restrict__ count, size_t n)
+__global__ void k_flow_mouths(const unsigned short *__restrict__ mask, const int *__restrict__ dense, int *__restrict__ out,
+                              int *__restrict__ count, size_t n)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     unsigned m = mask[i];
-    if (m != 0xFFFFu && (m & 16u) && (m & 512u)) out[atomicAdd(count, 1)] = (int)i;
+    if (m != 0xFFFFu && (m & 16u) && (m & 512u)) out[atomicAdd(count, 1)] = dense[i];
 }
 
 __global__ void k_flow_scatter_pairs(const int *__restrict__ idx, const int *__restrict__ v, int *__restrict__ dst, int n)
@@ -403,6 +418,31 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
     hipLaunchKernelGGL(k_flow_label, dim3(nb), dim3(256), 0, st, par[cur].i(), (const unsigned char *)code.p, label.i(), N);
 
     lap("pointer jumping");
+    // dense lake ids
+    dev_buf sflag, dense, sinkc, scan_tmp;
+    DMG_ALLOC(sflag, N * 4); DMG_ALLOC(dense, N * 4 + 4);
+    hipLaunchKernelGGL(k_flow_sinkflag, dim3(nb), dim3(256), 0, st, label.i(), sflag.i(), N);
+    {
+        size_t sb = 0;
+        (void)hipcub::DeviceScan::ExclusiveSum(nullptr, sb, sflag.i(), dense.i(), (int)N, st);
+        DMG_ALLOC(scan_tmp, sb + 256);
+        DMG_HIP(hipcub::DeviceScan::ExclusiveSum(scan_tmp.p, sb, sflag.i(), dense.i(), (int)N, st));
+    }
+    int nlakes = 0;
+    {
+        int last_dense = 0, last_flag = 0;
+        DMG_HIP(hipMemcpyAsync(&last_dense, dense.i() + (N - 1), 4, hipMemcpyDeviceToHost, st));
+        DMG_HIP(hipMemcpyAsync(&last_flag, sflag.i() + (N - 1), 4, hipMemcpyDeviceToHost, st));
+        DMG_HIP(hipStreamSynchronize(st));
+        nlakes = last_dense + last_flag;
+    }
+    std::vector<int> sink_cell(nlakes);
+    if (nlakes) {
+        DMG_ALLOC(sinkc, (size_t)nlakes * 4);
+        hipLaunchKernelGGL(k_flow_sinkcells, dim3(nb), dim3(256), 0, st, label.i(), dense.i(), sinkc.i(), N);
+        DMG_HIP(hipMemcpyAsync(sink_cell.data(), sinkc.p, (size_t)nlakes * 4, hipMemcpyDeviceToHost, st));
+    }
+
     // boundary cells -> pass candidates; reduce to the lowest pass per lake pair on the device:
     // sort by (height, s), stable sort by (lake, from), keep segment heads, then order each lake's passes by height
     int cap = (int)std::min<size_t>(N, (size_t)1 << 28);
@@ -410,15 +450,15 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
     DMG_ALLOC(k0, (size_t)cap * 8); DMG_ALLOC(v0, (size_t)cap * 8); DMG_ALLOC(k1, (size_t)cap * 8); DMG_ALLOC(v1, (size_t)cap * 8);
     DMG_ALLOC(nsel, 8);
     DMG_HIP(hipMemsetAsync(count.p, 0, 4, st));
-    hipLaunchKernelGGL(k_flow_passes, dim3(nb), dim3(256), 0, st, fc, d_h, label.i(), (const unsigned short *)mask.p,
+    hipLaunchKernelGGL(k_flow_passes, dim3(nb), dim3(256), 0, st, fc, d_h, label.i(), dense.i(), (const unsigned short *)mask.p,
                        (unsigned long long *)k0.p, (unsigned long long *)v0.p, count.i(), cap);
     DMG_HIP(hipGetLastError());
     int ncand = 0;
     DMG_HIP(hipMemcpyAsync(&ncand, count.p, 4, hipMemcpyDeviceToHost, st));
-    // river mouths, compacted (order restored on the host)
-    DMG_ALLOC(mouths_d, N * 4);
+    // river mouths (dense ids), compacted (order restored on the host)
+    DMG_ALLOC(mouths_d, (size_t)std::max(nlakes, 1) * 4);
     DMG_HIP(hipMemsetAsync(nsel.p, 0, 8, st));
-    hipLaunchKernelGGL(k_flow_mouths, dim3(nb), dim3(256), 0, st, (const unsigned short *)mask.p, mouths_d.i(), nsel.i(), N);
+    hipLaunchKernelGGL(k_flow_mouths, dim3(nb), dim3(256), 0, st, (const unsigned short *)mask.p, dense.i(), mouths_d.i(), nsel.i(), N);
     int nmouth = 0;
     DMG_HIP(hipMemcpyAsync(&nmouth, nsel.p, 4, hipMemcpyDeviceToHost, st));
     DMG_HIP(hipStreamSynchronize(st));
@@ -460,57 +500,74 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
     DMG_HIP(hipStreamSynchronize(st));
     std::sort(mouths.begin(), mouths.end());
     lap("passes: sort/reduce/download");
-    if (timing) fprintf(stderr, "[flow] %d pass candidates -> %d lake pairs, %d river mouths\n", ncand, nuniq, nmouth);
+    if (timing) fprintf(stderr, "[flow] %d lakes, %d pass candidates -> %d lake pairs, %d river mouths\n", nlakes, ncand, nuniq, nmouth);
 
-    // solvingConnections (:533-595) on the reduced list: entry i = pass into lake (hkey>>32) at cell s from lake `from`
+    // solvingConnections (:533-595) on the reduced list, all lakes by dense id: entry i = pass into lake `lake` at
+    // cell s from lake `from`; entries are sorted by (lake, height, from)
     struct Entry { float h; int from, s, lake, sdist; };
     std::vector<Entry> ent(nuniq);
-    std::unordered_map<int, std::pair<int, int>> range;      // lake -> [cursor, end) into ent
+    std::vector<int> cursor(nlakes + 1, 0), rend(nlakes + 1, 0);       // per lake: next unread entry, end of its entries
     for (int i = 0; i < nuniq; i++) {
         unsigned hb = (unsigned)(hkey[i] & 0xFFFFFFFFull);
         Entry e;
         memcpy(&e.h, &hb, 4);
         e.lake = (int)(hkey[i] >> 32); e.from = (int)(hpay[i] >> 32); e.s = (int)(hpay[i] & 0xFFFFFFFFull); e.sdist = hsdist[i];
         ent[i] = e;
-        auto it = range.find(e.lake);
-        if (it == range.end()) range[e.lake] = { i, i + 1 }; else it->second.second = i + 1;
+        rend[e.lake] = i + 1;
     }
-    auto worse = [&](int a, int b) {                         // priority_queue keeps the LOWEST (h, from, s) on top
+    for (int i = nuniq - 1; i >= 0; i--) cursor[ent[i].lake] = i;      // first entry of each lake
+    auto worse = [&](int a, int b) {                                   // priority_queue keeps the LOWEST (h, from, s) on top
         return std::tie(ent[a].h, ent[a].from, ent[a].s) > std::tie(ent[b].h, ent[b].from, ent[b].s);
     };
     std::priority_queue<int, std::vector<int>, decltype(worse)> candidates(worse);
-    std::unordered_map<int, char> placed;
-    placed.reserve(mouths.size() * 4 + 16);
+    std::vector<char> placed(nlakes, 0);
     for (int m : mouths) placed[m] = 1;
     auto push_next = [&](int lake) {
-        auto it = range.find(lake);
-        if (it == range.end()) return;
-        int &cursor = it->second.first;
-        while (cursor < it->second.second) {
-            int c = cursor++;
-            if (placed.count(ent[c].from)) continue;
-            candidates.push(c);
+        int &c = cursor[lake];
+        const int e = rend[lake];
+        while (c < e) {
+            int i = c++;
+            if (placed[ent[i].from]) continue;
+            candidates.push(i);
             break;
         }
     };
-    std::unordered_map<int, int> connections;                // tolocation -> entry (a later one replaces an earlier one, :588)
+    std::vector<int> assigned;                                         // connection events in order: connections[s] = entry
     for (int lake : mouths) push_next(lake);
     while (!candidates.empty()) {
         int c = candidates.top();
         candidates.pop();
         const Entry &p = ent[c];
-        if (placed.count(p.from)) { push_next(p.lake); continue; }
+        if (placed[p.from]) { push_next(p.lake); continue; }
         placed[p.from] = 1;
-        connections[p.s] = c;
+        assigned.push_back(c);                                         // a later pass at the same cell replaces this one (:588)
         push_next(p.from);
         push_next(p.lake);
     }
+    // resolve the overwrites: per tolocation cell the LAST assigned entry survives (open-addressing table on s)
+    std::vector<int> live;
+    {
+        size_t cap2 = 16;
+        while (cap2 < assigned.size() * 2 + 16) cap2 <<= 1;
+        std::vector<int> slot(cap2, -1);                               // entry index
+        for (int c : assigned) {
+            size_t hsh = ((size_t)(unsigned)ent[c].s * 2654435761u) & (cap2 - 1);
+            while (slot[hsh] >= 0 && ent[slot[hsh]].s != ent[c].s) hsh = (hsh + 1) & (cap2 - 1);
+            slot[hsh] = c;
+        }
+        for (int c : slot) if (c >= 0) live.push_back(c);
+    }
     lap("host: solve connections");
 
-    // depth offset of every lake that calculateflow's recursion reaches: river mouths at 0, a connected lake one
-    // below the cell it drains into
-    std::unordered_map<int, std::vector<int>> into;          // lake -> entries of the lakes draining into it
-    for (auto &kv : connections) into[ent[kv.second].lake].push_back(kv.second);
+    // depth offset and water level of every lake that calculateflow's recursion reaches: river mouths at 0, a
+    // connected lake one below the cell it drains into (CSR adjacency lake -> entries draining into it)
+    std::vector<int> adj_start(nlakes + 1, 0), adj(live.size());
+    for (int c : live) adj_start[ent[c].lake + 1]++;
+    for (int d = 0; d < nlakes; d++) adj_start[d + 1] += adj_start[d];
+    {
+        std::vector<int> fill(adj_start.begin(), adj_start.end() - 1);
+        for (int c : live) adj[fill[ent[c].lake]++] = c;
+    }
     std::vector<int> off_idx, off_val, conn_idx, conn_val;
     std::vector<float> off_level;                             // water level of the lake: highest pass on the way down (:683-690)
     struct Work { int lake, off; float level; };
@@ -518,16 +575,15 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
     for (int m : mouths) work.push_back({ m, 0, 0.0f });
     while (!work.empty()) {
         Work w = work.back(); work.pop_back();
-        off_idx.push_back(w.lake); off_val.push_back(w.off); off_level.push_back(w.level);
-        auto it = into.find(w.lake);
-        if (it == into.end()) continue;
-        for (int c : it->second) {
-            conn_idx.push_back(ent[c].s); conn_val.push_back(ent[c].from);
+        off_idx.push_back(sink_cell[w.lake]); off_val.push_back(w.off); off_level.push_back(w.level);
+        for (int k = adj_start[w.lake]; k < adj_start[w.lake + 1]; k++) {
+            int c = adj[k];
+            conn_idx.push_back(ent[c].s); conn_val.push_back(sink_cell[ent[c].from]);
             work.push_back({ ent[c].from, w.off + ent[c].sdist + 1, w.level > ent[c].h ? w.level : ent[c].h });
         }
     }
     lap("host: lake offsets");
-    if (timing) fprintf(stderr, "[flow] %zu connections, %zu lakes reached\n", connections.size(), off_idx.size());
+    if (timing) fprintf(stderr, "[flow] %zu connections, %zu lakes reached\n", live.size(), off_idx.size());
 
     dev_buf dlo, dcf, gdepth, hist, order, acc, doi, dov, dci, dcv, dmax;
     DMG_ALLOC(dlo, N * 4); DMG_ALLOC(dcf, N * 4); DMG_ALLOC(gdepth, N * 4); DMG_ALLOC(order, N * 4); DMG_ALLOC(acc, N * 4); DMG_ALLOC(dmax, 4);
