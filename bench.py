@@ -121,17 +121,24 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("no GPU visible: the HIP backend has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # rehearsal switches (tests only): DMG_BENCH_SHARE_GPU=1 puts every rank on GPU 0, DMG_DIST_BACKEND=gloo stages
+    # the halos through the host -- together they run the N-rank code path on a one-GPU box
+    dev_index = 0 if os.environ.get("DMG_BENCH_SHARE_GPU") == "1" else local_rank
+    backend = os.environ.get("DMG_DIST_BACKEND", "nccl")
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     W, H, sweeps = args.width, args.height, args.sweeps
     ghost = max(1, min(args.ghost, H // world))
     stream = torch.cuda.current_stream(device)
-    ctx = capi.Context(local_rank, stream=stream.cuda_stream)
+    ctx = capi.Context(dev_index, stream=stream.cuda_stream)
     grid = capi.make_grid(W, H)
     prm = capi.default_ocean_params()
     prm.jacobi_kernel = {"auto": capi.JACOBI_AUTO, "single": capi.JACOBI_SINGLE, "blocked": capi.JACOBI_BLOCKED}[args.kernel]
@@ -166,7 +173,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt, ev_ms], device=device, dtype=torch.float64)
+        tt = torch.tensor([dt, ev_ms], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt, ev_ms = float(tt[0]), float(tt[1])
 

@@ -67,3 +67,21 @@ def test_ocean_step_bands_gloo_hip(tmp_path):
     o.close()
     ctx.close()
     assert np.array_equal(got, ref)
+
+
+@pytest.mark.gpu
+def test_bench_multi_rank_rehearsal(tmp_path):
+    """bench.py launched exactly as the driver launches it for N=2 (torch.distributed.run, one process per rank), with
+    the rehearsal switches that let both ranks share this box's single GPU and exchange halos over gloo"""
+    import json, os, subprocess, sys
+    env = dict(os.environ, DMG_BENCH_SHARE_GPU="1", DMG_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+           "--width", "2048", "--height", "1024", "--sweeps", "96", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=str(ROOT))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and d["roofline"]["sweeps_per_launch"] == 8.0
+    assert "2 latitude bands" in d["config"]["parallelism"]
