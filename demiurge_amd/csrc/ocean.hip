@@ -293,7 +293,7 @@ void dmg_ocean_destroy(dmg_ocean *o)
     (void)hipSetDevice(o->ctx->device);
     (void)hipStreamSynchronize(o->ctx->stream);
     for (void *p : { (void *)o->p[0], (void *)o->p[1], (void *)o->divw, (void *)o->img, (void *)o->code, (void *)o->code8,
-                     (void *)o->v[0], (void *)o->v[1], (void *)o->rowtab, (void *)o->oob_flag })
+                     (void *)o->v[0], (void *)o->v[1], (void *)o->rowtab, (void *)o->oob_flag, (void *)o->rowclass })
         if (p) (void)hipFree(p);
     delete o;
 }
@@ -306,6 +306,8 @@ int dmg_ocean_set_terrain(dmg_ocean *o, const float *img)
     rc = ocean_build_codes(o);
     if (rc) return rc;
     rc = ocean_build_codes8(o);
+    if (rc) return rc;
+    rc = ocean_build_rowclass(o);
     if (rc) return rc;
     o->have_terrain = true;
     // keep the "land holds exact +0 in BOTH ping-pong buffers" invariant (the blocked kernel neither loads nor

@@ -33,6 +33,7 @@ struct dmg_ocean {
     float *divw = nullptr, *img = nullptr;
     unsigned char *code = nullptr;    // Jacobi/diffusion/subDiv 'use centre' bits + centre-solid bit
     unsigned char *code8 = nullptr;   // 8-neighbour solid bits (divergence, subDiv)
+    unsigned char *rowclass = nullptr; // blocked Jacobi: class of every (tile column, row) wave-row (ocean_jacobi_tb.hip)
     float *v[2] = { nullptr, nullptr };   // interleaved (vx,vy)
     int vcur = 0;
     int *oob_flag = nullptr;       // device word: advect out-of-band flag / reduction scratch
@@ -50,6 +51,7 @@ int ocean_build_codes8(dmg_ocean *o);
 int ocean_zero_land(dmg_ocean *o);            // p := +0 on land in BOTH ping-pong buffers (invariant of the blocked kernel)
 int ocean_launch_tb(dmg_ocean *o, int lo, int hi, int n);   // ocean_jacobi_tb.hip
 bool ocean_tb_supported(const dmg_ocean *o);
+int ocean_build_rowclass(dmg_ocean *o);
 int ocean_upload_rows(dmg_ocean *o, float *dst, const float *src_full, int comps);
 int ocean_download_rows(dmg_ocean *o, float *dst_full, const float *src, int comps);
 

@@ -35,6 +35,7 @@ struct tb_args {
     int spole, npole;
     int nsweeps;                    // 1..TB_T
     int tiles_x, tiles_y;
+    const unsigned char *rowclass;  // [tiles_x][L]: 0 open ocean, 1 land everywhere, 2 mixed -- per (tile column, local row), or null
     int order;                      // tile walk: 0 natural row-major, 1 XCD-chunked 16-column groups, 2 XCD-chunked column-major
 };
 
@@ -155,10 +156,26 @@ __global__ __launch_bounds__(NW * 64, (R <= 10 ? 4 : (R <= 12 ? 3 : 2))) void k_
     float4 p[R], b[R];
     unsigned code[R];
     unsigned mixed_rows = 0, land_rows = 0;         // bit r: row r of this wave has coast / is entirely land
-    // codes first: a wave-row that is land everywhere needs neither its pressure (exactly 0 in both ping-pong
-    // buffers, see k_zero_land) nor its right-hand side, and is not stored either
+    // Row classes first.  A wave-row that is land everywhere needs neither its pressure (exactly +0 in both ping-pong
+    // buffers, see k_zero_land) nor its right-hand side nor its codes, and is not stored either; an open-ocean
+    // wave-row has all-zero codes.  Both are known per (tile column, row) from a table built with the terrain, so
+    // only coast rows (and the few mirrored rows beyond an edge) wait for a dependent code load.
+    unsigned need_code = (1u << R) - 1u;
+    if (a.rowclass) {
+        int rr = min(lane, R - 1);
+        int lu = e0 + rr;                                              // unclamped local row of register row rr
+        int yg = a.y_first + lu;
+        unsigned cls = 2;
+        if (yg >= 0 && yg < a.H && lu >= 0 && lu < a.L) cls = a.rowclass[(size_t)tx * a.L + lu];
+        unsigned long long oc = __builtin_amdgcn_ballot_w64(lane < R && cls == 0);
+        unsigned long long ld = __builtin_amdgcn_ballot_w64(lane < R && cls == 1);
+        land_rows = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)ld);
+        need_code = ((1u << R) - 1u) & ~((unsigned)__builtin_amdgcn_readfirstlane((unsigned)oc) | land_rows);
+    }
 #pragma unroll
     for (int r = 0; r < R; r++) {
+        code[r] = 0;
+        if (!(need_code & (1u << r))) continue;
         tb_row m = tb_map_row(a, e0 + r);
         size_t off = (size_t)m.l * W + (m.shift ? colp : col);
         unsigned c = *reinterpret_cast<const unsigned *>(a.code + off);
@@ -171,6 +188,7 @@ __global__ __launch_bounds__(NW * 64, (R <= 10 ? 4 : (R <= 12 ? 3 : 2))) void k_
     }
 #pragma unroll
     for (int r = 0; r < R; r++) {
+        if (!(need_code & (1u << r))) continue;
         unsigned c = code[r];
         if (__builtin_amdgcn_ballot_w64((c & 0x1F1F1F1Fu) != 0)) mixed_rows |= (1u << r);
         if (__builtin_amdgcn_ballot_w64((c & 0x10101010u) != 0x10101010u) == 0) land_rows |= (1u << r);
@@ -250,6 +268,35 @@ __global__ __launch_bounds__(NW * 64, (R <= 10 ? 4 : (R <= 12 ? 3 : 2))) void k_
     }
 }
 
+// Class of every (tile column, local row) wave-row for the tile geometry above: columns [240*tx - 8, +256) wrapped.
+// Uses the codes as the kernel sees them on a real (not mirrored) row, i.e. with the clamp bit of a non-pole edge row
+// cleared.  One wave per (tx, l).
+__global__ __launch_bounds__(64) void k_tb_rowclass(const unsigned char *__restrict__ code, unsigned char *__restrict__ cls, int W, int L,
+                                                    int y_first, int H, int spole, int npole)
+{
+    const int lane = threadIdx.x, tx = blockIdx.x, l = blockIdx.y;
+    int col = tx * TB_OW - TB_T + 4 * lane;
+    col %= W; if (col < 0) col += W;
+    unsigned c = *reinterpret_cast<const unsigned *>(code + (size_t)l * W + col);
+    int yg = y_first + l;
+    if (yg == 0 && !spole) c &= ~0x02020202u;
+    if (yg == H - 1 && !npole) c &= ~0x01010101u;
+    bool any = __builtin_amdgcn_ballot_w64((c & 0x1F1F1F1Fu) != 0) != 0;
+    bool all_land = __builtin_amdgcn_ballot_w64((c & 0x10101010u) != 0x10101010u) == 0;
+    if (lane == 0) cls[(size_t)tx * L + l] = all_land ? 1 : (any ? 2 : 0);
+}
+
+int ocean_build_rowclass(dmg_ocean *o)
+{
+    if (!ocean_tb_supported(o)) return DMG_OK;
+    const int tiles_x = (o->grid.W + TB_OW - 1) / TB_OW;
+    if (!o->rowclass) DMG_HIP(hipMalloc((void **)&o->rowclass, (size_t)tiles_x * o->L));
+    hipLaunchKernelGGL(k_tb_rowclass, dim3(tiles_x, o->L), dim3(64), 0, o->ctx->stream, o->code, o->rowclass, o->grid.W, o->L,
+                       o->y0 - o->gs, o->grid.H, o->topo.spole ? 1 : 0, o->topo.npole ? 1 : 0);
+    DMG_HIP(hipGetLastError());
+    return DMG_OK;
+}
+
 // tile shapes built into the library: R rows per thread x NW waves per workgroup.  The default is chosen from
 // measurements; DMG_TB_SHAPE=<R>x<NW> overrides it for experiments.
 struct tb_shape { int R, NW; };
@@ -294,6 +341,8 @@ int ocean_launch_tb(dmg_ocean *o, int lo, int hi, int n)
     a.y_first = o->y0 - o->gs; a.H = o->grid.H;
     a.spole = o->topo.spole ? 1 : 0; a.npole = o->topo.npole ? 1 : 0;
     a.nsweeps = n;
+    static const bool use_cls = getenv("DMG_TB_NOCLASS") == nullptr;
+    a.rowclass = use_cls ? o->rowclass : nullptr;
     tb_shape sh = tb_pick_shape();
     hipStream_t st = o->ctx->stream;
     if (sh.R == 16) tb_launch<16, 8>(a, a.W, hi - lo, st);
