@@ -203,7 +203,9 @@ __global__ __launch_bounds__(NW * 64, (R <= 10 ? 4 : (R <= 12 ? 3 : 2))) void k_
         b[r] = *reinterpret_cast<const float4 *>(a.b + off);
     }
     mixed_rows = __builtin_amdgcn_readfirstlane(mixed_rows);
-    // wave-rows that are land everywhere stay exactly 0 (k_zero_land keeps land at 0 on input; :481 on output)
+    // wave-rows that are land everywhere stay exactly 0 (k_zero_land keeps land at 0 on input; :481 on output);
+    // a tile that is land everywhere has nothing to sweep or store
+    if (__syncthreads_and(land_rows == ((1u << R) - 1u))) return;
 
     for (int s = 0; s < a.nsweeps; s++) {
         // publish this wave's first and last rows (values before the sweep), fetch the neighbours' rows
