@@ -63,6 +63,8 @@ GLF(void, glUniform1i, GLint, GLint)
 GLF(void, glUniform1f, GLint, GLfloat)
 GLF(void, glUniform2f, GLint, GLfloat, GLfloat)
 GLF(void, glUniform1fv, GLint, GLsizei, const GLfloat *)
+GLF(void, glUniform3f, GLint, GLfloat, GLfloat, GLfloat)
+GLF(void, glUniformMatrix3fv, GLint, GLsizei, GLboolean, const GLfloat *)
 GLF(void, glGenVertexArrays, GLsizei, GLuint *)
 GLF(void, glBindVertexArray, GLuint)
 GLF(void, glGenBuffers, GLsizei, GLuint *)
@@ -125,7 +127,7 @@ int refgl_init(void)
     LOAD(glShaderSource) LOAD(glCompileShader) LOAD(glGetShaderiv) LOAD(glGetShaderInfoLog)
     LOAD(glCreateProgram) LOAD(glAttachShader) LOAD(glLinkProgram) LOAD(glGetProgramiv)
     LOAD(glGetProgramInfoLog) LOAD(glUseProgram) LOAD(glGetUniformLocation) LOAD(glUniform1i)
-    LOAD(glUniform1f) LOAD(glUniform2f) LOAD(glUniform1fv) LOAD(glGenVertexArrays) LOAD(glBindVertexArray)
+    LOAD(glUniform1f) LOAD(glUniform2f) LOAD(glUniform1fv) LOAD(glUniform3f) LOAD(glUniformMatrix3fv) LOAD(glGenVertexArrays) LOAD(glBindVertexArray)
     LOAD(glGenBuffers) LOAD(glBindBuffer) LOAD(glBufferData) LOAD(glVertexAttribPointer)
     LOAD(glEnableVertexAttribArray) LOAD(glDrawElements) LOAD(glFinish) LOAD(glGetError) LOAD(glGetString)
     LOAD(glPixelStorei)
@@ -276,6 +278,24 @@ int refgl_uniform2f(int prog, const char *name, float a, float b)
     GLint id = p_glGetUniformLocation(progs[prog].id, name);
     if (id < 0) return -1;
     p_glUniform2f(id, a, b);
+    return 0;
+}
+
+int refgl_uniform3f(int prog, const char *name, float a, float b, float c)
+{
+    p_glUseProgram(progs[prog].id);
+    GLint id = p_glGetUniformLocation(progs[prog].id, name);
+    if (id < 0) return -1;
+    p_glUniform3f(id, a, b, c);
+    return 0;
+}
+// glUniformMatrix3fv(id, 1, GL_FALSE, m): 9 floats, column-major (Plate.cpp:37-42)
+int refgl_uniform_mat3(int prog, const char *name, const float *m)
+{
+    p_glUseProgram(progs[prog].id);
+    GLint id = p_glGetUniformLocation(progs[prog].id, name);
+    if (id < 0) return -1;
+    p_glUniformMatrix3fv(id, 1, GL_FALSE, m);
     return 0;
 }
 

@@ -58,6 +58,8 @@ class RefGL:
         L.refgl_program.argtypes = [ctypes.c_char_p]
         L.refgl_uniform1f.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_float]
         L.refgl_uniform2f.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_float, ctypes.c_float]
+        L.refgl_uniform3f.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_float, ctypes.c_float, ctypes.c_float]
+        L.refgl_uniform_mat3.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.POINTER(ctypes.c_float)]
         L.refgl_apply.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                   ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_int)]
         L.refgl_pingpong.restype = ctypes.c_double
@@ -128,6 +130,13 @@ class RefGL:
 
     def uniform2f(self, prog, name, a, b):
         return self.L.refgl_uniform2f(prog, name.encode(), float(a), float(b))
+
+    def uniform3f(self, prog, name, a, b, c):
+        return self.L.refgl_uniform3f(prog, name.encode(), float(a), float(b), float(c))
+
+    def uniform_mat3(self, prog, name, m9):
+        arr = (ctypes.c_float * 9)(*[float(x) for x in m9])
+        return self.L.refgl_uniform_mat3(prog, name.encode(), arr)
 
     @staticmethod
     def _pairs(samplers):
@@ -428,3 +437,110 @@ def morphological_gradient(field, radius, coords=FULL_GLOBE, circ=42000.0):
     er = morphological(field, np.float32(radius) / np.float32(2), "min", coords, circ)
     di = morphological(field, (np.float32(radius) + np.float32(1)) / np.float32(2), "max", coords, circ)
     return (di - er).astype(np.float32)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Tectonics (src/filter/tectonics/Tectonics.cpp, Plate.cpp)
+# ---------------------------------------------------------------------------------------------------------------
+def glm_rotate(m, angle, axis):
+    """glm::rotate(mat4 m, float angle, vec3 axis) restated (GLM's published algorithm, matrix_transform.inl; the
+    reference's lib/glm submodule is empty in this checkout).  m: 4x4 float32, column-major as m[col][row]."""
+    f = np.float32
+    a = f(angle)
+    c, s = f(np.cos(a)), f(np.sin(a))
+    ax = np.asarray(axis, f)
+    ax = ax / f(np.sqrt(f(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2])))
+    temp = (f(1) - c) * ax
+    R = np.zeros((3, 3), f)
+    R[0][0] = c + temp[0] * ax[0]; R[0][1] = temp[0] * ax[1] + s * ax[2]; R[0][2] = temp[0] * ax[2] - s * ax[1]
+    R[1][0] = temp[1] * ax[0] - s * ax[2]; R[1][1] = c + temp[1] * ax[1]; R[1][2] = temp[1] * ax[2] + s * ax[0]
+    R[2][0] = temp[2] * ax[0] + s * ax[1]; R[2][1] = temp[2] * ax[1] - s * ax[0]; R[2][2] = c + temp[2] * ax[2]
+    out = np.array(m, f)
+    for k in range(3):
+        out[k] = m[0] * R[k][0] + m[1] * R[k][1] + m[2] * R[k][2]
+    out[3] = m[3]
+    return out.astype(f)
+
+
+class _Plate:
+    """Plate (Plate.cpp:10-48)"""
+
+    def __init__(self, g, W, H):
+        self.tex = g.tex(W, H, 4, False)
+        self.rotation = np.eye(4, dtype=np.float32)
+        self.av = np.zeros(3, np.float32)
+
+    def rotate(self):                                    # :26-28
+        ln = np.float32(np.sqrt(np.float32(self.av[0] * self.av[0] + self.av[1] * self.av[1] + self.av[2] * self.av[2])))
+        self.rotation = glm_rotate(self.rotation, ln, self.av / ln)
+
+    def uniforms(self, g, prog, index):                  # setPlateUniforms :30-44
+        g.uniform1f(prog, "plateIndex", index)
+        a = self.rotation[:3, :3]                        # glm::mat3 a = rotation (columns)
+        g.uniform_mat3(prog, "rotationmatrix", a.reshape(-1))
+        g.uniform_mat3(prog, "inverserotationmatrix", a.T.reshape(-1))   # glm::transpose(a)
+        g.uniform3f(prog, "plateVelocity", *self.av)
+
+
+def tectonics(img, steps, coords=FULL_GLOBE, circ=42000.0, trace=None):
+    """Tectonics::Tectonics + Tectonics::run (Tectonics.cpp:15-275) for `steps` (reference: 70) iterations.
+    Returns (terrain, [plate textures]).  Texture ids AND sizes move with Texture::swap exactly as in the reference:
+    the scratch maps a, b, c are W x W (:22-24) and trade places with the W x H plate textures in the unfold loop."""
+    g = RefGL.get()
+    g.set_canvas(coords, circ)
+    H, W = img.shape
+    t_img = g.tex(W, H, 1, False, img)
+    plates = [_Plate(g, W, H), _Plate(g, W, H)]
+    plates[0].av += np.float32(0.01) * np.array([-1, 0, 0], np.float32)       # :18
+    plates[1].av += -np.float32(0.01) * np.array([-1, 0, 0], np.float32)      # :20
+    a, b, c = g.tex(W, W, 4, False), g.tex(W, W, 4, False), g.tex(W, W, 4, False)
+    P = g.program
+    g.apply(P("Tectonics.cpp:28"), plates[0].tex, {"img": t_img})             # :41-43
+    g.apply(P("Tectonics.cpp:44"), plates[1].tex, {"img": t_img})             # :57-59
+    zero, fold = P("Tectonics.cpp:99"), P("Tectonics.cpp:112")
+    for it in range(steps):
+        for pl in plates:
+            pl.rotate()                                                       # :158-160
+        # fold(setzero, foldShader, a, b) :278-293
+        g.apply(zero, a, {})
+        g.swap(a, b)
+        for idx, pl in enumerate(plates, 1):
+            pl.uniforms(g, fold, idx)
+            g.apply(fold, a, {"foldtex": b, "plate": pl.tex})
+            g.swap(a, b)
+        if trace is not None and it == 0:
+            trace["fold"] = g.download(b)
+        # oceanSpreading :295-397
+        g.apply(P("Tectonics.cpp:303"), a, {"foldtex": b}); g.swap(a, b)
+        spread = P("Tectonics.cpp:325")
+        for i in list(range(5)) + list(range(5, 0, -1)):
+            g.uniform1f(spread, "radius", np.float32(2.0 ** i))
+            g.apply(spread, a, {"foldtex": b}); g.swap(a, b)
+        g.apply(P("Tectonics.cpp:376"), a, {"foldtex": b}); g.swap(a, b)
+        if trace is not None and it == 0:
+            trace["spread"] = g.download(b)
+        # collision :399-618
+        g.apply(P("Tectonics.cpp:400"), a, {}); g.swap(a, c)
+        setrot = P("Tectonics.cpp:410")
+        for idx, pl in enumerate(plates, 1):
+            pl.uniforms(g, setrot, idx)
+            g.apply(setrot, a, {"foldtex": c, "plateIndices": b}); g.swap(a, c)
+        g.apply(P("Tectonics.cpp:445"), a, {"foldtex": c, "plateIndices": b}); g.swap(a, c)
+        coll = P("Tectonics.cpp:534")
+        for i in range(10):
+            g.uniform1f(coll, "radius", float(i))
+            g.apply(coll, a, {"foldtex": c, "plateIndices": b}); g.swap(a, c)
+        # render :186-209
+        g.apply(P("Tectonics.cpp:186"), t_img, {"foldtex": c})
+        # back to plates :216-267
+        unfold = P("Tectonics.cpp:216")
+        for idx, pl in enumerate(plates, 1):
+            g.swap(c, pl.tex)
+            pl.uniforms(g, unfold, idx)
+            g.apply(unfold, pl.tex, {"foldtex": b, "oldPlate": c})
+    out = g.download(t_img)
+    pts = [g.download(pl.tex) for pl in plates]
+    if trace is not None:
+        trace["sizes"] = [g._shape[pl.tex] for pl in plates] + [g._shape[x] for x in (a, b, c)]
+    g.delete(t_img, a, b, c, *[pl.tex for pl in plates])
+    return out, pts
