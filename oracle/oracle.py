@@ -244,3 +244,156 @@ def morphological_gradient(g, field, radius):
     er = morphological(g, field, np.float32(radius) / np.float32(2), "min")
     di = morphological(g, field, (np.float32(radius) + np.float32(1)) / np.float32(2), "max")
     return (di - er).astype(np.float32)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Tectonics (src/filter/tectonics/Tectonics.cpp, Plate.cpp); pass arithmetic in tect_oracle.c
+# ---------------------------------------------------------------------------------------------------------------
+def glm_rotate(m, angle, axis):
+    """glm::rotate(mat4 m, float angle, vec3 axis) as published in GLM's ext/matrix_transform.inl (the reference's
+    lib/glm submodule is an empty directory in this checkout; .gitmodules:4-6 pins no version, the function has not
+    changed since GLM 0.9.x).  m: 4x4 float32 indexed m[col][row]."""
+    f = np.float32
+    a = f(angle)
+    c, s = f(np.cos(a)), f(np.sin(a))
+    ax = np.asarray(axis, f)
+    ax = ax * (f(1) / f(np.sqrt(f(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]))))   # glm::normalize: v * inversesqrt(dot)
+    temp = (f(1) - c) * ax
+    R = np.zeros((3, 3), f)
+    R[0][0] = c + temp[0] * ax[0]; R[0][1] = temp[0] * ax[1] + s * ax[2]; R[0][2] = temp[0] * ax[2] - s * ax[1]
+    R[1][0] = temp[1] * ax[0] - s * ax[2]; R[1][1] = c + temp[1] * ax[1]; R[1][2] = temp[1] * ax[2] + s * ax[0]
+    R[2][0] = temp[2] * ax[0] + s * ax[1]; R[2][1] = temp[2] * ax[1] - s * ax[0]; R[2][2] = c + temp[2] * ax[2]
+    m = np.asarray(m, f)
+    out = np.array(m, f)
+    for k in range(3):
+        out[k] = m[0] * R[k][0] + m[1] * R[k][1] + m[2] * R[k][2]
+    out[3] = m[3]
+    return out.astype(f)
+
+
+def tect_set_math(mode):
+    lib().orc_tect_set_math(int(mode))
+
+
+class TectPlate:
+    """Plate (Plate.cpp:10-48): RGBA texture (height, age, 0, 0) + accumulated rotation"""
+
+    def __init__(self, tex, angular_velocity):
+        self.tex = tex
+        self.rotation = np.eye(4, dtype=np.float32)
+        self.av = np.asarray(angular_velocity, np.float32)
+
+    def rotate(self):                                              # :26-28
+        f = np.float32
+        d = f(self.av[0] * self.av[0] + self.av[1] * self.av[1] + self.av[2] * self.av[2])
+        ln = f(np.sqrt(d))                                         # glm::length
+        unit = self.av * (f(1) / f(np.sqrt(d)))                    # glm::normalize (glm::rotate normalises once more)
+        self.rotation = glm_rotate(self.rotation, ln, unit)
+
+    def mat3(self):                                                # glm::mat3 a = rotation, value_ptr order
+        return np.ascontiguousarray(self.rotation[:3, :3].reshape(-1), np.float32)
+
+    def inv_mat3(self):                                            # glm::transpose(a)
+        return np.ascontiguousarray(self.rotation[:3, :3].T.reshape(-1), np.float32)
+
+
+def _tect_bind():
+    L = lib()
+    if not hasattr(L, "_tect_bound"):
+        P, G, I, F = ctypes.c_void_p, ctypes.POINTER(Grid), ctypes.c_int, ctypes.c_float
+        L.orc_tect_init_plate.argtypes = [G, P, I, P]
+        L.orc_tect_fold_zero.argtypes = [P, I, I]
+        L.orc_tect_fold.argtypes = [G, P, I, I, P, I, I, P, F, P, I, I]
+        L.orc_tect_spread_flag.argtypes = [P, I, P, I, I]
+        L.orc_tect_spread_ring.argtypes = [G, P, F, P, I, I]
+        L.orc_tect_render.argtypes = [G, P, I, I, P]
+        L.orc_tect_unfold.argtypes = [G, P, I, I, P, I, I, P, F, P, I, I]
+        L._tect_bound = True
+    return L
+
+
+def tect_init_plates(g, img):
+    L = _tect_bind()
+    img = _f32(img)
+    out = []
+    for which in (0, 1):
+        t = np.empty((g.H, g.W, 4), np.float32)
+        L.orc_tect_init_plate(ctypes.byref(g), _ptr(img), which, _ptr(t))
+        out.append(t)
+    f = np.float32
+    return [TectPlate(out[0], f(0.01) * np.array([-1, 0, 0], f)),      # Tectonics.cpp:18
+            TectPlate(out[1], -f(0.01) * np.array([-1, 0, 0], f))]     # :20
+
+
+def tect_fold(g, plates, S):
+    """Tectonics::fold (:278-293) -> global map (S x S x 4): plate index, height, age, overlap marker"""
+    L = _tect_bind()
+    a = np.empty((S, S, 4), np.float32)
+    L.orc_tect_fold_zero(_ptr(a), S, S)
+    for idx, pl in enumerate(plates, 1):
+        b = np.empty_like(a)
+        m = pl.mat3()
+        L.orc_tect_fold(ctypes.byref(g), _ptr(a), S, S, _ptr(pl.tex), pl.tex.shape[1], pl.tex.shape[0], _ptr(m),
+                        float(idx), _ptr(b), S, S)
+        a = b
+    return a
+
+
+def tect_spread(g, b):
+    """Tectonics::oceanSpreading (:295-397)"""
+    L = _tect_bind()
+    S = b.shape[0]
+    a = np.empty_like(b)
+    L.orc_tect_spread_flag(_ptr(b), 0, _ptr(a), S, S)
+    for i in list(range(5)) + list(range(5, 0, -1)):
+        nxt = np.empty_like(a)
+        L.orc_tect_spread_ring(ctypes.byref(g), _ptr(a), float(2.0 ** i), _ptr(nxt), S, S)
+        a = nxt
+    out = np.empty_like(a)
+    L.orc_tect_spread_flag(_ptr(a), 1, _ptr(out), S, S)
+    return out
+
+
+def tect_unfold(g, b, pl, idx, shape):
+    L = _tect_bind()
+    out = np.empty(shape + (4,), np.float32)
+    m = pl.inv_mat3()
+    L.orc_tect_unfold(ctypes.byref(g), _ptr(b), b.shape[1], b.shape[0], _ptr(pl.tex), pl.tex.shape[1], pl.tex.shape[0],
+                      _ptr(m), float(idx), _ptr(out), shape[1], shape[0])
+    return out
+
+
+def tectonics(g, img, steps, trace=None):
+    """Tectonics::Tectonics + Tectonics::run (:15-275) -> (terrain, [plate textures]).
+
+    collision() (:399-618) is evaluated only as far as anything reads it afterwards: its result texture c is consumed
+    by the render pass alone, which takes c.y = plateIndices.x (:590, :199); the other channels are overwritten before
+    any use.  Its 14 a<->c swaps cancel.  The unfold loop's c<->plate swaps (:260) rotate three storage sizes among
+    (c, plate 0, plate 1): W x W, W x H, W x H with period 3 -- reproduced through `c_shape`."""
+    L = _tect_bind()
+    plates = tect_init_plates(g, img)
+    S = g.W
+    c_shape = (S, S)
+    terrain = None
+    for it in range(steps):
+        for pl in plates:
+            pl.rotate()                                                       # :158-160
+        b = tect_fold(g, plates, S)
+        if trace is not None and it == 0:
+            trace["fold"] = b.copy()
+        b = tect_spread(g, b)
+        if trace is not None and it == 0:
+            trace["spread"] = b.copy()
+        # collision -> c.y = b.x at c's resolution; render :186-210 fetches it at W x H
+        cy = np.zeros(c_shape + (4,), np.float32)
+        sy = ((np.arange(c_shape[0], dtype=np.float32) + np.float32(0.5)) / np.float32(c_shape[0]))
+        sx = ((np.arange(c_shape[1], dtype=np.float32) + np.float32(0.5)) / np.float32(c_shape[1]))
+        jj = np.clip(np.floor(sy * np.float32(S)).astype(int), 0, S - 1)
+        ii = np.clip(np.floor(sx * np.float32(S)).astype(int), 0, S - 1)
+        cy[..., 1] = b[jj][:, ii, 0]
+        terrain = np.empty((g.H, g.W), np.float32)
+        L.orc_tect_render(ctypes.byref(g), _ptr(cy), c_shape[1], c_shape[0], _ptr(terrain))
+        for idx, pl in enumerate(plates, 1):                                  # :259-268
+            new_shape, c_shape = c_shape, pl.tex.shape[:2]                    # c->swap(plate texture)
+            pl.tex = tect_unfold(g, b, pl, idx, new_shape)
+    return terrain, [pl.tex for pl in plates]

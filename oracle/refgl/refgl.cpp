@@ -264,6 +264,24 @@ int refgl_program(const char *key)
     return (int)progs.size() - 1;
 }
 
+// probe programs written by the test tooling itself (e.g. to sample llvmpipe's sin/cos/asin/atan): vertex2D + src
+int refgl_program_source(const char *frag_src)
+{
+    GLuint vs = compile(GL_VERTEX_SHADER, vertex2D->getCode());
+    if (!vs) return -1;
+    GLuint fs = compile(GL_FRAGMENT_SHADER, frag_src);
+    if (!fs) return -1;
+    GLuint p = p_glCreateProgram();
+    p_glAttachShader(p, vs);
+    p_glAttachShader(p, fs);
+    p_glLinkProgram(p);
+    GLint ok = 0;
+    p_glGetProgramiv(p, GL_LINK_STATUS, &ok);
+    if (!ok) { last_err = "probe link failed"; return -1; }
+    progs.push_back({ p });
+    return (int)progs.size() - 1;
+}
+
 int refgl_uniform1f(int prog, const char *name, float v)
 {
     p_glUseProgram(progs[prog].id);

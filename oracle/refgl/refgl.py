@@ -56,6 +56,7 @@ class RefGL:
         L.refgl_tex_upload.argtypes = [ctypes.c_int, ctypes.c_void_p]
         L.refgl_tex_download.argtypes = [ctypes.c_int, ctypes.c_void_p]
         L.refgl_program.argtypes = [ctypes.c_char_p]
+        L.refgl_program_source.argtypes = [ctypes.c_char_p]
         L.refgl_uniform1f.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_float]
         L.refgl_uniform2f.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_float, ctypes.c_float]
         L.refgl_uniform3f.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_float, ctypes.c_float, ctypes.c_float]
@@ -124,6 +125,13 @@ class RefGL:
                 raise RuntimeError("program %s: %s" % (key, self.L.refgl_last_error().decode()))
             self._progs[key] = p
         return self._progs[key]
+
+    def program_source(self, frag_src):
+        """probe program from GLSL written by the tooling (vertex2D + frag_src)"""
+        p = self.L.refgl_program_source(frag_src.encode())
+        if p < 0:
+            raise RuntimeError(self.L.refgl_last_error().decode())
+        return p
 
     def uniform1f(self, prog, name, v):
         return self.L.refgl_uniform1f(prog, name.encode(), float(v))
@@ -442,44 +450,19 @@ def morphological_gradient(field, radius, coords=FULL_GLOBE, circ=42000.0):
 # ---------------------------------------------------------------------------------------------------------------
 # Tectonics (src/filter/tectonics/Tectonics.cpp, Plate.cpp)
 # ---------------------------------------------------------------------------------------------------------------
-def glm_rotate(m, angle, axis):
-    """glm::rotate(mat4 m, float angle, vec3 axis) restated (GLM's published algorithm, matrix_transform.inl; the
-    reference's lib/glm submodule is empty in this checkout).  m: 4x4 float32, column-major as m[col][row]."""
-    f = np.float32
-    a = f(angle)
-    c, s = f(np.cos(a)), f(np.sin(a))
-    ax = np.asarray(axis, f)
-    ax = ax / f(np.sqrt(f(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2])))
-    temp = (f(1) - c) * ax
-    R = np.zeros((3, 3), f)
-    R[0][0] = c + temp[0] * ax[0]; R[0][1] = temp[0] * ax[1] + s * ax[2]; R[0][2] = temp[0] * ax[2] - s * ax[1]
-    R[1][0] = temp[1] * ax[0] - s * ax[2]; R[1][1] = c + temp[1] * ax[1]; R[1][2] = temp[1] * ax[2] + s * ax[0]
-    R[2][0] = temp[2] * ax[0] + s * ax[1]; R[2][1] = temp[2] * ax[1] - s * ax[0]; R[2][2] = c + temp[2] * ax[2]
-    out = np.array(m, f)
-    for k in range(3):
-        out[k] = m[0] * R[k][0] + m[1] * R[k][1] + m[2] * R[k][2]
-    out[3] = m[3]
-    return out.astype(f)
+def _oracle_host():
+    """host-side arithmetic of Plate (glm::rotate, mat3 packing) lives in oracle.py; the GLSL runs here"""
+    import sys
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+    import oracle as orc
+    return orc
 
 
-class _Plate:
-    """Plate (Plate.cpp:10-48)"""
-
-    def __init__(self, g, W, H):
-        self.tex = g.tex(W, H, 4, False)
-        self.rotation = np.eye(4, dtype=np.float32)
-        self.av = np.zeros(3, np.float32)
-
-    def rotate(self):                                    # :26-28
-        ln = np.float32(np.sqrt(np.float32(self.av[0] * self.av[0] + self.av[1] * self.av[1] + self.av[2] * self.av[2])))
-        self.rotation = glm_rotate(self.rotation, ln, self.av / ln)
-
-    def uniforms(self, g, prog, index):                  # setPlateUniforms :30-44
-        g.uniform1f(prog, "plateIndex", index)
-        a = self.rotation[:3, :3]                        # glm::mat3 a = rotation (columns)
-        g.uniform_mat3(prog, "rotationmatrix", a.reshape(-1))
-        g.uniform_mat3(prog, "inverserotationmatrix", a.T.reshape(-1))   # glm::transpose(a)
-        g.uniform3f(prog, "plateVelocity", *self.av)
+def _plate_uniforms(g, prog, pl, index):                 # Plate::setPlateUniforms (Plate.cpp:30-44)
+    g.uniform1f(prog, "plateIndex", index)
+    g.uniform_mat3(prog, "rotationmatrix", pl.mat3())
+    g.uniform_mat3(prog, "inverserotationmatrix", pl.inv_mat3())
+    g.uniform3f(prog, "plateVelocity", *pl.av)
 
 
 def tectonics(img, steps, coords=FULL_GLOBE, circ=42000.0, trace=None):
@@ -490,9 +473,10 @@ def tectonics(img, steps, coords=FULL_GLOBE, circ=42000.0, trace=None):
     g.set_canvas(coords, circ)
     H, W = img.shape
     t_img = g.tex(W, H, 1, False, img)
-    plates = [_Plate(g, W, H), _Plate(g, W, H)]
-    plates[0].av += np.float32(0.01) * np.array([-1, 0, 0], np.float32)       # :18
-    plates[1].av += -np.float32(0.01) * np.array([-1, 0, 0], np.float32)      # :20
+    orc = _oracle_host()
+    f = np.float32
+    plates = [orc.TectPlate(g.tex(W, H, 4, False), f(0.01) * np.array([-1, 0, 0], f)),       # :16-18
+              orc.TectPlate(g.tex(W, H, 4, False), -f(0.01) * np.array([-1, 0, 0], f))]      # :17,:20
     a, b, c = g.tex(W, W, 4, False), g.tex(W, W, 4, False), g.tex(W, W, 4, False)
     P = g.program
     g.apply(P("Tectonics.cpp:28"), plates[0].tex, {"img": t_img})             # :41-43
@@ -505,7 +489,7 @@ def tectonics(img, steps, coords=FULL_GLOBE, circ=42000.0, trace=None):
         g.apply(zero, a, {})
         g.swap(a, b)
         for idx, pl in enumerate(plates, 1):
-            pl.uniforms(g, fold, idx)
+            _plate_uniforms(g, fold, pl, idx)
             g.apply(fold, a, {"foldtex": b, "plate": pl.tex})
             g.swap(a, b)
         if trace is not None and it == 0:
@@ -523,7 +507,7 @@ def tectonics(img, steps, coords=FULL_GLOBE, circ=42000.0, trace=None):
         g.apply(P("Tectonics.cpp:400"), a, {}); g.swap(a, c)
         setrot = P("Tectonics.cpp:410")
         for idx, pl in enumerate(plates, 1):
-            pl.uniforms(g, setrot, idx)
+            _plate_uniforms(g, setrot, pl, idx)
             g.apply(setrot, a, {"foldtex": c, "plateIndices": b}); g.swap(a, c)
         g.apply(P("Tectonics.cpp:445"), a, {"foldtex": c, "plateIndices": b}); g.swap(a, c)
         coll = P("Tectonics.cpp:534")
@@ -536,7 +520,7 @@ def tectonics(img, steps, coords=FULL_GLOBE, circ=42000.0, trace=None):
         unfold = P("Tectonics.cpp:216")
         for idx, pl in enumerate(plates, 1):
             g.swap(c, pl.tex)
-            pl.uniforms(g, unfold, idx)
+            _plate_uniforms(g, unfold, pl, idx)
             g.apply(unfold, pl.tex, {"foldtex": b, "oldPlate": c})
     out = g.download(t_img)
     pts = [g.download(pl.tex) for pl in plates]

@@ -84,13 +84,29 @@ def next_goldens():
          gradient_r3=refgl.morphological_gradient(f, 3.0))
 
 
+def tectonics_goldens():
+    """SURVEY 8a-11: Tectonics::run -- terrain + plate textures after N steps, and the global map of the first step
+    after fold and after oceanSpreading.  70 steps is the reference's own count (Tectonics.cpp:157)."""
+    for name, W, H, coords, steps in (("globe_64x32_s70", 64, 32, FULL, 70), ("globe_128x64_s10", 128, 64, FULL, 10),
+                                      ("belt_128x64_s12", 128, 64, BELT, 12), ("region_128x64_s12", 128, 64, REGION, 12),
+                                      ("globe_100x50_s5", 100, 50, FULL, 5)):
+        img = (synth.terrain(W, H) * 3).astype(f32)
+        tr = {}
+        terrain, plates = refgl.tectonics(img, steps, coords=coords, circ=CIRC, trace=tr)
+        save("tectonics_" + name, coords=np.array(coords), circ=f32(CIRC), img=img, steps=np.int32(steps),
+             terrain=terrain, plate0=plates[0], plate1=plates[1], fold1=tr["fold"], spread1=tr["spread"])
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "tectonics":
+        return tectonics_goldens()
     if len(sys.argv) > 1 and sys.argv[1] == "flow":
         return flow_goldens()
     if len(sys.argv) > 1 and sys.argv[1] == "next":
         return next_goldens()
     flow_goldens()
     next_goldens()
+    tectonics_goldens()
     # ---- Jacobi (headline) -------------------------------------------------
     W, H = 256, 128
     img, b = synth.terrain(W, H), synth.divw(W, H)
