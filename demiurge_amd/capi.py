@@ -105,6 +105,19 @@ def lib():
         "dmg_thermal_erosion": (c_int, [vp, PG, vp]),
         "dmg_morphological": (c_int, [vp, PG, vp, c_float, c_int]),
         "dmg_morphological_gradient": (c_int, [vp, PG, vp, c_float]),
+        "dmg_tectonics_create": (c_int, [vp, PG, vp, ctypes.POINTER(vp)]),
+        "dmg_tectonics_destroy": (None, [vp]),
+        "dmg_tectonics_update_rotation": (c_int, [vp, c_int, c_float, ctypes.POINTER(c_float)]),
+        "dmg_tectonics_step": (c_int, [vp, c_int]),
+        "dmg_tectonics_fold": (c_int, [vp]),
+        "dmg_tectonics_spread": (c_int, [vp]),
+        "dmg_tectonics_render": (c_int, [vp]),
+        "dmg_tectonics_unfold": (c_int, [vp]),
+        "dmg_tectonics_get_terrain": (c_int, [vp, vp]),
+        "dmg_tectonics_get_map": (c_int, [vp, vp]),
+        "dmg_tectonics_plate_count": (c_int, [vp]),
+        "dmg_tectonics_plate_size": (c_int, [vp, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+        "dmg_tectonics_get_plate": (c_int, [vp, c_int, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)          # AttributeError if the library does not export a declared symbol
@@ -346,4 +359,67 @@ class Ocean:
                 res[k] = a
         if "v" in want:
             res["v"] = np.stack([arr["vx"], arr["vy"]], axis=-1)
+        return res
+
+
+class Tectonics:
+    """dmg_tectonics: the Tectonics filter state (plates + global map)."""
+
+    def __init__(self, ctx, grid, terrain):
+        self.ctx, self.grid = ctx, grid
+        terrain = _f32(terrain)
+        assert terrain.shape == (grid.H, grid.W)
+        h = ctypes.c_void_p()
+        check(lib().dmg_tectonics_create(ctx.h, ctypes.byref(grid), _p(terrain), ctypes.byref(h)))
+        self.h = h
+        ctx._children.add(self)
+
+    def close(self):
+        if self.h:
+            lib().dmg_tectonics_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def update_rotation(self, plate, theta, axis):
+        ax = (ctypes.c_float * 3)(*[float(a) for a in axis])
+        check(lib().dmg_tectonics_update_rotation(self.h, plate, theta, ax))
+
+    def step(self, n=1):
+        check(lib().dmg_tectonics_step(self.h, n))
+
+    def fold(self):
+        check(lib().dmg_tectonics_fold(self.h))
+
+    def spread(self):
+        check(lib().dmg_tectonics_spread(self.h))
+
+    def render(self):
+        check(lib().dmg_tectonics_render(self.h))
+
+    def unfold(self):
+        check(lib().dmg_tectonics_unfold(self.h))
+
+    def terrain(self):
+        out = np.empty((self.grid.H, self.grid.W), np.float32)
+        check(lib().dmg_tectonics_get_terrain(self.h, _p(out)))
+        return out
+
+    def map(self):
+        out = np.empty((self.grid.W, self.grid.W, 4), np.float32)
+        check(lib().dmg_tectonics_get_map(self.h, _p(out)))
+        return out
+
+    def plates(self):
+        res = []
+        for k in range(lib().dmg_tectonics_plate_count(self.h)):
+            w, h = ctypes.c_int(), ctypes.c_int()
+            check(lib().dmg_tectonics_plate_size(self.h, k, ctypes.byref(w), ctypes.byref(h)))
+            out = np.empty((h.value, w.value, 4), np.float32)
+            check(lib().dmg_tectonics_get_plate(self.h, k, _p(out)))
+            res.append(out)
         return res

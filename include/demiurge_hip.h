@@ -196,6 +196,37 @@ int dmg_morphological(dmg_ctx *ctx, const dmg_grid *grid, float *field_inout, fl
 /* MorphologicalGradient (:87-131): dilate((radius+1)/2) - erode(radius/2) */
 int dmg_morphological_gradient(dmg_ctx *ctx, const dmg_grid *grid, float *field_inout, float radius);
 
+/* ---- plate tectonics: Tectonics + Plate (src/filter/tectonics/Tectonics.cpp, Plate.cpp), SURVEY.md 8(a-11) ----
+ * State: one RGBA texture (height, age, 0, 0) per plate in the plate's own rotating frame, and a W x W global map
+ * (plate index, height, spreading flag, overlap marker).  The reference builds two plates from the terrain, split at
+ * st.x = 0.5, turning about the x axis at +-0.01 rad/step (Tectonics.cpp:15-58). */
+typedef struct dmg_tectonics dmg_tectonics;
+/* Tectonics::Tectonics (:15-154): terrain = W*H heights (Texture::downloadDataRAW of Project::get_terrain) */
+int dmg_tectonics_create(dmg_ctx *ctx, const dmg_grid *grid, const float *terrain, dmg_tectonics **out);
+void dmg_tectonics_destroy(dmg_tectonics *t);
+/* Plate::updateRotationBy (Plate.cpp:46-48): angularVelocity += theta * axis */
+int dmg_tectonics_update_rotation(dmg_tectonics *t, int plate, float theta, const float axis[3]);
+/* Tectonics::run (:156-275), n_steps iterations (reference: 70) = { Plate::rotate ; fold ; oceanSpreading ;
+ * back-to-plates }, and the render pass (:186-210) after the last one.  Asynchronous on the context's stream. */
+int dmg_tectonics_step(dmg_tectonics *t, int n_steps);
+/* the passes of one iteration, for callers that interleave their own work (and for the parity tests):
+ *   fold    Plate::rotate (Plate.cpp:26-28) for every plate, then Tectonics::fold (:278-293)
+ *   spread  Tectonics::oceanSpreading (:295-397)
+ *   render  :186-210 -- what collision() (:399-618) leaves for it is plateIndices.x (:590)
+ *   unfold  back to plates (:216-268), including the c <-> plate Texture::swap that moves plate storage between
+ *           W x H and W x W (period 3) */
+int dmg_tectonics_fold(dmg_tectonics *t);
+int dmg_tectonics_spread(dmg_tectonics *t);
+int dmg_tectonics_render(dmg_tectonics *t);
+int dmg_tectonics_unfold(dmg_tectonics *t);
+/* results: terrain (W*H floats, what the render pass wrote into Project::get_terrain), the global map (W*W RGBA),
+ * plate textures (w*h RGBA with the size dmg_tectonics_plate_size reports).  These synchronise the stream. */
+int dmg_tectonics_get_terrain(dmg_tectonics *t, float *terrain);
+int dmg_tectonics_get_map(dmg_tectonics *t, float *rgba);
+int dmg_tectonics_plate_count(const dmg_tectonics *t);
+int dmg_tectonics_plate_size(const dmg_tectonics *t, int plate, int *w, int *h);
+int dmg_tectonics_get_plate(dmg_tectonics *t, int plate, float *rgba);
+
 #ifdef __cplusplus
 }
 #endif

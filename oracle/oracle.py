@@ -255,7 +255,7 @@ def glm_rotate(m, angle, axis):
     changed since GLM 0.9.x).  m: 4x4 float32 indexed m[col][row]."""
     f = np.float32
     a = f(angle)
-    c, s = f(np.cos(a)), f(np.sin(a))
+    c, s = f(_libm().cosf(float(a))), f(_libm().sinf(float(a)))       # std::cos(float) = libm cosf, not numpy's SIMD cos
     ax = np.asarray(axis, f)
     ax = ax * (f(1) / f(np.sqrt(f(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]))))   # glm::normalize: v * inversesqrt(dot)
     temp = (f(1) - c) * ax
@@ -269,6 +269,20 @@ def glm_rotate(m, angle, axis):
         out[k] = m[0] * R[k][0] + m[1] * R[k][1] + m[2] * R[k][2]
     out[3] = m[3]
     return out.astype(f)
+
+
+_libm_handle = None
+
+
+def _libm():
+    global _libm_handle
+    if _libm_handle is None:
+        import ctypes.util
+        m = ctypes.CDLL(ctypes.util.find_library("m") or "libm.so.6")
+        m.cosf.restype = m.sinf.restype = ctypes.c_float
+        m.cosf.argtypes = m.sinf.argtypes = [ctypes.c_float]
+        _libm_handle = m
+    return _libm_handle
 
 
 def tect_set_math(mode):
@@ -363,7 +377,7 @@ def tect_unfold(g, b, pl, idx, shape):
     return out
 
 
-def tectonics(g, img, steps, trace=None):
+def tectonics(g, img, steps, trace=None, extra_rotation=()):
     """Tectonics::Tectonics + Tectonics::run (:15-275) -> (terrain, [plate textures]).
 
     collision() (:399-618) is evaluated only as far as anything reads it afterwards: its result texture c is consumed
@@ -372,6 +386,8 @@ def tectonics(g, img, steps, trace=None):
     (c, plate 0, plate 1): W x W, W x H, W x H with period 3 -- reproduced through `c_shape`."""
     L = _tect_bind()
     plates = tect_init_plates(g, img)
+    for k, theta, axis in extra_rotation:                                     # Plate::updateRotationBy
+        plates[k].av = (plates[k].av + np.float32(theta) * np.asarray(axis, np.float32)).astype(np.float32)
     S = g.W
     c_shape = (S, S)
     terrain = None
