@@ -195,7 +195,8 @@ def main():
         traffic = None                     # measured separately with rocprofv3 --pmc (profiles/README.md)
         try:
             t = json.load(open(ROOT / "profiles" / "pmc_traffic.json")).get(kname)
-            if t and world == 1 and (t["W"], t["H"]) == (W, H) and sweeps_per_launch in (1.0, 8.0):
+            if t and world == 1 and (t["W"], t["H"]) == (W, H) and sweeps_per_launch in (1.0, 8.0) \
+                    and args.terrain == "survey":
                 traffic = t["hbm_bytes_per_launch"]
         except Exception:
             pass

@@ -34,6 +34,25 @@ FILES = {
     "src/filter/tectonics/Tectonics.cpp": "",
 }
 
+# GradientNoise.cpp:441-455 builds its shader from two host-side values: `code` (one raw string per noise mode, chosen
+# by the switch at :181-437) and `blendmode` (one of the static shaders of filter::blendMode(), Filter.cpp:170-207).
+# One variant per (mode, blend) is lifted, with both values spliced in as text by gradient_noise_prelude().
+NOISE_MODES = ["DEFAULT", "RIDGED", "BILLOWY", "IQNoise", "SWISS", "Jordan", "Plateaus"]
+NOISE_BLENDS = ["replace", "add"]
+for _m in NOISE_MODES:
+    for _b in NOISE_BLENDS:
+        if _b == "replace" or _m == "DEFAULT":
+            FILES["src/filter/GradientNoise.cpp#%s_%s" % (_m, _b)] = ("noise", _m, _b)
+
+
+def gradient_noise_prelude(ref, mode, blend):
+    src = (ref / "src/filter/GradientNoise.cpp").read_text()
+    m = re.search(r"case\s+%s\s*:\s*\{?\s*code\s*=\s*(R\"\(.*?\)\")\s*;" % mode, src, re.S)
+    code = m.group(1)
+    fsrc = (ref / "src/filter/Filter.cpp").read_text()
+    bl = {name: expr for _, name, expr in extract(fsrc)}[blend]
+    return "std::string code = %s; Shader* blendmode = %s;" % (code, bl)
+
 
 def scan(src):
     """Yield (kind, start, end) for comments/strings so callers can skip them."""
@@ -120,6 +139,8 @@ def main():
         p = ref / rel
         if not p.exists():
             continue
+        if isinstance(prelude, tuple):
+            prelude = gradient_noise_prelude(ref, prelude[1], prelude[2])
         src = p.read_text()
         items = extract(src)
         tag = re.sub(r"\W", "_", p.name + ("_" + variant if variant else ""))

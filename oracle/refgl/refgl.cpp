@@ -26,6 +26,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <random>
 #include <string>
 #include <vector>
 #include <chrono>
@@ -297,6 +298,23 @@ int refgl_uniform2f(int prog, const char *name, float a, float b)
     if (id < 0) return -1;
     p_glUniform2f(id, a, b);
     return 0;
+}
+
+int refgl_uniform1i(int prog, const char *name, int v)
+{
+    p_glUseProgram(progs[prog].id);
+    GLint id = p_glGetUniformLocation(progs[prog].id, name);
+    if (id < 0) return -1;
+    p_glUniform1i(id, v);
+    return 0;
+}
+
+// GradientNoise.cpp:489-491, the reference's own statements run against this image's libstdc++
+void refgl_noise_seed_offset(int seed, float *out3)
+{
+    std::mt19937 engine{(unsigned)seed};
+    std::uniform_real_distribution<float> dis(0.0, 10000.0);
+    out3[0] = dis(engine); out3[1] = dis(engine); out3[2] = dis(engine);
 }
 
 int refgl_uniform3f(int prog, const char *name, float a, float b, float c)

@@ -57,6 +57,8 @@ class RefGL:
         L.refgl_tex_download.argtypes = [ctypes.c_int, ctypes.c_void_p]
         L.refgl_program.argtypes = [ctypes.c_char_p]
         L.refgl_program_source.argtypes = [ctypes.c_char_p]
+        L.refgl_uniform1i.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_int]
+        L.refgl_noise_seed_offset.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
         L.refgl_uniform1f.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_float]
         L.refgl_uniform2f.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_float, ctypes.c_float]
         L.refgl_uniform3f.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_float, ctypes.c_float, ctypes.c_float]
@@ -135,6 +137,9 @@ class RefGL:
 
     def uniform1f(self, prog, name, v):
         return self.L.refgl_uniform1f(prog, name.encode(), float(v))
+
+    def uniform1i(self, prog, name, v):
+        return self.L.refgl_uniform1i(prog, name.encode(), int(v))
 
     def uniform2f(self, prog, name, a, b):
         return self.L.refgl_uniform2f(prog, name.encode(), float(a), float(b))
@@ -528,3 +533,36 @@ def tectonics(img, steps, coords=FULL_GLOBE, circ=42000.0, trace=None):
         trace["sizes"] = [g._shape[pl.tex] for pl in plates] + [g._shape[x] for x in (a, b, c)]
     g.delete(t_img, a, b, c, *[pl.tex for pl in plates])
     return out, pts
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# GradientNoise (src/filter/GradientNoise.cpp)
+# ---------------------------------------------------------------------------------------------------------------
+NOISE_DEFAULTS = dict(scale=1.0, lacunarity=2.0, persistence=0.5, min=-10.0, max=10.0, octaves=8, seed=0, warp=0.0)  # .h:39
+
+
+def noise_seed_offset(seed):
+    """GradientNoise.cpp:489-491: mt19937{seed} + uniform_real_distribution<float>(0, 10000), three draws"""
+    out = (ctypes.c_float * 3)()
+    RefGL.get().L.refgl_noise_seed_offset(int(seed), out)
+    return np.array(out[:], np.float32)
+
+
+def gradient_noise(img, mode="DEFAULT", blend="replace", sel=None, coords=FULL_GLOBE, circ=42000.0, **params):
+    """GradientNoiseFilter::step (GradientNoise.cpp:61-500): one pass; returns the new terrain"""
+    g = RefGL.get()
+    g.set_canvas(coords, circ)
+    prm = dict(NOISE_DEFAULTS); prm.update(params)
+    H, W = img.shape
+    sel = np.ones_like(img) if sel is None else sel
+    t_img, t_sel, t_out = g.tex(W, H, 1, False, img), g.tex(W, H, 1, False, sel), g.tex(W, H, 1, False)
+    p = g.program("GradientNoise.cpp:440#%s_%s" % (mode, blend))
+    g.uniform1f(p, "scale", prm["scale"]); g.uniform1i(p, "octaves", prm["octaves"])           # :462-466
+    g.uniform1f(p, "lacunarity", prm["lacunarity"]); g.uniform1f(p, "persistence", prm["persistence"])
+    g.uniform1f(p, "warp_factor", prm["warp"])
+    g.uniform1f(p, "lower_limit", prm["min"]); g.uniform1f(p, "higher_limit", prm["max"])
+    g.uniform3f(p, "seed_offset", *noise_seed_offset(prm["seed"]))
+    g.apply(p, t_out, {"img": t_img, "sel": t_sel})
+    out = g.download(t_out)
+    g.delete(t_img, t_sel, t_out)
+    return out
