@@ -39,6 +39,32 @@ class OceanParams(ctypes.Structure):
                 ("wind", ctypes.c_float), ("quirks", ctypes.c_int), ("jacobi_kernel", ctypes.c_int)]
 
 
+class NoiseParams(ctypes.Structure):
+    _fields_ = [("scale", ctypes.c_float), ("lacunarity", ctypes.c_float), ("persistence", ctypes.c_float),
+                ("min", ctypes.c_float), ("max", ctypes.c_float), ("octaves", ctypes.c_int), ("seed", ctypes.c_int),
+                ("warp", ctypes.c_float), ("mode", ctypes.c_int), ("blend", ctypes.c_int)]
+
+
+NOISE_MODES = ["DEFAULT", "RIDGED", "BILLOWY", "IQNoise", "SWISS", "Jordan", "Plateaus"]
+BLEND_MODES = ["replace", "add", "subtract", "multiply", "divide", "max", "min"]
+
+
+def noise_params(mode="DEFAULT", blend="replace", **kw):
+    """GradientNoiseMenu defaults (GradientNoise.h:39) with overrides by field name"""
+    p = NoiseParams()
+    lib().dmg_noise_params_default(ctypes.byref(p))
+    p.mode, p.blend = NOISE_MODES.index(mode), BLEND_MODES.index(blend)
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def noise_seed_offset(seed):
+    out = (ctypes.c_float * 3)()
+    check(lib().dmg_noise_seed_offset(int(seed), out))
+    return np.array(out[:], np.float32)
+
+
 def make_grid(W, H, coords=FULL_GLOBE, circumference=42000.0):
     g = Grid()
     g.W, g.H = int(W), int(H)
@@ -105,6 +131,10 @@ def lib():
         "dmg_thermal_erosion": (c_int, [vp, PG, vp]),
         "dmg_morphological": (c_int, [vp, PG, vp, c_float, c_int]),
         "dmg_morphological_gradient": (c_int, [vp, PG, vp, c_float]),
+        "dmg_noise_params_default": (None, [ctypes.POINTER(NoiseParams)]),
+        "dmg_noise_seed_offset": (c_int, [c_int, ctypes.POINTER(c_float)]),
+        "dmg_gradient_noise": (c_int, [vp, PG, vp, vp, ctypes.POINTER(NoiseParams)]),
+        "dmg_ocean_generate_terrain": (c_int, [vp, ctypes.POINTER(NoiseParams)]),
         "dmg_tectonics_create": (c_int, [vp, PG, vp, ctypes.POINTER(vp)]),
         "dmg_tectonics_destroy": (None, [vp]),
         "dmg_tectonics_update_rotation": (c_int, [vp, c_int, c_float, ctypes.POINTER(c_float)]),
@@ -219,6 +249,13 @@ def _ctx_erosion_run(self, grid, h, N=50, iters=150, exponent=0.5, slope_exponen
     return h
 
 
+def _ctx_gradient_noise(self, grid, field, params, sel=None):
+    f = _f32(field).copy()
+    sel = None if sel is None else _f32(sel)
+    check(lib().dmg_gradient_noise(self.h, ctypes.byref(grid), _p(f), _p(sel), ctypes.byref(params)))
+    return f
+
+
 def _ctx_thermal_erosion(self, grid, h):
     h = _f32(h).copy()
     check(lib().dmg_thermal_erosion(self.h, ctypes.byref(grid), _p(h)))
@@ -238,6 +275,7 @@ def _ctx_morphological_gradient(self, grid, field, radius):
 
 
 Context.thermal_erosion = _ctx_thermal_erosion
+Context.gradient_noise = _ctx_gradient_noise
 Context.morphological = _ctx_morphological
 Context.morphological_gradient = _ctx_morphological_gradient
 Context.flow_accumulate = _ctx_flow_accumulate
@@ -273,6 +311,10 @@ class Ocean:
             self.close()
         except Exception:
             pass
+
+    def generate_terrain(self, params):
+        """dmg_ocean_generate_terrain: gradient-noise terrain made on the device, band-local rows only"""
+        check(lib().dmg_ocean_generate_terrain(self.h, ctypes.byref(params)))
 
     def set_terrain(self, img):
         img = _f32(img)

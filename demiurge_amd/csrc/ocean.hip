@@ -303,7 +303,13 @@ int dmg_ocean_set_terrain(dmg_ocean *o, const float *img)
     DMG_CHECK_ARG(o != nullptr && img != nullptr);
     int rc = ocean_upload_rows(o, o->img, img, 1);
     if (rc) return rc;
-    rc = ocean_build_codes(o);
+    return ocean_terrain_changed(o);
+}
+
+// everything derived from o->img: neighbour codes, the blocked kernel's row classes, and p := +0 on land
+extern "C++" int ocean_terrain_changed(dmg_ocean *o)
+{
+    int rc = ocean_build_codes(o);
     if (rc) return rc;
     rc = ocean_build_codes8(o);
     if (rc) return rc;

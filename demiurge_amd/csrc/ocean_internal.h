@@ -52,6 +52,7 @@ int ocean_zero_land(dmg_ocean *o);            // p := +0 on land in BOTH ping-po
 int ocean_launch_tb(dmg_ocean *o, int lo, int hi, int n);   // ocean_jacobi_tb.hip
 bool ocean_tb_supported(const dmg_ocean *o);
 int ocean_build_rowclass(dmg_ocean *o);
+int ocean_terrain_changed(dmg_ocean *o);        // rebuilds what is derived from o->img (ocean.hip)
 int ocean_upload_rows(dmg_ocean *o, float *dst, const float *src_full, int comps);
 int ocean_download_rows(dmg_ocean *o, float *dst_full, const float *src, int comps);
 

@@ -196,6 +196,28 @@ int dmg_morphological(dmg_ctx *ctx, const dmg_grid *grid, float *field_inout, fl
 /* MorphologicalGradient (:87-131): dilate((radius+1)/2) - erode(radius/2) */
 int dmg_morphological_gradient(dmg_ctx *ctx, const dmg_grid *grid, float *field_inout, float radius);
 
+/* ---- gradient-noise terrain generator: GradientNoiseFilter (src/filter/GradientNoise.cpp), SURVEY.md 8(f-3) ---- */
+enum { DMG_NOISE_DEFAULT = 0, DMG_NOISE_RIDGED, DMG_NOISE_BILLOWY, DMG_NOISE_IQ, DMG_NOISE_SWISS, DMG_NOISE_JORDAN,
+       DMG_NOISE_PLATEAUS };                       /* enum noise_mode, GradientNoise.h:10 */
+enum { DMG_BLEND_REPLACE = 0, DMG_BLEND_ADD, DMG_BLEND_SUBTRACT, DMG_BLEND_MULTIPLY, DMG_BLEND_DIVIDE, DMG_BLEND_MAX,
+       DMG_BLEND_MIN };                            /* filter::blendMode(), src/filter/Filter.cpp:170-236 */
+typedef struct dmg_noise_params {                  /* struct NoiseParams, GradientNoise.h:15-25, + the blend mode */
+    float scale, lacunarity, persistence, min, max;
+    int octaves, seed;
+    float warp;
+    int mode, blend;
+} dmg_noise_params;
+/* GradientNoiseMenu::params (GradientNoise.h:39): {1.0, 2, 0.5, -10, 10, 8, 0, 0.0, DEFAULT}, blend Replace */
+void dmg_noise_params_default(dmg_noise_params *p);
+/* GradientNoise.cpp:489-491: std::mt19937{seed} + uniform_real_distribution<float>(0, 10000), three draws */
+int dmg_noise_seed_offset(int seed, float out3[3]);
+/* GradientNoiseFilter::step (:61-500): field := blend_mode(field, noise(st), sel); sel NULL = all ones */
+int dmg_gradient_noise(dmg_ctx *ctx, const dmg_grid *grid, float *field_inout, const float *sel_or_null,
+                       const dmg_noise_params *params);
+/* the same generator writing straight into an ocean handle's terrain on the device (each band generates its own
+ * rows; nothing crosses PCIe), followed by what dmg_ocean_set_terrain does after its upload.  blend must be Replace. */
+int dmg_ocean_generate_terrain(dmg_ocean *o, const dmg_noise_params *params);
+
 /* ---- plate tectonics: Tectonics + Plate (src/filter/tectonics/Tectonics.cpp, Plate.cpp), SURVEY.md 8(a-11) ----
  * State: one RGBA texture (height, age, 0, 0) per plate in the plate's own rotating frame, and a W x W global map
  * (plate index, height, spreading flag, overlap marker).  The reference builds two plates from the terrain, split at

@@ -58,9 +58,17 @@ static inline v3 sub3(v3 a, v3 b) { return V3(a.x - b.x, a.y - b.y, a.z - b.z); 
 static inline v3 adds3(v3 a, float s) { return V3(a.x + s, a.y + s, a.z + s); }
 static inline v3 mul3(v3 a, float s) { return V3(a.x * s, a.y * s, a.z * s); }
 static inline v3 div3(v3 a, float s) { return V3(a.x / s, a.y / s, a.z / s); }
-static inline float dot3(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+/* Mesa lowers dot() from the last component down: (a.z*b.z + a.y*b.y) + a.x*b.x (pinned against probe shaders) */
+static inline float dot3(v3 a, v3 b) { return (a.z * b.z + a.y * b.y) + a.x * b.x; }
+/* dot(a, vec3(c)): the products share a factor and NIR's algebraic pass pulls it out: ((a.z + a.y) + a.x) * c */
+static inline float dot3c(v3 a, float c) { return ((a.z + a.y) + a.x) * c; }
+/* 1 + dot(a,a) where the dot has no other use: NIR reassociates the constant to the innermost add (probe-pinned) */
+static inline float one_plus_dot(v3 a) { return ((1.0f + a.z * a.z) + a.y * a.y) + a.x * a.x; }
 static inline float len3(v3 a) { return sqrtf(dot3(a, a)); }
 static inline v3 cross3(v3 a, v3 b) { return V3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y); }
+/* p + cross(p, d): NIR reassociates the single-use difference into (p + a*b) - c*d per component (probe-pinned) */
+static inline v3 add_cross(v3 p, v3 d)
+{ return V3((p.x + p.y * d.z) - p.z * d.y, (p.y + p.z * d.x) - p.x * d.z, (p.z + p.x * d.y) - p.y * d.x); }
 static inline float mod289f(float x) { return x - floorf(x * (1.0f / 289.0f)) * 289.0f; }
 static inline float permute(float x) { return mod289f(((x * 34.0f) + 1.0f) * x); }
 static inline float stepf(float edge, float x) { return x < edge ? 0.0f : 1.0f; }
@@ -70,9 +78,9 @@ static inline float signf_(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f
 static float snoise(v3 v, v3 *gradient)
 {
     const float Cx = 1.0f / 6.0f, Cy = 1.0f / 3.0f;
-    float s = dot3(v, V3(Cy, Cy, Cy));
+    float s = dot3c(v, Cy);
     v3 i = V3(floorf(v.x + s), floorf(v.y + s), floorf(v.z + s));
-    float t = dot3(i, V3(Cx, Cx, Cx));
+    float t = dot3c(i, Cx);
     v3 x0 = adds3(sub3(v, i), t);
     v3 g = V3(stepf(x0.y, x0.x), stepf(x0.z, x0.y), stepf(x0.x, x0.z));
     v3 l = V3(1.0f - g.x, 1.0f - g.y, 1.0f - g.z);
@@ -125,7 +133,7 @@ static float snoise(v3 v, v3 *gradient)
     v3 gp = add3(add3(add3(mul3(P[0], m4[0]), mul3(P[1], m4[1])), mul3(P[2], m4[2])), mul3(P[3], m4[3]));
     gr = add3(gr, gp);
     *gradient = mul3(gr, 42.0f);
-    return 42.0f * (m4[0] * pdotx[0] + m4[1] * pdotx[1] + m4[2] * pdotx[2] + m4[3] * pdotx[3]);
+    return 42.0f * (((m4[3] * pdotx[3] + m4[2] * pdotx[2]) + m4[1] * pdotx[1]) + m4[0] * pdotx[0]);
 }
 
 /* rotation_matrix(theta, u) * p (src/Shader.h:35-41) */
@@ -158,7 +166,7 @@ static inline float smoothstepf(float e0, float e1, float x)
 {
     float t = (x - e0) / (e1 - e0);
     t = fminf(fmaxf(t, 0.0f), 1.0f);
-    return t * t * (3.0f - 2.0f * t);
+    return t * (t * (3.0f - 2.0f * t));      /* Mesa's association (pinned against a probe shader) */
 }
 
 typedef struct {
@@ -222,7 +230,7 @@ static float noise_value(const orc_grid *g, const noise_prm *q, float sx, float 
         p = domain_warp(p, p, q->warp);
         v3 dsum = V3(0, 0, 0);
         for (int i = 0; i < q->octaves; i++) {
-            v3 u = add3(p, cross3(p, dsum));
+            v3 u = add_cross(p, dsum);
             u = div3(u, dot3(u, u));
             float theta = 2.0f * 0.1f * len3(dsum);
             v3 p_ = rotate(theta, u, p);
@@ -248,7 +256,7 @@ static float noise_value(const orc_grid *g, const noise_prm *q, float sx, float 
         v3 dsum_damp = mul3(tangential(tmp, p), 1.0f);
         float damped = cur * q->persistence;
         for (int i = 1; i < q->octaves; i++) {
-            v3 u = add3(p, cross3(p, dsum_warp));
+            v3 u = add_cross(p, dsum_warp);
             u = div3(u, dot3(u, u));
             float theta = 2.0f * 0.1f * len3(dsum_warp);
             v3 p_ = rotate(theta, u, p);
@@ -260,7 +268,7 @@ static float noise_value(const orc_grid *g, const noise_prm *q, float sx, float 
             freq *= q->lacunarity;
             total += cur;
             cur *= q->persistence;
-            damped = cur * (1.0f - 1.0f / (1.0f + dot3(dsum_damp, dsum_damp)));
+            damped = cur * (1.0f - 1.0f / one_plus_dot(dsum_damp));
         }
         fc /= total;
         return fc * (q->hi - q->lo) + q->lo;
@@ -273,12 +281,12 @@ static float noise_value(const orc_grid *g, const noise_prm *q, float sx, float 
             float n = snoise(add3(mul3(p, freq), off), &tmp);
             v3 radial = radial_of(tmp, p);
             v3 dsum = mul3(mul3(mul3(sub3(tmp, radial), 1.0f - fabsf(n)), n), 2.0f);
-            v3 u = add3(p, cross3(p, dsum));
+            v3 u = add_cross(p, dsum);
             u = div3(u, dot3(u, u));
             float theta = 2.0f * 0.1f * len3(dsum);
             v3 p_ = rotate(theta, u, p);
             n = snoise(add3(mul3(p_, freq), off), &tmp);      /* r_offset (:419-420) is computed and never used */
-            fc += n * cur / (1.0f + fabsf(fc) * fabsf(fc) * 5.0f);
+            fc += n * cur / (1.0f + fabsf(fc) * (fabsf(fc) * 5.0f));   /* Mesa moves the constant inwards (probe-pinned) */
             freq *= q->lacunarity;
             total += cur;
             cur *= q->persistence;

@@ -413,3 +413,35 @@ def tectonics(g, img, steps, trace=None, extra_rotation=()):
             new_shape, c_shape = c_shape, pl.tex.shape[:2]                    # c->swap(plate texture)
             pl.tex = tect_unfold(g, b, pl, idx, new_shape)
     return terrain, [pl.tex for pl in plates]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# GradientNoise (src/filter/GradientNoise.cpp); arithmetic in noise_oracle.c
+# ---------------------------------------------------------------------------------------------------------------
+NOISE_MODES = ["DEFAULT", "RIDGED", "BILLOWY", "IQNoise", "SWISS", "Jordan", "Plateaus"]          # GradientNoise.h:10
+BLEND_MODES = ["replace", "add", "subtract", "multiply", "divide", "max", "min"]                  # Filter.cpp:210
+NOISE_DEFAULTS = dict(scale=1.0, lacunarity=2.0, persistence=0.5, min=-10.0, max=10.0, octaves=8, seed=0, warp=0.0)  # .h:39
+
+
+def noise_seed_offset(seed):
+    out = np.zeros(3, np.float32)
+    L = lib()
+    L.orc_noise_seed_offset.argtypes = [ctypes.c_int, ctypes.c_void_p]
+    L.orc_noise_seed_offset(int(seed), _ptr(out))
+    return out
+
+
+def gradient_noise(g, img, mode="DEFAULT", blend="replace", sel=None, **params):
+    """GradientNoiseFilter::step (GradientNoise.cpp:61-500) -> new terrain"""
+    prm = dict(NOISE_DEFAULTS)
+    prm.update(params)
+    img = _f32(img)
+    sel = None if sel is None else _f32(sel)
+    p6 = np.array([prm["scale"], prm["lacunarity"], prm["persistence"], prm["min"], prm["max"], prm["warp"]], np.float32)
+    out = np.empty_like(img)
+    L = lib()
+    L.orc_gradient_noise.argtypes = [ctypes.POINTER(Grid), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                     ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    L.orc_gradient_noise(ctypes.byref(g), _ptr(img), None if sel is None else _ptr(sel), _ptr(p6), int(prm["octaves"]),
+                         int(prm["seed"]), NOISE_MODES.index(mode), BLEND_MODES.index(blend), _ptr(out))
+    return out

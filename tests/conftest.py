@@ -28,8 +28,8 @@ def oracle():
     lib = ROOT / "oracle" / "liboracle.so"
     src = ROOT / "oracle" / "dmg_oracle.c"
     src2 = ROOT / "oracle" / "flow_oracle.cpp"
-    src3 = ROOT / "oracle" / "tect_oracle.c"
-    if not lib.exists() or lib.stat().st_mtime < max(s.stat().st_mtime for s in (src, src2, src3)):
+    srcs = [src, src2, ROOT / "oracle" / "tect_oracle.c", ROOT / "oracle" / "noise_oracle.c"]
+    if not lib.exists() or lib.stat().st_mtime < max(s.stat().st_mtime for s in srcs):
         subprocess.check_call(["make", "-C", str(ROOT / "oracle"), "liboracle.so"])
     import oracle as orc
     orc.set_linear_taps(False)

@@ -97,7 +97,39 @@ def tectonics_goldens():
              terrain=terrain, plate0=plates[0], plate1=plates[1], fold1=tr["fold"], spread1=tr["spread"])
 
 
+NOISE_MODES = ["DEFAULT", "RIDGED", "BILLOWY", "IQNoise", "SWISS", "Jordan", "Plateaus"]
+
+
+def noise_goldens():
+    """SURVEY 8f-3: GradientNoiseFilter::step, all seven modes, plus the seed offsets of the reference's own
+    mt19937 / uniform_real_distribution<float> statements"""
+    W, H = 128, 64
+    rng = np.random.default_rng(1)
+    img = (rng.normal(size=(H, W)) * 3).astype(f32)
+    sel = rng.uniform(0, 1, (H, W)).astype(f32)
+    A = dict(seed=3, warp=0.7)
+    outs = {"out_" + m: refgl.gradient_noise(img, m, "replace", **A) for m in NOISE_MODES}
+    save("noise_128x64_modes", coords=np.array(FULL), circ=f32(CIRC), img=img, seed=np.int32(3), warp=f32(0.7), **outs)
+    B = dict(seed=4, warp=2.0, scale=7.0, lacunarity=2.3, persistence=0.45, octaves=10, min=-2.0, max=6.0)
+    seeds = np.array([0, 1, 3, 4, 42, 12345, 123456, -7, 2 ** 31 - 1], np.int32)
+    save("noise_128x64_variants", coords=np.array(REGION), circ=f32(CIRC), img=img, sel=sel,
+         params_B=np.array([B[k] for k in ("scale", "lacunarity", "persistence", "min", "max", "warp")], f32),
+         octaves_B=np.int32(10), seed_B=np.int32(4),
+         region_DEFAULT_B=refgl.gradient_noise(img, "DEFAULT", "replace", coords=REGION, **B),
+         region_SWISS_B=refgl.gradient_noise(img, "SWISS", "replace", coords=REGION, **B),
+         region_sel_DEFAULT_replace=refgl.gradient_noise(img, "DEFAULT", "replace", sel=sel, coords=REGION, seed=1),
+         region_sel_DEFAULT_add=refgl.gradient_noise(img, "DEFAULT", "add", sel=sel, coords=REGION, seed=1),
+         region_sel_Jordan_replace=refgl.gradient_noise(img, "Jordan", "replace", sel=sel, coords=REGION, seed=123456),
+         seeds=seeds, seed_offsets=np.stack([refgl.noise_seed_offset(int(s)) for s in seeds]))
+    W, H = 100, 50
+    img = np.zeros((H, W), f32)
+    save("noise_100x50_default", coords=np.array(FULL), circ=f32(CIRC), img=img, seed=np.int32(2),
+         out_DEFAULT=refgl.gradient_noise(img, "DEFAULT", "replace", seed=2))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "noise":
+        return noise_goldens()
     if len(sys.argv) > 1 and sys.argv[1] == "tectonics":
         return tectonics_goldens()
     if len(sys.argv) > 1 and sys.argv[1] == "flow":
@@ -107,6 +139,7 @@ def main():
     flow_goldens()
     next_goldens()
     tectonics_goldens()
+    noise_goldens()
     # ---- Jacobi (headline) -------------------------------------------------
     W, H = 256, 128
     img, b = synth.terrain(W, H), synth.divw(W, H)
