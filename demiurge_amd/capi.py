@@ -131,6 +131,8 @@ def lib():
         "dmg_thermal_erosion": (c_int, [vp, PG, vp]),
         "dmg_morphological": (c_int, [vp, PG, vp, c_float, c_int]),
         "dmg_morphological_gradient": (c_int, [vp, PG, vp, c_float]),
+        "dmg_field_write_png": (c_int, [ctypes.c_char_p, c_int, c_int, vp, c_int]),
+        "dmg_ocean_speed_shade": (c_int, [vp, c_float, vp]),
         "dmg_noise_params_default": (None, [ctypes.POINTER(NoiseParams)]),
         "dmg_noise_seed_offset": (c_int, [c_int, ctypes.POINTER(c_float)]),
         "dmg_gradient_noise": (c_int, [vp, PG, vp, vp, ctypes.POINTER(NoiseParams)]),
@@ -249,6 +251,12 @@ def _ctx_erosion_run(self, grid, h, N=50, iters=150, exponent=0.5, slope_exponen
     return h
 
 
+def write_png(path, field, clamp=True):
+    """dmg_field_write_png: Project::file_write's 8-bit grey PNG (host-side; needs no GPU)"""
+    f = _f32(field)
+    check(lib().dmg_field_write_png(str(path).encode(), f.shape[1], f.shape[0], _p(f), 1 if clamp else 0))
+
+
 def _ctx_gradient_noise(self, grid, field, params, sel=None):
     f = _f32(field).copy()
     sel = None if sel is None else _f32(sel)
@@ -311,6 +319,11 @@ class Ocean:
             self.close()
         except Exception:
             pass
+
+    def speed_shade(self, land_value=0.5):
+        out = np.zeros((self.grid.H, self.grid.W), np.float32)
+        check(lib().dmg_ocean_speed_shade(self.h, land_value, _p(out)))
+        return out
 
     def generate_terrain(self, params):
         """dmg_ocean_generate_terrain: gradient-noise terrain made on the device, band-local rows only"""

@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <memory>
 #include "HipOceanCurrents.h"
+#include "HipTectonics.h"
 
 static bool read_f32(const char *path, std::vector<float> &v)
 {
@@ -22,8 +23,44 @@ static void write_f32(const std::string &path, const std::vector<float> &v)
     fclose(f);
 }
 
+// host_demo tectonics <W> <H> <terrain.f32> <n_steps> <out_prefix>
+// host_demo noise <W> <H> <mode 0..6> <seed> <out_prefix>
+static int other_tools(int argc, char **argv)
+{
+    std::string tool = argv[1];
+    Project p;
+    p.width = atoi(argv[2]); p.height = atoi(argv[3]);
+    p.terrain.assign((size_t)p.width * p.height, 0.0f);
+    std::unique_ptr<SubFilter> filter;
+    std::string out;
+    const std::string *err = nullptr;
+    if (tool == "tectonics" && argc == 7) {
+        if (!read_f32(argv[4], p.terrain)) { fprintf(stderr, "cannot read %s\n", argv[4]); return 2; }
+        auto f = std::make_unique<HipTectonics>(&p, atoi(argv[5]));
+        err = &f->error(); filter = std::move(f); out = argv[6];
+    } else if (tool == "noise" && argc == 7) {
+        dmg_noise_params prm;
+        dmg_noise_params_default(&prm);
+        prm.mode = atoi(argv[4]); prm.seed = atoi(argv[5]);
+        auto f = std::make_unique<HipGradientNoise>(prm);
+        err = &f->error(); filter = std::move(f); out = argv[6];
+    } else { fprintf(stderr, "usage: host_demo tectonics W H terrain.f32 n_steps out | host_demo noise W H mode seed out\n"); return 2; }
+    int frames = 0;
+    for (;;) {
+        auto [finished, progress] = filter->step(&p);
+        frames++;
+        if (finished) break;
+        std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    }
+    if (!err->empty()) { fprintf(stderr, "filter failed: %s\n", err->c_str()); return 1; }
+    write_f32(out + "_terrain.f32", p.terrain);
+    printf("finished after %d frames\n", frames);
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
+    if (argc >= 2 && (std::string(argv[1]) == "tectonics" || std::string(argv[1]) == "noise")) return other_tools(argc, argv);
     if (argc != 8) { fprintf(stderr, "usage: host_demo W H terrain.f32 n_outer jacobi_iters diffusion_iters out_prefix\n"); return 2; }
     Project p;
     p.width = atoi(argv[1]); p.height = atoi(argv[2]);

@@ -196,6 +196,14 @@ int dmg_morphological(dmg_ctx *ctx, const dmg_grid *grid, float *field_inout, fl
 /* MorphologicalGradient (:87-131): dilate((radius+1)/2) - erode(radius/2) */
 int dmg_morphological_gradient(dmg_ctx *ctx, const dmg_grid *grid, float *field_inout, float radius);
 
+/* ---- field export, SURVEY.md 8(f-4) ---- */
+/* Project::file_write (src/Project.cpp:56-67): 8-bit greyscale PNG, pixel = (unsigned char)(int)(255*field[i]), rows in
+ * memory order.  clamp != 0 limits the field to [0,1] first (the reference lets the byte wrap). */
+int dmg_field_write_png(const char *path, int W, int H, const float *field, int clamp);
+/* the ocean-current display shading (src/appearance/VectorField.cpp:117-118): 1 - 8*|v| on ocean cells, land_value on
+ * land; owned rows written into a FULL-grid array like dmg_ocean_get */
+int dmg_ocean_speed_shade(dmg_ocean *o, float land_value, float *out_full);
+
 /* ---- gradient-noise terrain generator: GradientNoiseFilter (src/filter/GradientNoise.cpp), SURVEY.md 8(f-3) ---- */
 enum { DMG_NOISE_DEFAULT = 0, DMG_NOISE_RIDGED, DMG_NOISE_BILLOWY, DMG_NOISE_IQ, DMG_NOISE_SWISS, DMG_NOISE_JORDAN,
        DMG_NOISE_PLATEAUS };                       /* enum noise_mode, GradientNoise.h:10 */

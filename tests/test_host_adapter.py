@@ -55,3 +55,21 @@ def test_adapter_matches_golden_and_oracle(oracle, tmp_path):
     vo, _, _ = oracle.ocean_step(oracle.grid(W, H), G["img"], np.zeros_like(v), int(G["n_outer"]), int(G["jacobi_iters"]),
                                  int(G["diffusion_iters"]), rows=True)
     assert relerr(v, vo) < 1e-4
+
+
+@pytest.mark.gpu
+def test_tectonics_and_noise_adapters(oracle, tmp_path):
+    """HipTectonics (AsyncSubFilter, one terrain hand-over per step) and HipGradientNoise (one-step SubFilter)"""
+    build()
+    G = load_golden("tectonics_globe_64x32_s70")
+    t = tmp_path / "terrain.f32"
+    G["img"].astype(np.float32).tofile(t)
+    r = subprocess.run([str(HOST / "host_demo"), "tectonics", "64", "32", str(t), "70", str(tmp_path / "tect")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert np.array_equal(np.fromfile(tmp_path / "tect_terrain.f32", np.float32).reshape(32, 64), G["terrain"])
+    r = subprocess.run([str(HOST / "host_demo"), "noise", "128", "64", "4", "3", str(tmp_path / "noise")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    ref = oracle.gradient_noise(oracle.grid(128, 64), np.zeros((64, 128), np.float32), "SWISS", seed=3)
+    assert np.array_equal(np.fromfile(tmp_path / "noise_terrain.f32", np.float32).reshape(64, 128), ref)
