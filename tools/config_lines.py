@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""One line per BASELINE.json config on one MI355X (what a single GPU can show of each): JSON objects on stdout."""
+import json
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch  # noqa: F401  (one HIP runtime per process: torch first)
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+from demiurge_amd import capi, synth  # noqa: E402
+
+
+def emit(**kw):
+    print(json.dumps(kw), flush=True)
+
+
+ctx = capi.Context(0)
+emit(device=ctx.name())
+
+# config 1: 1024x512 Gaussian blur (whole filter, host buffers in and out: PCIe-inclusive)
+W, H = 1024, 512
+g = capi.make_grid(W, H)
+f = synth.terrain(W, H)
+for r in (1.0, 10.0):
+    ctx.blur(g, f, r)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        ctx.blur(g, f, r)
+    emit(config=1, line="blur 1024x512 radius %g, host to host" % r, ms_per_filter=(time.perf_counter() - t0) / 5 * 1e3)
+
+# config 2: 4096x2048 stream-power erosion (1000 iterations in the config; per-round time from a short run)
+W, H = 4096, 2048
+g = capi.make_grid(W, H)
+h = (synth.terrain(W, H) * 100 + synth.lcg_uniform(W * H, 5).reshape(H, W) * 3).astype(np.float32)
+ctx.erosion_run(g, h, 50, 1, 0.5, 1.0, 1.0)
+t0 = time.perf_counter(); ctx.erosion_run(g, h, 50, 2, 0.5, 1.0, 1.0); ta = time.perf_counter() - t0
+t0 = time.perf_counter(); ctx.erosion_run(g, h, 50, 12, 0.5, 1.0, 1.0); tb = time.perf_counter() - t0
+per = (tb - ta) / 10
+emit(config=2, line="stream-power erosion round 4096x2048 (flow accumulation + erosion/uplift pass)", ms_per_round=per * 1e3,
+     projected_s_for_1000_iters=per * 1000)
+
+# configs 3 and 4: ocean outer step (advect + 50 diffusion + divergence + 5000 Jacobi + subDiv)
+for cfg, (W, H) in ((3, (8192, 4096)), (4, (16384, 8192))):
+    o = capi.Ocean(ctx, capi.make_grid(W, H))
+    img = synth.terrain(W, H)
+    o.set_terrain(img)
+    v = synth.velocity(W, H); v[img > 0] = 0
+    o.set_velocity(v); del v, img
+    o.step(1); ctx.sync()
+    t0 = time.perf_counter(); o.step(2); ctx.sync(); dt = (time.perf_counter() - t0) / 2
+    emit(config=cfg, line="ocean outer step %dx%d on ONE GPU (the config's 8-GPU band split runs at round end)" % (W, H) if cfg == 4
+         else "ocean outer step %dx%d" % (W, H), ms_per_outer_step=dt * 1e3, jacobi_mcell_steps_per_s_equiv=W * H * 5000 / dt / 1e6)
+    o.close()
+
+# config 5 pieces at 16384x8192: tectonics step, erosion round, climate step
+W, H = 16384, 8192
+g = capi.make_grid(W, H)
+h = (synth.terrain(W, H) * 100 + synth.lcg_uniform(W * H, 5).reshape(H, W) * 3).astype(np.float32)
+t = capi.Tectonics(ctx, g, h)
+t.step(3); ctx.sync()
+t0 = time.perf_counter(); t.step(10); ctx.sync()
+emit(config=5, line="tectonics step 16384x8192", ms_per_step=(time.perf_counter() - t0) * 100)
+t.close()
+t0 = time.perf_counter(); ctx.erosion_run(g, h, 50, 2, 0.5, 1.0, 1.0); dt = time.perf_counter() - t0
+emit(config=5, line="erosion round 16384x8192 (incl. PCIe of the heights)", ms_per_round=dt / 2 * 1e3)
+T0 = np.full((H, W), 50, np.float32)
+ctx.temperature_steps(g, T0, h, 0, 1)
+t0 = time.perf_counter(); ctx.temperature_steps(g, T0, h, 0, 1); ta = time.perf_counter() - t0
+t0 = time.perf_counter(); ctx.temperature_steps(g, T0, h, 0, 21); tb = time.perf_counter() - t0
+emit(config=5, line="climate step 16384x8192", ms_per_step=(tb - ta) / 20 * 1e3)
