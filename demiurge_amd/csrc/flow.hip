@@ -516,10 +516,14 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
         rend[e.lake] = i + 1;
     }
     for (int i = nuniq - 1; i >= 0; i--) cursor[ent[i].lake] = i;      // first entry of each lake
-    auto worse = [&](int a, int b) {                                   // priority_queue keeps the LOWEST (h, from, s) on top
-        return std::tie(ent[a].h, ent[a].from, ent[a].s) > std::tie(ent[b].h, ent[b].from, ent[b].s);
+    // the heap carries its keys (16 B) instead of indices into `ent`: a sift touches only the heap's own cache lines
+    struct Cand { float h; int from, s, idx; };
+    auto worse = [](const Cand &a, const Cand &b) {                    // priority_queue keeps the LOWEST (h, from, s) on top
+        return std::tie(a.h, a.from, a.s) > std::tie(b.h, b.from, b.s);
     };
-    std::priority_queue<int, std::vector<int>, decltype(worse)> candidates(worse);
+    std::vector<Cand> heap_store;
+    heap_store.reserve((size_t)nlakes + 16);
+    std::priority_queue<Cand, std::vector<Cand>, decltype(worse)> candidates(worse, std::move(heap_store));
     std::vector<char> placed(nlakes, 0);
     for (int m : mouths) placed[m] = 1;
     auto push_next = [&](int lake) {
@@ -528,21 +532,21 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
         while (c < e) {
             int i = c++;
             if (placed[ent[i].from]) continue;
-            candidates.push(i);
+            candidates.push(Cand{ ent[i].h, ent[i].from, ent[i].s, i });
             break;
         }
     };
     std::vector<int> assigned;                                         // connection events in order: connections[s] = entry
     for (int lake : mouths) push_next(lake);
     while (!candidates.empty()) {
-        int c = candidates.top();
+        const Cand top = candidates.top();
         candidates.pop();
-        const Entry &p = ent[c];
-        if (placed[p.from]) { push_next(p.lake); continue; }
-        placed[p.from] = 1;
+        const int c = top.idx;
+        if (placed[top.from]) { push_next(ent[c].lake); continue; }
+        placed[top.from] = 1;
         assigned.push_back(c);                                         // a later pass at the same cell replaces this one (:588)
-        push_next(p.from);
-        push_next(p.lake);
+        push_next(top.from);
+        push_next(ent[c].lake);
     }
     // resolve the overwrites: per tolocation cell the LAST assigned entry survives (open-addressing table on s)
     std::vector<int> live;
@@ -572,6 +576,9 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
     std::vector<float> off_level;                             // water level of the lake: highest pass on the way down (:683-690)
     struct Work { int lake, off; float level; };
     std::vector<Work> work;
+    off_idx.reserve(nlakes); off_val.reserve(nlakes); off_level.reserve(nlakes);
+    conn_idx.reserve(live.size()); conn_val.reserve(live.size());
+    work.reserve(mouths.size() + 1024);
     for (int m : mouths) work.push_back({ m, 0, 0.0f });
     while (!work.empty()) {
         Work w = work.back(); work.pop_back();
