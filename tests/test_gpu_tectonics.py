@@ -103,3 +103,16 @@ def test_tectonics_large_properties(dev):
     assert np.array_equal(ter, m[1::2, :, 0])                     # render = NEAREST resample of the W x W map
     sizes2, m2, ter2 = run()
     assert np.array_equal(m, m2) and np.array_equal(ter, ter2)
+
+
+def test_tectonics_argument_errors(dev):
+    capi, ctx = dev
+    with pytest.raises(capi.DmgError):                                    # plates are W x H inside W x W maps: H <= W
+        capi.Tectonics(ctx, capi.make_grid(32, 64), np.zeros((64, 32), np.float32))
+    t = capi.Tectonics(ctx, capi.make_grid(64, 32), np.zeros((32, 64), np.float32))
+    with pytest.raises(capi.DmgError):
+        t.update_rotation(2, 0.1, (1, 0, 0))                              # the reference has two plates
+    t.update_rotation(0, 0.01, (1, 0, 0))                                 # plate 0: -0.01 + 0.01 = no motion at all
+    with pytest.raises(capi.DmgError):
+        t.step(1)                                                         # glm::normalize(0) is NaN in the reference
+    t.close()

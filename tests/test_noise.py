@@ -144,3 +144,25 @@ def test_gpu_ocean_generate_terrain(dev, oracle):
     d = capi.Ocean(ctx, grid)
     d.set_terrain(terrain); d.set_divw(divw); d.jacobi_sweeps(8)
     assert np.array_equal(full, d.get(("pressure",))["pressure"])
+
+
+@pytest.mark.gpu
+def test_gpu_noise_argument_errors(dev):
+    """error behaviour of the boundary: bad enums / ranges are DMG_EINVAL with a message, nothing is written"""
+    capi, ctx = dev
+    grid = capi.make_grid(64, 32)
+    f = np.zeros((32, 64), np.float32)
+    for bad in (dict(mode=7), dict(mode=-1), dict(blend=9), dict(octaves=65), dict(octaves=-1)):
+        p = capi.noise_params()
+        for k, v in bad.items():
+            setattr(p, k, v)
+        with pytest.raises(capi.DmgError) as e:
+            ctx.gradient_noise(grid, f, p)
+        assert e.value.code == capi.EINVAL and "invalid argument" in str(e.value)
+    oc = capi.Ocean(ctx, grid)
+    with pytest.raises(capi.DmgError):
+        oc.generate_terrain(capi.noise_params("DEFAULT", "add"))          # nothing to blend with
+    oc.close()
+    # octaves = 0 divides 0 by 0 in the reference's shader (fc /= total_amplitude): NaN there, NaN here
+    out = ctx.gradient_noise(grid, f, capi.noise_params(octaves=0))
+    assert np.isnan(out).all()
