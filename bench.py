@@ -213,7 +213,10 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": kname, "launch_us": launch_s * 1e6, "sweeps_per_launch": sweeps_per_launch,
-                         "algorithmic_bytes_per_launch": algo_bytes},
+                         "algorithmic_bytes_per_launch": algo_bytes,
+                         "note": ("8 sweeps per launch on chip: real HBM traffic (`traffic`) is ~1/10 of the algorithmic "
+                                  "bytes, so frac > 1; the sweep phase is VALU-bound (DESIGN.md 4.1)") if sweeps_per_launch > 1
+                                 else "one sweep per launch: HBM-bound"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
