@@ -13,7 +13,7 @@
 //     east/west : adjacent lanes of the same wave -> DPP wave_shr:1 / wave_shl:1 (no LDS)
 //     north/south between the row blocks of adjacent waves -> 2 rows per wave through LDS (double-buffered by
 //     sweep parity, one s_barrier per sweep)
-// Per-row coefficients (6 floats) live in 6 VGPRs of the owning wave, lane r = row r, read with v_readlane.
+// Per-row coefficients (6 floats: the three divisors and their reciprocals) sit in an LDS table filled once per tile.
 // Canvas topology is applied when the extended tile is loaded: columns wrap (full longitude), rows beyond a pole
 // are the same rows read mirrored and shifted by W/2 (offset(), src/Shader.h:86-95); rows beyond a non-pole edge
 // are plain mirrors (CLAMP_TO_EDGE on a symmetric stencil).  Mirrored rows swap the N/S bits of their code.
