@@ -516,6 +516,7 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
         rend[e.lake] = i + 1;
     }
     for (int i = nuniq - 1; i >= 0; i--) cursor[ent[i].lake] = i;      // first entry of each lake
+    lap("host: entry table");
     // the heap carries its keys (16 B) instead of indices into `ent`: a sift touches only the heap's own cache lines
     struct Cand { float h; int from, s, idx; };
     auto worse = [](const Cand &a, const Cand &b) {                    // priority_queue keeps the LOWEST (h, from, s) on top
@@ -548,6 +549,7 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
         push_next(top.from);
         push_next(ent[c].lake);
     }
+    lap("host: prim growth");
     // resolve the overwrites: per tolocation cell the LAST assigned entry survives (open-addressing table on s)
     std::vector<int> live;
     {
@@ -561,7 +563,7 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
         }
         for (int c : slot) if (c >= 0) live.push_back(c);
     }
-    lap("host: solve connections");
+    lap("host: overwrite resolution");
 
     // depth offset and water level of every lake that calculateflow's recursion reaches: river mouths at 0, a
     // connected lake one below the cell it drains into (CSR adjacency lake -> entries draining into it)
