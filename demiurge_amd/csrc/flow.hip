@@ -278,18 +278,23 @@ __global__ void k_flow_gdepth(const int *__restrict__ label, const int *__restri
     if (g > 0) atomicMax(maxd, g);
 }
 
-__global__ void k_flow_hist(const int *__restrict__ gdepth, int *__restrict__ hist, size_t n)
+__global__ void k_flow_iota(unsigned *__restrict__ v, size_t n)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && gdepth[i] >= 0) atomicAdd(&hist[gdepth[i]], 1);
+    if (i < n) v[i] = (unsigned)i;
 }
 
-__global__ void k_flow_scatter(const int *__restrict__ gdepth, int *__restrict__ cursor, int *__restrict__ order, size_t n, int max_levels)
+// start[l] = first position in the depth-sorted order whose depth is >= l (l = 0..levels); unreached cells (-1) sort last
+__global__ void k_flow_level_starts(const unsigned *__restrict__ sorted_depth, size_t n, int *__restrict__ start, int levels)
 {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    int g = gdepth[i];
-    if (g >= 0 && g < max_levels) order[atomicAdd(&cursor[g], 1)] = (int)i;
+    int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l > levels) return;
+    size_t lo = 0, hi = n;
+    while (lo < hi) {
+        size_t mid = (lo + hi) >> 1;
+        if (sorted_depth[mid] < (unsigned)l) lo = mid + 1; else hi = mid;
+    }
+    start[l] = (int)lo;
 }
 
 __global__ void k_flow_level(flow_canvas fc, const int *__restrict__ order, int first, int count,
@@ -612,16 +617,26 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
     DMG_HIP(hipMemcpyAsync(&max_depth, dmax.p, 4, hipMemcpyDeviceToHost, st));
     DMG_HIP(hipStreamSynchronize(st));
     const int levels = max_depth + 1;
-    DMG_ALLOC(hist, (size_t)levels * 4);
-    DMG_HIP(hipMemsetAsync(hist.p, 0, (size_t)levels * 4, st));
-    hipLaunchKernelGGL(k_flow_hist, dim3(nb), dim3(256), 0, st, gdepth.i(), hist.i(), N);
+    // cells in depth order: a radix sort on just the bits a depth needs (was a histogram + scatter with one global
+    // atomic per cell, 3.6 ms at 4096x2048 on a handful of hot counters).  -1 (unreached) has all those bits set and
+    // lands behind every real depth.
+    int depth_bits = 1;
+    while ((1 << depth_bits) <= levels) depth_bits++;
+    dev_buf sdepth, iota, sorttmp;
+    DMG_ALLOC(sdepth, N * 4); DMG_ALLOC(iota, N * 4);
+    hipLaunchKernelGGL(k_flow_iota, dim3(nb), dim3(256), 0, st, (unsigned *)iota.p, N);
+    size_t sort_bytes = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, (const unsigned *)gdepth.p, (unsigned *)sdepth.p, (const unsigned *)iota.p,
+                                             (unsigned *)order.p, (int)N, 0, depth_bits, st);
+    DMG_ALLOC(sorttmp, sort_bytes + 256);
+    DMG_HIP(hipcub::DeviceRadixSort::SortPairs(sorttmp.p, sort_bytes, (const unsigned *)gdepth.p, (unsigned *)sdepth.p, (const unsigned *)iota.p,
+                                               (unsigned *)order.p, (int)N, 0, depth_bits, st));
+    DMG_ALLOC(hist, (size_t)(levels + 1) * 4);
+    hipLaunchKernelGGL(k_flow_level_starts, dim3((levels + 256) / 256), dim3(256), 0, st, (const unsigned *)sdepth.p, N, hist.i(), levels);
     DMG_HIP(hipGetLastError());
-    std::vector<int> hh(levels), start(levels + 1, 0);
-    DMG_HIP(hipMemcpyAsync(hh.data(), hist.p, (size_t)levels * 4, hipMemcpyDeviceToHost, st));
+    std::vector<int> start(levels + 1, 0);
+    DMG_HIP(hipMemcpyAsync(start.data(), hist.p, (size_t)(levels + 1) * 4, hipMemcpyDeviceToHost, st));
     DMG_HIP(hipStreamSynchronize(st));
-    for (int l = 0; l < levels; l++) start[l + 1] = start[l] + hh[l];
-    DMG_HIP(hipMemcpyAsync(hist.p, start.data(), (size_t)levels * 4, hipMemcpyHostToDevice, st));   // hist := scatter cursors
-    hipLaunchKernelGGL(k_flow_scatter, dim3(nb), dim3(256), 0, st, gdepth.i(), hist.i(), order.i(), N, levels);
     hipLaunchKernelGGL(k_fill_f, dim3(nb), dim3(256), 0, st, d_flow, -1.0f, N);        // unreached cells keep -1 (:598-604)
     DMG_HIP(hipGetLastError());
     if (timing) fprintf(stderr, "[flow] %d levels\n", levels);
