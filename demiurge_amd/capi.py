@@ -97,6 +97,7 @@ def lib():
         "dmg_create": (c_int, [c_int, vp, c_int, ctypes.POINTER(vp)]),
         "dmg_destroy": (None, [vp]),
         "dmg_sync": (c_int, [vp]),
+        "dmg_trim": (c_int, [vp]),
         "dmg_device_name": (c_int, [vp, ctypes.c_char_p, sz]),
         "dmg_copy_device": (c_int, [vp, vp, vp, sz]),
         "dmg_timer_start": (c_int, [vp]),
@@ -198,6 +199,10 @@ class Context:
             self.close()
         except Exception:
             pass
+
+    def trim(self):
+        """hand the cached temporaries of finished calls back to the device"""
+        check(lib().dmg_trim(self.h))
 
     def sync(self):
         check(lib().dmg_sync(self.h))

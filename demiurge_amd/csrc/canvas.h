@@ -88,10 +88,18 @@ int erosion_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo,
                    const float *d_updrift, float *d_out, const float *d_dx, const float *d_dy, float factor, float slope_exponent);
 
 namespace {
+// a temporary device buffer of one call, drawn from (and returned to) the context's scratch pool
 struct dev_buf {
     void *p = nullptr;
-    ~dev_buf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t n) { return hipMalloc(&p, n); }
+    dmg_ctx *owner = nullptr;
+    size_t bytes = 0;
+    ~dev_buf() { if (p) dmg_scratch_free(owner, p, bytes); }
+    hipError_t alloc(dmg_ctx *ctx, size_t n)
+    {
+        owner = ctx;
+        bytes = (n + 255) & ~(size_t)255;
+        return dmg_scratch_alloc(ctx, bytes, &p);
+    }
     float *f() const { return (float *)p; }
     int *i() const { return (int *)p; }
 };
@@ -99,7 +107,7 @@ struct dev_buf {
 
 #define DMG_ALLOC(buf, bytes)                                                                      \
     do {                                                                                           \
-        hipError_t _e = (buf).alloc(bytes);                                                        \
+        hipError_t _e = (buf).alloc(ctx, bytes);                                                   \
         if (_e != hipSuccess) return dmg_fail(DMG_ENOMEM, "hipMalloc(%zu) failed: %s", (size_t)(bytes), hipGetErrorString(_e)); \
     } while (0)
 

@@ -68,10 +68,21 @@ int dmg_create(int device_id, void *stream, int flags, dmg_ctx **out)
     return DMG_OK;
 }
 
+int dmg_trim(dmg_ctx *c)
+{
+    DMG_CHECK_ARG(c != nullptr);
+    DMG_HIP(hipStreamSynchronize(c->stream));
+    for (auto &kv : c->scratch_pool) (void)hipFree(kv.second);
+    c->scratch_pool.clear();
+    c->scratch_pool_bytes = 0;
+    return DMG_OK;
+}
+
 void dmg_destroy(dmg_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    (void)dmg_trim(c);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -122,3 +133,32 @@ int dmg_band_row0(int H, int band_count, int band_rank)
 }
 
 }  // extern "C"
+
+
+// ---- scratch pool (see dmg_ctx::scratch_pool) ----
+hipError_t dmg_scratch_alloc(dmg_ctx *ctx, size_t bytes, void **out)
+{
+    if (ctx) {
+        auto it = ctx->scratch_pool.find(bytes);
+        if (it != ctx->scratch_pool.end()) {
+            *out = it->second;
+            ctx->scratch_pool.erase(it);
+            ctx->scratch_pool_bytes -= bytes;
+            return hipSuccess;
+        }
+    }
+    hipError_t e = hipMalloc(out, bytes);
+    if (e != hipSuccess && ctx && !ctx->scratch_pool.empty()) {      // out of memory with blocks parked: release them, retry
+        (void)hipGetLastError();
+        (void)dmg_trim(ctx);
+        e = hipMalloc(out, bytes);
+    }
+    return e;
+}
+
+void dmg_scratch_free(dmg_ctx *ctx, void *p, size_t bytes)
+{
+    if (!ctx) { (void)hipFree(p); return; }
+    ctx->scratch_pool.emplace(bytes, p);
+    ctx->scratch_pool_bytes += bytes;
+}

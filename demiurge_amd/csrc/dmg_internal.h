@@ -5,11 +5,17 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 #include "../../include/demiurge_hip.h"
 
 struct dmg_ctx {
+    // scratch blocks handed back by finished calls, by size.  The filters that loop (erosion: ~45 temporaries per
+    // flow solve, 1000 solves) would otherwise pay hipMalloc + a device-synchronising hipFree for each of them every
+    // round.  One context = one stream = one caller thread at a time, so reuse is ordered by the stream itself.
+    std::multimap<size_t, void *> scratch_pool;
+    size_t scratch_pool_bytes = 0;
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -17,6 +23,10 @@ struct dmg_ctx {
     int num_cu = 0;
     char name[128] = {0};
 };
+
+// scratch memory of a context (dmg_core.hip): exact-size reuse, released by dmg_trim / dmg_destroy
+hipError_t dmg_scratch_alloc(dmg_ctx *ctx, size_t bytes, void **out);
+void dmg_scratch_free(dmg_ctx *ctx, void *p, size_t bytes);
 
 // thread-local error string behind dmg_last_error()
 int dmg_fail(int code, const char *fmt, ...);
