@@ -511,16 +511,17 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
     // cell s from lake `from`; entries are sorted by (lake, height, from)
     struct Entry { float h; int from, s, lake, sdist; };
     std::vector<Entry> ent(nuniq);
-    std::vector<int> cursor(nlakes + 1, 0), rend(nlakes + 1, 0);       // per lake: next unread entry, end of its entries
+    struct Span { int cur, end; };                                     // per lake: next unread entry, end of its entries
+    std::vector<Span> span(nlakes + 1, Span{ 0, 0 });
     for (int i = 0; i < nuniq; i++) {
         unsigned hb = (unsigned)(hkey[i] & 0xFFFFFFFFull);
         Entry e;
         memcpy(&e.h, &hb, 4);
         e.lake = (int)(hkey[i] >> 32); e.from = (int)(hpay[i] >> 32); e.s = (int)(hpay[i] & 0xFFFFFFFFull); e.sdist = hsdist[i];
         ent[i] = e;
-        rend[e.lake] = i + 1;
+        span[e.lake].end = i + 1;
     }
-    for (int i = nuniq - 1; i >= 0; i--) cursor[ent[i].lake] = i;      // first entry of each lake
+    for (int i = nuniq - 1; i >= 0; i--) span[ent[i].lake].cur = i;    // first entry of each lake
     lap("host: entry table");
     // the heap carries its keys (16 B) instead of indices into `ent`: a sift touches only the heap's own cache lines
     struct Cand { float h; int from, s, idx; };
@@ -532,13 +533,16 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
     std::priority_queue<Cand, std::vector<Cand>, decltype(worse)> candidates(worse, std::move(heap_store));
     std::vector<char> placed(nlakes, 0);
     for (int m : mouths) placed[m] = 1;
+    // The growth hops all over the map, so each visit of a lake is a chain of cache misses (its span, its first unread
+    // entry, the flag of that entry's lake).  The lake a candidate would place is known when the candidate is pushed:
+    // its span is prefetched then, and its first entry when the candidate is popped, one lake's worth of work ahead.
     auto push_next = [&](int lake) {
-        int &c = cursor[lake];
-        const int e = rend[lake];
-        while (c < e) {
-            int i = c++;
+        Span &sp = span[lake];
+        while (sp.cur < sp.end) {
+            int i = sp.cur++;
             if (placed[ent[i].from]) continue;
             candidates.push(Cand{ ent[i].h, ent[i].from, ent[i].s, i });
+            __builtin_prefetch(&span[ent[i].from]);
             break;
         }
     };
@@ -550,9 +554,10 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
         const int c = top.idx;
         if (placed[top.from]) { push_next(ent[c].lake); continue; }
         placed[top.from] = 1;
+        __builtin_prefetch(&ent[span[top.from].cur]);
         assigned.push_back(c);                                         // a later pass at the same cell replaces this one (:588)
+        push_next(ent[c].lake);                                        // (independent of the next line: disjoint lakes)
         push_next(top.from);
-        push_next(ent[c].lake);
     }
     lap("host: prim growth");
     // resolve the overwrites: per tolocation cell the LAST assigned entry survives (open-addressing table on s)
