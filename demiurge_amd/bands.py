@@ -25,11 +25,18 @@ class _DevSlab:
 
 
 class HaloExchanger:
+    """modes: zero-copy aliases of the library's slabs (nccl), torch-owned device bounce buffers filled by
+    device-to-device copies (`bounce`: DMG_HALO_BOUNCE=1, or automatically when torch cannot alias the slabs),
+    host staging on top of either (any backend but nccl)."""
+
     def __init__(self, dist, rank, world, device=None):
+        import os
         import torch
         self.torch, self.dist, self.rank, self.world, self.device = torch, dist, rank, world, device
         self.staged = dist.get_backend() != "nccl"
+        self.bounce = os.environ.get("DMG_HALO_BOUNCE") == "1"
         self._alias = {}
+        self._bounce = {}
 
     def _tensor(self, ptr, nbytes):
         """torch view of a slab: device alias for HIP memory, numpy-backed view when `ptr` is a host ndarray."""
@@ -40,6 +47,12 @@ class HaloExchanger:
             self._alias[key] = self.torch.as_tensor(_DevSlab(ptr, nbytes), device=self.device)
         return self._alias[key]
 
+    def _bounce_pair(self, key, nbytes):
+        if key not in self._bounce:
+            mk = lambda: self.torch.empty(nbytes // 4, dtype=self.torch.float32, device=self.device)
+            self._bounce[key] = (mk(), mk())
+        return self._bounce[key]
+
     def exchange(self, ocean, field, rows):
         """Refresh `rows` ghost rows of `field` on both sides of this rank's band."""
         dist, torch = self.dist, self.torch
@@ -48,18 +61,34 @@ class HaloExchanger:
             if peer < 0 or peer >= self.world:
                 continue
             send, recv, nbytes = ocean.halo(field, side, rows)
-            ts, tr = self._tensor(send, nbytes), self._tensor(recv, nbytes)
+            if isinstance(send, np.ndarray):
+                ts, tr = self._tensor(send, nbytes), self._tensor(recv, nbytes)
+            else:
+                if not self.bounce:
+                    try:
+                        ts, tr = self._tensor(send, nbytes), self._tensor(recv, nbytes)
+                    except Exception as e:   # torch build that cannot wrap foreign device memory: copy through its own
+                        import sys
+                        print("HaloExchanger: aliasing device slabs failed (%s); using bounce buffers" % e, file=sys.stderr)
+                        self.bounce = True
+                if self.bounce:
+                    ts, tr = self._bounce_pair((field, side, nbytes), nbytes)
+                    ocean.ctx.copy_device(ts.data_ptr(), send, nbytes)      # same stream as the sweeps and as torch
+                    post.append(("d2d", recv, tr, nbytes))
             if self.staged and ts.is_cuda:
                 hs, hr = ts.cpu(), torch.empty(ts.shape, dtype=ts.dtype)
-                post.append((tr, hr))
+                post.insert(0, ("h2d", tr, hr, nbytes))
                 ts, tr = hs, hr
             ops.append(dist.P2POp(dist.isend, ts, peer))
             ops.append(dist.P2POp(dist.irecv, tr, peer))
         if ops:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
-        for dst, src in post:
-            dst.copy_(src)
+        for kind, dst, src, nbytes in post:
+            if kind == "h2d":
+                dst.copy_(src)
+            else:
+                ocean.ctx.copy_device(dst, src.data_ptr(), nbytes)
 
 
 def jacobi_solve(ocean, exch, sweeps, ghost, zero_first=True, field=0):

@@ -46,6 +46,17 @@ def test_bands_gloo_hip_ranks_share_gpu(oracle, tmp_path, world, ghost, sweeps):
 
 
 @pytest.mark.gpu
+def test_bands_bounce_buffers(oracle, tmp_path, monkeypatch):
+    """the exchanger's fallback transport: slabs copied device-to-device through torch-owned buffers"""
+    from demiurge_amd import synth
+    monkeypatch.setenv("DMG_HALO_BOUNCE", "1")
+    W, H, sweeps, ghost = 512, 256, 40, 8
+    got = run_bands("hip", 2, W, H, sweeps, ghost, tmp_path)
+    ref = oracle.ocean_jacobi(oracle.grid(W, H), synth.terrain(W, H), synth.divw(W, H), sweeps, rows=True)
+    assert np.array_equal(got, ref)
+
+
+@pytest.mark.gpu
 def test_ocean_step_bands_gloo_hip(tmp_path):
     """the whole outer ocean step (advect, 50x diffusion, divergence, Jacobi, subDiv) on 3 bands = one band, bitwise"""
     from demiurge_amd import capi, synth
