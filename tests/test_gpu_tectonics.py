@@ -40,7 +40,8 @@ def test_tectonics_golden(dev, name):
 
 
 @pytest.mark.parametrize("W,H,steps,coords", [(256, 128, 7, None), (100, 50, 9, None), (512, 256, 3, None),
-                                              (192, 64, 5, (-1.0, 1.2, -np.pi, np.pi))])
+                                              (192, 64, 5, (-1.0, 1.2, -np.pi, np.pi)),
+                                              (128, 128, 4, None), (256, 64, 4, None), (96, 40, 4, None)])
 def test_tectonics_vs_oracle(dev, oracle, W, H, steps, coords):
     """other sizes (incl. non-power-of-two, where oracle and kernel share the exact st = (x+0.5)/W) and extents"""
     capi, ctx = dev
