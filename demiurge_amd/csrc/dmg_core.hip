@@ -51,6 +51,7 @@ int dmg_create(int device_id, void *stream, int flags, dmg_ctx **out)
     if (!c) return dmg_fail(DMG_ENOMEM, "out of host memory");
     c->device = device_id;
     c->num_cu = prop.multiProcessorCount;
+    c->scratch_cap = (size_t)prop.totalGlobalMem / 4;        // parked temporaries never hold more than a quarter of HBM
     snprintf(c->name, sizeof c->name, "%s (%s, %d CUs)", prop.name[0] ? prop.name : "AMD Instinct", prop.gcnArchName,
              prop.multiProcessorCount);
     if (!(flags & DMG_PRIVATE_STREAM)) {
@@ -158,7 +159,7 @@ hipError_t dmg_scratch_alloc(dmg_ctx *ctx, size_t bytes, void **out)
 
 void dmg_scratch_free(dmg_ctx *ctx, void *p, size_t bytes)
 {
-    if (!ctx) { (void)hipFree(p); return; }
+    if (!ctx || ctx->scratch_pool_bytes + bytes > ctx->scratch_cap) { (void)hipFree(p); return; }   // hipFree synchronises
     ctx->scratch_pool.emplace(bytes, p);
     ctx->scratch_pool_bytes += bytes;
 }

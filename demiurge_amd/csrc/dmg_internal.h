@@ -15,7 +15,7 @@ struct dmg_ctx {
     // flow solve, 1000 solves) would otherwise pay hipMalloc + a device-synchronising hipFree for each of them every
     // round.  One context = one stream = one caller thread at a time, so reuse is ordered by the stream itself.
     std::multimap<size_t, void *> scratch_pool;
-    size_t scratch_pool_bytes = 0;
+    size_t scratch_pool_bytes = 0, scratch_cap = 0;
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;

@@ -100,7 +100,7 @@ __device__ __forceinline__ tb_row tb_map_row(const tb_args &a, int local_unclamp
 
 // second launch-bound argument = waves per SIMD the register allocator must leave room for (R = 8: 128 VGPRs,
 // i.e. two 8-wave workgroups per CU, so one workgroup's load phase overlaps the other's sweeps)
-template <int R, int NW>
+template <int R, int NW, bool TRACE = false>
 __global__ __launch_bounds__(NW * 64, (R <= 10 ? 4 : (R <= 12 ? 3 : 2))) void k_jacobi_tb8(tb_args a)
 {
     constexpr int EH = R * NW;                      // extended tile rows
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(NW * 64, (R <= 10 ? 4 : (R <= 12 ? 3 : 2))) void k_
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int W = a.W;
-    if (a.trace && threadIdx.x == 0) {
+    if (TRACE && threadIdx.x == 0) {
         unsigned hw, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(NW * 64, (R <= 10 ? 4 : (R <= 12 ? 3 : 2))) void k_
     // wave-rows that are land everywhere stay exactly 0 (k_zero_land keeps land at 0 on input; :481 on output);
     // a tile that is land everywhere has nothing to sweep or store
     if (__syncthreads_and(land_rows == ((1u << R) - 1u))) return;
-    if (a.trace && threadIdx.x == 0) a.trace[4 * (size_t)blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+    if (TRACE && threadIdx.x == 0) a.trace[4 * (size_t)blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
 
     for (int s = 0; s < a.nsweeps; s++) {
         // publish this wave's first and last rows (values before the sweep), fetch the neighbours' rows
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(NW * 64, (R <= 10 ? 4 : (R <= 12 ? 3 : 2))) void k_
         }
     }
 
-    if (a.trace && threadIdx.x == 0) a.trace[4 * (size_t)blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
+    if (TRACE && threadIdx.x == 0) a.trace[4 * (size_t)blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
     // store the interior: extended rows [T, EH-T), lanes 2..61, clipped to the launch's row range and to W
     const int xcol = X0 - TB_T + 4 * lane;          // unwrapped column
     const bool lane_ok = (lane >= TB_T / 4) && (lane < 64 - TB_T / 4) && (xcol < W);
@@ -341,7 +341,10 @@ static void tb_launch(tb_args a, int W, int rows, hipStream_t stream)
         (void)hipMalloc((void **)&a.trace, nt * 32);
         (void)hipMemsetAsync(a.trace, 0, nt * 32, stream);
     }
-    hipLaunchKernelGGL((k_jacobi_tb8<R, NW>), dim3(a.tiles_x * a.tiles_y), dim3(NW * 64), 0, stream, a);
+    if (trace_path && R == 8 && NW == 8)       // the timeline build exists for the default shape only
+        hipLaunchKernelGGL((k_jacobi_tb8<8, 8, true>), dim3(a.tiles_x * a.tiles_y), dim3(NW * 64), 0, stream, a);
+    else
+        hipLaunchKernelGGL((k_jacobi_tb8<R, NW>), dim3(a.tiles_x * a.tiles_y), dim3(NW * 64), 0, stream, a);
     if (trace_path) {
         std::vector<unsigned long long> h(nt * 4);
         (void)hipStreamSynchronize(stream);
