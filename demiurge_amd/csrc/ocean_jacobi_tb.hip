@@ -37,7 +37,7 @@ struct tb_args {
     int tiles_x, tiles_y;
     const unsigned char *rowclass;  // [tiles_x][L]: 0 open ocean, 1 land everywhere, 2 mixed -- per (tile column, local row), or null
     int order;                      // tile walk: 0 natural row-major, 1 XCD-chunked 16-column groups, 2 XCD-chunked column-major
-    unsigned long long *trace;      // experiments only (DMG_TB_TRACE): per workgroup {start, loaded, swept, hw id}, 100 MHz ticks
+    unsigned long long *trace;      // experiments only (DMG_TB_TRACE): per workgroup {start, loaded, swept, hw id, shader clock at loaded, at swept}; times in 100 MHz ticks
 };
 
 __device__ __forceinline__ float dpp_from_prev_lane(float v)   // lane i <- lane i-1
@@ -115,8 +115,8 @@ __global__ __launch_bounds__(NW * 64, (R <= 10 ? 4 : (R <= 12 ? 3 : 2))) void k_
         unsigned hw, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        a.trace[4 * (size_t)blockIdx.x + 0] = __builtin_amdgcn_s_memrealtime();
-        a.trace[4 * (size_t)blockIdx.x + 3] = ((unsigned long long)xcc << 32) | hw;
+        a.trace[6 * (size_t)blockIdx.x + 0] = __builtin_amdgcn_s_memrealtime();
+        a.trace[6 * (size_t)blockIdx.x + 3] = ((unsigned long long)xcc << 32) | hw;
     }
 
     // tile id -> (tile column, tile row).  Workgroups are dealt round-robin over the 8 XCDs (id % 8, observed, not
@@ -214,7 +214,10 @@ __global__ __launch_bounds__(NW * 64, (R <= 10 ? 4 : (R <= 12 ? 3 : 2))) void k_
     // wave-rows that are land everywhere stay exactly 0 (k_zero_land keeps land at 0 on input; :481 on output);
     // a tile that is land everywhere has nothing to sweep or store
     if (__syncthreads_and(land_rows == ((1u << R) - 1u))) return;
-    if (TRACE && threadIdx.x == 0) a.trace[4 * (size_t)blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+    if (TRACE && threadIdx.x == 0) {
+        a.trace[6 * (size_t)blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+        a.trace[6 * (size_t)blockIdx.x + 4] = __builtin_amdgcn_s_memtime();
+    }
 
     for (int s = 0; s < a.nsweeps; s++) {
         // publish this wave's first and last rows (values before the sweep), fetch the neighbours' rows
@@ -262,7 +265,10 @@ __global__ __launch_bounds__(NW * 64, (R <= 10 ? 4 : (R <= 12 ? 3 : 2))) void k_
         }
     }
 
-    if (TRACE && threadIdx.x == 0) a.trace[4 * (size_t)blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
+    if (TRACE && threadIdx.x == 0) {
+        a.trace[6 * (size_t)blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
+        a.trace[6 * (size_t)blockIdx.x + 5] = __builtin_amdgcn_s_memtime();
+    }
     // store the interior: extended rows [T, EH-T), lanes 2..61, clipped to the launch's row range and to W
     const int xcol = X0 - TB_T + 4 * lane;          // unwrapped column
     const bool lane_ok = (lane >= TB_T / 4) && (lane < 64 - TB_T / 4) && (xcol < W);
@@ -338,19 +344,19 @@ static void tb_launch(tb_args a, int W, int rows, hipStream_t stream)
     static const char *trace_path = getenv("DMG_TB_TRACE");      // experiments: dump the per-workgroup timeline of every launch
     const size_t nt = (size_t)a.tiles_x * a.tiles_y;
     if (trace_path) {
-        (void)hipMalloc((void **)&a.trace, nt * 32);
-        (void)hipMemsetAsync(a.trace, 0, nt * 32, stream);
+        (void)hipMalloc((void **)&a.trace, nt * 48);
+        (void)hipMemsetAsync(a.trace, 0, nt * 48, stream);
     }
     if (trace_path && R == 8 && NW == 8)       // the timeline build exists for the default shape only
         hipLaunchKernelGGL((k_jacobi_tb8<8, 8, true>), dim3(a.tiles_x * a.tiles_y), dim3(NW * 64), 0, stream, a);
     else
         hipLaunchKernelGGL((k_jacobi_tb8<R, NW>), dim3(a.tiles_x * a.tiles_y), dim3(NW * 64), 0, stream, a);
     if (trace_path) {
-        std::vector<unsigned long long> h(nt * 4);
+        std::vector<unsigned long long> h(nt * 6);
         (void)hipStreamSynchronize(stream);
-        (void)hipMemcpy(h.data(), a.trace, nt * 32, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(h.data(), a.trace, nt * 48, hipMemcpyDeviceToHost);
         (void)hipFree(a.trace);
-        if (FILE *f = fopen(trace_path, "wb")) { fwrite(h.data(), 32, nt, f); fclose(f); }
+        if (FILE *f = fopen(trace_path, "wb")) { fwrite(h.data(), 48, nt, f); fclose(f); }
     }
 }
 

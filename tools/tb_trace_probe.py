@@ -23,7 +23,7 @@ oc.set_divw(synth.divw(W, H))
 oc.jacobi_sweeps(8)
 oc.jacobi_sweeps(8)          # the file holds the last launch (warm)
 ctx.sync()
-t = np.fromfile(out, dtype=np.uint64).reshape(-1, 4)
+t = np.fromfile(out, dtype=np.uint64).reshape(-1, 6)
 start, loaded, swept, hw = t[:, 0].astype(np.int64), t[:, 1].astype(np.int64), t[:, 2].astype(np.int64), t[:, 3]
 live = loaded > 0
 t0 = start.min()
@@ -33,6 +33,8 @@ ld = (loaded[live] - start[live]) / 100.0
 sw = (swept[live] - loaded[live]) / 100.0
 print("load phase  us: mean %.2f  p10 %.2f  p50 %.2f  p90 %.2f" % (ld.mean(), *np.percentile(ld, [10, 50, 90])))
 print("sweep phase us: mean %.2f  p10 %.2f  p50 %.2f  p90 %.2f" % (sw.mean(), *np.percentile(sw, [10, 50, 90])))
+clk = (t[live, 5].astype(np.int64) - t[live, 4].astype(np.int64)) / np.maximum(swept[live] - loaded[live], 1) * 100.0 / 1e3
+print("shader clock during the sweep phase (s_memtime / s_memrealtime): median %.2f GHz  p10 %.2f  p90 %.2f" % (np.median(clk), *np.percentile(clk, [10, 90])))
 # per-CU occupancy over time: identify CU by (xcc, se, sh, cu)
 hwid = (hw & np.uint64(0xFFFFFFFF)).astype(np.int64)
 xcc = (hw >> np.uint64(32)).astype(np.int64) & 0xF
