@@ -295,6 +295,7 @@ void dmg_ocean_destroy(dmg_ocean *o)
     for (void *p : { (void *)o->p[0], (void *)o->p[1], (void *)o->divw, (void *)o->img, (void *)o->code, (void *)o->code8,
                      (void *)o->v[0], (void *)o->v[1], (void *)o->rowtab, (void *)o->oob_flag, (void *)o->rowclass })
         if (p) (void)hipFree(p);
+    ocean_tb_free_lists(o);
     delete o;
 }
 

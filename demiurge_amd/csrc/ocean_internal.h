@@ -1,5 +1,7 @@
 // dmg_ocean: device state of one OceanCurrents instance (one latitude band).
 #pragma once
+#include <map>
+#include <utility>
 #include "dmg_internal.h"
 
 // per-local-row tables, evaluated on the host in fp32 with the GLSL's own operation order
@@ -34,6 +36,9 @@ struct dmg_ocean {
     unsigned char *code = nullptr;    // Jacobi/diffusion/subDiv 'use centre' bits + centre-solid bit
     unsigned char *code8 = nullptr;   // 8-neighbour solid bits (divergence, subDiv)
     unsigned char *rowclass = nullptr; // blocked Jacobi: class of every (tile column, row) wave-row (ocean_jacobi_tb.hip)
+    std::vector<unsigned char> rowclass_host;   // the same table on the host, for the live-tile lists
+    struct tile_list { int *d = nullptr; int n = 0; };
+    std::map<std::pair<int, int>, tile_list> tb_lists;   // (out_lo, out_hi) of a launch -> tiles that are not land everywhere
     float *v[2] = { nullptr, nullptr };   // interleaved (vx,vy)
     int vcur = 0;
     int *oob_flag = nullptr;       // device word: advect out-of-band flag / reduction scratch
@@ -52,6 +57,7 @@ int ocean_zero_land(dmg_ocean *o);            // p := +0 on land in BOTH ping-po
 int ocean_launch_tb(dmg_ocean *o, int lo, int hi, int n);   // ocean_jacobi_tb.hip
 bool ocean_tb_supported(const dmg_ocean *o);
 int ocean_build_rowclass(dmg_ocean *o);
+void ocean_tb_free_lists(dmg_ocean *o);
 int ocean_terrain_changed(dmg_ocean *o);        // rebuilds what is derived from o->img (ocean.hip)
 int ocean_upload_rows(dmg_ocean *o, float *dst, const float *src_full, int comps);
 int ocean_download_rows(dmg_ocean *o, float *dst_full, const float *src, int comps);

@@ -37,6 +37,7 @@ struct tb_args {
     int tiles_x, tiles_y;
     const unsigned char *rowclass;  // [tiles_x][L]: 0 open ocean, 1 land everywhere, 2 mixed -- per (tile column, local row), or null
     int order;                      // tile walk: 0 natural row-major, 1 XCD-chunked 16-column groups, 2 XCD-chunked column-major
+    const int *tile_list;           // tiles to run (those not land everywhere), or null = all tiles_x*tiles_y
     unsigned long long *trace;      // experiments only (DMG_TB_TRACE): per workgroup {start, loaded, swept, hw id, shader clock at loaded, at swept}; times in 100 MHz ticks
 };
 
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(NW * 64, (R <= 10 ? 4 : (R <= 12 ? 3 : 2))) void k_
     int tx, ty;
     {
         const int ntiles = a.tiles_x * a.tiles_y;
-        int t = blockIdx.x;
+        int t = a.tile_list ? a.tile_list[blockIdx.x] : (int)blockIdx.x;
         if (a.order != 0) {
             int per = ntiles >> 3;                  // tiles per XCD (the remainder keeps its natural order)
             if (t < per * 8) t = (t & 7) * per + (t >> 3);
@@ -304,6 +305,12 @@ __global__ __launch_bounds__(64) void k_tb_rowclass(const unsigned char *__restr
     if (lane == 0) cls[(size_t)tx * L + l] = all_land ? 1 : (any ? 2 : 0);
 }
 
+void ocean_tb_free_lists(dmg_ocean *o)
+{
+    for (auto &kv : o->tb_lists) if (kv.second.d) (void)hipFree(kv.second.d);
+    o->tb_lists.clear();
+}
+
 int ocean_build_rowclass(dmg_ocean *o)
 {
     if (!ocean_tb_supported(o)) return DMG_OK;
@@ -312,7 +319,43 @@ int ocean_build_rowclass(dmg_ocean *o)
     hipLaunchKernelGGL(k_tb_rowclass, dim3(tiles_x, o->L), dim3(64), 0, o->ctx->stream, o->code, o->rowclass, o->grid.W, o->L,
                        o->y0 - o->gs, o->grid.H, o->topo.spole ? 1 : 0, o->topo.npole ? 1 : 0);
     DMG_HIP(hipGetLastError());
+    ocean_tb_free_lists(o);                              // lists of the previous terrain
+    o->rowclass_host.resize((size_t)tiles_x * o->L);
+    DMG_HIP(hipMemcpyAsync(o->rowclass_host.data(), o->rowclass, o->rowclass_host.size(), hipMemcpyDeviceToHost, o->ctx->stream));
+    DMG_HIP(hipStreamSynchronize(o->ctx->stream));
     return DMG_OK;
+}
+
+// Tiles of a launch over local rows [lo, hi) that have any work: a tile whose extended rows are all "land everywhere"
+// returns before it loads or stores anything, so it need not be dispatched at all (30 % of the tiles on the survey
+// terrain; each would hold a workgroup slot for a few microseconds).  Rows beyond the stored band or the grid count as
+// not-land, as in the kernel.  Built on the host from the class table, once per (lo, hi) and terrain.
+template <int R, int NW>
+static const dmg_ocean::tile_list *tb_live_tiles(dmg_ocean *o, int lo, int hi, int tiles_x, int tiles_y)
+{
+    auto key = std::make_pair(lo, hi);
+    auto it = o->tb_lists.find(key);
+    if (it != o->tb_lists.end()) return &it->second;
+    constexpr int EH = R * NW, OH = EH - 2 * TB_T;
+    const int y_first = o->y0 - o->gs, L = o->L, H = o->grid.H;
+    std::vector<int> live;
+    live.reserve((size_t)tiles_x * tiles_y);
+    for (int ty = 0; ty < tiles_y; ty++)
+        for (int tx = 0; tx < tiles_x; tx++) {
+            const unsigned char *cls = o->rowclass_host.data() + (size_t)tx * L;
+            const int e0 = lo + ty * OH - TB_T;
+            bool dead = true;
+            for (int e = 0; e < EH && dead; e++) {
+                int lu = e0 + e, yg = y_first + lu;
+                dead = yg >= 0 && yg < H && lu >= 0 && lu < L && cls[lu] == 1;
+            }
+            if (!dead) live.push_back(ty * tiles_x + tx);
+        }
+    dmg_ocean::tile_list tl;
+    tl.n = (int)live.size();
+    if (tl.n && hipMalloc((void **)&tl.d, live.size() * sizeof(int)) != hipSuccess) return nullptr;
+    if (tl.n && hipMemcpy(tl.d, live.data(), live.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    return &(o->tb_lists[key] = tl);
 }
 
 // tile shapes built into the library: R rows per thread x NW waves per workgroup.  The default is chosen from
@@ -333,7 +376,7 @@ static tb_shape tb_pick_shape()
 }
 
 template <int R, int NW>
-static void tb_launch(tb_args a, int W, int rows, hipStream_t stream)
+static void tb_launch(dmg_ocean *o, tb_args a, int W, int rows, hipStream_t stream)
 {
     constexpr int OH = R * NW - 2 * TB_T;
     a.tiles_x = (W + TB_OW - 1) / TB_OW;
@@ -341,16 +384,26 @@ static void tb_launch(tb_args a, int W, int rows, hipStream_t stream)
     static const int order = [] { const char *e = getenv("DMG_TB_ORDER"); return e ? atoi(e) : 0; }();
     a.order = order;
     a.trace = nullptr;
+    a.tile_list = nullptr;
+    size_t nt = (size_t)a.tiles_x * a.tiles_y;
+    static const bool all_tiles = getenv("DMG_TB_ALLTILES") != nullptr;
+    if (a.rowclass && order == 0 && !all_tiles) {
+        const dmg_ocean::tile_list *tl = tb_live_tiles<R, NW>(o, a.out_lo, a.out_hi, a.tiles_x, a.tiles_y);
+        if (tl) {
+            if (tl->n == 0) return;                       // land everywhere: nothing changes
+            a.tile_list = tl->d;
+            nt = (size_t)tl->n;
+        }
+    }
     static const char *trace_path = getenv("DMG_TB_TRACE");      // experiments: dump the per-workgroup timeline of every launch
-    const size_t nt = (size_t)a.tiles_x * a.tiles_y;
     if (trace_path) {
         (void)hipMalloc((void **)&a.trace, nt * 48);
         (void)hipMemsetAsync(a.trace, 0, nt * 48, stream);
     }
     if (trace_path && R == 8 && NW == 8)       // the timeline build exists for the default shape only
-        hipLaunchKernelGGL((k_jacobi_tb8<8, 8, true>), dim3(a.tiles_x * a.tiles_y), dim3(NW * 64), 0, stream, a);
+        hipLaunchKernelGGL((k_jacobi_tb8<8, 8, true>), dim3((unsigned)nt), dim3(NW * 64), 0, stream, a);
     else
-        hipLaunchKernelGGL((k_jacobi_tb8<R, NW>), dim3(a.tiles_x * a.tiles_y), dim3(NW * 64), 0, stream, a);
+        hipLaunchKernelGGL((k_jacobi_tb8<R, NW>), dim3((unsigned)nt), dim3(NW * 64), 0, stream, a);
     if (trace_path) {
         std::vector<unsigned long long> h(nt * 6);
         (void)hipStreamSynchronize(stream);
@@ -380,11 +433,11 @@ int ocean_launch_tb(dmg_ocean *o, int lo, int hi, int n)
     a.rowclass = use_cls ? o->rowclass : nullptr;
     tb_shape sh = tb_pick_shape();
     hipStream_t st = o->ctx->stream;
-    if (sh.R == 16) tb_launch<16, 8>(a, a.W, hi - lo, st);
-    else if (sh.R == 10) tb_launch<10, 8>(a, a.W, hi - lo, st);
-    else if (sh.R == 12) tb_launch<12, 8>(a, a.W, hi - lo, st);
-    else if (sh.NW == 16) tb_launch<8, 16>(a, a.W, hi - lo, st);
-    else tb_launch<8, 8>(a, a.W, hi - lo, st);
+    if (sh.R == 16) tb_launch<16, 8>(o, a, a.W, hi - lo, st);
+    else if (sh.R == 10) tb_launch<10, 8>(o, a, a.W, hi - lo, st);
+    else if (sh.R == 12) tb_launch<12, 8>(o, a, a.W, hi - lo, st);
+    else if (sh.NW == 16) tb_launch<8, 16>(o, a, a.W, hi - lo, st);
+    else tb_launch<8, 8>(o, a, a.W, hi - lo, st);
     DMG_HIP(hipGetLastError());
     return DMG_OK;
 }
