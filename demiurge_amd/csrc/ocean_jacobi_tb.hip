@@ -361,18 +361,25 @@ static const dmg_ocean::tile_list *tb_live_tiles(dmg_ocean *o, int lo, int hi, i
 // tile shapes built into the library: R rows per thread x NW waves per workgroup.  The default is chosen from
 // measurements; DMG_TB_SHAPE=<R>x<NW> overrides it for experiments.
 struct tb_shape { int R, NW; };
-static tb_shape tb_pick_shape()
+static tb_shape tb_pick_shape(int W, int rows)
 {
-    static tb_shape s = [] {
-        tb_shape d = { 8, 8 };
+    static const tb_shape forced = [] {
+        tb_shape d = { 0, 0 };
         const char *e = getenv("DMG_TB_SHAPE");
         int r = 0, nw = 0;
         if (e && sscanf(e, "%dx%d", &r, &nw) == 2 &&
-            ((r == 8 && nw == 8) || (r == 16 && nw == 8) || (r == 8 && nw == 16) || (r == 12 && nw == 8) || (r == 10 && nw == 8)))
+            ((r == 8 && nw == 8) || (r == 16 && nw == 8) || (r == 8 && nw == 16) || (r == 12 && nw == 8) || (r == 10 && nw == 8) ||
+             (r == 4 && nw == 8) || (r == 6 && nw == 8)))
             d = { r, nw };
         return d;
     }();
-    return s;
+    if (forced.R) return forced;
+    // A launch is as long as its slowest tile.  With fewer 8x8 tiles than half the CUs (grids up to ~1.5 MP) the chip
+    // is mostly idle and the time is one tile's 8 sweeps; 32-row tiles halve that at the price of recomputing more
+    // halo on CUs that had nothing to do (1024x512: 17.2 -> 10.3 ms per 5000-sweep solve; from 2048x1024 on 8x8 wins)
+    const int tiles88 = ((W + TB_OW - 1) / TB_OW) * ((rows + 47) / 48);
+    if (tiles88 <= 128) return tb_shape{ 4, 8 };
+    return tb_shape{ 8, 8 };
 }
 
 template <int R, int NW>
@@ -431,9 +438,11 @@ int ocean_launch_tb(dmg_ocean *o, int lo, int hi, int n)
     a.nsweeps = n;
     static const bool use_cls = getenv("DMG_TB_NOCLASS") == nullptr;
     a.rowclass = use_cls ? o->rowclass : nullptr;
-    tb_shape sh = tb_pick_shape();
+    tb_shape sh = tb_pick_shape(a.W, hi - lo);
     hipStream_t st = o->ctx->stream;
-    if (sh.R == 16) tb_launch<16, 8>(o, a, a.W, hi - lo, st);
+    if (sh.R == 4) tb_launch<4, 8>(o, a, a.W, hi - lo, st);
+    else if (sh.R == 6) tb_launch<6, 8>(o, a, a.W, hi - lo, st);
+    else if (sh.R == 16) tb_launch<16, 8>(o, a, a.W, hi - lo, st);
     else if (sh.R == 10) tb_launch<10, 8>(o, a, a.W, hi - lo, st);
     else if (sh.R == 12) tb_launch<12, 8>(o, a, a.W, hi - lo, st);
     else if (sh.NW == 16) tb_launch<8, 16>(o, a, a.W, hi - lo, st);
