@@ -1,6 +1,7 @@
 // dmg_ocean: device state of one OceanCurrents instance (one latitude band).
 #pragma once
 #include <map>
+#include <tuple>
 #include <utility>
 #include "dmg_internal.h"
 
@@ -38,7 +39,10 @@ struct dmg_ocean {
     unsigned char *rowclass = nullptr; // blocked Jacobi: class of every (tile column, row) wave-row (ocean_jacobi_tb.hip)
     std::vector<unsigned char> rowclass_host;   // the same table on the host, for the live-tile lists
     struct tile_list { int *d = nullptr; int n = 0; };
-    std::map<std::pair<int, int>, tile_list> tb_lists;   // (out_lo, out_hi) of a launch -> tiles that are not land everywhere
+    std::map<std::tuple<int, int, int>, tile_list> tb_lists;   // (out_lo, out_hi, rows per wave) of a launch -> tiles that are not land everywhere
+    struct tb_tune { int trials[3] = { 0, 0, 0 }; float best_ms[3] = { 1e30f, 1e30f, 1e30f }; int chosen = -1; };
+    std::map<std::pair<int, int>, tb_tune> tb_tuning;           // (out_lo, out_hi) -> which tile shape is fastest there
+    hipEvent_t tune_ev0 = nullptr, tune_ev1 = nullptr;
     float *v[2] = { nullptr, nullptr };   // interleaved (vx,vy)
     int vcur = 0;
     int *oob_flag = nullptr;       // device word: advect out-of-band flag / reduction scratch

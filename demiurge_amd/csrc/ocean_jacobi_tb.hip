@@ -309,6 +309,7 @@ void ocean_tb_free_lists(dmg_ocean *o)
 {
     for (auto &kv : o->tb_lists) if (kv.second.d) (void)hipFree(kv.second.d);
     o->tb_lists.clear();
+    o->tb_tuning.clear();
 }
 
 int ocean_build_rowclass(dmg_ocean *o)
@@ -333,7 +334,7 @@ int ocean_build_rowclass(dmg_ocean *o)
 template <int R, int NW>
 static const dmg_ocean::tile_list *tb_live_tiles(dmg_ocean *o, int lo, int hi, int tiles_x, int tiles_y)
 {
-    auto key = std::make_pair(lo, hi);
+    auto key = std::make_tuple(lo, hi, R);
     auto it = o->tb_lists.find(key);
     if (it != o->tb_lists.end()) return &it->second;
     constexpr int EH = R * NW, OH = EH - 2 * TB_T;
@@ -361,7 +362,7 @@ static const dmg_ocean::tile_list *tb_live_tiles(dmg_ocean *o, int lo, int hi, i
 // tile shapes built into the library: R rows per thread x NW waves per workgroup.  The default is chosen from
 // measurements; DMG_TB_SHAPE=<R>x<NW> overrides it for experiments.
 struct tb_shape { int R, NW; };
-static tb_shape tb_pick_shape(int W, int rows)
+static tb_shape tb_forced_shape()
 {
     static const tb_shape forced = [] {
         tb_shape d = { 0, 0 };
@@ -373,17 +374,11 @@ static tb_shape tb_pick_shape(int W, int rows)
             d = { r, nw };
         return d;
     }();
-    if (forced.R) return forced;
-    // A launch is as long as its slowest tile.  With fewer 8x8 tiles than half the CUs (grids up to ~1.5 MP) the chip
-    // is mostly idle and the time is one tile's 8 sweeps; 32-row tiles halve that at the price of recomputing more
-    // halo on CUs that had nothing to do (1024x512: 17.2 -> 10.3 ms per 5000-sweep solve; from 2048x1024 on 8x8 wins)
-    const int tiles88 = ((W + TB_OW - 1) / TB_OW) * ((rows + 47) / 48);
-    if (tiles88 <= 128) return tb_shape{ 4, 8 };
-    return tb_shape{ 8, 8 };
+    return forced;
 }
 
 template <int R, int NW>
-static void tb_launch(dmg_ocean *o, tb_args a, int W, int rows, hipStream_t stream)
+static void tb_launch(dmg_ocean *o, tb_args a, int W, int rows, hipStream_t stream, float *ms = nullptr)
 {
     constexpr int OH = R * NW - 2 * TB_T;
     a.tiles_x = (W + TB_OW - 1) / TB_OW;
@@ -407,10 +402,16 @@ static void tb_launch(dmg_ocean *o, tb_args a, int W, int rows, hipStream_t stre
         (void)hipMalloc((void **)&a.trace, nt * 48);
         (void)hipMemsetAsync(a.trace, 0, nt * 48, stream);
     }
+    if (ms) (void)hipEventRecord(o->tune_ev0, stream);
     if (trace_path && R == 8 && NW == 8)       // the timeline build exists for the default shape only
         hipLaunchKernelGGL((k_jacobi_tb8<8, 8, true>), dim3((unsigned)nt), dim3(NW * 64), 0, stream, a);
     else
         hipLaunchKernelGGL((k_jacobi_tb8<R, NW>), dim3((unsigned)nt), dim3(NW * 64), 0, stream, a);
+    if (ms) {
+        (void)hipEventRecord(o->tune_ev1, stream);
+        (void)hipEventSynchronize(o->tune_ev1);
+        if (hipEventElapsedTime(ms, o->tune_ev0, o->tune_ev1) != hipSuccess) *ms = 1e30f;
+    }
     if (trace_path) {
         std::vector<unsigned long long> h(nt * 6);
         (void)hipStreamSynchronize(stream);
@@ -438,15 +439,47 @@ int ocean_launch_tb(dmg_ocean *o, int lo, int hi, int n)
     a.nsweeps = n;
     static const bool use_cls = getenv("DMG_TB_NOCLASS") == nullptr;
     a.rowclass = use_cls ? o->rowclass : nullptr;
-    tb_shape sh = tb_pick_shape(a.W, hi - lo);
     hipStream_t st = o->ctx->stream;
-    if (sh.R == 4) tb_launch<4, 8>(o, a, a.W, hi - lo, st);
-    else if (sh.R == 6) tb_launch<6, 8>(o, a, a.W, hi - lo, st);
-    else if (sh.R == 16) tb_launch<16, 8>(o, a, a.W, hi - lo, st);
-    else if (sh.R == 10) tb_launch<10, 8>(o, a, a.W, hi - lo, st);
-    else if (sh.R == 12) tb_launch<12, 8>(o, a, a.W, hi - lo, st);
-    else if (sh.NW == 16) tb_launch<8, 16>(o, a, a.W, hi - lo, st);
-    else tb_launch<8, 8>(o, a, a.W, hi - lo, st);
+    // Tile shape.  Every shape gives bit-identical results, so which one runs is purely a matter of time.  Large
+    // launches (thousands of tiles) keep the chip full with 64-row tiles.  Smaller ones are bound by the latency of a
+    // tile or by how the tile count divides into the 512-768 workgroup slots; there the first few launches of a
+    // geometry time the three candidates (two launches each) and the rest use the fastest:
+    // 1024x512 picks 4x8 (17.2 -> 10.3 ms per 5000-sweep solve), 4096x2048 picks 6x8 (46.0 -> 40.7 ms).
+    tb_shape sh = tb_forced_shape();
+    float *ms = nullptr, ms_val = 0.0f;
+    dmg_ocean::tb_tune *tune = nullptr;
+    int cand = -1;
+    static const tb_shape cands[3] = { { 8, 8 }, { 6, 8 }, { 4, 8 } };
+    if (!sh.R) {
+        sh = tb_shape{ 8, 8 };
+        const int tiles88 = ((a.W + TB_OW - 1) / TB_OW) * ((hi - lo + 47) / 48);
+        if (tiles88 <= 4096 && n == TB_T && a.rowclass) {
+            tune = &o->tb_tuning[std::make_pair(lo, hi)];
+            if (tune->chosen < 0) {
+                if (!o->tune_ev0 && (hipEventCreate(&o->tune_ev0) != hipSuccess || hipEventCreate(&o->tune_ev1) != hipSuccess))
+                    return dmg_fail(DMG_EHIP, "hipEventCreate failed");
+                cand = 0;
+                while (cand < 3 && tune->trials[cand] >= 2) cand++;
+                if (cand == 3) {
+                    tune->chosen = 0;
+                    for (int c = 1; c < 3; c++) if (tune->best_ms[c] < tune->best_ms[tune->chosen]) tune->chosen = c;
+                    cand = -1;
+                } else ms = &ms_val;
+            }
+            sh = cands[cand >= 0 ? cand : tune->chosen];
+        }
+    }
+    if (sh.R == 4) tb_launch<4, 8>(o, a, a.W, hi - lo, st, ms);
+    else if (sh.R == 6) tb_launch<6, 8>(o, a, a.W, hi - lo, st, ms);
+    else if (sh.R == 16) tb_launch<16, 8>(o, a, a.W, hi - lo, st, ms);
+    else if (sh.R == 10) tb_launch<10, 8>(o, a, a.W, hi - lo, st, ms);
+    else if (sh.R == 12) tb_launch<12, 8>(o, a, a.W, hi - lo, st, ms);
+    else if (sh.NW == 16) tb_launch<8, 16>(o, a, a.W, hi - lo, st, ms);
+    else tb_launch<8, 8>(o, a, a.W, hi - lo, st, ms);
+    if (ms && cand >= 0) {
+        tune->trials[cand]++;
+        if (ms_val < tune->best_ms[cand]) tune->best_ms[cand] = ms_val;
+    }
     DMG_HIP(hipGetLastError());
     return DMG_OK;
 }
