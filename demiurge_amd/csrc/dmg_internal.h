@@ -9,6 +9,7 @@
 #include <string>
 #include <vector>
 #include "../../include/demiurge_hip.h"
+#include "glsl_math.h"
 
 struct dmg_ctx {
     // scratch blocks handed back by finished calls, by size.  The filters that loop (erosion: ~45 temporaries per
@@ -75,7 +76,7 @@ inline void dmg_row_pixelsize(const dmg_grid &g, int y, float *dx, float *dy)
 {
     float lat = dmg_row_lat(g, y);
     float two_pi = 2.0f * DMG_PI;
-    *dx = ((g.coords[3] - g.coords[2]) * cosf(lat)) * g.circumference / two_pi / (float)g.W;
+    *dx = ((g.coords[3] - g.coords[2]) * glsl::cos(lat)) * g.circumference / two_pi / (float)g.W;   // the shader's runtime cos
     *dy = (g.coords[1] - g.coords[0]) * g.circumference / two_pi / (float)g.H;
 }
 

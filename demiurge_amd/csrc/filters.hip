@@ -64,24 +64,23 @@ static std::vector<float> blur_rlist(float radius)
 __device__ __forceinline__ float d_sign(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
 
 // QDay(phi, M) (:69-95) -> absorbed solar radiation of the row, ASR = (1-0.30)*QDay (:102,:122)
-__global__ void k_temperature_rows(canvas c, const float *__restrict__ lat, float M, float *__restrict__ asr)
+__global__ void k_temperature_rows(canvas c, const float *__restrict__ lat, float M, float sin_gamma, float *__restrict__ asr)
 {
     int y = blockIdx.x * blockDim.x + threadIdx.x;
     if (y >= c.H) return;
     float phi = lat[y];
     const float eccentricity = 0.017f;
-    const float gamma = 23.44f / 180.0f * DMG_PI;
     const float omega = 0.0f, omega2 = 77.05f / 180.0f * DMG_PI;
     const float S0 = 1365.0f;
     float e3 = eccentricity * eccentricity * eccentricity;
-    float A = M + (2.0f * eccentricity - e3 / 4.0f * sinf(M) + 5.0f / 4.0f * (eccentricity * eccentricity) * sinf(2.0f * M)
-                   + 13.0f / 12.0f * e3 * sinf(3.0f * M));
+    float A = M + (2.0f * eccentricity - e3 / 4.0f * glsl::sin(M) + 5.0f / 4.0f * (eccentricity * eccentricity) * glsl::sin(2.0f * M)
+                   + 13.0f / 12.0f * e3 * glsl::sin(3.0f * M));
     float Ls = A - omega2;
-    float delt = asinf(sinf(gamma) * sinf(Ls));
+    float delt = glsl::asin(sin_gamma * glsl::sin(Ls));
     float h = d_sign(phi) == d_sign(delt) ? DMG_PI : 0.0f;
-    if (fabsf(phi) <= DMG_PI / 2.0f - fabsf(delt)) h = acosf(-tanf(phi) * tanf(delt));
-    float S = S0 * (1.0f + 2.0f * eccentricity * cosf(A - omega));
-    float q = S / DMG_PI * (h * sinf(phi) * sinf(delt) + cosf(phi) * cosf(delt) * sinf(h));
+    if (fabsf(phi) <= DMG_PI / 2.0f - fabsf(delt)) h = glsl::acos(-glsl::tan(phi) * glsl::tan(delt));
+    float S = S0 * (1.0f + 2.0f * eccentricity * glsl::cos(A - omega));
+    float q = S / DMG_PI * (h * glsl::sin(phi) * glsl::sin(delt) + glsl::cos(phi) * glsl::cos(delt) * glsl::sin(h));
     asr[y] = (1.0f - 0.30f) * q;
 }
 
@@ -173,7 +172,7 @@ __device__ __forceinline__ float d_slope(const canvas &c, const float *img, int 
     float G = img[d_step(c, x, y, -1, 1)], Hh = img[d_step(c, x, y, 0, 1)], I = img[d_step(c, x, y, 1, 1)];
     float gx = __fdiv_rn(__fadd_rn(-__fadd_rn(__fadd_rn(C, __fmul_rn(2.0f, F)), I), __fadd_rn(__fadd_rn(A, __fmul_rn(2.0f, D)), G)), __fmul_rn(8.0f, psx));
     float gy = __fdiv_rn(__fsub_rn(__fadd_rn(__fadd_rn(G, __fmul_rn(2.0f, Hh)), I), __fadd_rn(__fadd_rn(A, __fmul_rn(2.0f, B)), C)), __fmul_rn(8.0f, psy));
-    return atanf(__fmul_rn(1.0f, sqrtf(__fadd_rn(__fmul_rn(gx, gx), __fmul_rn(gy, gy)))));
+    return glsl::atan(__fmul_rn(1.0f, sqrtf(__fadd_rn(__fmul_rn(gx, gx), __fmul_rn(gy, gy)))));
 }
 
 // talus "loss" pass (:30-72)
@@ -246,7 +245,7 @@ int blur_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, fl
 {
     canvas c = make_canvas(grid, topo);
     std::vector<float> pf(grid.H);
-    for (int y = 0; y < grid.H; y++) pf[y] = cosf(fabsf(dmg_row_lat(grid, y)));   // BlurMenu.cpp:49
+    for (int y = 0; y < grid.H; y++) pf[y] = glsl::cos(fabsf(dmg_row_lat(grid, y)));   // BlurMenu.cpp:49
     dev_buf dpf;
     int rc = upload_rows(ctx, dpf, pf);
     if (rc) return rc;
@@ -310,7 +309,7 @@ int dmg_temperature_steps(dmg_ctx *ctx, const dmg_grid *grid, float *T, const fl
         float dx, dy;
         dmg_row_pixelsize(*grid, y, &dx, &dy);
         lat[y] = dmg_row_lat(*grid, y);
-        cosphi[y] = cosf(lat[y]);
+        cosphi[y] = glsl::cos(lat[y]);
         dyr[y] = dy;
     }
     dev_buf a, b, terr, dlat, dcos, ddy, dasr;
@@ -320,9 +319,10 @@ int dmg_temperature_steps(dmg_ctx *ctx, const dmg_grid *grid, float *T, const fl
     DMG_HIP(hipMemcpyAsync(terr.p, terrain, n * 4, hipMemcpyHostToDevice, ctx->stream));
     float *cur = a.f(), *nxt = b.f();
     dim3 g((W + 255) / 256, H);
+    const float sin_gamma = sinf(23.44f / 180.0f * DMG_PI);   // sin(gamma): an expression of constants, folded by Mesa on the host
     for (int i = first_step; i < first_step + n_steps; i++) {
         float M = (float)(M_PI * 2 / 15000 * i);     // glUniform1f(id, M_PI*2/15000*i) (:146)
-        hipLaunchKernelGGL(k_temperature_rows, dim3((H + 255) / 256), dim3(256), 0, ctx->stream, c, dlat.f(), M, dasr.f());
+        hipLaunchKernelGGL(k_temperature_rows, dim3((H + 255) / 256), dim3(256), 0, ctx->stream, c, dlat.f(), M, sin_gamma, dasr.f());
         hipLaunchKernelGGL(k_temperature, g, dim3(256), 0, ctx->stream, c, cur, nxt, terr.f(), dasr.f(), dcos.f(), ddy.f());
         DMG_HIP(hipGetLastError());
         std::swap(cur, nxt);                         // terrain.swap(scratch2) (:148)
@@ -446,9 +446,9 @@ static int morph_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &
 {
     canvas c = make_canvas(grid, topo);
     std::vector<float> fac(grid.H);
-    for (int y = 0; y < grid.H; y++) fac[y] = 1 / cosf(fabsf(dmg_row_lat(grid, y)));     // :53-54
+    for (int y = 0; y < grid.H; y++) fac[y] = 1 / glsl::cos(fabsf(dmg_row_lat(grid, y)));     // :53-54
     ring64 ring;
-    for (int i = 0; i < 64; i++) { float a = 2 * 3.14159f * (float)i / 64.0f; ring.cs[i] = cosf(a); ring.sn[i] = sinf(a); }
+    for (int i = 0; i < 64; i++) { float a = 2 * 3.14159f * (float)i / 64.0f; ring.cs[i] = glsl::cos(a); ring.sn[i] = glsl::sin(a); }   // a 64-iteration shader loop: runtime sin/cos
     dev_buf dfac;
     int rc = upload_rows(ctx, dfac, fac);
     if (rc) return rc;

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void k_flow_direction(flow_canvas fc, const fl
                          __fmul_rn(8.0f, dxrow[y]));
     float gy = __fdiv_rn(__fsub_rn(__fadd_rn(__fadd_rn(G, __fmul_rn(2.0f, Hh)), I), __fadd_rn(__fadd_rn(A, __fmul_rn(2.0f, B)), C)),
                          __fmul_rn(8.0f, dyrow[y]));
-    float aspect = __fsub_rn(DMG_PI, atan2f(gy, -gx));
+    float aspect = __fsub_rn(DMG_PI, glsl::atan2(gy, -gx));
     const float two_pi = 2.0f * DMG_PI;
     float lower = __fmul_rn(__fmul_rn(__fdiv_rn(floorf(__fmul_rn(__fdiv_rn(aspect, two_pi), 8.0f)), 8.0f), 2.0f), DMG_PI);
     float upper = __fmul_rn(__fmul_rn(__fdiv_rn(ceilf(__fmul_rn(__fdiv_rn(aspect, two_pi), 8.0f)), 8.0f), 2.0f), DMG_PI);
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void k_flow_direction(flow_canvas fc, const fl
     float sx = d_stx(c, x), sy = d_sty(c, y);
     float q = __fadd_rn(__fmul_rn(d_flow_noise(__fmul_rn(__fmul_rn(sx, (float)c.W), 2.0f), __fmul_rn(__fmul_rn(sy, (float)c.H), 2.0f)), 0.5f), 0.5f);
     aspect = (q < prob) ? upper : lower;
-    int dx = (int)roundf(cosf(aspect)), dy = -(int)roundf(sinf(aspect));
+    int dx = (int)roundf(glsl::cos(aspect)), dy = -(int)roundf(glsl::sin(aspect));
     int fcode = 5 + dx + 3 * dy;                       // keypad code of (dx,dy): 9=(1,1) 8=(0,1) .. 1=(-1,-1); (0,0) stays 5
     int n = d_step(c, x, y, dx, dy);
     float a2 = img[n];

@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <cstdint>
 #include "canvas.h"
+#include "glsl_math.h"
 #include "ocean_internal.h"
 
 namespace {
@@ -35,34 +36,7 @@ __device__ __forceinline__ float step(float edge, float x) { return x < edge ? 0
 __device__ __forceinline__ float mod289(float x) { return x - floorf(x * (1.0f / 289.0f)) * 289.0f; }
 __device__ __forceinline__ float permute(float x) { return mod289(((x * 34.0f) + 1.0f) * x); }
 
-// sin and cos of one argument (same evaluation as tectonics.hip: Cephes octants, fused where gallivm fuses)
-__device__ __forceinline__ void n_sincos(float xin, float *sn, float *cs)
-{
-    float x = fabsf(xin);
-    int j = (int)(x * 1.27323954473516f);
-    j = (j + 1) & ~1;
-    float y = (float)j;
-    x = fmaf(y, -0.78515625f, x);
-    x = fmaf(y, -2.4187564849853515625e-4f, x);
-    x = fmaf(y, -3.77489497744594108e-8f, x);
-    float z = x * x;
-    float yc = 2.443315711809948E-005f;
-    yc = fmaf(yc, z, -1.388731625493765E-003f);
-    yc = fmaf(yc, z, 4.166664568298827E-002f);
-    yc = yc * z;
-    yc = yc * z;
-    yc = yc - z * 0.5f;
-    yc = yc + 1.0f;
-    float ys = -1.9515295891E-4f;
-    ys = fmaf(ys, z, 8.3321608736E-3f);
-    ys = fmaf(ys, z, -1.6666654611E-1f);
-    ys = ys * z;
-    ys = fmaf(ys, x, x);
-    int j2 = j - 2;
-    float s = (j & 2) ? yc : ys, c = (j2 & 2) ? yc : ys;
-    *sn = __uint_as_float(__float_as_uint(s) ^ (__float_as_uint(xin) & 0x80000000u) ^ ((unsigned)(j & 4) << 29));
-    *cs = __uint_as_float(__float_as_uint(c) ^ ((unsigned)(~j2 & 4) << 29));
-}
+__device__ __forceinline__ void n_sincos(float x, float *s, float *c) { glsl::sincos(x, s, c); }   // glsl_math.h
 
 // snoise(v, out gradient) (:97-175)
 __device__ float snoise(v3 v, v3 *gradient)

@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void k_subdiv(pass_args a)
     float fx = __fsub_rn(oldV.x, __fdiv_rn(__fdiv_rn(__fdiv_rn(__fdiv_rn(__fmul_rn(0.5f, __fsub_rn(pE, pW)), pwx), dx), dy), a.pressurefactor));
     float fy = __fsub_rn(oldV.y, __fdiv_rn(__fdiv_rn(__fdiv_rn(__fdiv_rn(__fmul_rn(0.5f, __fsub_rn(pN, pS)), pwy), dx), dy), a.pressurefactor));
     unsigned o8 = a.code8[i];                                             // o_array[k] > 0  <=>  bit k
-    float ang = __fadd_rn(__fmul_rn(__fdiv_rn(__fadd_rn(__fdiv_rn(atan2f(fy, fx), DMG_PI), 1.0f), 2.0f), 8.0f), 4.0f);
+    float ang = __fadd_rn(__fmul_rn(__fdiv_rn(__fadd_rn(__fdiv_rn(glsl::atan2(fy, fx), DMG_PI), 1.0f), 2.0f), 8.0f), 4.0f);
     float lower = glsl_mod(floorf(ang), 8.0f), upper = glsl_mod(ceilf(ang), 8.0f), theta = glsl_mod(ang, 8.0f);
     int il = min(max((int)lower, 0), 7), iu = min(max((int)upper, 0), 7);
     bool isBorder = ((o8 >> il) & 1u) || ((o8 >> iu) & 1u);
@@ -175,20 +175,20 @@ __device__ __forceinline__ vec3 cross3(vec3 a, vec3 b)
 { return v3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y); }
 __device__ __forceinline__ float dot3(vec3 a, vec3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 __device__ __forceinline__ vec3 norm3(vec3 a) { float r = 1.0f / sqrtf(dot3(a, a)); return v3(a.x * r, a.y * r, a.z * r); }
-__device__ __forceinline__ vec3 sph2cart(float lon, float lat) { return v3(cosf(lat) * cosf(lon), cosf(lat) * sinf(lon), sinf(lat)); }
+__device__ __forceinline__ vec3 sph2cart(float lon, float lat) { return v3(glsl::cos(lat) * glsl::cos(lon), glsl::cos(lat) * glsl::sin(lon), glsl::sin(lat)); }
 // v_to_cartesian / cartesian_to_v (:251-268)
 __device__ __forceinline__ void tangent_basis(float lon, float lat, vec3 *par, vec3 *ycomp)
 {
     vec3 c = sph2cart(lon, lat);
     float il = 1.0f / sqrtf(c.x * c.x + c.y * c.y);
     float inx = c.x * il, iny = c.y * il;
-    *ycomp = v3(sinf(lat) * (-inx), sinf(lat) * (-iny), cosf(lat));
+    *ycomp = v3(glsl::sin(lat) * (-inx), glsl::sin(lat) * (-iny), glsl::cos(lat));
     *par = norm3(cross3(v3(0, 0, 1), c));
 }
 // rotation_matrix(theta,u)*v (reference src/Shader.h:35-40; mat3 columns)
 __device__ __forceinline__ vec3 rotate3(float theta, vec3 u, vec3 v)
 {
-    float c = cosf(theta), s = sinf(theta), ic = 1.0f - c;
+    float c = glsl::cos(theta), s = glsl::sin(theta), ic = 1.0f - c;
     vec3 c0 = v3(c + u.x * u.x * ic, u.y * u.x * ic + u.z * s, u.z * u.x * ic - u.y * s);
     vec3 c1 = v3(u.x * u.y * ic - u.z * s, c + u.y * u.y * ic, u.z * u.y * ic + u.x * s);
     vec3 c2 = v3(u.x * u.z * ic + u.y * s, u.y * u.z * ic - u.x * s, c + u.z * u.z * ic);
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void k_advect(pass_args a, float k04)
     vec3 v_cart = v3(par.x * vel.x + yc.x * vel.y, par.y * vel.x + yc.y * vel.y, par.z * vel.x + yc.z * vel.y);
     vec3 rotdir = norm3(cross3(cart, v_cart));                                     // :306
     cart = rotate3(-arclength, rotdir, cart);                                      // :308
-    float lon_n = atan2f(cart.y, cart.x), lat_n = asinf(cart.z);                   // cartesian_to_spheric
+    float lon_n = glsl::atan2(cart.y, cart.x), lat_n = glsl::asin(cart.z);                   // cartesian_to_spheric
     float cu = (lon_n - a.c2) / (a.c3 - a.c2), cv = (lat_n - a.c0) / (a.c1 - a.c0);   // spheric_to_tex
     float2 nv = fetch_linear2(a.vin, W, a.H, cu, cv, a.y_first, a.L, a.oob_flag);  // :315
     vec3 par_n, yc_n;
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void k_advect(pass_args a, float k04)
     if (isnan(nvx) || isnan(nvy)) { nvx = 0.0f; nvy = 0.0f; }                      // :321 (zero velocity: normalize(0))
     float fcx = 1.0f * nvx, fcy = 1.0f * nvy;                                      // Dissipation :332; Coriolis x0.0 (:327)
     float phi = 2.0f * (sy - 0.5f) * 3.14159f;                                     // :341
-    float windx = a.wind * -cosf(phi * 3.0f / 2.0f), windy = a.wind * sinf(phi * 3.0f / 2.0f);
+    float windx = a.wind * -glsl::cos(phi * 3.0f / 2.0f), windy = a.wind * glsl::sin(phi * 3.0f / 2.0f);
     if (fabsf(phi * 3.0f / 2.0f) > 3.14159f) windx = -windx;
     if (fabsf(phi) > 3.14159f * 1.0f / 3.0f && fabsf(phi) < 3.1459f * 2.0f / 3.0f) windy = -windy;   // sic 3.1459 (:344)
     if (phi < 0.0f) windy = -windy;

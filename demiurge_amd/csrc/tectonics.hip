@@ -33,87 +33,19 @@
 // CHOICE, so "close" transcendentals would move plate boundaries; these forms are the ones the reference's pixels
 // were produced with.
 #include "canvas.h"
+#include "glsl_math.h"
 
 namespace {
 
 constexpr int TECT_MAX_PLATES = 8;
-constexpr float T_PI_2 = 1.57079632679489661923f;
-constexpr float T_PI_4 = 0.78539816339744830962f;
 
 // ------------------------------------------------------------------------------------------------ transcendentals
-__device__ __forceinline__ float t_sign(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
-
-// asin(x) = sign(x) * (pi/2 - sqrt(1-|x|) * (pi/2 + |x| (pi/4 - 1 + |x| (p0 + |x| p1))))
-__device__ __forceinline__ float t_asin(float x)
-{
-    float ax = fabsf(x);
-    float t = 0.086566724f + ax * -0.03102955f;
-    t = (T_PI_4 - 1.0f) + ax * t;
-    t = T_PI_2 + ax * t;
-    return t_sign(x) * (T_PI_2 - sqrtf(1.0f - ax) * t);
-}
-
-// atan for a >= 0: reduce to [0,1], odd degree-11 polynomial accumulated from the lowest power
-__device__ __forceinline__ float t_atan_pos(float a)
-{
-    float x = fminf(a, 1.0f) / fmaxf(a, 1.0f);
-    float x2 = x * x, x3 = x2 * x, x5 = x3 * x2, x7 = x5 * x2, x9 = x7 * x2, x11 = x9 * x2;
-    float p = x * 0.9999793128310355f;
-    p = p + x3 * -0.3326756418091246f;
-    p = p + x5 * 0.1938924977115610f;
-    p = p + x7 * -0.1173503194786851f;
-    p = p + x9 * 0.0536813784310406f;
-    p = p + x11 * -0.0121323213173444f;
-    p = p + (a > 1.0f ? 1.0f : 0.0f) * (p * -2.0f + T_PI_2);
-    return p * t_sign(a);
-}
-
-__device__ __forceinline__ float t_atan2(float y, float x)
-{
-    bool flip = 0.0f >= x;
-    float s = flip ? fabsf(x) : y;
-    float t = flip ? y : fabsf(x);
-    float scale = fabsf(t) >= 1e18f ? 0.25f : 1.0f;
-    float rcp_scaled_t = 1.0f / (t * scale);
-    float s_over_t = (s * scale) * rcp_scaled_t;
-    float tn = fabsf(x) == fabsf(y) ? 1.0f : fabsf(s_over_t);
-    float arc = (flip ? 1.0f : 0.0f) * T_PI_2 + t_atan_pos(tn);
-    return fminf(y, rcp_scaled_t) < 0.0f ? -arc : arc;
-}
-
-// sin and cos of one argument: shared octant reduction (three-part pi/4) and both minimax polynomials
-__device__ __forceinline__ void t_sincos(float xin, float *sn, float *cs)
-{
-    float x = fabsf(xin);
-    int j = (int)(x * 1.27323954473516f);
-    j = (j + 1) & ~1;
-    float y = (float)j;
-    x = fmaf(y, -0.78515625f, x);
-    x = fmaf(y, -2.4187564849853515625e-4f, x);
-    x = fmaf(y, -3.77489497744594108e-8f, x);
-    float z = x * x;
-    float yc = 2.443315711809948E-005f;
-    yc = fmaf(yc, z, -1.388731625493765E-003f);
-    yc = fmaf(yc, z, 4.166664568298827E-002f);
-    yc = yc * z;
-    yc = yc * z;
-    yc = yc - z * 0.5f;
-    yc = yc + 1.0f;
-    float ys = -1.9515295891E-4f;
-    ys = fmaf(ys, z, 8.3321608736E-3f);
-    ys = fmaf(ys, z, -1.6666654611E-1f);
-    ys = ys * z;
-    ys = fmaf(ys, x, x);
-    int j2 = j - 2;
-    float s = (j & 2) ? yc : ys;
-    float c = (j2 & 2) ? yc : ys;
-    unsigned ssign = (__float_as_uint(xin) & 0x80000000u) ^ ((unsigned)(j & 4) << 29);
-    unsigned csign = (unsigned)(~j2 & 4) << 29;
-    *sn = __uint_as_float(__float_as_uint(s) ^ ssign);
-    *cs = __uint_as_float(__float_as_uint(c) ^ csign);
-}
-__device__ __forceinline__ float t_sin(float x) { float s, c; t_sincos(x, &s, &c); return s; }
-__device__ __forceinline__ float t_cos(float x) { float s, c; t_sincos(x, &s, &c); return c; }
+// glsl_math.h: the forms Mesa / gallivm evaluate, bit for bit
+__device__ __forceinline__ float t_asin(float x) { return glsl::asin(x); }
+__device__ __forceinline__ float t_atan2(float y, float x) { return glsl::atan2(y, x); }
+__device__ __forceinline__ void t_sincos(float x, float *s, float *c) { glsl::sincos(x, s, c); }
+__device__ __forceinline__ float t_sin(float x) { return glsl::sin(x); }
+__device__ __forceinline__ float t_cos(float x) { return glsl::cos(x); }
 
 // ------------------------------------------------------------------------------------------------ geometry
 struct tex4 { float4 *p; int w, h; };

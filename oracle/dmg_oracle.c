@@ -8,6 +8,7 @@
 #include "dmg_oracle.h"
 #define _GNU_SOURCE
 #include <math.h>
+#include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP
@@ -40,6 +41,82 @@ static int nthreads_rows(int H, int want)
     int cap = H / 16;
     if (cap < 1) cap = 1;
     return n < cap ? n : cap;
+}
+
+/* ---------- GLSL transcendentals ----------
+ * mode 1 (default): as llvmpipe evaluates them -- asin / acos / atan / atan2 in the polynomial forms Mesa 23.2's
+ * compiler expands them to, sin / cos in gallivm's Cephes scheme, tan = sin / cos (pinned with probe shaders, see
+ * tect_oracle.c); mode 0: libm.  Expressions of constants are folded by Mesa on the host and stay libm calls. */
+static int g_glsl_math = 1;
+void orc_set_glsl_math(int mode) { g_glsl_math = mode; }
+static inline float m_sgn(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
+static inline void lp_sincos(float xin, float *sn, float *cs)
+{
+    float x = fabsf(xin);
+    int32_t j = (int32_t)(x * 1.27323954473516f);
+    j = (j + 1) & ~1;
+    float y = (float)j;
+    x = fmaf(y, -0.78515625f, x);
+    x = fmaf(y, -2.4187564849853515625e-4f, x);
+    x = fmaf(y, -3.77489497744594108e-8f, x);
+    float z = x * x;
+    float yc = 2.443315711809948E-005f;
+    yc = fmaf(yc, z, -1.388731625493765E-003f);
+    yc = fmaf(yc, z, 4.166664568298827E-002f);
+    yc = yc * z;
+    yc = yc * z;
+    yc = yc - z * 0.5f;
+    yc = yc + 1.0f;
+    float ys = -1.9515295891E-4f;
+    ys = fmaf(ys, z, 8.3321608736E-3f);
+    ys = fmaf(ys, z, -1.6666654611E-1f);
+    ys = ys * z;
+    ys = fmaf(ys, x, x);
+    int32_t j2 = j - 2;
+    float s = (j & 2) ? yc : ys, c = (j2 & 2) ? yc : ys;
+    uint32_t sb, cb, xb;
+    memcpy(&xb, &xin, 4); memcpy(&sb, &s, 4); memcpy(&cb, &c, 4);
+    sb ^= (xb & 0x80000000u) ^ (((uint32_t)(j & 4)) << 29);
+    cb ^= ((uint32_t)(~j2 & 4)) << 29;
+    memcpy(sn, &sb, 4); memcpy(cs, &cb, 4);
+}
+static inline float gsin(float x) { if (!g_glsl_math) return sinf(x); float s, c; lp_sincos(x, &s, &c); return s; }
+static inline float gcos(float x) { if (!g_glsl_math) return cosf(x); float s, c; lp_sincos(x, &s, &c); return c; }
+static inline float gtan(float x) { if (!g_glsl_math) return tanf(x); float s, c; lp_sincos(x, &s, &c); return s / c; }
+static inline float m_asin_poly(float x, float p0, float p1)
+{
+    float ax = fabsf(x);
+    float t = p0 + ax * p1;
+    t = (0.78539816339744830962f - 1.0f) + ax * t;
+    t = 1.57079632679489661923f + ax * t;
+    return m_sgn(x) * (1.57079632679489661923f - sqrtf(1.0f - ax) * t);
+}
+static inline float gasin(float x) { return g_glsl_math ? m_asin_poly(x, 0.086566724f, -0.03102955f) : asinf(x); }
+static inline float gacos(float x) { return g_glsl_math ? 1.57079632679489661923f - m_asin_poly(x, 0.08132463f, -0.02363318f) : acosf(x); }
+static inline float m_atan_pos(float a)
+{
+    float x = fminf(a, 1.0f) / fmaxf(a, 1.0f);
+    float x2 = x * x, x3 = x2 * x, x5 = x3 * x2, x7 = x5 * x2, x9 = x7 * x2, x11 = x9 * x2;
+    float p = x * 0.9999793128310355f;
+    p = p + x3 * -0.3326756418091246f;
+    p = p + x5 * 0.1938924977115610f;
+    p = p + x7 * -0.1173503194786851f;
+    p = p + x9 * 0.0536813784310406f;
+    p = p + x11 * -0.0121323213173444f;
+    return p + (a > 1.0f ? 1.0f : 0.0f) * (p * -2.0f + 1.57079632679489661923f);
+}
+static inline float gatan(float x) { return g_glsl_math ? m_atan_pos(fabsf(x)) * m_sgn(x) : atanf(x); }
+static inline float gatan2(float y, float x)
+{
+    if (!g_glsl_math) return atan2f(y, x);
+    int flip = 0.0f >= x;
+    float s = flip ? fabsf(x) : y, t = flip ? y : fabsf(x);
+    float scale = fabsf(t) >= 1e18f ? 0.25f : 1.0f;
+    float rcp = 1.0f / (t * scale);
+    float sot = (s * scale) * rcp;
+    float tn = fabsf(x) == fabsf(y) ? 1.0f : fabsf(sot);
+    float arc = (flip ? 1.0f : 0.0f) * 1.57079632679489661923f + m_atan_pos(tn) * m_sgn(tn);
+    return fminf(y, rcp) < 0.0f ? -arc : arc;
 }
 
 /* ---------- GLSL built-ins ---------- */
@@ -100,7 +177,7 @@ static inline void spheric_to_tex(const orc_grid *g, float lon, float lat, float
 
 static inline vec3 spheric_to_cartesian(float lon, float lat)
 {   /* :61-63 */
-    return v3(cosf(lat) * cosf(lon), cosf(lat) * sinf(lon), sinf(lat));
+    return v3(gcos(lat) * gcos(lon), gcos(lat) * gsin(lon), gsin(lat));
 }
 
 /* pixelsize(st) :71-74 -- `vec2(dlon*cos(lat), dlat)*circumference/(2*M_PI) / textureSize(img,0)` */
@@ -109,7 +186,7 @@ void orc_pixelsize(const orc_grid *g, float sty, float *dx, float *dy)
     float lon, lat;
     orc_tex_to_spheric(g, 0.0f, sty, &lon, &lat);
     float two_pi = 2.0f * MPI;
-    *dx = ((g->coords[3] - g->coords[2]) * cosf(lat)) * g->circumference / two_pi / (float)g->W;
+    *dx = ((g->coords[3] - g->coords[2]) * gcos(lat)) * g->circumference / two_pi / (float)g->W;
     *dy = (g->coords[1] - g->coords[0]) * g->circumference / two_pi / (float)g->H;
 }
 
@@ -384,7 +461,7 @@ static inline vec3 v_to_cartesian(float vx, float vy, float lon, float lat)
     vec3 c = spheric_to_cartesian(lon, lat);
     float il = 1.0f / sqrtf(c.x * c.x + c.y * c.y);
     float inx = c.x * il, iny = c.y * il;                                   /* normalize(c.xy) */
-    vec3 ycomp = v3(sinf(lat) * (-inx), sinf(lat) * (-iny), cosf(lat));
+    vec3 ycomp = v3(gsin(lat) * (-inx), gsin(lat) * (-iny), gcos(lat));
     vec3 par = v3_normalize(v3_cross(v3(0, 0, 1), c));
     return v3_add(v3_scale(par, vx), v3_scale(ycomp, vy));
 }
@@ -393,7 +470,7 @@ static inline void cartesian_to_v(vec3 v, float lon, float lat, float *ox, float
     vec3 c = spheric_to_cartesian(lon, lat);
     float il = 1.0f / sqrtf(c.x * c.x + c.y * c.y);
     float inx = c.x * il, iny = c.y * il;
-    vec3 ycomp = v3(sinf(lat) * (-inx), sinf(lat) * (-iny), cosf(lat));
+    vec3 ycomp = v3(gsin(lat) * (-inx), gsin(lat) * (-iny), gcos(lat));
     vec3 par = v3_normalize(v3_cross(v3(0, 0, 1), c));
     *ox = v3_dot(v, par);
     *oy = v3_dot(v, ycomp);
@@ -401,7 +478,7 @@ static inline void cartesian_to_v(vec3 v, float lon, float lat, float *ox, float
 /* rotation_matrix(theta,u)*v (src/Shader.h:35-40): mat3 is column-major, M*v = c0*v.x + c1*v.y + c2*v.z */
 static inline vec3 rotate(float theta, vec3 u, vec3 v)
 {
-    float c = cosf(theta), s = sinf(theta), ic = 1.0f - c;
+    float c = gcos(theta), s = gsin(theta), ic = 1.0f - c;
     vec3 c0 = v3(c + u.x * u.x * ic, u.y * u.x * ic + u.z * s, u.z * u.x * ic - u.y * s);
     vec3 c1 = v3(u.x * u.y * ic - u.z * s, c + u.y * u.y * ic, u.z * u.y * ic + u.x * s);
     vec3 c2 = v3(u.x * u.z * ic + u.y * s, u.y * u.z * ic - u.x * s, c + u.z * u.z * ic);
@@ -430,7 +507,7 @@ void orc_ocean_advect(const orc_grid *g, const float *img, const float *v, float
             vec3 v_cart = v_to_cartesian(velx, vely, lon, lat);
             vec3 rotdir = v3_normalize(v3_cross(cart, v_cart));                    /* :306 */
             cart = rotate(-arclength, rotdir, cart);                               /* :308 */
-            float lon_n = atan2f(cart.y, cart.x), lat_n = asinf(cart.z);           /* cartesian_to_spheric */
+            float lon_n = gatan2(cart.y, cart.x), lat_n = gasin(cart.z);           /* cartesian_to_spheric */
             float cx, cy;
             spheric_to_tex(g, lon_n, lat_n, &cx, &cy);
             float nvx = fetch_linear(v, W, H, 2, 0, cx, cy), nvy = fetch_linear(v, W, H, 2, 1, cx, cy);   /* :315 */
@@ -441,7 +518,7 @@ void orc_ocean_advect(const orc_grid *g, const float *img, const float *v, float
             /* Coriolis term is multiplied by 0.0 (:327); NaN/Inf cannot arise from it once newV is finite */
             float fcx = 1.0f * nvx, fcy = 1.0f * nvy;                              /* Dissipation :332 */
             float phi = 2.0f * (sy - 0.5f) * 3.14159f;                             /* :341 */
-            float windx = 10.0f * -cosf(phi * 3.0f / 2.0f), windy = 10.0f * sinf(phi * 3.0f / 2.0f);
+            float windx = 10.0f * -gcos(phi * 3.0f / 2.0f), windy = 10.0f * gsin(phi * 3.0f / 2.0f);
             if (fabsf(phi * 3.0f / 2.0f) > 3.14159f) windx = -windx;
             if (fabsf(phi) > 3.14159f * 1.0f / 3.0f && fabsf(phi) < 3.1459f * 2.0f / 3.0f) windy = -windy;   /* sic 3.1459 */
             if (phi < 0) windy = -windy;
@@ -491,7 +568,7 @@ void orc_ocean_subdiv(const orc_grid *g, const float *img, const float *v, const
                 orc_offset(g, sx, sy, offsets[i][0], offsets[i][1], rx, ry, &qx, &qy);
                 o_array[i] = fetch_nearest(img, W, H, 1, 0, qx, qy);
             }
-            float ang = (atan2f(fy, fx) / MPI + 1.0f) / 2.0f * 8.0f + 4.0f;
+            float ang = (gatan2(fy, fx) / MPI + 1.0f) / 2.0f * 8.0f + 4.0f;
             float lower = glsl_mod(floorf(ang), 8.0f);
             float upper = glsl_mod(ceilf(ang), 8.0f);
             float theta = glsl_mod(ang, 8.0f);
@@ -500,6 +577,7 @@ void orc_ocean_subdiv(const orc_grid *g, const float *img, const float *v, const
             float difference = 2.0f * MPI;
             for (int i = 0; i < 8; i++) {
                 float ox = offsets[i][0], oy = offsets[i][1];
+                /* compass offsets are constants: the 8-iteration loop unrolls and Mesa folds this atan on the host */
                 float thetai = glsl_mod((atan2f(oy, ox) / MPI + 1.0f) / 2.0f * 8.0f + 4.0f, 8.0f);
                 float d = fabsf(thetai - theta);
                 float angleToVel = fminf((2.0f * MPI) - d, d);
@@ -556,7 +634,7 @@ void orc_blur13_pass(const orc_grid *g, const float *src, float dirx, float diry
         float sy = sty(g, y);
         float lon, lat;
         orc_tex_to_spheric(g, 0.0f, sy, &lon, &lat);
-        float phifactor = cosf(fabsf(lat));                                   /* :49 */
+        float phifactor = gcos(fabsf(lat));                                   /* :49 */
         float o1x = k1 * dirx / phifactor, o2x = k2 * dirx / phifactor, o3x = k3 * dirx / phifactor;
         float o1y = k1 * diry, o2y = k2 * diry, o3y = k3 * diry;
         for (int x = 0; x < W; x++) {
@@ -599,15 +677,15 @@ static float qday(float phi, float M)
     const float S0 = 1365.0f;
     /* A(M) :73-75 */
     float e3 = eccentricity * eccentricity * eccentricity;   /* pow(e,3) */
-    float A = M + (2.0f * eccentricity - e3 / 4.0f * sinf(M) + 5.0f / 4.0f * (eccentricity * eccentricity) * sinf(2.0f * M)
-                   + 13.0f / 12.0f * e3 * sinf(3.0f * M));
+    float A = M + (2.0f * eccentricity - e3 / 4.0f * gsin(M) + 5.0f / 4.0f * (eccentricity * eccentricity) * gsin(2.0f * M)
+                   + 13.0f / 12.0f * e3 * gsin(3.0f * M));
     float Ls = A - omega2;
-    float delt = asinf(sinf(gamma) * sinf(Ls));
+    float delt = gasin(sinf(gamma) * gsin(Ls));          /* sin(gamma) is a constant expression: folded on the host */
     /* h0 :85-89 */
     float h = glsl_sign(phi) == glsl_sign(delt) ? MPI : 0.0f;
-    if (fabsf(phi) <= MPI / 2.0f - fabsf(delt)) h = acosf(-tanf(phi) * tanf(delt));
-    float S = S0 * (1.0f + 2.0f * eccentricity * cosf(A - omega));
-    return S / MPI * (h * sinf(phi) * sinf(delt) + cosf(phi) * cosf(delt) * sinf(h));
+    if (fabsf(phi) <= MPI / 2.0f - fabsf(delt)) h = gacos(-gtan(phi) * gtan(delt));
+    float S = S0 * (1.0f + 2.0f * eccentricity * gcos(A - omega));
+    return S / MPI * (h * gsin(phi) * gsin(delt) + gcos(phi) * gcos(delt) * gsin(h));
 }
 
 void orc_temperature(const orc_grid *g, float *T, float *scratch, const float *terrain, int first_step, int n_steps)
@@ -623,7 +701,7 @@ void orc_temperature(const orc_grid *g, float *T, float *scratch, const float *t
             float lon, phi;
             orc_tex_to_spheric(g, 0.0f, sy, &lon, &phi);
             float ASR = (1.0f - 0.30f) * qday(phi, M);     /* :102,:122 */
-            float factor = cosf(phi);                      /* get_texture_laplacian, Shader.h:301-302 */
+            float factor = gcos(phi);                      /* get_texture_laplacian, Shader.h:301-302 */
             float dx, dy;
             orc_pixelsize(g, sy, &dx, &dy);
             float den = 4.0f * (dy * dy);                  /* 4*pow(pixelwidth.y,2) */
@@ -753,13 +831,13 @@ void orc_flow_direction(const orc_grid *g0, const float *img, const float *sel, 
             float A = t[0], B = t[1], C = t[2], D = t[3], F = t[5], G = t[6], Hh = t[7], I = t[8];
             float gx = (-(C + 2 * F + I) + (A + 2 * D + G)) / (8 * psx);
             float gy = ((G + 2 * Hh + I) - (A + 2 * B + C)) / (8 * psy);
-            float aspect = MPI - atan2f(gy, -gx);
+            float aspect = MPI - gatan2(gy, -gx);
             float lower_aspect = floorf(aspect / (2 * MPI) * 8) / 8 * 2 * MPI;
             float upper_aspect = ceilf(aspect / (2 * MPI) * 8) / 8 * 2 * MPI;
             float prob = fabsf(aspect - lower_aspect) / MPI * 4;
             float q = flow_noise(sx * rx * 2, sy * ry * 2) * 0.5f + 0.5f;
             aspect = (q < prob) ? upper_aspect : lower_aspect;
-            float dx = roundf(cosf(aspect)), dy = -roundf(sinf(aspect));
+            float dx = roundf(gcos(aspect)), dy = -roundf(gsin(aspect));
             if (dx == 1 && dy == 1) *fc = 9;
             if (dx == 0 && dy == 1) *fc = 8;
             if (dx == -1 && dy == 1) *fc = 7;
@@ -867,7 +945,7 @@ static float orc_slope(const orc_grid *g, const float *img, float sx, float sy, 
     float A = t[0], B = t[1], C = t[2], D = t[3], F = t[5], G = t[6], Hh = t[7], I = t[8];
     float gx = (-(C + 2 * F + I) + (A + 2 * D + G)) / (8 * psx);
     float gy = ((G + 2 * Hh + I) - (A + 2 * B + C)) / (8 * psy);
-    return atanf(1.0f * sqrtf(gx * gx + gy * gy));
+    return gatan(1.0f * sqrtf(gx * gx + gy * gy));
 }
 
 /* ThermalErosion::step (src/filter/ThermalErosion.cpp:25-142): 10 x { loss pass :30-72, gain pass :84-128 } in place */
@@ -943,12 +1021,12 @@ void orc_morph_pass(const orc_grid *g, const float *src, float radius, int use_m
 {
     const int W = g->W, H = g->H;
     float cs[64], sn[64];
-    for (int i = 0; i < 64; i++) { float a = 2 * 3.14159f * (float)i / 64.0f; cs[i] = cosf(a); sn[i] = sinf(a); }
+    for (int i = 0; i < 64; i++) { float a = 2 * 3.14159f * (float)i / 64.0f; cs[i] = gcos(a); sn[i] = gsin(a); }
 #pragma omp parallel for schedule(static) num_threads(nthreads_rows(H, 0))
     for (int y = 0; y < H; y++) {
         float sy = sty(g, y), lon, phi;
         orc_tex_to_spheric(g, 0.0f, sy, &lon, &phi);
-        float factor = 1 / cosf(fabsf(phi));
+        float factor = 1 / gcos(fabsf(phi));
         for (int x = 0; x < W; x++) {
             float sx = stx(g, x);
             float a = fetch_nearest(src, W, H, 1, 0, sx, sy);
