@@ -57,9 +57,9 @@ __device__ __forceinline__ float d_fetch_linear(const float *t, int W, int H, fl
     int i0 = min(max((int)flu, 0), W - 1), i1 = min(max((int)flu + 1, 0), W - 1);
     int j0 = min(max((int)flv, 0), H - 1), j1 = min(max((int)flv + 1, 0), H - 1);
     float t00 = t[(size_t)j0 * W + i0], t10 = t[(size_t)j0 * W + i1], t01 = t[(size_t)j1 * W + i0], t11 = t[(size_t)j1 * W + i1];
-    float a = __fadd_rn(t00, __fmul_rn(wx, __fsub_rn(t10, t00)));
-    float b = __fadd_rn(t01, __fmul_rn(wx, __fsub_rn(t11, t01)));
-    return __fadd_rn(a, __fmul_rn(wy, __fsub_rn(b, a)));
+    float a = fmaf(wx, __fsub_rn(t10, t00), t00);        // llvmpipe's lerp is one fused multiply-add (lp_build_lerp)
+    float b = fmaf(wx, __fsub_rn(t11, t01), t01);
+    return fmaf(wy, __fsub_rn(b, a), a);
 }
 
 __device__ __forceinline__ float d_stx(const canvas &c, int x) { return __fdiv_rn(__fadd_rn((float)x, 0.5f), (float)c.W); }

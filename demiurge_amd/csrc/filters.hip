@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void k_erosion(canvas c, const float *__restri
     }
     float hdiff = __fsub_rn(__fmul_rn(SLOPE, dist), __fmul_rn(maxslope, dist));   // :192
     // :195 factor*4*flow*pow(maxslope,n)/pow(0.1,n)*0.1
-    float fl = __fmul_rn(__fdiv_rn(__fmul_rn(__fmul_rn(__fmul_rn(factor, 4.0f), flow[i]), powf(maxslope, slope_exponent)), pow01), 0.1f);
+    float fl = __fmul_rn(__fdiv_rn(__fmul_rn(__fmul_rn(__fmul_rn(factor, 4.0f), flow[i]), glsl::pow(maxslope, slope_exponent)), pow01), 0.1f);
     float up = updrift[i];
     out[i] = __fadd_rn(h, fminf(hdiff, fmaxf(0.0f, __fsub_rn(up, fl))));           // :198
 }
@@ -267,7 +267,7 @@ int erosion_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo,
 {
     canvas c = make_canvas(grid, topo);
     float SLOPE = tanf(DMG_PI / 2.0f / 3.0f);        // tan(M_PI/2/3), 30 degrees (cpufilter.cpp:191)
-    float pow01 = powf(0.1f, slope_exponent);        // pow(0.1, slope_exponent): a constant of the pass
+    float pow01 = glsl::pow(0.1f, slope_exponent);   // pow(0.1, slope_exponent): the exponent is a uniform, so the shader's runtime pow
     dim3 g((grid.W + 255) / 256, grid.H);
     hipLaunchKernelGGL(k_erosion, g, dim3(256), 0, ctx->stream, c, d_h, d_flow, d_updrift, d_out, d_dx, d_dy,
                        factor, slope_exponent, SLOPE, pow01);

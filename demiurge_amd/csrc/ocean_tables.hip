@@ -23,9 +23,11 @@ int ocean_upload_row_tables(dmg_ocean *o)
         t[(size_t)RT_JRB * L + l] = 1.0f / beta;
         t[(size_t)RT_DX * L + l] = dx;
         t[(size_t)RT_DY * L + l] = dy;
-        float px = 1.0f / (dx * dx) * scale * scale;            // 1*1/pow(pixelsize,2)*420*420
-        float py = 1.0f / (dy * dy) * scale * scale;
-        float s = 2.0f * (px + py);
+        // 1*1/pow(pixelsize,2)*420*420 and 2*(pw2.x+pw2.y) as Mesa's algebraic pass leaves them (probe-pinned, see
+        // oracle/dmg_oracle.c orc_ocean_diffusion): the two constants merge, and the common factor is pulled out of the sum
+        float ix = 1.0f / (dx * dx), iy = 1.0f / (dy * dy);
+        float px = ix * (scale * scale), py = iy * (scale * scale);
+        float s = (ix + iy) * (2.0f * (scale * scale));
         t[(size_t)RT_DIFPX * L + l] = px;
         t[(size_t)RT_DIFPY * L + l] = py;
         t[(size_t)RT_DIFBETA * L + l] = s * (1.0f + 1.0f / s);

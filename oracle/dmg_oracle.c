@@ -119,6 +119,42 @@ static inline float gatan2(float y, float x)
     return fminf(y, rcp) < 0.0f ? -arc : arc;
 }
 
+/* pow(x, y) as gallivm evaluates it: exp2(y * log2(x)) with its own minimax polynomials (lp_build_exp2: degree 5 on
+ * the fraction; lp_build_log2_approx: degree 4 in z = y*y, y = (m-1)/(m+1); both evaluated as even/odd split Horner
+ * with fused multiply-adds, lp_build_polynomial).  Pinned against llvmpipe with a probe shader: exp2, log2 and pow
+ * bit-equal on 16384/16384 random arguments.  libm powf is 2e-6 away, which advect's `1 - pow(stress, -1/12)`
+ * amplifies by three orders. */
+static inline float lp_exp2(float x)
+{
+    x = fminf(x, 128.0f);
+    x = fmaxf(x, -126.99999f);
+    float ip = floorf(x), fp = x - ip;
+    int32_t e = ((int32_t)ip + 127) << 23;
+    float scale;
+    memcpy(&scale, &e, 4);
+    float x2 = fp * fp;
+    float odd = 0.00187757667519147912699f, even = 0.00898934009049466391101f;
+    odd = fmaf(x2, odd, 0.0558263180532956664775f); even = fmaf(x2, even, 0.240153617044375388211f);
+    odd = fmaf(x2, odd, 0.693153073200168932794f); even = fmaf(x2, even, 1.000000000000000000000f);
+    return scale * fmaf(odd, fp, even);
+}
+static inline float lp_log2(float x)
+{
+    int32_t i;
+    memcpy(&i, &x, 4);
+    float logexp = (float)(((i >> 23) & 255) - 127);
+    int32_t mi = (i & 0x007fffff) | 0x3f800000;
+    float mant;
+    memcpy(&mant, &mi, 4);
+    float y = (mant - 1.0f) / (mant + 1.0f);
+    float z = y * y, z2 = z * z;
+    float even = 0.406718052498846252698f, odd = 0.403343858251329912514f;
+    even = fmaf(z2, even, 0.577440339438736392009f); odd = fmaf(z2, odd, 0.961791550404184197881f);
+    even = fmaf(z2, even, 2.88539009343309178325f);
+    return fmaf(y, fmaf(odd, z, even), logexp);
+}
+static inline float gpow(float x, float y) { return g_glsl_math ? lp_exp2(lp_log2(x) * y) : powf(x, y); }
+
 /* ---------- GLSL built-ins ---------- */
 static inline float glsl_mod(float x, float y) { return x - y * floorf(x / y); }
 static inline float glsl_sign(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
@@ -126,7 +162,8 @@ typedef struct { float x, y, z; } vec3;
 static inline vec3 v3(float x, float y, float z) { vec3 r = { x, y, z }; return r; }
 static inline vec3 v3_cross(vec3 a, vec3 b)
 { return v3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y); }
-static inline float v3_dot(vec3 a, vec3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+/* Mesa lowers dot() from the last component down (pinned with probe shaders, noise_oracle.c) */
+static inline float v3_dot(vec3 a, vec3 b) { return (a.z * b.z + a.y * b.y) + a.x * b.x; }
 static inline vec3 v3_scale(vec3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
 static inline vec3 v3_add(vec3 a, vec3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
 static inline vec3 v3_normalize(vec3 a)
@@ -151,9 +188,11 @@ static inline float fetch_linear(const float *t, int W, int H, int nc, int c, fl
     int j0 = clampi((int)flv, 0, H - 1), j1 = clampi((int)flv + 1, 0, H - 1);
     float t00 = t[((size_t)j0 * W + i0) * nc + c], t10 = t[((size_t)j0 * W + i1) * nc + c];
     float t01 = t[((size_t)j1 * W + i0) * nc + c], t11 = t[((size_t)j1 * W + i1) * nc + c];
-    float a = t00 + wx * (t10 - t00);
-    float b = t01 + wx * (t11 - t01);
-    return a + wy * (b - a);
+    /* llvmpipe's lerp is a fused multiply-add: lp_build_lerp -> a + w*(b-a) through lp_build_mad (advect goldens:
+     * 699 -> 93 differing cells of 8192 with it) */
+    float a = fmaf(wx, t10 - t00, t00);
+    float b = fmaf(wx, t11 - t01, t01);
+    return fmaf(wy, b - a, a);
 }
 
 /* tap of a GL_LINEAR texture at a texel-centre-ish coordinate (see orc_set_linear_taps) */
@@ -430,10 +469,12 @@ void orc_ocean_diffusion(const orc_grid *g, const float *img, float *v, float *s
             float sy = sty(g, y);
             float dx, dy;
             orc_pixelsize(g, sy, &dx, &dy);
-            /* :689  1*1/pow(pixelsize(st),vec2(2,2))*420*420 */
-            float px2 = 1.0f / (dx * dx) * 420.0f * 420.0f;
-            float py2 = 1.0f / (dy * dy) * 420.0f * 420.0f;
-            float s = 2.0f * (px2 + py2);
+            /* :689  1*1/pow(pixelsize(st),vec2(2,2))*420*420 and :690 Beta.  Mesa's algebraic pass merges the two
+             * constants, pulls the common factor out of pw2.x + pw2.y, and associates the final sum as (bC + a) + b
+             * (pinned with a probe shader: each form 100 % bit-equal on 16384 random inputs, the literal forms 66-76 %) */
+            float ix = 1.0f / (dx * dx), iy = 1.0f / (dy * dy);
+            float px2 = ix * 176400.0f, py2 = iy * 176400.0f;
+            float s = (ix + iy) * 352800.0f;
             float Beta = s * (1.0f + 1.0f / s);          /* :690 */
             for (int x = 0; x < W; x++) {
                 float sx = stx(g, x);
@@ -446,8 +487,8 @@ void orc_ocean_diffusion(const orc_grid *g, const float *img, float *v, float *s
                 }
                 float bCx = pCx, bCy = scalar_rhs ? pCx : pCy;     /* :687 `float bC = texture(v,st).r` */
                 /* :693  ((pW + pE)*pw2.x + (pS + pN)*pw2.y - (-bC)) / Beta */
-                b[((size_t)y * W + x) * 2 + 0] = ((pv[3][0] + pv[2][0]) * px2 + (pv[1][0] + pv[0][0]) * py2 - (-bCx)) / Beta;
-                b[((size_t)y * W + x) * 2 + 1] = ((pv[3][1] + pv[2][1]) * px2 + (pv[1][1] + pv[0][1]) * py2 - (-bCy)) / Beta;
+                b[((size_t)y * W + x) * 2 + 0] = ((bCx + (pv[3][0] + pv[2][0]) * px2) + (pv[1][0] + pv[0][0]) * py2) / Beta;
+                b[((size_t)y * W + x) * 2 + 1] = ((bCy + (pv[3][1] + pv[2][1]) * px2) + (pv[1][1] + pv[0][1]) * py2) / Beta;
             }
         }
         float *t = a; a = b; b = t;
@@ -525,8 +566,8 @@ void orc_ocean_advect(const orc_grid *g, const float *img, const float *v, float
             float ax = fabsf(windx - fcx), ay = fabsf(windy - fcy);
             float stressx = 1.0f + 0.0001f * (ax * ax), stressy = 1.0f + 0.0001f * (ay * ay);   /* :347 */
             float e = -1.0f / 24.0f * 2.0f;                                        /* -vec2(1.0)/24.0*2 */
-            o[0] = fcx + windx * (1.0f - powf(stressx, e)) - fcx * (1.0f - k04);    /* :348 */
-            o[1] = fcy + windy * (1.0f - powf(stressy, e)) - fcy * (1.0f - k04);
+            o[0] = fcx + windx * (1.0f - gpow(stressx, e)) - fcx * (1.0f - k04);    /* :348 */
+            o[1] = fcy + windy * (1.0f - gpow(stressy, e)) - fcy * (1.0f - k04);
         }
     }
 }
@@ -770,8 +811,8 @@ void orc_erosion_pass(const orc_grid *g, const float *hgt, const float *flow, co
             }
             float hdiff = SLOPE * dist - maxslope * dist;                  /* :192 */
             /* :195 factor*4*flow*pow(maxslope,n)/pow(0.1,n)*0.1 */
-            float fl = factor * 4.0f * fetch_nearest(flow, W, H, 1, 0, sx, sy) * powf(maxslope, slope_exponent)
-                       / powf(0.1f, slope_exponent) * 0.1f;
+            float fl = factor * 4.0f * fetch_nearest(flow, W, H, 1, 0, sx, sy) * gpow(maxslope, slope_exponent)
+                       / gpow(0.1f, slope_exponent) * 0.1f;
             float up = fetch_nearest(updrift, W, H, 1, 0, sx, sy);
             out[(size_t)y * W + x] = h + fminf(hdiff, fmaxf(0.0f, up - fl));   /* :198 */
         }
