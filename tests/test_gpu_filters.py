@@ -28,7 +28,7 @@ def test_blur(dev, oracle, name):
     G = load_golden(name)
     g, og = grids(capi, oracle, G, G["field"].shape)
     out = ctx.blur(g, G["field"], float(G["radius"]))
-    assert relerr(out, G["out"]) < 1e-5
+    assert relerr(out, G["out"]) < 2e-7
     assert np.array_equal(out, oracle.blur(og, G["field"], float(G["radius"])))
 
 
@@ -48,8 +48,8 @@ def test_temperature(dev, oracle):
     g, og = grids(capi, oracle, G, G["T0"].shape)
     for first, n, key in ((0, 1, "T1"), (0, 20, "T20"), (3000, 20, "T20_from3000")):
         out = ctx.temperature_steps(g, G["T0"], G["terrain"], first, n)
-        assert relerr(out, G[key]) < 1e-5                                            # vs the reference's GLSL
-        assert relerr(out, oracle.temperature(og, G["T0"], G["terrain"], first, n)) < 2e-6   # insolation: device vs glibc libm
+        assert relerr(out, G[key]) < 2e-7                                            # vs the reference's GLSL
+        assert np.array_equal(out, oracle.temperature(og, G["T0"], G["terrain"], first, n))
 
 
 def test_erosion(dev, oracle):
@@ -58,8 +58,8 @@ def test_erosion(dev, oracle):
     g, og = grids(capi, oracle, G, G["h"].shape)
     for (f, n, key) in ((1.0, 1.0, "out"), (2.0, 0.7, "out_f2_n07")):
         out = ctx.erosion_pass(g, G["h"], G["flow"], G["updrift"], f, n)
-        assert relerr(out, G[key]) < 1e-5
-        assert relerr(out, oracle.erosion_pass(og, G["h"], G["flow"], G["updrift"], f, n)) < 1e-6
+        assert np.array_equal(out, G[key])                                           # the reference's GLSL, bit for bit (incl. pow)
+        assert np.array_equal(out, oracle.erosion_pass(og, G["h"], G["flow"], G["updrift"], f, n))
 
 
 def test_erosion_config2_size(dev, oracle):
@@ -71,5 +71,5 @@ def test_erosion_config2_size(dev, oracle):
     flow = (np.abs(synth.divw(W, H)) * 3).astype(np.float32)
     up = (np.maximum(h, 0) / 50).astype(np.float32)
     out = ctx.erosion_pass(capi.make_grid(W, H), h, flow, up, 1.0, 1.0)
-    assert relerr(out, oracle.erosion_pass(oracle.grid(W, H), h, flow, up, 1.0, 1.0)) < 1e-6
+    assert np.array_equal(out, oracle.erosion_pass(oracle.grid(W, H), h, flow, up, 1.0, 1.0))
     assert np.array_equal(out[h <= 0], h[h <= 0])

@@ -41,9 +41,9 @@ def test_divergence(dev, oracle, name):
         o.set_velocity(G["v"])
         o.divergence()
         d = o.get(want=("divw",))["divw"]
-        assert relerr(d, G[key]) < 1e-5
+        assert np.array_equal(d, G[key])                                   # the reference's GLSL, bit for bit
         # the oracle evaluates the neighbour's pixel area at offset()'s fp32 coordinate, the kernel at the row centre
-        assert relerr(d, oracle.ocean_divergence(ogrid(oracle, grid), G["img"], G["v"], pf)) < 1e-6
+        assert np.array_equal(d, oracle.ocean_divergence(ogrid(oracle, grid), G["img"], G["v"], pf))
         o.close()
 
 
@@ -56,7 +56,7 @@ def test_diffusion_bitwise(dev, oracle, name):
         o.set_velocity(G["v"])
         o.diffusion(iters)
         v = o.get(want=("v",))["v"]
-        assert relerr(v, G[key]) < 1e-5
+        assert np.array_equal(v, G[key])                                   # the reference's GLSL, bit for bit (50 sweeps)
         assert np.array_equal(v, oracle.ocean_diffusion(ogrid(oracle, grid), G["img"], G["v"], iters))
         o.close()
     # without the reference's scalar-RHS quirk
@@ -76,11 +76,9 @@ def test_subdiv(dev, oracle, name):
     o.set_pressure(G["pressure200"])
     o.subdiv()
     v = o.get(want=("v",))["v"]
-    assert relerr(v, G["subdiv"]) < 1e-5
+    assert np.array_equal(v, G["subdiv"])                                  # the reference's GLSL, bit for bit
     ref = oracle.ocean_subdiv(ogrid(oracle, grid), G["img"], G["v"], G["pressure200"], 100.0)
-    # atan2f differs by an ulp between device and glibc: a direction-snapping decision may flip on an exact tie
-    bad = np.abs(v - ref).max(axis=2) > 1e-6 * np.abs(ref).max()
-    assert bad.sum() <= 2, bad.sum()
+    assert np.array_equal(v, ref)
     o.close()
 
 
@@ -92,8 +90,9 @@ def test_advect(dev, oracle, name):
     o.set_velocity(G["v"])
     o.advect()
     v = o.get(want=("v",))["v"]
-    assert relerr(v, oracle.ocean_advect(ogrid(oracle, grid), G["img"], G["v"])) < 1e-5
-    assert relerr(v, G["advect"]) < 1e-2      # Mesa's asin/atan polynomials, see test_oracle_golden.py
+    assert np.array_equal(v, oracle.ocean_advect(ogrid(oracle, grid), G["img"], G["v"]))
+    # the reference's GLSL: sin/cos/asin/atan/pow and the bilinear lerp as llvmpipe evaluates them; <1 % of cells keep an ulp
+    assert relerr(v, G["advect"]) < 1e-6 and (v != G["advect"]).mean() < 0.01
     o.close()
 
 
@@ -104,11 +103,11 @@ def test_outer_step(dev, oracle):
     grid, o = make(capi, ctx, G, jacobi_iters=int(G["jacobi_iters"]), diffusion_iters=int(G["diffusion_iters"]))
     o.step(int(G["n_outer"]))
     r = o.get()
-    assert relerr(r["v"], G["v"]) < 2e-3 and relerr(r["pressure"], G["pressure"]) < 2e-3 and relerr(r["divw"], G["divw"]) < 2e-3
+    assert relerr(r["v"], G["v"]) < 1e-6 and relerr(r["pressure"], G["pressure"]) < 1e-6 and relerr(r["divw"], G["divw"]) < 1e-6
     v0 = np.zeros(G["v"].shape, np.float32)
     v, p, d = oracle.ocean_step(ogrid(oracle, grid), G["img"], v0, int(G["n_outer"]), int(G["jacobi_iters"]),
                                 int(G["diffusion_iters"]), rows=True)
-    assert relerr(r["v"], v) < 1e-4 and relerr(r["pressure"], p) < 1e-4 and relerr(r["divw"], d) < 1e-4
+    assert np.array_equal(r["v"], v) and np.array_equal(r["pressure"], p) and np.array_equal(r["divw"], d)
     o.close()
 
 

@@ -38,10 +38,7 @@ def test_thermal_erosion(dev, oracle, n):
     G = load_golden("thermal_128x64_" + n)
     grid = capi.make_grid(128, 64, tuple(G["coords"]), float(G["circ"]))
     out = ctx.thermal_erosion(grid, G["h"])
-    # the talus test compares atan(|grad|) with pi/6: device atanf vs libm may differ on an ulp at the threshold
-    bad = out != G["out"]
-    assert bad.sum() <= 4, bad.sum()
-    assert relerr(out, G["out"]) < 1e-5 or bad.sum() <= 4
+    assert np.array_equal(out, G["out"])        # atan as Mesa expands it: the talus threshold falls where the reference's does
 
 
 @pytest.mark.gpu
