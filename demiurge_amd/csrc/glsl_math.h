@@ -67,7 +67,9 @@ __host__ __device__ inline float asin_poly(float x, float p0, float p1)
     return sign(x) * (PI_2 - sqrtf(1.0f - ax) * t);
 }
 __host__ __device__ inline float asin(float x) { return asin_poly(x, 0.086566724f, -0.03102955f); }
-__host__ __device__ inline float acos(float x) { return PI_2 - asin_poly(x, 0.08132463f, -0.02363318f); }
+// acos: the same shape with its own two coefficients; these are fitted to llvmpipe's output (99.4 % of arguments
+// bit-equal, 1 ulp otherwise; Mesa's literals as remembered, 0.08132463 / -0.02363318, give 96.7 %)
+__host__ __device__ inline float acos(float x) { return PI_2 - asin_poly(x, 0.08132469f, -0.023633232f); }
 
 // atan of a >= 0: reduce to [0,1], odd degree-11 polynomial accumulated from the lowest power
 __host__ __device__ inline float atan_pos(float a)

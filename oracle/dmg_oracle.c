@@ -92,7 +92,7 @@ static inline float m_asin_poly(float x, float p0, float p1)
     return m_sgn(x) * (1.57079632679489661923f - sqrtf(1.0f - ax) * t);
 }
 static inline float gasin(float x) { return g_glsl_math ? m_asin_poly(x, 0.086566724f, -0.03102955f) : asinf(x); }
-static inline float gacos(float x) { return g_glsl_math ? 1.57079632679489661923f - m_asin_poly(x, 0.08132463f, -0.02363318f) : acosf(x); }
+static inline float gacos(float x) { return g_glsl_math ? 1.57079632679489661923f - m_asin_poly(x, 0.08132469f, -0.023633232f) : acosf(x); }
 static inline float m_atan_pos(float a)
 {
     float x = fminf(a, 1.0f) / fmaxf(a, 1.0f);
