@@ -180,7 +180,7 @@ __device__ __forceinline__ vec3 sph2cart(float lon, float lat) { return v3(glsl:
 __device__ __forceinline__ void tangent_basis(float lon, float lat, vec3 *par, vec3 *ycomp)
 {
     vec3 c = sph2cart(lon, lat);
-    float il = 1.0f / sqrtf(c.x * c.x + c.y * c.y);
+    float il = 1.0f / sqrtf(c.y * c.y + c.x * c.x);      // normalize(c.xy): dot() from the last component down
     float inx = c.x * il, iny = c.y * il;
     *ycomp = v3(glsl::sin(lat) * (-inx), glsl::sin(lat) * (-iny), glsl::cos(lat));
     *par = norm3(cross3(v3(0, 0, 1), c));

@@ -500,7 +500,7 @@ void orc_ocean_diffusion(const orc_grid *g, const float *img, float *v, float *s
 static inline vec3 v_to_cartesian(float vx, float vy, float lon, float lat)
 {
     vec3 c = spheric_to_cartesian(lon, lat);
-    float il = 1.0f / sqrtf(c.x * c.x + c.y * c.y);
+    float il = 1.0f / sqrtf(c.y * c.y + c.x * c.x);      /* normalize(c.xy): dot() from the last component down */
     float inx = c.x * il, iny = c.y * il;                                   /* normalize(c.xy) */
     vec3 ycomp = v3(gsin(lat) * (-inx), gsin(lat) * (-iny), gcos(lat));
     vec3 par = v3_normalize(v3_cross(v3(0, 0, 1), c));
@@ -509,7 +509,7 @@ static inline vec3 v_to_cartesian(float vx, float vy, float lon, float lat)
 static inline void cartesian_to_v(vec3 v, float lon, float lat, float *ox, float *oy)
 {
     vec3 c = spheric_to_cartesian(lon, lat);
-    float il = 1.0f / sqrtf(c.x * c.x + c.y * c.y);
+    float il = 1.0f / sqrtf(c.y * c.y + c.x * c.x);      /* normalize(c.xy): dot() from the last component down */
     float inx = c.x * il, iny = c.y * il;
     vec3 ycomp = v3(gsin(lat) * (-inx), gsin(lat) * (-iny), gcos(lat));
     vec3 par = v3_normalize(v3_cross(v3(0, 0, 1), c));
