@@ -38,6 +38,7 @@ def lib():
         G = ctypes.POINTER(Grid)
         L.orc_set_linear_taps.argtypes = [ctypes.c_int]
         L.orc_set_threads.argtypes = [ctypes.c_int]
+        L.orc_set_glsl_math.argtypes = [ctypes.c_int]
         L.orc_ocean_jacobi.argtypes = [G, P, P, P, P, ctypes.c_int]
         L.orc_ocean_jacobi_rows.argtypes = [G, P, P, P, P, ctypes.c_int, ctypes.c_int]
         L.orc_ocean_divergence.argtypes = [G, P, P, ctypes.c_float, P]
@@ -79,6 +80,11 @@ def set_linear_taps(bilinear):
 
 def set_threads(n):
     lib().orc_set_threads(int(n))
+
+
+def set_glsl_math(mode):
+    """1 (default): GLSL sin/cos/tan/asin/acos/atan/pow as llvmpipe evaluates them; 0: libm"""
+    lib().orc_set_glsl_math(int(mode))
 
 
 def ocean_jacobi(g, img, divw, iters, p0=None, rows=False, nthreads=0):
