@@ -604,7 +604,7 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
     lap("host: lake offsets");
     if (timing) fprintf(stderr, "[flow] %zu connections, %zu lakes reached\n", live.size(), off_idx.size());
 
-    dev_buf dlo, dcf, gdepth, hist, order, acc, doi, dov, dci, dcv, dmax;
+    dev_buf dlo, dcf, gdepth, dstart, order, acc, doi, dov, dci, dcv, dmax;
     DMG_ALLOC(dlo, N * 4); DMG_ALLOC(dcf, N * 4); DMG_ALLOC(gdepth, N * 4); DMG_ALLOC(order, N * 4); DMG_ALLOC(acc, N * 4); DMG_ALLOC(dmax, 4);
     DMG_HIP(hipMemsetAsync(dlo.p, 0xFF, N * 4, st));         // -1
     DMG_HIP(hipMemsetAsync(dcf.p, 0xFF, N * 4, st));
@@ -636,11 +636,11 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
     DMG_ALLOC(sorttmp, sort_bytes + 256);
     DMG_HIP(hipcub::DeviceRadixSort::SortPairs(sorttmp.p, sort_bytes, (const unsigned *)gdepth.p, (unsigned *)sdepth.p, (const unsigned *)iota.p,
                                                (unsigned *)order.p, (int)N, 0, depth_bits, st));
-    DMG_ALLOC(hist, (size_t)(levels + 1) * 4);
-    hipLaunchKernelGGL(k_flow_level_starts, dim3((levels + 256) / 256), dim3(256), 0, st, (const unsigned *)sdepth.p, N, hist.i(), levels);
+    DMG_ALLOC(dstart, (size_t)(levels + 1) * 4);
+    hipLaunchKernelGGL(k_flow_level_starts, dim3((levels + 256) / 256), dim3(256), 0, st, (const unsigned *)sdepth.p, N, dstart.i(), levels);
     DMG_HIP(hipGetLastError());
     std::vector<int> start(levels + 1, 0);
-    DMG_HIP(hipMemcpyAsync(start.data(), hist.p, (size_t)(levels + 1) * 4, hipMemcpyDeviceToHost, st));
+    DMG_HIP(hipMemcpyAsync(start.data(), dstart.p, (size_t)(levels + 1) * 4, hipMemcpyDeviceToHost, st));
     DMG_HIP(hipStreamSynchronize(st));
     hipLaunchKernelGGL(k_fill_f, dim3(nb), dim3(256), 0, st, d_flow, -1.0f, N);        // unreached cells keep -1 (:598-604)
     DMG_HIP(hipGetLastError());

@@ -48,7 +48,6 @@ __device__ __forceinline__ float t_sin(float x) { return glsl::sin(x); }
 __device__ __forceinline__ float t_cos(float x) { return glsl::cos(x); }
 
 // ------------------------------------------------------------------------------------------------ geometry
-struct tex4 { float4 *p; int w, h; };
 struct ctex4 { const float4 *p; int w, h; };
 
 __device__ __forceinline__ float4 t_fetch(const float4 *t, int w, int h, float u, float v)
