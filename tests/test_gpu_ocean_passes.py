@@ -243,3 +243,26 @@ def test_checkpoint_resume(dev, tmp_path):
     with pytest.raises(capi.DmgError):
         d.restore(tmp_path / "ck")                          # shape mismatch is refused
     d.close()
+
+
+@pytest.mark.gpu
+def test_outer_step_4096x2048_bitwise_vs_oracle(dev, oracle):
+    """a whole outer step (advect, 50 diffusion sweeps, divergence, 200 Jacobi sweeps, subDiv) at 8.4 M cells against
+    the oracle: every field bit for bit (the oracle takes ~20 s of host time)"""
+    capi, ctx = dev
+    from demiurge_amd import synth
+    W, H = 4096, 2048
+    grid = capi.make_grid(W, H)
+    prm = capi.default_ocean_params()
+    prm.jacobi_iters, prm.diffusion_iters = 200, 50
+    img = synth.terrain(W, H)
+    v0 = synth.velocity(W, H)
+    v0[img > 0] = 0
+    o = capi.Ocean(ctx, grid, params=prm)
+    o.set_terrain(img)
+    o.set_velocity(v0)
+    o.step(1)
+    r = o.get()
+    o.close()
+    v, p, d = oracle.ocean_step(oracle.grid(W, H), img, v0, 1, 200, 50, rows=True)
+    assert np.array_equal(r["divw"], d) and np.array_equal(r["pressure"], p) and np.array_equal(r["v"], v)

@@ -166,3 +166,15 @@ def test_gpu_noise_argument_errors(dev):
     # octaves = 0 divides 0 by 0 in the reference's shader (fc /= total_amplitude): NaN there, NaN here
     out = ctx.gradient_noise(grid, f, capi.noise_params(octaves=0))
     assert np.isnan(out).all()
+
+
+@pytest.mark.gpu
+def test_gpu_noise_2048x1024_vs_oracle(dev, oracle):
+    """2 M texels, default parameters (8 octaves), the three heaviest modes"""
+    capi, ctx = dev
+    W, H = 2048, 1024
+    zero = np.zeros((H, W), np.float32)
+    for mode in ("DEFAULT", "SWISS", "Plateaus"):
+        ref = oracle.gradient_noise(oracle.grid(W, H), zero, mode, seed=12, warp=0.4)
+        out = ctx.gradient_noise(capi.make_grid(W, H), zero, capi.noise_params(mode, seed=12, warp=0.4))
+        assert np.array_equal(out, ref), mode
