@@ -21,21 +21,29 @@ static inline canvas make_canvas(const dmg_grid &g, const dmg_topology &t)
 
 __device__ __forceinline__ float d_mod(float x, float y) { return __fsub_rn(x, __fmul_rn(y, floorf(__fdiv_rn(x, y)))); }
 
+// mod(lon + 2*M_PI, 2*M_PI) - M_PI (Shader.h:88,93) with its constants combined the way Mesa's algebraic pass combines
+// them: (lon + pi) - 2pi*floor((lon + 2pi)/2pi).  Bit-equal to llvmpipe on pole-crossing taps with fractional offsets
+// (blur); the literal form is not (93 %).
+__device__ __forceinline__ float d_pole_lon(float lon)
+{
+    const float two_pi = 2.0f * DMG_PI;
+    return __fsub_rn(__fadd_rn(lon, DMG_PI), __fmul_rn(two_pi, floorf(__fdiv_rn(__fadd_rn(lon, two_pi), two_pi))));
+}
+
 // offset(p, dp, resolution)  (reference src/Shader.h:82-98), statement by statement in fp32
 __device__ __forceinline__ void d_offset(const canvas &c, float px, float py, float dpx, float dpy, float *ox, float *oy)
 {
-    const float two_pi = 2.0f * DMG_PI;
     px = __fadd_rn(px, __fdiv_rn(dpx, (float)c.W));
     py = __fadd_rn(py, __fdiv_rn(dpy, (float)c.H));
     if (c.lonwrap) px = d_mod(__fadd_rn(px, 1.0f), 1.0f);
     if (c.spole && py < 0.0f) {
         py = -py;
-        px = __fsub_rn(d_mod(__fadd_rn(__fadd_rn(__fmul_rn(px, __fsub_rn(c.c3, c.c2)), c.c2), two_pi), two_pi), DMG_PI);
+        px = d_pole_lon(__fadd_rn(__fmul_rn(px, __fsub_rn(c.c3, c.c2)), c.c2));
         px = __fdiv_rn(__fsub_rn(px, c.c2), __fsub_rn(c.c3, c.c2));
     }
     if (c.npole && py > 1.0f) {
         py = __fsub_rn(2.0f, py);
-        px = __fsub_rn(d_mod(__fadd_rn(__fadd_rn(__fmul_rn(px, __fsub_rn(c.c3, c.c2)), c.c2), two_pi), two_pi), DMG_PI);
+        px = d_pole_lon(__fadd_rn(__fmul_rn(px, __fsub_rn(c.c3, c.c2)), c.c2));
         px = __fdiv_rn(__fsub_rn(px, c.c2), __fsub_rn(c.c3, c.c2));
     }
     if (c.lonwrap) px = d_mod(__fadd_rn(px, 1.0f), 1.0f);

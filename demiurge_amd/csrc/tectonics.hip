@@ -68,18 +68,17 @@ __device__ __forceinline__ void t_spheric(const canvas &c, float sx, float sy, f
 __device__ __forceinline__ void t_offset(const canvas &c, float px, float py, float dpx, float dpy, float rx, float ry,
                                          float *ox, float *oy)
 {
-    const float two_pi = 2.0f * DMG_PI;
     px = px + dpx / rx;
     py = py + dpy / ry;
     if (c.lonwrap) px = d_mod(px + 1.0f, 1.0f);
     if (c.spole && py < 0.0f) {
         py = -py;
-        px = d_mod((px * (c.c3 - c.c2) + c.c2) + two_pi, two_pi) - DMG_PI;
+        px = d_pole_lon(px * (c.c3 - c.c2) + c.c2);
         px = (px - c.c2) / (c.c3 - c.c2);
     }
     if (c.npole && py > 1.0f) {
         py = 2.0f - py;
-        px = d_mod((px * (c.c3 - c.c2) + c.c2) + two_pi, two_pi) - DMG_PI;
+        px = d_pole_lon(px * (c.c3 - c.c2) + c.c2);
         px = (px - c.c2) / (c.c3 - c.c2);
     }
     if (c.lonwrap) px = d_mod(px + 1.0f, 1.0f);

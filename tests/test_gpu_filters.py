@@ -28,7 +28,7 @@ def test_blur(dev, oracle, name):
     G = load_golden(name)
     g, og = grids(capi, oracle, G, G["field"].shape)
     out = ctx.blur(g, G["field"], float(G["radius"]))
-    assert relerr(out, G["out"]) < 2e-7
+    assert np.array_equal(out, G["out"])                      # the reference's own pixels (llvmpipe golden)
     assert np.array_equal(out, oracle.blur(og, G["field"], float(G["radius"])))
 
 
