@@ -241,12 +241,14 @@ __global__ __launch_bounds__(256) void k_advect(pass_args a, float k04)
     if (isnan(nvx) || isnan(nvy)) { nvx = 0.0f; nvy = 0.0f; }                      // :321 (zero velocity: normalize(0))
     float fcx = 1.0f * nvx, fcy = 1.0f * nvy;                                      // Dissipation :332; Coriolis x0.0 (:327)
     float phi = 2.0f * (sy - 0.5f) * 3.14159f;                                     // :341
-    float windx = a.wind * -glsl::cos(phi * 3.0f / 2.0f), windy = a.wind * glsl::sin(phi * 3.0f / 2.0f);
-    if (fabsf(phi * 3.0f / 2.0f) > 3.14159f) windx = -windx;
+    // phi*3/2: Mesa merges the literal factors of the product chain into one constant (pinned with a probe shader)
+    const float phi32 = (sy - 0.5f) * ((2.0f * 3.14159f) * (3.0f * 0.5f));
+    float windx = a.wind * -glsl::cos(phi32), windy = a.wind * glsl::sin(phi32);
+    if (fabsf(phi32) > 3.14159f) windx = -windx;
     if (fabsf(phi) > 3.14159f * 1.0f / 3.0f && fabsf(phi) < 3.1459f * 2.0f / 3.0f) windy = -windy;   // sic 3.1459 (:344)
     if (phi < 0.0f) windy = -windy;
     float ax = fabsf(windx - fcx), ay = fabsf(windy - fcy);
-    float stressx = 1.0f + 0.0001f * (ax * ax), stressy = 1.0f + 0.0001f * (ay * ay);   // :347
+    float stressx = 1.0f + (0.0001f * ax) * ax, stressy = 1.0f + (0.0001f * ay) * ay;   // :347, pow(x,2) -> x*x, associated as Mesa does
     float e = -1.0f / 24.0f * 2.0f;
     float2 o;
     o.x = fcx + windx * (1.0f - glsl::pow(stressx, e)) - fcx * (1.0f - k04);            // :348

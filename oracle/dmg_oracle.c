@@ -536,6 +536,8 @@ static inline vec3 rotate(float theta, vec3 u, vec3 v)
 }
 
 /* advect shader :282-348 */
+static int g_advect_stage = 0;      /* debugging aid for probe shaders: which intermediate to write instead of fc */
+void orc_set_advect_stage(int s) { g_advect_stage = s; }
 void orc_ocean_advect(const orc_grid *g, const float *img, const float *v, float *out)
 {
     const int W = g->W, H = g->H;
@@ -557,24 +559,41 @@ void orc_ocean_advect(const orc_grid *g, const float *img, const float *v, float
             vec3 v_cart = v_to_cartesian(velx, vely, lon, lat);
             vec3 rotdir = v3_normalize(v3_cross(cart, v_cart));                    /* :306 */
             cart = rotate(-arclength, rotdir, cart);                               /* :308 */
+            if (g_advect_stage == 4) { o[0] = arclength; o[1] = rotdir.x; continue; }
+            if (g_advect_stage == 5) { o[0] = rotdir.y; o[1] = rotdir.z; continue; }
+            if (g_advect_stage == 6) { o[0] = v_cart.x; o[1] = v_cart.y; continue; }
+            if (g_advect_stage == 7) { o[0] = v_cart.z; o[1] = cart.z; continue; }
+            if (g_advect_stage == 8) { o[0] = cart.x; o[1] = cart.y; continue; }
             float lon_n = gatan2(cart.y, cart.x), lat_n = gasin(cart.z);           /* cartesian_to_spheric */
+            if (g_advect_stage == 9) { o[0] = lon_n; o[1] = lat_n; continue; }
             float cx, cy;
             spheric_to_tex(g, lon_n, lat_n, &cx, &cy);
+            if (g_advect_stage == 2) { o[0] = cx; o[1] = cy; continue; }
             float nvx = fetch_linear(v, W, H, 2, 0, cx, cy), nvy = fetch_linear(v, W, H, 2, 1, cx, cy);   /* :315 */
+            if (g_advect_stage == 3) { o[0] = nvx; o[1] = nvy; continue; }
             vec3 testv = v_to_cartesian(nvx, nvy, lon_n, lat_n);
             testv = rotate(arclength, rotdir, testv);
             cartesian_to_v(testv, lon, lat, &nvx, &nvy);
             if (isnan(nvx) || isnan(nvy)) { nvx = 0; nvy = 0; }                    /* :321 */
             /* Coriolis term is multiplied by 0.0 (:327); NaN/Inf cannot arise from it once newV is finite */
             float fcx = 1.0f * nvx, fcy = 1.0f * nvy;                              /* Dissipation :332 */
+            if (g_advect_stage == 1) { o[0] = fcx; o[1] = fcy; continue; }
             float phi = 2.0f * (sy - 0.5f) * 3.14159f;                             /* :341 */
-            float windx = 10.0f * -gcos(phi * 3.0f / 2.0f), windy = 10.0f * gsin(phi * 3.0f / 2.0f);
-            if (fabsf(phi * 3.0f / 2.0f) > 3.14159f) windx = -windx;
+            /* phi*3/2: Mesa merges the literal factors of the chain 2*(.)*3.14159*3/2 into one constant, and evaluates
+             * 0.0001*pow(a,2) as (0.0001*a)*a (probe shaders, tools/advect_probe.py: 100 % of cells either way) */
+            float phi32 = (sy - 0.5f) * ((2.0f * 3.14159f) * (3.0f * 0.5f));
+            float windx = 10.0f * -gcos(phi32), windy = 10.0f * gsin(phi32);
+            if (fabsf(phi32) > 3.14159f) windx = -windx;
             if (fabsf(phi) > 3.14159f * 1.0f / 3.0f && fabsf(phi) < 3.1459f * 2.0f / 3.0f) windy = -windy;   /* sic 3.1459 */
             if (phi < 0) windy = -windy;
             float ax = fabsf(windx - fcx), ay = fabsf(windy - fcy);
-            float stressx = 1.0f + 0.0001f * (ax * ax), stressy = 1.0f + 0.0001f * (ay * ay);   /* :347 */
+            float stressx = 1.0f + (0.0001f * ax) * ax, stressy = 1.0f + (0.0001f * ay) * ay;   /* :347 */
             float e = -1.0f / 24.0f * 2.0f;                                        /* -vec2(1.0)/24.0*2 */
+            if (g_advect_stage == 10) { o[0] = stressx; o[1] = stressy; continue; }
+            if (g_advect_stage == 11) { o[0] = gpow(stressx, e); o[1] = gpow(stressy, e); continue; }
+            if (g_advect_stage == 12) { o[0] = windx; o[1] = windy; continue; }
+            if (g_advect_stage == 13) { o[0] = windx * (1.0f - gpow(stressx, e)); o[1] = windy * (1.0f - gpow(stressy, e)); continue; }
+            if (g_advect_stage == 14) { o[0] = fcx * (1.0f - k04); o[1] = fcy * (1.0f - k04); continue; }
             o[0] = fcx + windx * (1.0f - gpow(stressx, e)) - fcx * (1.0f - k04);    /* :348 */
             o[1] = fcy + windy * (1.0f - gpow(stressy, e)) - fcy * (1.0f - k04);
         }

@@ -91,8 +91,8 @@ def test_advect(dev, oracle, name):
     o.advect()
     v = o.get(want=("v",))["v"]
     assert np.array_equal(v, oracle.ocean_advect(ogrid(oracle, grid), G["img"], G["v"]))
-    # the reference's GLSL: sin/cos/asin/atan/pow and the bilinear lerp as llvmpipe evaluates them; <1 % of cells keep an ulp
-    assert relerr(v, G["advect"]) < 1e-6 and (v != G["advect"]).mean() < 0.01
+    # the reference's own pixels: sin/cos/asin/atan2/pow, the bilinear lerp and the wind constants as Mesa/llvmpipe evaluate them
+    assert np.array_equal(v, G["advect"])
     o.close()
 
 
@@ -103,7 +103,8 @@ def test_outer_step(dev, oracle):
     grid, o = make(capi, ctx, G, jacobi_iters=int(G["jacobi_iters"]), diffusion_iters=int(G["diffusion_iters"]))
     o.step(int(G["n_outer"]))
     r = o.get()
-    assert relerr(r["v"], G["v"]) < 1e-6 and relerr(r["pressure"], G["pressure"]) < 1e-6 and relerr(r["divw"], G["divw"]) < 1e-6
+    # the reference's three textures after two outer steps, bit for bit
+    assert np.array_equal(r["v"], G["v"]) and np.array_equal(r["pressure"], G["pressure"]) and np.array_equal(r["divw"], G["divw"])
     v0 = np.zeros(G["v"].shape, np.float32)
     v, p, d = oracle.ocean_step(ogrid(oracle, grid), G["img"], v0, int(G["n_outer"]), int(G["jacobi_iters"]),
                                 int(G["diffusion_iters"]), rows=True)
