@@ -80,13 +80,15 @@ __global__ void k_temperature_rows(canvas c, const float *__restrict__ lat, floa
     float h = d_sign(phi) == d_sign(delt) ? DMG_PI : 0.0f;
     if (fabsf(phi) <= DMG_PI / 2.0f - fabsf(delt)) h = glsl::acos(-glsl::tan(phi) * glsl::tan(delt));
     float S = S0 * (1.0f + 2.0f * eccentricity * glsl::cos(A - omega));
-    float q = S / DMG_PI * (h * glsl::sin(phi) * glsl::sin(delt) + glsl::cos(phi) * glsl::cos(delt) * glsl::sin(h));
-    asr[y] = (1.0f - 0.30f) * q;
+    float X = h * glsl::sin(phi) * glsl::sin(delt) + glsl::cos(phi) * glsl::cos(delt) * glsl::sin(h);
+    // (1-alpha) * (S/M_PI * X): Mesa moves the constant factor next to the other one, ((S/pi) * 0.7) * X (probe shader)
+    asr[y] = ((S / DMG_PI) * (1.0f - 0.30f)) * X;
 }
 
 __global__ __launch_bounds__(256) void k_temperature(canvas c, const float *__restrict__ T, float *__restrict__ out,
                                                      const float *__restrict__ terrain, const float *__restrict__ asr,
-                                                     const float *__restrict__ cosphi, const float *__restrict__ dyrow)
+                                                     const float *__restrict__ cosphi, const float *__restrict__ dyrow,
+                                                     float ref_t4)
 {
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= c.W) return;
@@ -113,12 +115,12 @@ __global__ __launch_bounds__(256) void k_temperature(canvas c, const float *__re
     if (isnan(delta_x)) delta_x = 0.0f;
     if (isnan(delta_y)) delta_y = 0.0f;
     float t = __fadd_rn(Tc, 273.15f);
-    float t2 = __fmul_rn(t, t), r2 = __fmul_rn(273.4f, 273.4f);
-    float OLR = __fmul_rn(__fdiv_rn(__fmul_rn(210.0f, __fmul_rn(t2, t2)), __fmul_rn(r2, r2)), 0.93f);          // :125
+    float t2 = __fmul_rn(t, t);                                                   // pow(x,4) -> (x*x)*(x*x); pow(273.4,4): host constant
+    float OLR = __fmul_rn(__fdiv_rn(__fmul_rn(t2, __fmul_rn(t2, 210.0f)), ref_t4), 0.93f);   // :125, associated as Mesa does: x2*(x2*210)
     float change = __fadd_rn(__fsub_rn(asr[y], OLR), __fmul_rn(__fmul_rn(0.55f, 1e6f), __fadd_rn(delta_x, delta_y)));   // :128
     float atmosphere = 1e7f;
     float Cc = __fadd_rn(atmosphere, terr > 0.0f ? __fmul_rn(atmosphere, 0.5f) : __fmul_rn(__fmul_rn(4.0f, 1.5f), atmosphere));
-    out[(size_t)y * c.W + x] = __fadd_rn(Tc, __fdiv_rn(__fdiv_rn(__fmul_rn(__fmul_rn(change, 3.154f), 1e7f), 15000.0f), Cc));   // :133
+    out[(size_t)y * c.W + x] = __fadd_rn(Tc, __fdiv_rn(__fdiv_rn(__fmul_rn(change, __fmul_rn(3.154f, 1e7f)), 15000.0f), Cc));   // :133, the two factors merged
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -320,10 +322,11 @@ int dmg_temperature_steps(dmg_ctx *ctx, const dmg_grid *grid, float *T, const fl
     float *cur = a.f(), *nxt = b.f();
     dim3 g((W + 255) / 256, H);
     const float sin_gamma = sinf(23.44f / 180.0f * DMG_PI);   // sin(gamma): an expression of constants, folded by Mesa on the host
+    const float ref_t4 = powf(273.4f, 4.0f);                  // pow(273.4,4) (:125), likewise (not 273.4^2 squared: one ulp apart)
     for (int i = first_step; i < first_step + n_steps; i++) {
         float M = (float)(M_PI * 2 / 15000 * i);     // glUniform1f(id, M_PI*2/15000*i) (:146)
         hipLaunchKernelGGL(k_temperature_rows, dim3((H + 255) / 256), dim3(256), 0, ctx->stream, c, dlat.f(), M, sin_gamma, dasr.f());
-        hipLaunchKernelGGL(k_temperature, g, dim3(256), 0, ctx->stream, c, cur, nxt, terr.f(), dasr.f(), dcos.f(), ddy.f());
+        hipLaunchKernelGGL(k_temperature, g, dim3(256), 0, ctx->stream, c, cur, nxt, terr.f(), dasr.f(), dcos.f(), ddy.f(), ref_t4);
         DMG_HIP(hipGetLastError());
         std::swap(cur, nxt);                         // terrain.swap(scratch2) (:148)
     }

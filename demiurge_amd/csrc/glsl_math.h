@@ -6,7 +6,7 @@
 // the Cephes octant scheme.  Wherever such a value selects a texel (tectonics' rotated gathers, advect's departure
 // point), feeds a sum with 1e4 offsets (noise) or a row coefficient that 5000 Jacobi sweeps iterate on, "a few ulp
 // from libm" is not the reference's result.  With these forms the Jacobi solve, divergence, subDiv, the climate step,
-// tectonics and the noise generator reproduce the reference's output bit for bit and advect to 1e-6
+// tectonics, the noise generator and advect reproduce the reference's output bit for bit
 // (tests/test_oracle_golden.py; the forms were identified with probe shaders, see oracle/tect_oracle.c).
 //
 // Usable on the host (row tables) and on the device.  Expressions of constants are folded by Mesa on the host with
@@ -67,9 +67,9 @@ __host__ __device__ inline float asin_poly(float x, float p0, float p1)
     return sign(x) * (PI_2 - sqrtf(1.0f - ax) * t);
 }
 __host__ __device__ inline float asin(float x) { return asin_poly(x, 0.086566724f, -0.03102955f); }
-// acos: the same shape with its own two coefficients; these are fitted to llvmpipe's output (99.4 % of arguments
-// bit-equal, 1 ulp otherwise; Mesa's literals as remembered, 0.08132463 / -0.02363318, give 96.7 %)
-__host__ __device__ inline float acos(float x) { return PI_2 - asin_poly(x, 0.08132469f, -0.023633232f); }
+// acos: pi/2 - the same shape with its own two coefficients (Mesa's published acos expansion; 131072/131072 random
+// arguments bit-equal to llvmpipe's output, with pi/4 - 1 taken in float as above)
+__host__ __device__ inline float acos(float x) { return PI_2 - asin_poly(x, 0.08132463f, -0.02363318f); }
 
 // atan of a >= 0: reduce to [0,1], odd degree-11 polynomial accumulated from the lowest power
 __host__ __device__ inline float atan_pos(float a)

@@ -92,7 +92,7 @@ static inline float m_asin_poly(float x, float p0, float p1)
     return m_sgn(x) * (1.57079632679489661923f - sqrtf(1.0f - ax) * t);
 }
 static inline float gasin(float x) { return g_glsl_math ? m_asin_poly(x, 0.086566724f, -0.03102955f) : asinf(x); }
-static inline float gacos(float x) { return g_glsl_math ? 1.57079632679489661923f - m_asin_poly(x, 0.08132469f, -0.023633232f) : acosf(x); }
+static inline float gacos(float x) { return g_glsl_math ? 1.57079632679489661923f - m_asin_poly(x, 0.08132463f, -0.02363318f) : acosf(x); }
 static inline float m_atan_pos(float a)
 {
     float x = fminf(a, 1.0f) / fmaxf(a, 1.0f);
@@ -738,7 +738,8 @@ void orc_blur(const orc_grid *g, float *field, float *scratch, float radius)
 /* ====================================================================== */
 /* Climate (src/filter/Temperature.cpp:56-134)                             */
 /* ====================================================================== */
-static float qday(float phi, float M)
+/* returns ASR = (1-0.30)*QDay(phi,M) in the association Mesa gives it; parts[5] is QDay itself */
+static float qday_parts(float phi, float M, float *parts)
 {
     const float eccentricity = 0.017f;
     const float gamma = 23.44f / 180.0f * MPI;
@@ -754,14 +755,22 @@ static float qday(float phi, float M)
     float h = glsl_sign(phi) == glsl_sign(delt) ? MPI : 0.0f;
     if (fabsf(phi) <= MPI / 2.0f - fabsf(delt)) h = gacos(-gtan(phi) * gtan(delt));
     float S = S0 * (1.0f + 2.0f * eccentricity * gcos(A - omega));
-    return S / MPI * (h * gsin(phi) * gsin(delt) + gcos(phi) * gcos(delt) * gsin(h));
+    float X = h * gsin(phi) * gsin(delt) + gcos(phi) * gcos(delt) * gsin(h);
+    float Q = S / MPI * X;
+    if (parts) { parts[0] = A; parts[1] = delt; parts[2] = h; parts[3] = S; parts[4] = X; parts[5] = Q; parts[6] = ((S / MPI) * (1.0f - 0.30f)) * X; }
+    /* :122 (1-alpha)*QDay: Mesa moves the constant next to the division, ((S/pi)*0.7)*X (tools/climate_probe.py) */
+    return ((S / MPI) * (1.0f - 0.30f)) * X;
 }
+static float asr_row(float phi, float M) { return qday_parts(phi, M, 0); }
+/* debugging aid for probe shaders (tools/climate_probe.py): the intermediates of QDay for one latitude and M */
+void orc_qday_parts(float phi, float M, float *parts7) { qday_parts(phi, M, parts7); }
 
 void orc_temperature(const orc_grid *g, float *T, float *scratch, const float *terrain, int first_step, int n_steps)
 {
     const int W = g->W, H = g->H;
     const float rx = (float)W, ry = (float)H;
     float *a = T, *b = scratch;
+    const float ref_t4 = powf(273.4f, 4.0f);       /* pow(273.4,4): a constant expression, folded by Mesa with libm */
     for (int i = first_step; i < first_step + n_steps; i++) {
         float M = (float)(M_PI * 2 / 15000 * i);          /* :146 glUniform1f(id, M_PI*2/15000*i) */
 #pragma omp parallel for schedule(static) num_threads(nthreads_rows(H, 0))
@@ -769,7 +778,7 @@ void orc_temperature(const orc_grid *g, float *T, float *scratch, const float *t
             float sy = sty(g, y);
             float lon, phi;
             orc_tex_to_spheric(g, 0.0f, sy, &lon, &phi);
-            float ASR = (1.0f - 0.30f) * qday(phi, M);     /* :102,:122 */
+            float ASR = asr_row(phi, M);                    /* :102,:122 (1-0.30)*QDay(phi,M) */
             float factor = gcos(phi);                      /* get_texture_laplacian, Shader.h:301-302 */
             float dx, dy;
             orc_pixelsize(g, sy, &dx, &dy);
@@ -794,12 +803,12 @@ void orc_temperature(const orc_grid *g, float *T, float *scratch, const float *t
                 if (isnan(delta_x)) delta_x = 0;
                 if (isnan(delta_y)) delta_y = 0;
                 float t = Tc + 273.15f;
-                float t2 = t * t, r2 = 273.4f * 273.4f;
-                float OLR = 210.0f * (t2 * t2) / (r2 * r2) * 0.93f;            /* :125 */
+                float t2 = t * t;                                             /* pow(x,4) -> (x*x)*(x*x) */
+                float OLR = t2 * (t2 * 210.0f) / ref_t4 * 0.93f;               /* :125, in Mesa's association (tools/climate_probe.py) */
                 float change = ASR - OLR + 0.55f * 1e6f * (delta_x + delta_y);   /* :128 */
                 float atmosphere = 1e7f;
                 float C = atmosphere + (terr > 0 ? atmosphere * 0.5f : 4.0f * 1.5f * atmosphere);
-                b[(size_t)y * W + x] = Tc + change * 3.154f * 1e7f / 15000.0f / C;   /* :133 */
+                b[(size_t)y * W + x] = Tc + change * (3.154f * 1e7f) / 15000.0f / C;   /* :133, the two constant factors merged */
             }
         }
         float *t = a; a = b; b = t;

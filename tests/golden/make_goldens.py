@@ -127,7 +127,21 @@ def noise_goldens():
          out_DEFAULT=refgl.gradient_noise(img, "DEFAULT", "replace", seed=2))
 
 
+def climate_goldens():
+    """Temperature step on a rough field (a smooth one hides the association of the radiation terms behind the final
+    sum): full globe and regional extent, a few steps from the middle of the year."""
+    W, H = 128, 64
+    img = synth.terrain(W, H)
+    T = ((synth.lcg_uniform(W * H, 41).reshape(H, W) - 0.5) * 60).astype(f32)
+    save("temperature_128x64_rough", coords=np.array(FULL), circ=f32(CIRC), terrain=img, T0=T,
+         T1_from7=refgl.temperature(T, img, 7, 1), T5_from7000=refgl.temperature(T, img, 7000, 5))
+    save("temperature_128x64_rough_region", coords=np.array(REGION), circ=f32(CIRC), terrain=img, T0=T,
+         T3_from11=refgl.temperature(T, img, 11, 3, coords=REGION))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "climate":
+        return climate_goldens()
     if len(sys.argv) > 1 and sys.argv[1] == "noise":
         return noise_goldens()
     if len(sys.argv) > 1 and sys.argv[1] == "tectonics":
@@ -140,6 +154,7 @@ def main():
     next_goldens()
     tectonics_goldens()
     noise_goldens()
+    climate_goldens()
     # ---- Jacobi (headline) -------------------------------------------------
     W, H = 256, 128
     img, b = synth.terrain(W, H), synth.divw(W, H)

@@ -48,8 +48,19 @@ def test_temperature(dev, oracle):
     g, og = grids(capi, oracle, G, G["T0"].shape)
     for first, n, key in ((0, 1, "T1"), (0, 20, "T20"), (3000, 20, "T20_from3000")):
         out = ctx.temperature_steps(g, G["T0"], G["terrain"], first, n)
-        assert relerr(out, G[key]) < 2e-7                                            # vs the reference's GLSL
+        assert np.array_equal(out, G[key])                                           # the reference's GLSL output
         assert np.array_equal(out, oracle.temperature(og, G["T0"], G["terrain"], first, n))
+
+
+@pytest.mark.parametrize("name,cases", [("temperature_128x64_rough", (("T1_from7", 7, 1), ("T5_from7000", 7000, 5))),
+                                        ("temperature_128x64_rough_region", (("T3_from11", 11, 3),))])
+def test_temperature_rough_field(dev, oracle, name, cases):
+    capi, ctx = dev
+    G = load_golden(name)
+    g, og = grids(capi, oracle, G, G["T0"].shape)
+    for key, first, n in cases:
+        out = ctx.temperature_steps(g, G["T0"], G["terrain"], first, n)
+        assert np.array_equal(out, G[key]), key
 
 
 def test_erosion(dev, oracle):

@@ -50,6 +50,8 @@ for nm in ("blur_128x64_r1", "blur_128x64_r10", "blur_128x64_region_r3"):
         orc.blur(orc.grid(128, 64, c, float(G["circ"])), G["field"], float(G["radius"])))
 G = load_golden("temperature_128x64_full"); grid, g = capi.make_grid(128, 64), orc.grid(128, 64)
 rep("temperature x20", ctx.temperature_steps(grid, G["T0"], G["terrain"], 0, 20), G["T20"], orc.temperature(g, G["T0"], G["terrain"], 0, 20))
+G = load_golden("temperature_128x64_rough")
+rep("temperature, rough field x5", ctx.temperature_steps(grid, G["T0"], G["terrain"], 7000, 5), G["T5_from7000"], orc.temperature(g, G["T0"], G["terrain"], 7000, 5))
 G = load_golden("erosion_128x64_full")
 rep("erosion pass", ctx.erosion_pass(grid, G["h"], G["flow"], G["updrift"], 1.0, 1.0), G["out"], orc.erosion_pass(g, G["h"], G["flow"], G["updrift"], 1.0, 1.0))
 G = load_golden("thermal_128x64_full"); rep("thermal erosion", ctx.thermal_erosion(grid, G["h"]), G["out"], orc.thermal_erosion(g, G["h"]))
