@@ -19,6 +19,7 @@ enum {
     RT_JRX,         // RN(1/pw2.x), RN(1/pw2.y), RN(1/Beta): reciprocals for the FMA-corrected division
     RT_JRY,
     RT_JRB,
+    RT_DIFRB,       // RN(1/Beta) of the diffusion sweep, for the blocked kernel's FMA-corrected division
     ROWTAB_FIELDS
 };
 
@@ -59,6 +60,7 @@ int ocean_build_codes(dmg_ocean *o);
 int ocean_build_codes8(dmg_ocean *o);
 int ocean_zero_land(dmg_ocean *o);            // p := +0 on land in BOTH ping-pong buffers (invariant of the blocked kernel)
 int ocean_launch_tb(dmg_ocean *o, int lo, int hi, int n);   // ocean_jacobi_tb.hip
+int ocean_launch_diffusion_tb(dmg_ocean *o, int lo, int hi, int n);   // ocean_diffusion_tb.hip: n (1..8) sweeps over local rows [lo, hi)
 bool ocean_tb_supported(const dmg_ocean *o);
 int ocean_build_rowclass(dmg_ocean *o);
 void ocean_tb_free_lists(dmg_ocean *o);

@@ -18,10 +18,7 @@
 // are the same rows read mirrored and shifted by W/2 (offset(), src/Shader.h:86-95); rows beyond a non-pole edge
 // are plain mirrors (CLAMP_TO_EDGE on a symmetric stencil).  Mirrored rows swap the N/S bits of their code.
 #include "ocean_internal.h"
-
-#define TB_T 8            // halo depth = max sweeps per launch
-#define TB_EW 256         // extended tile width  (64 lanes x 4)
-#define TB_OW (TB_EW - 2 * TB_T)      // 240 output columns per tile
+#include "ocean_tb.h"
 
 struct tb_args {
     const float *pin;
@@ -41,14 +38,6 @@ struct tb_args {
     unsigned long long *trace;      // experiments only (DMG_TB_TRACE): per workgroup {start, loaded, swept, hw id, shader clock at loaded, at swept}; times in 100 MHz ticks
 };
 
-__device__ __forceinline__ float dpp_from_prev_lane(float v)   // lane i <- lane i-1
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float dpp_from_next_lane(float v)   // lane i <- lane i+1
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
-}
 // Land handling for wave-rows that contain coast.  Inside the tile every set neighbour bit means "that neighbour is
 // land" (the clamp-onto-self bits of non-pole edge rows are cleared at load: the mirrored row holds the cell's own
 // value), and land cells hold exactly +0.0 (k_zero_land on input, this kernel on output).  Replacing a land neighbour
@@ -57,13 +46,6 @@ __device__ __forceinline__ float dpp_from_next_lane(float v)   // lane i <- lane
 // (inline asm: left to itself the compiler turns the pattern back into v_cndmask and hoists 40 lane masks per row
 // out of the sweep loop into VGPR lanes, paying two v_readlane + s_nop per select)
 // `tick` is the sweep counter: an unused asm input that keeps the mask extraction inside the sweep loop.
-template <int BIT>
-__device__ __forceinline__ int code_mask(unsigned code, int tick)        // 0 or -1 from bit BIT
-{
-    int m;
-    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(code), "n"(BIT), "s"(tick));
-    return m;
-}
 template <int BIT>
 __device__ __forceinline__ float land_to_centre(unsigned code, int tick, float pC, float pK)
 {

@@ -407,6 +407,18 @@ int dmg_ocean_diffusion(dmg_ocean *o, int iters)
     DMG_CHECK_ARG(iters >= 0);
     if (o->count > 1 && iters > o->ghost)
         return dmg_fail(DMG_EINVAL, "%d diffusion sweeps between halo refreshes but only %d ghost rows", iters, o->ghost);
+    // after k sweeps since the last halo refresh the rows still computable lie k rows inside the ghost slabs
+    static const bool single = getenv("DMG_DIFFUSION_SINGLE") != nullptr;     // experiments: one sweep per launch
+    if (!single && ocean_tb_supported(o) && o->rowclass) {
+        for (int k = 0; k < iters;) {                     // up to 8 sweeps per launch (ocean_diffusion_tb.hip)
+            int m = iters - k < 8 ? iters - k : 8;
+            k += m;
+            rc = ocean_launch_diffusion_tb(o, o->gs ? k : 0, o->L - (o->gn ? k : 0), m);
+            if (rc) return rc;
+            o->vcur ^= 1;
+        }
+        return DMG_OK;
+    }
     for (int k = 1; k <= iters; k++) {                    // :701-707
         rc = launch_rows(o, k_diffusion, make_args(o), o->gs ? k : 0, o->L - (o->gn ? k : 0));
         if (rc) return rc;

@@ -30,7 +30,9 @@ int ocean_upload_row_tables(dmg_ocean *o)
         float s = (ix + iy) * (2.0f * (scale * scale));
         t[(size_t)RT_DIFPX * L + l] = px;
         t[(size_t)RT_DIFPY * L + l] = py;
-        t[(size_t)RT_DIFBETA * L + l] = s * (1.0f + 1.0f / s);
+        const float dbeta = s * (1.0f + 1.0f / s);
+        t[(size_t)RT_DIFBETA * L + l] = dbeta;
+        t[(size_t)RT_DIFRB * L + l] = 1.0f / dbeta;          // correctly rounded reciprocal (blocked diffusion)
         t[(size_t)RT_LAT * L + l] = dmg_row_lat(o->grid, y);
     }
     DMG_HIP(hipMemcpyAsync(o->rowtab, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice, o->ctx->stream));
