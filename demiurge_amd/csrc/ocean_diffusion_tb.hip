@@ -252,7 +252,8 @@ int ocean_launch_diffusion_tb(dmg_ocean *o, int lo, int hi, int n)
     a.scalar_rhs = (o->prm.quirks & DMG_QUIRK_DIFFUSION_SCALAR_RHS) ? 1 : 0;
     // tile shape: every shape gives identical results.  48-row tiles (R = 6: 122 VGPRs, two workgroups per CU) for
     // launches of more than a few hundred tiles, 32-row ones below.  Measured, 50 sweeps at 16384x8192: R = 6 7.9 ms,
-    // R = 4 10.3 ms, R = 8 13.5 ms (it needs ~150 VGPRs and spills at the 128 that two resident workgroups allow);
+    // R = 4 10.3 ms, R = 8 13.5 ms (it needs ~150 VGPRs and spills at the 128 that two resident workgroups allow;
+    // 6-wave workgroups of 8 or 10 rows per thread at 3 waves per SIMD: 11.5 / 10.9 ms);
     // one sweep per launch: 28.7 ms.  DMG_DTB_ROWS=4|6|8 forces a height for experiments.
     static const int forced = [] { const char *e = getenv("DMG_DTB_ROWS"); int r = e ? atoi(e) : 0; return (r == 4 || r == 6 || r == 8) ? r : 0; }();
     const int tiles88 = ((a.W + TB_OW - 1) / TB_OW) * ((hi - lo + 47) / 48);
