@@ -85,27 +85,74 @@ __global__ void k_temperature_rows(canvas c, const float *__restrict__ lat, floa
     asr[y] = ((S / DMG_PI) * (1.0f - 0.30f)) * X;
 }
 
-__global__ __launch_bounds__(256) void k_temperature(canvas c, const float *__restrict__ T, float *__restrict__ out,
-                                                     const float *__restrict__ terrain, const float *__restrict__ asr,
-                                                     const float *__restrict__ cosphi, const float *__restrict__ dyrow,
-                                                     float ref_t4)
+// The nine taps of get_texture_laplacian (Shader.h:304-312): offset(st, -vec2(i/factor, j)) fetched with GL_NEAREST.
+// Texel (column, row) the k-th tap of cell (x, y) lands on, through the literal fp32 offset() arithmetic.
+__device__ __forceinline__ void temperature_tap(const canvas &c, int x, int y, int k, float factor, int *col, int *row)
+{
+    const float ox[9] = { 1, 0, -1, 1, 0, -1, 1, 0, -1 }, oy[9] = { 1, 1, 1, 0, 0, 0, -1, -1, -1 };
+    float px, py;
+    float dpx = ox[k] == 0.0f ? -0.0f : -__fdiv_rn(ox[k], factor);
+    d_offset(c, d_stx(c, x), d_sty(c, y), dpx, -oy[k], &px, &py);
+    *col = min(max((int)floorf(__fmul_rn(px, (float)c.W)), 0), c.W - 1);
+    *row = min(max((int)floorf(__fmul_rn(py, (float)c.H)), 0), c.H - 1);
+}
+// column a tap with per-row shift `s` reaches from x: wrapped on a full-longitude grid, clamped otherwise
+__device__ __forceinline__ int temperature_shifted(const canvas &c, int x, int s)
+{
+    int i = x + s;
+    if (c.lonwrap) { if (i >= c.W) i -= c.W; return i; }
+    return min(max(i, 0), c.W - 1);
+}
+// Within a row the nine taps are the same texel displacement for every x -- almost: offset() runs in fp32 on
+// (x+0.5)/W, so a tap that lands within an ulp of a texel edge can go either way at some x.  This kernel derives each
+// row's nine displacements from its middle cell and CHECKS them against the literal arithmetic at every x; a row
+// where any cell disagrees is marked and keeps the literal per-cell path in k_temperature.  (9 x offset() per cell
+// is ~250 fp32 ops: with the table the step is bound by its 12 B per cell of HBM traffic instead.)
+__global__ __launch_bounds__(256) void k_temperature_taps(canvas c, const float *__restrict__ cosphi, int *__restrict__ shift,
+                                                          int *__restrict__ srow, int *__restrict__ literal_row)
 {
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= c.W) return;
-    float sx = d_stx(c, x), sy = d_sty(c, y);
+    const float factor = cosphi[y];
+    const int xm = c.W / 2;
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        int im, jm, i, j;
+        temperature_tap(c, xm, y, k, factor, &im, &jm);
+        temperature_tap(c, x, y, k, factor, &i, &j);
+        int s = im - xm;                             // signed displacement; as a forward wrap distance on a full-longitude grid
+        if (c.lonwrap && s < 0) s += c.W;
+        ok = ok && (j == jm) && (i == temperature_shifted(c, x, s));
+        if (x == 0) { shift[y * 9 + k] = s; srow[y * 9 + k] = jm; }
+    }
+    if (!ok) atomicOr(&literal_row[y], 1);
+}
+
+__global__ __launch_bounds__(256) void k_temperature(canvas c, const float *__restrict__ T, float *__restrict__ out,
+                                                     const float *__restrict__ terrain, const float *__restrict__ asr,
+                                                     const float *__restrict__ cosphi, const float *__restrict__ dyrow,
+                                                     float ref_t4, const int *__restrict__ shift, const int *__restrict__ srow,
+                                                     const int *__restrict__ literal_row)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= c.W) return;
     float factor = cosphi[y];                        // get_texture_laplacian: cos(geo.y) (Shader.h:301-302)
     float dy = dyrow[y];
     float den = __fmul_rn(4.0f, __fmul_rn(dy, dy));  // 4*pow(pixelwidth.y,2)
     float Tc = T[(size_t)y * c.W + x];
     float terr = terrain[(size_t)y * c.W + x];
     float s[9];
-    const float ox[9] = { 1, 0, -1, 1, 0, -1, 1, 0, -1 }, oy[9] = { 1, 1, 1, 0, 0, 0, -1, -1, -1 };
+    if (!literal_row[y]) {                           // row-uniform: the verified per-row displacements
 #pragma unroll
-    for (int k = 0; k < 9; k++) {                    // Shader.h:304-312: offset(st, -vec2(i/factor, j)), NEAREST `img`
-        float px, py;
-        float dpx = ox[k] == 0.0f ? -0.0f : -__fdiv_rn(ox[k], factor);
-        d_offset(c, sx, sy, dpx, -oy[k], &px, &py);
-        s[k] = d_fetch_nearest(T, c.W, c.H, px, py);
+        for (int k = 0; k < 9; k++) s[k] = T[(size_t)srow[y * 9 + k] * c.W + temperature_shifted(c, x, shift[y * 9 + k])];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            int i, j;
+            temperature_tap(c, x, y, k, factor, &i, &j);
+            s[k] = T[(size_t)j * c.W + i];
+        }
     }
     float A_ = s[0], B_ = s[1], C_ = s[2], D_ = s[3], E_ = s[4], F_ = s[5], G_ = s[6], H_ = s[7], I_ = s[8];
     // (a - 2*b + c + 2*d - 4*e + 2*f + g - 2*h + i) and (a + 2*b + c - 2*d - 4*e - 2*f + g + 2*h + i), left to right
@@ -314,8 +361,9 @@ int dmg_temperature_steps(dmg_ctx *ctx, const dmg_grid *grid, float *T, const fl
         cosphi[y] = glsl::cos(lat[y]);
         dyr[y] = dy;
     }
-    dev_buf a, b, terr, dlat, dcos, ddy, dasr;
+    dev_buf a, b, terr, dlat, dcos, ddy, dasr, dshift, dsrow, dlit;
     DMG_ALLOC(a, n * 4); DMG_ALLOC(b, n * 4); DMG_ALLOC(terr, n * 4); DMG_ALLOC(dasr, (size_t)H * 4);
+    DMG_ALLOC(dshift, (size_t)H * 9 * sizeof(int)); DMG_ALLOC(dsrow, (size_t)H * 9 * sizeof(int)); DMG_ALLOC(dlit, (size_t)H * sizeof(int));
     if ((rc = upload_rows(ctx, dlat, lat)) || (rc = upload_rows(ctx, dcos, cosphi)) || (rc = upload_rows(ctx, ddy, dyr))) return rc;
     DMG_HIP(hipMemcpyAsync(a.p, T, n * 4, hipMemcpyHostToDevice, ctx->stream));
     DMG_HIP(hipMemcpyAsync(terr.p, terrain, n * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -323,10 +371,23 @@ int dmg_temperature_steps(dmg_ctx *ctx, const dmg_grid *grid, float *T, const fl
     dim3 g((W + 255) / 256, H);
     const float sin_gamma = sinf(23.44f / 180.0f * DMG_PI);   // sin(gamma): an expression of constants, folded by Mesa on the host
     const float ref_t4 = powf(273.4f, 4.0f);                  // pow(273.4,4) (:125), likewise (not 273.4^2 squared: one ulp apart)
+    // per-row tap displacements, verified cell by cell against the literal offset() arithmetic (once per call)
+    static const bool literal_only = getenv("DMG_TEMPERATURE_LITERAL") != nullptr;      // experiments: every row literal
+    DMG_HIP(hipMemsetAsync(dlit.p, literal_only ? 0xFF : 0, (size_t)H * sizeof(int), ctx->stream));
+    if (n_steps > 0) hipLaunchKernelGGL(k_temperature_taps, g, dim3(256), 0, ctx->stream, c, dcos.f(), (int *)dshift.p, (int *)dsrow.p, (int *)dlit.p);
+    if (n_steps > 0 && getenv("DMG_TEMPERATURE_REPORT")) {                              // experiments: how many rows stay literal
+        std::vector<int> lit(H);
+        DMG_HIP(hipMemcpyAsync(lit.data(), dlit.p, (size_t)H * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        DMG_HIP(hipStreamSynchronize(ctx->stream));
+        int cnt = 0;
+        for (int y = 0; y < H; y++) cnt += lit[y] != 0;
+        fprintf(stderr, "dmg_temperature_steps: %d of %d rows keep the literal offset() path\n", cnt, H);
+    }
     for (int i = first_step; i < first_step + n_steps; i++) {
         float M = (float)(M_PI * 2 / 15000 * i);     // glUniform1f(id, M_PI*2/15000*i) (:146)
         hipLaunchKernelGGL(k_temperature_rows, dim3((H + 255) / 256), dim3(256), 0, ctx->stream, c, dlat.f(), M, sin_gamma, dasr.f());
-        hipLaunchKernelGGL(k_temperature, g, dim3(256), 0, ctx->stream, c, cur, nxt, terr.f(), dasr.f(), dcos.f(), ddy.f(), ref_t4);
+        hipLaunchKernelGGL(k_temperature, g, dim3(256), 0, ctx->stream, c, cur, nxt, terr.f(), dasr.f(), dcos.f(), ddy.f(), ref_t4,
+                           (const int *)dshift.p, (const int *)dsrow.p, (const int *)dlit.p);
         DMG_HIP(hipGetLastError());
         std::swap(cur, nxt);                         // terrain.swap(scratch2) (:148)
     }

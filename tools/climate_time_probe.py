@@ -1,0 +1,29 @@
+"""Times the climate step (Temperature.cpp:56-134) per step at WxH, host-to-host call cost subtracted (1 vs 41 steps).
+
+    python tools/climate_time_probe.py [W]                verified per-row tap table (default)
+    DMG_TEMPERATURE_LITERAL=1 python tools/...            literal offset() per tap and cell
+"""
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch  # noqa: F401
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+from demiurge_amd import capi, synth  # noqa: E402
+
+W = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+H = W // 2
+ctx = capi.Context(0)
+g = capi.make_grid(W, H)
+h = (synth.terrain(W, H) * 100).astype(np.float32)
+T0 = ((synth.lcg_uniform(W * H, 41).reshape(H, W)) * 60).astype(np.float32)
+ctx.temperature_steps(g, T0, h, 0, 1)
+best = 1e9
+for _ in range(3):
+    t0 = time.perf_counter(); ctx.temperature_steps(g, T0, h, 7, 1); ta = time.perf_counter() - t0
+    t0 = time.perf_counter(); ctx.temperature_steps(g, T0, h, 7, 41); tb = time.perf_counter() - t0
+    best = min(best, (tb - ta) / 40 * 1e3)
+print("%dx%d climate step: %.3f ms (%.0f GB/s at 12 B per cell)  literal=%s" % (W, H, best, W * H * 12 / best / 1e6, os.environ.get("DMG_TEMPERATURE_LITERAL", "0")))
