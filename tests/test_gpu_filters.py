@@ -63,6 +63,25 @@ def test_temperature_rough_field(dev, oracle, name, cases):
         assert np.array_equal(out, G[key]), key
 
 
+def test_temperature_tap_table(oracle, tmp_path):
+    """the per-row tap displacements (verified against the literal offset() arithmetic at set-up, rows that disagree
+    stay literal) give the fields of the all-literal path and of the oracle: the reference's own 1000x500 size,
+    a power-of-two globe, a regional extent (clamped columns) and a belt"""
+    import os, subprocess, sys
+    import temperature_worker
+    outs = {}
+    for tag, extra in (("table", {}), ("literal", {"DMG_TEMPERATURE_LITERAL": "1"})):
+        env = dict(os.environ, **extra)
+        env.pop("DMG_TEMPERATURE_LITERAL", None) if not extra else None
+        path = tmp_path / (tag + ".npz")
+        r = subprocess.run([sys.executable, temperature_worker.__file__, str(path)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs[tag] = np.load(path)
+    for name, W, H, coords, T, terr in temperature_worker.cases():
+        assert np.array_equal(outs["table"][name], outs["literal"][name]), name
+        assert np.array_equal(outs["table"][name], oracle.temperature(oracle.grid(W, H, coords, 42000.0), T, terr, 11, 3)), name
+
+
 def test_erosion(dev, oracle):
     capi, ctx = dev
     G = load_golden("erosion_128x64_full")
