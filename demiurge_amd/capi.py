@@ -129,6 +129,14 @@ def lib():
         "dmg_erosion_pass": (c_int, [vp, PG, vp, vp, vp, c_float, c_float]),
         "dmg_flow_accumulate": (c_int, [vp, PG, vp, vp, c_float, c_float, c_int, vp]),
         "dmg_erosion_run": (c_int, [vp, PG, vp, c_int, c_int, c_float, c_float, c_float]),
+        "dmg_climate_create": (c_int, [vp, PG, vp, vp, ctypes.POINTER(vp)]),
+        "dmg_climate_destroy": (None, [vp]),
+        "dmg_climate_steps": (c_int, [vp, c_int, c_int]),
+        "dmg_climate_get": (c_int, [vp, vp]),
+        "dmg_erosion_create": (c_int, [vp, PG, vp, c_int, c_float, c_float, c_float, c_int, ctypes.POINTER(vp)]),
+        "dmg_erosion_destroy": (None, [vp]),
+        "dmg_erosion_rounds": (c_int, [vp, c_int]),
+        "dmg_erosion_get": (c_int, [vp, vp]),
         "dmg_thermal_erosion": (c_int, [vp, PG, vp]),
         "dmg_morphological": (c_int, [vp, PG, vp, c_float, c_int]),
         "dmg_morphological_gradient": (c_int, [vp, PG, vp, c_float]),
@@ -293,6 +301,54 @@ Context.morphological = _ctx_morphological
 Context.morphological_gradient = _ctx_morphological_gradient
 Context.flow_accumulate = _ctx_flow_accumulate
 Context.erosion_run = _ctx_erosion_run
+
+
+class Climate:
+    """dmg_climate: the climate field (Temperature.cpp) resident on the device between step calls"""
+
+    def __init__(self, ctx, grid, T, terrain):
+        T, terrain = _f32(T), _f32(terrain)
+        self.ctx, self.shape = ctx, T.shape
+        h = ctypes.c_void_p()
+        check(lib().dmg_climate_create(ctx.h, ctypes.byref(grid), _p(T), _p(terrain), ctypes.byref(h)))
+        self.h = h
+
+    def steps(self, first_step, n_steps):
+        check(lib().dmg_climate_steps(self.h, first_step, n_steps))
+
+    def get(self):
+        out = np.empty(self.shape, np.float32)
+        check(lib().dmg_climate_get(self.h, _p(out)))
+        return out
+
+    def close(self):
+        if self.h:
+            lib().dmg_climate_destroy(self.h)
+            self.h = None
+
+
+class Erosion:
+    """dmg_erosion: cpufilter::run round by round, heights resident on the device"""
+
+    def __init__(self, ctx, grid, h, N=50, exponent=0.5, slope_exponent=1.0, factor=1.0, lakes=0):
+        h = _f32(h)
+        self.ctx, self.shape = ctx, h.shape
+        e = ctypes.c_void_p()
+        check(lib().dmg_erosion_create(ctx.h, ctypes.byref(grid), _p(h), N, exponent, slope_exponent, factor, lakes, ctypes.byref(e)))
+        self.h = e
+
+    def rounds(self, n):
+        check(lib().dmg_erosion_rounds(self.h, n))
+
+    def get(self):
+        out = np.empty(self.shape, np.float32)
+        check(lib().dmg_erosion_get(self.h, _p(out)))
+        return out
+
+    def close(self):
+        if self.h:
+            lib().dmg_erosion_destroy(self.h)
+            self.h = None
 
 
 def default_ocean_params():

@@ -8,6 +8,8 @@
 // texel each tap hits is the one the reference hits.  Row-constant transcendental factors (cos(lat)) come from the
 // host in fp32, exactly as in the ocean kernels; the per-row insolation of the climate step is evaluated on the
 // device (sin/cos/asin/acos/tan of device libm: a few ulp from glibc).
+#include <memory>
+#include <new>
 #include "canvas.h"
 #include <algorithm>
 
@@ -343,16 +345,27 @@ int dmg_blur(dmg_ctx *ctx, const dmg_grid *grid, float *field, float radius)
     return DMG_OK;
 }
 
-int dmg_temperature_steps(dmg_ctx *ctx, const dmg_grid *grid, float *T, const float *terrain, int first_step, int n_steps)
+// Device-resident climate state: Temperature::run (Temperature.cpp:47-162) keeps T in the terrain texture and steps it
+// ten times per frame for as long as the tool is open; with the field resident a frame costs its kernels only.
+struct dmg_climate {
+    dmg_ctx *ctx = nullptr;
+    dmg_grid grid{};
+    dmg_topology topo{};
+    dev_buf a, b, terr, dlat, dcos, ddy, dasr, dshift, dsrow, dlit;
+    float *cur = nullptr, *nxt = nullptr;
+    bool taps_ready = false;
+};
+
+int dmg_climate_create(dmg_ctx *ctx, const dmg_grid *grid, const float *T, const float *terrain, dmg_climate **out)
 {
-    DMG_CHECK_ARG(ctx != nullptr && T != nullptr && terrain != nullptr && n_steps >= 0);
+    DMG_CHECK_ARG(ctx != nullptr && T != nullptr && terrain != nullptr && out != nullptr);
+    *out = nullptr;
     dmg_topology topo;
     int rc = dmg_check_grid(grid, &topo);
     if (rc) return rc;
     DMG_HIP(hipSetDevice(ctx->device));
-    canvas c = make_canvas(*grid, topo);
-    const int W = grid->W, H = grid->H;
-    const size_t n = (size_t)W * H;
+    const int H = grid->H;
+    const size_t n = (size_t)grid->W * H;
     std::vector<float> lat(H), cosphi(H), dyr(H);
     for (int y = 0; y < H; y++) {
         float dx, dy;
@@ -361,39 +374,78 @@ int dmg_temperature_steps(dmg_ctx *ctx, const dmg_grid *grid, float *T, const fl
         cosphi[y] = glsl::cos(lat[y]);
         dyr[y] = dy;
     }
-    dev_buf a, b, terr, dlat, dcos, ddy, dasr, dshift, dsrow, dlit;
-    DMG_ALLOC(a, n * 4); DMG_ALLOC(b, n * 4); DMG_ALLOC(terr, n * 4); DMG_ALLOC(dasr, (size_t)H * 4);
-    DMG_ALLOC(dshift, (size_t)H * 9 * sizeof(int)); DMG_ALLOC(dsrow, (size_t)H * 9 * sizeof(int)); DMG_ALLOC(dlit, (size_t)H * sizeof(int));
-    if ((rc = upload_rows(ctx, dlat, lat)) || (rc = upload_rows(ctx, dcos, cosphi)) || (rc = upload_rows(ctx, ddy, dyr))) return rc;
-    DMG_HIP(hipMemcpyAsync(a.p, T, n * 4, hipMemcpyHostToDevice, ctx->stream));
-    DMG_HIP(hipMemcpyAsync(terr.p, terrain, n * 4, hipMemcpyHostToDevice, ctx->stream));
-    float *cur = a.f(), *nxt = b.f();
+    std::unique_ptr<dmg_climate> k(new (std::nothrow) dmg_climate);
+    if (!k) return dmg_fail(DMG_ENOMEM, "out of host memory");
+    k->ctx = ctx; k->grid = *grid; k->topo = topo;
+    DMG_ALLOC(k->a, n * 4); DMG_ALLOC(k->b, n * 4); DMG_ALLOC(k->terr, n * 4); DMG_ALLOC(k->dasr, (size_t)H * 4);
+    DMG_ALLOC(k->dshift, (size_t)H * 9 * sizeof(int)); DMG_ALLOC(k->dsrow, (size_t)H * 9 * sizeof(int)); DMG_ALLOC(k->dlit, (size_t)H * sizeof(int));
+    if ((rc = upload_rows(ctx, k->dlat, lat)) || (rc = upload_rows(ctx, k->dcos, cosphi)) || (rc = upload_rows(ctx, k->ddy, dyr))) return rc;
+    DMG_HIP(hipMemcpyAsync(k->a.p, T, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    DMG_HIP(hipMemcpyAsync(k->terr.p, terrain, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    DMG_HIP(hipStreamSynchronize(ctx->stream));      // the caller's buffers may go away
+    k->cur = k->a.f(); k->nxt = k->b.f();
+    *out = k.release();
+    return DMG_OK;
+}
+
+void dmg_climate_destroy(dmg_climate *k) { delete k; }
+
+int dmg_climate_steps(dmg_climate *k, int first_step, int n_steps)
+{
+    DMG_CHECK_ARG(k != nullptr && n_steps >= 0);
+    dmg_ctx *ctx = k->ctx;
+    DMG_HIP(hipSetDevice(ctx->device));
+    canvas c = make_canvas(k->grid, k->topo);
+    const int W = k->grid.W, H = k->grid.H;
     dim3 g((W + 255) / 256, H);
     const float sin_gamma = sinf(23.44f / 180.0f * DMG_PI);   // sin(gamma): an expression of constants, folded by Mesa on the host
     const float ref_t4 = powf(273.4f, 4.0f);                  // pow(273.4,4) (:125), likewise (not 273.4^2 squared: one ulp apart)
-    // per-row tap displacements, verified cell by cell against the literal offset() arithmetic (once per call)
-    static const bool literal_only = getenv("DMG_TEMPERATURE_LITERAL") != nullptr;      // experiments: every row literal
-    DMG_HIP(hipMemsetAsync(dlit.p, literal_only ? 0xFF : 0, (size_t)H * sizeof(int), ctx->stream));
-    if (n_steps > 0) hipLaunchKernelGGL(k_temperature_taps, g, dim3(256), 0, ctx->stream, c, dcos.f(), (int *)dshift.p, (int *)dsrow.p, (int *)dlit.p);
-    if (n_steps > 0 && getenv("DMG_TEMPERATURE_REPORT")) {                              // experiments: how many rows stay literal
-        std::vector<int> lit(H);
-        DMG_HIP(hipMemcpyAsync(lit.data(), dlit.p, (size_t)H * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        DMG_HIP(hipStreamSynchronize(ctx->stream));
-        int cnt = 0;
-        for (int y = 0; y < H; y++) cnt += lit[y] != 0;
-        fprintf(stderr, "dmg_temperature_steps: %d of %d rows keep the literal offset() path\n", cnt, H);
+    if (!k->taps_ready && n_steps > 0) {
+        // per-row tap displacements, verified cell by cell against the literal offset() arithmetic (once per field)
+        static const bool literal_only = getenv("DMG_TEMPERATURE_LITERAL") != nullptr;      // experiments: every row literal
+        DMG_HIP(hipMemsetAsync(k->dlit.p, literal_only ? 0xFF : 0, (size_t)H * sizeof(int), ctx->stream));
+        hipLaunchKernelGGL(k_temperature_taps, g, dim3(256), 0, ctx->stream, c, k->dcos.f(), k->dshift.i(), k->dsrow.i(), k->dlit.i());
+        DMG_HIP(hipGetLastError());
+        if (getenv("DMG_TEMPERATURE_REPORT")) {                                             // experiments: how many rows stay literal
+            std::vector<int> lit(H);
+            DMG_HIP(hipMemcpyAsync(lit.data(), k->dlit.p, (size_t)H * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            DMG_HIP(hipStreamSynchronize(ctx->stream));
+            int cnt = 0;
+            for (int y = 0; y < H; y++) cnt += lit[y] != 0;
+            fprintf(stderr, "dmg_climate_steps: %d of %d rows keep the literal offset() path\n", cnt, H);
+        }
+        k->taps_ready = true;
     }
     for (int i = first_step; i < first_step + n_steps; i++) {
         float M = (float)(M_PI * 2 / 15000 * i);     // glUniform1f(id, M_PI*2/15000*i) (:146)
-        hipLaunchKernelGGL(k_temperature_rows, dim3((H + 255) / 256), dim3(256), 0, ctx->stream, c, dlat.f(), M, sin_gamma, dasr.f());
-        hipLaunchKernelGGL(k_temperature, g, dim3(256), 0, ctx->stream, c, cur, nxt, terr.f(), dasr.f(), dcos.f(), ddy.f(), ref_t4,
-                           (const int *)dshift.p, (const int *)dsrow.p, (const int *)dlit.p);
+        hipLaunchKernelGGL(k_temperature_rows, dim3((H + 255) / 256), dim3(256), 0, ctx->stream, c, k->dlat.f(), M, sin_gamma, k->dasr.f());
+        hipLaunchKernelGGL(k_temperature, g, dim3(256), 0, ctx->stream, c, k->cur, k->nxt, k->terr.f(), k->dasr.f(), k->dcos.f(), k->ddy.f(),
+                           ref_t4, (const int *)k->dshift.p, (const int *)k->dsrow.p, (const int *)k->dlit.p);
         DMG_HIP(hipGetLastError());
-        std::swap(cur, nxt);                         // terrain.swap(scratch2) (:148)
+        std::swap(k->cur, k->nxt);                   // terrain.swap(scratch2) (:148)
     }
-    DMG_HIP(hipMemcpyAsync(T, cur, n * 4, hipMemcpyDeviceToHost, ctx->stream));
-    DMG_HIP(hipStreamSynchronize(ctx->stream));
     return DMG_OK;
+}
+
+int dmg_climate_get(dmg_climate *k, float *T)
+{
+    DMG_CHECK_ARG(k != nullptr && T != nullptr);
+    DMG_HIP(hipSetDevice(k->ctx->device));
+    DMG_HIP(hipMemcpyAsync(T, k->cur, (size_t)k->grid.W * k->grid.H * 4, hipMemcpyDeviceToHost, k->ctx->stream));
+    DMG_HIP(hipStreamSynchronize(k->ctx->stream));
+    return DMG_OK;
+}
+
+int dmg_temperature_steps(dmg_ctx *ctx, const dmg_grid *grid, float *T, const float *terrain, int first_step, int n_steps)
+{
+    DMG_CHECK_ARG(ctx != nullptr && T != nullptr && terrain != nullptr && n_steps >= 0);
+    dmg_climate *k = nullptr;
+    int rc = dmg_climate_create(ctx, grid, T, terrain, &k);
+    if (rc) return rc;
+    rc = dmg_climate_steps(k, first_step, n_steps);
+    if (!rc) rc = dmg_climate_get(k, T);
+    dmg_climate_destroy(k);
+    return rc;
 }
 
 int dmg_erosion_pass(dmg_ctx *ctx, const dmg_grid *grid, float *h, const float *flow, const float *updrift,
@@ -430,10 +482,22 @@ __global__ void k_erosion_prepare(const float *__restrict__ img, float *__restri
 }
 
 // cpufilter::run (:41-222), device resident: no readbacks between the flow solve and the erosion pass
-int dmg_erosion_run(dmg_ctx *ctx, const dmg_grid *grid, float *h, int N, int iters, float exponent,
-                    float slope_exponent, float factor)
+struct dmg_erosion {
+    dmg_ctx *ctx = nullptr;
+    dmg_grid grid{};
+    dmg_topology topo{};
+    dev_buf terrain, height, next, updrift, flow, ddx, ddy;
+    float *cur = nullptr, *nxt = nullptr;
+    float exponent = 0.5f, slope_exponent = 1.0f, factor = 1.0f;
+    int lakes = 0;
+    long long rounds = 0;
+};
+
+int dmg_erosion_create(dmg_ctx *ctx, const dmg_grid *grid, const float *h, int N, float exponent, float slope_exponent, float factor,
+                       int lakes, dmg_erosion **out)
 {
-    DMG_CHECK_ARG(ctx != nullptr && h != nullptr && N >= 1 && iters >= 0);
+    DMG_CHECK_ARG(ctx != nullptr && h != nullptr && N >= 1 && out != nullptr);
+    *out = nullptr;
     dmg_topology topo;
     int rc = dmg_check_grid(grid, &topo);
     if (rc) return rc;
@@ -442,24 +506,60 @@ int dmg_erosion_run(dmg_ctx *ctx, const dmg_grid *grid, float *h, int N, int ite
     const size_t n = (size_t)grid->W * H;
     std::vector<float> dxr(H), dyr(H);
     for (int y = 0; y < H; y++) dmg_row_pixelsize(*grid, y, &dxr[y], &dyr[y]);
-    dev_buf terrain, height, next, updrift, flow, ddx, ddy;
-    DMG_ALLOC(terrain, n * 4); DMG_ALLOC(height, n * 4); DMG_ALLOC(next, n * 4); DMG_ALLOC(updrift, n * 4); DMG_ALLOC(flow, n * 4);
-    if ((rc = upload_rows(ctx, ddx, dxr)) || (rc = upload_rows(ctx, ddy, dyr))) return rc;
-    DMG_HIP(hipMemcpyAsync(terrain.p, h, n * 4, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_erosion_prepare, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, terrain.f(), updrift.f(),
-                       height.f(), (float)N, n);
+    std::unique_ptr<dmg_erosion> e(new (std::nothrow) dmg_erosion);
+    if (!e) return dmg_fail(DMG_ENOMEM, "out of host memory");
+    e->ctx = ctx; e->grid = *grid; e->topo = topo;
+    e->exponent = exponent; e->slope_exponent = slope_exponent; e->factor = factor; e->lakes = lakes;
+    DMG_ALLOC(e->terrain, n * 4); DMG_ALLOC(e->height, n * 4); DMG_ALLOC(e->next, n * 4); DMG_ALLOC(e->updrift, n * 4); DMG_ALLOC(e->flow, n * 4);
+    if ((rc = upload_rows(ctx, e->ddx, dxr)) || (rc = upload_rows(ctx, e->ddy, dyr))) return rc;
+    DMG_HIP(hipMemcpyAsync(e->terrain.p, h, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_erosion_prepare, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, e->terrain.f(), e->updrift.f(),
+                       e->height.f(), (float)N, n);
     DMG_HIP(hipGetLastError());
-    float *cur = height.f(), *nxt = next.f();
-    for (int i = 0; i < iters; i++) {                    // :93
-        // the first FlowFilter sees the unscaled terrain texture, every later one the eroded scaled heights (:95-108)
-        const float *flow_in = (i == 0) ? terrain.f() : cur;
-        if ((rc = flow_device(ctx, *grid, topo, flow_in, nullptr, 0.5f, exponent, flow.f()))) return rc;
-        if ((rc = erosion_device(ctx, *grid, topo, cur, flow.f(), updrift.f(), nxt, ddx.f(), ddy.f(), factor, slope_exponent))) return rc;
-        std::swap(cur, nxt);
-    }
-    DMG_HIP(hipMemcpyAsync(h, cur, n * 4, hipMemcpyDeviceToHost, ctx->stream));
-    DMG_HIP(hipStreamSynchronize(ctx->stream));
+    DMG_HIP(hipStreamSynchronize(ctx->stream));      // the caller's buffer may go away
+    e->cur = e->height.f(); e->nxt = e->next.f();
+    *out = e.release();
     return DMG_OK;
+}
+
+void dmg_erosion_destroy(dmg_erosion *e) { delete e; }
+
+int dmg_erosion_rounds(dmg_erosion *e, int n_rounds)
+{
+    DMG_CHECK_ARG(e != nullptr && n_rounds >= 0);
+    DMG_HIP(hipSetDevice(e->ctx->device));
+    for (int i = 0; i < n_rounds; i++, e->rounds++) {      // :93
+        // the first FlowFilter sees the unscaled terrain texture, every later one the eroded scaled heights (:95-108)
+        const float *flow_in = (e->rounds == 0) ? e->terrain.f() : e->cur;
+        int rc = flow_device(e->ctx, e->grid, e->topo, flow_in, nullptr, 0.5f, e->exponent, e->flow.f(), e->lakes);
+        if (rc) return rc;
+        rc = erosion_device(e->ctx, e->grid, e->topo, e->cur, e->flow.f(), e->updrift.f(), e->nxt, e->ddx.f(), e->ddy.f(), e->factor, e->slope_exponent);
+        if (rc) return rc;
+        std::swap(e->cur, e->nxt);
+    }
+    return DMG_OK;
+}
+
+int dmg_erosion_get(dmg_erosion *e, float *h)
+{
+    DMG_CHECK_ARG(e != nullptr && h != nullptr);
+    DMG_HIP(hipSetDevice(e->ctx->device));
+    DMG_HIP(hipMemcpyAsync(h, e->cur, (size_t)e->grid.W * e->grid.H * 4, hipMemcpyDeviceToHost, e->ctx->stream));
+    DMG_HIP(hipStreamSynchronize(e->ctx->stream));
+    return DMG_OK;
+}
+
+int dmg_erosion_run(dmg_ctx *ctx, const dmg_grid *grid, float *h, int N, int iters, float exponent,
+                    float slope_exponent, float factor)
+{
+    DMG_CHECK_ARG(ctx != nullptr && h != nullptr && N >= 1 && iters >= 0);
+    dmg_erosion *e = nullptr;
+    int rc = dmg_erosion_create(ctx, grid, h, N, exponent, slope_exponent, factor, 0, &e);
+    if (rc) return rc;
+    rc = dmg_erosion_rounds(e, iters);
+    if (!rc) rc = dmg_erosion_get(e, h);
+    dmg_erosion_destroy(e);
+    return rc;
 }
 
 // ThermalErosion::step (reference src/filter/ThermalErosion.cpp:25-142): 10 rounds of loss + gain, in place

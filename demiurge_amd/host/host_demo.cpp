@@ -7,6 +7,7 @@
 #include <memory>
 #include "HipOceanCurrents.h"
 #include "HipTectonics.h"
+#include "HipSimulationTools.h"
 
 static bool read_f32(const char *path, std::vector<float> &v)
 {
@@ -25,6 +26,7 @@ static void write_f32(const std::string &path, const std::vector<float> &v)
 
 // host_demo tectonics <W> <H> <terrain.f32> <n_steps> <out_prefix>
 // host_demo noise <W> <H> <mode 0..6> <seed> <out_prefix>
+// host_demo erosion|climate|blur|dilate|erode|morphgrad|thermal|flow ...   (argument lists at each branch below)
 static int other_tools(int argc, char **argv)
 {
     std::string tool = argv[1];
@@ -44,7 +46,30 @@ static int other_tools(int argc, char **argv)
         prm.mode = atoi(argv[4]); prm.seed = atoi(argv[5]);
         auto f = std::make_unique<HipGradientNoise>(prm);
         err = &f->error(); filter = std::move(f); out = argv[6];
-    } else { fprintf(stderr, "usage: host_demo tectonics W H terrain.f32 n_steps out | host_demo noise W H mode seed out\n"); return 2; }
+    } else if (tool == "erosion" && argc == 8) {                 // host_demo erosion W H terrain.f32 rounds dolakes out
+        if (!read_f32(argv[4], p.terrain)) { fprintf(stderr, "cannot read %s\n", argv[4]); return 2; }
+        auto f = std::make_unique<HipErosion>(&p, 0.5f, 1.0f, 1.0f, atoi(argv[6]), 50, atoi(argv[5]));      // the menu's defaults, cpufilter.h:18-21
+        err = &f->error(); filter = std::move(f); out = argv[7];
+    } else if (tool == "climate" && argc == 7) {                 // host_demo climate W H heights.f32 frames out
+        if (!read_f32(argv[4], p.terrain)) { fprintf(stderr, "cannot read %s\n", argv[4]); return 2; }
+        auto f = std::make_unique<HipTemperature>(&p, atoi(argv[5]));
+        err = &f->error(); filter = std::move(f); out = argv[6];
+    } else if ((tool == "blur" || tool == "dilate" || tool == "erode" || tool == "morphgrad") && argc == 7) {   // host_demo blur W H field.f32 radius out
+        if (!read_f32(argv[4], p.terrain)) { fprintf(stderr, "cannot read %s\n", argv[4]); return 2; }
+        std::unique_ptr<HipOneShot> f;
+        if (tool == "blur") f = std::make_unique<HipBlur>(&p, (float)atof(argv[5]));
+        else if (tool == "morphgrad") f = std::make_unique<HipMorphologicalGradient>(&p, (float)atof(argv[5]));
+        else f = std::make_unique<HipMorphological>(&p, (float)atof(argv[5]), tool == "dilate" ? "max" : "min");
+        err = &f->error(); filter = std::move(f); out = argv[6];
+    } else if (tool == "thermal" && argc == 6) {                 // host_demo thermal W H terrain.f32 out
+        if (!read_f32(argv[4], p.terrain)) { fprintf(stderr, "cannot read %s\n", argv[4]); return 2; }
+        auto f = std::make_unique<HipThermalErosion>();
+        err = &f->error(); filter = std::move(f); out = argv[5];
+    } else if (tool == "flow" && argc == 8) {                    // host_demo flow W H terrain.f32 exponent lakeflag out
+        if (!read_f32(argv[4], p.terrain)) { fprintf(stderr, "cannot read %s\n", argv[4]); return 2; }
+        auto f = std::make_unique<HipFlow>(0.5f, (float)atof(argv[5]), atoi(argv[6]) != 0);
+        err = &f->error(); filter = std::move(f); out = argv[7];
+    } else { fprintf(stderr, "usage: host_demo {tectonics|noise|erosion|climate|blur|dilate|erode|morphgrad|thermal|flow} W H ... out (see host_demo.cpp)\n"); return 2; }
     int frames = 0;
     for (;;) {
         auto [finished, progress] = filter->step(&p);
@@ -60,7 +85,7 @@ static int other_tools(int argc, char **argv)
 
 int main(int argc, char **argv)
 {
-    if (argc >= 2 && (std::string(argv[1]) == "tectonics" || std::string(argv[1]) == "noise")) return other_tools(argc, argv);
+    if (argc >= 2 && !(argv[1][0] >= '0' && argv[1][0] <= '9')) return other_tools(argc, argv);
     if (argc != 8) { fprintf(stderr, "usage: host_demo W H terrain.f32 n_outer jacobi_iters diffusion_iters out_prefix\n"); return 2; }
     Project p;
     p.width = atoi(argv[1]); p.height = atoi(argv[2]);

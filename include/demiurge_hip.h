@@ -175,6 +175,14 @@ int dmg_blur(dmg_ctx *ctx, const dmg_grid *grid, float *field_inout, float radiu
 /* Temperature::run inner pass (src/filter/Temperature.cpp:140-150) n_steps times from step index first_step */
 int dmg_temperature_steps(dmg_ctx *ctx, const dmg_grid *grid, float *T_inout, const float *terrain,
                           int first_step, int n_steps);
+/* The same with the field resident on the device between calls: Temperature::run (:47-162) steps the field ten times
+ * per UI frame (:140) for as long as the tool runs, so a frame costs its kernels, not two PCIe crossings.
+ * T and terrain are copied at creation.  Destroy the handle before its context. */
+typedef struct dmg_climate dmg_climate;
+int dmg_climate_create(dmg_ctx *ctx, const dmg_grid *grid, const float *T, const float *terrain, dmg_climate **out);
+void dmg_climate_destroy(dmg_climate *k);
+int dmg_climate_steps(dmg_climate *k, int first_step, int n_steps);   /* asynchronous on the context's stream */
+int dmg_climate_get(dmg_climate *k, float *T_out);                    /* synchronises */
 /* erosion/uplift pass of cpufilter::run (src/filter/cpufilter.cpp:106-214) */
 int dmg_erosion_pass(dmg_ctx *ctx, const dmg_grid *grid, float *h_inout, const float *flow, const float *updrift,
                      float factor, float slope_exponent);
@@ -190,6 +198,15 @@ int dmg_flow_accumulate(dmg_ctx *ctx, const dmg_grid *grid, const float *h, cons
  * h_inout receives the scaled heights the reference leaves in the terrain texture. */
 int dmg_erosion_run(dmg_ctx *ctx, const dmg_grid *grid, float *h_inout, int N, int iters, float exponent,
                     float slope_exponent, float factor);
+/* The same round by round, heights resident on the device (the editor shows the terrain after every round and reports
+ * progress, cpufilter.cpp:93-104).  `lakes` = the menu's toggle handed to FlowFilter (:95, dolakes > 0).
+ * dmg_erosion_get returns the scaled heights of the current round.  Destroy the handle before its context. */
+typedef struct dmg_erosion dmg_erosion;
+int dmg_erosion_create(dmg_ctx *ctx, const dmg_grid *grid, const float *h, int N, float exponent, float slope_exponent,
+                       float factor, int lakes, dmg_erosion **out);
+void dmg_erosion_destroy(dmg_erosion *e);
+int dmg_erosion_rounds(dmg_erosion *e, int n_rounds);
+int dmg_erosion_get(dmg_erosion *e, float *h_out);
 
 /* ---- SURVEY.md section 8(f) "next" rows: adjacent Filter-menu tools on the same stencil skeleton ---- */
 /* ThermalErosion::step (src/filter/ThermalErosion.cpp:25-142): 10 rounds of talus loss + gain, in place */

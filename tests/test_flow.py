@@ -133,6 +133,36 @@ def test_erosion_run_matches_oracle(dev, oracle):
 
 
 @pytest.mark.gpu
+def test_erosion_handle_round_by_round(dev, oracle):
+    """dmg_erosion (heights resident, stepped round by round as the editor shows them) = dmg_erosion_run; with the
+    menu's lake toggle the FlowFilter of every round draws its lakes (cpufilter.cpp:95)"""
+    capi, ctx = dev
+    from demiurge_amd import synth
+    W, H, N = 128, 64, 50
+    h0 = (synth.terrain(W, H) * 100 + synth.lcg_uniform(W * H, 99).reshape(H, W) * 8).astype(np.float32)
+    grid = capi.make_grid(W, H)
+    e = capi.Erosion(ctx, grid, h0, N, 0.5, 1.0, 1.0)
+    e.rounds(1)
+    first = e.get()
+    e.rounds(3)
+    got = e.get()
+    e.close()
+    assert np.array_equal(got, ctx.erosion_run(grid, h0, N, 4, 0.5, 1.0, 1.0))
+    assert np.array_equal(first, ctx.erosion_run(grid, h0, N, 1, 0.5, 1.0, 1.0))
+    # lakes: the same loop built from the one-shot pieces
+    g = oracle.grid(W, H)
+    up = (np.maximum(h0, 0) / np.float32(N)).astype(np.float32)
+    hd = np.where(h0 <= 0, h0, h0 / np.float32(N)).astype(np.float32)
+    for i in range(2):
+        flow = ctx.flow_accumulate(grid, h0 if i == 0 else hd, 0.5, 0.5, lakes=1)
+        hd = ctx.erosion_pass(grid, hd, flow, up, 1.0, 1.0)
+    e = capi.Erosion(ctx, grid, h0, N, 0.5, 1.0, 1.0, lakes=1)
+    e.rounds(2)
+    assert np.array_equal(e.get(), hd)
+    e.close()
+
+
+@pytest.mark.gpu
 def test_flow_lake_drawing(dev, oracle):
     """FlowFilter lakeflag (the standalone Flow tool passes true, FlowFilter.cpp:24-27): lake surfaces are 0"""
     capi, ctx = dev

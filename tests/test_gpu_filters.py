@@ -63,6 +63,21 @@ def test_temperature_rough_field(dev, oracle, name, cases):
         assert np.array_equal(out, G[key]), key
 
 
+def test_climate_handle_equals_one_shot(dev):
+    """dmg_climate (field resident on the device, stepped in pieces as the editor does ten steps per frame) gives the
+    field of one dmg_temperature_steps call"""
+    capi, ctx = dev
+    G = load_golden("temperature_128x64_rough")
+    g = capi.make_grid(128, 64, tuple(G["coords"]), float(G["circ"]))
+    k = capi.Climate(ctx, g, G["T0"], G["terrain"])
+    k.steps(7000, 2)
+    k.steps(7002, 3)
+    got = k.get()
+    k.close()
+    assert np.array_equal(got, G["T5_from7000"])
+    assert np.array_equal(got, ctx.temperature_steps(g, G["T0"], G["terrain"], 7000, 5))
+
+
 def test_temperature_tap_table(oracle, tmp_path):
     """the per-row tap displacements (verified against the literal offset() arithmetic at set-up, rows that disagree
     stay literal) give the fields of the all-literal path and of the oracle: the reference's own 1000x500 size,

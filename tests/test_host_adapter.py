@@ -73,3 +73,43 @@ def test_tectonics_and_noise_adapters(oracle, tmp_path):
     assert r.returncode == 0, r.stderr
     ref = oracle.gradient_noise(oracle.grid(128, 64), np.zeros((64, 128), np.float32), "SWISS", seed=3)
     assert np.array_equal(np.fromfile(tmp_path / "noise_terrain.f32", np.float32).reshape(64, 128), ref)
+
+
+@pytest.mark.gpu
+def test_remaining_tool_adapters(tmp_path):
+    """HipErosion, HipTemperature, HipFlow (AsyncSubFilters) and the one-call tools (HipBlur, HipMorphological*,
+    HipThermalErosion) driven frame by frame like the editor, against the same work through the Python binding"""
+    build()
+    from demiurge_amd import capi, synth
+    W, H = 128, 64
+    ctx = capi.Context(0)
+    g = capi.make_grid(W, H)
+    h = (synth.terrain(W, H) * 100 + synth.lcg_uniform(W * H, 99).reshape(H, W) * 8).astype(np.float32)
+    t = tmp_path / "terrain.f32"
+    h.tofile(t)
+
+    def demo(*args):
+        r = subprocess.run([str(HOST / "host_demo")] + [str(a) for a in args], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr
+        return np.fromfile(str(args[-1]) + "_terrain.f32", np.float32).reshape(H, W)
+
+    # cpufilter: 3 rounds, lakes off / on
+    assert np.array_equal(demo("erosion", W, H, t, 3, 0, tmp_path / "ero"), ctx.erosion_run(g, h, 50, 3, 0.5, 1.0, 1.0))
+    e = capi.Erosion(ctx, g, h, 50, 0.5, 1.0, 1.0, lakes=1)
+    e.rounds(2)
+    assert np.array_equal(demo("erosion", W, H, t, 2, 1, tmp_path / "erol"), e.get())
+    e.close()
+    # Temperature: 3 frames of 10 steps from T = 50, step indices 0-9, 11-20, 22-31 (the reference's double increment)
+    T = np.full((H, W), 50, np.float32)
+    for first in (0, 11, 22):
+        T = ctx.temperature_steps(g, T, h, first, 10)
+    assert np.array_equal(demo("climate", W, H, t, 3, tmp_path / "clim"), T)
+    # FlowFilter, lakeflag on
+    assert np.array_equal(demo("flow", W, H, t, 1.0, 1, tmp_path / "flow"), ctx.flow_accumulate(g, h, 0.5, 1.0, lakes=1))
+    # one-call tools
+    assert np.array_equal(demo("blur", W, H, t, 3.0, tmp_path / "blur"), ctx.blur(g, h, 3.0))
+    assert np.array_equal(demo("dilate", W, H, t, 5.5, tmp_path / "dil"), ctx.morphological(g, h, 5.5, "max"))
+    assert np.array_equal(demo("erode", W, H, t, 5.5, tmp_path / "ero2"), ctx.morphological(g, h, 5.5, "min"))
+    assert np.array_equal(demo("morphgrad", W, H, t, 4.0, tmp_path / "mg"), ctx.morphological_gradient(g, h, 4.0))
+    assert np.array_equal(demo("thermal", W, H, t, tmp_path / "th"), ctx.thermal_erosion(g, h))
+    ctx.close()
