@@ -8,7 +8,8 @@ sweep, in 1/ghost as many messages (xGMI is latency-bound at 64 KiB).  Results a
 
 Transport: `torch.distributed` P2P -- backend "nccl" (= RCCL over xGMI) sends straight from / into the library's
 device slabs (zero copy); with backend "gloo" (CPU tests, or several ranks sharing one GPU) slabs are staged
-through host tensors.
+through host tensors.  In the Jacobi solve the exchange for the next block of sweeps overlaps the interior tiles of the
+current block's last launch (jacobi_solve).
 
 Stream contract: create the dmg context on the stream torch issues its copies / collectives on
 (`capi.Context(dev, stream=torch.cuda.current_stream().cuda_stream)`), so kernels, halo sends and halo receives
@@ -53,8 +54,10 @@ class HaloExchanger:
             self._bounce[key] = (mk(), mk())
         return self._bounce[key]
 
-    def exchange(self, ocean, field, rows):
-        """Refresh `rows` ghost rows of `field` on both sides of this rank's band."""
+    def start(self, ocean, field, rows):
+        """Post the sends and receives that refresh `rows` ghost rows of `field` on both sides of this rank's band and
+        return a token for finish().  With backend nccl the transfers run on RCCL's stream behind everything issued so
+        far on the compute stream; whatever the caller launches before finish() overlaps them."""
         dist, torch = self.dist, self.torch
         ops, post = [], []
         for side, peer in ((0, self.rank - 1), (1, self.rank + 1)):     # DMG_SIDE_SOUTH, DMG_SIDE_NORTH
@@ -81,29 +84,58 @@ class HaloExchanger:
                 ts, tr = hs, hr
             ops.append(dist.P2POp(dist.isend, ts, peer))
             ops.append(dist.P2POp(dist.irecv, tr, peer))
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
+        works = dist.batch_isend_irecv(ops) if ops else []
+        return works, post, ocean
+
+    def finish(self, token):
+        """Wait for the transfers of start() (nccl: the compute stream waits, not the host) and land staged copies."""
+        works, post, ocean = token
+        for w in works:
+            w.wait()
         for kind, dst, src, nbytes in post:
             if kind == "h2d":
                 dst.copy_(src)
             else:
                 ocean.ctx.copy_device(dst, src.data_ptr(), nbytes)
 
+    def exchange(self, ocean, field, rows):
+        """Refresh `rows` ghost rows of `field` on both sides of this rank's band."""
+        self.finish(self.start(ocean, field, rows))
+
+
+def _overlap_enabled(ocean):
+    import os
+    return os.environ.get("DMG_HALO_OVERLAP", "1") != "0" and hasattr(ocean, "jacobi_sweeps_begin")
+
 
 def jacobi_solve(ocean, exch, sweeps, ghost, zero_first=True, field=0):
     """OceanCurrents::jacobi (reference OceanCurrents.cpp:437-509) over latitude bands: pressure := 0, then
-    `sweeps` sweeps in blocks of `ghost` with one halo refresh per block.  Returns the number of sweep launches."""
+    `sweeps` sweeps in blocks of `ghost` with one halo refresh per block.  Returns the number of sweep launches.
+
+    The refresh for block b+1 is posted as soon as the rows it carries exist -- after the edge tiles of block b's last
+    launch -- and overlaps the interior tiles of that launch (dmg_ocean_jacobi_sweeps_begin/_end); DMG_HALO_OVERLAP=0
+    (or an ocean without the split call) falls back to exchange-then-sweep.  Both orders give the same bits."""
     if zero_first:
         ocean.zero_pressure()
     if exch is None or exch.world == 1:
         ocean.jacobi_sweeps(sweeps)
         return sweeps
+    overlap = _overlap_enabled(ocean)
     done = 0
+    if overlap and sweeps > 0:
+        exch.exchange(ocean, field, ghost)              # ghost rows for the first block
     while done < sweeps:
         n = min(ghost, sweeps - done)
-        exch.exchange(ocean, field, ghost)
-        ocean.jacobi_sweeps(n)
+        if not overlap:
+            exch.exchange(ocean, field, ghost)
+            ocean.jacobi_sweeps(n)
+        elif done + n < sweeps:
+            ocean.jacobi_sweeps_begin(n)                # ... up to the edge tiles of the block's last launch
+            token = exch.start(ocean, field, ghost)     # their rows travel
+            ocean.jacobi_sweeps_end()                   # while the interior tiles are swept
+            exch.finish(token)
+        else:
+            ocean.jacobi_sweeps(n)                      # last block: nobody waits for its rows
         done += n
     return sweeps
 

@@ -113,6 +113,8 @@ def lib():
         "dmg_ocean_jacobi": (c_int, [vp, c_int, c_int]),
         "dmg_ocean_jacobi_sweeps": (c_int, [vp, c_int]),
         "dmg_ocean_zero_pressure": (c_int, [vp]),
+        "dmg_ocean_jacobi_sweeps_begin": (c_int, [vp, c_int]),
+        "dmg_ocean_jacobi_sweeps_end": (c_int, [vp]),
         "dmg_ocean_counters": (c_int, [vp, ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_longlong)]),
         "dmg_ocean_halo": (c_int, [vp, c_int, c_int, c_int, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(sz)]),
         "dmg_ocean_step": (c_int, [vp, c_int]),
@@ -422,6 +424,13 @@ class Ocean:
 
     def jacobi_sweeps(self, n):
         check(lib().dmg_ocean_jacobi_sweeps(self.h, int(n)))
+
+    def jacobi_sweeps_begin(self, n):
+        """all of a block of n sweeps but the interior tiles of its last launch; halo() then serves the new iterate"""
+        check(lib().dmg_ocean_jacobi_sweeps_begin(self.h, int(n)))
+
+    def jacobi_sweeps_end(self):
+        check(lib().dmg_ocean_jacobi_sweeps_end(self.h))
 
     def counters(self):
         """-> (jacobi kernel launches, jacobi sweeps) since creation"""

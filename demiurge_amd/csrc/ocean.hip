@@ -335,7 +335,9 @@ int dmg_ocean_set_pressure(dmg_ocean *o, const float *pressure)
 {
     DMG_CHECK_ARG(o != nullptr && pressure != nullptr);
     if (!o->have_terrain) return dmg_fail(DMG_ESTATE, "dmg_ocean_set_terrain must come first");
-    int rc = ocean_upload_rows(o, o->p[o->cur], pressure, 1);
+    int rc = no_pending(o, "dmg_ocean_set_pressure");
+    if (rc) return rc;
+    rc = ocean_upload_rows(o, o->p[o->cur], pressure, 1);
     if (rc) return rc;
     return zero_land(o, o->p[o->cur]);      // the other buffer already holds 0 on land
 }
@@ -343,6 +345,7 @@ int dmg_ocean_set_pressure(dmg_ocean *o, const float *pressure)
 int dmg_ocean_zero_pressure(dmg_ocean *o)
 {
     DMG_CHECK_ARG(o != nullptr);
+    { int prc = no_pending(o, "dmg_ocean_zero_pressure"); if (prc) return prc; }
     // OceanCurrents.cpp:495-497  p->apply(setzero, pressure)
     DMG_HIP(hipMemsetAsync(o->p[o->cur], 0, (size_t)o->L * o->grid.W * 4, o->ctx->stream));
     return DMG_OK;
@@ -351,6 +354,7 @@ int dmg_ocean_zero_pressure(dmg_ocean *o)
 int dmg_ocean_jacobi_sweeps(dmg_ocean *o, int n)
 {
     DMG_CHECK_ARG(o != nullptr && n >= 0);
+    { int prc = no_pending(o, "dmg_ocean_jacobi_sweeps"); if (prc) return prc; }
     if (!o->have_terrain) return dmg_fail(DMG_ESTATE, "dmg_ocean_set_terrain must come first");
     if (o->count > 1 && n > o->ghost)
         return dmg_fail(DMG_EINVAL, "%d sweeps between halo refreshes but only %d ghost rows", n, o->ghost);
@@ -380,6 +384,53 @@ int dmg_ocean_jacobi_sweeps(dmg_ocean *o, int n)
         o->n_launches++; o->n_sweeps++;
     }
     return DMG_OK;
+}
+
+// A block of sweeps split so that the halo exchange of the NEXT block overlaps this block's last launch:
+//   _begin  runs every launch of the block but the last, then only those tiles of the last launch that produce the rows
+//           the neighbour bands wait for (the outermost `ghost` owned rows on each side), and makes that buffer current
+//           -- dmg_ocean_halo() now returns slabs of the new iterate, the host starts its sends and receives;
+//   _end    sweeps the remaining (interior) tiles of the last launch, which neither read the ghost rows being received
+//           nor write the rows being sent.
+// Both parts belong to one tiling of the same launch: results are bit-identical to dmg_ocean_jacobi_sweeps(o, n).
+// Without the blocked kernel (or with a single band) _begin does the whole block and _end nothing.
+int dmg_ocean_jacobi_sweeps_begin(dmg_ocean *o, int n)
+{
+    DMG_CHECK_ARG(o != nullptr && n >= 0);
+    if (!o->have_terrain) return dmg_fail(DMG_ESTATE, "dmg_ocean_set_terrain must come first");
+    int rc = no_pending(o, "dmg_ocean_jacobi_sweeps_begin");
+    if (rc) return rc;
+    const bool blocked = o->prm.jacobi_kernel != DMG_JACOBI_SINGLE && ocean_tb_supported(o);
+    static const int cap = [] { const char *e = getenv("DMG_TB_SWEEPS"); int v = e ? atoi(e) : 8; return v >= 1 && v <= 8 ? v : 8; }();
+    if (!blocked || o->count == 1 || n == 0 || cap != 8) return dmg_ocean_jacobi_sweeps(o, n);
+    if (n > o->ghost)
+        return dmg_fail(DMG_EINVAL, "%d sweeps between halo refreshes but only %d ghost rows", n, o->ghost);
+    DMG_HIP(hipSetDevice(o->ctx->device));
+    const int last = n - ((n - 1) / 8) * 8;              // sweeps of the block's last launch (1..8)
+    if (n > last) { rc = dmg_ocean_jacobi_sweeps(o, n - last); if (rc) return rc; }
+    const int k = n;                                     // sweeps since the last halo refresh once this launch is done
+    const int lo = o->gs ? k : 0, hi = o->L - (o->gn ? k : 0);
+    const int zone_lo = o->gs ? std::min(o->gs + o->ghost, hi) : lo;      // end of the rows sent southwards
+    const int zone_hi = o->gn ? std::max(o->L - o->gn - o->ghost, lo) : hi;   // start of the rows sent northwards
+    rc = ocean_launch_tb(o, lo, hi, last, 1, zone_lo, zone_hi);
+    if (rc) return rc;
+    o->pending.active = true;
+    o->pending.lo = lo; o->pending.hi = hi; o->pending.n = last; o->pending.zone_lo = zone_lo; o->pending.zone_hi = zone_hi;
+    o->cur ^= 1;                                         // the slabs handed out from now on are the new iterate's
+    o->n_launches++; o->n_sweeps += last;
+    return DMG_OK;
+}
+
+int dmg_ocean_jacobi_sweeps_end(dmg_ocean *o)
+{
+    DMG_CHECK_ARG(o != nullptr);
+    if (!o->pending.active) return DMG_OK;
+    DMG_HIP(hipSetDevice(o->ctx->device));
+    o->cur ^= 1;                                         // read the previous iterate, write the one made current by _begin
+    int rc = ocean_launch_tb(o, o->pending.lo, o->pending.hi, o->pending.n, 2, o->pending.zone_lo, o->pending.zone_hi);
+    o->cur ^= 1;
+    o->pending.active = false;
+    return rc;
 }
 
 int dmg_ocean_counters(dmg_ocean *o, long long *jacobi_launches, long long *jacobi_sweeps)
@@ -431,6 +482,7 @@ int dmg_ocean_get(dmg_ocean *o, float *vx, float *vy, float *pressure, float *di
     DMG_CHECK_ARG(o != nullptr);
     DMG_HIP(hipSetDevice(o->ctx->device));
     int rc;
+    if (pressure && (rc = no_pending(o, "dmg_ocean_get(pressure)"))) return rc;
     if (pressure && (rc = ocean_download_rows(o, pressure, o->p[o->cur], 1))) return rc;
     if (divw && (rc = ocean_download_rows(o, divw, o->divw, 1))) return rc;
     if (vx || vy) {

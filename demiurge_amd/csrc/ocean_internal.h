@@ -40,12 +40,16 @@ struct dmg_ocean {
     unsigned char *rowclass = nullptr; // blocked Jacobi: class of every (tile column, row) wave-row (ocean_jacobi_tb.hip)
     std::vector<unsigned char> rowclass_host;   // the same table on the host, for the live-tile lists
     struct tile_list { int *d = nullptr; int n = 0; };
-    std::map<std::tuple<int, int, int>, tile_list> tb_lists;   // (out_lo, out_hi, rows per wave) of a launch -> tiles that are not land everywhere
+    // (out_lo, out_hi, rows per wave, part, zone_lo, zone_hi) of a launch -> tiles that are not land everywhere; part 0 = all
+    // tile rows, 1 = tile rows touching the send zones [out_lo, zone_lo) / [zone_hi, out_hi), 2 = the tile rows in between
+    std::map<std::tuple<int, int, int, int, int, int>, tile_list> tb_lists;
     struct tb_tune { int trials[3] = { 0, 0, 0 }; float best_ms[3] = { 1e30f, 1e30f, 1e30f }; int chosen = -1; };
     std::map<std::pair<int, int>, tb_tune> tb_tuning;           // (out_lo, out_hi) -> which tile shape is fastest there
     hipEvent_t tune_ev0 = nullptr, tune_ev1 = nullptr;
     float *v[2] = { nullptr, nullptr };   // interleaved (vx,vy)
     int vcur = 0;
+    // dmg_ocean_jacobi_sweeps_begin/_end: the interior part of a block's last launch, still to be issued
+    struct { bool active = false; int lo = 0, hi = 0, n = 0, zone_lo = 0, zone_hi = 0; } pending;
     int *oob_flag = nullptr;       // device word: advect out-of-band flag / reduction scratch
     float *rowtab = nullptr;       // ROWTAB_FIELDS arrays of L floats
     const float *jac_cx = nullptr, *jac_cy = nullptr, *jac_beta = nullptr;
@@ -55,11 +59,20 @@ struct dmg_ocean {
     const float *rt(int field) const { return rowtab + (size_t)field * L; }
 };
 
+// between dmg_ocean_jacobi_sweeps_begin and _end the pressure buffers are half a launch apart
+static inline int no_pending(const dmg_ocean *o, const char *what)
+{
+    if (o->pending.active)
+        return dmg_fail(DMG_ESTATE, "%s between dmg_ocean_jacobi_sweeps_begin and dmg_ocean_jacobi_sweeps_end", what);
+    return DMG_OK;
+}
+
 int ocean_upload_row_tables(dmg_ocean *o);
 int ocean_build_codes(dmg_ocean *o);
 int ocean_build_codes8(dmg_ocean *o);
 int ocean_zero_land(dmg_ocean *o);            // p := +0 on land in BOTH ping-pong buffers (invariant of the blocked kernel)
-int ocean_launch_tb(dmg_ocean *o, int lo, int hi, int n);   // ocean_jacobi_tb.hip
+// ocean_jacobi_tb.hip: n (1..8) sweeps over local rows [lo, hi); part/zone: see tb_lists (part 0: zones ignored)
+int ocean_launch_tb(dmg_ocean *o, int lo, int hi, int n, int part = 0, int zone_lo = 0, int zone_hi = 0);
 int ocean_launch_diffusion_tb(dmg_ocean *o, int lo, int hi, int n);   // ocean_diffusion_tb.hip: n (1..8) sweeps over local rows [lo, hi)
 bool ocean_tb_supported(const dmg_ocean *o);
 int ocean_build_rowclass(dmg_ocean *o);

@@ -314,26 +314,35 @@ int ocean_build_rowclass(dmg_ocean *o)
 // terrain; each would hold a workgroup slot for a few microseconds).  Rows beyond the stored band or the grid count as
 // not-land, as in the kernel.  Built on the host from the class table, once per (lo, hi) and terrain.
 template <int R, int NW>
-static const dmg_ocean::tile_list *tb_live_tiles(dmg_ocean *o, int lo, int hi, int tiles_x, int tiles_y)
+static const dmg_ocean::tile_list *tb_live_tiles(dmg_ocean *o, int lo, int hi, int tiles_x, int tiles_y, int part, int zone_lo, int zone_hi)
 {
-    auto key = std::make_tuple(lo, hi, R);
+    auto key = std::make_tuple(lo, hi, R, part, zone_lo, zone_hi);
     auto it = o->tb_lists.find(key);
     if (it != o->tb_lists.end()) return &it->second;
     constexpr int EH = R * NW, OH = EH - 2 * TB_T;
     const int y_first = o->y0 - o->gs, L = o->L, H = o->grid.H;
+    const bool classes = !o->rowclass_host.empty();
     std::vector<int> live;
     live.reserve((size_t)tiles_x * tiles_y);
-    for (int ty = 0; ty < tiles_y; ty++)
+    for (int ty = 0; ty < tiles_y; ty++) {
+        if (part) {                                       // tile rows that produce rows of a send zone vs the rest
+            const int r0 = lo + ty * OH, r1 = std::min(r0 + OH, hi);
+            const bool edge = r0 < zone_lo || r1 > zone_hi;
+            if (edge != (part == 1)) continue;
+        }
         for (int tx = 0; tx < tiles_x; tx++) {
-            const unsigned char *cls = o->rowclass_host.data() + (size_t)tx * L;
-            const int e0 = lo + ty * OH - TB_T;
-            bool dead = true;
-            for (int e = 0; e < EH && dead; e++) {
-                int lu = e0 + e, yg = y_first + lu;
-                dead = yg >= 0 && yg < H && lu >= 0 && lu < L && cls[lu] == 1;
+            bool dead = classes;
+            if (classes) {
+                const unsigned char *cls = o->rowclass_host.data() + (size_t)tx * L;
+                const int e0 = lo + ty * OH - TB_T;
+                for (int e = 0; e < EH && dead; e++) {
+                    int lu = e0 + e, yg = y_first + lu;
+                    dead = yg >= 0 && yg < H && lu >= 0 && lu < L && cls[lu] == 1;
+                }
             }
             if (!dead) live.push_back(ty * tiles_x + tx);
         }
+    }
     dmg_ocean::tile_list tl;
     tl.n = (int)live.size();
     if (tl.n && hipMalloc((void **)&tl.d, live.size() * sizeof(int)) != hipSuccess) return nullptr;
@@ -360,7 +369,8 @@ static tb_shape tb_forced_shape()
 }
 
 template <int R, int NW>
-static void tb_launch(dmg_ocean *o, tb_args a, int W, int rows, hipStream_t stream, float *ms = nullptr)
+static int tb_launch(dmg_ocean *o, tb_args a, int W, int rows, hipStream_t stream, float *ms = nullptr, int part = 0, int zone_lo = 0,
+                     int zone_hi = 0)
 {
     constexpr int OH = R * NW - 2 * TB_T;
     a.tiles_x = (W + TB_OW - 1) / TB_OW;
@@ -371,13 +381,15 @@ static void tb_launch(dmg_ocean *o, tb_args a, int W, int rows, hipStream_t stre
     a.tile_list = nullptr;
     size_t nt = (size_t)a.tiles_x * a.tiles_y;
     static const bool all_tiles = getenv("DMG_TB_ALLTILES") != nullptr;
-    if (a.rowclass && order == 0 && !all_tiles) {
-        const dmg_ocean::tile_list *tl = tb_live_tiles<R, NW>(o, a.out_lo, a.out_hi, a.tiles_x, a.tiles_y);
-        if (tl) {
-            if (tl->n == 0) return;                       // land everywhere: nothing changes
+    if ((a.rowclass && order == 0 && !all_tiles) || part) {
+        const dmg_ocean::tile_list *tl = tb_live_tiles<R, NW>(o, a.out_lo, a.out_hi, a.tiles_x, a.tiles_y, part, zone_lo, zone_hi);
+        if (!tl && part) return dmg_fail(DMG_ENOMEM, "tile list allocation failed");
+        if (tl) {                                         // (no list for a whole launch: every tile runs)
+            if (tl->n == 0) return DMG_OK;                // land everywhere, or an empty part: nothing to do
             a.tile_list = tl->d;
             nt = (size_t)tl->n;
         }
+        if (part) a.order = 0;                            // lists of a part hold natural tile ids
     }
     static const char *trace_path = getenv("DMG_TB_TRACE");      // experiments: dump the per-workgroup timeline of every launch
     if (trace_path) {
@@ -401,10 +413,13 @@ static void tb_launch(dmg_ocean *o, tb_args a, int W, int rows, hipStream_t stre
         (void)hipFree(a.trace);
         if (FILE *f = fopen(trace_path, "wb")) { fwrite(h.data(), 48, nt, f); fclose(f); }
     }
+    return DMG_OK;
 }
 
 // host launcher: `n` (1..8) sweeps over local rows [lo, hi).  The caller flips o->cur.
-int ocean_launch_tb(dmg_ocean *o, int lo, int hi, int n)
+// part 1 / 2 launch only the tile rows that do / do not produce rows of [lo, zone_lo) or [zone_hi, hi): the two parts of
+// one tiling, so that the rows a neighbour band waits for can be sent while the rest is still being swept.
+int ocean_launch_tb(dmg_ocean *o, int lo, int hi, int n, int part, int zone_lo, int zone_hi)
 {
     if (hi <= lo) return DMG_OK;
     tb_args a;
@@ -437,7 +452,7 @@ int ocean_launch_tb(dmg_ocean *o, int lo, int hi, int n)
         const int tiles88 = ((a.W + TB_OW - 1) / TB_OW) * ((hi - lo + 47) / 48);
         if (tiles88 <= 4096 && n == TB_T && a.rowclass) {
             tune = &o->tb_tuning[std::make_pair(lo, hi)];
-            if (tune->chosen < 0) {
+            if (tune->chosen < 0 && !part) {
                 if (!o->tune_ev0 && (hipEventCreate(&o->tune_ev0) != hipSuccess || hipEventCreate(&o->tune_ev1) != hipSuccess))
                     return dmg_fail(DMG_EHIP, "hipEventCreate failed");
                 cand = 0;
@@ -448,16 +463,20 @@ int ocean_launch_tb(dmg_ocean *o, int lo, int hi, int n)
                     cand = -1;
                 } else ms = &ms_val;
             }
-            sh = cands[cand >= 0 ? cand : tune->chosen];
+            // the two parts of a split launch share one tiling: the geometry's chosen shape, or the default until the
+            // whole launches of this geometry have been timed
+            sh = cands[cand >= 0 ? cand : (tune->chosen >= 0 ? tune->chosen : 0)];
         }
     }
-    if (sh.R == 4) tb_launch<4, 8>(o, a, a.W, hi - lo, st, ms);
-    else if (sh.R == 6) tb_launch<6, 8>(o, a, a.W, hi - lo, st, ms);
-    else if (sh.R == 16) tb_launch<16, 8>(o, a, a.W, hi - lo, st, ms);
-    else if (sh.R == 10) tb_launch<10, 8>(o, a, a.W, hi - lo, st, ms);
-    else if (sh.R == 12) tb_launch<12, 8>(o, a, a.W, hi - lo, st, ms);
-    else if (sh.NW == 16) tb_launch<8, 16>(o, a, a.W, hi - lo, st, ms);
-    else tb_launch<8, 8>(o, a, a.W, hi - lo, st, ms);
+    int rc;
+    if (sh.R == 4) rc = tb_launch<4, 8>(o, a, a.W, hi - lo, st, ms, part, zone_lo, zone_hi);
+    else if (sh.R == 6) rc = tb_launch<6, 8>(o, a, a.W, hi - lo, st, ms, part, zone_lo, zone_hi);
+    else if (sh.R == 16) rc = tb_launch<16, 8>(o, a, a.W, hi - lo, st, ms, part, zone_lo, zone_hi);
+    else if (sh.R == 10) rc = tb_launch<10, 8>(o, a, a.W, hi - lo, st, ms, part, zone_lo, zone_hi);
+    else if (sh.R == 12) rc = tb_launch<12, 8>(o, a, a.W, hi - lo, st, ms, part, zone_lo, zone_hi);
+    else if (sh.NW == 16) rc = tb_launch<8, 16>(o, a, a.W, hi - lo, st, ms, part, zone_lo, zone_hi);
+    else rc = tb_launch<8, 8>(o, a, a.W, hi - lo, st, ms, part, zone_lo, zone_hi);
+    if (rc) return rc;
     if (ms && cand >= 0) {
         tune->trials[cand]++;
         if (ms_val < tune->best_ms[cand]) tune->best_ms[cand] = ms_val;

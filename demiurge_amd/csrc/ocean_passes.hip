@@ -431,6 +431,7 @@ int dmg_ocean_subdiv(dmg_ocean *o)
 {
     int rc = require_terrain(o, "dmg_ocean_subdiv");
     if (rc) return rc;
+    if ((rc = no_pending(o, "dmg_ocean_subdiv"))) return rc;
     rc = launch_rows(o, k_subdiv, make_args(o), o->gs, o->gs + (o->y1 - o->y0));
     if (rc) return rc;
     o->vcur ^= 1;                                          // v->swap(v_scratch) (:621)

@@ -137,6 +137,14 @@ int dmg_ocean_jacobi(dmg_ocean *o, int iters, int zero_first);
  * rows are n sweeps ahead and the ghost rows are stale until the host refreshes them via dmg_ocean_halo. */
 int dmg_ocean_jacobi_sweeps(dmg_ocean *o, int n);
 int dmg_ocean_zero_pressure(dmg_ocean *o);
+/* The same block of n sweeps in two calls, so that the host can exchange the NEXT block's ghost rows while this
+ * block's last launch is still running: _begin runs all but the interior tiles of the last launch and makes the new
+ * iterate current (dmg_ocean_halo then returns its slabs: start the sends/receives), _end sweeps the interior tiles,
+ * which touch neither the rows being sent nor the ghost rows being received.  Bit-identical to
+ * dmg_ocean_jacobi_sweeps(o, n); with one band or without the blocked kernel _begin does everything.  Between the two
+ * calls only dmg_ocean_halo (and velocity / terrain accessors) may be used on this ocean. */
+int dmg_ocean_jacobi_sweeps_begin(dmg_ocean *o, int n);
+int dmg_ocean_jacobi_sweeps_end(dmg_ocean *o);
 /* cumulative counters since creation: Jacobi kernel launches and sweeps performed (a temporally blocked launch
  * advances up to 8 sweeps) -- what bench.py divides its HIP-event time by */
 int dmg_ocean_counters(dmg_ocean *o, long long *jacobi_launches, long long *jacobi_sweeps);
