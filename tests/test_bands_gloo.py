@@ -96,3 +96,17 @@ def test_bench_multi_rank_rehearsal(tmp_path):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and d["roofline"]["sweeps_per_launch"] == 8.0
     assert "2 latitude bands" in d["config"]["parallelism"]
+
+
+@pytest.mark.gpu
+def test_overlapped_solve_over_rccl():
+    """backend nccl (= RCCL) on this box's single GPU: two bands of one process exchange their halos with
+    ncclSend/ncclRecv to the process's own rank, so the transfers run on RCCL's own stream next to the interior tiles --
+    the stream ordering the gloo tests cannot reach.  Both orders must reproduce the single-band solve bit for bit."""
+    import os, subprocess, sys
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
+    r = subprocess.run([sys.executable, str(ROOT / "tools" / "nccl_self_probe.py"), "1024", "512", "100", "16"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=str(ROOT))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if "bit-identical" in l]
+    assert len(lines) == 2 and all(l.rstrip().endswith("True") for l in lines), r.stdout
