@@ -11,6 +11,22 @@
 #include "../../include/demiurge_hip.h"
 #include "glsl_math.h"
 
+// x / c for a constant c with r = RN(1/c):  q = x*r ; q' = fma(fma(-c, q, x), r, q)   (Markstein correction).
+// Equals the IEEE quotient RN(x/c) for finite x with 2^-100 <= |x| <= 2^100 (and for x = 0); outside that range the
+// remainder can underflow or the product overflow, and callers that can meet such values fall back to the IEEE
+// sequence (dmg_div_rc_safe).  See oracle/dmg_oracle.c div_rc() and DESIGN.md section 4.
+__device__ __forceinline__ float dmg_div_rc(float x, float c, float r)
+{
+    float q = __fmul_rn(x, r);
+    return __fmaf_rn(__fmaf_rn(-c, q, x), r, q);
+}
+// true where dmg_div_rc(x, ...) is the IEEE quotient for certain (NaN and infinities compare false)
+__device__ __forceinline__ bool dmg_div_rc_exact_for(float x)
+{
+    float a = fabsf(x);
+    return x == 0.0f || (a >= 0x1p-100f && a <= 0x1p100f);
+}
+
 struct dmg_ctx {
     // scratch blocks handed back by finished calls, by size.  The filters that loop (erosion: ~45 temporaries per
     // flow solve, 1000 solves) would otherwise pay hipMalloc + a device-synchronising hipFree for each of them every

@@ -131,45 +131,121 @@ __global__ __launch_bounds__(256) void k_temperature_taps(canvas c, const float 
     if (!ok) atomicOr(&literal_row[y], 1);
 }
 
-__global__ __launch_bounds__(256) void k_temperature(canvas c, const float *__restrict__ T, float *__restrict__ out,
-                                                     const float *__restrict__ terrain, const float *__restrict__ asr,
-                                                     const float *__restrict__ cosphi, const float *__restrict__ dyrow,
-                                                     float ref_t4, const int *__restrict__ shift, const int *__restrict__ srow,
-                                                     const int *__restrict__ literal_row)
+struct temp_consts { float ref_t4, r_t4, r_15000, r_c_land, r_c_ocean; };
+
+// one cell of the step (Temperature.cpp:97-133) from its own value, the terrain height and the nine Laplacian taps
+__device__ __forceinline__ float temperature_update(float Tc, float terr, const float s[9], float asr, float den, float rden,
+                                                    const temp_consts &k)
 {
-    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= c.W) return;
-    float factor = cosphi[y];                        // get_texture_laplacian: cos(geo.y) (Shader.h:301-302)
-    float dy = dyrow[y];
-    float den = __fmul_rn(4.0f, __fmul_rn(dy, dy));  // 4*pow(pixelwidth.y,2)
-    float Tc = T[(size_t)y * c.W + x];
-    float terr = terrain[(size_t)y * c.W + x];
-    float s[9];
-    if (!literal_row[y]) {                           // row-uniform: the verified per-row displacements
-#pragma unroll
-        for (int k = 0; k < 9; k++) s[k] = T[(size_t)srow[y * 9 + k] * c.W + temperature_shifted(c, x, shift[y * 9 + k])];
-    } else {
-#pragma unroll
-        for (int k = 0; k < 9; k++) {
-            int i, j;
-            temperature_tap(c, x, y, k, factor, &i, &j);
-            s[k] = T[(size_t)j * c.W + i];
-        }
-    }
     float A_ = s[0], B_ = s[1], C_ = s[2], D_ = s[3], E_ = s[4], F_ = s[5], G_ = s[6], H_ = s[7], I_ = s[8];
     // (a - 2*b + c + 2*d - 4*e + 2*f + g - 2*h + i) and (a + 2*b + c - 2*d - 4*e - 2*f + g + 2*h + i), left to right
     float nx = __fadd_rn(__fsub_rn(__fadd_rn(__fadd_rn(__fsub_rn(__fadd_rn(__fadd_rn(__fsub_rn(A_, __fmul_rn(2.0f, B_)), C_), __fmul_rn(2.0f, D_)), __fmul_rn(4.0f, E_)), __fmul_rn(2.0f, F_)), G_), __fmul_rn(2.0f, H_)), I_);
     float ny = __fadd_rn(__fadd_rn(__fadd_rn(__fsub_rn(__fsub_rn(__fsub_rn(__fadd_rn(__fadd_rn(A_, __fmul_rn(2.0f, B_)), C_), __fmul_rn(2.0f, D_)), __fmul_rn(4.0f, E_)), __fmul_rn(2.0f, F_)), G_), __fmul_rn(2.0f, H_)), I_);
-    float delta_x = __fdiv_rn(nx, den), delta_y = __fdiv_rn(ny, den);
-    if (isnan(delta_x)) delta_x = 0.0f;
-    if (isnan(delta_y)) delta_y = 0.0f;
+    // The five divisions of the step are by row or literal constants: Markstein form through the constant's correctly
+    // rounded reciprocal (3 ops instead of the ~14 issue slots of the IEEE sequence), with the IEEE sequence kept for the
+    // numerators that form is not exact for -- 0 < |n| < 2^-100, |n| > 2^100, inf, NaN (the reference's explicit scheme
+    // does blow up at fine resolutions, so non-finite fields are real inputs here).
     float t = __fadd_rn(Tc, 273.15f);
     float t2 = __fmul_rn(t, t);                                                   // pow(x,4) -> (x*x)*(x*x); pow(273.4,4): host constant
-    float OLR = __fmul_rn(__fdiv_rn(__fmul_rn(t2, __fmul_rn(t2, 210.0f)), ref_t4), 0.93f);   // :125, associated as Mesa does: x2*(x2*210)
-    float change = __fadd_rn(__fsub_rn(asr[y], OLR), __fmul_rn(__fmul_rn(0.55f, 1e6f), __fadd_rn(delta_x, delta_y)));   // :128
-    float atmosphere = 1e7f;
-    float Cc = __fadd_rn(atmosphere, terr > 0.0f ? __fmul_rn(atmosphere, 0.5f) : __fmul_rn(__fmul_rn(4.0f, 1.5f), atmosphere));
-    out[(size_t)y * c.W + x] = __fadd_rn(Tc, __fdiv_rn(__fdiv_rn(__fmul_rn(change, __fmul_rn(3.154f, 1e7f)), 15000.0f), Cc));   // :133, the two factors merged
+    float olr_n = __fmul_rn(t2, __fmul_rn(t2, 210.0f));                           // :125, associated as Mesa does: x2*(x2*210)
+    float delta_x, delta_y, olr_q;
+    {
+        const float thr = 0x1p-100f, big = 0x1p100f;
+        float lo = fminf(fminf(fabsf(nx), fabsf(ny)), fabsf(olr_n));
+        bool fast = lo >= thr && fabsf(nx) <= big && fabsf(ny) <= big && fabsf(olr_n) <= big;          // NaN fails
+        if (!fast) fast = dmg_div_rc_exact_for(nx) && dmg_div_rc_exact_for(ny) && dmg_div_rc_exact_for(olr_n);   // zeros are fine
+        if (fast) {
+            delta_x = dmg_div_rc(nx, den, rden); delta_y = dmg_div_rc(ny, den, rden);
+            olr_q = dmg_div_rc(olr_n, k.ref_t4, k.r_t4);
+        } else {
+            delta_x = __fdiv_rn(nx, den); delta_y = __fdiv_rn(ny, den);
+            olr_q = __fdiv_rn(olr_n, k.ref_t4);
+        }
+    }
+    if (isnan(delta_x)) delta_x = 0.0f;
+    if (isnan(delta_y)) delta_y = 0.0f;
+    float OLR = __fmul_rn(olr_q, 0.93f);
+    float change = __fadd_rn(__fsub_rn(asr, OLR), __fmul_rn(__fmul_rn(0.55f, 1e6f), __fadd_rn(delta_x, delta_y)));   // :128
+    const bool land = terr > 0.0f;
+    const float Cc = land ? 1.5e7f : 7e7f;          // atmosphere + (terrain>0 ? atmosphere*0.5 : 4*1.5*atmosphere), atmosphere = 1e7 (:131-132)
+    const float rCc = land ? k.r_c_land : k.r_c_ocean;
+    float n1 = __fmul_rn(change, __fmul_rn(3.154f, 1e7f));                        // :133, the two factors merged
+    float q1 = dmg_div_rc_exact_for(n1) ? dmg_div_rc(n1, 15000.0f, k.r_15000) : __fdiv_rn(n1, 15000.0f);
+    float q2 = dmg_div_rc_exact_for(q1) ? dmg_div_rc(q1, Cc, rCc) : __fdiv_rn(q1, Cc);
+    return __fadd_rn(Tc, q2);
+}
+
+// One cell per thread: rows whose taps stay literal (only_literal != 0: the rows listed in `rows`), or every row of a
+// grid whose width is not a multiple of 4 (only_literal == 0, rows == null).
+__global__ __launch_bounds__(256) void k_temperature(canvas c, const float *__restrict__ T, float *__restrict__ out,
+                                                     const float *__restrict__ terrain, const float *__restrict__ asr,
+                                                     const float *__restrict__ cosphi, const float *__restrict__ dyrow,
+                                                     const float *__restrict__ rdenrow, temp_consts k,
+                                                     const int *__restrict__ shift, const int *__restrict__ srow,
+                                                     const int *__restrict__ literal_row, const int *__restrict__ rows)
+{
+    const int y = rows ? rows[blockIdx.y] : (int)blockIdx.y;
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= c.W) return;
+    float factor = cosphi[y];                        // get_texture_laplacian: cos(geo.y) (Shader.h:301-302)
+    float dy = dyrow[y];
+    float den = __fmul_rn(4.0f, __fmul_rn(dy, dy));  // 4*pow(pixelwidth.y,2)
+    float s[9];
+    if (!literal_row[y]) {                           // row-uniform: the verified per-row displacements
+#pragma unroll
+        for (int t = 0; t < 9; t++) s[t] = T[(size_t)srow[y * 9 + t] * c.W + temperature_shifted(c, x, shift[y * 9 + t])];
+    } else {
+#pragma unroll
+        for (int t = 0; t < 9; t++) {
+            int i, j;
+            temperature_tap(c, x, y, t, factor, &i, &j);
+            s[t] = T[(size_t)j * c.W + i];
+        }
+    }
+    size_t p = (size_t)y * c.W + x;
+    out[p] = temperature_update(T[p], terrain[p], s, asr[y], den, rdenrow[y], k);
+}
+
+// Four consecutive cells per thread for the rows whose tap displacements were verified (W % 4 == 0): every tap is one
+// 16-byte load at (tap row, x + displacement) -- unaligned in general, which the global load unit takes -- unless the
+// four cells straddle the seam or the clamped edge, and the index arithmetic is paid once per four cells.
+__global__ __launch_bounds__(256) void k_temperature_v4(canvas c, const float *__restrict__ T, float *__restrict__ out,
+                                                        const float *__restrict__ terrain, const float *__restrict__ asr,
+                                                        const float *__restrict__ dyrow, const float *__restrict__ rdenrow, temp_consts k,
+                                                        const int *__restrict__ shift, const int *__restrict__ srow,
+                                                        const int *__restrict__ literal_row)
+{
+    const int y = blockIdx.y;
+    const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (x0 >= c.W || literal_row[y]) return;
+    const int W = c.W;
+    float dy = dyrow[y];
+    float den = __fmul_rn(4.0f, __fmul_rn(dy, dy));
+    float s[4][9];
+#pragma unroll
+    for (int t = 0; t < 9; t++) {
+        const int sh = shift[y * 9 + t];
+        const float *row = T + (size_t)srow[y * 9 + t] * W;
+        int i = x0 + sh;
+        if (c.lonwrap && i >= W) i -= W;             // sh is a forward distance in [0, W)
+        if (i >= 0 && i + 3 < W) {
+            float4 v;
+            __builtin_memcpy(&v, row + i, 16);
+            s[0][t] = v.x; s[1][t] = v.y; s[2][t] = v.z; s[3][t] = v.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) s[j][t] = row[temperature_shifted(c, x0 + j, sh)];
+        }
+    }
+    const size_t p = (size_t)y * W + x0;
+    const float4 Tc = *reinterpret_cast<const float4 *>(T + p), terr = *reinterpret_cast<const float4 *>(terrain + p);
+    const float a = asr[y], rden = rdenrow[y];
+    float4 o;
+    o.x = temperature_update(Tc.x, terr.x, s[0], a, den, rden, k);
+    o.y = temperature_update(Tc.y, terr.y, s[1], a, den, rden, k);
+    o.z = temperature_update(Tc.z, terr.z, s[2], a, den, rden, k);
+    o.w = temperature_update(Tc.w, terr.w, s[3], a, den, rden, k);
+    *reinterpret_cast<float4 *>(out + p) = o;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -351,7 +427,9 @@ struct dmg_climate {
     dmg_ctx *ctx = nullptr;
     dmg_grid grid{};
     dmg_topology topo{};
-    dev_buf a, b, terr, dlat, dcos, ddy, dasr, dshift, dsrow, dlit;
+    dev_buf a, b, terr, dlat, dcos, ddy, drden, dasr, dshift, dsrow, dlit;
+    dev_buf dlitrows;
+    int n_literal = 0;                               // rows that keep the literal taps (their indices in dlitrows)
     float *cur = nullptr, *nxt = nullptr;
     bool taps_ready = false;
 };
@@ -366,20 +444,22 @@ int dmg_climate_create(dmg_ctx *ctx, const dmg_grid *grid, const float *T, const
     DMG_HIP(hipSetDevice(ctx->device));
     const int H = grid->H;
     const size_t n = (size_t)grid->W * H;
-    std::vector<float> lat(H), cosphi(H), dyr(H);
+    std::vector<float> lat(H), cosphi(H), dyr(H), rden(H);
     for (int y = 0; y < H; y++) {
         float dx, dy;
         dmg_row_pixelsize(*grid, y, &dx, &dy);
         lat[y] = dmg_row_lat(*grid, y);
         cosphi[y] = glsl::cos(lat[y]);
         dyr[y] = dy;
+        rden[y] = 1.0f / (4.0f * (dy * dy));         // correctly rounded reciprocal of the kernel's den = 4*pow(pixelwidth.y,2)
     }
     std::unique_ptr<dmg_climate> k(new (std::nothrow) dmg_climate);
     if (!k) return dmg_fail(DMG_ENOMEM, "out of host memory");
     k->ctx = ctx; k->grid = *grid; k->topo = topo;
     DMG_ALLOC(k->a, n * 4); DMG_ALLOC(k->b, n * 4); DMG_ALLOC(k->terr, n * 4); DMG_ALLOC(k->dasr, (size_t)H * 4);
     DMG_ALLOC(k->dshift, (size_t)H * 9 * sizeof(int)); DMG_ALLOC(k->dsrow, (size_t)H * 9 * sizeof(int)); DMG_ALLOC(k->dlit, (size_t)H * sizeof(int));
-    if ((rc = upload_rows(ctx, k->dlat, lat)) || (rc = upload_rows(ctx, k->dcos, cosphi)) || (rc = upload_rows(ctx, k->ddy, dyr))) return rc;
+    if ((rc = upload_rows(ctx, k->dlat, lat)) || (rc = upload_rows(ctx, k->dcos, cosphi)) || (rc = upload_rows(ctx, k->ddy, dyr)) ||
+        (rc = upload_rows(ctx, k->drden, rden))) return rc;
     DMG_HIP(hipMemcpyAsync(k->a.p, T, n * 4, hipMemcpyHostToDevice, ctx->stream));
     DMG_HIP(hipMemcpyAsync(k->terr.p, terrain, n * 4, hipMemcpyHostToDevice, ctx->stream));
     DMG_HIP(hipStreamSynchronize(ctx->stream));      // the caller's buffers may go away
@@ -400,27 +480,39 @@ int dmg_climate_steps(dmg_climate *k, int first_step, int n_steps)
     dim3 g((W + 255) / 256, H);
     const float sin_gamma = sinf(23.44f / 180.0f * DMG_PI);   // sin(gamma): an expression of constants, folded by Mesa on the host
     const float ref_t4 = powf(273.4f, 4.0f);                  // pow(273.4,4) (:125), likewise (not 273.4^2 squared: one ulp apart)
+    const temp_consts tc = { ref_t4, 1.0f / ref_t4, 1.0f / 15000.0f, 1.0f / 1.5e7f, 1.0f / 7e7f };   // host IEEE divisions: correctly rounded reciprocals
     if (!k->taps_ready && n_steps > 0) {
         // per-row tap displacements, verified cell by cell against the literal offset() arithmetic (once per field)
         static const bool literal_only = getenv("DMG_TEMPERATURE_LITERAL") != nullptr;      // experiments: every row literal
         DMG_HIP(hipMemsetAsync(k->dlit.p, literal_only ? 0xFF : 0, (size_t)H * sizeof(int), ctx->stream));
         hipLaunchKernelGGL(k_temperature_taps, g, dim3(256), 0, ctx->stream, c, k->dcos.f(), k->dshift.i(), k->dsrow.i(), k->dlit.i());
         DMG_HIP(hipGetLastError());
-        if (getenv("DMG_TEMPERATURE_REPORT")) {                                             // experiments: how many rows stay literal
-            std::vector<int> lit(H);
+        {                                                // which rows stay literal: needed on the host to launch the scalar kernel on them
+            std::vector<int> lit(H), rows;
             DMG_HIP(hipMemcpyAsync(lit.data(), k->dlit.p, (size_t)H * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
             DMG_HIP(hipStreamSynchronize(ctx->stream));
-            int cnt = 0;
-            for (int y = 0; y < H; y++) cnt += lit[y] != 0;
-            fprintf(stderr, "dmg_climate_steps: %d of %d rows keep the literal offset() path\n", cnt, H);
+            for (int y = 0; y < H; y++) if (lit[y]) rows.push_back(y);
+            k->n_literal = (int)rows.size();
+            if (k->n_literal) { int rc = upload_vec(ctx, k->dlitrows, rows); if (rc) return rc; }
+            if (getenv("DMG_TEMPERATURE_REPORT"))       // experiments
+                fprintf(stderr, "dmg_climate_steps: %d of %d rows keep the literal offset() path\n", k->n_literal, H);
         }
         k->taps_ready = true;
     }
     for (int i = first_step; i < first_step + n_steps; i++) {
         float M = (float)(M_PI * 2 / 15000 * i);     // glUniform1f(id, M_PI*2/15000*i) (:146)
         hipLaunchKernelGGL(k_temperature_rows, dim3((H + 255) / 256), dim3(256), 0, ctx->stream, c, k->dlat.f(), M, sin_gamma, k->dasr.f());
-        hipLaunchKernelGGL(k_temperature, g, dim3(256), 0, ctx->stream, c, k->cur, k->nxt, k->terr.f(), k->dasr.f(), k->dcos.f(), k->ddy.f(),
-                           ref_t4, (const int *)k->dshift.p, (const int *)k->dsrow.p, (const int *)k->dlit.p);
+        if (W % 4 == 0) {                            // tabled rows four cells per thread, the few literal rows one cell per thread
+            hipLaunchKernelGGL(k_temperature_v4, dim3((W / 4 + 255) / 256, H), dim3(256), 0, ctx->stream, c, k->cur, k->nxt, k->terr.f(),
+                               k->dasr.f(), k->ddy.f(), k->drden.f(), tc, (const int *)k->dshift.p, (const int *)k->dsrow.p, (const int *)k->dlit.p);
+            if (k->n_literal)
+                hipLaunchKernelGGL(k_temperature, dim3((W + 255) / 256, k->n_literal), dim3(256), 0, ctx->stream, c, k->cur, k->nxt, k->terr.f(),
+                                   k->dasr.f(), k->dcos.f(), k->ddy.f(), k->drden.f(), tc, (const int *)k->dshift.p, (const int *)k->dsrow.p,
+                                   (const int *)k->dlit.p, (const int *)k->dlitrows.p);
+        } else {
+            hipLaunchKernelGGL(k_temperature, g, dim3(256), 0, ctx->stream, c, k->cur, k->nxt, k->terr.f(), k->dasr.f(), k->dcos.f(), k->ddy.f(),
+                               k->drden.f(), tc, (const int *)k->dshift.p, (const int *)k->dsrow.p, (const int *)k->dlit.p, (const int *)nullptr);
+        }
         DMG_HIP(hipGetLastError());
         std::swap(k->cur, k->nxt);                   // terrain.swap(scratch2) (:148)
     }

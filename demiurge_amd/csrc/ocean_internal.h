@@ -84,13 +84,7 @@ int ocean_download_rows(dmg_ocean *o, float *dst_full, const float *src, int com
 // ---- Jacobi cell arithmetic shared by the single-sweep and the temporally blocked kernels ----
 struct jacobi_row { float cx, cy, beta, rx, ry, rb; };     // pw2.x, pw2.y, Beta and their correctly rounded reciprocals
 
-// x / c for a row constant c with r = RN(1/c):  q = x*r ; q' = fma(fma(-c, q, x), r, q)   (Markstein correction).
-// Equals the IEEE quotient unless the remainder underflows (|x| < 2^-100 here); see oracle/dmg_oracle.c div_rc().
-__device__ __forceinline__ float dmg_div_rc(float x, float c, float r)
-{
-    float q = __fmul_rn(x, r);
-    return __fmaf_rn(__fmaf_rn(-c, q, x), r, q);
-}
+// dmg_div_rc (x / c through the row constant's reciprocal, Markstein form) lives in dmg_internal.h
 __device__ __forceinline__ float jacobi_value(float pN, float pS, float pE, float pW, float b, const jacobi_row &k)
 {
     float t = __fadd_rn(dmg_div_rc(__fadd_rn(pW, pE), k.cx, k.rx), dmg_div_rc(__fadd_rn(pS, pN), k.cy, k.ry));

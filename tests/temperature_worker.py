@@ -19,6 +19,17 @@ def cases():
                                ("belt_256x96", 256, 96, BELT)):
         T = ((synth.lcg_uniform(W * H, 41).reshape(H, W)) * 60).astype(f32)
         yield name, W, H, coords, T, synth.terrain(W, H)
+    # values the reciprocal-based divisions of the kernel are not exact for: they must take the IEEE path
+    W, H = 256, 128
+    T = ((synth.lcg_uniform(W * H, 7).reshape(H, W)) * 40).astype(f32)
+    T[10:20, 30:60] = 0.0
+    T[30:40, :] *= f32(1e-33)
+    T[50:52, 100:140] = f32(3e-39)                     # denormals
+    T[60, 10] = np.inf; T[62, 50] = -np.inf; T[64, 90] = np.nan
+    T[70:74, 200:220] = f32(2e38); T[80:84, 20:40] = f32(-1e30)
+    T[90:100, :] = f32(-273.15)                        # t = 0: the OLR numerator is exactly 0
+    T[100:104, 64:128] = f32(-273.15) + f32(1e-5)
+    yield "weird_256x128", W, H, FULL, T, synth.terrain(W, H)
 
 
 def main(out):

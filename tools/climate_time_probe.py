@@ -1,4 +1,4 @@
-"""Times the climate step (Temperature.cpp:56-134) per step at WxH, host-to-host call cost subtracted (1 vs 41 steps).
+"""Times the climate step (Temperature.cpp:56-134) per step at WxH with the field resident on the device (dmg_climate).
 
     python tools/climate_time_probe.py [W]                verified per-row tap table (default)
     DMG_TEMPERATURE_LITERAL=1 python tools/...            literal offset() per tap and cell
@@ -20,10 +20,12 @@ ctx = capi.Context(0)
 g = capi.make_grid(W, H)
 h = (synth.terrain(W, H) * 100).astype(np.float32)
 T0 = ((synth.lcg_uniform(W * H, 41).reshape(H, W)) * 60).astype(np.float32)
-ctx.temperature_steps(g, T0, h, 0, 1)
+k = capi.Climate(ctx, g, T0, h)                 # field resident on the device: the timed region holds kernels only
+k.steps(0, 3); ctx.sync()
 best = 1e9
 for _ in range(3):
-    t0 = time.perf_counter(); ctx.temperature_steps(g, T0, h, 7, 1); ta = time.perf_counter() - t0
-    t0 = time.perf_counter(); ctx.temperature_steps(g, T0, h, 7, 41); tb = time.perf_counter() - t0
-    best = min(best, (tb - ta) / 40 * 1e3)
+    ctx.timer_start()
+    k.steps(7, 40)
+    best = min(best, ctx.timer_stop() / 40)
+k.close()
 print("%dx%d climate step: %.3f ms (%.0f GB/s at 12 B per cell)  literal=%s" % (W, H, best, W * H * 12 / best / 1e6, os.environ.get("DMG_TEMPERATURE_LITERAL", "0")))
