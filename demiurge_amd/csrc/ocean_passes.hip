@@ -409,7 +409,7 @@ int dmg_ocean_diffusion(dmg_ocean *o, int iters)
         return dmg_fail(DMG_EINVAL, "%d diffusion sweeps between halo refreshes but only %d ghost rows", iters, o->ghost);
     // after k sweeps since the last halo refresh the rows still computable lie k rows inside the ghost slabs
     static const bool single = getenv("DMG_DIFFUSION_SINGLE") != nullptr;     // experiments: one sweep per launch
-    if (!single && ocean_tb_supported(o) && o->rowclass) {
+    if (!single && o->prm.jacobi_kernel != DMG_JACOBI_SINGLE && ocean_tb_supported(o) && o->rowclass) {
         for (int k = 0; k < iters;) {                     // up to 8 sweeps per launch (ocean_diffusion_tb.hip)
             int m = iters - k < 8 ? iters - k : 8;
             k += m;

@@ -71,7 +71,9 @@ typedef struct {
     float wind;                    /* 10    :342 */
     int quirks;                    /* DMG_QUIRK_* bit set; default = reference behaviour */
     int jacobi_kernel;             /* DMG_JACOBI_AUTO (default) | _SINGLE (one sweep per launch) | _BLOCKED (8 sweeps
-                                      per launch, temporally blocked on chip); results are bit-identical */
+                                      per launch, temporally blocked on chip); results are bit-identical.  The 50
+                                      velocity-diffusion sweeps follow it: blocked where the blocked Jacobi kernel
+                                      applies, one sweep per launch with _SINGLE */
 } dmg_ocean_params;
 enum { DMG_JACOBI_AUTO = 0, DMG_JACOBI_SINGLE = 1, DMG_JACOBI_BLOCKED = 2 };
 

@@ -30,3 +30,25 @@ def test_single_sweep_kernel_still_agrees():
     env = dict(os.environ, DMG_DIFFUSION_SINGLE="1")
     r = subprocess.run([sys.executable, str(ROOT / "tests" / "dtb_worker.py")], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("sweeps", [1, 5, 8, 13, 50])
+def test_blocked_equals_single_sweep_kernel(sweeps):
+    """same ocean, same inputs, the two kernels selected through dmg_ocean_params.jacobi_kernel: identical bits"""
+    import numpy as np
+    from demiurge_amd import capi, synth
+    ctx = capi.Context(0)
+    W, H = 768, 384
+    grid = capi.make_grid(W, H)
+    img = synth.terrain(W, H)
+    v = (synth.lcg_uniform(W * H * 2, 9).reshape(H, W, 2) * 6).astype(np.float32)
+    outs = []
+    for kernel in (capi.JACOBI_SINGLE, capi.JACOBI_AUTO):
+        prm = capi.default_ocean_params()
+        prm.jacobi_kernel = kernel
+        o = capi.Ocean(ctx, grid, params=prm)
+        o.set_terrain(img); o.set_velocity(v); o.diffusion(sweeps)
+        outs.append(o.get(want=("v",))["v"])
+        o.close()
+    ctx.close()
+    assert np.array_equal(outs[0], outs[1])
