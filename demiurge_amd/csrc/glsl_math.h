@@ -75,13 +75,13 @@ __host__ __device__ inline float acos(float x) { return PI_2 - asin_poly(x, 0.08
 __host__ __device__ inline float atan_pos(float a)
 {
     float x = fminf(a, 1.0f) / fmaxf(a, 1.0f);
-    float x2 = x * x, x3 = x2 * x, x5 = x3 * x2, x7 = x5 * x2, x9 = x7 * x2, x11 = x9 * x2;
+    float x2 = x * x, x3 = x2 * x, x5 = x3 * x2, x7 = x5 * x2, x9 = x7 * x2;
     float p = x * 0.9999793128310355f;
     p = p + x3 * -0.3326756418091246f;
     p = p + x5 * 0.1938924977115610f;
     p = p + x7 * -0.1173503194786851f;
     p = p + x9 * 0.0536813784310406f;
-    p = p + x11 * -0.0121323213173444f;
+    p = p + (x9 * -0.0121323213173444f) * x2;   // x^11 is used once: Mesa multiplies x^9 by the constant first (probe: 131072/131072)
     return p + (a > 1.0f ? 1.0f : 0.0f) * (p * -2.0f + PI_2);
 }
 __host__ __device__ inline float atan(float x) { return atan_pos(fabsf(x)) * sign(x); }

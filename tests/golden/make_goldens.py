@@ -139,7 +139,32 @@ def climate_goldens():
          T3_from11=refgl.temperature(T, img, 11, 3, coords=REGION))
 
 
+def blocked_goldens():
+    """Grids wide enough for the temporally blocked kernels (W >= 256), so that those kernels are compared with the
+    reference's pixels directly and not only through the oracle.  The fields are too large for fixtures: inputs come
+    from demiurge_amd.synth (the test regenerates them), outputs are stored as SHA-256 of their bytes plus every 8th
+    row and column for diagnostics."""
+    import hashlib
+    W, H = 512, 256
+    BELT_WRAP = (f32(-1.0), f32(1.2), f32(-np.pi), f32(np.pi))
+    for name, c in (("full", FULL), ("belt", BELT_WRAP)):
+        img = synth.terrain(W, H)
+        v = (synth.velocity(W, H) * f32(3)).astype(f32)
+        out = {"diffusion50": refgl.ocean_diffusion(img, v, 50, coords=c)}
+        v2, p2, d2 = refgl.ocean_step(img, np.zeros_like(v), n_outer=2, jacobi_iters=48, diffusion_iters=50, coords=c)
+        out.update(step_v=v2, step_pressure=p2, step_divw=d2)
+        arrs = {}
+        for k, a in out.items():
+            a = np.ascontiguousarray(a, f32)
+            arrs[k + "_sha256"] = np.array(hashlib.sha256(a.tobytes()).hexdigest())
+            arrs[k + "_sample"] = a[::8, ::8].copy()
+        save("blocked_512x256_" + name, coords=np.array(c), circ=f32(CIRC), velocity_scale=f32(3), n_outer=np.int32(2),
+             jacobi_iters=np.int32(48), diffusion_iters=np.int32(50), **arrs)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "blocked":
+        return blocked_goldens()
     if len(sys.argv) > 1 and sys.argv[1] == "climate":
         return climate_goldens()
     if len(sys.argv) > 1 and sys.argv[1] == "noise":
@@ -155,6 +180,7 @@ def main():
     tectonics_goldens()
     noise_goldens()
     climate_goldens()
+    blocked_goldens()
     # ---- Jacobi (headline) -------------------------------------------------
     W, H = 256, 128
     img, b = synth.terrain(W, H), synth.divw(W, H)

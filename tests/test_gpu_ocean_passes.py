@@ -267,3 +267,31 @@ def test_outer_step_4096x2048_bitwise_vs_oracle(dev, oracle):
     o.close()
     v, p, d = oracle.ocean_step(oracle.grid(W, H), img, v0, 1, 200, 50, rows=True)
     assert np.array_equal(r["divw"], d) and np.array_equal(r["pressure"], p) and np.array_equal(r["v"], v)
+
+
+@pytest.mark.parametrize("name", ["full", "belt"])
+def test_blocked_kernels_vs_reference_hashes(dev, name):
+    """the temporally blocked diffusion and Jacobi kernels (W = 512 takes them) against the reference's own pixels:
+    SHA-256 of the llvmpipe output of 50 diffusion sweeps and of two outer steps (tests/golden/make_goldens.py blocked)"""
+    import hashlib
+    from demiurge_amd import synth
+    capi, ctx = dev
+    G = load_golden("blocked_512x256_" + name)
+    W, H = 512, 256
+    grid = capi.make_grid(W, H, tuple(G["coords"]), float(G["circ"]))
+    img = synth.terrain(W, H)
+    v = (synth.velocity(W, H) * np.float32(G["velocity_scale"])).astype(np.float32)
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a, np.float32).tobytes()).hexdigest()
+    prm = capi.default_ocean_params()
+    prm.jacobi_iters, prm.diffusion_iters = int(G["jacobi_iters"]), int(G["diffusion_iters"])
+    o = capi.Ocean(ctx, grid, params=prm)
+    o.set_terrain(img); o.set_velocity(v); o.diffusion(50)
+    d = o.get(want=("v",))["v"]
+    assert np.array_equal(d[::8, ::8], G["diffusion50_sample"]) and sha(d) == str(G["diffusion50_sha256"])
+    o.set_velocity(np.zeros_like(v))
+    o.step(int(G["n_outer"]))
+    r = o.get()
+    o.close()
+    for key, a in (("step_v", r["v"]), ("step_pressure", r["pressure"]), ("step_divw", r["divw"])):
+        assert np.array_equal(np.ascontiguousarray(a)[::8, ::8], G[key + "_sample"]), key
+        assert sha(a) == str(G[key + "_sha256"]), key
