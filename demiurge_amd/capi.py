@@ -131,6 +131,7 @@ def lib():
         "dmg_erosion_pass": (c_int, [vp, PG, vp, vp, vp, c_float, c_float]),
         "dmg_flow_accumulate": (c_int, [vp, PG, vp, vp, c_float, c_float, c_int, vp]),
         "dmg_erosion_run": (c_int, [vp, PG, vp, c_int, c_int, c_float, c_float, c_float]),
+        "dmg_flow_passes": (c_int, [vp, PG, vp, vp, c_float, vp, vp]),
         "dmg_climate_create": (c_int, [vp, PG, vp, vp, ctypes.POINTER(vp)]),
         "dmg_climate_destroy": (None, [vp]),
         "dmg_climate_steps": (c_int, [vp, c_int, c_int]),
@@ -260,6 +261,15 @@ def _ctx_flow_accumulate(self, grid, h, preblur=0.5, exponent=1.0, sel=None, lak
     return out
 
 
+def _ctx_flow_passes(self, grid, h, preblur=0.5, sel=None):
+    """-> (direction codes, receiver mask) of FlowFilter::findMagicNumbers' two GLSL passes"""
+    h = _f32(h)
+    sel = None if sel is None else _f32(sel)
+    codes, mask = np.empty_like(h), np.empty_like(h)
+    check(lib().dmg_flow_passes(self.h, ctypes.byref(grid), _p(h), _p(sel), preblur, _p(codes), _p(mask)))
+    return codes, mask
+
+
 def _ctx_erosion_run(self, grid, h, N=50, iters=150, exponent=0.5, slope_exponent=1.0, factor=1.0):
     h = _f32(h).copy()
     check(lib().dmg_erosion_run(self.h, ctypes.byref(grid), _p(h), N, iters, exponent, slope_exponent, factor))
@@ -303,6 +313,7 @@ Context.morphological = _ctx_morphological
 Context.morphological_gradient = _ctx_morphological_gradient
 Context.flow_accumulate = _ctx_flow_accumulate
 Context.erosion_run = _ctx_erosion_run
+Context.flow_passes = _ctx_flow_passes
 
 
 class Climate:

@@ -39,15 +39,18 @@ __device__ __forceinline__ float d_fract(float x) { return __fsub_rn(x, floorf(x
 // hash() and noise() of the direction shader (:114-131).  noise() is sampled at st*resolution*2 = (2x+1, 2y+1), an
 // integer lattice point in exact arithmetic; in fp32 it can land an ulp below (non-power-of-two sizes), so the full
 // bilinear form is kept.
+// hash() as Mesa's algebraic pass leaves it (probe shader: 131072/131072 lattice points; the literal form 99.4 %): with
+// p = 50*fract(..), the sum p.x + p.y is factored into 50*(fract_x + fract_y), the product p.x*p.y is not touched
 __device__ __forceinline__ float d_flow_hash(float px, float py)
 {
-    px = __fmul_rn(50.0f, d_fract(__fadd_rn(__fmul_rn(px, 0.3183099f), 0.71f)));
-    py = __fmul_rn(50.0f, d_fract(__fadd_rn(__fmul_rn(py, 0.3183099f), 0.113f)));
-    return __fadd_rn(-1.0f, __fmul_rn(2.0f, d_fract(__fmul_rn(__fmul_rn(px, py), __fadd_rn(px, py)))));
+    float fx = d_fract(__fadd_rn(__fmul_rn(px, 0.3183099f), 0.71f)), fy = d_fract(__fadd_rn(__fmul_rn(py, 0.3183099f), 0.113f));
+    px = __fmul_rn(50.0f, fx);
+    py = __fmul_rn(50.0f, fy);
+    return __fadd_rn(-1.0f, __fmul_rn(2.0f, d_fract(__fmul_rn(__fmul_rn(px, py), __fmul_rn(50.0f, __fadd_rn(fx, fy))))));
 }
-__device__ __forceinline__ float d_mix(float a, float b, float t)      // GLSL mix: a*(1-t) + b*t
+__device__ __forceinline__ float d_mix(float a, float b, float t)      // GLSL mix as lowered by Mesa (nir_lower_flrp): a + t*(b - a)
 {
-    return __fadd_rn(__fmul_rn(a, __fsub_rn(1.0f, t)), __fmul_rn(b, t));
+    return __fadd_rn(a, __fmul_rn(t, __fsub_rn(b, a)));
 }
 __device__ __forceinline__ float d_flow_noise(float px, float py)
 {
@@ -669,6 +672,47 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
 }
 
 extern "C" {
+
+// The two GLSL passes of FlowFilter::findMagicNumbers (:104-320) on their own: pre-blur, direction codes (keypad
+// 1..9, 5 = sink, 0 = sea / unselected) and receiver bitmask, as floats like the reference's textures
+int dmg_flow_passes(dmg_ctx *ctx, const dmg_grid *grid, const float *h, const float *sel, float preblur, float *codes_out, float *mask_out)
+{
+    DMG_CHECK_ARG(ctx != nullptr && h != nullptr && codes_out != nullptr && mask_out != nullptr && preblur >= 0.0f);
+    dmg_topology topo;
+    int rc = dmg_check_grid(grid, &topo);
+    if (rc) return rc;
+    DMG_HIP(hipSetDevice(ctx->device));
+    const int W = grid->W, H = grid->H;
+    const size_t N = (size_t)W * H;
+    hipStream_t st = ctx->stream;
+    flow_canvas fc;
+    fc.c = make_canvas(*grid, topo);
+    dmg_grid gm = *grid;                                 // coordsMod (:253-256)
+    gm.coords[0] = (float)((double)gm.coords[0] + 1e-3);
+    gm.coords[1] = (float)((double)gm.coords[1] - 1e-3);
+    fc.cm = make_canvas(gm, dmg_topology_of(gm));
+    fc.wrap = fabs(grid->coords[3] - grid->coords[2]) > 2 * M_PI - 1e-4;
+    std::vector<float> dxr(H), dyr(H);
+    for (int y = 0; y < H; y++) dmg_row_pixelsize(gm, y, &dxr[y], &dyr[y]);
+    dev_buf ddx, ddy, hb, tmp, dsel, code, mask;
+    if ((rc = upload_vec(ctx, ddx, dxr)) || (rc = upload_vec(ctx, ddy, dyr))) return rc;
+    DMG_ALLOC(hb, N * 4); DMG_ALLOC(tmp, N * 4); DMG_ALLOC(code, N); DMG_ALLOC(mask, N * 2);
+    DMG_HIP(hipMemcpyAsync(hb.p, h, N * 4, hipMemcpyHostToDevice, st));
+    if (sel) { DMG_ALLOC(dsel, N * 4); DMG_HIP(hipMemcpyAsync(dsel.p, sel, N * 4, hipMemcpyHostToDevice, st)); }
+    if (preblur > 0.0f && (rc = blur_device(ctx, *grid, topo, hb.f(), tmp.f(), preblur))) return rc;
+    dim3 g2((W + 255) / 256, H);
+    hipLaunchKernelGGL(k_flow_direction, g2, dim3(256), 0, st, fc, hb.f(), sel ? dsel.f() : nullptr, ddx.f(), ddy.f(), (unsigned char *)code.p);
+    hipLaunchKernelGGL(k_flow_mask, g2, dim3(256), 0, st, fc, hb.f(), sel ? dsel.f() : nullptr, (const unsigned char *)code.p, (unsigned short *)mask.p);
+    DMG_HIP(hipGetLastError());
+    std::vector<unsigned char> hc(N);
+    std::vector<unsigned short> hm(N);
+    DMG_HIP(hipMemcpyAsync(hc.data(), code.p, N, hipMemcpyDeviceToHost, st));
+    DMG_HIP(hipMemcpyAsync(hm.data(), mask.p, N * 2, hipMemcpyDeviceToHost, st));
+    DMG_HIP(hipStreamSynchronize(st));
+    // the reference's texture values: -1 off the land, else the bit sum on top of its 0.5 seed (:269-303)
+    for (size_t i = 0; i < N; i++) { codes_out[i] = (float)hc[i]; mask_out[i] = hm[i] == 0xFFFFu ? -1.0f : (float)hm[i] + 0.5f; }
+    return DMG_OK;
+}
 
 // FlowFilter::run (:719-786): flow_out[i] = pow(upstream area, exponent), -1 off the drained land; lakes != 0 also
 // draws the lakes (lakeflag, :660-699)

@@ -203,6 +203,12 @@ int dmg_erosion_pass(dmg_ctx *ctx, const dmg_grid *grid, float *h_inout, const f
  * lakes != 0 = FlowFilter's lakeflag (:660-699): cells at or below their lake's water level are set to 0. */
 int dmg_flow_accumulate(dmg_ctx *ctx, const dmg_grid *grid, const float *h, const float *sel_or_null, float preblur,
                         float exponent, int lakes, float *flow_out);
+/* The two GLSL passes of FlowFilter::findMagicNumbers (:104-320) alone, on h pre-blurred by `preblur` (0 = none):
+ * codes_out = flow direction per cell in keypad numbering (1..9, 5 = sink, 0 = sea or unselected, :149-262),
+ * mask_out = 0.5 + bitmask of the neighbours that drain into the cell, +16 sink, +512 river mouth, -1 off the land
+ * (:268-315); both as floats, like the reference's textures. */
+int dmg_flow_passes(dmg_ctx *ctx, const dmg_grid *grid, const float *h, const float *sel_or_null, float preblur,
+                    float *codes_out, float *mask_out);
 /* cpufilter::run (src/filter/cpufilter.cpp:41-222): uplift = max(h,0)/N, heights scaled by 1/N on land, then
  * `iters` (reference: N*3 = 150) rounds of { flow accumulation (preblur 0.5, `exponent`) ; erosion/uplift pass }.
  * h_inout receives the scaled heights the reference leaves in the terrain texture. */

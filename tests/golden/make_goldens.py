@@ -162,7 +162,40 @@ def blocked_goldens():
              jacobi_iters=np.int32(48), diffusion_iters=np.int32(50), **arrs)
 
 
+def large_goldens():
+    """Every other tool once at 512x256 (65 times the cells of the small fixtures: rare rounding cases show up here,
+    e.g. the last term of Mesa's atan polynomial).  Outputs as SHA-256 + every 8th row/column."""
+    import hashlib
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+    from large_inputs import large_inputs
+    W, H = 512, 256
+    I = large_inputs(W, H)
+    out = {}
+    out["blur_r3"] = refgl.blur(I["terrain"], 3.0)
+    out["temperature_3_from11"] = refgl.temperature(I["T"], I["heights"], 11, 3)
+    out["erosion_pass"] = refgl.erosion_shader(I["heights"], I["flow"], np.maximum(I["heights"], 0) / f32(50), 1.0, 1.0)
+    out["erosion_pass_f2_n07"] = refgl.erosion_shader(I["heights"], I["flow"], np.maximum(I["heights"], 0) / f32(50), 2.0, 0.7)
+    out["thermal"] = refgl.thermal_erosion(I["relief"])
+    out["erode_r5"] = refgl.morphological(I["terrain"], 5.5, "min")
+    out["dilate_r2"] = refgl.morphological(I["terrain"], 2.0, "max")
+    hb = refgl.blur(I["heights"], 0.5)
+    codes, mask = refgl.flow_direction_and_mask(hb)
+    out["flow_codes"], out["flow_mask"] = codes.astype(f32), mask.astype(f32)
+    for m in NOISE_MODES:
+        out["noise_" + m] = refgl.gradient_noise(np.zeros((H, W), f32), m, "replace", seed=5, warp=0.6)
+    terrain, plates = refgl.tectonics(I["tect"], 12, coords=FULL, circ=CIRC)
+    out["tectonics_12_terrain"] = terrain
+    arrs = {}
+    for k, a in out.items():
+        a = np.ascontiguousarray(a, f32)
+        arrs[k + "_sha256"] = np.array(hashlib.sha256(a.tobytes()).hexdigest())
+        arrs[k + "_sample"] = a[::8, ::8].copy()
+    save("large_512x256_full", coords=np.array(FULL), circ=f32(CIRC), **arrs)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "large":
+        return large_goldens()
     if len(sys.argv) > 1 and sys.argv[1] == "blocked":
         return blocked_goldens()
     if len(sys.argv) > 1 and sys.argv[1] == "climate":
@@ -181,6 +214,7 @@ def main():
     noise_goldens()
     climate_goldens()
     blocked_goldens()
+    large_goldens()
     # ---- Jacobi (headline) -------------------------------------------------
     W, H = 256, 128
     img, b = synth.terrain(W, H), synth.divw(W, H)

@@ -15,14 +15,13 @@ def test_oracle_flow_passes_golden(oracle):
     g = oracle.grid(W, H, tuple(G["coords"]), float(G["circ"]))
     codes = oracle.flow_direction(g, G["blurred"])
     # the direction goes through GLSL atan(): a stochastic-rounding threshold may flip on an ulp; <= 0.1 % of land
-    land = (G["codes"] > 0).sum()
-    assert (codes != G["codes"]).sum() <= max(2, land // 1000)
+    assert np.array_equal(codes, G["codes"])                       # hash() and mix() in Mesa's forms: every code
     assert np.array_equal(oracle.flow_mask(g, G["blurred"], G["codes"]), G["mask"])
     lid = np.where(G["label"] < 0, np.float32(-1), (G["label"] + 1073741824).astype(np.int32).view(np.float32))
     assert np.array_equal(oracle.lake_adjacency(g, lid.astype(np.float32)), G["adjacency"])
     S = load_golden("flow_passes_128x64_sel")
     c2 = oracle.flow_direction(g, S["blurred"], S["sel"])
-    assert (c2 != S["codes"]).sum() <= 2
+    assert np.array_equal(c2, S["codes"])
     assert np.array_equal(oracle.flow_mask(g, S["blurred"], S["codes"], S["sel"]), S["mask"])
 
 

@@ -119,3 +119,31 @@ def test_erosion_config2_size(dev, oracle):
     out = ctx.erosion_pass(capi.make_grid(W, H), h, flow, up, 1.0, 1.0)
     assert np.array_equal(out, oracle.erosion_pass(oracle.grid(W, H), h, flow, up, 1.0, 1.0))
     assert np.array_equal(out[h <= 0], h[h <= 0])
+
+
+def test_large_grid_hashes(dev):
+    """every tool through the C ABI at 512x256 against the SHA-256 of the reference's own output
+    (tests/golden/large_512x256_full.npz, tests/golden/make_goldens.py large)"""
+    from large_inputs import NOISE_MODES, check, large_inputs
+    capi, ctx = dev
+    G = load_golden("large_512x256_full")
+    W, H = 512, 256
+    g = capi.make_grid(W, H, tuple(G["coords"]), float(G["circ"]))
+    I = large_inputs(W, H)
+    up = (np.maximum(I["heights"], 0) / np.float32(50)).astype(np.float32)
+    check(G, "blur_r3", ctx.blur(g, I["terrain"], 3.0))
+    check(G, "temperature_3_from11", ctx.temperature_steps(g, I["T"], I["heights"], 11, 3))
+    check(G, "erosion_pass", ctx.erosion_pass(g, I["heights"], I["flow"], up, 1.0, 1.0))
+    check(G, "erosion_pass_f2_n07", ctx.erosion_pass(g, I["heights"], I["flow"], up, 2.0, 0.7))
+    check(G, "thermal", ctx.thermal_erosion(g, I["relief"]))
+    check(G, "erode_r5", ctx.morphological(g, I["terrain"], 5.5, "min"))
+    check(G, "dilate_r2", ctx.morphological(g, I["terrain"], 2.0, "max"))
+    codes, mask = ctx.flow_passes(g, I["heights"], 0.5)
+    check(G, "flow_codes", codes)
+    check(G, "flow_mask", mask)
+    for m in NOISE_MODES:
+        check(G, "noise_" + m, ctx.gradient_noise(g, np.zeros((H, W), np.float32), capi.noise_params(m, seed=5, warp=0.6)))
+    t = capi.Tectonics(ctx, g, I["tect"])
+    t.step(12)
+    check(G, "tectonics_12_terrain", t.terrain())
+    t.close()
