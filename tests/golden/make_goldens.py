@@ -193,7 +193,36 @@ def large_goldens():
     save("large_512x256_full", coords=np.array(FULL), circ=f32(CIRC), **arrs)
 
 
+def huge_goldens():
+    """2048x1024 (2 M cells): one ocean outer step with 300 Jacobi sweeps, the flow passes, the climate step and three
+    noise modes; hashes only (see large_goldens).  Catches 1-in-a-million rounding cases."""
+    import hashlib
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+    from large_inputs import large_inputs
+    W, H = 2048, 1024
+    I = large_inputs(W, H)
+    out = {}
+    v = (synth.velocity(W, H) * f32(3)).astype(f32)
+    v[I["terrain"] > 0] = 0
+    out["advect"] = refgl.ocean_advect(I["terrain"], v)
+    v2, p2, d2 = refgl.ocean_step(I["terrain"], v, n_outer=1, jacobi_iters=300, diffusion_iters=50)
+    out.update(step_v=v2, step_pressure=p2, step_divw=d2)
+    out["temperature_2_from7000"] = refgl.temperature(I["T"], I["heights"], 7000, 2)
+    codes, mask = refgl.flow_direction_and_mask(refgl.blur(I["heights"], 0.5))
+    out["flow_codes"], out["flow_mask"] = codes.astype(f32), mask.astype(f32)
+    for m in ("DEFAULT", "SWISS", "Jordan"):
+        out["noise_" + m] = refgl.gradient_noise(np.zeros((H, W), f32), m, "replace", seed=9, warp=0.4)
+    arrs = {}
+    for k, a in out.items():
+        a = np.ascontiguousarray(a, f32)
+        arrs[k + "_sha256"] = np.array(hashlib.sha256(a.tobytes()).hexdigest())
+        arrs[k + "_sample"] = a[::32, ::32].copy()
+    save("huge_2048x1024_full", coords=np.array(FULL), circ=f32(CIRC), **arrs)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "huge":
+        return huge_goldens()
     if len(sys.argv) > 1 and sys.argv[1] == "large":
         return large_goldens()
     if len(sys.argv) > 1 and sys.argv[1] == "blocked":
@@ -215,6 +244,7 @@ def main():
     climate_goldens()
     blocked_goldens()
     large_goldens()
+    huge_goldens()
     # ---- Jacobi (headline) -------------------------------------------------
     W, H = 256, 128
     img, b = synth.terrain(W, H), synth.divw(W, H)

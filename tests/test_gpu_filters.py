@@ -147,3 +147,31 @@ def test_large_grid_hashes(dev):
     t.step(12)
     check(G, "tectonics_12_terrain", t.terrain())
     t.close()
+
+
+def test_huge_grid_hashes(dev):
+    """the same at 2048x1024 (2 M cells) through the C ABI: advect and a whole ocean outer step with 300 Jacobi sweeps
+    (blocked kernels), the climate step, the flow passes, three noise modes"""
+    from demiurge_amd import synth
+    from large_inputs import check, large_inputs
+    capi, ctx = dev
+    G = load_golden("huge_2048x1024_full")
+    W, H = 2048, 1024
+    g = capi.make_grid(W, H, tuple(G["coords"]), float(G["circ"]))
+    I = large_inputs(W, H)
+    v = (synth.velocity(W, H) * np.float32(3)).astype(np.float32)
+    v[I["terrain"] > 0] = 0
+    prm = capi.default_ocean_params()
+    prm.jacobi_iters, prm.diffusion_iters = 300, 50
+    o = capi.Ocean(ctx, g, params=prm)
+    o.set_terrain(I["terrain"]); o.set_velocity(v); o.advect()
+    check(G, "advect", o.get(want=("v",))["v"], 32)
+    o.set_velocity(v); o.step(1)
+    r = o.get()
+    o.close()
+    check(G, "step_v", r["v"], 32); check(G, "step_pressure", r["pressure"], 32); check(G, "step_divw", r["divw"], 32)
+    check(G, "temperature_2_from7000", ctx.temperature_steps(g, I["T"], I["heights"], 7000, 2), 32)
+    codes, mask = ctx.flow_passes(g, I["heights"], 0.5)
+    check(G, "flow_codes", codes, 32); check(G, "flow_mask", mask, 32)
+    for m in ("DEFAULT", "SWISS", "Jordan"):
+        check(G, "noise_" + m, ctx.gradient_noise(g, np.zeros((H, W), np.float32), capi.noise_params(m, seed=9, warp=0.4)), 32)
