@@ -1,7 +1,6 @@
 """Parity of the remaining OceanCurrents passes (advect, diffusion, divergence, subDiv, outer step) through the
-C ABI: against the oracle (tight: same fp32 operations; device libm differs from glibc by a few ulp where the
-shader calls trig/pow) and against the llvmpipe goldens (the reference's own GLSL; BASELINE tolerance 1e-5, looser
-only where the GL implementation's asin/atan/pow polynomials dominate -- see tests/test_oracle_golden.py)."""
+C ABI: bit for bit against the oracle and against the llvmpipe goldens (the reference's own GLSL; its transcendentals
+are evaluated as Mesa/gallivm evaluate them, csrc/glsl_math.h -- see tests/test_oracle_golden.py)."""
 import numpy as np
 import pytest
 
