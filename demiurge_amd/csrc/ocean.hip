@@ -412,6 +412,15 @@ int dmg_ocean_jacobi_sweeps_begin(dmg_ocean *o, int n)
     const int lo = o->gs ? k : 0, hi = o->L - (o->gn ? k : 0);
     const int zone_lo = o->gs ? std::min(o->gs + o->ghost, hi) : lo;      // end of the rows sent southwards
     const int zone_hi = o->gn ? std::max(o->L - o->gn - o->ghost, lo) : hi;   // start of the rows sent northwards
+    // while the tile-shape tuner of this launch geometry is still timing its candidates (the first six launches of a
+    // geometry below 4096 tiles), issue the launch whole so that it gets timed: the split starts once a shape is chosen
+    if (last == 8 && ocean_tb_tuning_open(o, lo, hi)) {
+        rc = ocean_launch_tb(o, lo, hi, last);
+        if (rc) return rc;
+        o->cur ^= 1;
+        o->n_launches++; o->n_sweeps += last;
+        return DMG_OK;
+    }
     rc = ocean_launch_tb(o, lo, hi, last, 1, zone_lo, zone_hi);
     if (rc) return rc;
     o->pending.active = true;

@@ -75,6 +75,7 @@ int ocean_zero_land(dmg_ocean *o);            // p := +0 on land in BOTH ping-po
 int ocean_launch_tb(dmg_ocean *o, int lo, int hi, int n, int part = 0, int zone_lo = 0, int zone_hi = 0);
 int ocean_launch_diffusion_tb(dmg_ocean *o, int lo, int hi, int n);   // ocean_diffusion_tb.hip: n (1..8) sweeps over local rows [lo, hi)
 bool ocean_tb_supported(const dmg_ocean *o);
+bool ocean_tb_tuning_open(dmg_ocean *o, int lo, int hi);   // the shape tuner of the 8-sweep launch over [lo, hi) has not decided yet
 int ocean_build_rowclass(dmg_ocean *o);
 void ocean_tb_free_lists(dmg_ocean *o);
 int ocean_terrain_changed(dmg_ocean *o);        // rebuilds what is derived from o->img (ocean.hip)

@@ -485,6 +485,18 @@ int ocean_launch_tb(dmg_ocean *o, int lo, int hi, int n, int part, int zone_lo, 
     return DMG_OK;
 }
 
+// true while the per-geometry shape tuner (ocean_launch_tb) would still time a candidate for a whole 8-sweep launch
+bool ocean_tb_tuning_open(dmg_ocean *o, int lo, int hi)
+{
+    if (tb_forced_shape().R) return false;
+    static const bool use_cls = getenv("DMG_TB_NOCLASS") == nullptr;
+    if (!use_cls || !o->rowclass) return false;
+    const int tiles88 = ((o->grid.W + TB_OW - 1) / TB_OW) * ((hi - lo + 47) / 48);
+    if (tiles88 > 4096) return false;
+    auto it = o->tb_tuning.find(std::make_pair(lo, hi));
+    return it == o->tb_tuning.end() || it->second.chosen < 0;
+}
+
 // the temporally blocked kernel needs: full longitude (columns wrap), float4-aligned pole shift, a tile-wide row
 bool ocean_tb_supported(const dmg_ocean *o)
 {

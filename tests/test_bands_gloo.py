@@ -105,7 +105,7 @@ def test_overlapped_solve_over_rccl():
     the stream ordering the gloo tests cannot reach.  Both orders must reproduce the single-band solve bit for bit."""
     import os, subprocess, sys
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
-    r = subprocess.run([sys.executable, str(ROOT / "tools" / "nccl_self_probe.py"), "1024", "512", "100", "16"],
+    r = subprocess.run([sys.executable, str(ROOT / "tools" / "nccl_self_probe.py"), "1024", "512", "200", "16"],
                        capture_output=True, text=True, timeout=600, env=env, cwd=str(ROOT))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if "bit-identical" in l]

@@ -216,8 +216,8 @@ def test_blocked_band_split_is_bitwise(dev, bands, ghost, block):
     assert np.array_equal(one, split)
 
 
-@pytest.mark.parametrize("bands,ghost,W,H,iters", [(2, 32, 512, 384, 100), (3, 16, 512, 384, 45), (4, 8, 768, 256, 29), (8, 32, 2048, 1024, 96)])
-def test_overlapped_block_order_is_bitwise(dev, bands, ghost, W, H, iters):
+@pytest.mark.parametrize("bands,ghost,W,H", [(2, 32, 512, 384), (3, 16, 512, 384), (4, 8, 768, 256), (8, 32, 2048, 1024)])
+def test_overlapped_block_order_is_bitwise(dev, bands, ghost, W, H):
     """dmg_ocean_jacobi_sweeps_begin/_end: the exchange for the next block is done between the edge tiles and the
     interior tiles of a block's last launch (what bands.jacobi_solve does with RCCL running alongside).  Here the copies
     happen on the same stream right after _begin, i.e. while the interior tiles have not run yet: they must neither
@@ -226,6 +226,7 @@ def test_overlapped_block_order_is_bitwise(dev, bands, ghost, W, H, iters):
     from demiurge_amd import synth
     grid = capi.make_grid(W, H)
     img, b = synth.terrain(W, H), synth.divw(W, H)
+    iters = ghost * 10 + 5          # the first six blocks of a geometry are launched whole (tile-shape tuner), then split
     one = run_jacobi(capi, ctx, grid, img, b, iters, block=iters, kernel=capi.JACOBI_SINGLE)
     prm = capi.default_ocean_params()
     prm.jacobi_kernel = capi.JACOBI_BLOCKED
@@ -239,8 +240,9 @@ def test_overlapped_block_order_is_bitwise(dev, bands, ghost, W, H, iters):
         if done + n < iters:
             for o in oc:
                 o.jacobi_sweeps_begin(n)
-            with pytest.raises(capi.DmgError):
-                oc[0].get(want=("pressure",))             # the pressure is half a launch apart: refused
+            if done >= 7 * ghost:
+                with pytest.raises(capi.DmgError):
+                    oc[0].get(want=("pressure",))         # the pressure is half a launch apart: refused
             exchange(capi, ctx, oc, ghost)                # slabs of the NEW iterate, interior tiles still to come
             for o in oc:
                 o.jacobi_sweeps_end()
