@@ -54,16 +54,17 @@ class HaloExchanger:
             self._bounce[key] = (mk(), mk())
         return self._bounce[key]
 
-    def start(self, ocean, field, rows):
+    def start(self, ocean, field, rows, buffer=None):
         """Post the sends and receives that refresh `rows` ghost rows of `field` on both sides of this rank's band and
         return a token for finish().  With backend nccl the transfers run on RCCL's stream behind everything issued so
-        far on the compute stream; whatever the caller launches before finish() overlaps them."""
+        far on torch's current stream; whatever the caller launches before finish() overlaps them.
+        buffer: which of the two pressure buffers (default: the ocean's current one)."""
         dist, torch = self.dist, self.torch
         ops, post = [], []
         for side, peer in ((0, self.rank - 1), (1, self.rank + 1)):     # DMG_SIDE_SOUTH, DMG_SIDE_NORTH
             if peer < 0 or peer >= self.world:
                 continue
-            send, recv, nbytes = ocean.halo(field, side, rows)
+            send, recv, nbytes = ocean.halo(field, side, rows) if buffer is None else ocean.pressure_halo(buffer, side, rows)
             if isinstance(send, np.ndarray):
                 ts, tr = self._tensor(send, nbytes), self._tensor(recv, nbytes)
             else:
@@ -115,6 +116,9 @@ def jacobi_solve(ocean, exch, sweeps, ghost, zero_first=True, field=0):
     The refresh for block b+1 is posted as soon as the rows it carries exist -- after the edge tiles of block b's last
     launch -- and overlaps the interior tiles of that launch (dmg_ocean_jacobi_sweeps_begin/_end); DMG_HALO_OVERLAP=0
     (or an ocean without the split call) falls back to exchange-then-sweep.  Both orders give the same bits."""
+    import os
+    if exch is not None and exch.world > 1 and os.environ.get("DMG_HALO_PIPELINE") == "1":
+        return jacobi_solve_pipelined(ocean, exch, sweeps, ghost, zero_first)      # opt-in: see its docstring
     if zero_first:
         ocean.zero_pressure()
     if exch is None or exch.world == 1:
@@ -137,6 +141,119 @@ def jacobi_solve(ocean, exch, sweeps, ghost, zero_first=True, field=0):
         else:
             ocean.jacobi_sweeps(n)                      # last block: nobody waits for its rows
         done += n
+    return sweeps
+
+
+def _block_plan(ocean, n, ghost):
+    """Edge / interior split of the n/8 launches of a block: for launch k its rows [lo, hi), and the tile-row boundaries
+    a <= b such that the tile rows below a and above b (its edge part) are all that the edge part of launch k+1 and the
+    halo exchange need.  None when the block cannot be pipelined (tile shape still being tuned, odd sweep count)."""
+    if n % 8 or n < 8:
+        return None
+    L, gs, gn = ocean.band_rows()
+    m = n // 8
+    geo = [ocean.jacobi_geometry(8 * (k + 1)) for k in range(m)]
+    if any(g[2] == 0 for g in geo):
+        return None
+    need_s, need_n = gs + ghost, L - gn - ghost          # the rows to send: [gs, need_s) and [need_n, L - gn)
+    plan = [None] * m
+    for k in reversed(range(m)):
+        lo, hi, oh = geo[k]
+        a = min(hi, lo + oh * -(-(need_s - lo) // oh)) if gs else lo      # first tile-row boundary >= need_s
+        b = max(lo, lo + oh * ((need_n - lo) // oh)) if gn else hi        # last tile-row boundary <= need_n
+        plan[k] = (lo, hi, a, b)
+        need_s, need_n = a + 8, b - 8                    # launch k reads 8 rows beyond what it writes
+    return plan
+
+
+def jacobi_solve_pipelined(ocean, exch, sweeps, ghost, zero_first=True):
+    # `ocean` may be a list of bands living in this process (tools/nccl_self_probe.py: the exchanger then takes the list)
+    """jacobi_solve with the halo exchange hidden behind the interior sweeps of a whole block.
+
+    Every launch of a block is issued as two parts of one tiling (dmg_ocean_jacobi_launch): the tile rows next to the
+    band edges on a second, high-priority stream, the rest on the compute stream.  The edge parts form a chain of their
+    own -- the edge part of launch k+1 reads nothing but the edge part of launch k -- so that stream runs ahead, reaches
+    the rows the neighbours wait for after about a third of the block's work, and posts the exchange there; the ghost
+    rows arrive while the interior parts are still being swept.  Events order the two streams where they meet:
+    interior k+1 after edge k, the next block's first edge part after this block's last interior part and the exchange.
+    Same tiles, same arithmetic: bit-identical to jacobi_solve.  Falls back to it per block while a launch geometry's
+    tile shape is still being tuned, for the last block, and altogether without two device streams (gloo, bounce).
+
+    Opt-in (DMG_HALO_PIPELINE=1).  The two streams only run side by side when the HIP runtime may use more than its
+    default four hardware queues (GPU_MAX_HW_QUEUES=8 in the environment before the process starts); with four, the
+    edge and interior launches serialise and the block takes 1.5x as long.  Measured on one GPU with two bands
+    exchanging through RCCL with the process's own rank (tools/nccl_self_probe.py, 8-rank band size, per 32-sweep
+    block): no exchange 690 us; with 8 queues exchange-then-sweep 870 / pipelined 790 us; with the default 4 queues
+    exchange-then-sweep 750 us.  What it does across xGMI, one band per GPU, is not measurable on one GPU."""
+    torch = exch.torch
+    oceans = list(ocean) if isinstance(ocean, (list, tuple)) else [ocean]
+    if (exch.staged or exch.bounce or not all(hasattr(o, "jacobi_launch") for o in oceans) or not torch.cuda.is_available()):
+        return jacobi_solve(ocean, exch, sweeps, ghost, zero_first)
+    if zero_first:
+        for o in oceans:
+            o.zero_pressure()
+    dev = exch.device if exch.device is not None else torch.device("cuda", torch.cuda.current_device())
+    s_int = torch.cuda.current_stream(dev)               # the stream the ocean's context was created on (module docstring)
+    if not hasattr(exch, "_edge_stream"):
+        exch._edge_stream = torch.cuda.Stream(device=dev, priority=-1)
+    s_edge = exch._edge_stream
+    # invariant at the top of the loop: the ghost rows are fresh; `ev_ready` marks the interior stream's progress and
+    # `ev_last_edge` (if any) the edge stream's, including the exchange it waited for
+    if sweeps > 0:
+        exch.exchange(ocean, F_PRESSURE, ghost)
+    ev_ready = torch.cuda.Event()
+    ev_ready.record(s_int)
+    ev_last_edge = None
+    done = 0
+    while done < sweeps:
+        n = min(ghost, sweeps - done)
+        last = done + n >= sweeps
+        plans = None if last else [_block_plan(o, n, ghost) for o in oceans]
+        plan = None if plans is None or any(p is None for p in plans) else plans
+        if plan is None:                                 # plain order: sweep, then refresh the ghost rows for the next block
+            if ev_last_edge is not None:
+                s_int.wait_event(ev_last_edge)
+                ev_last_edge = None
+            for o in oceans:
+                o.jacobi_sweeps(n)
+            if not last:
+                exch.exchange(ocean, F_PRESSURE, ghost)
+            ev_ready = torch.cuda.Event()
+            ev_ready.record(s_int)
+            done += n
+            continue
+        m = n // 8
+        c = oceans[0].pressure_buffer()                  # every band of the process is at the same buffer
+        s_edge.wait_event(ev_ready)                      # edge part 1 reads rows the previous interior part wrote
+        if ev_last_edge is not None:
+            s_int.wait_event(ev_last_edge)               # interior part 1 reads / overwrites rows of the previous edge chain
+        ev_edge = []
+        for k in range(m):
+            for o, pl in zip(oceans, plan):
+                lo, hi, a, b = pl[k]
+                o.jacobi_launch(lo, hi, 8, 1, a, b, (c + k) & 1, s_edge.cuda_stream)
+            e = torch.cuda.Event()
+            e.record(s_edge)
+            ev_edge.append(e)
+        with torch.cuda.stream(s_edge):                  # RCCL orders itself behind the edge chain only
+            token = exch.start(ocean, F_PRESSURE, ghost, buffer=(c + m) & 1)
+        for k in range(m):
+            if k:
+                s_int.wait_event(ev_edge[k - 1])         # interior part k reads up to 8 rows of edge part k-1
+            for o, pl in zip(oceans, plan):
+                lo, hi, a, b = pl[k]
+                o.jacobi_launch(lo, hi, 8, 2, a, b, (c + k) & 1, None)
+        ev_ready = torch.cuda.Event()
+        ev_ready.record(s_int)
+        with torch.cuda.stream(s_edge):
+            exch.finish(token)                           # the edge stream waits for the ghost rows
+        ev_last_edge = torch.cuda.Event()
+        ev_last_edge.record(s_edge)
+        for o in oceans:
+            o.set_pressure_buffer((c + m) & 1, m, n)
+        done += n
+    if ev_last_edge is not None:
+        s_int.wait_event(ev_last_edge)
     return sweeps
 
 

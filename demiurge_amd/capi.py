@@ -115,6 +115,12 @@ def lib():
         "dmg_ocean_zero_pressure": (c_int, [vp]),
         "dmg_ocean_jacobi_sweeps_begin": (c_int, [vp, c_int]),
         "dmg_ocean_jacobi_sweeps_end": (c_int, [vp]),
+        "dmg_ocean_jacobi_geometry": (c_int, [vp, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+        "dmg_ocean_band_rows": (c_int, [vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+        "dmg_ocean_jacobi_launch": (c_int, [vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, vp]),
+        "dmg_ocean_pressure_buffer": (c_int, [vp, ctypes.POINTER(c_int)]),
+        "dmg_ocean_set_pressure_buffer": (c_int, [vp, c_int, c_int, c_int]),
+        "dmg_ocean_pressure_halo": (c_int, [vp, c_int, c_int, c_int, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(sz)]),
         "dmg_ocean_counters": (c_int, [vp, ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_longlong)]),
         "dmg_ocean_halo": (c_int, [vp, c_int, c_int, c_int, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(sz)]),
         "dmg_ocean_step": (c_int, [vp, c_int]),
@@ -442,6 +448,35 @@ class Ocean:
 
     def jacobi_sweeps_end(self):
         check(lib().dmg_ocean_jacobi_sweeps_end(self.h))
+
+    # ---- pieces for a self-scheduled block (bands.jacobi_solve_pipelined) ----
+    def jacobi_geometry(self, k):
+        """-> (lo, hi, tile_rows) of the 8-sweep launch ending k sweeps after the last halo refresh"""
+        lo, hi, tr = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        check(lib().dmg_ocean_jacobi_geometry(self.h, int(k), ctypes.byref(lo), ctypes.byref(hi), ctypes.byref(tr)))
+        return lo.value, hi.value, tr.value
+
+    def band_rows(self):
+        """-> (stored rows L, ghost rows south, ghost rows north)"""
+        a, b, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        check(lib().dmg_ocean_band_rows(self.h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return a.value, b.value, c.value
+
+    def jacobi_launch(self, lo, hi, n, part, zone_lo, zone_hi, src, stream=None):
+        check(lib().dmg_ocean_jacobi_launch(self.h, lo, hi, n, part, zone_lo, zone_hi, src, ctypes.c_void_p(stream or 0)))
+
+    def pressure_buffer(self):
+        c = ctypes.c_int()
+        check(lib().dmg_ocean_pressure_buffer(self.h, ctypes.byref(c)))
+        return c.value
+
+    def set_pressure_buffer(self, idx, launches=0, sweeps=0):
+        check(lib().dmg_ocean_set_pressure_buffer(self.h, idx, launches, sweeps))
+
+    def pressure_halo(self, buffer, side, rows):
+        s, r, n = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_size_t()
+        check(lib().dmg_ocean_pressure_halo(self.h, buffer, side, rows, ctypes.byref(s), ctypes.byref(r), ctypes.byref(n)))
+        return s.value, r.value, n.value
 
     def counters(self):
         """-> (jacobi kernel launches, jacobi sweeps) since creation"""

@@ -442,6 +442,73 @@ int dmg_ocean_jacobi_sweeps_end(dmg_ocean *o)
     return rc;
 }
 
+// ---- pieces for a host that schedules the launches of a block itself (demiurge_amd/bands.py, pipelined solve) ----
+// rows [lo, hi) the 8-sweep launch computes that ends `k` sweeps after the last halo refresh, and the output rows per
+// tile row of the shape it runs with (0 while that geometry's shape tuner is still open, or without the blocked kernel)
+int dmg_ocean_jacobi_geometry(dmg_ocean *o, int k, int *lo, int *hi, int *tile_rows)
+{
+    DMG_CHECK_ARG(o != nullptr && lo != nullptr && hi != nullptr && tile_rows != nullptr && k >= 0);
+    *lo = o->gs ? k : 0;
+    *hi = o->L - (o->gn ? k : 0);
+    const bool blocked = o->have_terrain && o->prm.jacobi_kernel != DMG_JACOBI_SINGLE && ocean_tb_supported(o);
+    *tile_rows = blocked ? ocean_tb_tile_rows(o, *lo, *hi) : 0;
+    return DMG_OK;
+}
+
+int dmg_ocean_band_rows(dmg_ocean *o, int *stored_rows, int *ghost_south, int *ghost_north)
+{
+    DMG_CHECK_ARG(o != nullptr);
+    if (stored_rows) *stored_rows = o->L;
+    if (ghost_south) *ghost_south = o->gs;
+    if (ghost_north) *ghost_north = o->gn;
+    return DMG_OK;
+}
+
+// n (1..8) sweeps over local rows [lo, hi) from pressure buffer `src` (0/1) into the other one, on `stream` (a
+// hipStream_t; NULL = the context's).  part 0 = every tile row, 1 = the tile rows that produce rows below zone_lo or
+// above zone_hi, 2 = the others (one tiling, anchored at lo).  Changes neither the current buffer nor the counters.
+int dmg_ocean_jacobi_launch(dmg_ocean *o, int lo, int hi, int n, int part, int zone_lo, int zone_hi, int src, void *stream)
+{
+    DMG_CHECK_ARG(o != nullptr && n >= 1 && n <= 8 && part >= 0 && part <= 2 && (src == 0 || src == 1));
+    DMG_CHECK_ARG(lo >= 0 && hi <= o->L);
+    if (!o->have_terrain) return dmg_fail(DMG_ESTATE, "dmg_ocean_set_terrain must come first");
+    if (o->prm.jacobi_kernel == DMG_JACOBI_SINGLE || !ocean_tb_supported(o))
+        return dmg_fail(DMG_EINVAL, "dmg_ocean_jacobi_launch needs the blocked kernel");
+    int rc = no_pending(o, "dmg_ocean_jacobi_launch");
+    if (rc) return rc;
+    DMG_HIP(hipSetDevice(o->ctx->device));
+    return ocean_launch_tb(o, lo, hi, n, part, zone_lo, zone_hi, src, (hipStream_t)stream);
+}
+
+int dmg_ocean_pressure_buffer(dmg_ocean *o, int *current)
+{
+    DMG_CHECK_ARG(o != nullptr && current != nullptr);
+    *current = o->cur;
+    return DMG_OK;
+}
+
+// after a self-scheduled block: buffer `idx` holds the new iterate; account for `launches` launches of `sweeps` sweeps
+int dmg_ocean_set_pressure_buffer(dmg_ocean *o, int idx, int launches, int sweeps)
+{
+    DMG_CHECK_ARG(o != nullptr && (idx == 0 || idx == 1) && launches >= 0 && sweeps >= 0);
+    int rc = no_pending(o, "dmg_ocean_set_pressure_buffer");
+    if (rc) return rc;
+    o->cur = idx;
+    o->n_launches += launches; o->n_sweeps += sweeps;
+    return DMG_OK;
+}
+
+// the pressure slabs of dmg_ocean_halo, but of buffer `buffer` (0/1) instead of the current one
+int dmg_ocean_pressure_halo(dmg_ocean *o, int buffer, int side, int rows, void **send, void **recv, size_t *bytes)
+{
+    DMG_CHECK_ARG(o != nullptr && (buffer == 0 || buffer == 1));
+    const int keep = o->cur;
+    o->cur = buffer;
+    int rc = dmg_ocean_halo(o, DMG_F_PRESSURE, side, rows, send, recv, bytes);
+    o->cur = keep;
+    return rc;
+}
+
 int dmg_ocean_counters(dmg_ocean *o, long long *jacobi_launches, long long *jacobi_sweeps)
 {
     DMG_CHECK_ARG(o != nullptr);

@@ -72,7 +72,9 @@ int ocean_build_codes(dmg_ocean *o);
 int ocean_build_codes8(dmg_ocean *o);
 int ocean_zero_land(dmg_ocean *o);            // p := +0 on land in BOTH ping-pong buffers (invariant of the blocked kernel)
 // ocean_jacobi_tb.hip: n (1..8) sweeps over local rows [lo, hi); part/zone: see tb_lists (part 0: zones ignored)
-int ocean_launch_tb(dmg_ocean *o, int lo, int hi, int n, int part = 0, int zone_lo = 0, int zone_hi = 0);
+int ocean_launch_tb(dmg_ocean *o, int lo, int hi, int n, int part = 0, int zone_lo = 0, int zone_hi = 0, int src = -1,
+                    hipStream_t stream = nullptr);   // src >= 0: from p[src] into p[src ^ 1] instead of the current pair; stream: instead of the context's
+int ocean_tb_tile_rows(dmg_ocean *o, int lo, int hi);    // output rows per tile row of the shape an 8-sweep launch over [lo, hi) uses; 0 while its tuner is open
 int ocean_launch_diffusion_tb(dmg_ocean *o, int lo, int hi, int n);   // ocean_diffusion_tb.hip: n (1..8) sweeps over local rows [lo, hi)
 bool ocean_tb_supported(const dmg_ocean *o);
 bool ocean_tb_tuning_open(dmg_ocean *o, int lo, int hi);   // the shape tuner of the 8-sweep launch over [lo, hi) has not decided yet

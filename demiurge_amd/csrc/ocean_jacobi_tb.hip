@@ -419,12 +419,13 @@ static int tb_launch(dmg_ocean *o, tb_args a, int W, int rows, hipStream_t strea
 // host launcher: `n` (1..8) sweeps over local rows [lo, hi).  The caller flips o->cur.
 // part 1 / 2 launch only the tile rows that do / do not produce rows of [lo, zone_lo) or [zone_hi, hi): the two parts of
 // one tiling, so that the rows a neighbour band waits for can be sent while the rest is still being swept.
-int ocean_launch_tb(dmg_ocean *o, int lo, int hi, int n, int part, int zone_lo, int zone_hi)
+int ocean_launch_tb(dmg_ocean *o, int lo, int hi, int n, int part, int zone_lo, int zone_hi, int src, hipStream_t stream)
 {
     if (hi <= lo) return DMG_OK;
     tb_args a;
-    a.pin = o->p[o->cur];
-    a.pout = o->p[o->cur ^ 1];
+    const int from = src >= 0 ? (src & 1) : o->cur;
+    a.pin = o->p[from];
+    a.pout = o->p[from ^ 1];
     a.b = o->divw;
     a.code = o->code;
     a.cx = o->jac_cx; a.cy = o->jac_cy; a.beta = o->jac_beta;
@@ -436,7 +437,7 @@ int ocean_launch_tb(dmg_ocean *o, int lo, int hi, int n, int part, int zone_lo, 
     a.nsweeps = n;
     static const bool use_cls = getenv("DMG_TB_NOCLASS") == nullptr;
     a.rowclass = use_cls ? o->rowclass : nullptr;
-    hipStream_t st = o->ctx->stream;
+    hipStream_t st = stream ? stream : o->ctx->stream;
     // Tile shape.  Every shape gives bit-identical results, so which one runs is purely a matter of time.  Large
     // launches (thousands of tiles) keep the chip full with 64-row tiles.  Smaller ones are bound by the latency of a
     // tile or by how the tile count divides into the 512-768 workgroup slots; there the first few launches of a
@@ -483,6 +484,17 @@ int ocean_launch_tb(dmg_ocean *o, int lo, int hi, int n, int part, int zone_lo, 
     }
     DMG_HIP(hipGetLastError());
     return DMG_OK;
+}
+
+// output rows per tile row (R*8 - 16) of the shape the 8-sweep launch over [lo, hi) runs with; 0 = tuner still open
+int ocean_tb_tile_rows(dmg_ocean *o, int lo, int hi)
+{
+    tb_shape f = tb_forced_shape();
+    if (f.R) return f.R * f.NW - 2 * TB_T;
+    if (ocean_tb_tuning_open(o, lo, hi)) return 0;
+    static const int rows_of[3] = { 8 * 8 - 2 * TB_T, 6 * 8 - 2 * TB_T, 4 * 8 - 2 * TB_T };
+    auto it = o->tb_tuning.find(std::make_pair(lo, hi));
+    return (it != o->tb_tuning.end() && it->second.chosen >= 0) ? rows_of[it->second.chosen] : rows_of[0];
 }
 
 // true while the per-geometry shape tuner (ocean_launch_tb) would still time a candidate for a whole 8-sweep launch

@@ -147,6 +147,23 @@ int dmg_ocean_zero_pressure(dmg_ocean *o);
  * calls only dmg_ocean_halo (and velocity / terrain accessors) may be used on this ocean. */
 int dmg_ocean_jacobi_sweeps_begin(dmg_ocean *o, int n);
 int dmg_ocean_jacobi_sweeps_end(dmg_ocean *o);
+/* Pieces for a host that schedules the launches of a block of sweeps itself, e.g. to run the tile rows next to the
+ * band edges on a second stream ahead of the rest so that the halo exchange hides behind the interior sweeps
+ * (demiurge_amd/bands.py, jacobi_solve_pipelined).  All results stay bit-identical to dmg_ocean_jacobi_sweeps.
+ *   _geometry         rows [lo, hi) of the launch that ends k sweeps after the last halo refresh; output rows per tile
+ *                     row of the tile shape chosen for it (0: still being tuned, or no blocked kernel -- do not split)
+ *   _band_rows        stored rows and ghost rows of this band
+ *   _jacobi_launch    n (1..8) sweeps over [lo, hi) from pressure buffer src (0/1) into the other one on `stream`
+ *                     (hipStream_t, NULL = the context's); part 0 all tile rows, 1 those producing rows < zone_lo or
+ *                     >= zone_hi, 2 the others; touches neither the current-buffer index nor the counters
+ *   _pressure_buffer / _set_pressure_buffer   which buffer is current; make one current after a self-scheduled block
+ *   _pressure_halo    dmg_ocean_halo's pressure slabs of a given buffer */
+int dmg_ocean_jacobi_geometry(dmg_ocean *o, int k, int *lo, int *hi, int *tile_rows);
+int dmg_ocean_band_rows(dmg_ocean *o, int *stored_rows, int *ghost_south, int *ghost_north);
+int dmg_ocean_jacobi_launch(dmg_ocean *o, int lo, int hi, int n, int part, int zone_lo, int zone_hi, int src, void *stream);
+int dmg_ocean_pressure_buffer(dmg_ocean *o, int *current);
+int dmg_ocean_set_pressure_buffer(dmg_ocean *o, int idx, int launches, int sweeps);
+int dmg_ocean_pressure_halo(dmg_ocean *o, int buffer, int side, int rows, void **send, void **recv, size_t *bytes);
 /* cumulative counters since creation: Jacobi kernel launches and sweeps performed (a temporally blocked launch
  * advances up to 8 sweeps) -- what bench.py divides its HIP-event time by */
 int dmg_ocean_counters(dmg_ocean *o, long long *jacobi_launches, long long *jacobi_sweeps);

@@ -102,11 +102,12 @@ def test_bench_multi_rank_rehearsal(tmp_path):
 def test_overlapped_solve_over_rccl():
     """backend nccl (= RCCL) on this box's single GPU: two bands of one process exchange their halos with
     ncclSend/ncclRecv to the process's own rank, so the transfers run on RCCL's own stream next to the interior tiles --
-    the stream ordering the gloo tests cannot reach.  Both orders must reproduce the single-band solve bit for bit."""
+    the stream ordering the gloo tests cannot reach.  All three orders (exchange then sweep, exchange overlapped with the
+    last launch's interior, edge chain pipelined on a second stream) must reproduce the single-band solve bit for bit."""
     import os, subprocess, sys
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
     r = subprocess.run([sys.executable, str(ROOT / "tools" / "nccl_self_probe.py"), "1024", "512", "200", "16"],
                        capture_output=True, text=True, timeout=600, env=env, cwd=str(ROOT))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    lines = [l for l in r.stdout.splitlines() if "bit-identical" in l]
-    assert len(lines) == 2 and all(l.rstrip().endswith("True") for l in lines), r.stdout
+    lines = [l for l in r.stdout.splitlines() if "bit-identical" in l]      # exchange-then-sweep, overlapped last launch, pipelined
+    assert len(lines) == 3 and all(l.rstrip().endswith("True") for l in lines), r.stdout
