@@ -9,7 +9,7 @@ sweep, in 1/ghost as many messages (xGMI is latency-bound at 64 KiB).  Results a
 Transport: `torch.distributed` P2P -- backend "nccl" (= RCCL over xGMI) sends straight from / into the library's
 device slabs (zero copy); with backend "gloo" (CPU tests, or several ranks sharing one GPU) slabs are staged
 through host tensors.  In the Jacobi solve the exchange for the next block of sweeps overlaps the interior tiles of the
-current block's last launch (jacobi_solve).
+current block's last launch when DMG_HALO_OVERLAP=1 (jacobi_solve).
 
 Stream contract: create the dmg context on the stream torch issues its copies / collectives on
 (`capi.Context(dev, stream=torch.cuda.current_stream().cuda_stream)`), so kernels, halo sends and halo receives
@@ -106,16 +106,19 @@ class HaloExchanger:
 
 def _overlap_enabled(ocean):
     import os
-    return os.environ.get("DMG_HALO_OVERLAP", "1") != "0" and hasattr(ocean, "jacobi_sweeps_begin")
+    return os.environ.get("DMG_HALO_OVERLAP", "0") == "1" and hasattr(ocean, "jacobi_sweeps_begin")
 
 
 def jacobi_solve(ocean, exch, sweeps, ghost, zero_first=True, field=0):
     """OceanCurrents::jacobi (reference OceanCurrents.cpp:437-509) over latitude bands: pressure := 0, then
     `sweeps` sweeps in blocks of `ghost` with one halo refresh per block.  Returns the number of sweep launches.
 
-    The refresh for block b+1 is posted as soon as the rows it carries exist -- after the edge tiles of block b's last
-    launch -- and overlaps the interior tiles of that launch (dmg_ocean_jacobi_sweeps_begin/_end); DMG_HALO_OVERLAP=0
-    (or an ocean without the split call) falls back to exchange-then-sweep.  Both orders give the same bits."""
+    Default order: exchange, then sweep.  Two overlapped orders are implemented and bit-identical, both opt-in because
+    on one GPU (two bands exchanging through RCCL with the process's own rank, tools/nccl_self_probe.py) the plain order
+    measured fastest (profiles/r01_rccl_self_probe.log) and there is no second GPU here to measure them across xGMI:
+      DMG_HALO_OVERLAP=1   the refresh for block b+1 is posted after the edge tiles of block b's last launch and overlaps
+                           the interior tiles of that launch (dmg_ocean_jacobi_sweeps_begin/_end);
+      DMG_HALO_PIPELINE=1  jacobi_solve_pipelined: every launch split, the edge chain on a second stream."""
     import os
     if exch is not None and exch.world > 1 and os.environ.get("DMG_HALO_PIPELINE") == "1":
         return jacobi_solve_pipelined(ocean, exch, sweeps, ghost, zero_first)      # opt-in: see its docstring

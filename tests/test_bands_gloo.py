@@ -35,10 +35,12 @@ def test_bands_gloo_cpu(oracle, tmp_path, world, ghost, sweeps):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,ghost,sweeps", [(2, 8, 40), (4, 3, 10)])
-def test_bands_gloo_hip_ranks_share_gpu(oracle, tmp_path, world, ghost, sweeps):
-    """N ranks (one process each) drive the HIP library on the same GPU; host-staged gloo halos."""
+@pytest.mark.parametrize("world,ghost,sweeps,overlap", [(2, 8, 40, "0"), (4, 3, 10, "0"), (2, 8, 100, "1"), (3, 16, 200, "1")])
+def test_bands_gloo_hip_ranks_share_gpu(oracle, tmp_path, monkeypatch, world, ghost, sweeps, overlap):
+    """N ranks (one process each) drive the HIP library on the same GPU; host-staged gloo halos.  overlap = "1": the
+    exchange posted between the edge and the interior tiles of each block's last launch (DMG_HALO_OVERLAP)."""
     from demiurge_amd import synth
+    monkeypatch.setenv("DMG_HALO_OVERLAP", overlap)
     W, H = 512, 256
     got = run_bands("hip", world, W, H, sweeps, ghost, tmp_path)
     ref = oracle.ocean_jacobi(oracle.grid(W, H), synth.terrain(W, H), synth.divw(W, H), sweeps, rows=True)
