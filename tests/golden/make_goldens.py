@@ -193,6 +193,35 @@ def large_goldens():
     save("large_512x256_full", coords=np.array(FULL), circ=f32(CIRC), **arrs)
 
 
+def large_region_goldens():
+    """512x256 on the regional extent (no longitude wrap, no poles: CLAMP_TO_EDGE everywhere) -- hashes, as large_goldens"""
+    import hashlib
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+    from large_inputs import large_inputs
+    W, H = 512, 256
+    I = large_inputs(W, H)
+    v = (synth.velocity(W, H) * f32(3)).astype(f32)
+    v[I["terrain"] > 0] = 0
+    out = {}
+    v2, p2, d2 = refgl.ocean_step(I["terrain"], v, n_outer=2, jacobi_iters=100, diffusion_iters=50, coords=REGION)
+    out.update(step_v=v2, step_pressure=p2, step_divw=d2)
+    out["blur_r3"] = refgl.blur(I["terrain"], 3.0, coords=REGION)
+    out["temperature_3_from11"] = refgl.temperature(I["T"], I["heights"], 11, 3, coords=REGION)
+    out["thermal"] = refgl.thermal_erosion(I["relief"], coords=REGION)
+    out["erode_r5"] = refgl.morphological(I["terrain"], 5.5, "min", coords=REGION)
+    codes, mask = refgl.flow_direction_and_mask(refgl.blur(I["heights"], 0.5, coords=REGION), coords=REGION)
+    out["flow_codes"], out["flow_mask"] = codes.astype(f32), mask.astype(f32)
+    out["noise_SWISS"] = refgl.gradient_noise(np.zeros((H, W), f32), "SWISS", "replace", coords=REGION, seed=5, warp=0.6)
+    terrain, plates = refgl.tectonics(I["tect"], 8, coords=REGION, circ=CIRC)
+    out["tectonics_8_terrain"] = terrain
+    arrs = {}
+    for k, a in out.items():
+        a = np.ascontiguousarray(a, f32)
+        arrs[k + "_sha256"] = np.array(hashlib.sha256(a.tobytes()).hexdigest())
+        arrs[k + "_sample"] = a[::8, ::8].copy()
+    save("large_512x256_region", coords=np.array(REGION), circ=f32(CIRC), **arrs)
+
+
 def huge_goldens():
     """2048x1024 (2 M cells): one ocean outer step with 300 Jacobi sweeps, the flow passes, the climate step and three
     noise modes; hashes only (see large_goldens).  Catches 1-in-a-million rounding cases."""
@@ -221,6 +250,8 @@ def huge_goldens():
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "large_region":
+        return large_region_goldens()
     if len(sys.argv) > 1 and sys.argv[1] == "huge":
         return huge_goldens()
     if len(sys.argv) > 1 and sys.argv[1] == "large":
@@ -244,6 +275,7 @@ def main():
     climate_goldens()
     blocked_goldens()
     large_goldens()
+    large_region_goldens()
     huge_goldens()
     # ---- Jacobi (headline) -------------------------------------------------
     W, H = 256, 128

@@ -175,3 +175,34 @@ def test_huge_grid_hashes(dev):
     check(G, "flow_codes", codes, 32); check(G, "flow_mask", mask, 32)
     for m in ("DEFAULT", "SWISS", "Jordan"):
         check(G, "noise_" + m, ctx.gradient_noise(g, np.zeros((H, W), np.float32), capi.noise_params(m, seed=9, warp=0.4)), 32)
+
+
+def test_large_grid_hashes_regional_extent(dev):
+    """the same tools on the regional extent (CLAMP_TO_EDGE everywhere; the ocean passes take the one-sweep kernels)"""
+    from demiurge_amd import synth
+    from large_inputs import check, large_inputs
+    capi, ctx = dev
+    G = load_golden("large_512x256_region")
+    W, H = 512, 256
+    g = capi.make_grid(W, H, tuple(G["coords"]), float(G["circ"]))
+    I = large_inputs(W, H)
+    v = (synth.velocity(W, H) * np.float32(3)).astype(np.float32)
+    v[I["terrain"] > 0] = 0
+    prm = capi.default_ocean_params()
+    prm.jacobi_iters, prm.diffusion_iters = 100, 50
+    o = capi.Ocean(ctx, g, params=prm)
+    o.set_terrain(I["terrain"]); o.set_velocity(v); o.step(2)
+    r = o.get()
+    o.close()
+    check(G, "step_v", r["v"]); check(G, "step_pressure", r["pressure"]); check(G, "step_divw", r["divw"])
+    check(G, "blur_r3", ctx.blur(g, I["terrain"], 3.0))
+    check(G, "temperature_3_from11", ctx.temperature_steps(g, I["T"], I["heights"], 11, 3))
+    check(G, "thermal", ctx.thermal_erosion(g, I["relief"]))
+    check(G, "erode_r5", ctx.morphological(g, I["terrain"], 5.5, "min"))
+    codes, mask = ctx.flow_passes(g, I["heights"], 0.5)
+    check(G, "flow_codes", codes); check(G, "flow_mask", mask)
+    check(G, "noise_SWISS", ctx.gradient_noise(g, np.zeros((H, W), np.float32), capi.noise_params("SWISS", seed=5, warp=0.6)))
+    t = capi.Tectonics(ctx, g, I["tect"])
+    t.step(8)
+    check(G, "tectonics_8_terrain", t.terrain())
+    t.close()
