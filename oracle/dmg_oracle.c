@@ -266,6 +266,26 @@ void orc_offset(const orc_grid *g, float px, float py, float dpx, float dpy, flo
 static inline float stx(const orc_grid *g, int x) { return ((float)x + 0.5f) / (float)g->W; }
 static inline float sty(const orc_grid *g, int y) { return ((float)y + 0.5f) / (float)g->H; }
 
+/* `st` as llvmpipe's rasteriser interpolates it over the reference's full-screen quad (tools/st_probe.py: the model
+ * matches a shader that writes `st` at 100 % of the pixels of every size tried).  Two triangles split along the
+ * anti-diagonal, plane equations in fp32, each anchored at its own vertex; exactly (x+0.5)/W on power-of-two grids, up
+ * to an ulp of 1.0 off elsewhere.  Used only where a test wants the reference's pixels on a non-power-of-two grid
+ * (orc_set_raster_st); the product takes st = (x+0.5)/W, which is what the maths says and what the grids of
+ * BASELINE.json give under any rasteriser. */
+static int g_raster_st = 0;
+void orc_set_raster_st(int on) { g_raster_st = on; }
+static inline void st_raster(const orc_grid *g, int x, int y, float *sx, float *sy)
+{
+    const float Wf = (float)g->W, Hf = (float)g->H;
+    const float ooa = 1.0f / (Wf * Hf);
+    const float d = Hf * ooa, e = Wf * ooa;
+    const int lower = ((double)x + 0.5) / g->W + ((double)y + 0.5) / g->H < 1.0;
+    const float a0x = lower ? 0.0f - d * (0.0f - 0.5f) : 1.0f - d * (Wf - 0.5f);
+    const float a0y = lower ? 0.0f - e * (0.0f - 0.5f) : 1.0f - e * (Hf - 0.5f);
+    *sx = fmaf(d, (float)x, a0x);
+    *sy = fmaf(e, (float)y, a0y);
+}
+
 /* ====================================================================== */
 /* Ocean currents                                                          */
 /* ====================================================================== */
@@ -286,6 +306,13 @@ static void jacobi_sweep_literal(const orc_grid *g, const float *img, const floa
         float Beta = 2.0f * (1.0f / pw2x + 1.0f / pw2y);      /* :479 */
         for (int x = 0; x < W; x++) {
             float sx = stx(g, x);
+            if (g_raster_st) {                                /* per fragment, as the shader has it */
+                st_raster(g, x, y, &sx, &sy);
+                orc_pixelsize(g, sy, &dx, &dy);
+                wx = dx / 420.0f; wy = dy / 420.0f;
+                pw2x = wx * wx; pw2y = wy * wy;
+                Beta = 2.0f * (1.0f / pw2x + 1.0f / pw2y);
+            }
             float nx, ny, sx2, sy2, ex, ey, wx2, wy2;
             orc_offset(g, sx, sy, 0, 1, rx, ry, &nx, &ny);
             orc_offset(g, sx, sy, 0, -1, rx, ry, &sx2, &sy2);

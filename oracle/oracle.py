@@ -38,6 +38,7 @@ def lib():
         G = ctypes.POINTER(Grid)
         L.orc_set_linear_taps.argtypes = [ctypes.c_int]
         L.orc_set_threads.argtypes = [ctypes.c_int]
+        L.orc_set_raster_st.argtypes = [ctypes.c_int]
         L.orc_set_glsl_math.argtypes = [ctypes.c_int]
         L.orc_ocean_jacobi.argtypes = [G, P, P, P, P, ctypes.c_int]
         L.orc_ocean_jacobi_rows.argtypes = [G, P, P, P, P, ctypes.c_int, ctypes.c_int]
@@ -76,6 +77,12 @@ def _ptr(a):
 
 def set_linear_taps(bilinear):
     lib().orc_set_linear_taps(1 if bilinear else 0)
+
+
+def set_raster_st(on):
+    """literal Jacobi form only: take `st` as llvmpipe's rasteriser interpolates it (tools/st_probe.py) instead of
+    (x+0.5)/W -- identical on power-of-two grids; with set_linear_taps(True) this reproduces llvmpipe on any grid"""
+    lib().orc_set_raster_st(1 if on else 0)
 
 
 def set_threads(n):
