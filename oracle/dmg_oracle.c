@@ -274,17 +274,21 @@ static inline float sty(const orc_grid *g, int y) { return ((float)y + 0.5f) / (
  * BASELINE.json give under any rasteriser. */
 static int g_raster_st = 0;
 void orc_set_raster_st(int on) { g_raster_st = on; }
-static inline void st_raster(const orc_grid *g, int x, int y, float *sx, float *sy)
+int orc_raster_st(void) { return g_raster_st; }
+void orc_st_raster(const orc_grid *g, int x, int y, float *sx, float *sy);
+static inline void st_raster(const orc_grid *g, int x, int y, float *sx, float *sy) { orc_st_raster(g, x, y, sx, sy); }
+void orc_st_raster_wh(int W, int H, int x, int y, float *sx, float *sy)
 {
-    const float Wf = (float)g->W, Hf = (float)g->H;
+    const float Wf = (float)W, Hf = (float)H;
     const float ooa = 1.0f / (Wf * Hf);
     const float d = Hf * ooa, e = Wf * ooa;
-    const int lower = ((double)x + 0.5) / g->W + ((double)y + 0.5) / g->H < 1.0;
+    const int lower = ((double)x + 0.5) / W + ((double)y + 0.5) / H < 1.0;
     const float a0x = lower ? 0.0f - d * (0.0f - 0.5f) : 1.0f - d * (Wf - 0.5f);
     const float a0y = lower ? 0.0f - e * (0.0f - 0.5f) : 1.0f - e * (Hf - 0.5f);
     *sx = fmaf(d, (float)x, a0x);
     *sy = fmaf(e, (float)y, a0y);
 }
+void orc_st_raster(const orc_grid *g, int x, int y, float *sx, float *sy) { orc_st_raster_wh(g->W, g->H, x, y, sx, sy); }
 
 /* ====================================================================== */
 /* Ocean currents                                                          */

@@ -13,6 +13,8 @@
 #include <stdint.h>
 #include <string.h>
 #include "dmg_oracle.h"
+int orc_raster_st(void);
+void orc_st_raster(const orc_grid *g, int x, int y, float *sx, float *sy);
 
 static const float MPI = 3.1415926535897932384626433832795f;
 
@@ -345,6 +347,7 @@ void orc_gradient_noise(const orc_grid *g, const float *img, const float *sel, c
     for (int y = 0; y < g->H; y++)
         for (int x = 0; x < g->W; x++) {
             float sx = ((float)x + 0.5f) / (float)g->W, sy = ((float)y + 0.5f) / (float)g->H;
+            if (orc_raster_st()) orc_st_raster(g, x, y, &sx, &sy);      /* llvmpipe's interpolated st (dmg_oracle.c) */
             float fc = noise_value(g, &q, sx, sy);
             size_t k = (size_t)y * g->W + x;
             out[k] = blend(blend_mode, img[k], fc, sel ? sel[k] : 1.0f);

@@ -185,6 +185,15 @@ static inline float geodistance(const orc_grid *g, float p1x, float p1y, float p
 }
 
 #define ST(x, n) (((float)(x) + 0.5f) / (float)(n))
+/* st of the fragment (x, y) of a w x h target: (x+0.5)/w, or as llvmpipe's rasteriser interpolates it (dmg_oracle.c,
+ * orc_set_raster_st: identical on power-of-two targets) */
+int orc_raster_st(void);
+void orc_st_raster_wh(int W, int H, int x, int y, float *sx, float *sy);
+static inline void st_of(int x, int y, int w, int h, float *sx, float *sy)
+{
+    *sx = ST(x, w); *sy = ST(y, h);
+    if (orc_raster_st()) orc_st_raster_wh(w, h, x, y, sx, sy);
+}
 
 /* ---------- passes ---------- */
 /* plate initialisation, Tectonics.cpp:28-34 (which = 0) and :44-50 (which = 1); img and dst are W x H */
@@ -192,7 +201,8 @@ void orc_tect_init_plate(const orc_grid *g, const float *img, int which, float *
 {
     for (int y = 0; y < g->H; y++)
         for (int x = 0; x < g->W; x++) {
-            float a = img[(size_t)y * g->W + x], sx = ST(x, g->W);
+            float a = img[(size_t)y * g->W + x], sx, sy_unused;
+            st_of(x, y, g->W, g->H, &sx, &sy_unused);
             vec4 fc;
             if (which == 0) {
                 float h = a > 0.0f ? a : -1.0f;
@@ -220,7 +230,8 @@ void orc_tect_fold(const orc_grid *g, const float *foldtex, int fw, int fh, cons
 #pragma omp parallel for schedule(static)
     for (int y = 0; y < h; y++)
         for (int x = 0; x < w; x++) {
-            float sx = ST(x, w), sy = ST(y, h);
+            float sx, sy;
+            st_of(x, y, w, h, &sx, &sy);
             vec4 fc = fetch4(foldtex, fw, fh, sx, sy);
             vec4 p = rotated_fetch(g, plate, pw, ph, rot, sx, sy);
             float plateHeight = p.x, plateAge = p.y;
@@ -260,7 +271,8 @@ void orc_tect_spread_ring(const orc_grid *g, const float *src, float radius, flo
 #pragma omp parallel for schedule(static)
     for (int y = 0; y < h; y++)
         for (int x = 0; x < w; x++) {
-            float sx = ST(x, w), sy = ST(y, h);
+            float sx, sy;
+            st_of(x, y, w, h, &sx, &sy);
             vec4 fc = fetch4(src, w, h, sx, sy);
             float lon, phi;
             to_spheric(g, sx, sy, &lon, &phi);
@@ -281,7 +293,11 @@ void orc_tect_render(const orc_grid *g, const float *foldtex, int fw, int fh, fl
 {
     for (int y = 0; y < g->H; y++)
         for (int x = 0; x < g->W; x++)
-            terrain[(size_t)y * g->W + x] = fetch4(foldtex, fw, fh, ST(x, g->W), ST(y, g->H)).y;
+        {
+            float sx, sy;
+            st_of(x, y, g->W, g->H, &sx, &sy);
+            terrain[(size_t)y * g->W + x] = fetch4(foldtex, fw, fh, sx, sy).y;
+        }
 }
 
 /* the only channel of collision() (:399-618) that anything reads afterwards: c.y = plateIndices.x (:590) */
@@ -289,7 +305,11 @@ void orc_tect_collision_y(const float *plateIndices, int bw, int bh, float *c, i
 {
     for (int y = 0; y < h; y++)
         for (int x = 0; x < w; x++)
-            c[((size_t)y * w + x) * 4 + 1] = fetch4(plateIndices, bw, bh, ST(x, w), ST(y, h)).x;
+        {
+            float sx, sy;
+            st_of(x, y, w, h, &sx, &sy);
+            c[((size_t)y * w + x) * 4 + 1] = fetch4(plateIndices, bw, bh, sx, sy).x;
+        }
 }
 
 /* back to plates :216-251: dst (w x h) from the global map `foldtex` and the plate's previous texture */
@@ -299,7 +319,8 @@ void orc_tect_unfold(const orc_grid *g, const float *foldtex, int fw, int fh, co
 #pragma omp parallel for schedule(static)
     for (int y = 0; y < h; y++)
         for (int x = 0; x < w; x++) {
-            float sx = ST(x, w), sy = ST(y, h);
+            float sx, sy;
+            st_of(x, y, w, h, &sx, &sy);
             vec4 a = rotated_fetch(g, foldtex, fw, fh, invrot, sx, sy);
             vec4 fc = fetch4(oldPlate, ow, oh, sx, sy);
             if (fc.y >= 0.0f) fc.y += 0.01f;

@@ -52,6 +52,12 @@ def test_oracle_noise_non_pow2(oracle):
     g = oracle.grid(100, 50)
     out = oracle.gradient_noise(g, G["img"], "DEFAULT", seed=int(G["seed"]))
     assert (out != G["out_DEFAULT"]).mean() < 0.05 and relerr(out, G["out_DEFAULT"]) < 5e-3
+    # ... and with st as llvmpipe's rasteriser interpolates it (tools/st_probe.py) every texel is the reference's
+    oracle.set_raster_st(True)
+    try:
+        assert np.array_equal(oracle.gradient_noise(g, G["img"], "DEFAULT", seed=int(G["seed"])), G["out_DEFAULT"])
+    finally:
+        oracle.set_raster_st(False)
 
 
 def test_oracle_blend_modes(oracle):
