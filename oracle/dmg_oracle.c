@@ -476,6 +476,7 @@ void orc_ocean_divergence(const orc_grid *g, const float *img, const float *v, f
         float pwx = dxc / 420.0f, pwy = dyc / 420.0f;      /* :419 */
         for (int x = 0; x < W; x++) {
             float sx = stx(g, x);
+            if (g_raster_st) { st_raster(g, x, y, &sx, &sy); orc_pixelsize(g, sy, &dxc, &dyc); pwx = dxc / 420.0f; pwy = dyc / 420.0f; }
             float vel[4][2], so[4][2];
             const float offs[4][2] = { { 0, 1 }, { 0, -1 }, { 1, 0 }, { -1, 0 } };   /* N S E W */
             float o[4];
@@ -518,6 +519,14 @@ void orc_ocean_diffusion(const orc_grid *g, const float *img, float *v, float *s
             float Beta = s * (1.0f + 1.0f / s);          /* :690 */
             for (int x = 0; x < W; x++) {
                 float sx = stx(g, x);
+                if (g_raster_st) {                       /* per fragment, as the shader has it */
+                    st_raster(g, x, y, &sx, &sy);
+                    orc_pixelsize(g, sy, &dx, &dy);
+                    ix = 1.0f / (dx * dx); iy = 1.0f / (dy * dy);
+                    px2 = ix * 176400.0f; py2 = iy * 176400.0f;
+                    s = (ix + iy) * 352800.0f;
+                    Beta = s * (1.0f + 1.0f / s);
+                }
                 const float offs[4][2] = { { 0, 1 }, { 0, -1 }, { 1, 0 }, { -1, 0 } };
                 float pv[4][2], so[4][2];
                 float pCx = tap_linear(a, W, H, 2, 0, sx, sy), pCy = tap_linear(a, W, H, 2, 1, sx, sy);
@@ -578,6 +587,7 @@ void orc_ocean_advect(const orc_grid *g, const float *img, const float *v, float
         float sy = sty(g, y);
         for (int x = 0; x < W; x++) {
             float sx = stx(g, x);
+            if (g_raster_st) st_raster(g, x, y, &sx, &sy);
             float *o = out + ((size_t)y * W + x) * 2;
             if (fetch_nearest(img, W, H, 1, 0, sx, sy) > 0) { o[0] = 0; o[1] = 0; continue; }   /* :284-288 */
             float velx = tap_linear(v, W, H, 2, 0, sx, sy), vely = tap_linear(v, W, H, 2, 1, sx, sy);   /* :290 */
@@ -646,6 +656,7 @@ void orc_ocean_subdiv(const orc_grid *g, const float *img, const float *v, const
         float pwx = dx / 420.0f, pwy = dy / 420.0f;      /* :574 */
         for (int x = 0; x < W; x++) {
             float sx = stx(g, x);
+            if (g_raster_st) { st_raster(g, x, y, &sx, &sy); orc_pixelsize(g, sy, &dx, &dy); pwx = dx / 420.0f; pwy = dy / 420.0f; }
             float *o = out + ((size_t)y * W + x) * 2;
             if (fetch_nearest(img, W, H, 1, 0, sx, sy) > 0) { o[0] = 0; o[1] = 0; continue; }   /* :536-540 */
             float c[4][2];

@@ -222,6 +222,24 @@ def large_region_goldens():
     save("large_512x256_region", coords=np.array(REGION), circ=f32(CIRC), **arrs)
 
 
+def default_size_goldens():
+    """The reference's own default canvas, 1000x500 (not a power of two): one ocean outer step with 100 Jacobi sweeps,
+    every 8th row and column of each pass.  The oracle reproduces these with llvmpipe's rasteriser `st` and float-weight
+    filter modelled (orc_set_raster_st, orc_set_linear_taps), up to llvmpipe's flush of denormals."""
+    W, H = 1000, 500
+    img = synth.terrain(W, H)
+    v = (synth.velocity(W, H) * f32(3)).astype(f32)
+    v[img > 0] = 0
+    a = refgl.ocean_advect(img, v)
+    d = refgl.ocean_diffusion(img, a, 50)
+    w = refgl.ocean_divergence(img, d, 100.0)
+    p = refgl.ocean_jacobi(img, w, 100)
+    s = refgl.ocean_subdiv(img, d, p, 100.0)
+    save("default_1000x500_step", coords=np.array(FULL), circ=f32(CIRC), velocity_scale=f32(3), jacobi_iters=np.int32(100),
+         advect=a[::8, ::8].copy(), diffusion50=d[::8, ::8].copy(), divergence=w[::8, ::8].copy(), pressure=p[::8, ::8].copy(),
+         subdiv=s[::8, ::8].copy())
+
+
 def huge_goldens():
     """2048x1024 (2 M cells): one ocean outer step with 300 Jacobi sweeps, the flow passes, the climate step and three
     noise modes; hashes only (see large_goldens).  Catches 1-in-a-million rounding cases."""
@@ -250,6 +268,8 @@ def huge_goldens():
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "default_size":
+        return default_size_goldens()
     if len(sys.argv) > 1 and sys.argv[1] == "large_region":
         return large_region_goldens()
     if len(sys.argv) > 1 and sys.argv[1] == "huge":
@@ -276,6 +296,7 @@ def main():
     blocked_goldens()
     large_goldens()
     large_region_goldens()
+    default_size_goldens()
     huge_goldens()
     # ---- Jacobi (headline) -------------------------------------------------
     W, H = 256, 128
