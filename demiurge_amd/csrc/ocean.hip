@@ -296,8 +296,6 @@ void dmg_ocean_destroy(dmg_ocean *o)
                      (void *)o->v[0], (void *)o->v[1], (void *)o->rowtab, (void *)o->oob_flag, (void *)o->rowclass })
         if (p) (void)hipFree(p);
     ocean_tb_free_lists(o);
-    if (o->tune_ev0) (void)hipEventDestroy(o->tune_ev0);
-    if (o->tune_ev1) (void)hipEventDestroy(o->tune_ev1);
     delete o;
 }
 

@@ -43,9 +43,13 @@ struct dmg_ocean {
     // (out_lo, out_hi, rows per wave, part, zone_lo, zone_hi) of a launch -> tiles that are not land everywhere; part 0 = all
     // tile rows, 1 = tile rows touching the send zones [out_lo, zone_lo) / [zone_hi, out_hi), 2 = the tile rows in between
     std::map<std::tuple<int, int, int, int, int, int>, tile_list> tb_lists;
-    struct tb_tune { int trials[3] = { 0, 0, 0 }; float best_ms[3] = { 1e30f, 1e30f, 1e30f }; int chosen = -1; };
+    // per launch geometry: which of the three candidate shapes is fastest.  A trial is timed with an event pair that is
+    // read back when the geometry is launched the next time, so that trial launches run back to back with their
+    // neighbours like every other launch (timing them in isolation, with a host synchronisation after each, favoured
+    // shapes that lose in steady state)
+    struct tb_tune { int trials[3] = { 0, 0, 0 }; float best_ms[3] = { 1e30f, 1e30f, 1e30f }; int chosen = -1;
+                     hipEvent_t ev0 = nullptr, ev1 = nullptr; int pending = -1; };
     std::map<std::pair<int, int>, tb_tune> tb_tuning;           // (out_lo, out_hi) -> which tile shape is fastest there
-    hipEvent_t tune_ev0 = nullptr, tune_ev1 = nullptr;
     float *v[2] = { nullptr, nullptr };   // interleaved (vx,vy)
     int vcur = 0;
     // dmg_ocean_jacobi_sweeps_begin/_end: the interior part of a block's last launch, still to be issued

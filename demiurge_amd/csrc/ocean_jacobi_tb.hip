@@ -291,6 +291,10 @@ void ocean_tb_free_lists(dmg_ocean *o)
 {
     for (auto &kv : o->tb_lists) if (kv.second.d) (void)hipFree(kv.second.d);
     o->tb_lists.clear();
+    for (auto &kv : o->tb_tuning) {
+        if (kv.second.ev0) (void)hipEventDestroy(kv.second.ev0);
+        if (kv.second.ev1) (void)hipEventDestroy(kv.second.ev1);
+    }
     o->tb_tuning.clear();
 }
 
@@ -369,8 +373,8 @@ static tb_shape tb_forced_shape()
 }
 
 template <int R, int NW>
-static int tb_launch(dmg_ocean *o, tb_args a, int W, int rows, hipStream_t stream, float *ms = nullptr, int part = 0, int zone_lo = 0,
-                     int zone_hi = 0)
+static int tb_launch(dmg_ocean *o, tb_args a, int W, int rows, hipStream_t stream, dmg_ocean::tb_tune *timed = nullptr, int part = 0,
+                     int zone_lo = 0, int zone_hi = 0)
 {
     constexpr int OH = R * NW - 2 * TB_T;
     a.tiles_x = (W + TB_OW - 1) / TB_OW;
@@ -396,16 +400,12 @@ static int tb_launch(dmg_ocean *o, tb_args a, int W, int rows, hipStream_t strea
         (void)hipMalloc((void **)&a.trace, nt * 48);
         (void)hipMemsetAsync(a.trace, 0, nt * 48, stream);
     }
-    if (ms) (void)hipEventRecord(o->tune_ev0, stream);
+    if (timed) (void)hipEventRecord(timed->ev0, stream);
     if (trace_path && R == 8 && NW == 8)       // the timeline build exists for the default shape only
         hipLaunchKernelGGL((k_jacobi_tb8<8, 8, true>), dim3((unsigned)nt), dim3(NW * 64), 0, stream, a);
     else
         hipLaunchKernelGGL((k_jacobi_tb8<R, NW>), dim3((unsigned)nt), dim3(NW * 64), 0, stream, a);
-    if (ms) {
-        (void)hipEventRecord(o->tune_ev1, stream);
-        (void)hipEventSynchronize(o->tune_ev1);
-        if (hipEventElapsedTime(ms, o->tune_ev0, o->tune_ev1) != hipSuccess) *ms = 1e30f;
-    }
+    if (timed) (void)hipEventRecord(timed->ev1, stream);      // read back at the next launch of this geometry
     if (trace_path) {
         std::vector<unsigned long long> h(nt * 6);
         (void)hipStreamSynchronize(stream);
@@ -444,8 +444,7 @@ int ocean_launch_tb(dmg_ocean *o, int lo, int hi, int n, int part, int zone_lo, 
     // geometry time the three candidates (two launches each) and the rest use the fastest:
     // 1024x512 picks 4x8 (17.2 -> 10.3 ms per 5000-sweep solve), 4096x2048 picks 6x8 (46.0 -> 40.7 ms).
     tb_shape sh = tb_forced_shape();
-    float *ms = nullptr, ms_val = 0.0f;
-    dmg_ocean::tb_tune *tune = nullptr;
+    dmg_ocean::tb_tune *tune = nullptr, *timed = nullptr;
     int cand = -1;
     static const tb_shape cands[3] = { { 8, 8 }, { 6, 8 }, { 4, 8 } };
     if (!sh.R) {
@@ -454,15 +453,23 @@ int ocean_launch_tb(dmg_ocean *o, int lo, int hi, int n, int part, int zone_lo, 
         if (tiles88 <= 4096 && n == TB_T && a.rowclass) {
             tune = &o->tb_tuning[std::make_pair(lo, hi)];
             if (tune->chosen < 0 && !part) {
-                if (!o->tune_ev0 && (hipEventCreate(&o->tune_ev0) != hipSuccess || hipEventCreate(&o->tune_ev1) != hipSuccess))
+                if (!tune->ev0 && (hipEventCreate(&tune->ev0) != hipSuccess || hipEventCreate(&tune->ev1) != hipSuccess))
                     return dmg_fail(DMG_EHIP, "hipEventCreate failed");
+                if (tune->pending >= 0) {                      // the previous trial of this geometry: finished long ago
+                    float ms = 1e30f;
+                    (void)hipEventSynchronize(tune->ev1);
+                    if (hipEventElapsedTime(&ms, tune->ev0, tune->ev1) != hipSuccess) ms = 1e30f;
+                    tune->trials[tune->pending]++;
+                    if (ms < tune->best_ms[tune->pending]) tune->best_ms[tune->pending] = ms;
+                    tune->pending = -1;
+                }
                 cand = 0;
                 while (cand < 3 && tune->trials[cand] >= 2) cand++;
                 if (cand == 3) {
                     tune->chosen = 0;
                     for (int c = 1; c < 3; c++) if (tune->best_ms[c] < tune->best_ms[tune->chosen]) tune->chosen = c;
                     cand = -1;
-                } else ms = &ms_val;
+                } else { timed = tune; tune->pending = cand; }
             }
             // the two parts of a split launch share one tiling: the geometry's chosen shape, or the default until the
             // whole launches of this geometry have been timed
@@ -470,18 +477,14 @@ int ocean_launch_tb(dmg_ocean *o, int lo, int hi, int n, int part, int zone_lo, 
         }
     }
     int rc;
-    if (sh.R == 4) rc = tb_launch<4, 8>(o, a, a.W, hi - lo, st, ms, part, zone_lo, zone_hi);
-    else if (sh.R == 6) rc = tb_launch<6, 8>(o, a, a.W, hi - lo, st, ms, part, zone_lo, zone_hi);
-    else if (sh.R == 16) rc = tb_launch<16, 8>(o, a, a.W, hi - lo, st, ms, part, zone_lo, zone_hi);
-    else if (sh.R == 10) rc = tb_launch<10, 8>(o, a, a.W, hi - lo, st, ms, part, zone_lo, zone_hi);
-    else if (sh.R == 12) rc = tb_launch<12, 8>(o, a, a.W, hi - lo, st, ms, part, zone_lo, zone_hi);
-    else if (sh.NW == 16) rc = tb_launch<8, 16>(o, a, a.W, hi - lo, st, ms, part, zone_lo, zone_hi);
-    else rc = tb_launch<8, 8>(o, a, a.W, hi - lo, st, ms, part, zone_lo, zone_hi);
+    if (sh.R == 4) rc = tb_launch<4, 8>(o, a, a.W, hi - lo, st, timed, part, zone_lo, zone_hi);
+    else if (sh.R == 6) rc = tb_launch<6, 8>(o, a, a.W, hi - lo, st, timed, part, zone_lo, zone_hi);
+    else if (sh.R == 16) rc = tb_launch<16, 8>(o, a, a.W, hi - lo, st, timed, part, zone_lo, zone_hi);
+    else if (sh.R == 10) rc = tb_launch<10, 8>(o, a, a.W, hi - lo, st, timed, part, zone_lo, zone_hi);
+    else if (sh.R == 12) rc = tb_launch<12, 8>(o, a, a.W, hi - lo, st, timed, part, zone_lo, zone_hi);
+    else if (sh.NW == 16) rc = tb_launch<8, 16>(o, a, a.W, hi - lo, st, timed, part, zone_lo, zone_hi);
+    else rc = tb_launch<8, 8>(o, a, a.W, hi - lo, st, timed, part, zone_lo, zone_hi);
     if (rc) return rc;
-    if (ms && cand >= 0) {
-        tune->trials[cand]++;
-        if (ms_val < tune->best_ms[cand]) tune->best_ms[cand] = ms_val;
-    }
     DMG_HIP(hipGetLastError());
     return DMG_OK;
 }
