@@ -250,16 +250,18 @@ int ocean_launch_diffusion_tb(dmg_ocean *o, int lo, int hi, int n)
     a.nsweeps = n;
     a.rowclass = o->rowclass;
     a.scalar_rhs = (o->prm.quirks & DMG_QUIRK_DIFFUSION_SCALAR_RHS) ? 1 : 0;
-    // tile shape: every shape gives identical results.  48-row tiles (R = 6: 122 VGPRs, two workgroups per CU) for
-    // launches of more than a few hundred tiles, 32-row ones below.  Measured, 50 sweeps at 16384x8192: R = 6 7.9 ms,
+    // tile shape: every shape gives identical results.  56-row tiles (R = 7: 128 VGPRs with 16 B of spill, two workgroups
+    // per CU) for launches of thousands of tiles, 48-row ones (R = 6, 122 VGPRs) for hundreds, 32-row ones below.
+    // Measured, 50 sweeps at 16384x8192: R = 7 7.6 ms, R = 6 7.8 ms,
     // R = 4 10.3 ms, R = 8 13.5 ms (it needs ~150 VGPRs and spills at the 128 that two resident workgroups allow;
     // 6-wave workgroups of 8 or 10 rows per thread at 3 waves per SIMD: 11.5 / 10.9 ms);
-    // one sweep per launch: 28.7 ms.  DMG_DTB_ROWS=4|6|8 forces a height for experiments.
-    static const int forced = [] { const char *e = getenv("DMG_DTB_ROWS"); int r = e ? atoi(e) : 0; return (r == 4 || r == 6 || r == 8) ? r : 0; }();
+    // one sweep per launch: 28.7 ms.  DMG_DTB_ROWS=4|6|7|8 forces a height for experiments.
+    static const int forced = [] { const char *e = getenv("DMG_DTB_ROWS"); int r = e ? atoi(e) : 0; return (r == 4 || r == 6 || r == 7 || r == 8) ? r : 0; }();
     const int tiles88 = ((a.W + TB_OW - 1) / TB_OW) * ((hi - lo + 47) / 48);
-    const int R = forced ? forced : (tiles88 > 400 ? 6 : 4);
+    const int R = forced ? forced : (tiles88 > 2000 ? 7 : (tiles88 > 400 ? 6 : 4));
     hipStream_t st = o->ctx->stream;
     if (R == 4) dtb_launch<4, 8>(a, hi - lo, st);
+    else if (R == 7) dtb_launch<7, 8>(a, hi - lo, st);
     else if (R == 6) dtb_launch<6, 8>(a, hi - lo, st);
     else dtb_launch<8, 8>(a, hi - lo, st);
     DMG_HIP(hipGetLastError());

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 ROOT = Path(__file__).resolve().parents[1]
 
 
-@pytest.mark.parametrize("rows", ["default", "4", "6", "8"])
+@pytest.mark.parametrize("rows", ["default", "4", "6", "7", "8"])
 def test_blocked_diffusion_bitwise_vs_oracle(rows):
     env = dict(os.environ)
     env.pop("DMG_DIFFUSION_SINGLE", None)
