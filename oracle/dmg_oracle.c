@@ -827,6 +827,14 @@ void orc_temperature(const orc_grid *g, float *T, float *scratch, const float *t
             float den = 4.0f * (dy * dy);                  /* 4*pow(pixelwidth.y,2) */
             for (int x = 0; x < W; x++) {
                 float sx = stx(g, x);
+                if (g_raster_st) {                       /* per fragment, as the shader has it */
+                    st_raster(g, x, y, &sx, &sy);
+                    orc_tex_to_spheric(g, 0.0f, sy, &lon, &phi);
+                    ASR = asr_row(phi, M);
+                    factor = gcos(phi);
+                    orc_pixelsize(g, sy, &dx, &dy);
+                    den = 4.0f * (dy * dy);
+                }
                 float Tc = fetch_nearest(a, W, H, 1, 0, sx, sy);
                 float terr = fetch_nearest(terrain, W, H, 1, 0, sx, sy);
                 float s[9];

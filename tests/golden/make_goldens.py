@@ -235,9 +235,11 @@ def default_size_goldens():
     w = refgl.ocean_divergence(img, d, 100.0)
     p = refgl.ocean_jacobi(img, w, 100)
     s = refgl.ocean_subdiv(img, d, p, 100.0)
+    T = ((synth.lcg_uniform(W * H, 41).reshape(H, W)) * 60).astype(f32)
+    t3 = refgl.temperature(T, (img * 100).astype(f32), 11, 3)
     save("default_1000x500_step", coords=np.array(FULL), circ=f32(CIRC), velocity_scale=f32(3), jacobi_iters=np.int32(100),
          advect=a[::8, ::8].copy(), diffusion50=d[::8, ::8].copy(), divergence=w[::8, ::8].copy(), pressure=p[::8, ::8].copy(),
-         subdiv=s[::8, ::8].copy())
+         subdiv=s[::8, ::8].copy(), temperature_3_from11=t3[::8, ::8].copy())
 
 
 def huge_goldens():
