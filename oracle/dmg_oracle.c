@@ -750,6 +750,12 @@ void orc_blur13_pass(const orc_grid *g, const float *src, float dirx, float diry
         float o1y = k1 * diry, o2y = k2 * diry, o3y = k3 * diry;
         for (int x = 0; x < W; x++) {
             float sx = stx(g, x);
+            if (g_raster_st) {                           /* per fragment, as the shader has it */
+                st_raster(g, x, y, &sx, &sy);
+                orc_tex_to_spheric(g, 0.0f, sy, &lon, &lat);
+                phifactor = gcos(fabsf(lat));
+                o1x = k1 * dirx / phifactor; o2x = k2 * dirx / phifactor; o3x = k3 * dirx / phifactor;
+            }
             float color = 0.0f, px, py;
             color += fetch_linear(src, W, H, 1, 0, sx, sy) * w0;
             orc_offset(g, sx, sy, o1x, o1y, rx, ry, &px, &py);   color += fetch_linear(src, W, H, 1, 0, px, py) * w1;
@@ -883,6 +889,7 @@ void orc_erosion_pass(const orc_grid *g, const float *hgt, const float *flow, co
         orc_pixelsize(g, sy, &psx, &psy);
         for (int x = 0; x < W; x++) {
             float sx = stx(g, x);
+            if (g_raster_st) { st_raster(g, x, y, &sx, &sy); orc_pixelsize(g, sy, &psx, &psy); }
             float h = fetch_nearest(hgt, W, H, 1, 0, sx, sy);
             if (h <= 0) { out[(size_t)y * W + x] = h; continue; }        /* :122-123 */
             float maxslope = 0;
@@ -945,6 +952,7 @@ void orc_flow_direction(const orc_grid *g0, const float *img, const float *sel, 
         orc_pixelsize(g, sy, &psx, &psy);
         for (int x = 0; x < W; x++) {
             float sx = stx(g, x);
+            if (g_raster_st) { st_raster(g, x, y, &sx, &sy); orc_pixelsize(g, sy, &psx, &psy); }
             float *fc = codes + (size_t)y * W + x;
             float a = fetch_nearest(img, W, H, 1, 0, sx, sy);
             *fc = 0.0f;
@@ -1012,6 +1020,7 @@ void orc_flow_mask(const orc_grid *g, const float *img, const float *sel, const 
         float sy = sty(g, y);
         for (int x = 0; x < W; x++) {
             float sx = stx(g, x);
+            if (g_raster_st) st_raster(g, x, y, &sx, &sy);
             float *fc = mask + (size_t)y * W + x;
             *fc = -1.0f;
             if (fetch_nearest(img, W, H, 1, 0, sx, sy) <= 0.0f) continue;
@@ -1094,6 +1103,7 @@ void orc_thermal_erosion(const orc_grid *g, float *h, float *scratch, float *scr
             orc_pixelsize(g, sy, &psx, &psy);
             for (int x = 0; x < W; x++) {
                 float sx = stx(g, x);
+                if (g_raster_st) { st_raster(g, x, y, &sx, &sy); orc_pixelsize(g, sy, &psx, &psy); }
                 float slope = orc_slope(g, img, sx, sy, psx, psy);
                 float hh = fetch_nearest(img, W, H, 1, 0, sx, sy);
                 float fc = 0;
@@ -1117,6 +1127,7 @@ void orc_thermal_erosion(const orc_grid *g, float *h, float *scratch, float *scr
             orc_pixelsize(g, sy, &psx, &psy);
             for (int x = 0; x < W; x++) {
                 float sx = stx(g, x);
+                if (g_raster_st) { st_raster(g, x, y, &sx, &sy); orc_pixelsize(g, sy, &psx, &psy); }
                 float hh = fetch_nearest(img, W, H, 1, 0, sx, sy);
                 float gain = 0;
                 for (int k = 0; k < 8; k++) {
@@ -1160,6 +1171,7 @@ void orc_morph_pass(const orc_grid *g, const float *src, float radius, int use_m
         float factor = 1 / gcos(fabsf(phi));
         for (int x = 0; x < W; x++) {
             float sx = stx(g, x);
+            if (g_raster_st) { st_raster(g, x, y, &sx, &sy); orc_tex_to_spheric(g, 0.0f, sy, &lon, &phi); factor = 1 / gcos(fabsf(phi)); }
             float a = fetch_nearest(src, W, H, 1, 0, sx, sy);
             for (int i = 0; i < 64; i++) {
                 float px, py;

@@ -239,7 +239,21 @@ def default_size_goldens():
     t3 = refgl.temperature(T, (img * 100).astype(f32), 11, 3)
     save("default_1000x500_step", coords=np.array(FULL), circ=f32(CIRC), velocity_scale=f32(3), jacobi_iters=np.int32(100),
          advect=a[::8, ::8].copy(), diffusion50=d[::8, ::8].copy(), divergence=w[::8, ::8].copy(), pressure=p[::8, ::8].copy(),
-         subdiv=s[::8, ::8].copy(), temperature_3_from11=t3[::8, ::8].copy())
+         subdiv=s[::8, ::8].copy(), temperature_3_from11=t3[::8, ::8].copy(), **default_size_tools(W, H))
+
+
+def default_size_tools(W, H):
+    """the other tools at the default size, every 8th row and column"""
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+    from large_inputs import large_inputs
+    I = large_inputs(W, H)
+    up = (np.maximum(I["heights"], 0) / f32(50)).astype(f32)
+    hb = refgl.blur(I["heights"], 0.5)
+    codes, mask = refgl.flow_direction_and_mask(hb)
+    out = dict(blur_r3=refgl.blur(I["terrain"], 3.0), erosion_pass=refgl.erosion_shader(I["heights"], I["flow"], up, 1.0, 1.0),
+               thermal=refgl.thermal_erosion(I["relief"]), erode_r5=refgl.morphological(I["terrain"], 5.5, "min"),
+               flow_codes=codes.astype(f32), flow_mask=mask.astype(f32))
+    return {k: np.ascontiguousarray(v, f32)[::8, ::8].copy() for k, v in out.items()}
 
 
 def huge_goldens():
