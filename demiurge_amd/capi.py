@@ -17,6 +17,7 @@ OK, EINVAL, ENOMEM, EHIP, ENODEVICE, ESTATE = 0, -1, -2, -3, -4, -5
 F_PRESSURE, F_DIVW, F_TERRAIN, F_V = range(4)
 SIDE_SOUTH, SIDE_NORTH = 0, 1
 QUIRK_DIFFUSION_SCALAR_RHS = 1
+QUIRK_LLVMPIPE_RASTER = 2
 PRIVATE_STREAM = 1
 JACOBI_AUTO, JACOBI_SINGLE, JACOBI_BLOCKED = 0, 1, 2
 FULL_GLOBE = (np.float32(-np.pi / 2), np.float32(np.pi / 2), np.float32(-np.pi), np.float32(np.pi))  # Project.h:97

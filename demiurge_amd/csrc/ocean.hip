@@ -357,6 +357,15 @@ int dmg_ocean_jacobi_sweeps(dmg_ocean *o, int n)
     if (o->count > 1 && n > o->ghost)
         return dmg_fail(DMG_EINVAL, "%d sweeps between halo refreshes but only %d ghost rows", n, o->ghost);
     DMG_HIP(hipSetDevice(o->ctx->device));
+    if (o->prm.quirks & DMG_QUIRK_LLVMPIPE_RASTER) {     // opt-in: the software GL path's pixels on any grid size
+        for (int k = 0; k < n; k++) {
+            int rc = ocean_launch_literal(o);
+            if (rc) return rc;
+            o->cur ^= 1;
+            o->n_launches++; o->n_sweeps++;
+        }
+        return DMG_OK;
+    }
     bool blocked = o->prm.jacobi_kernel != DMG_JACOBI_SINGLE && ocean_tb_supported(o);
     if (o->prm.jacobi_kernel == DMG_JACOBI_BLOCKED && !blocked)
         return dmg_fail(DMG_EINVAL, "DMG_JACOBI_BLOCKED needs a full-longitude grid with W %% 8 == 0 and W >= 256");

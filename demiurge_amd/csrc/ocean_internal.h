@@ -80,6 +80,7 @@ int ocean_launch_tb(dmg_ocean *o, int lo, int hi, int n, int part = 0, int zone_
                     hipStream_t stream = nullptr);   // src >= 0: from p[src] into p[src ^ 1] instead of the current pair; stream: instead of the context's
 int ocean_tb_tile_rows(dmg_ocean *o, int lo, int hi);    // output rows per tile row of the shape an 8-sweep launch over [lo, hi) uses; 0 while its tuner is open
 int ocean_launch_diffusion_tb(dmg_ocean *o, int lo, int hi, int n);   // ocean_diffusion_tb.hip: n (1..8) sweeps over local rows [lo, hi)
+int ocean_launch_literal(dmg_ocean *o);          // ocean_jacobi_literal.hip: one per-fragment sweep as llvmpipe evaluates the shader
 bool ocean_tb_supported(const dmg_ocean *o);
 bool ocean_tb_tuning_open(dmg_ocean *o, int lo, int hi);   // the shape tuner of the 8-sweep launch over [lo, hi) has not decided yet
 int ocean_build_rowclass(dmg_ocean *o);

@@ -79,6 +79,11 @@ enum { DMG_JACOBI_AUTO = 0, DMG_JACOBI_SINGLE = 1, DMG_JACOBI_BLOCKED = 2 };
 
 /* the reference's `float bC = texture(v,st).r` adds v.x to BOTH components in velocity diffusion (:687,:693) */
 #define DMG_QUIRK_DIFFUSION_SCALAR_RHS 1
+/* opt-in, Jacobi sweeps of a single band only: evaluate the shader per fragment the way Mesa llvmpipe does, including its
+ * rasteriser's `st` (an ulp of 1.0 off (x+0.5)/W on grids that are not powers of two) and float-weight GL_LINEAR taps --
+ * the software GL path's pixels on e.g. the reference's default 1000x500 canvas.  Identical to the default kernels on
+ * power-of-two grids; slow (not a performance path). */
+#define DMG_QUIRK_LLVMPIPE_RASTER 2
 
 /* field ids for dmg_ocean_halo */
 enum { DMG_F_PRESSURE = 0, DMG_F_DIVW = 1, DMG_F_TERRAIN = 2, DMG_F_V = 3 /* interleaved (vx,vy), 8 B per cell */ };

@@ -295,3 +295,39 @@ def test_blocked_randomised_geometries(dev, oracle):
             got = run_jacobi(capi, ctx, grid, img, b, iters, p0=p0, bands=bands, ghost=ghost, block=min(ghost, iters),
                              kernel=capi.JACOBI_BLOCKED)
             assert np.array_equal(got, ref), ("bands", case, W, H, iters)
+
+
+def test_llvmpipe_raster_quirk(dev, oracle):
+    """DMG_QUIRK_LLVMPIPE_RASTER: the per-fragment kernel with llvmpipe's rasteriser `st` and float-weight taps gives the
+    software GL path's pixels on grids that are not powers of two -- the 96x64 golden (300 sweeps) and the reference's
+    default 1000x500 (vs the oracle in the same mode, itself pinned to llvmpipe there by default_1000x500_step.npz) --
+    and the bits of the default kernels on a power-of-two grid"""
+    capi, ctx = dev
+    from demiurge_amd import synth
+    prm = capi.default_ocean_params()
+    prm.quirks |= capi.QUIRK_LLVMPIPE_RASTER
+    G = load_golden("jacobi_96x64_full")
+    o = capi.Ocean(ctx, capi.make_grid(96, 64, tuple(G["coords"]), float(G["circ"])), params=prm)
+    o.set_terrain(G["img"]); o.set_divw(G["divw"]); o.jacobi(300)
+    assert np.array_equal(o.get(want=("pressure",))["pressure"], G["p300"])
+    o.close()
+    W, H = 1000, 500
+    img, b = synth.terrain(W, H), synth.divw(W, H)
+    o = capi.Ocean(ctx, capi.make_grid(W, H), params=prm)
+    o.set_terrain(img); o.set_divw(b); o.jacobi(50)
+    got = o.get(want=("pressure",))["pressure"]
+    o.close()
+    oracle.set_linear_taps(True); oracle.set_raster_st(True)
+    try:
+        want = oracle.ocean_jacobi(oracle.grid(W, H), img, b, 50)
+    finally:
+        oracle.set_raster_st(False); oracle.set_linear_taps(False)
+    assert np.array_equal(got, want)
+    W, H = 256, 128
+    img, b = synth.terrain(W, H), synth.divw(W, H)
+    outs = []
+    for q in (prm, capi.default_ocean_params()):
+        o = capi.Ocean(ctx, capi.make_grid(W, H), params=q)
+        o.set_terrain(img); o.set_divw(b); o.jacobi(40)
+        outs.append(o.get(want=("pressure",))["pressure"]); o.close()
+    assert np.array_equal(outs[0], outs[1])
