@@ -79,9 +79,19 @@ int dmg_trim(dmg_ctx *c)
     return DMG_OK;
 }
 
+static void ctx_free(dmg_ctx *c);
+
+// A context outlives the handles created on it: destroying it first is allowed and takes effect when the last of them
+// is destroyed (the recorded round-1 abort was a dmg_ocean destroyed after its context).
 void dmg_destroy(dmg_ctx *c)
 {
     if (!c) return;
+    if (c->children.load() > 0) { c->destroy_requested = true; return; }
+    ctx_free(c);
+}
+
+static void ctx_free(dmg_ctx *c)
+{
     (void)hipSetDevice(c->device);
     (void)dmg_trim(c);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -135,6 +145,13 @@ int dmg_band_row0(int H, int band_count, int band_rank)
 
 }  // extern "C"
 
+
+void dmg_ctx_retain(dmg_ctx *ctx) { if (ctx) ctx->children.fetch_add(1); }
+void dmg_ctx_release(dmg_ctx *ctx)
+{
+    if (!ctx) return;
+    if (ctx->children.fetch_sub(1) == 1 && ctx->destroy_requested) ctx_free(ctx);
+}
 
 // ---- scratch pool (see dmg_ctx::scratch_pool) ----
 hipError_t dmg_scratch_alloc(dmg_ctx *ctx, size_t bytes, void **out)

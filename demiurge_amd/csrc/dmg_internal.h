@@ -1,6 +1,7 @@
 // Internal declarations shared by the HIP translation units of libdemiurge_hip.so.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -39,7 +40,13 @@ struct dmg_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int num_cu = 0;
     char name[128] = {0};
+    // handles created on this context (dmg_ocean, dmg_tectonics, dmg_climate, dmg_erosion, dmg_multi) keep it alive:
+    // dmg_destroy with live children only marks it, the last child's destroy releases it (dmg_ctx_release)
+    std::atomic<int> children{0};
+    bool destroy_requested = false;
 };
+void dmg_ctx_retain(dmg_ctx *ctx);
+void dmg_ctx_release(dmg_ctx *ctx);
 
 // scratch memory of a context (dmg_core.hip): exact-size reuse, released by dmg_trim / dmg_destroy
 hipError_t dmg_scratch_alloc(dmg_ctx *ctx, size_t bytes, void **out);

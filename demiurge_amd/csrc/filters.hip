@@ -464,11 +464,18 @@ int dmg_climate_create(dmg_ctx *ctx, const dmg_grid *grid, const float *T, const
     DMG_HIP(hipMemcpyAsync(k->terr.p, terrain, n * 4, hipMemcpyHostToDevice, ctx->stream));
     DMG_HIP(hipStreamSynchronize(ctx->stream));      // the caller's buffers may go away
     k->cur = k->a.f(); k->nxt = k->b.f();
+    dmg_ctx_retain(ctx);
     *out = k.release();
     return DMG_OK;
 }
 
-void dmg_climate_destroy(dmg_climate *k) { delete k; }
+void dmg_climate_destroy(dmg_climate *k)
+{
+    if (!k) return;
+    dmg_ctx *ctx = k->ctx;
+    delete k;                                        // its buffers go back to the context's scratch pool first
+    dmg_ctx_release(ctx);
+}
 
 int dmg_climate_steps(dmg_climate *k, int first_step, int n_steps)
 {
@@ -610,11 +617,18 @@ int dmg_erosion_create(dmg_ctx *ctx, const dmg_grid *grid, const float *h, int N
     DMG_HIP(hipGetLastError());
     DMG_HIP(hipStreamSynchronize(ctx->stream));      // the caller's buffer may go away
     e->cur = e->height.f(); e->nxt = e->next.f();
+    dmg_ctx_retain(ctx);
     *out = e.release();
     return DMG_OK;
 }
 
-void dmg_erosion_destroy(dmg_erosion *e) { delete e; }
+void dmg_erosion_destroy(dmg_erosion *e)
+{
+    if (!e) return;
+    dmg_ctx *ctx = e->ctx;
+    delete e;
+    dmg_ctx_release(ctx);
+}
 
 int dmg_erosion_rounds(dmg_erosion *e, int n_rounds)
 {

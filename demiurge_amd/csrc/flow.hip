@@ -302,7 +302,7 @@ __global__ void k_flow_level_starts(const unsigned *__restrict__ sorted_depth, s
 
 __global__ void k_flow_level(flow_canvas fc, const int *__restrict__ order, int first, int count,
                              const unsigned short *__restrict__ mask, const int *__restrict__ conn_from,
-                             const float *__restrict__ own_row, float *__restrict__ acc, float *__restrict__ out, float exponent)
+                             const float *__restrict__ own_row, float *__restrict__ acc)
 {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= count) return;
@@ -322,7 +322,16 @@ __global__ void k_flow_level(flow_canvas fc, const int *__restrict__ order, int 
     int from = conn_from[p];
     if (from >= 0) sum = __fadd_rn(sum, acc[from]);     // sum += rec(connections[p].from) (:617-619)
     acc[p] = sum;
-    out[p] = powf(sum, exponent);                       // lakeID[p] = pow(sum, exponent) (:620)
+}
+
+// lakeID[p] = pow(sum, exponent) (:620) for every reached cell, one launch after the level sums.  The reference's
+// unqualified pow(float, float) is the C double function under g++ (its headers pull <cmath> only), rounded to float
+// by the assignment: double pow, one rounding.
+__global__ void k_flow_pow(const int *__restrict__ gdepth, const float *__restrict__ acc, float *__restrict__ out, float exponent, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || gdepth[i] < 0) return;
+    out[i] = (float)pow((double)acc[i], (double)exponent);
 }
 
 // lake drawing (:660-699): cells of a reached lake's catchment at or below the lake's water level become 0
@@ -392,7 +401,7 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
         dmg_row_pixelsize(gm, y, &dxr[y], &dyr[y]);
         float fy = (float)y / H;
         float geoy = (fy * (grid.coords[1] - grid.coords[0]) + grid.coords[0]);
-        own[y] = (float)(pwy * pwx * cosf(geoy) * 1e-5);
+        own[y] = (float)(pwy * pwx * cos((double)geoy) * 1e-5);      // unqualified cos(float) = the C double cos there
     }
     dev_buf ddx, ddy, down, hb, tmp, code, mask, par[2], dst[2], label, changed, count;
     int rc;
@@ -539,18 +548,21 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
     // The growth hops all over the map, so each visit of a lake is a chain of cache misses (its span, its first unread
     // entry, the flag of that entry's lake).  The lake a candidate would place is known when the candidate is pushed:
     // its span is prefetched then, and its first entry when the candidate is popped, one lake's worth of work ahead.
-    auto push_next = [&](int lake) {
+    const bool mouth_filter = !(lakes & DMG_FLOW_FIX_MOUTH_FILTER);
+    auto push_next = [&](int lake, bool initial = false) {
         Span &sp = span[lake];
         while (sp.cur < sp.end) {
             int i = sp.cur++;
             if (placed[ent[i].from]) continue;
+            // `if (Nthbit(c.from,10)) continue;` (:552): bit 10 of the neighbouring lake's cell index, first stage only
+            if (initial && mouth_filter && (sink_cell[ent[i].from] & 512)) continue;
             candidates.push(Cand{ ent[i].h, ent[i].from, ent[i].s, i });
             __builtin_prefetch(&span[ent[i].from]);
             break;
         }
     };
     std::vector<int> assigned;                                         // connection events in order: connections[s] = entry
-    for (int lake : mouths) push_next(lake);
+    for (int lake : mouths) push_next(lake, true);
     while (!candidates.empty()) {
         const Cand top = candidates.top();
         candidates.pop();
@@ -653,10 +665,11 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
         int cnt = start[l + 1] - start[l];
         if (!cnt) continue;
         hipLaunchKernelGGL(k_flow_level, dim3((cnt + 255) / 256), dim3(256), 0, st, fc, order.i(), start[l], cnt,
-                           (const unsigned short *)mask.p, dcf.i(), down.f(), acc.f(), d_flow, exponent);
+                           (const unsigned short *)mask.p, dcf.i(), down.f(), acc.f());
     }
+    hipLaunchKernelGGL(k_flow_pow, dim3(nb), dim3(256), 0, st, gdepth.i(), acc.f(), d_flow, exponent, N);
     DMG_HIP(hipGetLastError());
-    if (lakes && !off_idx.empty()) {
+    if ((lakes & DMG_FLOW_LAKES) && !off_idx.empty()) {
         dev_buf dlevel, dlv;
         DMG_ALLOC(dlevel, N * 4);
         DMG_HIP(hipMemsetAsync(dlevel.p, 0xFF, N * 4, st));                          // NaN: compares false

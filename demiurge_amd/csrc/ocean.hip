@@ -250,6 +250,7 @@ int dmg_ocean_create(dmg_ctx *ctx, const dmg_grid *grid, const dmg_ocean_params 
     dmg_ocean *o = new (std::nothrow) dmg_ocean();
     if (!o) return dmg_fail(DMG_ENOMEM, "out of host memory");
     o->ctx = ctx;
+    dmg_ctx_retain(ctx);
     o->grid = *grid;
     o->topo = topo;
     if (params) o->prm = *params; else dmg_ocean_params_default(&o->prm);
@@ -296,7 +297,9 @@ void dmg_ocean_destroy(dmg_ocean *o)
                      (void *)o->v[0], (void *)o->v[1], (void *)o->rowtab, (void *)o->oob_flag, (void *)o->rowclass })
         if (p) (void)hipFree(p);
     ocean_tb_free_lists(o);
+    dmg_ctx *ctx = o->ctx;
     delete o;
+    dmg_ctx_release(ctx);
 }
 
 int dmg_ocean_set_terrain(dmg_ocean *o, const float *img)

@@ -154,8 +154,8 @@ __global__ __launch_bounds__(NW * 64, (R <= 8 ? 4 : 2)) void k_diffusion_tb(dtb_
 
         // rows closer than s+1 to the top/bottom edge of the extended tile are stale after this sweep whatever we do
         unsigned skip = 0;
-        if (wave == 0) skip |= (2u << s) - 1u;                                  // rows r <= s
-        if (wave == NW - 1) skip |= ~((1u << (R - 1 - s)) - 1u);                // rows r >= R-1-s
+        if (wave == 0) skip |= (2u << s) - 1u;                                  // rows r <= s (s <= 7)
+        if (wave == NW - 1) { const int keep = R - 1 - s; skip |= keep <= 0 ? ~0u : ~((1u << keep) - 1u); }   // rows r >= R-1-s
 
 #pragma unroll
         for (int r = 0; r < R; r++) {

@@ -216,8 +216,8 @@ __global__ __launch_bounds__(NW * 64, (R <= 10 ? 4 : (R <= 12 ? 3 : 2))) void k_
         // do (staleness creeps in one row per sweep) and nothing reads them for a valid output: skip them
         // ... and rows that are land everywhere are and stay exactly 0: one wave-uniform skip mask per sweep
         unsigned skip = land_rows;
-        if (wave == 0) skip |= (2u << s) - 1u;                                  // rows r <= s
-        if (wave == NW - 1) skip |= ~((1u << (R - 1 - s)) - 1u);                // rows r >= R-1-s
+        if (wave == 0) skip |= (2u << s) - 1u;                                  // rows r <= s (s <= 7)
+        if (wave == NW - 1) { const int keep = R - 1 - s; skip |= keep <= 0 ? ~0u : ~((1u << keep) - 1u); }   // rows r >= R-1-s
 
         float4 prev = south;                        // pre-sweep values of row r-1
 #pragma unroll

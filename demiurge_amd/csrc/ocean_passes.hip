@@ -1,9 +1,9 @@
 // The non-Jacobi passes of OceanCurrents::run (reference src/filter/OceanCurrents.cpp:155-209):
 // advect (:235-360), diffusion (:625-708), divergence (:363-435), subDiv (:511-622) and the outer step.
 // One thread per cell, coalesced row-major access; velocity is interleaved (vx,vy) like the reference's RG32F.
-// Arithmetic follows the GLSL statement order with IEEE ops and host-computed per-row tables, so divergence and
-// diffusion match the oracle bit for bit; advect/subDiv call device libm (sin/cos/atan2/asin/pow) and match the
-// oracle to a few ulp.
+// Arithmetic follows the GLSL statement order with IEEE ops and host-computed per-row tables; GLSL transcendentals
+// (advect, subDiv) go through glsl_math.h's restatement of Mesa/gallivm's forms, never through device libm, so every
+// pass matches the oracle -- and the reference's llvmpipe output on power-of-two grids -- bit for bit.
 #include "ocean_internal.h"
 
 struct pass_args {
@@ -447,15 +447,15 @@ int dmg_ocean_advect(dmg_ocean *o)
     if (o->count > 1) DMG_HIP(hipMemsetAsync(o->oob_flag, 0, sizeof(int), o->ctx->stream));
     rc = launch_rows(o, k_advect, a, o->gs, o->gs + (o->y1 - o->y0), k04);
     if (rc) return rc;
-    o->vcur ^= 1;                                          // v->swap(v_scratch) (:359)
     if (o->count > 1) {                                    // did a departure point leave the stored rows?
         int flag = 0;
         DMG_HIP(hipMemcpyAsync(&flag, o->oob_flag, sizeof(int), hipMemcpyDeviceToHost, o->ctx->stream));
         DMG_HIP(hipStreamSynchronize(o->ctx->stream));
-        if (flag)
+        if (flag)                                          // the result sits in the scratch buffer: v itself is untouched
             return dmg_fail(DMG_EINVAL, "advect: a departure point lies more than %d rows outside the band; create the "
                                         "ocean with ghost >= dmg_ocean_advect_reach()", o->ghost);
     }
+    o->vcur ^= 1;                                          // v->swap(v_scratch) (:359)
     return DMG_OK;
 }
 
@@ -474,6 +474,7 @@ int dmg_ocean_step(dmg_ocean *o, int n_outer)
         if ((rc = dmg_ocean_divergence(o))) return rc;                              // :162
         if ((rc = dmg_ocean_jacobi(o, o->prm.jacobi_iters, 1))) return rc;          // :166
         if ((rc = dmg_ocean_subdiv(o))) return rc;                                  // :168
+        o->n_outer++;
         // :170 divergence(p, divw_showcase) is a display-only field; :175-205 exports are dmg_ocean_get
     }
     return DMG_OK;

@@ -336,6 +336,7 @@ int dmg_tectonics_create(dmg_ctx *ctx, const dmg_grid *grid, const float *terrai
     DMG_CHECK_ARG((size_t)grid->W * grid->W <= ((size_t)1 << 31));
     dmg_tectonics *t = new dmg_tectonics;
     t->ctx = ctx;
+    dmg_ctx_retain(ctx);
     t->grid = *grid;
     t->cv = make_canvas(*grid, topo);
     t->S = grid->W;
@@ -380,6 +381,8 @@ int dmg_tectonics_create(dmg_ctx *ctx, const dmg_grid *grid, const float *terrai
 void dmg_tectonics_destroy(dmg_tectonics *t)
 {
     if (!t) return;
+    (void)hipSetDevice(t->ctx->device);
+    (void)hipStreamSynchronize(t->ctx->stream);
     for (int k = 0; k < 2; k++) if (t->map[k]) (void)hipFree(t->map[k]);
     for (int k = 0; k < TECT_MAX_PLATES; k++) if (t->plate[k]) (void)hipFree(t->plate[k]);
     if (t->cbuf) (void)hipFree(t->cbuf);
@@ -387,7 +390,9 @@ void dmg_tectonics_destroy(dmg_tectonics *t)
     if (t->ring) (void)hipFree(t->ring);
     if (t->active) (void)hipFree(t->active);
     if (t->count) (void)hipFree(t->count);
+    dmg_ctx *ctx = t->ctx;
     delete t;
+    dmg_ctx_release(ctx);
 }
 
 int dmg_tectonics_update_rotation(dmg_tectonics *t, int plate, float theta, const float axis[3])

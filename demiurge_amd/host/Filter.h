@@ -85,3 +85,10 @@ private:
     bool pending = false;
     std::thread worker;
 };
+
+// Texture::downloadDataRAW hands over exactly width*height floats (reference src/Texture.cpp:56-67); a layer vector of
+// another size would make the C ABI read past its end.
+inline bool layer_matches(const std::vector<float> &layer, int W, int H)
+{
+    return W > 0 && H > 0 && layer.size() == (size_t)W * (size_t)H;
+}

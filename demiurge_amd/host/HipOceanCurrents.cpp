@@ -22,6 +22,7 @@ void HipOceanCurrents::run()
         if (ctx) dmg_destroy(ctx);
         setProgress({ true, 1.0f });
     };
+    if (!layer_matches(img, g.W, g.H)) { error_ = "terrain layer does not hold width*height texels"; setProgress({ true, 1.0f }); return; }
     if (dmg_create(0, nullptr, DMG_PRIVATE_STREAM, &ctx)) return fail("dmg_create");
     dmg_ocean_params prm;
     dmg_ocean_params_default(&prm);

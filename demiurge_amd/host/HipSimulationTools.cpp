@@ -26,6 +26,7 @@ void HipErosion::run()
         if (ctx) dmg_destroy(ctx);
         setProgress({ true, 1.0f });
     };
+    if (!layer_matches(h, g.W, g.H)) { error_ = "terrain layer does not hold width*height texels"; setProgress({ true, 1.0f }); return; }
     if (dmg_create(0, nullptr, DMG_PRIVATE_STREAM, &ctx)) return fail("dmg_create");
     if (dmg_erosion_create(ctx, &g, h.data(), N_, exponent_, slope_exponent_, factor_, dolakes_ > 0 ? 1 : 0, &e)) return fail("dmg_erosion_create");
     for (int i = 0; i < rounds_; i++) {                                                  // :93
@@ -54,7 +55,7 @@ void HipTemperature::run()
         if (ctx) dmg_destroy(ctx);
         setProgress({ true, 1.0f });
     };
-    if (heights.size() != T.size()) { error_ = "scratch1 (terrain heights) has the wrong size"; setProgress({ true, 1.0f }); return; }
+    if (!layer_matches(T, g.W, g.H) || heights.size() != T.size()) { error_ = "terrain / scratch1 layers do not hold width*height texels"; setProgress({ true, 1.0f }); return; }
     if (dmg_create(0, nullptr, DMG_PRIVATE_STREAM, &ctx)) return fail("dmg_create");
     if (dmg_climate_create(ctx, &g, T.data(), heights.data(), &k)) return fail("dmg_climate_create");
     int i = 0;
@@ -77,6 +78,7 @@ void HipFlow::run()
     std::vector<float> h;
     dmg_grid g{};
     dispatchGPU([&](Project *p) { h = p->terrain; g = grid_of(p); });
+    if (!layer_matches(h, g.W, g.H)) { error_ = "terrain layer does not hold width*height texels"; setProgress({ true, 1.0f }); return; }
     dmg_ctx *ctx = nullptr;
     if (dmg_create(0, nullptr, DMG_PRIVATE_STREAM, &ctx)) { error_ = std::string("dmg_create: ") + dmg_last_error(); setProgress({ true, 1.0f }); return; }
     std::vector<float> flow(h.size());
@@ -91,6 +93,7 @@ void HipFlow::run()
 std::pair<bool, float> HipOneShot::step(Project *p)
 {
     dmg_grid g = grid_of(p);
+    if (!layer_matches(p->terrain, g.W, g.H)) { error_ = "terrain layer does not hold width*height texels"; return { true, 1.0f }; }
     dmg_ctx *ctx = nullptr;
     if (dmg_create(0, nullptr, DMG_PRIVATE_STREAM, &ctx)) { error_ = std::string("dmg_create: ") + dmg_last_error(); return { true, 1.0f }; }
     if (apply(ctx, &g, p->terrain.data())) error_ = dmg_last_error();

@@ -21,6 +21,7 @@ void HipTectonics::run()
         if (ctx) dmg_destroy(ctx);
         setProgress({ true, 1.0f });
     };
+    if (!layer_matches(img, g.W, g.H)) { error_ = "terrain layer does not hold width*height texels"; setProgress({ true, 1.0f }); return; }
     if (dmg_create(0, nullptr, DMG_PRIVATE_STREAM, &ctx)) return fail("dmg_create");
     if (dmg_tectonics_create(ctx, &g, img.data(), &t)) return fail("dmg_tectonics_create");     // Tectonics::Tectonics :15-154
     std::vector<float> terrain((size_t)g.W * g.H);
@@ -42,6 +43,7 @@ std::pair<bool, float> HipGradientNoise::step(Project *p)
     g.W = p->getWidth(); g.H = p->getHeight();
     for (int i = 0; i < 4; i++) g.coords[i] = p->coords[i];
     g.circumference = p->circumference;
+    if (!layer_matches(p->terrain, g.W, g.H)) { error_ = "terrain layer does not hold width*height texels"; return { true, 1.0f }; }
     dmg_ctx *ctx = nullptr;
     if (dmg_create(0, nullptr, DMG_PRIVATE_STREAM, &ctx)) { error_ = std::string("dmg_create: ") + dmg_last_error(); return { true, 1.0f }; }
     // terrain := blend_mode(terrain, noise, selection); no selection layer in this mirror = all ones (src/Project.cpp:102-104)

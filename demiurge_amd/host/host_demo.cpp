@@ -83,8 +83,41 @@ static int other_tools(int argc, char **argv)
     return 0;
 }
 
+// host_demo lifetime: handles outlive their context.  The recorded round-1 abort was a dmg_ocean destroyed after
+// dmg_destroy(ctx); the context now stays alive until its last handle goes (include/demiurge_hip.h, dmg_destroy).
+static int lifetime_check()
+{
+    const int W = 256, H = 128;
+    dmg_grid g = { W, H, { -1.57079632679f, 1.57079632679f, -3.14159265359f, 3.14159265359f }, 42000.0f };
+    std::vector<float> terrain((size_t)W * H), field((size_t)W * H, 1.0f);
+    for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) terrain[(size_t)y * W + x] = ((x / 32 + y / 32) % 3 == 0) ? 5.0f : -5.0f;
+    dmg_ctx *ctx = nullptr;
+    if (dmg_create(0, nullptr, DMG_PRIVATE_STREAM, &ctx)) { fprintf(stderr, "dmg_create: %s\n", dmg_last_error()); return 1; }
+    dmg_ocean *oc = nullptr; dmg_tectonics *te = nullptr; dmg_climate *cl = nullptr; dmg_erosion *er = nullptr;
+    dmg_ocean_params prm; dmg_ocean_params_default(&prm);
+    if (dmg_ocean_create(ctx, &g, &prm, 0, 1, 1, &oc) || dmg_tectonics_create(ctx, &g, terrain.data(), &te) ||
+        dmg_climate_create(ctx, &g, field.data(), terrain.data(), &cl) ||
+        dmg_erosion_create(ctx, &g, terrain.data(), 50, 0.5f, 1.0f, 1.0f, 0, &er)) { fprintf(stderr, "create: %s\n", dmg_last_error()); return 1; }
+    dmg_destroy(ctx);                                    // wrong order on purpose: the handles keep the context alive
+    int rc = dmg_ocean_set_terrain(oc, terrain.data());
+    if (!rc) rc = dmg_ocean_set_divw(oc, field.data());
+    if (!rc) rc = dmg_ocean_jacobi(oc, 16, 1);
+    if (!rc) rc = dmg_ocean_get(oc, nullptr, nullptr, field.data(), nullptr);
+    if (!rc) rc = dmg_tectonics_step(te, 1);
+    if (!rc) rc = dmg_climate_steps(cl, 0, 2);
+    if (!rc) rc = dmg_erosion_rounds(er, 1);
+    if (rc) { fprintf(stderr, "work after dmg_destroy failed: %s\n", dmg_last_error()); return 1; }
+    dmg_climate_destroy(cl);
+    dmg_erosion_destroy(er);
+    dmg_tectonics_destroy(te);
+    dmg_ocean_destroy(oc);                               // the last handle releases the context
+    printf("lifetime ok\n");
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
+    if (argc == 2 && std::string(argv[1]) == "lifetime") return lifetime_check();
     if (argc >= 2 && !(argv[1][0] >= '0' && argv[1][0] <= '9')) return other_tools(argc, argv);
     if (argc != 8) { fprintf(stderr, "usage: host_demo W H terrain.f32 n_outer jacobi_iters diffusion_iters out_prefix\n"); return 2; }
     Project p;

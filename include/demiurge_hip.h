@@ -98,6 +98,9 @@ const char *dmg_last_error(void);
  * with DMG_PRIVATE_STREAM in `flags`, a new non-blocking stream owned by the context (`stream` ignored). */
 #define DMG_PRIVATE_STREAM 1
 int dmg_create(int device_id, void *stream, int flags, dmg_ctx **out);
+/* Handles created on a context (dmg_ocean, dmg_tectonics, dmg_climate, dmg_erosion, dmg_multi) keep it alive:
+ * dmg_destroy while such handles exist only marks the context, and the last handle's destroy releases it.  Destroying
+ * in either order is therefore safe; a caller-provided stream must outlive the last handle. */
 void dmg_destroy(dmg_ctx *ctx);
 int dmg_sync(dmg_ctx *ctx);
 /* Temporaries of finished calls stay with the context for reuse (a 1000-round erosion run would otherwise spend a
@@ -138,7 +141,11 @@ int dmg_ocean_set_pressure(dmg_ocean *o, const float *pressure);
 
 /* OceanCurrents::jacobi (:437-509) on one GPU (band_count == 1): pressure := 0 (:495-497) when
  * zero_first != 0, then `iters` sweeps of the Jacobi shader (:450-481) with the ping-pong of :500-508.
- * Asynchronous on the context's stream. */
+ * Asynchronous on the context's stream.
+ * Arithmetic: the shader's three divisions by row constants are evaluated through the constant's correctly rounded
+ * reciprocal with one FMA correction, which IS the IEEE quotient for 0 and for 2^-100 <= |numerator| <= 2^100.
+ * Outside that window (|x| < 7.9e-31, where llvmpipe itself flushes to zero below 1.2e-38, or a diverged solve) the
+ * last bit may differ, and an infinite iterate becomes NaN one sweep earlier than with a true division. */
 int dmg_ocean_jacobi(dmg_ocean *o, int iters, int zero_first);
 /* Band form: `n` (<= ghost) sweeps assuming the pressure ghost rows are current; afterwards the owned
  * rows are n sweeps ahead and the ghost rows are stale until the host refreshes them via dmg_ocean_halo. */
@@ -209,7 +216,7 @@ int dmg_temperature_steps(dmg_ctx *ctx, const dmg_grid *grid, float *T_inout, co
                           int first_step, int n_steps);
 /* The same with the field resident on the device between calls: Temperature::run (:47-162) steps the field ten times
  * per UI frame (:140) for as long as the tool runs, so a frame costs its kernels, not two PCIe crossings.
- * T and terrain are copied at creation.  Destroy the handle before its context. */
+ * T and terrain are copied at creation. */
 typedef struct dmg_climate dmg_climate;
 int dmg_climate_create(dmg_ctx *ctx, const dmg_grid *grid, const float *T, const float *terrain, dmg_climate **out);
 void dmg_climate_destroy(dmg_climate *k);
@@ -222,7 +229,12 @@ int dmg_erosion_pass(dmg_ctx *ctx, const dmg_grid *grid, float *h_inout, const f
 /* FlowFilter::run (src/filter/FlowFilter.cpp:719-786): pre-blur, stochastic-D8 directions, catchments, lake graph,
  * upstream area.  flow_out[i] = pow(area, exponent), -1 where no river mouth is reached (what the reference uploads
  * into the terrain texture, :714-716).  sel = selection mask or NULL (all ones, src/Project.cpp:102-104).
- * lakes != 0 = FlowFilter's lakeflag (:660-699): cells at or below their lake's water level are set to 0. */
+ * lakes = bit set: DMG_FLOW_LAKES = FlowFilter's lakeflag (:660-699), cells at or below their lake's water level are
+ * set to 0; DMG_FLOW_FIX_MOUTH_FILTER = do NOT replicate `if (Nthbit(c.from,10)) continue;` (:552), which tests bit 10
+ * of the neighbouring lake's cell index and so drops about half of a river-mouth lake's first candidates.
+ * Host arithmetic follows the reference's overload resolution: area = double cos, flow = double pow, rounded once. */
+#define DMG_FLOW_LAKES 1
+#define DMG_FLOW_FIX_MOUTH_FILTER 2
 int dmg_flow_accumulate(dmg_ctx *ctx, const dmg_grid *grid, const float *h, const float *sel_or_null, float preblur,
                         float exponent, int lakes, float *flow_out);
 /* The two GLSL passes of FlowFilter::findMagicNumbers (:104-320) alone, on h pre-blurred by `preblur` (0 = none):
@@ -238,7 +250,7 @@ int dmg_erosion_run(dmg_ctx *ctx, const dmg_grid *grid, float *h_inout, int N, i
                     float slope_exponent, float factor);
 /* The same round by round, heights resident on the device (the editor shows the terrain after every round and reports
  * progress, cpufilter.cpp:93-104).  `lakes` = the menu's toggle handed to FlowFilter (:95, dolakes > 0).
- * dmg_erosion_get returns the scaled heights of the current round.  Destroy the handle before its context. */
+ * dmg_erosion_get returns the scaled heights of the current round. */
 typedef struct dmg_erosion dmg_erosion;
 int dmg_erosion_create(dmg_ctx *ctx, const dmg_grid *grid, const float *h, int N, float exponent, float slope_exponent,
                        float factor, int lakes, dmg_erosion **out);

@@ -9,9 +9,15 @@
 //   * the candidate set of solvingConnections has the same comparator (:534);
 //   * `lakes` is filled in thread-completion order (:353-355) and iterated in that order.
 // Here every such choice uses the canonical total order (height, from, tolocation) and lakes are visited in
-// ascending cell index; the HIP backend implements the same rule.  Two reference bugs are NOT replicated:
-// `Nthbit(c.from,10)` tests a cell index instead of its data word (:552), and the float-keyed pass map (:449)
-// aliases lake ids above 2^24.
+// ascending cell index; the HIP backend implements the same rule.
+// Replicated literally (flag `fix_mouth_filter` = 0, the default): `if (Nthbit(c.from,10)) continue;` (:552) tests bit 10
+// of the neighbouring lake's CELL INDEX, not of its data word, so a river-mouth lake's first candidate skips (and
+// loses) every pass whose `from` sink has bit 512 set in its index.  Not replicated: the float-keyed pass map (:449)
+// aliases lake ids above 2^24 (grids beyond 16.7 M cells only) in DFS order.
+// Host arithmetic: with the reference's includes (<cmath> through glm and the std headers, never <math.h>) the
+// unqualified `cos(geoy)` (:613) and `pow(sum,exponent)` (:620) resolve to the C `double` functions under g++
+// (checked here with the same header set: sizeof(pow(float,float)) == 8), so both are evaluated in double and rounded
+// to float once.
 #include "dmg_oracle.h"
 #include <cmath>
 #include <cstring>
@@ -49,7 +55,7 @@ inline int neighbours(const Topo &t, int pos, int dat, int out[8])
 }  // namespace
 
 static void flow_accumulate(const orc_grid *g, const float *h, const float *sel_in, float preblur, float exponent,
-                            int lakeflag, float *flow, float *codes_out, float *mask_out, int *label_out)
+                            int lakeflag, float *flow, float *codes_out, float *mask_out, int *label_out, int fix_mouth_filter = 0)
 {
     const int W = g->W, H = g->H;
     const size_t N = (size_t)W * H;
@@ -123,12 +129,13 @@ static void flow_accumulate(const orc_grid *g, const float *h, const float *sel_
     std::set<Pass, PassLess> candidates;
     std::set<int> placed;
     std::unordered_map<int, Pass> connections;             // tolocation -> pass (:588)
-    auto push_next = [&](int lake) {
+    auto push_next = [&](int lake, bool initial = false) {
         auto &set = passes[lake];
         while (!set.empty()) {
             Pass c = *set.begin();
             set.erase(set.begin());
             if (placed.count(c.from)) continue;
+            if (initial && !fix_mouth_filter && nthbit(c.from, 10)) continue;     // :552, bit 10 of a cell index
             candidates.insert(c);
             break;
         }
@@ -138,7 +145,7 @@ static void flow_accumulate(const orc_grid *g, const float *h, const float *sel_
         placed.insert(lake);
     }
     for (int lake : lakes)
-        if (nthbit((int)data[lake], 10)) push_next(lake);
+        if (nthbit((int)data[lake], 10)) push_next(lake, true);
     while (!candidates.empty()) {
         Pass p = *candidates.begin();
         candidates.erase(candidates.begin());
@@ -157,7 +164,7 @@ static void flow_accumulate(const orc_grid *g, const float *h, const float *sel_
     auto own = [&](int p) {
         float y = (float)(p / W) / H;
         float geoy = (y * (g->coords[1] - g->coords[0]) + g->coords[0]);
-        return (float)(pixelwidthy * pixelwidthx * std::cos(geoy) * 1e-5);
+        return (float)(pixelwidthy * pixelwidthx * std::cos((double)geoy) * 1e-5);          // double cos, see the header
     };
     struct Frame { int p; int child; float sum; int kids[9]; int nk; };
     std::vector<Frame> st;
@@ -177,7 +184,7 @@ static void flow_accumulate(const orc_grid *g, const float *h, const float *sel_
             Frame &f = st.back();
             if (returning) { f.sum += ret; returning = false; }
             if (f.child < f.nk) { int c = f.kids[f.child++]; open(c); continue; }
-            out[f.p] = std::pow(f.sum, exponent);          // lakeID[p] = pow(sum, exponent) (:620), float overload
+            out[f.p] = (float)std::pow((double)f.sum, (double)exponent);   // lakeID[p] = pow(sum, exponent) (:620): C double pow
             ret = f.sum; returning = true;
             st.pop_back();
         }
@@ -215,6 +222,11 @@ extern "C" void orc_flow_accumulate(const orc_grid *g, const float *h, const flo
                                     float *flow, float *codes, float *mask, int *label)
 {
     flow_accumulate(g, h, sel, preblur, exponent, 0, flow, codes, mask, label);
+}
+extern "C" void orc_flow_accumulate_flags(const orc_grid *g, const float *h, const float *sel, float preblur, float exponent,
+                                          int lakeflag, int fix_mouth_filter, float *flow)
+{
+    flow_accumulate(g, h, sel, preblur, exponent, lakeflag, flow, nullptr, nullptr, nullptr, fix_mouth_filter);
 }
 extern "C" void orc_flow_accumulate_lakes(const orc_grid *g, const float *h, const float *sel, float preblur, float exponent,
                                           float *flow)

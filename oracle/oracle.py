@@ -63,6 +63,7 @@ def lib():
         L.orc_lake_adjacency.argtypes = [G, P, P]
         L.orc_flow_accumulate.argtypes = [G, P, P, ctypes.c_float, ctypes.c_float, P, P, P, P]
         L.orc_flow_accumulate_lakes.argtypes = [G, P, P, ctypes.c_float, ctypes.c_float, P]
+        L.orc_flow_accumulate_flags.argtypes = [G, P, P, ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_int, P]
         _lib = L
     return _lib
 
@@ -230,6 +231,15 @@ def flow_accumulate_lakes(g, h, preblur=0.5, exponent=1.0, sel=None):
     sel = None if sel is None else _f32(sel)
     flow = np.empty_like(h)
     lib().orc_flow_accumulate_lakes(ctypes.byref(g), _ptr(h), None if sel is None else _ptr(sel), preblur, exponent, _ptr(flow))
+    return flow
+
+
+def flow_accumulate_flags(g, h, preblur=0.5, exponent=1.0, sel=None, lakes=0, fix_mouth_filter=0):
+    h = _f32(h)
+    sel = None if sel is None else _f32(sel)
+    flow = np.empty_like(h)
+    lib().orc_flow_accumulate_flags(ctypes.byref(g), _ptr(h), None if sel is None else _ptr(sel), preblur, exponent,
+                                    lakes, fix_mouth_filter, _ptr(flow))
     return flow
 
 

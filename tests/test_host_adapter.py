@@ -113,3 +113,12 @@ def test_remaining_tool_adapters(tmp_path):
     assert np.array_equal(demo("morphgrad", W, H, t, 4.0, tmp_path / "mg"), ctx.morphological_gradient(g, h, 4.0))
     assert np.array_equal(demo("thermal", W, H, t, tmp_path / "th"), ctx.thermal_erosion(g, h))
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_handles_outlive_their_context():
+    """C side of the round-1 core dump: dmg_destroy(ctx) before its ocean / tectonics / climate / erosion handles.
+    The context is reference-counted by its handles; work after dmg_destroy still runs, teardown is clean."""
+    build()
+    r = subprocess.run([str(HOST / "host_demo"), "lifetime"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "lifetime ok" in r.stdout, (r.returncode, r.stdout, r.stderr)
