@@ -357,6 +357,7 @@ static const dmg_ocean::tile_list *tb_live_tiles(dmg_ocean *o, int lo, int hi, i
 // tile shapes built into the library: R rows per thread x NW waves per workgroup.  The default is chosen from
 // measurements; DMG_TB_SHAPE=<R>x<NW> overrides it for experiments.
 struct tb_shape { int R, NW; };
+#define TB_NCAND 5
 static tb_shape tb_forced_shape()
 {
     static const tb_shape forced = [] {
@@ -446,10 +447,14 @@ int ocean_launch_tb(dmg_ocean *o, int lo, int hi, int n, int part, int zone_lo, 
     tb_shape sh = tb_forced_shape();
     dmg_ocean::tb_tune *tune = nullptr, *timed = nullptr;
     int cand = -1;
-    static const tb_shape cands[3] = { { 8, 8 }, { 6, 8 }, { 4, 8 } };
+    // candidates: three tile shapes of the workgroup kernel (k_jacobi_tb8) and the streaming kernel (k_jacobi_stream,
+    // ocean_jacobi_stream.hip) with two unit heights.  R < 0 = streaming with -R rows per unit.
+    static const tb_shape cands[TB_NCAND] = { { 8, 8 }, { 6, 8 }, { 4, 8 }, { -96, 0 }, { -32, 0 } };
+    const bool stream_ok = n == TB_T && ocean_stream_enabled();
     if (!sh.R) {
-        sh = tb_shape{ 8, 8 };
         const int tiles88 = ((a.W + TB_OW - 1) / TB_OW) * ((hi - lo + 47) / 48);
+        // thousands of tiles: the chip is full either way and the streaming kernel does the least work
+        sh = stream_ok ? tb_shape{ -1000, 0 } : tb_shape{ 8, 8 };   // -1000: the streaming kernel's default unit height
         if (tiles88 <= 4096 && n == TB_T && a.rowclass) {
             tune = &o->tb_tuning[std::make_pair(lo, hi)];
             if (tune->chosen < 0 && !part) {
@@ -463,11 +468,12 @@ int ocean_launch_tb(dmg_ocean *o, int lo, int hi, int n, int part, int zone_lo, 
                     if (ms < tune->best_ms[tune->pending]) tune->best_ms[tune->pending] = ms;
                     tune->pending = -1;
                 }
+                const int ncand = stream_ok ? TB_NCAND : 3;
                 cand = 0;
-                while (cand < 3 && tune->trials[cand] >= 2) cand++;
-                if (cand == 3) {
+                while (cand < ncand && tune->trials[cand] >= 2) cand++;
+                if (cand == ncand) {
                     tune->chosen = 0;
-                    for (int c = 1; c < 3; c++) if (tune->best_ms[c] < tune->best_ms[tune->chosen]) tune->chosen = c;
+                    for (int c = 1; c < ncand; c++) if (tune->best_ms[c] < tune->best_ms[tune->chosen]) tune->chosen = c;
                     cand = -1;
                 } else { timed = tune; tune->pending = cand; }
             }
@@ -477,7 +483,12 @@ int ocean_launch_tb(dmg_ocean *o, int lo, int hi, int n, int part, int zone_lo, 
         }
     }
     int rc;
-    if (sh.R == 4) rc = tb_launch<4, 8>(o, a, a.W, hi - lo, st, timed, part, zone_lo, zone_hi);
+    if (sh.R < 0) {
+        if (timed) (void)hipEventRecord(timed->ev0, st);
+        rc = ocean_launch_stream(o, lo, hi, part, zone_lo, zone_hi, from, st, sh.R == -1000 ? 0 : -sh.R);
+        if (timed) (void)hipEventRecord(timed->ev1, st);
+    }
+    else if (sh.R == 4) rc = tb_launch<4, 8>(o, a, a.W, hi - lo, st, timed, part, zone_lo, zone_hi);
     else if (sh.R == 6) rc = tb_launch<6, 8>(o, a, a.W, hi - lo, st, timed, part, zone_lo, zone_hi);
     else if (sh.R == 16) rc = tb_launch<16, 8>(o, a, a.W, hi - lo, st, timed, part, zone_lo, zone_hi);
     else if (sh.R == 10) rc = tb_launch<10, 8>(o, a, a.W, hi - lo, st, timed, part, zone_lo, zone_hi);
@@ -495,9 +506,11 @@ int ocean_tb_tile_rows(dmg_ocean *o, int lo, int hi)
     tb_shape f = tb_forced_shape();
     if (f.R) return f.R * f.NW - 2 * TB_T;
     if (ocean_tb_tuning_open(o, lo, hi)) return 0;
-    static const int rows_of[3] = { 8 * 8 - 2 * TB_T, 6 * 8 - 2 * TB_T, 4 * 8 - 2 * TB_T };
+    static const int rows_of[TB_NCAND] = { 8 * 8 - 2 * TB_T, 6 * 8 - 2 * TB_T, 4 * 8 - 2 * TB_T, 96, 32 };   // streaming: rows per unit
     auto it = o->tb_tuning.find(std::make_pair(lo, hi));
-    return (it != o->tb_tuning.end() && it->second.chosen >= 0) ? rows_of[it->second.chosen] : rows_of[0];
+    if (it != o->tb_tuning.end() && it->second.chosen >= 0) return rows_of[it->second.chosen];
+    const int tiles88 = ((o->grid.W + TB_OW - 1) / TB_OW) * ((hi - lo + 47) / 48);
+    return (tiles88 > 4096 && ocean_stream_enabled()) ? 96 : rows_of[0];
 }
 
 // true while the per-geometry shape tuner (ocean_launch_tb) would still time a candidate for a whole 8-sweep launch

@@ -43,5 +43,12 @@ int ocean_upload_row_tables(dmg_ocean *o)
     o->jac_rx = o->rt(RT_JRX);
     o->jac_ry = o->rt(RT_JRY);
     o->jac_rb = o->rt(RT_JRB);
+    std::vector<float> jc((size_t)L * 8, 0.0f);
+    for (int l = 0; l < L; l++) {
+        static const int f[6] = { RT_JCX, RT_JRX, RT_JBETA, RT_JRB, RT_JCY, RT_JRY };     // first four: one 16-byte load per row
+        for (int k = 0; k < 6; k++) jc[(size_t)l * 8 + k] = t[(size_t)f[k] * L + l];
+    }
+    DMG_HIP(hipMemcpyAsync(o->jcoef, jc.data(), jc.size() * sizeof(float), hipMemcpyHostToDevice, o->ctx->stream));
+    DMG_HIP(hipStreamSynchronize(o->ctx->stream));
     return DMG_OK;
 }
