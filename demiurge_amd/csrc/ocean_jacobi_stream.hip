@@ -26,9 +26,10 @@
 // cleared.  Arithmetic: jacobi_value() of ocean_internal.h, the same instruction sequence as every other Jacobi kernel.
 #include "ocean_internal.h"
 #include "ocean_tb.h"
+#include <algorithm>
 
 #define ST_MAXROWS 112            // output rows per unit: the 128 window rows' classes fit two registers
-#define ST_RING 9                 // rows in flight between level 0 and level 8
+#define ST_RING 12                // ring slots (rows): 10 rows are in flight between level 0 and level 8, two arrive
 
 struct st_args {
     const float *pin;
@@ -92,57 +93,86 @@ __device__ __forceinline__ float st_zero_land(unsigned code, int tick, float r) 
 }
 
 struct st_state {
-    v4f w[8][3];                   // w[s][k]: rows of level s (after s sweeps), ring of three
-    v4f bnext;                      // right-hand side and (raw) codes of the row that arrives at the next step
-    unsigned cnext;
-    unsigned landbits, mixbits;     // bit j: row e_t - j is land everywhere / has coast
-    int slot;                       // t mod ST_RING
-    v4f knext;                      // its coefficients {cx, 1/cx, Beta, 1/Beta}
+    v4f w[8][2][2];                 // w[s][pair][row]: rows of level s (after s sweeps); the pair a step produces, and the one before
+    // staging registers, two steps deep: set [t mod 2] holds the pressure, right-hand side and (raw) codes of the pair
+    // that arrives at step t; it is refilled for step t + 2 as soon as step t has taken it (a load has two whole steps,
+    // ~4-6 us of the wave's arithmetic, to come back: one step was not enough, the waves sat in s_waitcnt a third of the time)
+    v4f ps[2][2], bs[2][2];
+    unsigned cs[2][2];
+    unsigned landbits, mixbits;     // bit j: row (newest - j) is land everywhere / has coast; newest = second row of this step's pair
+    int slot;                       // ring slot of the first row of this step's pair (row offset mod ST_RING)
     float cy, ry;                   // the same for every row (pixelsize().y, src/Shader.h:71-74): two SGPRs
 };
 
-// one level: sweep S of row (e_t - S) from level S-1's rows; K = t mod 3
-template <int S, int K>
-__device__ __forceinline__ void st_level(const st_args &a, st_state &z, v4f (*bring)[64], unsigned (*cring)[64], const v4f *kring,
-                                         int lane, int t, int e_t, bool lane_ok, int xcol, const v4f bb, v4f &bb_next, const v4f kk, v4f &kk_next)
+__device__ __forceinline__ int st_wrap(int slot) { return slot < 0 ? slot + ST_RING : slot; }
+
+// one row of one level, generic: open ocean or coast (wave-uniform choice); N, C, S = the level below's rows y+1, y, y-1
+__device__ __forceinline__ v4f st_row_any(const v4f N, const v4f C, const v4f S, const v4f bb, const v4f kk, float cy, float ry, bool mixed,
+                                          const unsigned *crow, int lane, int tick)
 {
-    // the next level's right-hand side and coefficients are read from the rings while this level computes
-    if (S < 8) {
-        int sn = z.slot - (S + 1);
-        if (sn < 0) sn += ST_RING;
-        bb_next = bring[sn][lane];
-        kk_next = kring[sn];                                 // every lane reads the same 16 bytes: one broadcast
-    }
-    if (t < 2 * S) return;                                   // level S starts once its first needed row exists
-    if ((z.landbits >> S) & 1u) {                            // land everywhere: exactly 0, neither computed nor stored
-        if (S < 8) z.w[S & 7][K] = (v4f)(0.0f);
-        return;
-    }
-    const jacobi_row k = { kk.x, z.cy, kk.z, kk.y, z.ry, kk.w };
-    const v4f Sv = z.w[S - 1][(K + 1) % 3], C = z.w[S - 1][(K + 2) % 3], N = z.w[S - 1][K];
+    const jacobi_row k = { kk.x, cy, kk.z, kk.y, ry, kk.w };
     const float wl = dpp_from_prev_lane(C.w);                // west neighbour of C.x
     const float er = dpp_from_next_lane(C.x);                // east neighbour of C.w
     v2f o0, o1;
-    if (!((z.mixbits >> S) & 1u)) {                          // wave-uniform: open ocean, no selects
+    if (!mixed) {
         const v2f Wlo = { wl, C.x }, Mid = { C.y, C.z }, Ehi = { C.w, er };
-        o0 = st_value2(N.xy, Sv.xy, Mid, Wlo, bb.xy, k);     // cells x, y: W = (wl, x), E = (y, z)
-        o1 = st_value2(N.zw, Sv.zw, Ehi, Mid, bb.zw, k);     // cells z, w: W = (y, z), E = (w, er)
+        o0 = st_value2(N.xy, S.xy, Mid, Wlo, bb.xy, k);      // cells x, y: W = (wl, x), E = (y, z)
+        o1 = st_value2(N.zw, S.zw, Ehi, Mid, bb.zw, k);      // cells z, w: W = (y, z), E = (w, er)
     } else {
-        int sl = z.slot - S;
-        if (sl < 0) sl += ST_RING;
-        const unsigned c = cring[sl][lane];
+        const unsigned c = crow[lane];
+        const int t = tick;
         const v2f n0 = { st_sel<0>(c, t, C.x, N.x), st_sel<8>(c, t, C.y, N.y) }, n1 = { st_sel<16>(c, t, C.z, N.z), st_sel<24>(c, t, C.w, N.w) };
-        const v2f s0 = { st_sel<1>(c, t, C.x, Sv.x), st_sel<9>(c, t, C.y, Sv.y) }, s1 = { st_sel<17>(c, t, C.z, Sv.z), st_sel<25>(c, t, C.w, Sv.w) };
+        const v2f s0 = { st_sel<1>(c, t, C.x, S.x), st_sel<9>(c, t, C.y, S.y) }, s1 = { st_sel<17>(c, t, C.z, S.z), st_sel<25>(c, t, C.w, S.w) };
         const v2f e0 = { st_sel<2>(c, t, C.x, C.y), st_sel<10>(c, t, C.y, C.z) }, e1 = { st_sel<18>(c, t, C.z, C.w), st_sel<26>(c, t, C.w, er) };
         const v2f w0 = { st_sel<3>(c, t, C.x, wl), st_sel<11>(c, t, C.y, C.x) }, w1 = { st_sel<19>(c, t, C.z, C.y), st_sel<27>(c, t, C.w, C.z) };
         const v2f r0 = st_value2(n0, s0, e0, w0, bb.xy, k), r1 = st_value2(n1, s1, e1, w1, bb.zw, k);
         o0 = v2f{ st_zero_land<4>(c, t, r0.x), st_zero_land<12>(c, t, r0.y) };
         o1 = v2f{ st_zero_land<20>(c, t, r1.x), st_zero_land<28>(c, t, r1.y) };
     }
-    const v4f o = { o0.x, o0.y, o1.x, o1.y };
-    if (S < 8) z.w[S & 7][K] = o;
-    else if (lane_ok)
-        __builtin_nontemporal_store(o, reinterpret_cast<v4f *>(a.pout + (size_t)(e_t - 8) * a.W + xcol));   // never re-read in this launch
+    return v4f{ o0.x, o0.y, o1.x, o1.y };
+}
+
+// one level: sweep S of rows yA = e0 + 2t - S and yB = yA + 1 from level S-1's rows yA-1 .. yB+1 (the pair made one step ago
+// and the pair made in this step); K = t mod 2
+template <int S, int K>
+__device__ __forceinline__ void st_level(const st_args &a, st_state &z, v4f (*bring)[64], unsigned (*cring)[64], const v4f *ktab,
+                                         int lane, int t, int yA, int r1, bool lane_ok, int xcol,
+                                         const v4f bA, const v4f bB, v4f &bA_next, v4f &bB_next,
+                                         const v4f kA, const v4f kB, v4f &kA_next, v4f &kB_next)
+{
+    // the next level's right-hand sides and coefficients are read from the rings while this level computes
+    if (S < 8) {
+        const int sa = st_wrap(z.slot - (S + 1)), sb = sa + 1 == ST_RING ? 0 : sa + 1;
+        bA_next = bring[sa][lane]; bB_next = bring[sb][lane];
+        const int ra = max(2 * t - (S + 1), 0);               // window row of the next level's first row
+        kA_next = ktab[ra]; kB_next = ktab[ra + 1];           // every lane reads the same 16 bytes: one broadcast
+    }
+    if (t < S) return;                                        // level S starts once its first needed rows exist
+    const unsigned landA = (z.landbits >> (S + 1)) & 1u, landB = (z.landbits >> S) & 1u;
+    const unsigned mixA = (z.mixbits >> (S + 1)) & 1u, mixB = (z.mixbits >> S) & 1u;
+    const v4f S0 = z.w[S - 1][K ^ 1][0], C0 = z.w[S - 1][K ^ 1][1], N0 = z.w[S - 1][K][0], N1 = z.w[S - 1][K][1];
+    v4f oA, oB;
+    if (!(landA | landB | mixA | mixB)) {
+        // both rows open ocean (wave-uniform): one block of 8 independent division chains
+        const jacobi_row ka = { kA.x, z.cy, kA.z, kA.y, z.ry, kA.w }, kb = { kB.x, z.cy, kB.z, kB.y, z.ry, kB.w };
+        const float wlA = dpp_from_prev_lane(C0.w), erA = dpp_from_next_lane(C0.x);
+        const float wlB = dpp_from_prev_lane(N0.w), erB = dpp_from_next_lane(N0.x);
+        const v2f WloA = { wlA, C0.x }, MidA = { C0.y, C0.z }, EhiA = { C0.w, erA };
+        const v2f WloB = { wlB, N0.x }, MidB = { N0.y, N0.z }, EhiB = { N0.w, erB };
+        const v2f a0 = st_value2(N0.xy, S0.xy, MidA, WloA, bA.xy, ka), a1 = st_value2(N0.zw, S0.zw, EhiA, MidA, bA.zw, ka);
+        const v2f b0 = st_value2(N1.xy, C0.xy, MidB, WloB, bB.xy, kb), b1 = st_value2(N1.zw, C0.zw, EhiB, MidB, bB.zw, kb);
+        oA = v4f{ a0.x, a0.y, a1.x, a1.y };
+        oB = v4f{ b0.x, b0.y, b1.x, b1.y };
+    } else {
+        const int sa = st_wrap(z.slot - S), sb = sa + 1 == ST_RING ? 0 : sa + 1;
+        oA = landA ? (v4f)(0.0f) : st_row_any(N0, C0, S0, bA, kA, z.cy, z.ry, mixA != 0, cring[sa], lane, t);
+        oB = landB ? (v4f)(0.0f) : st_row_any(N1, N0, C0, bB, kB, z.cy, z.ry, mixB != 0, cring[sb], lane, t);
+    }
+    if (S < 8) { z.w[S & 7][K][0] = oA; z.w[S & 7][K][1] = oB; }
+    else if (lane_ok) {                                       // never re-read in this launch; land rows hold 0 in both buffers already
+        if (!landA) __builtin_nontemporal_store(oA, reinterpret_cast<v4f *>(a.pout + (size_t)yA * a.W + xcol));
+        if (!landB && yA + 1 < r1) __builtin_nontemporal_store(oB, reinterpret_cast<v4f *>(a.pout + (size_t)(yA + 1) * a.W + xcol));
+    }
 }
 
 // class of window row i (0..127) from the two class registers (lane i holds rows i and 64 + i)
@@ -151,74 +181,83 @@ __device__ __forceinline__ unsigned st_class(unsigned cls_lo, unsigned cls_hi, i
     return (unsigned)__builtin_amdgcn_readlane((int)(i < 64 ? cls_lo : cls_hi), i & 63);
 }
 
-// issue the loads of window row e (arrives at the next step): p into `dst`, b and codes into the state
-__device__ __forceinline__ void st_fetch(const st_args &a, st_state &z, v4f &dst, int e, unsigned cls, int col, int colp)
+// issue the loads of window row e into staging slot [set][j].  Always the same three loads, whatever the row's class:
+// the compiler can then count them, and the wait in front of a step's arrival is a counted vmcnt that leaves the other
+// staging set's loads (and the stores) in flight -- with class-dependent loads it falls back to vmcnt(0) and the
+// prefetch distance collapses to nothing.  (Land rows inside a live unit are few; their loads are wasted bytes.)
+__device__ __forceinline__ void st_fetch(const st_args &a, st_state &z, int set, int j, int e, int col, int colp)
 {
     const st_row m = st_map_row(a, e);
-    if (cls == 1u) return;                                   // land everywhere: nothing to read (its coefficients are never used)
     const size_t off = (size_t)m.l * a.W + (m.shift ? colp : col);
-    dst = *reinterpret_cast<const v4f *>(a.pin + off);
-    z.bnext = *reinterpret_cast<const v4f *>(a.b + off);
-    z.knext = *reinterpret_cast<const v4f *>(a.jcoef + (size_t)m.l * 8);            // one address for the whole wave
-    if (cls == 2u) z.cnext = *reinterpret_cast<const unsigned *>(a.code + off);     // looked at when the row has arrived
+    z.ps[set][j] = *reinterpret_cast<const v4f *>(a.pin + off);
+    z.bs[set][j] = *reinterpret_cast<const v4f *>(a.b + off);
+    z.cs[set][j] = *reinterpret_cast<const unsigned *>(a.code + off);
 }
 typedef const float __attribute__((address_space(4))) *st_kptr;
 
+// the row that has arrived in staging slot [K][j]: classify it, take its pressure into level 0, park its right-hand side
+// and codes in the rings
 template <int K>
-__device__ __forceinline__ void st_step(const st_args &a, st_state &z, v4f (*bring)[64], unsigned (*cring)[64], v4f *kring, int lane, int t,
-                                        int e0, int nsteps, unsigned cls_lo, unsigned cls_hi, int col, int colp, bool lane_ok, int xcol)
+__device__ __forceinline__ void st_arrive(const st_args &a, st_state &z, v4f (*bring)[64], unsigned (*cring)[64], int lane,
+                                          int j, int e, unsigned cls, int slot, unsigned &land, unsigned &mix)
 {
-    const int e_t = e0 + t;
-    // level 1's right-hand side (row e_t - 1) is in the ring already
-    int s1 = z.slot - 1;
-    if (s1 < 0) s1 += ST_RING;
-    v4f bcur = bring[s1][lane], bnxt, kcur = kring[s1], knxt;
-    // the row that has just arrived: classify it, park its right-hand side and codes in the ring
-    const unsigned cls = st_class(cls_lo, cls_hi, t);
-    unsigned land = cls == 1u, mix = 0;
-    if (cls == 1u) z.w[0][K] = (v4f)(0.0f);
-    else if (cls == 2u) {
-        unsigned c = z.cnext;
-        const st_row m = st_map_row(a, e_t);
+    land = cls == 1u; mix = 0;
+    z.w[0][K][j] = z.ps[K][j];                               // (a land row's pressure is +0 in memory: k_zero_land)
+    if (cls == 2u) {
+        unsigned c = z.cs[K][j];
+        const st_row m = st_map_row(a, e);
         if (m.flip) c = (c & 0xFCFCFCFCu) | ((c & 0x01010101u) << 1) | ((c & 0x02020202u) >> 1);   // mirrored row: swap N/S bits
         // a non-pole edge row's clamp bit only says "the tap lands on the cell itself"; its mirror row is in the window
-        const int yg = a.y_first + e_t;
+        const int yg = a.y_first + e;
         if (yg == 0 && !a.spole) c &= ~0x02020202u;
         if (yg == a.H - 1 && !a.npole) c &= ~0x01010101u;
         mix = __builtin_amdgcn_ballot_w64((c & 0x1F1F1F1Fu) != 0) != 0;
         land = __builtin_amdgcn_ballot_w64((c & 0x10101010u) != 0x10101010u) == 0;
-        if (mix && !land) cring[z.slot][lane] = c;
+        mix &= ~land;
+        if (mix) cring[slot][lane] = c;
     }
-    if (!land) {
-        bring[z.slot][lane] = z.bnext;
-        if (lane == 0) kring[z.slot] = z.knext;
-    }
-    z.landbits = (z.landbits << 1) | land;
-    z.mixbits = (z.mixbits << 1) | (mix & ~land);
-    st_level<1, K>(a, z, bring, cring, kring, lane, t, e_t, lane_ok, xcol, bcur, bnxt, kcur, knxt);
-    // level 1 was the last reader of w[0][(K+1)%3]: the next row lands there
-    if (t + 1 < nsteps) st_fetch(a, z, z.w[0][(K + 1) % 3], e_t + 1, st_class(cls_lo, cls_hi, t + 1), col, colp);
-    st_level<2, K>(a, z, bring, cring, kring, lane, t, e_t, lane_ok, xcol, bnxt, bcur, knxt, kcur);
-    st_level<3, K>(a, z, bring, cring, kring, lane, t, e_t, lane_ok, xcol, bcur, bnxt, kcur, knxt);
-    st_level<4, K>(a, z, bring, cring, kring, lane, t, e_t, lane_ok, xcol, bnxt, bcur, knxt, kcur);
-    st_level<5, K>(a, z, bring, cring, kring, lane, t, e_t, lane_ok, xcol, bcur, bnxt, kcur, knxt);
-    st_level<6, K>(a, z, bring, cring, kring, lane, t, e_t, lane_ok, xcol, bnxt, bcur, knxt, kcur);
-    st_level<7, K>(a, z, bring, cring, kring, lane, t, e_t, lane_ok, xcol, bcur, bnxt, kcur, knxt);
-    st_level<8, K>(a, z, bring, cring, kring, lane, t, e_t, lane_ok, xcol, bnxt, bcur, knxt, kcur);
-    z.slot = z.slot == ST_RING - 1 ? 0 : z.slot + 1;
+    bring[slot][lane] = z.bs[K][j];
 }
 
-// one wave per unit; 3 waves per SIMD leave 168 registers each
-__global__ __launch_bounds__(64, 3) void k_jacobi_stream(st_args a)
+template <int K>
+__device__ __forceinline__ void st_step(const st_args &a, st_state &z, v4f (*bring)[64], unsigned (*cring)[64], const v4f *ktab, int lane, int t,
+                                        int e0, int nsteps, int r1, unsigned cls_lo, unsigned cls_hi, int col, int colp, bool lane_ok, int xcol)
+{
+    const int e_t = e0 + 2 * t;                              // first row of the pair that has just arrived
+    const int slotB = z.slot + 1;                            // (ST_RING is even: a pair never wraps)
+    unsigned landA, mixA, landB, mixB;
+    st_arrive<K>(a, z, bring, cring, lane, 0, e_t, st_class(cls_lo, cls_hi, 2 * t), z.slot, landA, mixA);
+    st_arrive<K>(a, z, bring, cring, lane, 1, e_t + 1, st_class(cls_lo, cls_hi, 2 * t + 1), slotB, landB, mixB);
+    z.landbits = (z.landbits << 2) | (landA << 1) | landB;
+    z.mixbits = (z.mixbits << 2) | (mixA << 1) | mixB;
+    // the staging set is free again: the pair of step t + 2 (past the window's end the rows are clamped and unused)
+    st_fetch(a, z, K, 0, e_t + 4, col, colp);
+    st_fetch(a, z, K, 1, e_t + 5, col, colp);
+    // level 1: rows e_t - 1 (in the ring since the last step) and e_t (just written)
+    const int s1 = st_wrap(z.slot - 1), r1w = max(2 * t - 1, 0);
+    v4f b0 = bring[s1][lane], b1 = bring[z.slot][lane], k0 = ktab[r1w], k1 = ktab[r1w + 1], b2, b3, k2, k3;
+    st_level<1, K>(a, z, bring, cring, ktab, lane, t, e_t - 1, r1, lane_ok, xcol, b0, b1, b2, b3, k0, k1, k2, k3);
+    st_level<2, K>(a, z, bring, cring, ktab, lane, t, e_t - 2, r1, lane_ok, xcol, b2, b3, b0, b1, k2, k3, k0, k1);
+    st_level<3, K>(a, z, bring, cring, ktab, lane, t, e_t - 3, r1, lane_ok, xcol, b0, b1, b2, b3, k0, k1, k2, k3);
+    st_level<4, K>(a, z, bring, cring, ktab, lane, t, e_t - 4, r1, lane_ok, xcol, b2, b3, b0, b1, k2, k3, k0, k1);
+    st_level<5, K>(a, z, bring, cring, ktab, lane, t, e_t - 5, r1, lane_ok, xcol, b0, b1, b2, b3, k0, k1, k2, k3);
+    st_level<6, K>(a, z, bring, cring, ktab, lane, t, e_t - 6, r1, lane_ok, xcol, b2, b3, b0, b1, k2, k3, k0, k1);
+    st_level<7, K>(a, z, bring, cring, ktab, lane, t, e_t - 7, r1, lane_ok, xcol, b0, b1, b2, b3, k0, k1, k2, k3);
+    st_level<8, K>(a, z, bring, cring, ktab, lane, t, e_t - 8, r1, lane_ok, xcol, b2, b3, b0, b1, k2, k3, k0, k1);
+    z.slot = z.slot + 2 == ST_RING ? 0 : z.slot + 2;
+}
+
+// one wave per unit; two waves per SIMD leave 256 registers each: all issue slots of a SIMD belong to two fat waves
+__global__ __launch_bounds__(64, 2) void k_jacobi_stream(st_args a)
 {
     __shared__ v4f bring[ST_RING][64];
     __shared__ unsigned cring[ST_RING][64];
-    __shared__ v4f kring[ST_RING];
+    __shared__ v4f ktab[ST_MAXROWS + 2 * TB_T + 2];   // coefficients {cx, 1/cx, Beta, 1/Beta} of every window row, filled once
     const int lane = threadIdx.x;
     const int4 u = a.units[blockIdx.x];
     const int tx = __builtin_amdgcn_readfirstlane(u.x), r0 = __builtin_amdgcn_readfirstlane(u.y), r1 = __builtin_amdgcn_readfirstlane(u.z);
     const int W = a.W;
-    const int nsteps = (r1 - r0) + 2 * TB_T;
+    const int nsteps = ((r1 - r0) + 2 * TB_T + 1) / 2;     // two window rows per step
     const int e0 = r0 - TB_T;                       // unclamped local row of the first window row
     int col = tx * TB_OW - TB_T + 4 * lane;         // this lane's 4 columns (wrapped), plain and pole-shifted
     const int xcol = col;                           // unwrapped, for the store
@@ -232,27 +271,32 @@ __global__ __launch_bounds__(64, 3) void k_jacobi_stream(st_args a)
         int lu = e0 + lane, yg = a.y_first + lu;
         if (yg >= 0 && yg < a.H && lu >= 0 && lu < a.L) cls_lo = a.rowclass[(size_t)tx * a.L + lu];
         lu += 64; yg += 64;
-        if (lane + 64 < nsteps && yg >= 0 && yg < a.H && lu >= 0 && lu < a.L) cls_hi = a.rowclass[(size_t)tx * a.L + lu];
+        if (yg >= 0 && yg < a.H && lu >= 0 && lu < a.L) cls_hi = a.rowclass[(size_t)tx * a.L + lu];
     }
 
     st_state z;
 #pragma unroll
     for (int s = 0; s < 8; s++)
 #pragma unroll
-        for (int k = 0; k < 3; k++) z.w[s][k] = (v4f)(0.0f);
-    z.bnext = (v4f)(0.0f);
-    z.cnext = 0;
+        for (int k = 0; k < 2; k++) { z.w[s][k][0] = (v4f)(0.0f); z.w[s][k][1] = (v4f)(0.0f); }
+#pragma unroll
+    for (int k = 0; k < 2; k++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) { z.ps[k][j] = (v4f)(0.0f); z.bs[k][j] = (v4f)(0.0f); z.cs[k][j] = 0; }
     z.landbits = 0; z.mixbits = 0; z.slot = 0;
-    z.knext = (v4f)(1.0f);
+    for (int i = lane; i < 2 * nsteps + 2; i += 64)          // one 16-byte table entry per window row (two spare: the next level's prefetch)
+        ktab[i] = *reinterpret_cast<const v4f *>(a.jcoef + (size_t)st_map_row(a, e0 + i).l * 8);
     {
         const st_kptr cf = (st_kptr)(unsigned long long)a.jcoef;
         z.cy = cf[4]; z.ry = cf[5];
     }
-    st_fetch(a, z, z.w[0][0], e0, st_class(cls_lo, cls_hi, 0), col, colp);
-    for (int t = 0; t < nsteps; t += 3) {
-        st_step<0>(a, z, bring, cring, kring, lane, t, e0, nsteps, cls_lo, cls_hi, col, colp, lane_ok, xcol);
-        if (t + 1 < nsteps) st_step<1>(a, z, bring, cring, kring, lane, t + 1, e0, nsteps, cls_lo, cls_hi, col, colp, lane_ok, xcol);
-        if (t + 2 < nsteps) st_step<2>(a, z, bring, cring, kring, lane, t + 2, e0, nsteps, cls_lo, cls_hi, col, colp, lane_ok, xcol);
+    st_fetch(a, z, 0, 0, e0, col, colp);
+    st_fetch(a, z, 0, 1, e0 + 1, col, colp);
+    st_fetch(a, z, 1, 0, e0 + 2, col, colp);                 // (rows past the window are clamped into the band: harmless)
+    st_fetch(a, z, 1, 1, e0 + 3, col, colp);
+    for (int t = 0; t < nsteps; t += 2) {
+        st_step<0>(a, z, bring, cring, ktab, lane, t, e0, nsteps, r1, cls_lo, cls_hi, col, colp, lane_ok, xcol);
+        if (t + 1 < nsteps) st_step<1>(a, z, bring, cring, ktab, lane, t + 1, e0, nsteps, r1, cls_lo, cls_hi, col, colp, lane_ok, xcol);
     }
 }
 
@@ -263,34 +307,34 @@ bool ocean_stream_enabled()
     return on;
 }
 
-static int st_unit_rows()
+static int st_unit_rows()                                 // DMG_ST_ROWS=<n>: fixed unit height (experiments); default 0 = chosen per launch geometry
 {
     static const int rows = [] {
         const char *e = getenv("DMG_ST_ROWS");
-        int v = e ? atoi(e) : 96;
-        return v >= 8 && v <= ST_MAXROWS ? v : 96;
+        int v = e ? atoi(e) : 0;
+        return v >= 8 && v <= ST_MAXROWS ? v : 0;
     }();
     return rows;
 }
 
-// Units of a launch over local rows [lo, hi): every strip cut into segments of st_unit_rows() rows, each trimmed to its
-// first / last row that is not land everywhere; empty ones are dropped.  part 1 / 2: only the units that do / do not
-// produce rows of [lo, zone_lo) or [zone_hi, hi) (the two halves of a launch split around a halo exchange).
-static const dmg_ocean::tile_list *st_units(dmg_ocean *o, int lo, int hi, int part, int zone_lo, int zone_hi, int seg)
+namespace {
+struct st_unit { int tx, r0, r1; float cost; };
+}
+
+// Units of a launch over local rows [lo, hi) for one unit height: every strip cut into segments of `seg` rows, each trimmed
+// to its first / last row that is not land everywhere; empty ones are dropped.  cost ~ the unit's level-rows, a coast row
+// counted 1.6 times an open one and a land row a tenth (what the kernel spends on them).
+static void st_cut(const dmg_ocean *o, int lo, int hi, int seg, int part, int zone_lo, int zone_hi, std::vector<st_unit> &units)
 {
-    auto key = std::make_tuple(lo, hi, -seg, part, zone_lo, zone_hi);    // "rows per wave" < 0 = stream units of -that many rows
-    auto it = o->tb_lists.find(key);
-    if (it != o->tb_lists.end()) return &it->second;
     const int tiles_x = (o->grid.W + TB_OW - 1) / TB_OW, L = o->L;
     const bool classes = !o->rowclass_host.empty();
-    std::vector<int> units;                              // int4 per unit
-    units.reserve((size_t)tiles_x * ((hi - lo) / seg + 1) * 4);
+    units.clear();
     for (int s0 = lo; s0 < hi; s0 += seg) {
         const int s1 = std::min(s0 + seg, hi);
         for (int tx = 0; tx < tiles_x; tx++) {
             int r0 = s0, r1 = s1;
-            if (classes) {
-                const unsigned char *cls = o->rowclass_host.data() + (size_t)tx * L;
+            const unsigned char *cls = classes ? o->rowclass_host.data() + (size_t)tx * L : nullptr;
+            if (cls) {
                 while (r0 < r1 && cls[r0] == 1) r0++;
                 while (r1 > r0 && cls[r1 - 1] == 1) r1--;
             }
@@ -299,20 +343,70 @@ static const dmg_ocean::tile_list *st_units(dmg_ocean *o, int lo, int hi, int pa
                 const bool edge = r0 < zone_lo || r1 > zone_hi;
                 if (edge != (part == 1)) continue;
             }
-            units.push_back(tx); units.push_back(r0); units.push_back(r1); units.push_back(0);
+            float cost = 0.0f;
+            for (int r = r0 - TB_T; r < r1 + TB_T; r++) {
+                const int c = (cls && r >= 0 && r < L) ? cls[r] : 2;
+                const int depth = std::min(std::min(r - (r0 - TB_T), (r1 + TB_T - 1) - r), TB_T);   // levels that still need this row
+                cost += (c == 1 ? 0.1f : (c == 2 ? 1.6f : 1.0f)) * (float)depth;
+            }
+            units.push_back(st_unit{ tx, r0, r1, cost + 4.0f });
         }
     }
+}
+
+// makespan of the units on `slots` waves that each take the next unit when they are done (how the dispatcher hands
+// workgroups to free slots), units in descending cost order
+static float st_makespan(std::vector<st_unit> &units, int slots)
+{
+    std::sort(units.begin(), units.end(), [](const st_unit &a, const st_unit &b) { return a.cost > b.cost; });
+    std::vector<float> heap((size_t)slots, 0.0f);          // min-heap of slot finish times
+    auto cmp = [](float a, float b) { return a > b; };
+    float span = 0.0f;
+    for (const st_unit &u : units) {
+        std::pop_heap(heap.begin(), heap.end(), cmp);
+        heap.back() += u.cost;
+        span = std::max(span, heap.back());
+        std::push_heap(heap.begin(), heap.end(), cmp);
+    }
+    return span;
+}
+
+// The unit list of a launch geometry.  A launch has only 2 x 4 x CUs wave slots and its units all take about the same
+// time, so the chip works in "rounds": 2.49 rounds of 96-row units cost as much as 3.  The unit height is therefore chosen
+// per geometry (and terrain) by simulating the dispatch for every candidate height -- taller units recompute less
+// (7/n), but the last round must be full -- and the units are issued longest first.
+// part 1 / 2: only the units that do / do not produce rows of [lo, zone_lo) or [zone_hi, hi) (the two halves of a launch
+// split around a halo exchange).
+static const dmg_ocean::tile_list *st_units(dmg_ocean *o, int lo, int hi, int part, int zone_lo, int zone_hi, int seg)
+{
+    auto key = std::make_tuple(lo, hi, -1000 - seg, part, zone_lo, zone_hi);    // "rows per wave" <= -1000 = stream units (seg 0 = auto)
+    auto it = o->tb_lists.find(key);
+    if (it != o->tb_lists.end()) return &it->second;
+    const int slots = std::max(o->ctx->num_cu, 1) * 8;     // two waves per SIMD
+    std::vector<st_unit> units, best;
+    if (seg > 0) { st_cut(o, lo, hi, seg, part, zone_lo, zone_hi, best); (void)st_makespan(best, slots); }
+    else {
+        float best_span = 1e30f;
+        for (int cand = 24; cand <= ST_MAXROWS; cand += 4) {
+            st_cut(o, lo, hi, cand, part, zone_lo, zone_hi, units);
+            const float span = st_makespan(units, slots);
+            if (span < best_span) { best_span = span; best.swap(units); }
+        }
+    }
+    std::vector<int> flat;
+    flat.reserve(best.size() * 4);
+    for (const st_unit &u : best) { flat.push_back(u.tx); flat.push_back(u.r0); flat.push_back(u.r1); flat.push_back(0); }
     dmg_ocean::tile_list tl;
-    tl.n = (int)(units.size() / 4);
-    if (tl.n && hipMalloc((void **)&tl.d, units.size() * sizeof(int)) != hipSuccess) return nullptr;
-    if (tl.n && hipMemcpy(tl.d, units.data(), units.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    tl.n = (int)best.size();
+    if (tl.n && hipMalloc((void **)&tl.d, flat.size() * sizeof(int)) != hipSuccess) return nullptr;
+    if (tl.n && hipMemcpy(tl.d, flat.data(), flat.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
     return &(o->tb_lists[key] = tl);
 }
 
 // 8 sweeps over local rows [lo, hi) from p[from] into p[from ^ 1]; seg = rows per unit (0: the default)
 int ocean_launch_stream(dmg_ocean *o, int lo, int hi, int part, int zone_lo, int zone_hi, int from, hipStream_t st, int seg)
 {
-    if (seg <= 0) seg = st_unit_rows();
+    if (seg <= 0) seg = st_unit_rows();                    // 0: chosen per geometry
     if (seg > ST_MAXROWS) seg = ST_MAXROWS;
     const dmg_ocean::tile_list *tl = st_units(o, lo, hi, part, zone_lo, zone_hi, seg);
     if (!tl) return dmg_fail(DMG_ENOMEM, "unit list allocation failed");
