@@ -42,6 +42,7 @@ struct st_args {
     int spole, npole;
     const unsigned char *rowclass;  // [tiles_x][L]: 0 open ocean, 1 land everywhere, 2 mixed; or null
     const int4 *units;              // {tile column, first output row, end output row, -}
+    int dbg;                        // experiments only (DMG_ST_DBG bits): 1 = every unit re-reads 64 rows (cache hits), 2 = no stores, 4 = plain instead of nontemporal stores
 };
 
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -169,15 +170,21 @@ __device__ __forceinline__ void st_level(const st_args &a, st_state &z, v4f (*br
         oB = landB ? (v4f)(0.0f) : st_row_any(N1, N0, C0, bB, kB, z.cy, z.ry, mixB != 0, cring[sb], lane, t);
     }
     if (S < 8) { z.w[S & 7][K][0] = oA; z.w[S & 7][K][1] = oB; }
-    else if (lane_ok) {                                       // never re-read in this launch; land rows hold 0 in both buffers already
-        if (!landA) __builtin_nontemporal_store(oA, reinterpret_cast<v4f *>(a.pout + (size_t)yA * a.W + xcol));
+    else if (lane_ok && !(a.dbg & 2)) {                          // never re-read in this launch; land rows hold 0 in both buffers already
+        if (a.dbg & 4) {
+            if (!landA && yA < r1) *reinterpret_cast<v4f *>(a.pout + (size_t)yA * a.W + xcol) = oA;
+            if (!landB && yA + 1 < r1) *reinterpret_cast<v4f *>(a.pout + (size_t)(yA + 1) * a.W + xcol) = oB;
+        } else {
+        if (!landA && yA < r1) __builtin_nontemporal_store(oA, reinterpret_cast<v4f *>(a.pout + (size_t)yA * a.W + xcol));
         if (!landB && yA + 1 < r1) __builtin_nontemporal_store(oB, reinterpret_cast<v4f *>(a.pout + (size_t)(yA + 1) * a.W + xcol));
+        }
     }
 }
 
 // class of window row i (0..127) from the two class registers (lane i holds rows i and 64 + i)
 __device__ __forceinline__ unsigned st_class(unsigned cls_lo, unsigned cls_hi, int i)
 {
+    if (i > 127) return 2u;                                  // the padding rows of the last step: never used
     return (unsigned)__builtin_amdgcn_readlane((int)(i < 64 ? cls_lo : cls_hi), i & 63);
 }
 
@@ -185,9 +192,11 @@ __device__ __forceinline__ unsigned st_class(unsigned cls_lo, unsigned cls_hi, i
 // the compiler can then count them, and the wait in front of a step's arrival is a counted vmcnt that leaves the other
 // staging set's loads (and the stores) in flight -- with class-dependent loads it falls back to vmcnt(0) and the
 // prefetch distance collapses to nothing.  (Land rows inside a live unit are few; their loads are wasted bytes.)
+// (Measured and dropped: pointing the loads a row does not need -- everything of a land row, the codes of an open-ocean
+// row -- at an already cached row saves ~10 % of the bytes but costs more in address arithmetic: 2.58 -> 2.49 M.)
 __device__ __forceinline__ void st_fetch(const st_args &a, st_state &z, int set, int j, int e, int col, int colp)
 {
-    const st_row m = st_map_row(a, e);
+    const st_row m = st_map_row(a, (a.dbg & 1) ? (e & 63) : e);
     const size_t off = (size_t)m.l * a.W + (m.shift ? colp : col);
     z.ps[set][j] = *reinterpret_cast<const v4f *>(a.pin + off);
     z.bs[set][j] = *reinterpret_cast<const v4f *>(a.b + off);
@@ -202,7 +211,15 @@ __device__ __forceinline__ void st_arrive(const st_args &a, st_state &z, v4f (*b
                                           int j, int e, unsigned cls, int slot, unsigned &land, unsigned &mix)
 {
     land = cls == 1u; mix = 0;
-    z.w[0][K][j] = z.ps[K][j];                               // (a land row's pressure is +0 in memory: k_zero_land)
+    // (a land row's pressure is +0 in memory: k_zero_land.)  A real move, opaque to the register coalescer: merged with the
+    // staging registers, level 0's rows stay live past the point where the set is reloaded, the reload gets other
+    // registers, and the copies the compiler then puts on the loop's back edge wait for loads that were only just issued
+    {
+        v2f lo, hi;
+        asm("v_mov_b64 %0, %1" : "=v"(lo) : "v"(z.ps[K][j].xy));
+        asm("v_mov_b64 %0, %1" : "=v"(hi) : "v"(z.ps[K][j].zw));
+        z.w[0][K][j] = v4f{ lo.x, lo.y, hi.x, hi.y };
+    }
     if (cls == 2u) {
         unsigned c = z.cs[K][j];
         const st_row m = st_map_row(a, e);
@@ -252,12 +269,14 @@ __global__ __launch_bounds__(64, 2) void k_jacobi_stream(st_args a)
 {
     __shared__ v4f bring[ST_RING][64];
     __shared__ unsigned cring[ST_RING][64];
-    __shared__ v4f ktab[ST_MAXROWS + 2 * TB_T + 2];   // coefficients {cx, 1/cx, Beta, 1/Beta} of every window row, filled once
+    __shared__ v4f ktab[ST_MAXROWS + 2 * TB_T + 6];   // coefficients {cx, 1/cx, Beta, 1/Beta} of every window row, filled once
     const int lane = threadIdx.x;
     const int4 u = a.units[blockIdx.x];
     const int tx = __builtin_amdgcn_readfirstlane(u.x), r0 = __builtin_amdgcn_readfirstlane(u.y), r1 = __builtin_amdgcn_readfirstlane(u.z);
     const int W = a.W;
-    const int nsteps = ((r1 - r0) + 2 * TB_T + 1) / 2;     // two window rows per step
+    // two window rows per step, and an even number of steps: the loop body is two steps with no branch in between, so that
+    // every wait for a staged load is a counted vmcnt (a conditional second step makes the compiler wait for vmcnt(0))
+    const int nsteps = (((r1 - r0) + 2 * TB_T + 3) / 4) * 2;
     const int e0 = r0 - TB_T;                       // unclamped local row of the first window row
     int col = tx * TB_OW - TB_T + 4 * lane;         // this lane's 4 columns (wrapped), plain and pole-shifted
     const int xcol = col;                           // unwrapped, for the store
@@ -296,7 +315,7 @@ __global__ __launch_bounds__(64, 2) void k_jacobi_stream(st_args a)
     st_fetch(a, z, 1, 1, e0 + 3, col, colp);
     for (int t = 0; t < nsteps; t += 2) {
         st_step<0>(a, z, bring, cring, ktab, lane, t, e0, nsteps, r1, cls_lo, cls_hi, col, colp, lane_ok, xcol);
-        if (t + 1 < nsteps) st_step<1>(a, z, bring, cring, ktab, lane, t + 1, e0, nsteps, r1, cls_lo, cls_hi, col, colp, lane_ok, xcol);
+        st_step<1>(a, z, bring, cring, ktab, lane, t + 1, e0, nsteps, r1, cls_lo, cls_hi, col, colp, lane_ok, xcol);
     }
 }
 
@@ -324,13 +343,22 @@ struct st_unit { int tx, r0, r1; float cost; };
 // Units of a launch over local rows [lo, hi) for one unit height: every strip cut into segments of `seg` rows, each trimmed
 // to its first / last row that is not land everywhere; empty ones are dropped.  cost ~ the unit's level-rows, a coast row
 // counted 1.6 times an open one and a land row a tenth (what the kernel spends on them).
-static void st_cut(const dmg_ocean *o, int lo, int hi, int seg, int part, int zone_lo, int zone_hi, std::vector<st_unit> &units)
+static void st_cut(const dmg_ocean *o, int lo, int hi, int seg, int part, int zone_lo, int zone_hi, std::vector<st_unit> &units,
+                   int seg2 = 0, int split = 0)
 {
     const int tiles_x = (o->grid.W + TB_OW - 1) / TB_OW, L = o->L;
     const bool classes = !o->rowclass_host.empty();
     units.clear();
-    for (int s0 = lo; s0 < hi; s0 += seg) {
-        const int s1 = std::min(s0 + seg, hi);
+    // rows [lo, split) in segments of `seg` rows, the rest in (shorter) segments of `seg2` rows: the short units fill
+    // the last round of the dispatch
+    if (!seg2) split = hi;
+    for (int s0 = lo; s0 < hi;) {
+        const int h = s0 < split ? seg : seg2;
+        const int s1 = std::min(s0 + h, s0 < split ? split : hi);
+        const int s0_this = s0;
+        s0 = s1;
+        {
+            const int s0 = s0_this;
         for (int tx = 0; tx < tiles_x; tx++) {
             int r0 = s0, r1 = s1;
             const unsigned char *cls = classes ? o->rowclass_host.data() + (size_t)tx * L : nullptr;
@@ -350,6 +378,7 @@ static void st_cut(const dmg_ocean *o, int lo, int hi, int seg, int part, int zo
                 cost += (c == 1 ? 0.1f : (c == 2 ? 1.6f : 1.0f)) * (float)depth;
             }
             units.push_back(st_unit{ tx, r0, r1, cost + 4.0f });
+        }
         }
     }
 }
@@ -387,10 +416,27 @@ static const dmg_ocean::tile_list *st_units(dmg_ocean *o, int lo, int hi, int pa
     if (seg > 0) { st_cut(o, lo, hi, seg, part, zone_lo, zone_hi, best); (void)st_makespan(best, slots); }
     else {
         float best_span = 1e30f;
+        int best_seg = 0, best_seg2 = 0, best_split = 0;
         for (int cand = 24; cand <= ST_MAXROWS; cand += 4) {
             st_cut(o, lo, hi, cand, part, zone_lo, zone_hi, units);
-            const float span = st_makespan(units, slots);
-            if (span < best_span) { best_span = span; best.swap(units); }
+            float span = st_makespan(units, slots);
+            if (span < best_span) { best_span = span; best.swap(units); best_seg = cand; best_seg2 = 0; best_split = hi; }
+            // two tiers: the top eighth .. half of the rows in units a half, a third or a quarter as tall
+            for (int frac = 1; frac <= 4 && cand >= 48; frac++)
+                for (int div = 2; div <= 4; div++) {
+                    const int split = hi - ((hi - lo) * frac / 8 / cand) * cand, seg2 = ((cand / div + 3) / 4) * 4;
+                    if (split <= lo || split >= hi || seg2 < 12) continue;
+                    st_cut(o, lo, hi, cand, part, zone_lo, zone_hi, units, seg2, split);
+                    span = st_makespan(units, slots);
+                    if (span < best_span) { best_span = span; best.swap(units); best_seg = cand; best_seg2 = seg2; best_split = split; }
+                }
+        }
+        static const bool dbg = getenv("DMG_ST_DEBUG") != nullptr;
+        if (dbg) {
+            double total = 0;
+            for (const st_unit &u : best) total += u.cost;
+            fprintf(stderr, "[stream] rows [%d,%d) part %d: %zu units, %d rows up to row %d then %d; predicted span %.0f, mean load %.0f (%.1f %% of the slots' time)\n",
+                    lo, hi, part, best.size(), best_seg, best_split, best_seg2, best_span, total / slots, 100.0 * total / slots / best_span);
         }
     }
     std::vector<int> flat;
@@ -423,6 +469,8 @@ int ocean_launch_stream(dmg_ocean *o, int lo, int hi, int part, int zone_lo, int
     static const bool use_cls = getenv("DMG_TB_NOCLASS") == nullptr;
     a.rowclass = use_cls ? o->rowclass : nullptr;
     a.units = (const int4 *)tl->d;
+    static const int dbg = [] { const char *e = getenv("DMG_ST_DBG"); return e ? atoi(e) : 0; }();
+    a.dbg = dbg;
     hipLaunchKernelGGL(k_jacobi_stream, dim3((unsigned)tl->n), dim3(64), 0, st, a);
     DMG_HIP(hipGetLastError());
     return DMG_OK;
