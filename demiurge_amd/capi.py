@@ -40,6 +40,17 @@ class OceanParams(ctypes.Structure):
                 ("wind", ctypes.c_float), ("quirks", ctypes.c_int), ("jacobi_kernel", ctypes.c_int)]
 
 
+class MultiStats(ctypes.Structure):
+    _fields_ = [("bands_total", ctypes.c_int), ("bands_local", ctypes.c_int), ("transport", ctypes.c_int), ("order", ctypes.c_int),
+                ("ghost", ctypes.c_int), ("exchanges", ctypes.c_longlong), ("exchange_ms", ctypes.c_double),
+                ("exchange_bytes", ctypes.c_longlong), ("jacobi_launches", ctypes.c_longlong), ("jacobi_sweeps", ctypes.c_longlong)]
+
+
+MULTI_AUTO, MULTI_RCCL, MULTI_PEER, MULTI_RCCL_LOOPBACK = 0, 1, 2, 3
+MULTI_EXCHANGE_THEN_SWEEP, MULTI_OVERLAP_LAST_LAUNCH = 0, 16
+MULTI_TRANSPORT_NAMES = {1: "rccl", 2: "peer-copies", 3: "rccl-loopback"}
+
+
 class NoiseParams(ctypes.Structure):
     _fields_ = [("scale", ctypes.c_float), ("lacunarity", ctypes.c_float), ("persistence", ctypes.c_float),
                 ("min", ctypes.c_float), ("max", ctypes.c_float), ("octaves", ctypes.c_int), ("seed", ctypes.c_int),
@@ -169,6 +180,26 @@ def lib():
         "dmg_tectonics_plate_count": (c_int, [vp]),
         "dmg_tectonics_plate_size": (c_int, [vp, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
         "dmg_tectonics_get_plate": (c_int, [vp, c_int, vp]),
+        "dmg_multi_create": (c_int, [c_int, ctypes.POINTER(c_int), PG, PP, c_int, c_int, ctypes.POINTER(vp)]),
+        "dmg_multi_unique_id": (c_int, [vp]),
+        "dmg_multi_create_rank": (c_int, [c_int, c_int, vp, c_int, PG, PP, c_int, c_int, ctypes.POINTER(vp)]),
+        "dmg_multi_destroy": (None, [vp]),
+        "dmg_multi_set_order": (c_int, [vp, c_int]),
+        "dmg_multi_set_terrain": (c_int, [vp, vp]),
+        "dmg_multi_generate_terrain": (c_int, [vp, ctypes.POINTER(NoiseParams)]),
+        "dmg_multi_set_divw": (c_int, [vp, vp]),
+        "dmg_multi_set_pressure": (c_int, [vp, vp]),
+        "dmg_multi_set_velocity": (c_int, [vp, vp, vp]),
+        "dmg_multi_get": (c_int, [vp, vp, vp, vp, vp]),
+        "dmg_multi_sync": (c_int, [vp]),
+        "dmg_multi_jacobi": (c_int, [vp, c_int, c_int]),
+        "dmg_multi_step": (c_int, [vp, c_int]),
+        "dmg_multi_exchange": (c_int, [vp, c_int, c_int]),
+        "dmg_multi_band_count": (c_int, [vp]),
+        "dmg_multi_band": (c_int, [vp, c_int, ctypes.POINTER(vp)]),
+        "dmg_multi_get_stats": (c_int, [vp, ctypes.POINTER(MultiStats)]),
+        "dmg_multi_timer_start": (c_int, [vp]),
+        "dmg_multi_timer_stop": (c_int, [vp, ctypes.POINTER(c_float)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)          # AttributeError if the library does not export a declared symbol
@@ -532,6 +563,92 @@ class Ocean:
         if "v" in want:
             res["v"] = np.stack([arr["vx"], arr["vy"]], axis=-1)
         return res
+
+
+class Multi:
+    """dmg_multi: one ocean over several bands / GPUs, driven by the library (RCCL or peer-copy halo exchange).
+    Multi(grid, devices=[0, 1, ...]) = one process; Multi(grid, rank=r, world=n, unique_id=..., device=d) = one process per GPU."""
+
+    def __init__(self, grid, devices=None, params=None, ghost=32, flags=MULTI_AUTO, rank=None, world=None, unique_id=None, device=0):
+        self.grid, self.params = grid, params if params is not None else default_ocean_params()
+        h = ctypes.c_void_p()
+        if rank is None:
+            devs = (ctypes.c_int * len(devices))(*devices)
+            check(lib().dmg_multi_create(len(devices), devs, ctypes.byref(grid), ctypes.byref(self.params), ghost, flags, ctypes.byref(h)))
+        else:
+            idbuf = ctypes.create_string_buffer(bytes(unique_id), 128) if unique_id is not None else None
+            check(lib().dmg_multi_create_rank(rank, world, idbuf, device, ctypes.byref(grid), ctypes.byref(self.params), ghost, flags,
+                                              ctypes.byref(h)))
+        self.h = h
+
+    @staticmethod
+    def unique_id():
+        buf = ctypes.create_string_buffer(128)
+        check(lib().dmg_multi_unique_id(buf))
+        return buf.raw
+
+    def close(self):
+        if self.h:
+            lib().dmg_multi_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_order(self, order):
+        check(lib().dmg_multi_set_order(self.h, order))
+
+    def set_terrain(self, img):
+        check(lib().dmg_multi_set_terrain(self.h, _p(_f32(img))))
+
+    def set_divw(self, b):
+        check(lib().dmg_multi_set_divw(self.h, _p(_f32(b))))
+
+    def set_pressure(self, p):
+        check(lib().dmg_multi_set_pressure(self.h, _p(_f32(p))))
+
+    def set_velocity(self, v):
+        v = _f32(v)
+        vx, vy = np.ascontiguousarray(v[..., 0]), np.ascontiguousarray(v[..., 1])
+        check(lib().dmg_multi_set_velocity(self.h, _p(vx), _p(vy)))
+
+    def jacobi(self, iters, zero_first=True):
+        check(lib().dmg_multi_jacobi(self.h, iters, 1 if zero_first else 0))
+
+    def step(self, n_outer=1):
+        check(lib().dmg_multi_step(self.h, n_outer))
+
+    def sync(self):
+        check(lib().dmg_multi_sync(self.h))
+
+    def get(self, want=("v", "pressure", "divw"), out=None):
+        H, W = self.grid.H, self.grid.W
+        out = {} if out is None else out
+        arr = lambda k: out.setdefault(k, np.zeros((H, W), np.float32))
+        vx = arr("vx") if "v" in want else None
+        vy = arr("vy") if "v" in want else None
+        p = arr("pressure") if "pressure" in want else None
+        d = arr("divw") if "divw" in want else None
+        check(lib().dmg_multi_get(self.h, _p(vx), _p(vy), _p(p), _p(d)))
+        if "v" in want:
+            out["v"] = np.stack([out["vx"], out["vy"]], -1)
+        return out
+
+    def stats(self):
+        s = MultiStats()
+        check(lib().dmg_multi_get_stats(self.h, ctypes.byref(s)))
+        return {k: getattr(s, k) for k, _ in MultiStats._fields_}
+
+    def timer_start(self):
+        check(lib().dmg_multi_timer_start(self.h))
+
+    def timer_stop(self):
+        ms = ctypes.c_float()
+        check(lib().dmg_multi_timer_stop(self.h, ctypes.byref(ms)))
+        return ms.value
 
 
 class Tectonics:

@@ -204,7 +204,12 @@ __device__ __forceinline__ float2 fetch_linear2(const float2 *t, int W, int H, f
     float wx = fu - flu, wy = fv - flv;
     int i0 = min(max((int)flu, 0), W - 1), i1 = min(max((int)flu + 1, 0), W - 1);
     int j0 = min(max((int)flv, 0), H - 1) - y_first, j1 = min(max((int)flv + 1, 0), H - 1) - y_first;
-    if (j0 < 0 || j1 >= L) { *oob = 1; j0 = min(max(j0, 0), L - 1); j1 = min(max(j1, 0), L - 1); }
+    if (j0 < 0 || j1 >= L) {
+        // a cell at rest has no back-trace direction (normalize(0), :306): its coordinates are NaN and whatever is fetched
+        // is discarded (:321) -- that is not a reach beyond the band
+        if (fv == fv && fu == fu) *oob = 1;
+        j0 = min(max(j0, 0), L - 1); j1 = min(max(j1, 0), L - 1);
+    }
     float2 t00 = t[(size_t)j0 * W + i0], t10 = t[(size_t)j0 * W + i1], t01 = t[(size_t)j1 * W + i0], t11 = t[(size_t)j1 * W + i1];
     // the reference's pixels come from a filter whose lerp is one fused multiply-add, a + w*(b-a) (llvmpipe lp_build_lerp)
     float ax = fmaf(wx, t10.x - t00.x, t00.x), bx = fmaf(wx, t11.x - t01.x, t01.x);

@@ -25,11 +25,13 @@
  *  - work is enqueued on the context's HIP stream; calls that return data to the
  *    host synchronise that stream, the others do not (dmg_sync does).
  *
- * Latitude bands (multi-GPU): one process per GPU.  A dmg_ocean created with
- * band (rank r of n) owns grid rows [dmg_band_row0(H,n,r), dmg_band_row0(H,n,r+1))
- * plus `ghost` rows towards each neighbouring band.  The host refreshes ghost
- * rows between sweep blocks with dmg_ocean_halo() slabs (RCCL send/recv over
- * xGMI, or any transport); the library never communicates by itself.
+ * Latitude bands (multi-GPU).  A dmg_ocean created with band (rank r of n) owns
+ * grid rows [dmg_band_row0(H,n,r), dmg_band_row0(H,n,r+1)) plus `ghost` rows
+ * towards each neighbouring band; dmg_ocean_halo() hands out the slabs to
+ * exchange.  dmg_multi (below) is the library's own driver of such bands: one
+ * process with a stream and a thread per GPU, or one process per GPU, RCCL
+ * send/recv over xGMI.  A host that brings its own transport can still drive
+ * dmg_ocean bands itself (demiurge_amd/bands.py does, over torch.distributed).
  */
 #ifndef DEMIURGE_HIP_H
 #define DEMIURGE_HIP_H
@@ -208,6 +210,63 @@ int dmg_ocean_get(dmg_ocean *o, float *vx, float *vy, float *pressure, float *di
 int dmg_ocean_checkpoint(dmg_ocean *o, const char *prefix);
 int dmg_ocean_restore(dmg_ocean *o, const char *prefix);      /* after dmg_ocean_set_terrain, same grid and band */
 
+/* ---- one ocean over several GPUs: latitude bands driven by the library -----------------------------
+ * Replaces the same interface as dmg_ocean (OceanCurrents behind AsyncSubFilter::run, src/filter/Filter.cpp:125-166): the
+ * bands, one stream and one host thread per band, every halo exchange (RCCL ncclSend/ncclRecv of the slabs that
+ * dmg_ocean_halo hands out, or peer copies) and the all-reduce of the advect reach live below this boundary.  Results
+ * are bit-identical to a single dmg_ocean for every split and transport.  Full-grid host arrays in, full-grid arrays out. */
+typedef struct dmg_multi dmg_multi;
+/* flags of dmg_multi_create / dmg_multi_create_rank: one transport, optionally the exchange order */
+#define DMG_MULTI_AUTO 0            /* RCCL when every band has its own GPU, else peer copies */
+#define DMG_MULTI_RCCL 1            /* grouped ncclSend/ncclRecv on each band's stream (ncclCommInitAll / ncclCommInitRank) */
+#define DMG_MULTI_PEER 2            /* hipMemcpyPeerAsync + events: one process; also several bands on one GPU */
+#define DMG_MULTI_RCCL_LOOPBACK 3   /* tests on a one-GPU box: all bands on one device and stream, every slab sent through a
+                                       communicator of size 1 to the process's own rank -- the RCCL calls run for real */
+#define DMG_MULTI_TRANSPORT_MASK 15
+#define DMG_MULTI_EXCHANGE_THEN_SWEEP 0     /* order of a Jacobi block: refresh the ghost rows, then sweep (default) */
+#define DMG_MULTI_OVERLAP_LAST_LAUNCH 16    /* the exchange for the next block runs while the interior of this block's last
+                                               launch is swept (dmg_ocean_jacobi_sweeps_begin/_end) */
+#define DMG_MULTI_ID_BYTES 128
+/* One process, n_bands bands; device_ids[i] = HIP device of band i (ids may repeat with DMG_MULTI_PEER / _LOOPBACK).
+ * ghost = halo rows per band side: the Jacobi solve exchanges every `ghost` sweeps (rounded down to whole 8-sweep
+ * launches), and advect may reach at most `ghost` rows (dmg_multi_step checks this on all bands before it moves). */
+int dmg_multi_create(int n_bands, const int *device_ids, const dmg_grid *grid, const dmg_ocean_params *params, int ghost, int flags,
+                     dmg_multi **out);
+/* One process per GPU: rank 0 calls dmg_multi_unique_id, the host hands the 128 bytes to every rank (torch.distributed,
+ * MPI, a file), each rank creates its band.  Collective: every rank must call it. */
+int dmg_multi_unique_id(void *id128);
+int dmg_multi_create_rank(int rank, int n_ranks, const void *id128, int device_id, const dmg_grid *grid, const dmg_ocean_params *params,
+                          int ghost, int flags, dmg_multi **out);
+void dmg_multi_destroy(dmg_multi *m);
+int dmg_multi_set_order(dmg_multi *m, int order);          /* DMG_MULTI_EXCHANGE_THEN_SWEEP | DMG_MULTI_OVERLAP_LAST_LAUNCH, per call site */
+/* the dmg_ocean_* calls of the same names, on every local band (full-grid arrays; each band takes / fills its rows) */
+int dmg_multi_set_terrain(dmg_multi *m, const float *img);
+int dmg_multi_generate_terrain(dmg_multi *m, const struct dmg_noise_params *params);
+int dmg_multi_set_divw(dmg_multi *m, const float *divw);
+int dmg_multi_set_pressure(dmg_multi *m, const float *pressure);
+int dmg_multi_set_velocity(dmg_multi *m, const float *vx, const float *vy);
+int dmg_multi_get(dmg_multi *m, float *vx, float *vy, float *pressure, float *divw);
+int dmg_multi_sync(dmg_multi *m);
+/* OceanCurrents::jacobi (:437-509) over the bands: pressure := 0 when zero_first, then `iters` sweeps, ghost rows refreshed
+ * every block.  Asynchronous on the bands' streams (dmg_multi_sync / dmg_multi_get wait). */
+int dmg_multi_jacobi(dmg_multi *m, int iters, int zero_first);
+/* OceanCurrents::run body (:155-209) n_outer times over the bands.  Before each advect the bands all-reduce the longest
+ * back-trace (|v| * timestep, :298-299): if it exceeds `ghost` every rank returns DMG_EINVAL with its state untouched. */
+int dmg_multi_step(dmg_multi *m, int n_outer);
+int dmg_multi_exchange(dmg_multi *m, int field, int rows);  /* one halo refresh of DMG_F_* on every band */
+int dmg_multi_band_count(const dmg_multi *m);               /* bands in this process */
+int dmg_multi_band(dmg_multi *m, int local_index, dmg_ocean **out);   /* borrow a band (checkpoints, dmg_ocean_speed_shade ...) */
+typedef struct {
+    int bands_total, bands_local, transport, order, ghost;
+    long long exchanges;             /* halo exchanges since creation */
+    double exchange_ms;              /* their time on band 0's stream (HIP events around each exchange) */
+    long long exchange_bytes;        /* bytes band 0 sent + received */
+    long long jacobi_launches, jacobi_sweeps;     /* of band 0 */
+} dmg_multi_stats;
+int dmg_multi_get_stats(dmg_multi *m, dmg_multi_stats *s);  /* synchronises */
+int dmg_multi_timer_start(dmg_multi *m);                    /* HIP events on band 0's stream; _stop waits for every band */
+int dmg_multi_timer_stop(dmg_multi *m, float *elapsed_ms);
+
 /* ---- generic stencil filters on a whole grid ---------------------------- */
 /* Blur::Blur + Blur::step until finished (src/filter/BlurMenu.cpp:24-117), in place on host data */
 int dmg_blur(dmg_ctx *ctx, const dmg_grid *grid, float *field_inout, float radius);
@@ -279,6 +338,7 @@ enum { DMG_NOISE_DEFAULT = 0, DMG_NOISE_RIDGED, DMG_NOISE_BILLOWY, DMG_NOISE_IQ,
        DMG_NOISE_PLATEAUS };                       /* enum noise_mode, GradientNoise.h:10 */
 enum { DMG_BLEND_REPLACE = 0, DMG_BLEND_ADD, DMG_BLEND_SUBTRACT, DMG_BLEND_MULTIPLY, DMG_BLEND_DIVIDE, DMG_BLEND_MAX,
        DMG_BLEND_MIN };                            /* filter::blendMode(), src/filter/Filter.cpp:170-236 */
+struct dmg_noise_params;
 typedef struct dmg_noise_params {                  /* struct NoiseParams, GradientNoise.h:15-25, + the blend mode */
     float scale, lacunarity, persistence, min, max;
     int octaves, seed;
