@@ -134,6 +134,7 @@ def lib():
         "dmg_ocean_set_pressure_buffer": (c_int, [vp, c_int, c_int, c_int]),
         "dmg_ocean_pressure_halo": (c_int, [vp, c_int, c_int, c_int, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(sz)]),
         "dmg_ocean_counters": (c_int, [vp, ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_longlong)]),
+        "dmg_ocean_jacobi_kernel_name": (c_int, [vp, ctypes.c_char_p, sz]),
         "dmg_ocean_halo": (c_int, [vp, c_int, c_int, c_int, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(sz)]),
         "dmg_ocean_step": (c_int, [vp, c_int]),
         "dmg_ocean_advect": (c_int, [vp]),
@@ -423,7 +424,8 @@ class Ocean:
 
     def close(self):
         if self.h:
-            lib().dmg_ocean_destroy(self.h)
+            if not getattr(self, "borrowed", False):       # a band borrowed from a Multi belongs to it
+                lib().dmg_ocean_destroy(self.h)
             self.h = None
 
     def __del__(self):
@@ -515,6 +517,11 @@ class Ocean:
         a, b = ctypes.c_longlong(), ctypes.c_longlong()
         check(lib().dmg_ocean_counters(self.h, ctypes.byref(a), ctypes.byref(b)))
         return a.value, b.value
+
+    def kernel_name(self):
+        buf = ctypes.create_string_buffer(64)
+        check(lib().dmg_ocean_jacobi_kernel_name(self.h, buf, 64))
+        return buf.value.decode()
 
     def halo(self, field, side, rows):
         """-> (send_ptr, recv_ptr, nbytes) device addresses (ints); nbytes == 0 at a grid edge."""
@@ -636,6 +643,14 @@ class Multi:
         if "v" in want:
             out["v"] = np.stack([out["vx"], out["vy"]], -1)
         return out
+
+    def band(self, i=0):
+        """borrowed Ocean view of local band i (do not close it)"""
+        h = ctypes.c_void_p()
+        check(lib().dmg_multi_band(self.h, i, ctypes.byref(h)))
+        o = Ocean.__new__(Ocean)
+        o.h, o.ctx, o.grid, o.params, o.borrowed = h, None, self.grid, self.params, True
+        return o
 
     def stats(self):
         s = MultiStats()

@@ -165,6 +165,7 @@ static int launch_sweep(dmg_ocean *o, int row_lo, int row_hi)
     a.l_north_pole = (o->topo.npole && o->y1 == o->grid.H) ? o->gs + (o->y1 - o->y0) - 1 : -1;
     a.lonwrap = o->topo.lonwrap ? 1 : 0;
     const int W = o->grid.W;
+    o->last_kernel = W % 8 == 0 ? "k_jacobi_sweep_v4" : "k_jacobi_sweep_s";
     if (W % 8 == 0) {
         dim3 grid((W / 4 + 255) / 256, row_hi - row_lo);
         hipLaunchKernelGGL(k_jacobi_sweep_v4, grid, dim3(256), 0, o->ctx->stream, a);
@@ -525,6 +526,13 @@ int dmg_ocean_counters(dmg_ocean *o, long long *jacobi_launches, long long *jaco
     DMG_CHECK_ARG(o != nullptr);
     if (jacobi_launches) *jacobi_launches = o->n_launches;
     if (jacobi_sweeps) *jacobi_sweeps = o->n_sweeps;
+    return DMG_OK;
+}
+
+int dmg_ocean_jacobi_kernel_name(dmg_ocean *o, char *buf, size_t len)
+{
+    DMG_CHECK_ARG(o != nullptr && buf != nullptr && len > 0);
+    snprintf(buf, len, "%s", o->last_kernel);
     return DMG_OK;
 }
 

@@ -61,6 +61,7 @@ struct dmg_ocean {
     const float *jac_rx = nullptr, *jac_ry = nullptr, *jac_rb = nullptr;
     bool have_terrain = false;
     long long n_launches = 0, n_sweeps = 0;   // Jacobi statistics
+    const char *last_kernel = "none";         // the kernel the most recent Jacobi launch used (bench.py names it in its roofline block)
     long long n_outer = 0;                    // outer steps completed (dmg_ocean_step / the multi-GPU driver); travels with checkpoints
     const float *rt(int field) const { return rowtab + (size_t)field * L; }
 };

@@ -483,6 +483,7 @@ int ocean_launch_tb(dmg_ocean *o, int lo, int hi, int n, int part, int zone_lo, 
         }
     }
     int rc;
+    o->last_kernel = sh.R < 0 ? "k_jacobi_stream" : "k_jacobi_tb8";
     if (sh.R < 0) {
         if (timed) (void)hipEventRecord(timed->ev0, st);
         rc = ocean_launch_stream(o, lo, hi, part, zone_lo, zone_hi, from, st, sh.R == -1000 ? 0 : -sh.R);

@@ -1,6 +1,7 @@
 // Drives HipOceanCurrents the way the editor does: ProgressFilter::run calls subFilter->step(p) once per frame
 // until it reports finished (reference src/filter/Filter.cpp:97-115).  Reads a terrain (raw fp32), writes vx, vy.
 //   host_demo <W> <H> <terrain.f32> <n_outer> <jacobi_iters> <diffusion_iters> <out_prefix>
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -119,12 +120,14 @@ int main(int argc, char **argv)
 {
     if (argc == 2 && std::string(argv[1]) == "lifetime") return lifetime_check();
     if (argc >= 2 && !(argv[1][0] >= '0' && argv[1][0] <= '9')) return other_tools(argc, argv);
-    if (argc != 8) { fprintf(stderr, "usage: host_demo W H terrain.f32 n_outer jacobi_iters diffusion_iters out_prefix\n"); return 2; }
+    if (argc != 8 && argc != 9) { fprintf(stderr, "usage: host_demo W H terrain.f32 n_outer jacobi_iters diffusion_iters out_prefix [n_bands on GPU 0]\n"); return 2; }
     Project p;
     p.width = atoi(argv[1]); p.height = atoi(argv[2]);
     p.terrain.resize((size_t)p.width * p.height);
     if (!read_f32(argv[3], p.terrain)) { fprintf(stderr, "cannot read %s\n", argv[3]); return 2; }
-    auto filter = std::make_unique<HipOceanCurrents>(&p, 100.0f, atoi(argv[4]), atoi(argv[5]), atoi(argv[6]));
+    std::vector<int> devices(argc == 9 ? (size_t)std::max(atoi(argv[8]), 1) : 1, 0);      // the rehearsal form: every band on GPU 0
+    auto filter = std::make_unique<HipOceanCurrents>(&p, 100.0f, atoi(argv[4]), atoi(argv[5]), atoi(argv[6]), devices,
+                                                     std::min(32, p.height / (int)devices.size()));
     int frames = 0;
     for (;;) {                                           // one step() per UI frame
         auto [finished, progress] = filter->step(&p);

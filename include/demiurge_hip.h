@@ -181,6 +181,9 @@ int dmg_ocean_pressure_halo(dmg_ocean *o, int buffer, int side, int rows, void *
 /* cumulative counters since creation: Jacobi kernel launches and sweeps performed (a temporally blocked launch
  * advances up to 8 sweeps) -- what bench.py divides its HIP-event time by */
 int dmg_ocean_counters(dmg_ocean *o, long long *jacobi_launches, long long *jacobi_sweeps);
+/* name of the kernel the most recent Jacobi launch ran (k_jacobi_stream, k_jacobi_tb8, k_jacobi_sweep_v4 ...): the row to
+ * look for in a rocprofv3 --kernel-trace --stats table */
+int dmg_ocean_jacobi_kernel_name(dmg_ocean *o, char *buf, size_t len);
 
 /* One exchange slab of a field: `send` = this band's `rows` rows next to `side`, `recv` = the ghost rows
  * beyond that side; both contiguous device memory of `bytes` bytes.  bytes == 0 when the side is a grid edge. */

@@ -85,9 +85,10 @@ def test_ocean_step_bands_gloo_hip(tmp_path):
 @pytest.mark.gpu
 def test_bench_multi_rank_rehearsal(tmp_path):
     """bench.py launched exactly as the driver launches it for N=2 (torch.distributed.run, one process per rank), with
-    the rehearsal switches that let both ranks share this box's single GPU and exchange halos over gloo"""
+    the rehearsal switch for a one-GPU box: rendezvous, RCCL-id broadcast, barrier and max-over-ranks run over gloo, and
+    each rank drives both bands on GPU 0 through the library's one-process dmg_multi (RCCL refuses two ranks per GPU)"""
     import json, os, subprocess, sys
-    env = dict(os.environ, DMG_BENCH_SHARE_GPU="1", DMG_DIST_BACKEND="gloo")
+    env = dict(os.environ, DMG_BENCH_REHEARSAL="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
            "--width", "2048", "--height", "1024", "--sweeps", "96", "--no-cpu-baseline"]
@@ -98,6 +99,7 @@ def test_bench_multi_rank_rehearsal(tmp_path):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and d["roofline"]["sweeps_per_launch"] == 8.0
     assert "2 latitude bands" in d["config"]["parallelism"]
+    assert d["halo_exchange"]["exchanges"] >= 3 and 0 < d["halo_exchange"]["share_of_stream_time"] < 1
 
 
 @pytest.mark.gpu

@@ -19,7 +19,7 @@ def test_adapter_builds_and_links_only_the_c_abi():
     build()
     out = subprocess.check_output(["nm", "-D", "--undefined-only", str(HOST / "host_demo")], text=True)
     used = sorted({l.split()[-1] for l in out.splitlines() if " dmg_" in l})
-    assert "dmg_ocean_step" in used and "dmg_ocean_get" in used and "dmg_create" in used
+    assert "dmg_multi_step" in used and "dmg_multi_get" in used and "dmg_create" in used
     assert not [s for s in used if not s.startswith("dmg_")]
     assert "hip" not in out.lower().replace("demiurge_hip", "")       # no HIP/torch types or symbols cross the boundary
 
@@ -55,6 +55,13 @@ def test_adapter_matches_golden_and_oracle(oracle, tmp_path):
     vo, _, _ = oracle.ocean_step(oracle.grid(W, H), G["img"], np.zeros_like(v), int(G["n_outer"]), int(G["jacobi_iters"]),
                                  int(G["diffusion_iters"]), rows=True)
     assert np.array_equal(v, vo)
+    # the same filter split over two bands (HipOceanCurrents devices = {0, 0}: dmg_multi underneath): the same bits
+    r = subprocess.run([str(HOST / "host_demo"), str(W), str(H), str(t), str(int(G["n_outer"])), str(int(G["jacobi_iters"])),
+                        str(int(G["diffusion_iters"])), str(tmp_path / "out2"), "2"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    vx2 = np.fromfile(tmp_path / "out2_vx.f32", np.float32).reshape(H, W)
+    vy2 = np.fromfile(tmp_path / "out2_vy.f32", np.float32).reshape(H, W)
+    assert np.array_equal(vx2, vx) and np.array_equal(vy2, vy)
 
 
 @pytest.mark.gpu
