@@ -181,6 +181,19 @@ def lib():
         "dmg_tectonics_plate_count": (c_int, [vp]),
         "dmg_tectonics_plate_size": (c_int, [vp, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
         "dmg_tectonics_get_plate": (c_int, [vp, c_int, vp]),
+        "dmg_climate_create_band": (c_int, [vp, PG, vp, vp, c_int, c_int, c_int, ctypes.POINTER(vp)]),
+        "dmg_climate_halo": (c_int, [vp, c_int, c_int, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(sz)]),
+        "dmg_field_create": (c_int, [vp, PG, c_int, c_int, c_int, ctypes.POINTER(vp)]),
+        "dmg_field_destroy": (None, [vp]),
+        "dmg_field_set": (c_int, [vp, vp]),
+        "dmg_field_get": (c_int, [vp, vp]),
+        "dmg_field_halo": (c_int, [vp, c_int, c_int, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(sz)]),
+        "dmg_fields_exchange": (c_int, [ctypes.POINTER(vp), c_int, c_int]),
+        "dmg_blur_schedule": (c_int, [c_float, ctypes.POINTER(c_float), c_int]),
+        "dmg_field_blur_halo": (c_int, [c_float, c_int]),
+        "dmg_field_blur_pass": (c_int, [vp, c_float, c_int]),
+        "dmg_field_erosion_pass": (c_int, [vp, vp, vp, c_float, c_float]),
+        "dmg_field_thermal_round": (c_int, [vp, vp]),
         "dmg_multi_create": (c_int, [c_int, ctypes.POINTER(c_int), PG, PP, c_int, c_int, ctypes.POINTER(vp)]),
         "dmg_multi_unique_id": (c_int, [vp]),
         "dmg_multi_create_rank": (c_int, [c_int, c_int, vp, c_int, PG, PP, c_int, c_int, ctypes.POINTER(vp)]),
@@ -358,17 +371,25 @@ Context.flow_passes = _ctx_flow_passes
 class Climate:
     """dmg_climate: the climate field (Temperature.cpp) resident on the device between step calls"""
 
-    def __init__(self, ctx, grid, T, terrain):
+    def __init__(self, ctx, grid, T, terrain, band_rank=0, band_count=1, ghost=0):
         T, terrain = _f32(T), _f32(terrain)
         self.ctx, self.shape = ctx, T.shape
         h = ctypes.c_void_p()
-        check(lib().dmg_climate_create(ctx.h, ctypes.byref(grid), _p(T), _p(terrain), ctypes.byref(h)))
+        check(lib().dmg_climate_create_band(ctx.h, ctypes.byref(grid), _p(T), _p(terrain), band_rank, band_count, ghost, ctypes.byref(h)))
         self.h = h
 
     def steps(self, first_step, n_steps):
         check(lib().dmg_climate_steps(self.h, first_step, n_steps))
 
-    def get(self):
+    def halo(self, side, rows):
+        send, recv, nbytes = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_size_t()
+        check(lib().dmg_climate_halo(self.h, side, rows, ctypes.byref(send), ctypes.byref(recv), ctypes.byref(nbytes)))
+        return send.value, recv.value, nbytes.value
+
+    def get(self, out=None):
+        if out is not None:                                    # a band: its owned rows into the caller's full-grid array
+            check(lib().dmg_climate_get(self.h, _p(out)))
+            return out
         out = np.empty(self.shape, np.float32)
         check(lib().dmg_climate_get(self.h, _p(out)))
         return out
@@ -570,6 +591,63 @@ class Ocean:
         if "v" in want:
             res["v"] = np.stack([arr["vx"], arr["vy"]], axis=-1)
         return res
+
+
+class Field:
+    """dmg_field: one scalar field of one latitude band on the device (ghost rows towards the neighbouring bands)."""
+
+    def __init__(self, ctx, grid, band_rank=0, band_count=1, ghost=0, data=None):
+        self.ctx, self.grid = ctx, grid
+        h = ctypes.c_void_p()
+        check(lib().dmg_field_create(ctx.h, ctypes.byref(grid), band_rank, band_count, ghost, ctypes.byref(h)))
+        self.h = h
+        ctx._children.add(self)
+        if data is not None:
+            self.set(data)
+
+    def close(self):
+        if self.h:
+            lib().dmg_field_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set(self, full):
+        check(lib().dmg_field_set(self.h, _p(_f32(full))))
+
+    def get(self, out):
+        check(lib().dmg_field_get(self.h, _p(out)))
+        return out
+
+    def blur_pass(self, r, vertical):
+        check(lib().dmg_field_blur_pass(self.h, r, 1 if vertical else 0))
+
+    def erosion_pass(self, flow, updrift, factor=1.0, slope_exponent=1.0):
+        check(lib().dmg_field_erosion_pass(self.h, flow.h, updrift.h, factor, slope_exponent))
+
+    def thermal_round(self, loss):
+        check(lib().dmg_field_thermal_round(self.h, loss.h))
+
+
+def fields_exchange(bands, rows):
+    arr = (ctypes.c_void_p * len(bands))(*[b.h for b in bands])
+    check(lib().dmg_fields_exchange(arr, len(bands), rows))
+
+
+def blur_schedule(radius):
+    buf = (ctypes.c_float * 64)()
+    n = lib().dmg_blur_schedule(radius, buf, 64)
+    if n < 0:
+        check(n)
+    return [buf[i] for i in range(n)]
+
+
+def blur_halo(r, vertical):
+    return lib().dmg_field_blur_halo(r, 1 if vertical else 0)
 
 
 class Multi:

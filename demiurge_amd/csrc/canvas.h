@@ -7,6 +7,7 @@ struct canvas {
     int W, H;
     float c0, c1, c2, c3, circumference;
     int lonwrap, spole, npole;
+    int row0;                  // first grid row a launch computes (blockIdx.y = 0): 0 for a whole grid, a band's row range otherwise
 };
 
 static inline canvas make_canvas(const dmg_grid &g, const dmg_topology &t)
@@ -16,6 +17,7 @@ static inline canvas make_canvas(const dmg_grid &g, const dmg_topology &t)
     c.c0 = g.coords[0]; c.c1 = g.coords[1]; c.c2 = g.coords[2]; c.c3 = g.coords[3];
     c.circumference = g.circumference;
     c.lonwrap = t.lonwrap; c.spole = t.spole; c.npole = t.npole;
+    c.row0 = 0;
     return c;
 }
 

@@ -19,7 +19,7 @@
 __global__ __launch_bounds__(256) void k_blur13(canvas c, const float *__restrict__ src, float *__restrict__ dst,
                                                 const float *__restrict__ phifactor, float dirx, float diry)
 {
-    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = c.row0 + (int)blockIdx.y;
     if (x >= c.W) return;
     const float k1 = 1.411764705882353f, k2 = 3.2941176470588234f, k3 = 5.176470588235294f;
     const float w0 = 0.1964825501511404f, w1 = 0.2969069646728344f, w2 = 0.09447039785044732f, w3 = 0.010381362401148057f;
@@ -113,7 +113,7 @@ __device__ __forceinline__ int temperature_shifted(const canvas &c, int x, int s
 __global__ __launch_bounds__(256) void k_temperature_taps(canvas c, const float *__restrict__ cosphi, int *__restrict__ shift,
                                                           int *__restrict__ srow, int *__restrict__ literal_row)
 {
-    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = c.row0 + (int)blockIdx.y;
     if (x >= c.W) return;
     const float factor = cosphi[y];
     const int xm = c.W / 2;
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void k_temperature(canvas c, const float *__re
                                                      const int *__restrict__ shift, const int *__restrict__ srow,
                                                      const int *__restrict__ literal_row, const int *__restrict__ rows)
 {
-    const int y = rows ? rows[blockIdx.y] : (int)blockIdx.y;
+    const int y = rows ? rows[blockIdx.y] : c.row0 + (int)blockIdx.y;
     const int x = blockIdx.x * 256 + threadIdx.x;
     if (x >= c.W) return;
     float factor = cosphi[y];                        // get_texture_laplacian: cos(geo.y) (Shader.h:301-302)
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void k_temperature_v4(canvas c, const float *_
                                                         const int *__restrict__ shift, const int *__restrict__ srow,
                                                         const int *__restrict__ literal_row)
 {
-    const int y = blockIdx.y;
+    const int y = c.row0 + (int)blockIdx.y;
     const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4;
     if (x0 >= c.W || literal_row[y]) return;
     const int W = c.W;
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void k_erosion(canvas c, const float *__restri
                                                  const float *__restrict__ dxrow, const float *__restrict__ dyrow,
                                                  float factor, float slope_exponent, float SLOPE, float pow01)
 {
-    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = c.row0 + (int)blockIdx.y;
     if (x >= c.W) return;
     const int W = c.W, H = c.H;
     size_t i = (size_t)y * W + x;
@@ -306,7 +306,7 @@ __device__ __forceinline__ float d_slope(const canvas &c, const float *img, int 
 __global__ __launch_bounds__(256) void k_thermal_loss(canvas c, const float *__restrict__ img, const float *__restrict__ dxrow,
                                                       const float *__restrict__ dyrow, float *__restrict__ loss)
 {
-    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = c.row0 + (int)blockIdx.y;
     if (x >= c.W) return;
     size_t i = (size_t)y * c.W + x;
     float h = img[i];
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256) void k_thermal_loss(canvas c, const float *__r
 __global__ __launch_bounds__(256) void k_thermal_gain(canvas c, const float *__restrict__ img, const float *__restrict__ loss,
                                                       const float *__restrict__ dxrow, const float *__restrict__ dyrow, float *__restrict__ out)
 {
-    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = c.row0 + (int)blockIdx.y;
     if (x >= c.W) return;
     size_t i = (size_t)y * c.W + x;
     float h = img[i], gain = 0.0f;
@@ -349,7 +349,7 @@ struct ring64 { float cs[64], sn[64]; };      // cos/sin(2*3.14159*i/64) evaluat
 __global__ __launch_bounds__(256) void k_morph(canvas c, const float *__restrict__ src, float *__restrict__ dst,
                                                const float *__restrict__ factor_row, float radius, int use_max, ring64 ring)
 {
-    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = c.row0 + (int)blockIdx.y;
     if (x >= c.W) return;
     float sx = d_stx(c, x), sy = d_sty(c, y);
     float factor = factor_row[y];
@@ -430,20 +430,36 @@ struct dmg_climate {
     dev_buf a, b, terr, dlat, dcos, ddy, drden, dasr, dshift, dsrow, dlit;
     dev_buf dlitrows;
     int n_literal = 0;                               // rows that keep the literal taps (their indices in dlitrows)
+    std::vector<int> lit_rows;                       // the same list on the host (ascending), to launch the rows of a range
     float *cur = nullptr, *nxt = nullptr;
     bool taps_ready = false;
+    // latitude band (count == 1: the whole grid): owned rows [y0, y1), gs / gn ghost rows, L stored rows; the field
+    // pointers handed to the kernels are "virtual": base - (y0 - gs) * W, so that a kernel indexes them by grid row
+    int rank = 0, count = 1, ghost = 0, y0 = 0, y1 = 0, gs = 0, gn = 0, L = 0;
+    size_t voff() const { return (size_t)(y0 - gs) * grid.W; }
 };
 
 int dmg_climate_create(dmg_ctx *ctx, const dmg_grid *grid, const float *T, const float *terrain, dmg_climate **out)
+{
+    return dmg_climate_create_band(ctx, grid, T, terrain, 0, 1, 0, out);
+}
+
+int dmg_climate_create_band(dmg_ctx *ctx, const dmg_grid *grid, const float *T, const float *terrain, int band_rank, int band_count,
+                            int ghost, dmg_climate **out)
 {
     DMG_CHECK_ARG(ctx != nullptr && T != nullptr && terrain != nullptr && out != nullptr);
     *out = nullptr;
     dmg_topology topo;
     int rc = dmg_check_grid(grid, &topo);
     if (rc) return rc;
+    DMG_CHECK_ARG(band_count >= 1 && band_rank >= 0 && band_rank < band_count && (band_count == 1 || ghost >= 1));
+    DMG_CHECK_ARG(band_count == 1 || grid->H / band_count >= ghost);
     DMG_HIP(hipSetDevice(ctx->device));
     const int H = grid->H;
-    const size_t n = (size_t)grid->W * H;
+    const int by0 = dmg_band_row0(H, band_count, band_rank), by1 = dmg_band_row0(H, band_count, band_rank + 1);
+    const int bgs = band_rank > 0 ? ghost : 0, bgn = band_rank < band_count - 1 ? ghost : 0, bL = bgs + (by1 - by0) + bgn;
+    const size_t n = (size_t)grid->W * bL;
+    const size_t src_off = (size_t)(by0 - bgs) * grid->W;
     std::vector<float> lat(H), cosphi(H), dyr(H), rden(H);
     for (int y = 0; y < H; y++) {
         float dx, dy;
@@ -456,12 +472,14 @@ int dmg_climate_create(dmg_ctx *ctx, const dmg_grid *grid, const float *T, const
     std::unique_ptr<dmg_climate> k(new (std::nothrow) dmg_climate);
     if (!k) return dmg_fail(DMG_ENOMEM, "out of host memory");
     k->ctx = ctx; k->grid = *grid; k->topo = topo;
+    k->rank = band_rank; k->count = band_count; k->ghost = ghost; k->y0 = by0; k->y1 = by1; k->gs = bgs; k->gn = bgn; k->L = bL;
     DMG_ALLOC(k->a, n * 4); DMG_ALLOC(k->b, n * 4); DMG_ALLOC(k->terr, n * 4); DMG_ALLOC(k->dasr, (size_t)H * 4);
     DMG_ALLOC(k->dshift, (size_t)H * 9 * sizeof(int)); DMG_ALLOC(k->dsrow, (size_t)H * 9 * sizeof(int)); DMG_ALLOC(k->dlit, (size_t)H * sizeof(int));
     if ((rc = upload_rows(ctx, k->dlat, lat)) || (rc = upload_rows(ctx, k->dcos, cosphi)) || (rc = upload_rows(ctx, k->ddy, dyr)) ||
         (rc = upload_rows(ctx, k->drden, rden))) return rc;
-    DMG_HIP(hipMemcpyAsync(k->a.p, T, n * 4, hipMemcpyHostToDevice, ctx->stream));
-    DMG_HIP(hipMemcpyAsync(k->terr.p, terrain, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    DMG_HIP(hipMemcpyAsync(k->a.p, T + src_off, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    DMG_HIP(hipMemcpyAsync(k->b.p, T + src_off, n * 4, hipMemcpyHostToDevice, ctx->stream));      // (rows a band step does not write keep a defined value)
+    DMG_HIP(hipMemcpyAsync(k->terr.p, terrain + src_off, n * 4, hipMemcpyHostToDevice, ctx->stream));
     DMG_HIP(hipStreamSynchronize(ctx->stream));      // the caller's buffers may go away
     k->cur = k->a.f(); k->nxt = k->b.f();
     dmg_ctx_retain(ctx);
@@ -484,7 +502,11 @@ int dmg_climate_steps(dmg_climate *k, int first_step, int n_steps)
     DMG_HIP(hipSetDevice(ctx->device));
     canvas c = make_canvas(k->grid, k->topo);
     const int W = k->grid.W, H = k->grid.H;
-    dim3 g((W + 255) / 256, H);
+    if (k->count > 1 && n_steps > k->ghost)
+        return dmg_fail(DMG_EINVAL, "%d climate steps between halo refreshes but only %d ghost rows", n_steps, k->ghost);
+    const int first_row = k->y0 - k->gs;             // stored rows
+    c.row0 = first_row;
+    dim3 g((W + 255) / 256, k->L);
     const float sin_gamma = sinf(23.44f / 180.0f * DMG_PI);   // sin(gamma): an expression of constants, folded by Mesa on the host
     const float ref_t4 = powf(273.4f, 4.0f);                  // pow(273.4,4) (:125), likewise (not 273.4^2 squared: one ulp apart)
     const temp_consts tc = { ref_t4, 1.0f / ref_t4, 1.0f / 15000.0f, 1.0f / 1.5e7f, 1.0f / 7e7f };   // host IEEE divisions: correctly rounded reciprocals
@@ -498,27 +520,39 @@ int dmg_climate_steps(dmg_climate *k, int first_step, int n_steps)
             std::vector<int> lit(H), rows;
             DMG_HIP(hipMemcpyAsync(lit.data(), k->dlit.p, (size_t)H * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
             DMG_HIP(hipStreamSynchronize(ctx->stream));
-            for (int y = 0; y < H; y++) if (lit[y]) rows.push_back(y);
+            for (int y = first_row; y < first_row + k->L; y++) if (lit[y]) rows.push_back(y);
             k->n_literal = (int)rows.size();
+            k->lit_rows = rows;
             if (k->n_literal) { int rc = upload_vec(ctx, k->dlitrows, rows); if (rc) return rc; }
             if (getenv("DMG_TEMPERATURE_REPORT"))       // experiments
                 fprintf(stderr, "dmg_climate_steps: %d of %d rows keep the literal offset() path\n", k->n_literal, H);
         }
         k->taps_ready = true;
     }
-    for (int i = first_step; i < first_step + n_steps; i++) {
+    const float *terr_v = k->terr.f() - k->voff();
+    for (int i = first_step, s = 1; i < first_step + n_steps; i++, s++) {
+        // rows whose nine taps are current s steps after the last halo refresh: the region shrinks a row per step on
+        // every side that has a neighbour band (the whole grid when there is none)
+        const int lo = k->gs ? first_row + s : k->y0, hi = k->gn ? first_row + k->L - s : k->y1;
+        const int nrows = hi - lo;
+        c.row0 = lo;
+        const float *cur_v = k->cur - k->voff();
+        float *nxt_v = k->nxt - k->voff();
         float M = (float)(M_PI * 2 / 15000 * i);     // glUniform1f(id, M_PI*2/15000*i) (:146)
         hipLaunchKernelGGL(k_temperature_rows, dim3((H + 255) / 256), dim3(256), 0, ctx->stream, c, k->dlat.f(), M, sin_gamma, k->dasr.f());
         if (W % 4 == 0) {                            // tabled rows four cells per thread, the few literal rows one cell per thread
-            hipLaunchKernelGGL(k_temperature_v4, dim3((W / 4 + 255) / 256, H), dim3(256), 0, ctx->stream, c, k->cur, k->nxt, k->terr.f(),
+            hipLaunchKernelGGL(k_temperature_v4, dim3((W / 4 + 255) / 256, nrows), dim3(256), 0, ctx->stream, c, cur_v, nxt_v, terr_v,
                                k->dasr.f(), k->ddy.f(), k->drden.f(), tc, (const int *)k->dshift.p, (const int *)k->dsrow.p, (const int *)k->dlit.p);
-            if (k->n_literal)
-                hipLaunchKernelGGL(k_temperature, dim3((W + 255) / 256, k->n_literal), dim3(256), 0, ctx->stream, c, k->cur, k->nxt, k->terr.f(),
+            const int l0 = (int)(std::lower_bound(k->lit_rows.begin(), k->lit_rows.end(), lo) - k->lit_rows.begin());
+            const int l1 = (int)(std::lower_bound(k->lit_rows.begin(), k->lit_rows.end(), hi) - k->lit_rows.begin());
+            if (l1 > l0)
+                hipLaunchKernelGGL(k_temperature, dim3((W + 255) / 256, l1 - l0), dim3(256), 0, ctx->stream, c, cur_v, nxt_v, terr_v,
                                    k->dasr.f(), k->dcos.f(), k->ddy.f(), k->drden.f(), tc, (const int *)k->dshift.p, (const int *)k->dsrow.p,
-                                   (const int *)k->dlit.p, (const int *)k->dlitrows.p);
+                                   (const int *)k->dlit.p, (const int *)k->dlitrows.p + l0);
         } else {
-            hipLaunchKernelGGL(k_temperature, g, dim3(256), 0, ctx->stream, c, k->cur, k->nxt, k->terr.f(), k->dasr.f(), k->dcos.f(), k->ddy.f(),
-                               k->drden.f(), tc, (const int *)k->dshift.p, (const int *)k->dsrow.p, (const int *)k->dlit.p, (const int *)nullptr);
+            hipLaunchKernelGGL(k_temperature, dim3((W + 255) / 256, nrows), dim3(256), 0, ctx->stream, c, cur_v, nxt_v, terr_v, k->dasr.f(),
+                               k->dcos.f(), k->ddy.f(), k->drden.f(), tc, (const int *)k->dshift.p, (const int *)k->dsrow.p, (const int *)k->dlit.p,
+                               (const int *)nullptr);
         }
         DMG_HIP(hipGetLastError());
         std::swap(k->cur, k->nxt);                   // terrain.swap(scratch2) (:148)
@@ -530,8 +564,23 @@ int dmg_climate_get(dmg_climate *k, float *T)
 {
     DMG_CHECK_ARG(k != nullptr && T != nullptr);
     DMG_HIP(hipSetDevice(k->ctx->device));
-    DMG_HIP(hipMemcpyAsync(T, k->cur, (size_t)k->grid.W * k->grid.H * 4, hipMemcpyDeviceToHost, k->ctx->stream));
+    // owned rows into the FULL-grid array (the whole field when there is one band)
+    DMG_HIP(hipMemcpyAsync(T + (size_t)k->y0 * k->grid.W, k->cur + (size_t)k->gs * k->grid.W, (size_t)k->grid.W * (k->y1 - k->y0) * 4,
+                           hipMemcpyDeviceToHost, k->ctx->stream));
     DMG_HIP(hipStreamSynchronize(k->ctx->stream));
+    return DMG_OK;
+}
+
+// ghost slabs of the temperature field, as dmg_ocean_halo
+int dmg_climate_halo(dmg_climate *k, int side, int rows, void **send, void **recv, size_t *bytes)
+{
+    DMG_CHECK_ARG(k != nullptr && send != nullptr && recv != nullptr && bytes != nullptr && (side == DMG_SIDE_SOUTH || side == DMG_SIDE_NORTH));
+    DMG_CHECK_ARG(rows >= 1 && rows <= std::max(k->ghost, 1));
+    const size_t row = (size_t)k->grid.W;
+    const int own = k->y1 - k->y0;
+    *send = *recv = nullptr; *bytes = 0;
+    if (side == DMG_SIDE_SOUTH && k->gs) { *send = k->cur + row * k->gs; *recv = k->cur + row * (k->gs - rows); *bytes = row * rows * 4; }
+    else if (side == DMG_SIDE_NORTH && k->gn) { *send = k->cur + row * (k->gs + own - rows); *recv = k->cur + row * (k->gs + own); *bytes = row * rows * 4; }
     return DMG_OK;
 }
 
@@ -780,6 +829,243 @@ int dmg_morphological_gradient(dmg_ctx *ctx, const dmg_grid *grid, float *field,
     DMG_HIP(hipGetLastError());
     DMG_HIP(hipMemcpyAsync(field, out, n * 4, hipMemcpyDeviceToHost, ctx->stream));
     DMG_HIP(hipStreamSynchronize(ctx->stream));
+    return DMG_OK;
+}
+
+}  // extern "C"
+
+// =================================================================================================================
+// Latitude-band forms of the generic filters (blur, temperature, erosion pass, thermal erosion
+// shard by latitude band with 1-row / ceil(5.18 r)+1-row halos).  A dmg_field is one scalar field of one band, resident
+// on the device with `ghost` rows towards each neighbouring band -- the same layout and the same dmg_*_halo slabs as a
+// dmg_ocean band.  The kernels are the whole-grid kernels: they index a field by GRID row, so a band hands them
+// base - (y0 - gs) * W ("virtual" base) and a row range (canvas::row0 + gridDim.y); the canvas keeps the full grid's
+// topology, so wrap, pole reflection (lon += pi) and CLAMP_TO_EDGE resolve exactly as on one GPU.  A pass computes the
+// band's OWNED rows from a field whose ghost rows the host has refreshed as deep as the pass reads
+// (dmg_field_halo -> RCCL send/recv, or dmg_fields_exchange for bands living in one process).
+// =================================================================================================================
+struct dmg_field {
+    dmg_ctx *ctx = nullptr;
+    dmg_grid grid{};
+    dmg_topology topo{};
+    int rank = 0, count = 1, ghost = 0, y0 = 0, y1 = 0, gs = 0, gn = 0, L = 0;
+    float *d[2] = { nullptr, nullptr };
+    int cur = 0;
+    dev_buf dpf, ddx, ddy;                           // per-row tables of the whole grid (tiny): blur's cos|lat|, pixelsize x / y
+    bool tables = false;
+    float *virt(int k) const { return d[k] - (size_t)(y0 - gs) * grid.W; }
+};
+
+static int field_tables(dmg_field *f)
+{
+    if (f->tables) return DMG_OK;
+    const int H = f->grid.H;
+    std::vector<float> pf(H), dxr(H), dyr(H);
+    for (int y = 0; y < H; y++) {
+        pf[y] = glsl::cos(fabsf(dmg_row_lat(f->grid, y)));                       // BlurMenu.cpp:49
+        dmg_row_pixelsize(f->grid, y, &dxr[y], &dyr[y]);
+    }
+    dmg_ctx *ctx = f->ctx;
+    int rc;
+    if ((rc = upload_rows(ctx, f->dpf, pf)) || (rc = upload_rows(ctx, f->ddx, dxr)) || (rc = upload_rows(ctx, f->ddy, dyr))) return rc;
+    f->tables = true;
+    return DMG_OK;
+}
+
+static bool same_band(const dmg_field *a, const dmg_field *b)
+{
+    return a->grid.W == b->grid.W && a->grid.H == b->grid.H && a->y0 == b->y0 && a->y1 == b->y1 && a->gs == b->gs && a->gn == b->gn &&
+           a->ctx->device == b->ctx->device;
+}
+
+extern "C" {
+
+int dmg_field_create(dmg_ctx *ctx, const dmg_grid *grid, int band_rank, int band_count, int ghost, dmg_field **out)
+{
+    DMG_CHECK_ARG(ctx != nullptr && out != nullptr);
+    *out = nullptr;
+    dmg_topology topo;
+    int rc = dmg_check_grid(grid, &topo);
+    if (rc) return rc;
+    DMG_CHECK_ARG(band_count >= 1 && band_rank >= 0 && band_rank < band_count && ghost >= 0 && (band_count == 1 || ghost >= 1));
+    DMG_CHECK_ARG(band_count == 1 || grid->H / band_count >= ghost);
+    DMG_HIP(hipSetDevice(ctx->device));
+    std::unique_ptr<dmg_field> f(new (std::nothrow) dmg_field);
+    if (!f) return dmg_fail(DMG_ENOMEM, "out of host memory");
+    f->ctx = ctx; f->grid = *grid; f->topo = topo;
+    f->rank = band_rank; f->count = band_count; f->ghost = ghost;
+    f->y0 = dmg_band_row0(grid->H, band_count, band_rank);
+    f->y1 = dmg_band_row0(grid->H, band_count, band_rank + 1);
+    f->gs = band_rank > 0 ? ghost : 0;
+    f->gn = band_rank < band_count - 1 ? ghost : 0;
+    f->L = f->gs + (f->y1 - f->y0) + f->gn;
+    const size_t bytes = (size_t)f->L * grid->W * 4;
+    if (hipMalloc((void **)&f->d[0], bytes) != hipSuccess || hipMalloc((void **)&f->d[1], bytes) != hipSuccess) {
+        if (f->d[0]) (void)hipFree(f->d[0]);
+        return dmg_fail(DMG_ENOMEM, "hipMalloc of a %d-row band failed", f->L);
+    }
+    DMG_HIP(hipMemsetAsync(f->d[0], 0, bytes, ctx->stream));
+    DMG_HIP(hipMemsetAsync(f->d[1], 0, bytes, ctx->stream));
+    dmg_ctx_retain(ctx);
+    *out = f.release();
+    return DMG_OK;
+}
+
+void dmg_field_destroy(dmg_field *f)
+{
+    if (!f) return;
+    dmg_ctx *ctx = f->ctx;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (f->d[0]) (void)hipFree(f->d[0]);
+    if (f->d[1]) (void)hipFree(f->d[1]);
+    delete f;
+    dmg_ctx_release(ctx);
+}
+
+// band + ghost rows out of a FULL-grid host array (Texture::uploadData side)
+int dmg_field_set(dmg_field *f, const float *full)
+{
+    DMG_CHECK_ARG(f != nullptr && full != nullptr);
+    DMG_HIP(hipSetDevice(f->ctx->device));
+    DMG_HIP(hipMemcpyAsync(f->d[f->cur], full + (size_t)(f->y0 - f->gs) * f->grid.W, (size_t)f->L * f->grid.W * 4, hipMemcpyHostToDevice,
+                           f->ctx->stream));
+    DMG_HIP(hipStreamSynchronize(f->ctx->stream));
+    return DMG_OK;
+}
+
+// owned rows into a FULL-grid host array (Texture::downloadDataRAW side)
+int dmg_field_get(dmg_field *f, float *full)
+{
+    DMG_CHECK_ARG(f != nullptr && full != nullptr);
+    DMG_HIP(hipSetDevice(f->ctx->device));
+    DMG_HIP(hipMemcpyAsync(full + (size_t)f->y0 * f->grid.W, f->d[f->cur] + (size_t)f->gs * f->grid.W,
+                           (size_t)(f->y1 - f->y0) * f->grid.W * 4, hipMemcpyDeviceToHost, f->ctx->stream));
+    DMG_HIP(hipStreamSynchronize(f->ctx->stream));
+    return DMG_OK;
+}
+
+int dmg_field_halo(dmg_field *f, int side, int rows, void **send, void **recv, size_t *bytes)
+{
+    DMG_CHECK_ARG(f != nullptr && send != nullptr && recv != nullptr && bytes != nullptr && (side == DMG_SIDE_SOUTH || side == DMG_SIDE_NORTH));
+    DMG_CHECK_ARG(rows >= 1 && rows <= std::max(f->ghost, 1));
+    const size_t row = (size_t)f->grid.W;
+    const int own = f->y1 - f->y0;
+    float *base = f->d[f->cur];
+    *send = *recv = nullptr; *bytes = 0;
+    if (side == DMG_SIDE_SOUTH && f->gs) { *send = base + row * f->gs; *recv = base + row * (f->gs - rows); *bytes = row * rows * 4; }
+    else if (side == DMG_SIDE_NORTH && f->gn) { *send = base + row * (f->gs + own - rows); *recv = base + row * (f->gs + own); *bytes = row * rows * 4; }
+    return DMG_OK;
+}
+
+// One halo refresh among the n bands of a field that live in THIS process (bands[i] = band i of n, any devices):
+// every band pulls its ghost rows from its neighbours' owned rows with peer copies on its own stream, ordered by events.
+int dmg_fields_exchange(dmg_field *const *bands, int n, int rows)
+{
+    DMG_CHECK_ARG(bands != nullptr && n >= 1 && rows >= 1);
+    if (n == 1) return DMG_OK;
+    std::vector<hipEvent_t> done(n, nullptr), copied(n, nullptr);
+    int rc = DMG_OK;
+    auto cleanup = [&] { for (hipEvent_t e : done) if (e) (void)hipEventDestroy(e); for (hipEvent_t e : copied) if (e) (void)hipEventDestroy(e); };
+    for (int i = 0; i < n && !rc; i++) {
+        DMG_CHECK_ARG(bands[i] != nullptr && bands[i]->rank == i && bands[i]->count == n);
+        if (hipSetDevice(bands[i]->ctx->device) != hipSuccess || hipEventCreateWithFlags(&done[i], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&copied[i], hipEventDisableTiming) != hipSuccess || hipEventRecord(done[i], bands[i]->ctx->stream) != hipSuccess)
+            rc = dmg_fail(DMG_EHIP, "dmg_fields_exchange: event set-up failed");
+    }
+    for (int i = 0; i < n && !rc; i++) {
+        dmg_field *f = bands[i];
+        (void)hipSetDevice(f->ctx->device);
+        for (int side = 0; side < 2 && !rc; side++) {
+            const int j = side == DMG_SIDE_SOUTH ? i - 1 : i + 1;
+            if (j < 0 || j >= n) continue;
+            void *send, *recv, *nsend, *nrecv; size_t bytes, nbytes;
+            if ((rc = dmg_field_halo(f, side, rows, &send, &recv, &bytes)) || (rc = dmg_field_halo(bands[j], side ^ 1, rows, &nsend, &nrecv, &nbytes))) break;
+            if (hipStreamWaitEvent(f->ctx->stream, done[j], 0) != hipSuccess ||
+                hipMemcpyPeerAsync(recv, f->ctx->device, nsend, bands[j]->ctx->device, bytes, f->ctx->stream) != hipSuccess)
+                rc = dmg_fail(DMG_EHIP, "dmg_fields_exchange: peer copy failed");
+        }
+        if (!rc && hipEventRecord(copied[i], f->ctx->stream) != hipSuccess) rc = dmg_fail(DMG_EHIP, "hipEventRecord failed");
+    }
+    for (int i = 0; i < n && !rc; i++)
+        for (int j : { i - 1, i + 1 })
+            if (j >= 0 && j < n && hipStreamWaitEvent(bands[i]->ctx->stream, copied[j], 0) != hipSuccess) rc = dmg_fail(DMG_EHIP, "hipStreamWaitEvent failed");
+    for (int i = 0; i < n; i++) { (void)hipSetDevice(bands[i]->ctx->device); (void)hipStreamSynchronize(bands[i]->ctx->stream); }   // the events go away
+    cleanup();
+    return rc;
+}
+
+// Blur::Blur's radius list (BlurMenu.cpp:27,79-94): Blur::step then runs, per radius, a vertical and a horizontal pass
+int dmg_blur_schedule(float radius, float *r_out, int cap)
+{
+    if (!(radius > 0.0f) || r_out == nullptr || cap <= 0) return dmg_fail(DMG_EINVAL, "dmg_blur_schedule: bad argument");
+    std::vector<float> rl = blur_rlist(radius);
+    if ((int)rl.size() > cap) return dmg_fail(DMG_EINVAL, "dmg_blur_schedule: %zu radii, room for %d", rl.size(), cap);
+    for (size_t i = 0; i < rl.size(); i++) r_out[i] = rl[i];
+    return (int)rl.size();
+}
+
+// ghost rows a pass of radius r reads: the outermost of the 13 taps sits 5.18 r rows away (blur13, BlurMenu.cpp:54-60), the
+// bilinear footprint adds one; a horizontal pass only its own row's bilinear neighbour
+int dmg_field_blur_halo(float r, int vertical) { return vertical ? (int)ceilf(5.1765f * r) + 1 : 1; }
+
+// one pass of Blur::step on the band: (0, r) when vertical, (r, 0) otherwise; the result becomes the current buffer
+int dmg_field_blur_pass(dmg_field *f, float r, int vertical)
+{
+    DMG_CHECK_ARG(f != nullptr && r > 0.0f);
+    if (f->count > 1 && dmg_field_blur_halo(r, vertical) > f->ghost)
+        return dmg_fail(DMG_EINVAL, "blur pass of radius %g reads %d rows beyond the band, %d ghost rows kept", r, dmg_field_blur_halo(r, vertical), f->ghost);
+    DMG_HIP(hipSetDevice(f->ctx->device));
+    int rc = field_tables(f);
+    if (rc) return rc;
+    canvas c = make_canvas(f->grid, f->topo);
+    c.row0 = f->y0;
+    dim3 g((f->grid.W + 255) / 256, f->y1 - f->y0);
+    hipLaunchKernelGGL(k_blur13, g, dim3(256), 0, f->ctx->stream, c, (const float *)f->virt(f->cur), f->virt(f->cur ^ 1), f->dpf.f(),
+                       vertical ? 0.0f : r, vertical ? r : 0.0f);
+    DMG_HIP(hipGetLastError());
+    f->cur ^= 1;
+    return DMG_OK;
+}
+
+// erosion / uplift pass of cpufilter::run (cpufilter.cpp:106-214) on the band: h needs 1 current ghost row; flow and
+// updrift are read at the cell only
+int dmg_field_erosion_pass(dmg_field *h, const dmg_field *flow, const dmg_field *updrift, float factor, float slope_exponent)
+{
+    DMG_CHECK_ARG(h != nullptr && flow != nullptr && updrift != nullptr && same_band(h, flow) && same_band(h, updrift));
+    DMG_HIP(hipSetDevice(h->ctx->device));
+    int rc = field_tables(h);
+    if (rc) return rc;
+    canvas c = make_canvas(h->grid, h->topo);
+    c.row0 = h->y0;
+    const float SLOPE = tanf(DMG_PI / 2.0f / 3.0f), pow01 = glsl::pow(0.1f, slope_exponent);     // as erosion_device
+    dim3 g((h->grid.W + 255) / 256, h->y1 - h->y0);
+    hipLaunchKernelGGL(k_erosion, g, dim3(256), 0, h->ctx->stream, c, (const float *)h->virt(h->cur), (const float *)flow->virt(flow->cur),
+                       (const float *)updrift->virt(updrift->cur), h->virt(h->cur ^ 1), h->ddx.f(), h->ddy.f(), factor, slope_exponent, SLOPE, pow01);
+    DMG_HIP(hipGetLastError());
+    h->cur ^= 1;
+    return DMG_OK;
+}
+
+// one of ThermalErosion::step's ten rounds (ThermalErosion.cpp:25-142) on the band: talus loss on the owned rows and one
+// row beyond them, gain on the owned rows -- h needs 2 current ghost rows, `loss` is scratch of the same band
+int dmg_field_thermal_round(dmg_field *h, dmg_field *loss)
+{
+    DMG_CHECK_ARG(h != nullptr && loss != nullptr && same_band(h, loss));
+    if (h->count > 1 && h->ghost < 2) return dmg_fail(DMG_EINVAL, "a thermal-erosion round reads 2 rows beyond the band, %d ghost rows kept", h->ghost);
+    DMG_HIP(hipSetDevice(h->ctx->device));
+    int rc = field_tables(h);
+    if (rc) return rc;
+    canvas c = make_canvas(h->grid, h->topo);
+    const int lo = h->gs ? h->y0 - 1 : h->y0, hi = h->gn ? h->y1 + 1 : h->y1;
+    c.row0 = lo;
+    hipLaunchKernelGGL(k_thermal_loss, dim3((h->grid.W + 255) / 256, hi - lo), dim3(256), 0, h->ctx->stream, c, (const float *)h->virt(h->cur),
+                       h->ddx.f(), h->ddy.f(), loss->virt(loss->cur));
+    c.row0 = h->y0;
+    hipLaunchKernelGGL(k_thermal_gain, dim3((h->grid.W + 255) / 256, h->y1 - h->y0), dim3(256), 0, h->ctx->stream, c, (const float *)h->virt(h->cur),
+                       (const float *)loss->virt(loss->cur), h->ddx.f(), h->ddy.f(), h->virt(h->cur ^ 1));
+    DMG_HIP(hipGetLastError());
+    h->cur ^= 1;                                      // scratch2.swap(terrain) (:134)
     return DMG_OK;
 }
 

@@ -284,6 +284,13 @@ int dmg_climate_create(dmg_ctx *ctx, const dmg_grid *grid, const float *T, const
 void dmg_climate_destroy(dmg_climate *k);
 int dmg_climate_steps(dmg_climate *k, int first_step, int n_steps);   /* asynchronous on the context's stream */
 int dmg_climate_get(dmg_climate *k, float *T_out);                    /* synchronises */
+/* The same field as one latitude band of a multi-GPU run (the laplacian reads 1 row): rows of band
+ * `band_rank` of `band_count` plus `ghost` rows per side; T and terrain are FULL-grid arrays, the band is sliced out.
+ * dmg_climate_steps then takes n_steps <= ghost between halo refreshes (the computed region shrinks a row per step) and
+ * dmg_climate_get writes the owned rows into a FULL-grid array; dmg_climate_halo = dmg_ocean_halo for the temperature. */
+int dmg_climate_create_band(dmg_ctx *ctx, const dmg_grid *grid, const float *T, const float *terrain, int band_rank, int band_count,
+                            int ghost, dmg_climate **out);
+int dmg_climate_halo(dmg_climate *k, int side, int rows, void **send, void **recv, size_t *bytes);
 /* erosion/uplift pass of cpufilter::run (src/filter/cpufilter.cpp:106-214) */
 int dmg_erosion_pass(dmg_ctx *ctx, const dmg_grid *grid, float *h_inout, const float *flow, const float *updrift,
                      float factor, float slope_exponent);
@@ -319,6 +326,28 @@ int dmg_erosion_create(dmg_ctx *ctx, const dmg_grid *grid, const float *h, int N
 void dmg_erosion_destroy(dmg_erosion *e);
 int dmg_erosion_rounds(dmg_erosion *e, int n_rounds);
 int dmg_erosion_get(dmg_erosion *e, float *h_out);
+
+/* ---- latitude-band forms of the generic filters ---------------------------------------------------------
+ * dmg_field = one scalar field (a Texture, src/Texture.h) of one band, resident on the device with `ghost` rows towards each
+ * neighbouring band: the layout and the halo slabs of a dmg_ocean band.  A pass computes the band's OWNED rows from fields
+ * whose ghost rows are current as deep as the pass reads; the host refreshes them in between (dmg_field_halo slabs over RCCL,
+ * or dmg_fields_exchange for bands that live in one process).  Bit-identical to the whole-grid calls above. */
+typedef struct dmg_field dmg_field;
+int dmg_field_create(dmg_ctx *ctx, const dmg_grid *grid, int band_rank, int band_count, int ghost, dmg_field **out);
+void dmg_field_destroy(dmg_field *f);
+int dmg_field_set(dmg_field *f, const float *full);           /* band + ghost rows out of a FULL-grid array */
+int dmg_field_get(dmg_field *f, float *full);                 /* owned rows into a FULL-grid array */
+int dmg_field_halo(dmg_field *f, int side, int rows, void **send, void **recv, size_t *bytes);
+int dmg_fields_exchange(dmg_field *const *bands, int n, int rows);   /* bands[i] = band i of n, all in this process: peer copies */
+/* Blur (src/filter/BlurMenu.cpp:24-117): dmg_blur_schedule returns Blur::Blur's radius list (count, or < 0); Blur::step is,
+ * per radius r in order, dmg_field_blur_pass(f, r, 1) then (f, r, 0); a pass reads dmg_field_blur_halo(r, vertical) ghost rows */
+int dmg_blur_schedule(float radius, float *r_out, int cap);
+int dmg_field_blur_halo(float r, int vertical);
+int dmg_field_blur_pass(dmg_field *f, float r, int vertical);
+/* erosion/uplift pass (cpufilter.cpp:106-214): h reads 1 ghost row; flow / updrift at the cell */
+int dmg_field_erosion_pass(dmg_field *h, const dmg_field *flow, const dmg_field *updrift, float factor, float slope_exponent);
+/* one of ThermalErosion::step's ten rounds (ThermalErosion.cpp:25-142): h reads 2 ghost rows; `loss` = scratch of the same band */
+int dmg_field_thermal_round(dmg_field *h, dmg_field *loss);
 
 /* ---- SURVEY.md section 8(f) "next" rows: adjacent Filter-menu tools on the same stencil skeleton ---- */
 /* ThermalErosion::step (src/filter/ThermalErosion.cpp:25-142): 10 rounds of talus loss + gain, in place */
