@@ -40,6 +40,12 @@ class OceanParams(ctypes.Structure):
                 ("wind", ctypes.c_float), ("quirks", ctypes.c_int), ("jacobi_kernel", ctypes.c_int)]
 
 
+class WorldParams(ctypes.Structure):
+    _fields_ = [("tectonics_steps", ctypes.c_int), ("erosion_rounds", ctypes.c_int), ("climate_steps", ctypes.c_int),
+                ("erosion_N", ctypes.c_int), ("exponent", ctypes.c_float), ("slope_exponent", ctypes.c_float), ("factor", ctypes.c_float),
+                ("lakes", ctypes.c_int)]
+
+
 class MultiStats(ctypes.Structure):
     _fields_ = [("bands_total", ctypes.c_int), ("bands_local", ctypes.c_int), ("transport", ctypes.c_int), ("order", ctypes.c_int),
                 ("ghost", ctypes.c_int), ("exchanges", ctypes.c_longlong), ("exchange_ms", ctypes.c_double),
@@ -183,6 +189,12 @@ def lib():
         "dmg_tectonics_get_plate": (c_int, [vp, c_int, vp]),
         "dmg_climate_create_band": (c_int, [vp, PG, vp, vp, c_int, c_int, c_int, ctypes.POINTER(vp)]),
         "dmg_climate_halo": (c_int, [vp, c_int, c_int, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(sz)]),
+        "dmg_climate_set_terrain": (c_int, [vp, vp]),
+        "dmg_world_params_default": (None, [ctypes.POINTER(WorldParams)]),
+        "dmg_world_create": (c_int, [vp, PG, vp, vp, ctypes.POINTER(vp)]),
+        "dmg_world_destroy": (None, [vp]),
+        "dmg_world_step": (c_int, [vp, ctypes.POINTER(WorldParams)]),
+        "dmg_world_get": (c_int, [vp, vp, vp, vp]),
         "dmg_field_create": (c_int, [vp, PG, c_int, c_int, c_int, ctypes.POINTER(vp)]),
         "dmg_field_destroy": (None, [vp]),
         "dmg_field_set": (c_int, [vp, vp]),
@@ -591,6 +603,43 @@ class Ocean:
         if "v" in want:
             res["v"] = np.stack([arr["vx"], arr["vy"]], axis=-1)
         return res
+
+
+class World:
+    """dmg_world: BASELINE config 5, tectonic uplift -> erosion -> climate on one terrain"""
+
+    def __init__(self, ctx, grid, terrain, T0):
+        self.ctx, self.grid = ctx, grid
+        h = ctypes.c_void_p()
+        check(lib().dmg_world_create(ctx.h, ctypes.byref(grid), _p(_f32(terrain)), _p(_f32(T0)), ctypes.byref(h)))
+        self.h = h
+        ctx._children.add(self)
+
+    def close(self):
+        if self.h:
+            lib().dmg_world_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def default_params():
+        p = WorldParams()
+        lib().dmg_world_params_default(ctypes.byref(p))
+        return p
+
+    def step(self, params=None):
+        check(lib().dmg_world_step(self.h, None if params is None else ctypes.byref(params)))
+
+    def get(self):
+        H, W = self.grid.H, self.grid.W
+        t, e, T = (np.empty((H, W), np.float32) for _ in range(3))
+        check(lib().dmg_world_get(self.h, _p(t), _p(e), _p(T)))
+        return dict(terrain=t, eroded=e, T=T)
 
 
 class Field:

@@ -571,6 +571,16 @@ int dmg_climate_get(dmg_climate *k, float *T)
     return DMG_OK;
 }
 
+// new heights under the same climate field (only their sign matters, :131-132): FULL-grid array, the band is sliced out
+int dmg_climate_set_terrain(dmg_climate *k, const float *terrain)
+{
+    DMG_CHECK_ARG(k != nullptr && terrain != nullptr);
+    DMG_HIP(hipSetDevice(k->ctx->device));
+    DMG_HIP(hipMemcpyAsync(k->terr.p, terrain + k->voff(), (size_t)k->grid.W * k->L * 4, hipMemcpyHostToDevice, k->ctx->stream));
+    DMG_HIP(hipStreamSynchronize(k->ctx->stream));
+    return DMG_OK;
+}
+
 // ghost slabs of the temperature field, as dmg_ocean_halo
 int dmg_climate_halo(dmg_climate *k, int side, int rows, void **send, void **recv, size_t *bytes)
 {

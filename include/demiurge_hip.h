@@ -291,6 +291,7 @@ int dmg_climate_get(dmg_climate *k, float *T_out);                    /* synchro
 int dmg_climate_create_band(dmg_ctx *ctx, const dmg_grid *grid, const float *T, const float *terrain, int band_rank, int band_count,
                             int ghost, dmg_climate **out);
 int dmg_climate_halo(dmg_climate *k, int side, int rows, void **send, void **recv, size_t *bytes);
+int dmg_climate_set_terrain(dmg_climate *k, const float *terrain);   /* new heights (FULL-grid array) under the same field */
 /* erosion/uplift pass of cpufilter::run (src/filter/cpufilter.cpp:106-214) */
 int dmg_erosion_pass(dmg_ctx *ctx, const dmg_grid *grid, float *h_inout, const float *flow, const float *updrift,
                      float factor, float slope_exponent);
@@ -418,6 +419,26 @@ int dmg_tectonics_get_map(dmg_tectonics *t, float *rgba);
 int dmg_tectonics_plate_count(const dmg_tectonics *t);
 int dmg_tectonics_plate_size(const dmg_tectonics *t, int plate, int *w, int *h);
 int dmg_tectonics_get_plate(dmg_tectonics *t, int plate, float *rgba);
+
+/* ---- BASELINE.json config 5: tectonic uplift + stream-power erosion + year-cycle climate on one terrain ----------------
+ * The reference applies its tools one after the other to the shared terrain layer; this handle is that sequence behind the
+ * C ABI.  One dmg_world_step = Tectonics::run steps (tectonics/Tectonics.cpp:156-275) -> cpufilter::run rounds on the
+ * rendered terrain (cpufilter.cpp:41-222) -> Temperature::run steps over the eroded land/sea mask, the orbital phase
+ * advancing through the year from step to step (Temperature.cpp:140-150).  One-way coupling, as in the editor. */
+typedef struct dmg_world dmg_world;
+typedef struct {
+    int tectonics_steps, erosion_rounds, climate_steps;      /* per dmg_world_step; 0 skips a stage */
+    int erosion_N;                                           /* cpufilter's N = 50 (:42) */
+    float exponent, slope_exponent, factor;                  /* the erosion menu's 0.5, 1, 1 (cpufilter.h:18-21) */
+    int lakes;
+} dmg_world_params;
+void dmg_world_params_default(dmg_world_params *p);
+int dmg_world_create(dmg_ctx *ctx, const dmg_grid *grid, const float *terrain, const float *T0, dmg_world **out);
+void dmg_world_destroy(dmg_world *w);
+int dmg_world_step(dmg_world *w, const dmg_world_params *params_or_null);
+/* terrain = what the tectonics render pass left; eroded = after the erosion rounds (scaled by 1/N like the reference's
+ * terrain texture); T = the climate field.  NULL skips. */
+int dmg_world_get(dmg_world *w, float *terrain, float *eroded, float *T);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,79 @@
+"""BASELINE.json config 5: coupled tectonic uplift + stream-power erosion + year-cycle climate (dmg_world)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from demiurge_amd import capi
+    ctx = capi.Context(0)
+    yield capi, ctx
+    ctx.close()
+
+
+def inputs(W, H):
+    from demiurge_amd import synth
+    terrain = (synth.terrain(W, H) * 100).astype(np.float32)
+    T0 = (15 - 40 * np.abs(np.linspace(-1, 1, H, dtype=np.float32))[:, None] + np.zeros((1, W), np.float32)).astype(np.float32)
+    return terrain, T0
+
+
+def test_world_is_the_sequence_of_its_tools(dev):
+    """one coupled iteration == Tectonics step -> erosion rounds on its terrain -> climate steps on the eroded terrain, through
+    the individual handles"""
+    capi, ctx = dev
+    W, H = 512, 256
+    grid = capi.make_grid(W, H)
+    terrain, T0 = inputs(W, H)
+    p = capi.World.default_params()
+    p.tectonics_steps, p.erosion_rounds, p.climate_steps = 2, 2, 5
+    w = capi.World(ctx, grid, terrain, T0)
+    w.step(p)
+    w.step(p)
+    got = w.get()
+    w.close()
+    t = capi.Tectonics(ctx, grid, terrain)
+    k = capi.Climate(ctx, grid, T0, terrain)
+    for it in range(2):
+        t.step(2)
+        tt = t.terrain()
+        er = ctx.erosion_run(grid, tt, 50, 2, 0.5, 1.0, 1.0)
+        from demiurge_amd.capi import lib, check, _p
+        check(lib().dmg_climate_set_terrain(k.h, _p(er)))
+        k.steps(5 * it, 5)
+    assert np.array_equal(got["terrain"], tt) and np.array_equal(got["eroded"], er) and np.array_equal(got["T"], k.get())
+    t.close(); k.close()
+
+
+def test_config5_at_size(dev):
+    """16384x8192: one coupled iteration (tectonics step -> erosion round -> climate steps): finite, deterministic, the
+    stages' invariants hold at the BASELINE size"""
+    capi, ctx = dev
+    W, H = 16384, 8192
+    grid = capi.make_grid(W, H)
+    terrain, T0 = inputs(W, H)
+    p = capi.World.default_params()
+    p.tectonics_steps, p.erosion_rounds, p.climate_steps = 1, 1, 3
+    runs = []
+    for _ in range(2):
+        w = capi.World(ctx, grid, terrain, T0)
+        w.step(p)
+        runs.append(w.get())
+        w.close()
+        ctx.trim()
+    a, b = runs
+    for k in ("terrain", "eroded", "T"):
+        assert np.array_equal(a[k], b[k]), k                     # deterministic
+        assert np.isfinite(a[k]).all(), k
+    # what the reference's render pass leaves in the terrain is collision()'s plateIndices.x (Tectonics.cpp:186-210,:590):
+    # the plate map, a handful of distinct values -- reproduced, and it is what the erosion rounds then work on
+    vals = np.unique(a["terrain"][::64, ::64])
+    assert 2 <= len(vals) <= 16
+    sea = a["terrain"] <= 0
+    assert np.array_equal(a["eroded"][sea], a["terrain"][sea])   # `if (h<=0) return;` (cpufilter.cpp:126): the sea is untouched
+    land = ~sea
+    assert (a["eroded"][land] <= a["terrain"][land] / np.float32(50) + 3 * np.tan(np.pi / 6) * np.hypot(42000 / W, 21000 / H) + 1e-3).all()
+    assert not np.array_equal(a["T"], T0)                        # the climate moved ...
+    assert np.abs(a["T"] - T0).max() < 50                        # ... by a few steps' worth, nowhere near blowing up
