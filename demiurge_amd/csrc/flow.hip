@@ -324,6 +324,74 @@ __global__ void k_flow_level(flow_canvas fc, const int *__restrict__ order, int 
     acc[p] = sum;
 }
 
+// Upstream-area sums as a dataflow instead of one launch per depth level.  The level-synchronous form is bound by the
+// ~5 us a dependent launch costs, times the depth of the drainage forest (1 800 levels at 4096x2048: 9 ms of a 21 ms
+// erosion round); the arithmetic itself is a few adds per cell.  Here a persistent grid walks the cells in depth order,
+// deepest first, 64 cells per wave ticket; a cell waits until the sums it adds have been published (a sum is its own
+// ready flag: the array starts as NaN bit patterns), adds them in FlowFilter::neighbours order plus its connected lake
+// -- the reference's fp32 sums, whatever the timing -- and publishes its own.  Every cell a ticket waits for has a
+// smaller ticket, held by a wave that is already running, so the grid always drains; the critical path is the longest
+// river times one L2 round trip.  Values cross CUs through sc1 (L2) loads and stores.  A poll budget turns a protocol
+// error into a failed call instead of a hung GPU.
+#define FLOW_NOT_READY 0xFFFFFFFFu
+__global__ __launch_bounds__(256) void k_flow_dataflow(flow_canvas fc, const int *__restrict__ order, int n_reached,
+                                                       const unsigned short *__restrict__ mask, const int *__restrict__ conn_from,
+                                                       const float *__restrict__ own_row, unsigned *acc, int *ticket, int *error)
+{
+    const int W = fc.c.W, H = fc.c.H;
+    const int lane = threadIdx.x & 63;
+    for (;;) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(ticket, 64);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base >= n_reached) return;
+        const int idx = n_reached - 1 - (base + lane);       // deepest cells first
+        bool pending = idx >= 0;
+        int p = 0, nsrc = 0, src[9];
+        float own = 0.0f;
+        if (pending) {
+            p = order[idx];
+            const int x0 = p % W, y0 = p / W;
+            own = own_row[y0];                               // pixelwidthy*pixelwidthx*cos(geoy)*1e-5 (:608-613)
+            const unsigned m = mask[p];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {                    // FlowFilter::neighbours order (:614-616)
+                if (!(m & (unsigned)c_nbit[k])) continue;
+                int x = x0 + c_ndx[k], y = y0 + c_ndy[k];
+                if (fc.wrap) x = (x + W) % W; else if (x < 0 || x >= W) continue;
+                if (y < 0 || y >= H) continue;
+                src[nsrc++] = y * W + x;
+            }
+            const int from = conn_from[p];
+            if (from >= 0) src[nsrc++] = from;               // sum += rec(connections[p].from) (:617-619)
+        }
+        int polls = 0;
+        while (__builtin_amdgcn_ballot_w64(pending)) {
+            if (pending) {
+                unsigned v[9];
+                bool ready = true;
+#pragma unroll
+                for (int k = 0; k < 9; k++)
+                    if (k < nsrc) {
+                        v[k] = __hip_atomic_load(acc + src[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ready = ready && v[k] != FLOW_NOT_READY;
+                    }
+                if (ready) {
+                    float sum = own;
+#pragma unroll
+                    for (int k = 0; k < 9; k++)
+                        if (k < nsrc) sum = __fadd_rn(sum, __uint_as_float(v[k]));
+                    __hip_atomic_store(acc + p, __float_as_uint(sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    pending = false;
+                } else if (++polls > (1 << 20)) {            // ~a second: something upstream was never published
+                    atomicOr(error, 1);
+                    pending = false;
+                } else __builtin_amdgcn_s_sleep(2);
+            }
+        }
+    }
+}
+
 // lakeID[p] = pow(sum, exponent) (:620) for every reached cell, one launch after the level sums.  The reference's
 // unqualified pow(float, float) is the C double function under g++ (its headers pull <cmath> only), rounded to float
 // by the assignment: double pow, one rounding.
@@ -661,11 +729,29 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
     DMG_HIP(hipGetLastError());
     if (timing) fprintf(stderr, "[flow] %d levels\n", levels);
     lap("upload + depth sort");
-    for (int l = levels - 1; l >= 0; l--) {
-        int cnt = start[l + 1] - start[l];
-        if (!cnt) continue;
-        hipLaunchKernelGGL(k_flow_level, dim3((cnt + 255) / 256), dim3(256), 0, st, fc, order.i(), start[l], cnt,
-                           (const unsigned short *)mask.p, dcf.i(), down.f(), acc.f());
+    static const bool by_levels = getenv("DMG_FLOW_LEVELS") != nullptr;      // experiments: the level-synchronous form
+    const int n_reached = start[levels];
+    if (by_levels) {
+        for (int l = levels - 1; l >= 0; l--) {
+            int cnt = start[l + 1] - start[l];
+            if (!cnt) continue;
+            hipLaunchKernelGGL(k_flow_level, dim3((cnt + 255) / 256), dim3(256), 0, st, fc, order.i(), start[l], cnt,
+                               (const unsigned short *)mask.p, dcf.i(), down.f(), acc.f());
+        }
+    } else if (n_reached > 0) {
+        dev_buf dtick;
+        DMG_ALLOC(dtick, 8);
+        DMG_HIP(hipMemsetAsync(dtick.p, 0, 8, st));
+        DMG_HIP(hipMemsetAsync(acc.p, 0xFF, N * 4, st));                  // FLOW_NOT_READY everywhere
+        const int waves = (n_reached + 63) / 64;
+        const int blocks = std::min((waves + 3) / 4, std::max(ctx->num_cu, 1) * 8);      // persistent: what the chip holds at once
+        hipLaunchKernelGGL(k_flow_dataflow, dim3(blocks), dim3(256), 0, st, fc, order.i(), n_reached, (const unsigned short *)mask.p, dcf.i(),
+                           down.f(), (unsigned *)acc.p, dtick.i(), dtick.i() + 1);
+        DMG_HIP(hipGetLastError());
+        int flow_err = 0;
+        DMG_HIP(hipMemcpyAsync(&flow_err, dtick.i() + 1, 4, hipMemcpyDeviceToHost, st));
+        DMG_HIP(hipStreamSynchronize(st));
+        if (flow_err) return dmg_fail(DMG_EHIP, "flow: the upstream sums did not complete (a cell waited for a sum that was never published)");
     }
     hipLaunchKernelGGL(k_flow_pow, dim3(nb), dim3(256), 0, st, gdepth.i(), acc.f(), d_flow, exponent, N);
     DMG_HIP(hipGetLastError());
