@@ -274,7 +274,16 @@ def ocean_step(ocean, exch, n_outer=1):
         ocean.step(n_outer)
         return
     for _ in range(n_outer):
-        exch.exchange(ocean, F_V, g)                    # advect gathers v up to advect_reach() rows away
+        # the back-trace of advect travels |v| * timestep: every rank learns the longest reach BEFORE anybody moves, so
+        # that all of them go on or raise together (one rank failing alone would leave its peers in the next exchange)
+        reach = ocean.advect_reach()
+        t = exch.torch.tensor([reach], dtype=exch.torch.int32, device=exch.device if not exch.staged else "cpu")
+        exch.dist.all_reduce(t, op=exch.dist.ReduceOp.MAX)
+        reach = int(t[0])
+        if reach > g:
+            raise ValueError("advect reaches %d rows but the bands keep %d ghost rows: create the oceans with ghost >= %d "
+                             "(every rank stopped before the step)" % (reach, g, reach))
+        exch.exchange(ocean, F_V, g)                    # advect gathers v up to `reach` rows away
         ocean.advect()                                  # :158
         done = 0
         while done < prm.diffusion_iters:               # :160, 50 sweeps in blocks of `ghost`

@@ -448,8 +448,8 @@ int ocean_launch_tb(dmg_ocean *o, int lo, int hi, int n, int part, int zone_lo, 
     dmg_ocean::tb_tune *tune = nullptr, *timed = nullptr;
     int cand = -1;
     // candidates: three tile shapes of the workgroup kernel (k_jacobi_tb8) and the streaming kernel (k_jacobi_stream,
-    // ocean_jacobi_stream.hip) with two unit heights.  R < 0 = streaming with -R rows per unit.
-    static const tb_shape cands[TB_NCAND] = { { 8, 8 }, { 6, 8 }, { 4, 8 }, { -96, 0 }, { -32, 0 } };
+    // ocean_jacobi_stream.hip) with its own choice of unit height and with short units.  R < 0 = streaming with -R rows per unit.
+    static const tb_shape cands[TB_NCAND] = { { 8, 8 }, { 6, 8 }, { 4, 8 }, { -1000, 0 }, { -32, 0 } };   // -1000: unit height from the dispatch simulation
     const bool stream_ok = n == TB_T && ocean_stream_enabled();
     if (!sh.R) {
         const int tiles88 = ((a.W + TB_OW - 1) / TB_OW) * ((hi - lo + 47) / 48);

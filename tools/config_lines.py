@@ -40,6 +40,8 @@ t0 = time.perf_counter(); ctx.erosion_run(g, h, 50, 12, 0.5, 1.0, 1.0); tb = tim
 per = (tb - ta) / 10
 emit(config=2, line="stream-power erosion round 4096x2048 (flow accumulation + erosion/uplift pass)", ms_per_round=per * 1e3,
      projected_s_for_1000_iters=per * 1000)
+t0 = time.perf_counter(); ctx.erosion_run(g, h, 50, 1000, 0.5, 1.0, 1.0); tc = time.perf_counter() - t0
+emit(config=2, line="stream-power erosion 4096x2048, the config's 1000 iterations, host to host", seconds=tc, ms_per_round=tc)
 
 # configs 3 and 4: ocean outer step (advect + 50 diffusion + divergence + 5000 Jacobi + subDiv)
 for cfg, (W, H) in ((3, (8192, 4096)), (4, (16384, 8192))):
@@ -70,3 +72,11 @@ ctx.temperature_steps(g, T0, h, 0, 1)
 t0 = time.perf_counter(); ctx.temperature_steps(g, T0, h, 0, 1); ta = time.perf_counter() - t0
 t0 = time.perf_counter(); ctx.temperature_steps(g, T0, h, 0, 21); tb = time.perf_counter() - t0
 emit(config=5, line="climate step 16384x8192", ms_per_step=(tb - ta) / 20 * 1e3)
+
+# config 5 through its entry point: one coupled iteration (tectonics step -> erosion round -> 10 climate steps)
+terr = (synth.terrain(W, H) * 100).astype(np.float32)
+w = capi.World(ctx, g, terr, T0)
+w.step()
+t0 = time.perf_counter(); w.step(); dt = time.perf_counter() - t0
+emit(config=5, line="dmg_world_step 16384x8192: 1 tectonics step + 1 erosion round + 10 climate steps, one GPU", ms_per_iteration=dt * 1e3)
+w.close()
