@@ -39,6 +39,8 @@ struct dmg_ocean {
     unsigned char *code8 = nullptr;   // 8-neighbour solid bits (divergence, subDiv)
     unsigned char *rowclass = nullptr; // blocked Jacobi: class of every (tile column, row) wave-row (ocean_jacobi_tb.hip)
     std::vector<unsigned char> rowclass_host;   // the same table on the host, for the live-tile lists
+    unsigned char *rowclass_n = nullptr;        // the same for the narrow streaming kernel's 112-column strips
+    std::vector<unsigned char> rowclass_n_host;
     struct tile_list { int *d = nullptr; int n = 0; };
     // (out_lo, out_hi, rows per wave, part, zone_lo, zone_hi) of a launch -> tiles that are not land everywhere; part 0 = all
     // tile rows, 1 = tile rows touching the send zones [out_lo, zone_lo) / [zone_hi, out_hi), 2 = the tile rows in between
@@ -47,7 +49,7 @@ struct dmg_ocean {
     // read back when the geometry is launched the next time, so that trial launches run back to back with their
     // neighbours like every other launch (timing them in isolation, with a host synchronisation after each, favoured
     // shapes that lose in steady state)
-    struct tb_tune { int trials[5] = { 0, 0, 0, 0, 0 }; float best_ms[5] = { 1e30f, 1e30f, 1e30f, 1e30f, 1e30f }; int chosen = -1;
+    struct tb_tune { int trials[6] = { 0, 0, 0, 0, 0, 0 }; float best_ms[6] = { 1e30f, 1e30f, 1e30f, 1e30f, 1e30f, 1e30f }; int chosen = -1;
                      hipEvent_t ev0 = nullptr, ev1 = nullptr; int pending = -1; };
     std::map<std::pair<int, int>, tb_tune> tb_tuning;           // (out_lo, out_hi) -> which tile shape is fastest there
     float *v[2] = { nullptr, nullptr };   // interleaved (vx,vy)
@@ -56,6 +58,7 @@ struct dmg_ocean {
     struct { bool active = false; int lo = 0, hi = 0, n = 0, zone_lo = 0, zone_hi = 0; } pending;
     int *oob_flag = nullptr;       // device word: advect out-of-band flag / reduction scratch
     float *rowtab = nullptr;       // ROWTAB_FIELDS arrays of L floats
+    float *jcoefp = nullptr;       // [L + 32][4] = cx, 1/cx, Beta, 1/Beta of local rows -16 .. L+15, rows beyond the grid mirrored (scalar loads, no mapping)
     float *jcoef = nullptr;        // [L][8] = cx, 1/cx, Beta, 1/Beta, cy, 1/cy, -, -: a row's Jacobi coefficients in one 16-byte load (ocean_jacobi_stream.hip)
     const float *jac_cx = nullptr, *jac_cy = nullptr, *jac_beta = nullptr;
     const float *jac_rx = nullptr, *jac_ry = nullptr, *jac_rb = nullptr;
@@ -83,7 +86,8 @@ int ocean_launch_tb(dmg_ocean *o, int lo, int hi, int n, int part = 0, int zone_
                     hipStream_t stream = nullptr);   // src >= 0: from p[src] into p[src ^ 1] instead of the current pair; stream: instead of the context's
 int ocean_tb_tile_rows(dmg_ocean *o, int lo, int hi);    // output rows per tile row of the shape an 8-sweep launch over [lo, hi) uses; 0 while its tuner is open
 // ocean_jacobi_stream.hip: 8 sweeps over local rows [lo, hi) by the streaming kernel; seg = rows per unit (0 = default)
-int ocean_launch_stream(dmg_ocean *o, int lo, int hi, int part, int zone_lo, int zone_hi, int from, hipStream_t st, int seg = 0);
+// variant 0: 4 columns per lane, two waves per SIMD; 1: 2 columns per lane, four waves per SIMD
+int ocean_launch_stream(dmg_ocean *o, int lo, int hi, int part, int zone_lo, int zone_hi, int from, hipStream_t st, int seg = 0, int variant = -1);
 bool ocean_stream_enabled();
 int ocean_launch_diffusion_tb(dmg_ocean *o, int lo, int hi, int n);   // ocean_diffusion_tb.hip: n (1..8) sweeps over local rows [lo, hi)
 int ocean_launch_literal(dmg_ocean *o);          // ocean_jacobi_literal.hip: one per-fragment sweep as llvmpipe evaluates the shader

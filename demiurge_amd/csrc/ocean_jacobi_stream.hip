@@ -42,6 +42,7 @@ struct st_args {
     int spole, npole;
     const unsigned char *rowclass;  // [tiles_x][L]: 0 open ocean, 1 land everywhere, 2 mixed; or null
     const int4 *units;              // {tile column, first output row, end output row, -}
+    const float *jcoef_cy;          // {cy, 1/cy}: the same for every row
     int dbg;                        // experiments only (DMG_ST_DBG bits): 1 = every unit re-reads 64 rows (cache hits), 2 = no stores, 4 = plain instead of nontemporal stores
 };
 
@@ -319,6 +320,205 @@ __global__ __launch_bounds__(64, 2) void k_jacobi_stream(st_args a)
     }
 }
 
+// =================================================================================================================
+// The narrow form: 2 columns per lane (128-column strips, 112 written), everything else as above.  A wave's register
+// state halves (8 levels x 4 rows x 2 floats = 64 VGPRs), the kernel fits 128 registers, and FOUR waves share a SIMD
+// instead of two.  Measured on the wide form with loads and stores taken out: one wave per SIMD keeps the vector ALU
+// 40 % busy, two 68 % -- an in-order wave spends a third of its issue slots on scalar bookkeeping, waits and hazard
+// nops, and only other waves can fill them.  The price is a wider relative halo in x (16 of 128 columns instead of 16 of
+// 256) and twice the per-visit bookkeeping per cell: +15 % vector and 2.2x scalar instructions (rocprofv3), for a SIMD
+// that is then 74 % instead of 70 % busy -- it ends up level with the wide form on the survey terrain and 7 % behind it
+// without land, so it is a tuner candidate for small launch geometries, not the default.  The per-row coefficients come through scalar loads from a table padded with the mirrored rows (no LDS table,
+// no address VGPRs); right-hand side and codes travel through LDS rings as above.
+// =================================================================================================================
+#define STN_EW 128
+#define STN_OW (STN_EW - 2 * TB_T)
+#define ST_PAD 16                 // rows of padding on both ends of the coefficient table: window rows -16 .. L+15 need no mapping
+
+struct stn_state {
+    v2f w[8][2][2];
+    v2f ps[2][2], bs[2][2];
+    unsigned cs[2][2];
+    unsigned landbits, mixbits;
+    int slot;
+    float cy, ry;
+};
+struct stn_coef { float cx, rx, beta, rb; };
+typedef const float __attribute__((address_space(4))) *stn_kptr;
+
+// coefficients of window rows y and y + 1: consecutive entries of the padded table, scalar loads
+__device__ __forceinline__ void stn_coefs(const st_args &a, int y, stn_coef &ka, stn_coef &kb)
+{
+    const stn_kptr cf = (stn_kptr)(unsigned long long)(a.jcoef + (size_t)(y + ST_PAD) * 4);
+    ka = stn_coef{ cf[0], cf[1], cf[2], cf[3] };
+    kb = stn_coef{ cf[4], cf[5], cf[6], cf[7] };
+}
+
+__device__ __forceinline__ v2f stn_row_any(const v2f N, const v2f C, const v2f S, const v2f bb, const stn_coef kk, float cy, float ry, bool mixed,
+                                           const unsigned short *crow, int lane, int tick)
+{
+    const jacobi_row k = { kk.cx, cy, kk.beta, kk.rx, ry, kk.rb };
+    const float wl = dpp_from_prev_lane(C.y);                // west neighbour of C.x
+    const float er = dpp_from_next_lane(C.x);                // east neighbour of C.y
+    if (!mixed) {
+        const v2f Wp = { wl, C.x }, Ep = { C.y, er };
+        return st_value2(N, S, Ep, Wp, bb, k);
+    }
+    const unsigned c = crow[lane];
+    const int t = tick;
+    const v2f n0 = { st_sel<0>(c, t, C.x, N.x), st_sel<8>(c, t, C.y, N.y) };
+    const v2f s0 = { st_sel<1>(c, t, C.x, S.x), st_sel<9>(c, t, C.y, S.y) };
+    const v2f e0 = { st_sel<2>(c, t, C.x, C.y), st_sel<10>(c, t, C.y, er) };
+    const v2f w0 = { st_sel<3>(c, t, C.x, wl), st_sel<11>(c, t, C.y, C.x) };
+    const v2f r0 = st_value2(n0, s0, e0, w0, bb, k);
+    return v2f{ st_zero_land<4>(c, t, r0.x), st_zero_land<12>(c, t, r0.y) };
+}
+
+template <int S, int K>
+__device__ __forceinline__ void stn_level(const st_args &a, stn_state &z, v2f (*bring)[64], unsigned short (*cring)[64],
+                                          int lane, int t, int yA, int r0, int r1, bool lane_ok, int xcol,
+                                          const v2f bA, const v2f bB, v2f &bA_next, v2f &bB_next,
+                                          const stn_coef kA, const stn_coef kB, stn_coef &kA_next, stn_coef &kB_next)
+{
+    if (S < 8) {                                              // the next level's operands, while this level computes
+        const int sa = st_wrap(z.slot - (S + 1)), sb = sa + 1 == ST_RING ? 0 : sa + 1;
+        bA_next = bring[sa][lane]; bB_next = bring[sb][lane];
+        stn_coefs(a, yA - 1, kA_next, kB_next);
+    }
+    // (a level whose rows do not exist yet sees them as land: landbits starts as all ones)
+    const unsigned landA = (z.landbits >> (S + 1)) & 1u, landB = (z.landbits >> S) & 1u;
+    const unsigned mixA = (z.mixbits >> (S + 1)) & 1u, mixB = (z.mixbits >> S) & 1u;
+    const v2f S0 = z.w[S - 1][K ^ 1][0], C0 = z.w[S - 1][K ^ 1][1], N0 = z.w[S - 1][K][0], N1 = z.w[S - 1][K][1];
+    v2f oA, oB;
+    if (!(landA | landB | mixA | mixB)) {
+        const jacobi_row ka = { kA.cx, z.cy, kA.beta, kA.rx, z.ry, kA.rb }, kb = { kB.cx, z.cy, kB.beta, kB.rx, z.ry, kB.rb };
+        const float wlA = dpp_from_prev_lane(C0.y), erA = dpp_from_next_lane(C0.x);
+        const float wlB = dpp_from_prev_lane(N0.y), erB = dpp_from_next_lane(N0.x);
+        const v2f WA = { wlA, C0.x }, EA = { C0.y, erA }, WB = { wlB, N0.x }, EB = { N0.y, erB };
+        oA = st_value2(N0, S0, EA, WA, bA, ka);
+        oB = st_value2(N1, C0, EB, WB, bB, kb);
+    } else {
+        const int sa = st_wrap(z.slot - S), sb = sa + 1 == ST_RING ? 0 : sa + 1;
+        oA = landA ? (v2f)(0.0f) : stn_row_any(N0, C0, S0, bA, kA, z.cy, z.ry, mixA != 0, cring[sa], lane, t);
+        oB = landB ? (v2f)(0.0f) : stn_row_any(N1, N0, C0, bB, kB, z.cy, z.ry, mixB != 0, cring[sb], lane, t);
+    }
+    if (S < 8) { z.w[S & 7][K][0] = oA; z.w[S & 7][K][1] = oB; }
+    else if (lane_ok && !(a.dbg & 2)) {
+        // only the unit's own rows [r0, r1): in its first steps level 8 runs on rows below r0 (window rows that exist but
+        // are not yet valid at this level) -- computed like any halo row, never stored
+        if (!landA && yA >= r0 && yA < r1) __builtin_nontemporal_store(oA, reinterpret_cast<v2f *>(a.pout + (size_t)yA * a.W + xcol));
+        if (!landB && yA + 1 >= r0 && yA + 1 < r1) __builtin_nontemporal_store(oB, reinterpret_cast<v2f *>(a.pout + (size_t)(yA + 1) * a.W + xcol));
+    }
+}
+
+__device__ __forceinline__ void stn_fetch(const st_args &a, stn_state &z, int set, int j, int e, int col, int colp)
+{
+    const st_row m = st_map_row(a, (a.dbg & 1) ? (e & 63) : e);
+    const size_t off = (size_t)m.l * a.W + (m.shift ? colp : col);
+    z.ps[set][j] = *reinterpret_cast<const v2f *>(a.pin + off);
+    z.bs[set][j] = *reinterpret_cast<const v2f *>(a.b + off);
+    z.cs[set][j] = *reinterpret_cast<const unsigned short *>(a.code + off);
+}
+
+template <int K>
+__device__ __forceinline__ void stn_arrive(const st_args &a, stn_state &z, v2f (*bring)[64], unsigned short (*cring)[64], int lane,
+                                           int j, int e, unsigned cls, int slot, unsigned &land, unsigned &mix)
+{
+    land = cls == 1u; mix = 0;
+    {
+        v2f lo;
+        asm("v_mov_b64 %0, %1" : "=v"(lo) : "v"(z.ps[K][j]));       // a real move (see st_arrive)
+        z.w[0][K][j] = lo;
+    }
+    if (cls == 2u) {
+        unsigned c = z.cs[K][j];
+        const st_row m = st_map_row(a, e);
+        if (m.flip) c = (c & 0xFCFCu) | ((c & 0x0101u) << 1) | ((c & 0x0202u) >> 1);   // mirrored row: swap N/S bits
+        const int yg = a.y_first + e;
+        if (yg == 0 && !a.spole) c &= ~0x0202u;
+        if (yg == a.H - 1 && !a.npole) c &= ~0x0101u;
+        mix = __builtin_amdgcn_ballot_w64((c & 0x1F1Fu) != 0) != 0;
+        land = __builtin_amdgcn_ballot_w64((c & 0x1010u) != 0x1010u) == 0;
+        mix &= ~land;
+        if (mix) cring[slot][lane] = (unsigned short)c;
+    }
+    bring[slot][lane] = z.bs[K][j];
+}
+
+template <int K>
+__device__ __forceinline__ void stn_step(const st_args &a, stn_state &z, v2f (*bring)[64], unsigned short (*cring)[64], int lane, int t,
+                                         int e0, int r0, int r1, unsigned cls_lo, unsigned cls_hi, int col, int colp, bool lane_ok, int xcol)
+{
+    const int e_t = e0 + 2 * t;
+    unsigned landA, mixA, landB, mixB;
+    stn_arrive<K>(a, z, bring, cring, lane, 0, e_t, st_class(cls_lo, cls_hi, 2 * t), z.slot, landA, mixA);
+    stn_arrive<K>(a, z, bring, cring, lane, 1, e_t + 1, st_class(cls_lo, cls_hi, 2 * t + 1), z.slot + 1, landB, mixB);
+    z.landbits = (z.landbits << 2) | (landA << 1) | landB;
+    z.mixbits = (z.mixbits << 2) | (mixA << 1) | mixB;
+    stn_fetch(a, z, K, 0, e_t + 4, col, colp);
+    stn_fetch(a, z, K, 1, e_t + 5, col, colp);
+    const int s1 = st_wrap(z.slot - 1);
+    v2f b0 = bring[s1][lane], b1 = bring[z.slot][lane], b2, b3;
+    stn_coef k0, k1, k2, k3;
+    stn_coefs(a, e_t - 1, k0, k1);
+    stn_level<1, K>(a, z, bring, cring, lane, t, e_t - 1, r0, r1, lane_ok, xcol, b0, b1, b2, b3, k0, k1, k2, k3);
+    stn_level<2, K>(a, z, bring, cring, lane, t, e_t - 2, r0, r1, lane_ok, xcol, b2, b3, b0, b1, k2, k3, k0, k1);
+    stn_level<3, K>(a, z, bring, cring, lane, t, e_t - 3, r0, r1, lane_ok, xcol, b0, b1, b2, b3, k0, k1, k2, k3);
+    stn_level<4, K>(a, z, bring, cring, lane, t, e_t - 4, r0, r1, lane_ok, xcol, b2, b3, b0, b1, k2, k3, k0, k1);
+    stn_level<5, K>(a, z, bring, cring, lane, t, e_t - 5, r0, r1, lane_ok, xcol, b0, b1, b2, b3, k0, k1, k2, k3);
+    stn_level<6, K>(a, z, bring, cring, lane, t, e_t - 6, r0, r1, lane_ok, xcol, b2, b3, b0, b1, k2, k3, k0, k1);
+    stn_level<7, K>(a, z, bring, cring, lane, t, e_t - 7, r0, r1, lane_ok, xcol, b0, b1, b2, b3, k0, k1, k2, k3);
+    stn_level<8, K>(a, z, bring, cring, lane, t, e_t - 8, r0, r1, lane_ok, xcol, b2, b3, b0, b1, k2, k3, k0, k1);
+    z.slot = z.slot + 2 == ST_RING ? 0 : z.slot + 2;
+}
+
+__global__ __launch_bounds__(64, 4) void k_jacobi_stream_n(st_args a)
+{
+    __shared__ v2f bring[ST_RING][64];
+    __shared__ unsigned short cring[ST_RING][64];
+    const int lane = threadIdx.x;
+    const int4 u = a.units[blockIdx.x];
+    const int tx = __builtin_amdgcn_readfirstlane(u.x), r0 = __builtin_amdgcn_readfirstlane(u.y), r1 = __builtin_amdgcn_readfirstlane(u.z);
+    const int W = a.W;
+    const int nsteps = (((r1 - r0) + 2 * TB_T + 3) / 4) * 2;
+    const int e0 = r0 - TB_T;
+    int col = tx * STN_OW - TB_T + 2 * lane;
+    const int xcol = col;
+    col %= W; if (col < 0) col += W;
+    int colp = col + W / 2; if (colp >= W) colp -= W;
+    const bool lane_ok = (lane >= TB_T / 2) && (lane < 64 - TB_T / 2) && (xcol < W);
+    unsigned cls_lo = 2u, cls_hi = 2u;
+    if (a.rowclass) {
+        int lu = e0 + lane, yg = a.y_first + lu;
+        if (yg >= 0 && yg < a.H && lu >= 0 && lu < a.L) cls_lo = a.rowclass[(size_t)tx * a.L + lu];
+        lu += 64; yg += 64;
+        if (yg >= 0 && yg < a.H && lu >= 0 && lu < a.L) cls_hi = a.rowclass[(size_t)tx * a.L + lu];
+    }
+    stn_state z;
+#pragma unroll
+    for (int s = 0; s < 8; s++)
+#pragma unroll
+        for (int k = 0; k < 2; k++) { z.w[s][k][0] = (v2f)(0.0f); z.w[s][k][1] = (v2f)(0.0f); }
+#pragma unroll
+    for (int k = 0; k < 2; k++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) { z.ps[k][j] = (v2f)(0.0f); z.bs[k][j] = (v2f)(0.0f); z.cs[k][j] = 0; }
+    z.landbits = 0xFFFFFFFFu;                                // rows before the window: "land", so that a level idles until its rows exist
+    z.mixbits = 0; z.slot = 0;
+    {
+        const stn_kptr cf = (stn_kptr)(unsigned long long)a.jcoef_cy;
+        z.cy = cf[0]; z.ry = cf[1];
+    }
+    stn_fetch(a, z, 0, 0, e0, col, colp);
+    stn_fetch(a, z, 0, 1, e0 + 1, col, colp);
+    stn_fetch(a, z, 1, 0, e0 + 2, col, colp);
+    stn_fetch(a, z, 1, 1, e0 + 3, col, colp);
+    for (int t = 0; t < nsteps; t += 2) {
+        stn_step<0>(a, z, bring, cring, lane, t, e0, r0, r1, cls_lo, cls_hi, col, colp, lane_ok, xcol);
+        stn_step<1>(a, z, bring, cring, lane, t + 1, e0, r0, r1, cls_lo, cls_hi, col, colp, lane_ok, xcol);
+    }
+}
+
 // ---- host ---------------------------------------------------------------------------------------------------------
 bool ocean_stream_enabled()
 {
@@ -343,11 +543,13 @@ struct st_unit { int tx, r0, r1; float cost; };
 // Units of a launch over local rows [lo, hi) for one unit height: every strip cut into segments of `seg` rows, each trimmed
 // to its first / last row that is not land everywhere; empty ones are dropped.  cost ~ the unit's level-rows, a coast row
 // counted 1.6 times an open one and a land row a tenth (what the kernel spends on them).
-static void st_cut(const dmg_ocean *o, int lo, int hi, int seg, int part, int zone_lo, int zone_hi, std::vector<st_unit> &units,
+static void st_cut(const dmg_ocean *o, int variant, int lo, int hi, int seg, int part, int zone_lo, int zone_hi, std::vector<st_unit> &units,
                    int seg2 = 0, int split = 0)
 {
-    const int tiles_x = (o->grid.W + TB_OW - 1) / TB_OW, L = o->L;
-    const bool classes = !o->rowclass_host.empty();
+    const int ow = variant ? STN_OW : TB_OW;
+    const std::vector<unsigned char> &table = variant ? o->rowclass_n_host : o->rowclass_host;
+    const int tiles_x = (o->grid.W + ow - 1) / ow, L = o->L;
+    const bool classes = !table.empty();
     units.clear();
     // rows [lo, split) in segments of `seg` rows, the rest in (shorter) segments of `seg2` rows: the short units fill
     // the last round of the dispatch
@@ -361,7 +563,7 @@ static void st_cut(const dmg_ocean *o, int lo, int hi, int seg, int part, int zo
             const int s0 = s0_this;
         for (int tx = 0; tx < tiles_x; tx++) {
             int r0 = s0, r1 = s1;
-            const unsigned char *cls = classes ? o->rowclass_host.data() + (size_t)tx * L : nullptr;
+            const unsigned char *cls = classes ? table.data() + (size_t)tx * L : nullptr;
             if (cls) {
                 while (r0 < r1 && cls[r0] == 1) r0++;
                 while (r1 > r0 && cls[r1 - 1] == 1) r1--;
@@ -406,19 +608,19 @@ static float st_makespan(std::vector<st_unit> &units, int slots)
 // (7/n), but the last round must be full -- and the units are issued longest first.
 // part 1 / 2: only the units that do / do not produce rows of [lo, zone_lo) or [zone_hi, hi) (the two halves of a launch
 // split around a halo exchange).
-static const dmg_ocean::tile_list *st_units(dmg_ocean *o, int lo, int hi, int part, int zone_lo, int zone_hi, int seg)
+static const dmg_ocean::tile_list *st_units(dmg_ocean *o, int variant, int lo, int hi, int part, int zone_lo, int zone_hi, int seg)
 {
-    auto key = std::make_tuple(lo, hi, -1000 - seg, part, zone_lo, zone_hi);    // "rows per wave" <= -1000 = stream units (seg 0 = auto)
+    auto key = std::make_tuple(lo, hi, (variant ? -3000 : -1000) - seg, part, zone_lo, zone_hi);    // "rows per wave" <= -1000 = stream units (seg 0 = auto)
     auto it = o->tb_lists.find(key);
     if (it != o->tb_lists.end()) return &it->second;
-    const int slots = std::max(o->ctx->num_cu, 1) * 8;     // two waves per SIMD
+    const int slots = std::max(o->ctx->num_cu, 1) * (variant ? 16 : 8);     // four / two waves per SIMD
     std::vector<st_unit> units, best;
-    if (seg > 0) { st_cut(o, lo, hi, seg, part, zone_lo, zone_hi, best); (void)st_makespan(best, slots); }
+    if (seg > 0) { st_cut(o, variant, lo, hi, seg, part, zone_lo, zone_hi, best); (void)st_makespan(best, slots); }
     else {
         float best_span = 1e30f;
         int best_seg = 0, best_seg2 = 0, best_split = 0;
         for (int cand = 24; cand <= ST_MAXROWS; cand += 4) {
-            st_cut(o, lo, hi, cand, part, zone_lo, zone_hi, units);
+            st_cut(o, variant, lo, hi, cand, part, zone_lo, zone_hi, units);
             float span = st_makespan(units, slots);
             if (span < best_span) { best_span = span; best.swap(units); best_seg = cand; best_seg2 = 0; best_split = hi; }
             // two tiers: the top eighth .. half of the rows in units a half, a third or a quarter as tall
@@ -426,7 +628,7 @@ static const dmg_ocean::tile_list *st_units(dmg_ocean *o, int lo, int hi, int pa
                 for (int div = 2; div <= 4; div++) {
                     const int split = hi - ((hi - lo) * frac / 8 / cand) * cand, seg2 = ((cand / div + 3) / 4) * 4;
                     if (split <= lo || split >= hi || seg2 < 12) continue;
-                    st_cut(o, lo, hi, cand, part, zone_lo, zone_hi, units, seg2, split);
+                    st_cut(o, variant, lo, hi, cand, part, zone_lo, zone_hi, units, seg2, split);
                     span = st_makespan(units, slots);
                     if (span < best_span) { best_span = span; best.swap(units); best_seg = cand; best_seg2 = seg2; best_split = split; }
                 }
@@ -450,11 +652,14 @@ static const dmg_ocean::tile_list *st_units(dmg_ocean *o, int lo, int hi, int pa
 }
 
 // 8 sweeps over local rows [lo, hi) from p[from] into p[from ^ 1]; seg = rows per unit (0: the default)
-int ocean_launch_stream(dmg_ocean *o, int lo, int hi, int part, int zone_lo, int zone_hi, int from, hipStream_t st, int seg)
+int ocean_launch_stream(dmg_ocean *o, int lo, int hi, int part, int zone_lo, int zone_hi, int from, hipStream_t st, int seg, int variant)
 {
     if (seg <= 0) seg = st_unit_rows();                    // 0: chosen per geometry
     if (seg > ST_MAXROWS) seg = ST_MAXROWS;
-    const dmg_ocean::tile_list *tl = st_units(o, lo, hi, part, zone_lo, zone_hi, seg);
+    static const int forced = [] { const char *e = getenv("DMG_ST_VARIANT"); return e ? atoi(e) : -1; }();     // experiments: 0 wide, 1 narrow
+    if (variant < 0) variant = forced >= 0 ? forced : 0;   // default: the wide kernel (measured: 2.52 vs 2.51 M on the survey terrain, 1.97 vs 1.83 M without land)
+    if (o->grid.W < STN_EW) variant = 0;
+    const dmg_ocean::tile_list *tl = st_units(o, variant, lo, hi, part, zone_lo, zone_hi, seg);
     if (!tl) return dmg_fail(DMG_ENOMEM, "unit list allocation failed");
     if (tl->n == 0) return DMG_OK;
     st_args a;
@@ -462,16 +667,20 @@ int ocean_launch_stream(dmg_ocean *o, int lo, int hi, int part, int zone_lo, int
     a.pout = o->p[from ^ 1];
     a.b = o->divw;
     a.code = o->code;
-    a.jcoef = o->jcoef;
+    a.jcoef = variant ? o->jcoefp : o->jcoef;
+    a.jcoef_cy = o->jcoef + 4;                           // row 0's {cy, 1/cy}: the same for every row
     a.W = o->grid.W; a.L = o->L;
     a.y_first = o->y0 - o->gs; a.H = o->grid.H;
     a.spole = o->topo.spole ? 1 : 0; a.npole = o->topo.npole ? 1 : 0;
     static const bool use_cls = getenv("DMG_TB_NOCLASS") == nullptr;
-    a.rowclass = use_cls ? o->rowclass : nullptr;
+    a.rowclass = use_cls ? (variant ? o->rowclass_n : o->rowclass) : nullptr;
     a.units = (const int4 *)tl->d;
+    o->last_kernel = variant ? "k_jacobi_stream_n" : "k_jacobi_stream";
     static const int dbg = [] { const char *e = getenv("DMG_ST_DBG"); return e ? atoi(e) : 0; }();
     a.dbg = dbg;
-    hipLaunchKernelGGL(k_jacobi_stream, dim3((unsigned)tl->n), dim3(64), 0, st, a);
+    static const int extra_lds = [] { const char *e = getenv("DMG_ST_EXTRA_LDS"); return e ? atoi(e) : 0; }();   // experiments: caps the waves per CU
+    if (variant) hipLaunchKernelGGL(k_jacobi_stream_n, dim3((unsigned)tl->n), dim3(64), (size_t)extra_lds, st, a);
+    else hipLaunchKernelGGL(k_jacobi_stream, dim3((unsigned)tl->n), dim3(64), (size_t)extra_lds, st, a);
     DMG_HIP(hipGetLastError());
     return DMG_OK;
 }

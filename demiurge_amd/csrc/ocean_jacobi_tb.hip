@@ -287,6 +287,22 @@ __global__ __launch_bounds__(64) void k_tb_rowclass(const unsigned char *__restr
     if (lane == 0) cls[(size_t)tx * L + l] = all_land ? 1 : (any ? 2 : 0);
 }
 
+// the same for the narrow streaming kernel: strips of 128 columns (112 written), two cells per lane
+__global__ __launch_bounds__(64) void k_tb_rowclass_n(const unsigned char *__restrict__ code, unsigned char *__restrict__ cls, int W, int L,
+                                                      int y_first, int H, int spole, int npole)
+{
+    const int lane = threadIdx.x, tx = blockIdx.x, l = blockIdx.y;
+    int col = tx * (128 - 2 * TB_T) - TB_T + 2 * lane;
+    col %= W; if (col < 0) col += W;
+    unsigned c = *reinterpret_cast<const unsigned short *>(code + (size_t)l * W + col);
+    int yg = y_first + l;
+    if (yg == 0 && !spole) c &= ~0x0202u;
+    if (yg == H - 1 && !npole) c &= ~0x0101u;
+    bool any = __builtin_amdgcn_ballot_w64((c & 0x1F1Fu) != 0) != 0;
+    bool all_land = __builtin_amdgcn_ballot_w64((c & 0x1010u) != 0x1010u) == 0;
+    if (lane == 0) cls[(size_t)tx * L + l] = all_land ? 1 : (any ? 2 : 0);
+}
+
 void ocean_tb_free_lists(dmg_ocean *o)
 {
     for (auto &kv : o->tb_lists) if (kv.second.d) (void)hipFree(kv.second.d);
@@ -309,6 +325,13 @@ int ocean_build_rowclass(dmg_ocean *o)
     ocean_tb_free_lists(o);                              // lists of the previous terrain
     o->rowclass_host.resize((size_t)tiles_x * o->L);
     DMG_HIP(hipMemcpyAsync(o->rowclass_host.data(), o->rowclass, o->rowclass_host.size(), hipMemcpyDeviceToHost, o->ctx->stream));
+    const int tiles_n = (o->grid.W + (128 - 2 * TB_T) - 1) / (128 - 2 * TB_T);
+    if (!o->rowclass_n) DMG_HIP(hipMalloc((void **)&o->rowclass_n, (size_t)tiles_n * o->L));
+    hipLaunchKernelGGL(k_tb_rowclass_n, dim3(tiles_n, o->L), dim3(64), 0, o->ctx->stream, o->code, o->rowclass_n, o->grid.W, o->L,
+                       o->y0 - o->gs, o->grid.H, o->topo.spole ? 1 : 0, o->topo.npole ? 1 : 0);
+    DMG_HIP(hipGetLastError());
+    o->rowclass_n_host.resize((size_t)tiles_n * o->L);
+    DMG_HIP(hipMemcpyAsync(o->rowclass_n_host.data(), o->rowclass_n, o->rowclass_n_host.size(), hipMemcpyDeviceToHost, o->ctx->stream));
     DMG_HIP(hipStreamSynchronize(o->ctx->stream));
     return DMG_OK;
 }
@@ -357,7 +380,7 @@ static const dmg_ocean::tile_list *tb_live_tiles(dmg_ocean *o, int lo, int hi, i
 // tile shapes built into the library: R rows per thread x NW waves per workgroup.  The default is chosen from
 // measurements; DMG_TB_SHAPE=<R>x<NW> overrides it for experiments.
 struct tb_shape { int R, NW; };
-#define TB_NCAND 5
+#define TB_NCAND 6
 static tb_shape tb_forced_shape()
 {
     static const tb_shape forced = [] {
@@ -449,12 +472,12 @@ int ocean_launch_tb(dmg_ocean *o, int lo, int hi, int n, int part, int zone_lo, 
     int cand = -1;
     // candidates: three tile shapes of the workgroup kernel (k_jacobi_tb8) and the streaming kernel (k_jacobi_stream,
     // ocean_jacobi_stream.hip) with its own choice of unit height and with short units.  R < 0 = streaming with -R rows per unit.
-    static const tb_shape cands[TB_NCAND] = { { 8, 8 }, { 6, 8 }, { 4, 8 }, { -1000, 0 }, { -32, 0 } };   // -1000: unit height from the dispatch simulation
+    static const tb_shape cands[TB_NCAND] = { { 8, 8 }, { 6, 8 }, { 4, 8 }, { -1000, 0 }, { -32, 0 }, { -1000, 1 } };   // NW = 1 with R < 0: the narrow streaming kernel   // -1000: unit height from the dispatch simulation
     const bool stream_ok = n == TB_T && ocean_stream_enabled();
     if (!sh.R) {
         const int tiles88 = ((a.W + TB_OW - 1) / TB_OW) * ((hi - lo + 47) / 48);
         // thousands of tiles: the chip is full either way and the streaming kernel does the least work
-        sh = stream_ok ? tb_shape{ -1000, 0 } : tb_shape{ 8, 8 };   // -1000: the streaming kernel's default unit height
+        sh = stream_ok ? tb_shape{ -1000, -1 } : tb_shape{ 8, 8 };   // -1000: the streaming kernel's default unit height
         if (tiles88 <= 4096 && n == TB_T && a.rowclass) {
             tune = &o->tb_tuning[std::make_pair(lo, hi)];
             if (tune->chosen < 0 && !part) {
@@ -483,10 +506,10 @@ int ocean_launch_tb(dmg_ocean *o, int lo, int hi, int n, int part, int zone_lo, 
         }
     }
     int rc;
-    o->last_kernel = sh.R < 0 ? "k_jacobi_stream" : "k_jacobi_tb8";
+    if (sh.R >= 0) o->last_kernel = "k_jacobi_tb8";
     if (sh.R < 0) {
         if (timed) (void)hipEventRecord(timed->ev0, st);
-        rc = ocean_launch_stream(o, lo, hi, part, zone_lo, zone_hi, from, st, sh.R == -1000 ? 0 : -sh.R);
+        rc = ocean_launch_stream(o, lo, hi, part, zone_lo, zone_hi, from, st, sh.R == -1000 ? 0 : -sh.R, sh.NW);
         if (timed) (void)hipEventRecord(timed->ev1, st);
     }
     else if (sh.R == 4) rc = tb_launch<4, 8>(o, a, a.W, hi - lo, st, timed, part, zone_lo, zone_hi);
@@ -507,7 +530,7 @@ int ocean_tb_tile_rows(dmg_ocean *o, int lo, int hi)
     tb_shape f = tb_forced_shape();
     if (f.R) return f.R * f.NW - 2 * TB_T;
     if (ocean_tb_tuning_open(o, lo, hi)) return 0;
-    static const int rows_of[TB_NCAND] = { 8 * 8 - 2 * TB_T, 6 * 8 - 2 * TB_T, 4 * 8 - 2 * TB_T, 96, 32 };   // streaming: rows per unit
+    static const int rows_of[TB_NCAND] = { 8 * 8 - 2 * TB_T, 6 * 8 - 2 * TB_T, 4 * 8 - 2 * TB_T, 96, 32, 96 };   // streaming: rows per unit
     auto it = o->tb_tuning.find(std::make_pair(lo, hi));
     if (it != o->tb_tuning.end() && it->second.chosen >= 0) return rows_of[it->second.chosen];
     const int tiles88 = ((o->grid.W + TB_OW - 1) / TB_OW) * ((hi - lo + 47) / 48);

@@ -2,6 +2,7 @@
 // shader two pow()s, OceanCurrents.cpp:478-479); they depend on the row only, so they are computed once on
 // the host, in fp32, statement by statement as the shader does, and the kernels read 3 floats per row.
 #include "ocean_internal.h"
+#include <algorithm>
 
 int ocean_upload_row_tables(dmg_ocean *o)
 {
@@ -47,6 +48,19 @@ int ocean_upload_row_tables(dmg_ocean *o)
     for (int l = 0; l < L; l++) {
         static const int f[6] = { RT_JCX, RT_JRX, RT_JBETA, RT_JRB, RT_JCY, RT_JRY };     // first four: one 16-byte load per row
         for (int k = 0; k < 6; k++) jc[(size_t)l * 8 + k] = t[(size_t)f[k] * L + l];
+    }
+    {   // the same coefficients, 4 per row, for local rows -16 .. L+15: a row beyond the grid is the mirrored row (as the
+        // streaming kernels map it), a row beyond the stored band the band's last row
+        const int PAD = 16, H = o->grid.H, y_first = o->y0 - o->gs;
+        std::vector<float> jp((size_t)(L + 2 * PAD) * 4);
+        for (int e = -PAD; e < L + PAD; e++) {
+            int y = y_first + e;
+            if (y < 0) y = -1 - y; else if (y >= H) y = 2 * H - 1 - y;
+            const int l = std::min(std::max(y - y_first, 0), L - 1);
+            for (int k = 0; k < 4; k++) jp[(size_t)(e + PAD) * 4 + k] = jc[(size_t)l * 8 + k];
+        }
+        DMG_HIP(hipMemcpyAsync(o->jcoefp, jp.data(), jp.size() * sizeof(float), hipMemcpyHostToDevice, o->ctx->stream));
+        DMG_HIP(hipStreamSynchronize(o->ctx->stream));
     }
     DMG_HIP(hipMemcpyAsync(o->jcoef, jc.data(), jc.size() * sizeof(float), hipMemcpyHostToDevice, o->ctx->stream));
     DMG_HIP(hipStreamSynchronize(o->ctx->stream));

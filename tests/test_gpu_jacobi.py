@@ -226,7 +226,7 @@ def test_overlapped_block_order_is_bitwise(dev, bands, ghost, W, H):
     from demiurge_amd import synth
     grid = capi.make_grid(W, H)
     img, b = synth.terrain(W, H), synth.divw(W, H)
-    iters = ghost * 14 + 5          # the first ten blocks of a geometry are launched whole (kernel/shape tuner), then split
+    iters = ghost * 17 + 5          # the first twelve blocks of a geometry are launched whole (kernel/shape tuner), then split
     one = run_jacobi(capi, ctx, grid, img, b, iters, block=iters, kernel=capi.JACOBI_SINGLE)
     prm = capi.default_ocean_params()
     prm.jacobi_kernel = capi.JACOBI_BLOCKED
@@ -240,7 +240,7 @@ def test_overlapped_block_order_is_bitwise(dev, bands, ghost, W, H):
         if done + n < iters:
             for o in oc:
                 o.jacobi_sweeps_begin(n)
-            if done >= 11 * ghost:
+            if done >= 13 * ghost:
                 with pytest.raises(capi.DmgError):
                     oc[0].get(want=("pressure",))         # the pressure is half a launch apart: refused
             exchange(capi, ctx, oc, ghost)                # slabs of the NEW iterate, interior tiles still to come
