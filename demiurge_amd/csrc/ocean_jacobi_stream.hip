@@ -138,7 +138,7 @@ __device__ __forceinline__ v4f st_row_any(const v4f N, const v4f C, const v4f S,
 // and the pair made in this step); K = t mod 2
 template <int S, int K>
 __device__ __forceinline__ void st_level(const st_args &a, st_state &z, v4f (*bring)[64], unsigned (*cring)[64], const v4f *ktab,
-                                         int lane, int t, int yA, int r1, bool lane_ok, int xcol,
+                                         int lane, int t, int yA, int r0, int r1, bool lane_ok, int xcol,
                                          const v4f bA, const v4f bB, v4f &bA_next, v4f &bB_next,
                                          const v4f kA, const v4f kB, v4f &kA_next, v4f &kB_next)
 {
@@ -149,7 +149,8 @@ __device__ __forceinline__ void st_level(const st_args &a, st_state &z, v4f (*br
         const int ra = max(2 * t - (S + 1), 0);               // window row of the next level's first row
         kA_next = ktab[ra]; kB_next = ktab[ra + 1];           // every lane reads the same 16 bytes: one broadcast
     }
-    if (t < S) return;                                        // level S starts once its first needed rows exist
+    // (a level whose rows do not exist yet sees them as land: landbits starts as all ones; rows that exist but are not
+    // yet valid at this level are computed like any halo row)
     const unsigned landA = (z.landbits >> (S + 1)) & 1u, landB = (z.landbits >> S) & 1u;
     const unsigned mixA = (z.mixbits >> (S + 1)) & 1u, mixB = (z.mixbits >> S) & 1u;
     const v4f S0 = z.w[S - 1][K ^ 1][0], C0 = z.w[S - 1][K ^ 1][1], N0 = z.w[S - 1][K][0], N1 = z.w[S - 1][K][1];
@@ -172,13 +173,9 @@ __device__ __forceinline__ void st_level(const st_args &a, st_state &z, v4f (*br
     }
     if (S < 8) { z.w[S & 7][K][0] = oA; z.w[S & 7][K][1] = oB; }
     else if (lane_ok && !(a.dbg & 2)) {                          // never re-read in this launch; land rows hold 0 in both buffers already
-        if (a.dbg & 4) {
-            if (!landA && yA < r1) *reinterpret_cast<v4f *>(a.pout + (size_t)yA * a.W + xcol) = oA;
-            if (!landB && yA + 1 < r1) *reinterpret_cast<v4f *>(a.pout + (size_t)(yA + 1) * a.W + xcol) = oB;
-        } else {
-        if (!landA && yA < r1) __builtin_nontemporal_store(oA, reinterpret_cast<v4f *>(a.pout + (size_t)yA * a.W + xcol));
-        if (!landB && yA + 1 < r1) __builtin_nontemporal_store(oB, reinterpret_cast<v4f *>(a.pout + (size_t)(yA + 1) * a.W + xcol));
-        }
+        // only the unit's own rows [r0, r1): in its first steps level 8 runs on rows below r0, never stored
+        if (!landA && yA >= r0 && yA < r1) __builtin_nontemporal_store(oA, reinterpret_cast<v4f *>(a.pout + (size_t)yA * a.W + xcol));
+        if (!landB && yA + 1 >= r0 && yA + 1 < r1) __builtin_nontemporal_store(oB, reinterpret_cast<v4f *>(a.pout + (size_t)(yA + 1) * a.W + xcol));
     }
 }
 
@@ -198,10 +195,13 @@ __device__ __forceinline__ unsigned st_class(unsigned cls_lo, unsigned cls_hi, i
 __device__ __forceinline__ void st_fetch(const st_args &a, st_state &z, int set, int j, int e, int col, int colp)
 {
     const st_row m = st_map_row(a, (a.dbg & 1) ? (e & 63) : e);
-    const size_t off = (size_t)m.l * a.W + (m.shift ? colp : col);
-    z.ps[set][j] = *reinterpret_cast<const v4f *>(a.pin + off);
-    z.bs[set][j] = *reinterpret_cast<const v4f *>(a.b + off);
-    z.cs[set][j] = *reinterpret_cast<const unsigned *>(a.code + off);
+    // the row's base address is wave-uniform (scalar arithmetic), the lane adds a 32-bit column offset: the loads take
+    // the SGPR-base + VGPR-offset form and the 64-bit address arithmetic leaves the vector ALU
+    const size_t rowoff = (size_t)m.l * a.W;
+    const unsigned coff = (unsigned)(m.shift ? colp : col);
+    z.ps[set][j] = *reinterpret_cast<const v4f *>(a.pin + rowoff + coff);
+    z.bs[set][j] = *reinterpret_cast<const v4f *>(a.b + rowoff + coff);
+    z.cs[set][j] = *reinterpret_cast<const unsigned *>(a.code + rowoff + coff);
 }
 typedef const float __attribute__((address_space(4))) *st_kptr;
 
@@ -254,14 +254,14 @@ __device__ __forceinline__ void st_step(const st_args &a, st_state &z, v4f (*bri
     // level 1: rows e_t - 1 (in the ring since the last step) and e_t (just written)
     const int s1 = st_wrap(z.slot - 1), r1w = max(2 * t - 1, 0);
     v4f b0 = bring[s1][lane], b1 = bring[z.slot][lane], k0 = ktab[r1w], k1 = ktab[r1w + 1], b2, b3, k2, k3;
-    st_level<1, K>(a, z, bring, cring, ktab, lane, t, e_t - 1, r1, lane_ok, xcol, b0, b1, b2, b3, k0, k1, k2, k3);
-    st_level<2, K>(a, z, bring, cring, ktab, lane, t, e_t - 2, r1, lane_ok, xcol, b2, b3, b0, b1, k2, k3, k0, k1);
-    st_level<3, K>(a, z, bring, cring, ktab, lane, t, e_t - 3, r1, lane_ok, xcol, b0, b1, b2, b3, k0, k1, k2, k3);
-    st_level<4, K>(a, z, bring, cring, ktab, lane, t, e_t - 4, r1, lane_ok, xcol, b2, b3, b0, b1, k2, k3, k0, k1);
-    st_level<5, K>(a, z, bring, cring, ktab, lane, t, e_t - 5, r1, lane_ok, xcol, b0, b1, b2, b3, k0, k1, k2, k3);
-    st_level<6, K>(a, z, bring, cring, ktab, lane, t, e_t - 6, r1, lane_ok, xcol, b2, b3, b0, b1, k2, k3, k0, k1);
-    st_level<7, K>(a, z, bring, cring, ktab, lane, t, e_t - 7, r1, lane_ok, xcol, b0, b1, b2, b3, k0, k1, k2, k3);
-    st_level<8, K>(a, z, bring, cring, ktab, lane, t, e_t - 8, r1, lane_ok, xcol, b2, b3, b0, b1, k2, k3, k0, k1);
+    st_level<1, K>(a, z, bring, cring, ktab, lane, t, e_t - 1, e0 + TB_T, r1, lane_ok, xcol, b0, b1, b2, b3, k0, k1, k2, k3);
+    st_level<2, K>(a, z, bring, cring, ktab, lane, t, e_t - 2, e0 + TB_T, r1, lane_ok, xcol, b2, b3, b0, b1, k2, k3, k0, k1);
+    st_level<3, K>(a, z, bring, cring, ktab, lane, t, e_t - 3, e0 + TB_T, r1, lane_ok, xcol, b0, b1, b2, b3, k0, k1, k2, k3);
+    st_level<4, K>(a, z, bring, cring, ktab, lane, t, e_t - 4, e0 + TB_T, r1, lane_ok, xcol, b2, b3, b0, b1, k2, k3, k0, k1);
+    st_level<5, K>(a, z, bring, cring, ktab, lane, t, e_t - 5, e0 + TB_T, r1, lane_ok, xcol, b0, b1, b2, b3, k0, k1, k2, k3);
+    st_level<6, K>(a, z, bring, cring, ktab, lane, t, e_t - 6, e0 + TB_T, r1, lane_ok, xcol, b2, b3, b0, b1, k2, k3, k0, k1);
+    st_level<7, K>(a, z, bring, cring, ktab, lane, t, e_t - 7, e0 + TB_T, r1, lane_ok, xcol, b0, b1, b2, b3, k0, k1, k2, k3);
+    st_level<8, K>(a, z, bring, cring, ktab, lane, t, e_t - 8, e0 + TB_T, r1, lane_ok, xcol, b2, b3, b0, b1, k2, k3, k0, k1);
     z.slot = z.slot + 2 == ST_RING ? 0 : z.slot + 2;
 }
 
@@ -303,7 +303,8 @@ __global__ __launch_bounds__(64, 2) void k_jacobi_stream(st_args a)
     for (int k = 0; k < 2; k++)
 #pragma unroll
         for (int j = 0; j < 2; j++) { z.ps[k][j] = (v4f)(0.0f); z.bs[k][j] = (v4f)(0.0f); z.cs[k][j] = 0; }
-    z.landbits = 0; z.mixbits = 0; z.slot = 0;
+    z.landbits = 0xFFFFFFFFu;                                // rows before the window: "land", so that a level idles until its rows exist
+    z.mixbits = 0; z.slot = 0;
     for (int i = lane; i < 2 * nsteps + 2; i += 64)          // one 16-byte table entry per window row (two spare: the next level's prefetch)
         ktab[i] = *reinterpret_cast<const v4f *>(a.jcoef + (size_t)st_map_row(a, e0 + i).l * 8);
     {
