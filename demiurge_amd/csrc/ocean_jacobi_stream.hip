@@ -548,6 +548,8 @@ static void st_cut(const dmg_ocean *o, int variant, int lo, int hi, int seg, int
                    int seg2 = 0, int split = 0)
 {
     const int ow = variant ? STN_OW : TB_OW;
+    static const float w_mixed = [] { const char *e = getenv("DMG_ST_WMIXED"); return e ? (float)atof(e) : 1.6f; }();    // experiments: the cost model's weights
+    static const float w_land = [] { const char *e = getenv("DMG_ST_WLAND"); return e ? (float)atof(e) : 0.1f; }();
     const std::vector<unsigned char> &table = variant ? o->rowclass_n_host : o->rowclass_host;
     const int tiles_x = (o->grid.W + ow - 1) / ow, L = o->L;
     const bool classes = !table.empty();
@@ -578,7 +580,7 @@ static void st_cut(const dmg_ocean *o, int variant, int lo, int hi, int seg, int
             for (int r = r0 - TB_T; r < r1 + TB_T; r++) {
                 const int c = (cls && r >= 0 && r < L) ? cls[r] : 2;
                 const int depth = std::min(std::min(r - (r0 - TB_T), (r1 + TB_T - 1) - r), TB_T);   // levels that still need this row
-                cost += (c == 1 ? 0.1f : (c == 2 ? 1.6f : 1.0f)) * (float)depth;
+                cost += (c == 1 ? w_land : (c == 2 ? w_mixed : 1.0f)) * (float)depth;
             }
             units.push_back(st_unit{ tx, r0, r1, cost + 4.0f });
         }

@@ -105,3 +105,23 @@ def test_multi_single_rank_and_rccl_self(dev):
         assert np.array_equal(m.get(want=("pressure",))["pressure"], ref)
         m.close()
     assert len(capi.Multi.unique_id()) == 128
+
+
+def test_multi_full_size_eight_bands(dev):
+    """BASELINE config 4's split -- 16384x8192 over 8 latitude bands, 32 ghost rows -- on the one GPU of the test box (peer
+    copies between 8 band threads / streams): bit-identical to one band"""
+    capi, ctx = dev
+    from demiurge_amd import synth
+    W, H, iters = 16384, 8192, 72
+    grid = capi.make_grid(W, H)
+    img, b = synth.terrain(W, H), synth.divw(W, H)
+    ref = single_jacobi(capi, ctx, grid, img, b, iters)
+    ctx.trim()
+    m = capi.Multi(grid, devices=[0] * 8, ghost=32, flags=capi.MULTI_PEER)
+    m.set_terrain(img); m.set_divw(b)
+    m.jacobi(iters, zero_first=True)
+    got = m.get(want=("pressure",))["pressure"]
+    st = m.stats()
+    m.close()
+    assert np.array_equal(got, ref)
+    assert st["exchanges"] == 3 and st["exchange_bytes"] == 3 * 32 * W * 4          # band 0 has one neighbour: 2 MiB per exchange
