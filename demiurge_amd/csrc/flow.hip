@@ -374,6 +374,7 @@ __global__ __launch_bounds__(256) void k_flow_dataflow(flow_canvas fc, const int
         if (lane == 0) base = atomicAdd(ticket, 64);
         base = __builtin_amdgcn_readfirstlane(base);
         if (base >= n_reached) return;
+        if (__hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;     // somebody gave up: so does everybody
         const int idx = n_reached - 1 - (base + lane);       // deepest cells first
         bool pending = idx >= 0;
         int p = 0, nsrc = 0, src[9];
@@ -412,8 +413,9 @@ __global__ __launch_bounds__(256) void k_flow_dataflow(flow_canvas fc, const int
                         if (k < nsrc) sum = __fadd_rn(sum, __uint_as_float(v[k]));
                     __hip_atomic_store(acc + p, __float_as_uint(sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     pending = false;
-                } else if (++polls > (1 << 20)) {            // ~a second: something upstream was never published
-                    atomicOr(error, 1);
+                } else if (++polls > (1 << 20) ||            // ~a second: something upstream was never published
+                           ((polls & 1023) == 0 && __hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                    atomicOr(error, 1);                      // (the whole grid then drains within a millisecond)
                     pending = false;
                 } else __builtin_amdgcn_s_sleep(2);
             }
