@@ -217,8 +217,10 @@ __device__ __forceinline__ void st_arrive(const st_args &a, st_state &z, v4f (*b
     // registers, and the copies the compiler then puts on the loop's back edge wait for loads that were only just issued
     {
         v2f lo, hi;
-        asm("v_mov_b64 %0, %1" : "=v"(lo) : "v"(z.ps[K][j].xy));
-        asm("v_mov_b64 %0, %1" : "=v"(hi) : "v"(z.ps[K][j].zw));
+        // (volatile + "memory": the scheduler must not hoist the set's reload above these moves either -- it did for one
+        // of the two sets, whose p rows then went through copies and an early vmcnt wait on the loop's back edge)
+        asm volatile("v_mov_b64 %0, %1" : "=v"(lo) : "v"(z.ps[K][j].xy) : "memory");
+        asm volatile("v_mov_b64 %0, %1" : "=v"(hi) : "v"(z.ps[K][j].zw) : "memory");
         z.w[0][K][j] = v4f{ lo.x, lo.y, hi.x, hi.y };
     }
     if (cls == 2u) {
@@ -428,7 +430,7 @@ __device__ __forceinline__ void stn_arrive(const st_args &a, stn_state &z, v2f (
     land = cls == 1u; mix = 0;
     {
         v2f lo;
-        asm("v_mov_b64 %0, %1" : "=v"(lo) : "v"(z.ps[K][j]));       // a real move (see st_arrive)
+        asm volatile("v_mov_b64 %0, %1" : "=v"(lo) : "v"(z.ps[K][j]) : "memory");       // a real move (see st_arrive)
         z.w[0][K][j] = lo;
     }
     if (cls == 2u) {
@@ -616,7 +618,7 @@ static const dmg_ocean::tile_list *st_units(dmg_ocean *o, int variant, int lo, i
     auto key = std::make_tuple(lo, hi, (variant ? -3000 : -1000) - seg, part, zone_lo, zone_hi);    // "rows per wave" <= -1000 = stream units (seg 0 = auto)
     auto it = o->tb_lists.find(key);
     if (it != o->tb_lists.end()) return &it->second;
-    const int slots = std::max(o->ctx->num_cu, 1) * (variant ? 16 : 8);     // four / two waves per SIMD
+    const int slots = std::max(o->ctx->num_cu, 1) * (variant ? 20 : 8);     // five (96 VGPRs) / two waves per SIMD
     std::vector<st_unit> units, best;
     if (seg > 0) { st_cut(o, variant, lo, hi, seg, part, zone_lo, zone_hi, best); (void)st_makespan(best, slots); }
     else {
