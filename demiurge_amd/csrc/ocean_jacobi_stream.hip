@@ -28,7 +28,8 @@
 #include "ocean_tb.h"
 #include <algorithm>
 
-#define ST_MAXROWS 112            // output rows per unit: the 128 window rows' classes fit two registers
+#define ST_MAXROWS 104            // output rows per unit: the window rows' classes fit two registers, and the coefficient
+                                  // table of 104 + 22 rows leaves the wide form's LDS at 20448 bytes: 8 waves share 160 KB
 #define ST_RING 12                // ring slots (rows): 10 rows are in flight between level 0 and level 8, two arrive
 
 struct st_args {
@@ -43,6 +44,7 @@ struct st_args {
     const unsigned char *rowclass;  // [tiles_x][L]: 0 open ocean, 1 land everywhere, 2 mixed; or null
     const int4 *units;              // {tile column, first output row, end output row, -}
     const float *jcoef_cy;          // {cy, 1/cy}: the same for every row
+    unsigned long long *prof;       // experiments only (DMG_ST_PROF): {start, end} of every unit on the 100 MHz s_memrealtime clock, or null
     int dbg;                        // experiments only (DMG_ST_DBG bits): 1 = every unit re-reads 64 rows (cache hits), 2 = no stores, 4 = plain instead of nontemporal stores
 };
 
@@ -110,7 +112,7 @@ __device__ __forceinline__ int st_wrap(int slot) { return slot < 0 ? slot + ST_R
 
 // one row of one level, generic: open ocean or coast (wave-uniform choice); N, C, S = the level below's rows y+1, y, y-1
 __device__ __forceinline__ v4f st_row_any(const v4f N, const v4f C, const v4f S, const v4f bb, const v4f kk, float cy, float ry, bool mixed,
-                                          const unsigned *crow, int lane, int tick)
+                                          const uint2 *crow, int lane)
 {
     const jacobi_row k = { kk.x, cy, kk.z, kk.y, ry, kk.w };
     const float wl = dpp_from_prev_lane(C.w);                // west neighbour of C.x
@@ -121,15 +123,28 @@ __device__ __forceinline__ v4f st_row_any(const v4f N, const v4f C, const v4f S,
         o0 = st_value2(N.xy, S.xy, Mid, Wlo, bb.xy, k);      // cells x, y: W = (wl, x), E = (y, z)
         o1 = st_value2(N.zw, S.zw, Ehi, Mid, bb.zw, k);      // cells z, w: W = (y, z), E = (w, er)
     } else {
-        const unsigned c = crow[lane];
-        const int t = tick;
-        const v2f n0 = { st_sel<0>(c, t, C.x, N.x), st_sel<8>(c, t, C.y, N.y) }, n1 = { st_sel<16>(c, t, C.z, N.z), st_sel<24>(c, t, C.w, N.w) };
-        const v2f s0 = { st_sel<1>(c, t, C.x, S.x), st_sel<9>(c, t, C.y, S.y) }, s1 = { st_sel<17>(c, t, C.z, S.z), st_sel<25>(c, t, C.w, S.w) };
-        const v2f e0 = { st_sel<2>(c, t, C.x, C.y), st_sel<10>(c, t, C.y, C.z) }, e1 = { st_sel<18>(c, t, C.z, C.w), st_sel<26>(c, t, C.w, er) };
-        const v2f w0 = { st_sel<3>(c, t, C.x, wl), st_sel<11>(c, t, C.y, C.x) }, w1 = { st_sel<19>(c, t, C.z, C.y), st_sel<27>(c, t, C.w, C.z) };
-        const v2f r0 = st_value2(n0, s0, e0, w0, bb.xy, k), r1 = st_value2(n1, s1, e1, w1, bb.zw, k);
-        o0 = v2f{ st_zero_land<4>(c, t, r0.x), st_zero_land<12>(c, t, r0.y) };
-        o1 = v2f{ st_zero_land<20>(c, t, r1.x), st_zero_land<28>(c, t, r1.y) };
+        // coast row.  Land holds exactly +0.0 at every level, so "a land neighbour reads the centre value"
+        // (OceanCurrents.cpp:470-473) is pW' + pE' = (pW + pE) + n * pC with n = the number of land neighbours among the
+        // two -- exactly, in one rounding: n = 0 adds a zero, n = 1 leaves pK + pC (the other addend is the land cell's
+        // +0), n = 2 leaves 0 + 2 pC.  The counts travel as four fp8 values per word (0, 1, 2 are exact in E4M3),
+        // unpacked two at a time by v_cvt_pk_f32_fp8, and one v_pk_fma_f32 per pair replaces eight bit-field selects.
+        // A land centre carries the count -1 in the N/S word: L = clamp(n + 1) is 0 there and 1 on water, and
+        // x = L * t - b (b is -0.0 on land, st_arrive) is then +0, which the divisions by Beta > 0 keep: land -> +0.0 (:481).
+        // (A pressure of -0.0, which no sweep that started from +0.0 produces inside the division window of
+        // demiurge_hip.h, would read back as +0.0 from an open neighbour pair here.)
+        const uint2 c = crow[lane];
+        const v2f kwe0 = __builtin_amdgcn_cvt_pk_f32_fp8((int)c.x, false), kwe1 = __builtin_amdgcn_cvt_pk_f32_fp8((int)c.x, true);
+        const v2f ksn0 = __builtin_amdgcn_cvt_pk_f32_fp8((int)c.y, false), ksn1 = __builtin_amdgcn_cvt_pk_f32_fp8((int)c.y, true);
+        const v2f one = { 1.0f, 1.0f };
+        v2f L0, L1;
+        asm("v_pk_add_f32 %0, %1, %2 clamp" : "=v"(L0) : "v"(ksn0), "v"(one));
+        asm("v_pk_add_f32 %0, %1, %2 clamp" : "=v"(L1) : "v"(ksn1), "v"(one));
+        const v2f Wlo = { wl, C.x }, Mid = { C.y, C.z }, Ehi = { C.w, er };
+        const v2f we0 = __builtin_elementwise_fma(kwe0, C.xy, Wlo + Mid), we1 = __builtin_elementwise_fma(kwe1, C.zw, Mid + Ehi);
+        const v2f sn0 = __builtin_elementwise_fma(ksn0, C.xy, S.xy + N.xy), sn1 = __builtin_elementwise_fma(ksn1, C.zw, S.zw + N.zw);
+        const v2f t0 = st_div2(we0, k.cx, k.rx) + st_div2(sn0, k.cy, k.ry), t1 = st_div2(we1, k.cx, k.rx) + st_div2(sn1, k.cy, k.ry);
+        o0 = st_div2(__builtin_elementwise_fma(L0, t0, -bb.xy), k.beta, k.rb);
+        o1 = st_div2(__builtin_elementwise_fma(L1, t1, -bb.zw), k.beta, k.rb);
     }
     return v4f{ o0.x, o0.y, o1.x, o1.y };
 }
@@ -137,7 +152,7 @@ __device__ __forceinline__ v4f st_row_any(const v4f N, const v4f C, const v4f S,
 // one level: sweep S of rows yA = e0 + 2t - S and yB = yA + 1 from level S-1's rows yA-1 .. yB+1 (the pair made one step ago
 // and the pair made in this step); K = t mod 2
 template <int S, int K>
-__device__ __forceinline__ void st_level(const st_args &a, st_state &z, v4f (*bring)[64], unsigned (*cring)[64], const v4f *ktab,
+__device__ __forceinline__ void st_level(const st_args &a, st_state &z, v4f (*bring)[64], uint2 (*cring)[64], const v4f *ktab,
                                          int lane, int t, int yA, int r0, int r1, bool lane_ok, int xcol,
                                          const v4f bA, const v4f bB, v4f &bA_next, v4f &bB_next,
                                          const v4f kA, const v4f kB, v4f &kA_next, v4f &kB_next)
@@ -168,8 +183,8 @@ __device__ __forceinline__ void st_level(const st_args &a, st_state &z, v4f (*br
         oB = v4f{ b0.x, b0.y, b1.x, b1.y };
     } else {
         const int sa = st_wrap(z.slot - S), sb = sa + 1 == ST_RING ? 0 : sa + 1;
-        oA = landA ? (v4f)(0.0f) : st_row_any(N0, C0, S0, bA, kA, z.cy, z.ry, mixA != 0, cring[sa], lane, t);
-        oB = landB ? (v4f)(0.0f) : st_row_any(N1, N0, C0, bB, kB, z.cy, z.ry, mixB != 0, cring[sb], lane, t);
+        oA = landA ? (v4f)(0.0f) : st_row_any(N0, C0, S0, bA, kA, z.cy, z.ry, mixA != 0, cring[sa], lane);
+        oB = landB ? (v4f)(0.0f) : st_row_any(N1, N0, C0, bB, kB, z.cy, z.ry, mixB != 0, cring[sb], lane);
     }
     if (S < 8) { z.w[S & 7][K][0] = oA; z.w[S & 7][K][1] = oB; }
     else if (lane_ok && !(a.dbg & 2)) {                          // never re-read in this launch; land rows hold 0 in both buffers already
@@ -208,7 +223,7 @@ typedef const float __attribute__((address_space(4))) *st_kptr;
 // the row that has arrived in staging slot [K][j]: classify it, take its pressure into level 0, park its right-hand side
 // and codes in the rings
 template <int K>
-__device__ __forceinline__ void st_arrive(const st_args &a, st_state &z, v4f (*bring)[64], unsigned (*cring)[64], int lane,
+__device__ __forceinline__ void st_arrive(const st_args &a, st_state &z, v4f (*bring)[64], uint2 (*cring)[64], int lane,
                                           int j, int e, unsigned cls, int slot, unsigned &land, unsigned &mix)
 {
     land = cls == 1u; mix = 0;
@@ -234,13 +249,28 @@ __device__ __forceinline__ void st_arrive(const st_args &a, st_state &z, v4f (*b
         mix = __builtin_amdgcn_ballot_w64((c & 0x1F1F1F1Fu) != 0) != 0;
         land = __builtin_amdgcn_ballot_w64((c & 0x10101010u) != 0x10101010u) == 0;
         mix &= ~land;
-        if (mix) cring[slot][lane] = c;
+        if (mix) {
+            // code byte of a cell: bit 0 N, 1 S, 2 E, 3 W neighbour is land, bit 4 the cell itself.  v_perm_b32 as a byte
+            // table: {E,W} -> fp8 of their count; {N,S} likewise, and -1.0 for a land cell (E4M3: 0x38 = 1, 0x40 = 2, 0xB8 = -1)
+            const unsigned c2 = c >> 2;
+            const unsigned we = __builtin_amdgcn_perm(0u, 0x40383800u, c2 & 0x03030303u);
+            const unsigned sn = __builtin_amdgcn_perm(0xB8B8B8B8u, 0x40383800u, (c & 0x03030303u) | (c2 & 0x04040404u));
+            cring[slot][lane] = uint2{ we, sn };
+            // the right-hand side of a land cell becomes -0.0: x = 0 * t - (-0.0) is then +0.0 whatever the sign of t
+            v4f bq = z.bs[K][j];
+            asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(bq.x) : "v"(code_mask<4>(c, 0)), "v"(0x80000000u), "v"(bq.x));
+            asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(bq.y) : "v"(code_mask<12>(c, 0)), "v"(0x80000000u), "v"(bq.y));
+            asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(bq.z) : "v"(code_mask<20>(c, 0)), "v"(0x80000000u), "v"(bq.z));
+            asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(bq.w) : "v"(code_mask<28>(c, 0)), "v"(0x80000000u), "v"(bq.w));
+            bring[slot][lane] = bq;
+            return;
+        }
     }
     bring[slot][lane] = z.bs[K][j];
 }
 
 template <int K>
-__device__ __forceinline__ void st_step(const st_args &a, st_state &z, v4f (*bring)[64], unsigned (*cring)[64], const v4f *ktab, int lane, int t,
+__device__ __forceinline__ void st_step(const st_args &a, st_state &z, v4f (*bring)[64], uint2 (*cring)[64], const v4f *ktab, int lane, int t,
                                         int e0, int nsteps, int r1, unsigned cls_lo, unsigned cls_hi, int col, int colp, bool lane_ok, int xcol)
 {
     const int e_t = e0 + 2 * t;                              // first row of the pair that has just arrived
@@ -271,12 +301,13 @@ __device__ __forceinline__ void st_step(const st_args &a, st_state &z, v4f (*bri
 __global__ __launch_bounds__(64, 2) void k_jacobi_stream(st_args a)
 {
     __shared__ v4f bring[ST_RING][64];
-    __shared__ unsigned cring[ST_RING][64];
+    __shared__ uint2 cring[ST_RING][64];             // coast rows: land-neighbour counts {E/W, N/S} as 4 x fp8 each (st_row_any)
     __shared__ v4f ktab[ST_MAXROWS + 2 * TB_T + 6];   // coefficients {cx, 1/cx, Beta, 1/Beta} of every window row, filled once
     const int lane = threadIdx.x;
     const int4 u = a.units[blockIdx.x];
     const int tx = __builtin_amdgcn_readfirstlane(u.x), r0 = __builtin_amdgcn_readfirstlane(u.y), r1 = __builtin_amdgcn_readfirstlane(u.z);
     const int W = a.W;
+    if (a.prof && lane == 0) a.prof[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
     // two window rows per step, and an even number of steps: the loop body is two steps with no branch in between, so that
     // every wait for a staged load is a counted vmcnt (a conditional second step makes the compiler wait for vmcnt(0))
     const int nsteps = (((r1 - r0) + 2 * TB_T + 3) / 4) * 2;
@@ -321,6 +352,7 @@ __global__ __launch_bounds__(64, 2) void k_jacobi_stream(st_args a)
         st_step<0>(a, z, bring, cring, ktab, lane, t, e0, nsteps, r1, cls_lo, cls_hi, col, colp, lane_ok, xcol);
         st_step<1>(a, z, bring, cring, ktab, lane, t + 1, e0, nsteps, r1, cls_lo, cls_hi, col, colp, lane_ok, xcol);
     }
+    if (a.prof && lane == 0) a.prof[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
 }
 
 // =================================================================================================================
@@ -683,9 +715,33 @@ int ocean_launch_stream(dmg_ocean *o, int lo, int hi, int part, int zone_lo, int
     o->last_kernel = variant ? "k_jacobi_stream_n" : "k_jacobi_stream";
     static const int dbg = [] { const char *e = getenv("DMG_ST_DBG"); return e ? atoi(e) : 0; }();
     a.dbg = dbg;
+    a.prof = nullptr;
+    static const char *prof_path = getenv("DMG_ST_PROF");  // experiments: the first full-size launch writes one line per unit to this file
+    static bool prof_done = false;
+    const bool prof_now = prof_path && !prof_done && !variant && tl->n > 1024;
+    if (prof_now && hipMalloc((void **)&a.prof, (size_t)tl->n * 16) != hipSuccess) a.prof = nullptr;
     static const int extra_lds = [] { const char *e = getenv("DMG_ST_EXTRA_LDS"); return e ? atoi(e) : 0; }();   // experiments: caps the waves per CU
     if (variant) hipLaunchKernelGGL(k_jacobi_stream_n, dim3((unsigned)tl->n), dim3(64), (size_t)extra_lds, st, a);
     else hipLaunchKernelGGL(k_jacobi_stream, dim3((unsigned)tl->n), dim3(64), (size_t)extra_lds, st, a);
     DMG_HIP(hipGetLastError());
+    if (prof_now && a.prof) {
+        prof_done = true;
+        std::vector<unsigned long long> tt((size_t)tl->n * 2);
+        std::vector<int> uu((size_t)tl->n * 4);
+        DMG_HIP(hipStreamSynchronize(st));
+        DMG_HIP(hipMemcpy(tt.data(), a.prof, tt.size() * 8, hipMemcpyDeviceToHost));
+        DMG_HIP(hipMemcpy(uu.data(), tl->d, uu.size() * 4, hipMemcpyDeviceToHost));
+        (void)hipFree(a.prof);
+        if (FILE *f = fopen(prof_path, "w")) {
+            fprintf(f, "tx,r0,r1,open,mixed,land,t0,t1\n");
+            for (int i = 0; i < tl->n; i++) {
+                int cnt[3] = { 0, 0, 0 };
+                const unsigned char *cls = o->rowclass_host.empty() ? nullptr : o->rowclass_host.data() + (size_t)uu[4 * i] * o->L;
+                for (int r = uu[4 * i + 1] - TB_T; r < uu[4 * i + 2] + TB_T; r++) cnt[(cls && r >= 0 && r < o->L) ? cls[r] : 2]++;
+                fprintf(f, "%d,%d,%d,%d,%d,%d,%llu,%llu\n", uu[4 * i], uu[4 * i + 1], uu[4 * i + 2], cnt[0], cnt[2], cnt[1], tt[2 * i], tt[2 * i + 1]);
+            }
+            fclose(f);
+        }
+    }
     return DMG_OK;
 }
