@@ -297,7 +297,7 @@ void dmg_ocean_destroy(dmg_ocean *o)
     (void)hipSetDevice(o->ctx->device);
     (void)hipStreamSynchronize(o->ctx->stream);
     for (void *p : { (void *)o->p[0], (void *)o->p[1], (void *)o->divw, (void *)o->img, (void *)o->code, (void *)o->code8,
-                     (void *)o->v[0], (void *)o->v[1], (void *)o->rowtab, (void *)o->jcoef, (void *)o->jcoefp, (void *)o->oob_flag, (void *)o->rowclass, (void *)o->rowclass_n })
+                     (void *)o->v[0], (void *)o->v[1], (void *)o->rowtab, (void *)o->jcoef, (void *)o->jcoefp, (void *)o->oob_flag, (void *)o->rowclass, (void *)o->rowclass_n, (void *)o->rowclass32 })
         if (p) (void)hipFree(p);
     ocean_tb_free_lists(o);
     dmg_ctx *ctx = o->ctx;

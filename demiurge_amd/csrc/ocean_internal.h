@@ -40,8 +40,16 @@ struct dmg_ocean {
     unsigned char *rowclass = nullptr; // blocked Jacobi: class of every (tile column, row) wave-row (ocean_jacobi_tb.hip)
     std::vector<unsigned char> rowclass_host;   // the same table on the host, for the live-tile lists
     unsigned char *rowclass_n = nullptr;        // the same for the narrow streaming kernel's 112-column strips
+    unsigned *rowclass32 = nullptr;             // rowclass widened to 32 bits per entry (the persistent streaming kernel loads it per row)
     std::vector<unsigned char> rowclass_n_host;
-    struct tile_list { int *d = nullptr; int n = 0; };
+    struct tile_list {
+        int *d = nullptr; int n = 0;
+        // persistent streaming kernel: segment table templates and the launch's live copies (ocean_jacobi_stream.hip)
+        unsigned long long *seg_word0 = nullptr, *seg_word = nullptr;
+        unsigned *seg_cur0 = nullptr, *seg_cur = nullptr;
+        int *seg_ctl = nullptr;
+        int cap = 0, waves = 0;
+    };
     // (out_lo, out_hi, rows per wave, part, zone_lo, zone_hi) of a launch -> tiles that are not land everywhere; part 0 = all
     // tile rows, 1 = tile rows touching the send zones [out_lo, zone_lo) / [zone_hi, out_hi), 2 = the tile rows in between
     std::map<std::tuple<int, int, int, int, int, int>, tile_list> tb_lists;

@@ -44,8 +44,16 @@ struct st_args {
     const unsigned char *rowclass;  // [tiles_x][L]: 0 open ocean, 1 land everywhere, 2 mixed; or null
     const int4 *units;              // {tile column, first output row, end output row, -}
     const float *jcoef_cy;          // {cy, 1/cy}: the same for every row
+    // persistent form (k_jacobi_stream_p): segment table and queue, see there
+    unsigned long long *seg_word;   // [cap + waves]: stp_word(strip, first row, end row); the end row only ever moves down (compare-and-swap by a thief)
+    unsigned *seg_cur;              // [cap + waves]: next window row its owner will take + STP_BIAS (owner's progress, plain stores; advisory)
+    int *seg_ctl;                   // [0] next queued segment, [1] next free table slot
+    int nseg0, cap;
+    const unsigned *rowclass32;     // rowclass, one 32-bit word per entry
     unsigned long long *prof;       // experiments only (DMG_ST_PROF): {start, end} of every unit on the 100 MHz s_memrealtime clock, or null
-    int dbg;                        // experiments only (DMG_ST_DBG bits): 1 = every unit re-reads 64 rows (cache hits), 2 = no stores, 4 = plain instead of nontemporal stores
+    int dbg;                        // experiments only (DMG_ST_DBG bits): 1 = every unit re-reads 64 rows (cache hits), 2 = no stores, 4 = plain instead of nontemporal stores;
+                                    // persistent form: 8 = owners do not re-read their end row, 16 = no stealing, 32 = owners do not publish progress,
+                                    // 64 = row classes from the table instead of from the codes, 128 = no coefficient refills (timing only: wrong results)
 };
 
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -103,10 +111,13 @@ struct st_state {
     // ~4-6 us of the wave's arithmetic, to come back: one step was not enough, the waves sat in s_waitcnt a third of the time)
     v4f ps[2][2], bs[2][2];
     unsigned cs[2][2];
+    unsigned ks[2][2];              // persistent form: the row's class travels with its loads
     unsigned landbits, mixbits;     // bit j: row (newest - j) is land everywhere / has coast; newest = second row of this step's pair
     int slot;                       // ring slot of the first row of this step's pair (row offset mod ST_RING)
     float cy, ry;                   // the same for every row (pixelsize().y, src/Shader.h:71-74): two SGPRs
 };
+#define STP_KT 128                // persistent form: the coefficient table is a ring over the window rows
+template <bool P> __device__ __forceinline__ int st_kt(int window_row) { return P ? (window_row & (STP_KT - 1)) : window_row; }
 
 __device__ __forceinline__ int st_wrap(int slot) { return slot < 0 ? slot + ST_RING : slot; }
 
@@ -151,7 +162,7 @@ __device__ __forceinline__ v4f st_row_any(const v4f N, const v4f C, const v4f S,
 
 // one level: sweep S of rows yA = e0 + 2t - S and yB = yA + 1 from level S-1's rows yA-1 .. yB+1 (the pair made one step ago
 // and the pair made in this step); K = t mod 2
-template <int S, int K>
+template <int S, int K, bool P>
 __device__ __forceinline__ void st_level(const st_args &a, st_state &z, v4f (*bring)[64], uint2 (*cring)[64], const v4f *ktab,
                                          int lane, int t, int yA, int r0, int r1, bool lane_ok, int xcol,
                                          const v4f bA, const v4f bB, v4f &bA_next, v4f &bB_next,
@@ -162,7 +173,7 @@ __device__ __forceinline__ void st_level(const st_args &a, st_state &z, v4f (*br
         const int sa = st_wrap(z.slot - (S + 1)), sb = sa + 1 == ST_RING ? 0 : sa + 1;
         bA_next = bring[sa][lane]; bB_next = bring[sb][lane];
         const int ra = max(2 * t - (S + 1), 0);               // window row of the next level's first row
-        kA_next = ktab[ra]; kB_next = ktab[ra + 1];           // every lane reads the same 16 bytes: one broadcast
+        kA_next = ktab[st_kt<P>(ra)]; kB_next = ktab[st_kt<P>(ra + 1)];    // every lane reads the same 16 bytes: one broadcast
     }
     // (a level whose rows do not exist yet sees them as land: landbits starts as all ones; rows that exist but are not
     // yet valid at this level are computed like any halo row)
@@ -207,7 +218,8 @@ __device__ __forceinline__ unsigned st_class(unsigned cls_lo, unsigned cls_hi, i
 // prefetch distance collapses to nothing.  (Land rows inside a live unit are few; their loads are wasted bytes.)
 // (Measured and dropped: pointing the loads a row does not need -- everything of a land row, the codes of an open-ocean
 // row -- at an already cached row saves ~10 % of the bytes but costs more in address arithmetic: 2.58 -> 2.49 M.)
-__device__ __forceinline__ void st_fetch(const st_args &a, st_state &z, int set, int j, int e, int col, int colp)
+template <bool P>
+__device__ __forceinline__ void st_fetch(const st_args &a, st_state &z, int set, int j, int e, int col, int colp, int tx = 0)
 {
     const st_row m = st_map_row(a, (a.dbg & 1) ? (e & 63) : e);
     // the row's base address is wave-uniform (scalar arithmetic), the lane adds a 32-bit column offset: the loads take
@@ -217,6 +229,7 @@ __device__ __forceinline__ void st_fetch(const st_args &a, st_state &z, int set,
     z.ps[set][j] = *reinterpret_cast<const v4f *>(a.pin + rowoff + coff);
     z.bs[set][j] = *reinterpret_cast<const v4f *>(a.b + rowoff + coff);
     z.cs[set][j] = *reinterpret_cast<const unsigned *>(a.code + rowoff + coff);
+    if (P && (a.dbg & 64)) z.ks[set][j] = a.rowclass32[(size_t)tx * a.L + m.l];          // every lane the same word
 }
 typedef const float __attribute__((address_space(4))) *st_kptr;
 
@@ -269,31 +282,45 @@ __device__ __forceinline__ void st_arrive(const st_args &a, st_state &z, v4f (*b
     bring[slot][lane] = z.bs[K][j];
 }
 
+// class of the row in staging slot [K][j] (persistent form): rows beyond the grid or the stored band count as mixed
 template <int K>
+__device__ __forceinline__ unsigned st_class_p(const st_args &a, const st_state &z, int j, int e)
+{
+    const int yg = a.y_first + e;
+    if (!(a.dbg & 64)) return 2u;                            // the codes decide (st_arrive)
+    const bool inside = yg >= 0 && yg < a.H && e >= 0 && e < a.L;
+    // (volatile: left to the scheduler, this read -- and with it the wait for the staging set's loads -- moves a whole step
+    // up, to where the set before it has only just been taken)
+    unsigned c;
+    asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(c) : "v"(z.ks[K][j]) : "memory");
+    return inside ? c : 2u;
+}
+
+template <int K, bool P = false>
 __device__ __forceinline__ void st_step(const st_args &a, st_state &z, v4f (*bring)[64], uint2 (*cring)[64], const v4f *ktab, int lane, int t,
-                                        int e0, int nsteps, int r1, unsigned cls_lo, unsigned cls_hi, int col, int colp, bool lane_ok, int xcol)
+                                        int e0, int nsteps, int r1, unsigned cls_lo, unsigned cls_hi, int col, int colp, bool lane_ok, int xcol, int tx = 0)
 {
     const int e_t = e0 + 2 * t;                              // first row of the pair that has just arrived
     const int slotB = z.slot + 1;                            // (ST_RING is even: a pair never wraps)
     unsigned landA, mixA, landB, mixB;
-    st_arrive<K>(a, z, bring, cring, lane, 0, e_t, st_class(cls_lo, cls_hi, 2 * t), z.slot, landA, mixA);
-    st_arrive<K>(a, z, bring, cring, lane, 1, e_t + 1, st_class(cls_lo, cls_hi, 2 * t + 1), slotB, landB, mixB);
+    st_arrive<K>(a, z, bring, cring, lane, 0, e_t, P ? st_class_p<K>(a, z, 0, e_t) : st_class(cls_lo, cls_hi, 2 * t), z.slot, landA, mixA);
+    st_arrive<K>(a, z, bring, cring, lane, 1, e_t + 1, P ? st_class_p<K>(a, z, 1, e_t + 1) : st_class(cls_lo, cls_hi, 2 * t + 1), slotB, landB, mixB);
     z.landbits = (z.landbits << 2) | (landA << 1) | landB;
     z.mixbits = (z.mixbits << 2) | (mixA << 1) | mixB;
     // the staging set is free again: the pair of step t + 2 (past the window's end the rows are clamped and unused)
-    st_fetch(a, z, K, 0, e_t + 4, col, colp);
-    st_fetch(a, z, K, 1, e_t + 5, col, colp);
+    st_fetch<P>(a, z, K, 0, e_t + 4, col, colp, tx);
+    st_fetch<P>(a, z, K, 1, e_t + 5, col, colp, tx);
     // level 1: rows e_t - 1 (in the ring since the last step) and e_t (just written)
     const int s1 = st_wrap(z.slot - 1), r1w = max(2 * t - 1, 0);
-    v4f b0 = bring[s1][lane], b1 = bring[z.slot][lane], k0 = ktab[r1w], k1 = ktab[r1w + 1], b2, b3, k2, k3;
-    st_level<1, K>(a, z, bring, cring, ktab, lane, t, e_t - 1, e0 + TB_T, r1, lane_ok, xcol, b0, b1, b2, b3, k0, k1, k2, k3);
-    st_level<2, K>(a, z, bring, cring, ktab, lane, t, e_t - 2, e0 + TB_T, r1, lane_ok, xcol, b2, b3, b0, b1, k2, k3, k0, k1);
-    st_level<3, K>(a, z, bring, cring, ktab, lane, t, e_t - 3, e0 + TB_T, r1, lane_ok, xcol, b0, b1, b2, b3, k0, k1, k2, k3);
-    st_level<4, K>(a, z, bring, cring, ktab, lane, t, e_t - 4, e0 + TB_T, r1, lane_ok, xcol, b2, b3, b0, b1, k2, k3, k0, k1);
-    st_level<5, K>(a, z, bring, cring, ktab, lane, t, e_t - 5, e0 + TB_T, r1, lane_ok, xcol, b0, b1, b2, b3, k0, k1, k2, k3);
-    st_level<6, K>(a, z, bring, cring, ktab, lane, t, e_t - 6, e0 + TB_T, r1, lane_ok, xcol, b2, b3, b0, b1, k2, k3, k0, k1);
-    st_level<7, K>(a, z, bring, cring, ktab, lane, t, e_t - 7, e0 + TB_T, r1, lane_ok, xcol, b0, b1, b2, b3, k0, k1, k2, k3);
-    st_level<8, K>(a, z, bring, cring, ktab, lane, t, e_t - 8, e0 + TB_T, r1, lane_ok, xcol, b2, b3, b0, b1, k2, k3, k0, k1);
+    v4f b0 = bring[s1][lane], b1 = bring[z.slot][lane], k0 = ktab[st_kt<P>(r1w)], k1 = ktab[st_kt<P>(r1w + 1)], b2, b3, k2, k3;
+    st_level<1, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 1, e0 + TB_T, r1, lane_ok, xcol, b0, b1, b2, b3, k0, k1, k2, k3);
+    st_level<2, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 2, e0 + TB_T, r1, lane_ok, xcol, b2, b3, b0, b1, k2, k3, k0, k1);
+    st_level<3, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 3, e0 + TB_T, r1, lane_ok, xcol, b0, b1, b2, b3, k0, k1, k2, k3);
+    st_level<4, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 4, e0 + TB_T, r1, lane_ok, xcol, b2, b3, b0, b1, k2, k3, k0, k1);
+    st_level<5, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 5, e0 + TB_T, r1, lane_ok, xcol, b0, b1, b2, b3, k0, k1, k2, k3);
+    st_level<6, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 6, e0 + TB_T, r1, lane_ok, xcol, b2, b3, b0, b1, k2, k3, k0, k1);
+    st_level<7, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 7, e0 + TB_T, r1, lane_ok, xcol, b0, b1, b2, b3, k0, k1, k2, k3);
+    st_level<8, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 8, e0 + TB_T, r1, lane_ok, xcol, b2, b3, b0, b1, k2, k3, k0, k1);
     z.slot = z.slot + 2 == ST_RING ? 0 : z.slot + 2;
 }
 
@@ -344,15 +371,203 @@ __global__ __launch_bounds__(64, 2) void k_jacobi_stream(st_args a)
         const st_kptr cf = (st_kptr)(unsigned long long)a.jcoef;
         z.cy = cf[4]; z.ry = cf[5];
     }
-    st_fetch(a, z, 0, 0, e0, col, colp);
-    st_fetch(a, z, 0, 1, e0 + 1, col, colp);
-    st_fetch(a, z, 1, 0, e0 + 2, col, colp);                 // (rows past the window are clamped into the band: harmless)
-    st_fetch(a, z, 1, 1, e0 + 3, col, colp);
+    st_fetch<false>(a, z, 0, 0, e0, col, colp);
+    st_fetch<false>(a, z, 0, 1, e0 + 1, col, colp);
+    st_fetch<false>(a, z, 1, 0, e0 + 2, col, colp);          // (rows past the window are clamped into the band: harmless)
+    st_fetch<false>(a, z, 1, 1, e0 + 3, col, colp);
     for (int t = 0; t < nsteps; t += 2) {
         st_step<0>(a, z, bring, cring, ktab, lane, t, e0, nsteps, r1, cls_lo, cls_hi, col, colp, lane_ok, xcol);
         st_step<1>(a, z, bring, cring, ktab, lane, t + 1, e0, nsteps, r1, cls_lo, cls_hi, col, colp, lane_ok, xcol);
     }
     if (a.prof && lane == 0) a.prof[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+}
+
+// =================================================================================================================
+// The persistent form: the same wave program, but a wave does not end with its unit.
+//
+// Measured on k_jacobi_stream (DMG_ST_PROF, one line per unit): identical units take 120 .. 183 us depending on what
+// their neighbours on the CU and in the memory system are doing, so however the units are cut, the last of a launch's
+// ~2.4 rounds leaves 8-11 % of the wave slots idle; and a unit of n rows pays for n + 15 (the pipeline's fill and drain),
+// which at the 84-104 rows a balanced cut allows is another 15 %.  Here the launch has exactly as many waves as the chip
+// has slots.  Every wave first takes segments from a queue (cut so that there is about one per wave: ~270 rows on the
+// full grid, 5 % fill overhead), and a wave that finds the queue empty takes the upper part of the segment with the most
+// rows left: the owner of a segment publishes its progress, re-reads its end row every four rows, and a thief moves the end
+// row down with one compare-and-swap.  Nobody ever waits for anybody: a wave that finds nothing worth taking (fewer than
+// STP_MIN_STEAL rows left anywhere) ends, so the grid drains by itself.
+//
+// Why a stale view is harmless: every row a wave stores is the correct value of that row (a level's row is computed
+// from three correct rows of the level below, wherever the wave started), so a row stored by two waves is stored twice
+// with the same bits.  What must hold is only that every row of a segment is stored by somebody: the thief stores
+// [h', end) for the end it swapped out, and the owner stops at no end it has not read from the word itself.
+// =================================================================================================================
+#define STP_BIAS 1024             // rows are stored + STP_BIAS (a window starts 8 rows below its segment)
+#define STP_MIN_STEAL 24          // rows left (not yet taken in by the owner) below which a segment is left alone
+// A segment's word: strip (12 bits) | first row + STP_BIAS (26 bits) | end row + STP_BIAS (26 bits).  Everything a thief
+// needs to stay inside the segment is in this one word; the owner's progress (seg_cur) is advisory -- whatever a thief
+// reads there is clamped into [first - 8, end], so a stale or not yet written value only makes the split less even.
+#define STP_FIELD 26
+#define STP_MASK ((1u << STP_FIELD) - 1u)
+__host__ __device__ __forceinline__ unsigned long long stp_word(int tx, int lo, int hi)
+{
+    return ((unsigned long long)(unsigned)tx << (2 * STP_FIELD)) | ((unsigned long long)(unsigned)(lo + STP_BIAS) << STP_FIELD) | (unsigned)(hi + STP_BIAS);
+}
+__device__ __forceinline__ int stp_hi(unsigned long long w) { return (int)((unsigned)w & STP_MASK) - STP_BIAS; }
+__device__ __forceinline__ int stp_lo(unsigned long long w) { return (int)((unsigned)(w >> STP_FIELD) & STP_MASK) - STP_BIAS; }
+__device__ __forceinline__ int stp_tx(unsigned long long w) { return (int)(w >> (2 * STP_FIELD)); }
+
+__global__ void k_st_reset(unsigned long long *word, unsigned *cur, int *ctl, const unsigned long long *word0,
+                                                     const unsigned *cur0, int nseg0, int total)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) { word[i] = i < nseg0 ? word0[i] : 0ull; cur[i] = i < nseg0 ? cur0[i] : 0u; }
+    if (i == 0) { ctl[0] = 0; ctl[1] = nseg0; }
+}
+
+__global__ __launch_bounds__(64, 2) void k_jacobi_stream_p(st_args a)
+{
+    __shared__ v4f bring[ST_RING][64];
+    __shared__ uint2 cring[ST_RING][64];
+    __shared__ v4f ktab[STP_KT];                     // coefficients of window rows, a ring refilled every 64 rows
+    const int lane = threadIdx.x;
+    const int W = a.W;
+    unsigned scan_from = (blockIdx.x * 2654435761u) >> 8;             // where this wave starts to look for a victim
+    if (a.prof && lane == 0) a.prof[4 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+    unsigned prof_rows = 0, prof_q = 0, prof_s = 0;
+    unsigned long long prof_look = 0;
+    for (;;) {
+        // ---- a segment: the next one of the queue, or the upper part of what somebody still has to do ----
+        int id, tx, lo, hi;
+        {
+            int q = 0;
+            if (lane == 0) q = atomicAdd(&a.seg_ctl[0], 1);
+            q = __builtin_amdgcn_readfirstlane(q);
+            if (q < a.nseg0) {
+                id = q;
+                unsigned long long w = __hip_atomic_load(&a.seg_word[id], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                w = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(w >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)w);
+                tx = stp_tx(w); lo = stp_lo(w); hi = stp_hi(w);
+                prof_q++;
+            } else {
+                bool got = false;
+                if (a.dbg & 16) break;
+                const unsigned long long look0 = a.prof ? __builtin_amdgcn_s_memrealtime() : 0ull;
+                const int nwin = a.cap / 1024;
+                const unsigned start = scan_from >> 8;
+                for (int win = 0; win < nwin && !got; win++) {
+                    // one window of 1024 entries per look (16 per lane, all loads in flight together: a look costs one memory
+                    // round trip, a pass over the whole table a handful -- the wave that finds nothing must not take long to
+                    // find that out, the launch ends when the last one has).  Thieves start at different windows, and within
+                    // a window every thief ranks the candidates of the largest size class (rows left, to a factor of two) in
+                    // its own random order: a launch's waves all run dry at about the same time, and with everybody after the
+                    // one largest remainder a steal was won by one and retried by dozens (measured: 250 us per wave spent looking)
+                    const unsigned base = (start + (unsigned)win) % (unsigned)nwin * 1024u;
+                    unsigned best = 0;                                   // size class << 24 | random rank << 12 | slot within the window
+                    unsigned long long bw = 0ull;
+                    int bl = 0;
+#pragma unroll
+                    for (int k = 0; k < 16; k++) {
+                        const unsigned sl = 64u * k + lane, i = base + sl;
+                        const unsigned long long w = __hip_atomic_load(&a.seg_word[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const int c = (int)__hip_atomic_load(&a.seg_cur[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - STP_BIAS;
+                        const int vlo = stp_lo(w), vhi = stp_hi(w);
+                        const int lf = vhi - min(max(c, vlo - TB_T), vhi);         // rows left: 0 .. vhi - vlo + 8
+                        const unsigned rank = ((sl + 1u) * 2654435761u + scan_from * 40503u) >> 20;
+                        const unsigned key = (w != 0ull && vhi > vlo && lf >= STP_MIN_STEAL) ? (((unsigned)(31 - __clz(lf)) << 24) | (rank << 12) | sl) : 0u;
+                        if (key > best) { best = key; bw = w; bl = lf; }
+                    }
+                    unsigned top = best;
+#pragma unroll
+                    for (int off = 32; off; off >>= 1) top = max(top, (unsigned)__shfl_xor((int)top, off));
+                    top = (unsigned)__builtin_amdgcn_readfirstlane((int)top);
+                    if (!top) continue;                                  // nothing in this window: the next one
+                    scan_from = scan_from * 1664525u + 1013904223u;
+                    const unsigned sl = top & 4095u;
+                    const int ln = (int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(best == top));
+                    const unsigned long long wv = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(bw >> 32), ln) << 32) |
+                                                  (unsigned)__builtin_amdgcn_readlane((int)(unsigned)bw, ln);
+                    const int left = __builtin_amdgcn_readlane(bl, ln), vhi = stp_hi(wv), vlo = stp_lo(wv), vtx = stp_tx(wv), vcur = vhi - left;
+                    // equal shares of the rows still to be taken in: the owner needs [vcur, h' + 8), the thief [h' - 8, vhi + 8)
+                    const int hnew = min(max((vhi + vcur) / 2 + 4, vlo + 1), vhi - 1);
+                    int ok = 0, slot = 0;
+                    if (lane == 0) {
+                        unsigned long long expect = wv;
+                        ok = __hip_atomic_compare_exchange_strong(&a.seg_word[base + sl], &expect, stp_word(vtx, vlo, hnew), __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0;
+                        if (ok) {
+                            slot = atomicAdd(&a.seg_ctl[1], 1);
+                            if (slot >= a.cap) slot = a.cap + (int)blockIdx.x;        // table full: a private entry nobody scans
+                            __hip_atomic_store(&a.seg_cur[slot], (unsigned)(hnew - TB_T + STP_BIAS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(&a.seg_word[slot], stp_word(vtx, hnew, vhi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
+                    ok = __builtin_amdgcn_readfirstlane(ok);
+                    if (!ok) continue;                                   // somebody else was faster (or the owner's end moved): on to the next window
+                    id = __builtin_amdgcn_readfirstlane(slot); tx = vtx; lo = hnew; hi = vhi;
+                    got = true; prof_s++;
+                }
+                if (a.prof) prof_look += __builtin_amdgcn_s_memrealtime() - look0;
+                if (!got) break;                                         // nothing left worth taking: this wave is done
+            }
+        }
+        if (hi <= lo || lo < 0 || hi > a.L || tx < 0 || tx * TB_OW >= W) continue;      // (cannot happen; never follow a bad entry into memory)
+
+        // ---- stream rows [lo, hi) of strip tx, as k_jacobi_stream does for a unit ----
+        const int e0 = lo - TB_T;
+        int col = tx * TB_OW - TB_T + 4 * lane;
+        const int xcol = col;
+        col %= W; if (col < 0) col += W;
+        int colp = col + W / 2; if (colp >= W) colp -= W;
+        const bool lane_ok = (lane >= TB_T / 4) && (lane < 64 - TB_T / 4) && (xcol < W);
+        st_state z;
+#pragma unroll
+        for (int s = 0; s < 8; s++)
+#pragma unroll
+            for (int k = 0; k < 2; k++) { z.w[s][k][0] = (v4f)(0.0f); z.w[s][k][1] = (v4f)(0.0f); }
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) { z.ps[k][j] = (v4f)(0.0f); z.bs[k][j] = (v4f)(0.0f); z.cs[k][j] = 0; z.ks[k][j] = 2u; }
+        z.landbits = 0xFFFFFFFFu;
+        z.mixbits = 0; z.slot = 0;
+        {
+            const st_kptr cf = (st_kptr)(unsigned long long)a.jcoef;
+            z.cy = cf[4]; z.ry = cf[5];
+        }
+        // window rows [0, 16): the first chapter's refill brings [16, 80)
+        if (lane < 16) ktab[lane] = *reinterpret_cast<const v4f *>(a.jcoef + (size_t)st_map_row(a, e0 + lane).l * 8);
+        st_fetch<true>(a, z, 0, 0, e0, col, colp, tx);
+        st_fetch<true>(a, z, 0, 1, e0 + 1, col, colp, tx);
+        st_fetch<true>(a, z, 1, 0, e0 + 2, col, colp, tx);
+        st_fetch<true>(a, z, 1, 1, e0 + 3, col, colp, tx);
+        int t = 0, hi_known = hi;
+        for (;;) {
+            // a chapter of 64 window rows.  The levels read the coefficients of window rows [2t - 10, 2t + 67) in it: the
+            // entries [2t + 16, 2t + 80) replace rows that left the window long ago
+            if (!(a.dbg & 128) || t == 0)
+                ktab[(2 * t + 16 + lane) & (STP_KT - 1)] = *reinterpret_cast<const v4f *>(a.jcoef + (size_t)st_map_row(a, e0 + 2 * t + 16 + lane).l * 8);
+            const int t_chapter = t + 32;
+            int nsteps;
+            do {
+                // the end row is in the word's low half: a 32-bit load (the unused upper register of a 64-bit one is handed
+                // out again at once, and overwriting it means waiting for this load and every staged load before it)
+                unsigned w = ~0u;
+                if (!(a.dbg & 8)) w = __hip_atomic_load(reinterpret_cast<const unsigned *>(&a.seg_word[id]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!(a.dbg & 32)) __hip_atomic_store(&a.seg_cur[id], (unsigned)(e0 + 2 * (t + 2) + STP_BIAS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                st_step<0, true>(a, z, bring, cring, ktab, lane, t, e0, 0, hi_known, 0u, 0u, col, colp, lane_ok, xcol, tx);
+                st_step<1, true>(a, z, bring, cring, ktab, lane, t + 1, e0, 0, hi_known, 0u, 0u, col, colp, lane_ok, xcol, tx);
+                t += 2;
+                hi_known = min(hi_known, max((int)(((unsigned)__builtin_amdgcn_readfirstlane((int)w)) & STP_MASK) - STP_BIAS, lo));
+                nsteps = (((hi_known - lo) + 2 * TB_T + 3) / 4) * 2;
+            } while (t < t_chapter && t < nsteps);
+            if (t >= nsteps) break;
+        }
+        // (the owner's progress now stands at or past the end row: nothing is left to take here)
+        prof_rows += 2 * t;
+    }
+    if (a.prof && lane == 0) {
+        a.prof[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+        a.prof[4 * blockIdx.x + 2] = prof_rows | (prof_look << 32);
+        a.prof[4 * blockIdx.x + 3] = ((unsigned long long)prof_s << 32) | prof_q;
+    }
 }
 
 // =================================================================================================================
@@ -577,12 +792,12 @@ struct st_unit { int tx, r0, r1; float cost; };
 
 // Units of a launch over local rows [lo, hi) for one unit height: every strip cut into segments of `seg` rows, each trimmed
 // to its first / last row that is not land everywhere; empty ones are dropped.  cost ~ the unit's level-rows, a coast row
-// counted 1.6 times an open one and a land row a tenth (what the kernel spends on them).
+// counted 1.4 times an open one and a land row a tenth (what the kernel spends on them).
 static void st_cut(const dmg_ocean *o, int variant, int lo, int hi, int seg, int part, int zone_lo, int zone_hi, std::vector<st_unit> &units,
                    int seg2 = 0, int split = 0)
 {
     const int ow = variant ? STN_OW : TB_OW;
-    static const float w_mixed = [] { const char *e = getenv("DMG_ST_WMIXED"); return e ? (float)atof(e) : 1.6f; }();    // experiments: the cost model's weights
+    static const float w_mixed = [] { const char *e = getenv("DMG_ST_WMIXED"); return e ? (float)atof(e) : 1.4f; }();    // experiments: the cost model's weights (1.4: fitted to per-unit timings, DMG_ST_PROF)
     static const float w_land = [] { const char *e = getenv("DMG_ST_WLAND"); return e ? (float)atof(e) : 0.1f; }();
     const std::vector<unsigned char> &table = variant ? o->rowclass_n_host : o->rowclass_host;
     const int tiles_x = (o->grid.W + ow - 1) / ow, L = o->L;
@@ -622,6 +837,64 @@ static void st_cut(const dmg_ocean *o, int variant, int lo, int hi, int seg, int
     }
 }
 
+// Segments for the persistent form: every strip cut into pieces of about equal cost (the waves even out the rest among
+// themselves).  Runs of 24 or more rows that are land everywhere are left out; a piece starts and ends on a row with water.
+static void st_cut_cost(const dmg_ocean *o, int lo, int hi, float target, std::vector<st_unit> &units, double *total)
+{
+    static const float w_mixed = [] { const char *e = getenv("DMG_ST_WMIXED"); return e ? (float)atof(e) : 1.4f; }();
+    static const float w_land = [] { const char *e = getenv("DMG_ST_WLAND"); return e ? (float)atof(e) : 0.15f; }();
+    const float fill = 15.0f;                              // a piece of n rows costs about n + 15 (measured: fill and drain of the 8 levels)
+    const std::vector<unsigned char> &table = o->rowclass_host;
+    const int tiles_x = (o->grid.W + TB_OW - 1) / TB_OW, L = o->L;
+    units.clear();
+    double sum = 0.0;
+    for (int tx = 0; tx < tiles_x; tx++) {
+        const unsigned char *cls = table.empty() ? nullptr : table.data() + (size_t)tx * L;
+        auto cost_of = [&](int r) { const int c = cls ? cls[r] : 0; return c == 1 ? w_land : (c == 2 ? w_mixed : 1.0f); };
+        int r = lo;
+        while (r < hi) {
+            while (r < hi && cls && cls[r] == 1) r++;      // land before the piece
+            if (r >= hi) break;
+            const int s0 = r;
+            float acc = fill;
+            int last_water = r;                            // last row of the piece that is not land everywhere
+            bool absorb = false;                           // the rest of this stretch is too short for a piece of its own
+            while (r < hi) {
+                if (cls && cls[r] == 1) {
+                    int e = r;
+                    while (e < hi && cls[e] == 1) e++;
+                    if (e - r >= 24 || e == hi) break;     // a long run of land (or land up to the end): the piece ends before it
+                    for (; r < e; r++) acc += w_land;
+                    continue;
+                }
+                acc += cost_of(r);
+                last_water = r;
+                r++;
+                if (!absorb && acc >= target) {
+                    // do not leave a sliver behind: if the stretch ends within the next 24 rows, take them along
+                    int e = r;
+                    bool ends = false;
+                    while (e - r < 24) {
+                        if (e >= hi) { ends = true; break; }
+                        if (cls && cls[e] == 1) {
+                            int f = e;
+                            while (f < hi && cls[f] == 1) f++;
+                            if (f - e >= 24 || f == hi) { ends = true; break; }
+                            e = f;
+                        } else e++;
+                    }
+                    if (!ends) break;                      // plenty follows: cut here
+                    absorb = true;
+                }
+            }
+            units.push_back(st_unit{ tx, s0, last_water + 1, acc });
+            sum += acc;
+            r = std::max(r, last_water + 1);
+        }
+    }
+    if (total) *total = sum;
+}
+
 // makespan of the units on `slots` waves that each take the next unit when they are done (how the dispatcher hands
 // workgroups to free slots), units in descending cost order
 static float st_makespan(std::vector<st_unit> &units, int slots)
@@ -647,12 +920,28 @@ static float st_makespan(std::vector<st_unit> &units, int slots)
 // split around a halo exchange).
 static const dmg_ocean::tile_list *st_units(dmg_ocean *o, int variant, int lo, int hi, int part, int zone_lo, int zone_hi, int seg)
 {
-    auto key = std::make_tuple(lo, hi, (variant ? -3000 : -1000) - seg, part, zone_lo, zone_hi);    // "rows per wave" <= -1000 = stream units (seg 0 = auto)
+    auto key = std::make_tuple(lo, hi, (variant == 2 ? -5000 : (variant ? -3000 : -1000)) - seg, part, zone_lo, zone_hi);    // "rows per wave" <= -1000 = stream units (seg 0 = auto)
     auto it = o->tb_lists.find(key);
     if (it != o->tb_lists.end()) return &it->second;
-    const int slots = std::max(o->ctx->num_cu, 1) * (variant ? 20 : 8);     // five (96 VGPRs) / two waves per SIMD
+    const int slots = std::max(o->ctx->num_cu, 1) * (variant == 1 ? 20 : 8);     // five (96 VGPRs) / two waves per SIMD
     std::vector<st_unit> units, best;
-    if (seg > 0) { st_cut(o, variant, lo, hi, seg, part, zone_lo, zone_hi, best); (void)st_makespan(best, slots); }
+    int p_waves = 0;
+    if (variant == 2) {
+        // persistent form: about one segment per wave (the waves balance the rest among themselves); a strip's rows that
+        // are land everywhere at either end of a cut are trimmed as for the units
+        double total = 0.0;
+        st_cut_cost(o, lo, hi, 1e30f, units, &total);      // uncut: one piece per stretch of water, for the total
+        p_waves = (int)std::max(1.0, std::min((double)std::max(o->ctx->num_cu, 1) * 8, total / 32.0));
+        // every further cut adds a fill: solve target = (total + 15 (pieces - stretches)) / waves for pieces ~ waves
+        float target = (float)((total + 15.0 * std::max(0, p_waves - (int)units.size())) / p_waves);
+        if (seg > 0) target = (float)seg;
+        st_cut_cost(o, lo, hi, std::max(target, 39.0f), best, &total);
+        (void)st_makespan(best, p_waves);                  // (sorts: longest first)
+        static const bool dbg = getenv("DMG_ST_DEBUG") != nullptr;
+        if (dbg) fprintf(stderr, "[stream] rows [%d,%d): persistent, %d waves, %zu segments of cost %.0f (total %.0f, longest %.0f, shortest %.0f)\n", lo, hi, p_waves,
+                         best.size(), target, total, best.empty() ? 0.0f : best.front().cost, best.empty() ? 0.0f : best.back().cost);
+    }
+    else if (seg > 0) { st_cut(o, variant, lo, hi, seg, part, zone_lo, zone_hi, best); (void)st_makespan(best, slots); }
     else {
         float best_span = 1e30f;
         int best_seg = 0, best_seg2 = 0, best_split = 0;
@@ -685,6 +974,22 @@ static const dmg_ocean::tile_list *st_units(dmg_ocean *o, int variant, int lo, i
     tl.n = (int)best.size();
     if (tl.n && hipMalloc((void **)&tl.d, flat.size() * sizeof(int)) != hipSuccess) return nullptr;
     if (tl.n && hipMemcpy(tl.d, flat.data(), flat.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    if (variant == 2 && tl.n) {
+        tl.waves = p_waves;
+        tl.cap = ((tl.n + p_waves + 1023) / 1024) * 1024;   // initial segments + about one steal per wave (a thief that finds the table full keeps its piece to itself)
+        std::vector<unsigned long long> w0((size_t)tl.n);
+        std::vector<unsigned> c0((size_t)tl.n);
+        for (int i = 0; i < tl.n; i++) {
+            w0[i] = stp_word(best[i].tx, best[i].r0, best[i].r1);
+            c0[i] = (unsigned)(best[i].r0 - TB_T + STP_BIAS);
+        }
+        const size_t total = (size_t)tl.cap + tl.waves;
+        if (hipMalloc((void **)&tl.seg_word0, w0.size() * 8) != hipSuccess || hipMalloc((void **)&tl.seg_cur0, c0.size() * 4) != hipSuccess ||
+            hipMalloc((void **)&tl.seg_word, total * 8) != hipSuccess || hipMalloc((void **)&tl.seg_cur, total * 4) != hipSuccess ||
+            hipMalloc((void **)&tl.seg_ctl, 2 * sizeof(int)) != hipSuccess) return nullptr;
+        if (hipMemcpy(tl.seg_word0, w0.data(), w0.size() * 8, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(tl.seg_cur0, c0.data(), c0.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    }
     return &(o->tb_lists[key] = tl);
 }
 
@@ -696,6 +1001,7 @@ int ocean_launch_stream(dmg_ocean *o, int lo, int hi, int part, int zone_lo, int
     static const int forced = [] { const char *e = getenv("DMG_ST_VARIANT"); return e ? atoi(e) : -1; }();     // experiments: 0 wide, 1 narrow
     if (variant < 0) variant = forced >= 0 ? forced : 0;   // default: the wide kernel (measured: 2.52 vs 2.51 M on the survey terrain, 1.97 vs 1.83 M without land)
     if (o->grid.W < STN_EW) variant = 0;
+    if (variant == 2 && (part != 0 || !o->rowclass32 || o->L + STP_BIAS >= (1 << STP_FIELD) || (o->grid.W + TB_OW - 1) / TB_OW >= 4096)) variant = 0;   // the halves of a split launch keep their unit lists
     const dmg_ocean::tile_list *tl = st_units(o, variant, lo, hi, part, zone_lo, zone_hi, seg);
     if (!tl) return dmg_fail(DMG_ENOMEM, "unit list allocation failed");
     if (tl->n == 0) return DMG_OK;
@@ -704,15 +1010,17 @@ int ocean_launch_stream(dmg_ocean *o, int lo, int hi, int part, int zone_lo, int
     a.pout = o->p[from ^ 1];
     a.b = o->divw;
     a.code = o->code;
-    a.jcoef = variant ? o->jcoefp : o->jcoef;
+    a.jcoef = variant == 1 ? o->jcoefp : o->jcoef;
     a.jcoef_cy = o->jcoef + 4;                           // row 0's {cy, 1/cy}: the same for every row
     a.W = o->grid.W; a.L = o->L;
     a.y_first = o->y0 - o->gs; a.H = o->grid.H;
     a.spole = o->topo.spole ? 1 : 0; a.npole = o->topo.npole ? 1 : 0;
     static const bool use_cls = getenv("DMG_TB_NOCLASS") == nullptr;
-    a.rowclass = use_cls ? (variant ? o->rowclass_n : o->rowclass) : nullptr;
+    a.rowclass = use_cls ? (variant == 1 ? o->rowclass_n : o->rowclass) : nullptr;
     a.units = (const int4 *)tl->d;
-    o->last_kernel = variant ? "k_jacobi_stream_n" : "k_jacobi_stream";
+    a.rowclass32 = o->rowclass32;
+    a.seg_word = tl->seg_word; a.seg_cur = tl->seg_cur; a.seg_ctl = tl->seg_ctl; a.nseg0 = tl->n; a.cap = tl->cap;
+    o->last_kernel = variant == 2 ? "k_jacobi_stream_p" : (variant ? "k_jacobi_stream_n" : "k_jacobi_stream");
     static const int dbg = [] { const char *e = getenv("DMG_ST_DBG"); return e ? atoi(e) : 0; }();
     a.dbg = dbg;
     a.prof = nullptr;
@@ -721,7 +1029,29 @@ int ocean_launch_stream(dmg_ocean *o, int lo, int hi, int part, int zone_lo, int
     const bool prof_now = prof_path && !prof_done && !variant && tl->n > 1024;
     if (prof_now && hipMalloc((void **)&a.prof, (size_t)tl->n * 16) != hipSuccess) a.prof = nullptr;
     static const int extra_lds = [] { const char *e = getenv("DMG_ST_EXTRA_LDS"); return e ? atoi(e) : 0; }();   // experiments: caps the waves per CU
-    if (variant) hipLaunchKernelGGL(k_jacobi_stream_n, dim3((unsigned)tl->n), dim3(64), (size_t)extra_lds, st, a);
+    if (variant == 2) {
+        const int total = tl->cap + tl->waves;
+        if (prof_path && !prof_done && tl->waves > 1024 && hipMalloc((void **)&a.prof, (size_t)tl->waves * 32) != hipSuccess) a.prof = nullptr;
+        hipLaunchKernelGGL(k_st_reset, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, tl->seg_word, tl->seg_cur, tl->seg_ctl,
+                           (const unsigned long long *)tl->seg_word0, (const unsigned *)tl->seg_cur0, tl->n, total);
+        hipLaunchKernelGGL(k_jacobi_stream_p, dim3((unsigned)tl->waves), dim3(64), 0, st, a);
+        if (a.prof) {
+            prof_done = true;
+            std::vector<unsigned long long> tt((size_t)tl->waves * 4);
+            DMG_HIP(hipStreamSynchronize(st));
+            DMG_HIP(hipMemcpy(tt.data(), a.prof, tt.size() * 8, hipMemcpyDeviceToHost));
+            (void)hipFree(a.prof);
+            if (FILE *f = fopen(prof_path, "w")) {
+                fprintf(f, "wave,t0,t1,rows,queued,stolen,look\n");
+                for (int i = 0; i < tl->waves; i++)
+                    fprintf(f, "%d,%llu,%llu,%llu,%llu,%llu,%llu\n", i, tt[4 * i], tt[4 * i + 1], tt[4 * i + 2] & 0xFFFFFFFFull, tt[4 * i + 3] & 0xFFFFFFFFull,
+                            tt[4 * i + 3] >> 32, tt[4 * i + 2] >> 32);
+                fclose(f);
+            }
+            a.prof = nullptr;
+        }
+    }
+    else if (variant) hipLaunchKernelGGL(k_jacobi_stream_n, dim3((unsigned)tl->n), dim3(64), (size_t)extra_lds, st, a);
     else hipLaunchKernelGGL(k_jacobi_stream, dim3((unsigned)tl->n), dim3(64), (size_t)extra_lds, st, a);
     DMG_HIP(hipGetLastError());
     if (prof_now && a.prof) {

@@ -19,6 +19,7 @@
 // are plain mirrors (CLAMP_TO_EDGE on a symmetric stencil).  Mirrored rows swap the N/S bits of their code.
 #include "ocean_internal.h"
 #include "ocean_tb.h"
+#include <cstring>
 
 struct tb_args {
     const float *pin;
@@ -305,13 +306,21 @@ __global__ __launch_bounds__(64) void k_tb_rowclass_n(const unsigned char *__res
 
 void ocean_tb_free_lists(dmg_ocean *o)
 {
-    for (auto &kv : o->tb_lists) if (kv.second.d) (void)hipFree(kv.second.d);
+    for (auto &kv : o->tb_lists)
+        for (void *q : { (void *)kv.second.d, (void *)kv.second.seg_word0, (void *)kv.second.seg_word, (void *)kv.second.seg_cur0, (void *)kv.second.seg_cur, (void *)kv.second.seg_ctl })
+            if (q) (void)hipFree(q);
     o->tb_lists.clear();
     for (auto &kv : o->tb_tuning) {
         if (kv.second.ev0) (void)hipEventDestroy(kv.second.ev0);
         if (kv.second.ev1) (void)hipEventDestroy(kv.second.ev1);
     }
     o->tb_tuning.clear();
+}
+
+__global__ void k_tb_widen(const unsigned char *__restrict__ in, unsigned *__restrict__ out, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i];
 }
 
 int ocean_build_rowclass(dmg_ocean *o)
@@ -322,6 +331,12 @@ int ocean_build_rowclass(dmg_ocean *o)
     hipLaunchKernelGGL(k_tb_rowclass, dim3(tiles_x, o->L), dim3(64), 0, o->ctx->stream, o->code, o->rowclass, o->grid.W, o->L,
                        o->y0 - o->gs, o->grid.H, o->topo.spole ? 1 : 0, o->topo.npole ? 1 : 0);
     DMG_HIP(hipGetLastError());
+    {
+        const size_t n = (size_t)tiles_x * o->L;
+        if (!o->rowclass32) DMG_HIP(hipMalloc((void **)&o->rowclass32, n * sizeof(unsigned)));
+        hipLaunchKernelGGL(k_tb_widen, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, o->ctx->stream, o->rowclass, o->rowclass32, n);
+        DMG_HIP(hipGetLastError());
+    }
     ocean_tb_free_lists(o);                              // lists of the previous terrain
     o->rowclass_host.resize((size_t)tiles_x * o->L);
     DMG_HIP(hipMemcpyAsync(o->rowclass_host.data(), o->rowclass, o->rowclass_host.size(), hipMemcpyDeviceToHost, o->ctx->stream));
@@ -387,7 +402,11 @@ static tb_shape tb_forced_shape()
         tb_shape d = { 0, 0 };
         const char *e = getenv("DMG_TB_SHAPE");
         int r = 0, nw = 0;
-        if (e && sscanf(e, "%dx%d", &r, &nw) == 2 &&
+        // stream / stream-n / stream-p: the streaming kernel's unit, narrow and persistent forms for every 8-sweep launch
+        if (e && !strcmp(e, "stream")) d = { -1000, 0 };
+        else if (e && !strcmp(e, "stream-n")) d = { -1000, 1 };
+        else if (e && !strcmp(e, "stream-p")) d = { -1000, 2 };
+        else if (e && sscanf(e, "%dx%d", &r, &nw) == 2 &&
             ((r == 8 && nw == 8) || (r == 16 && nw == 8) || (r == 8 && nw == 16) || (r == 12 && nw == 8) || (r == 10 && nw == 8) ||
              (r == 4 && nw == 8) || (r == 6 && nw == 8)))
             d = { r, nw };
@@ -474,6 +493,7 @@ int ocean_launch_tb(dmg_ocean *o, int lo, int hi, int n, int part, int zone_lo, 
     // ocean_jacobi_stream.hip) with its own choice of unit height and with short units.  R < 0 = streaming with -R rows per unit.
     static const tb_shape cands[TB_NCAND] = { { 8, 8 }, { 6, 8 }, { 4, 8 }, { -1000, 0 }, { -32, 0 }, { -1000, 1 } };   // NW = 1 with R < 0: the narrow streaming kernel   // -1000: unit height from the dispatch simulation
     const bool stream_ok = n == TB_T && ocean_stream_enabled();
+    if (sh.R < 0 && !stream_ok) sh = tb_shape{ 8, 8 };      // (a forced streaming form: launches of fewer than 8 sweeps keep the tile kernel)
     if (!sh.R) {
         const int tiles88 = ((a.W + TB_OW - 1) / TB_OW) * ((hi - lo + 47) / 48);
         // thousands of tiles: the chip is full either way and the streaming kernel does the least work
@@ -528,6 +548,7 @@ int ocean_launch_tb(dmg_ocean *o, int lo, int hi, int n, int part, int zone_lo, 
 int ocean_tb_tile_rows(dmg_ocean *o, int lo, int hi)
 {
     tb_shape f = tb_forced_shape();
+    if (f.R < 0) return 96;
     if (f.R) return f.R * f.NW - 2 * TB_T;
     if (ocean_tb_tuning_open(o, lo, hi)) return 0;
     static const int rows_of[TB_NCAND] = { 8 * 8 - 2 * TB_T, 6 * 8 - 2 * TB_T, 4 * 8 - 2 * TB_T, 96, 32, 96 };   // streaming: rows per unit

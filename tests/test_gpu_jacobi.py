@@ -331,3 +331,19 @@ def test_llvmpipe_raster_quirk(dev, oracle):
         o.set_terrain(img); o.set_divw(b); o.jacobi(40)
         outs.append(o.get(want=("pressure",))["pressure"]); o.close()
     assert np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form", ["stream", "stream-n", "stream-p"])
+def test_streaming_forms_forced_are_bitwise(form):
+    """Every form of the streaming kernel (units, narrow units, persistent waves with work stealing), forced for all
+    8-sweep launches of a 2048x1024 solve through DMG_TB_SHAPE, against single-sweep launches, bit for bit.  The
+    environment is read once per process, hence the child process (tools/stream_check.py does the comparison)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DMG_TB_SHAPE=form)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "stream_check.py"), "2048", "1024", "64"], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    kern = {"stream": "k_jacobi_stream ", "stream-n": "k_jacobi_stream_n", "stream-p": "k_jacobi_stream_p"}[form]
+    assert kern.strip() in r.stdout and "bit-identical" in r.stdout, r.stdout[-2000:]
