@@ -165,15 +165,16 @@ __device__ __forceinline__ v4f st_row_any(const v4f N, const v4f C, const v4f S,
 template <int S, int K, bool P>
 __device__ __forceinline__ void st_level(const st_args &a, st_state &z, v4f (*bring)[64], uint2 (*cring)[64], const v4f *ktab,
                                          int lane, int t, int yA, int r0, int r1, bool lane_ok, int xcol,
-                                         const v4f bA, const v4f bB, v4f &bA_next, v4f &bB_next,
-                                         const v4f kA, const v4f kB, v4f &kA_next, v4f &kB_next)
+                                         const v4f bA, const v4f bB, v4f &bA_next, const v4f kA, const v4f kB, v4f &kA_next)
 {
-    // the next level's right-hand sides and coefficients are read from the rings while this level computes
+    // the next level's right-hand side and coefficients are read from the rings while this level computes.  Level S + 1
+    // works one row further south: its second row is this level's first (whose operands are in registers already), only
+    // its first row's are new
     if (S < 8) {
-        const int sa = st_wrap(z.slot - (S + 1)), sb = sa + 1 == ST_RING ? 0 : sa + 1;
-        bA_next = bring[sa][lane]; bB_next = bring[sb][lane];
+        const int sa = st_wrap(z.slot - (S + 1));
+        bA_next = bring[sa][lane];
         const int ra = max(2 * t - (S + 1), 0);               // window row of the next level's first row
-        kA_next = ktab[st_kt<P>(ra)]; kB_next = ktab[st_kt<P>(ra + 1)];    // every lane reads the same 16 bytes: one broadcast
+        kA_next = ktab[st_kt<P>(ra)];                         // every lane reads the same 16 bytes: one broadcast
     }
     // (a level whose rows do not exist yet sees them as land: landbits starts as all ones; rows that exist but are not
     // yet valid at this level are computed like any halo row)
@@ -259,6 +260,11 @@ __device__ __forceinline__ void st_arrive(const st_args &a, st_state &z, v4f (*b
         const int yg = a.y_first + e;
         if (yg == 0 && !a.spole) c &= ~0x02020202u;
         if (yg == a.H - 1 && !a.npole) c &= ~0x01010101u;
+        // ... and the same bit seen from the mirror row (after the swap: row -1's north, row H's south neighbour is the
+        // edge row, whose values are the mirror row's own).  The counts below need a set bit to mean "that neighbour
+        // holds +0.0"; the bit-field selects of the other kernels did not care (pK | pC with pK == pC)
+        if (yg == -1 && !a.spole) c &= ~0x01010101u;
+        if (yg == a.H && !a.npole) c &= ~0x02020202u;
         mix = __builtin_amdgcn_ballot_w64((c & 0x1F1F1F1Fu) != 0) != 0;
         land = __builtin_amdgcn_ballot_w64((c & 0x10101010u) != 0x10101010u) == 0;
         mix &= ~land;
@@ -312,15 +318,15 @@ __device__ __forceinline__ void st_step(const st_args &a, st_state &z, v4f (*bri
     st_fetch<P>(a, z, K, 1, e_t + 5, col, colp, tx);
     // level 1: rows e_t - 1 (in the ring since the last step) and e_t (just written)
     const int s1 = st_wrap(z.slot - 1), r1w = max(2 * t - 1, 0);
-    v4f b0 = bring[s1][lane], b1 = bring[z.slot][lane], k0 = ktab[st_kt<P>(r1w)], k1 = ktab[st_kt<P>(r1w + 1)], b2, b3, k2, k3;
-    st_level<1, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 1, e0 + TB_T, r1, lane_ok, xcol, b0, b1, b2, b3, k0, k1, k2, k3);
-    st_level<2, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 2, e0 + TB_T, r1, lane_ok, xcol, b2, b3, b0, b1, k2, k3, k0, k1);
-    st_level<3, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 3, e0 + TB_T, r1, lane_ok, xcol, b0, b1, b2, b3, k0, k1, k2, k3);
-    st_level<4, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 4, e0 + TB_T, r1, lane_ok, xcol, b2, b3, b0, b1, k2, k3, k0, k1);
-    st_level<5, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 5, e0 + TB_T, r1, lane_ok, xcol, b0, b1, b2, b3, k0, k1, k2, k3);
-    st_level<6, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 6, e0 + TB_T, r1, lane_ok, xcol, b2, b3, b0, b1, k2, k3, k0, k1);
-    st_level<7, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 7, e0 + TB_T, r1, lane_ok, xcol, b0, b1, b2, b3, k0, k1, k2, k3);
-    st_level<8, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 8, e0 + TB_T, r1, lane_ok, xcol, b2, b3, b0, b1, k2, k3, k0, k1);
+    v4f b0 = bring[s1][lane], b1 = bring[z.slot][lane], k0 = ktab[st_kt<P>(r1w)], k1 = ktab[st_kt<P>(r1w + 1)], b2, k2;
+    st_level<1, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 1, e0 + TB_T, r1, lane_ok, xcol, b0, b1, b2, k0, k1, k2);
+    st_level<2, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 2, e0 + TB_T, r1, lane_ok, xcol, b2, b0, b1, k2, k0, k1);
+    st_level<3, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 3, e0 + TB_T, r1, lane_ok, xcol, b1, b2, b0, k1, k2, k0);
+    st_level<4, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 4, e0 + TB_T, r1, lane_ok, xcol, b0, b1, b2, k0, k1, k2);
+    st_level<5, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 5, e0 + TB_T, r1, lane_ok, xcol, b2, b0, b1, k2, k0, k1);
+    st_level<6, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 6, e0 + TB_T, r1, lane_ok, xcol, b1, b2, b0, k1, k2, k0);
+    st_level<7, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 7, e0 + TB_T, r1, lane_ok, xcol, b0, b1, b2, k0, k1, k2);
+    st_level<8, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 8, e0 + TB_T, r1, lane_ok, xcol, b2, b0, b1, k2, k0, k1);
     z.slot = z.slot + 2 == ST_RING ? 0 : z.slot + 2;
 }
 
@@ -451,21 +457,21 @@ __global__ __launch_bounds__(64, 2) void k_jacobi_stream_p(st_args a)
                 bool got = false;
                 if (a.dbg & 16) break;
                 const unsigned long long look0 = a.prof ? __builtin_amdgcn_s_memrealtime() : 0ull;
-                const int nwin = a.cap / 1024;
+                const int nwin = a.cap / 512;
                 const unsigned start = scan_from >> 8;
                 for (int win = 0; win < nwin && !got; win++) {
-                    // one window of 1024 entries per look (16 per lane, all loads in flight together: a look costs one memory
+                    // one window of 512 entries per look (8 per lane, all loads in flight together: a look costs one memory
                     // round trip, a pass over the whole table a handful -- the wave that finds nothing must not take long to
                     // find that out, the launch ends when the last one has).  Thieves start at different windows, and within
                     // a window every thief ranks the candidates of the largest size class (rows left, to a factor of two) in
                     // its own random order: a launch's waves all run dry at about the same time, and with everybody after the
                     // one largest remainder a steal was won by one and retried by dozens (measured: 250 us per wave spent looking)
-                    const unsigned base = (start + (unsigned)win) % (unsigned)nwin * 1024u;
+                    const unsigned base = (start + (unsigned)win) % (unsigned)nwin * 512u;
                     unsigned best = 0;                                   // size class << 24 | random rank << 12 | slot within the window
                     unsigned long long bw = 0ull;
                     int bl = 0;
 #pragma unroll
-                    for (int k = 0; k < 16; k++) {
+                    for (int k = 0; k < 8; k++) {
                         const unsigned sl = 64u * k + lane, i = base + sl;
                         const unsigned long long w = __hip_atomic_load(&a.seg_word[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         const int c = (int)__hip_atomic_load(&a.seg_cur[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - STP_BIAS;
@@ -976,7 +982,7 @@ static const dmg_ocean::tile_list *st_units(dmg_ocean *o, int variant, int lo, i
     if (tl.n && hipMemcpy(tl.d, flat.data(), flat.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
     if (variant == 2 && tl.n) {
         tl.waves = p_waves;
-        tl.cap = ((tl.n + p_waves + 1023) / 1024) * 1024;   // initial segments + about one steal per wave (a thief that finds the table full keeps its piece to itself)
+        tl.cap = ((tl.n + p_waves + 511) / 512) * 512;   // initial segments + about one steal per wave (a thief that finds the table full keeps its piece to itself)
         std::vector<unsigned long long> w0((size_t)tl.n);
         std::vector<unsigned> c0((size_t)tl.n);
         for (int i = 0; i < tl.n; i++) {

@@ -334,15 +334,17 @@ def test_llvmpipe_raster_quirk(dev, oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("canvas", ["globe", "belt"])
 @pytest.mark.parametrize("form", ["stream", "stream-n", "stream-p"])
-def test_streaming_forms_forced_are_bitwise(form):
+def test_streaming_forms_forced_are_bitwise(form, canvas):
     """Every form of the streaming kernel (units, narrow units, persistent waves with work stealing), forced for all
-    8-sweep launches of a 2048x1024 solve through DMG_TB_SHAPE, against single-sweep launches, bit for bit.  The
-    environment is read once per process, hence the child process (tools/stream_check.py does the comparison)."""
+    8-sweep launches of a 2048x1024 solve through DMG_TB_SHAPE, against single-sweep launches, bit for bit, on the globe
+    (rows beyond a pole are the pole rows shifted by W/2) and on a latitude belt (rows beyond an edge are plain mirrors).
+    The environment is read once per process, hence the child process (tools/stream_check.py does the comparison)."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, DMG_TB_SHAPE=form)
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "stream_check.py"), "2048", "1024", "64"], cwd=root, env=env,
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "stream_check.py"), "2048", "1024", "64", "survey", canvas], cwd=root, env=env,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     kern = {"stream": "k_jacobi_stream ", "stream-n": "k_jacobi_stream_n", "stream-p": "k_jacobi_stream_p"}[form]

@@ -1,6 +1,8 @@
 """Bitwise check of the 8-sweep Jacobi launch against single-sweep launches at a given size (GPU).
 
-usage: python tools/stream_check.py [W H [sweeps]]    (environment: DMG_ST_VARIANT etc. choose the streaming form)
+usage: python tools/stream_check.py [W H [sweeps [survey|ocean [globe|belt]]]]
+(environment: DMG_TB_SHAPE=stream|stream-n|stream-p forces a streaming form; belt = latitudes -1 .. 1.2 rad, both edges
+ clamp instead of reflecting through a pole)
 """
 import sys, time
 import numpy as np
@@ -11,7 +13,8 @@ W = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 H = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
 sweeps = int(sys.argv[3]) if len(sys.argv) > 3 else 24
 terrain = synth.terrain(W, H) if (len(sys.argv) <= 4 or sys.argv[4] == "survey") else -np.ones((H, W), np.float32)
-grid = capi.make_grid(W, H)
+belt = len(sys.argv) > 5 and sys.argv[5] == "belt"
+grid = capi.make_grid(W, H, (-1.0, 1.2, -np.pi, np.pi)) if belt else capi.make_grid(W, H)
 res = {}
 ctx = capi.Context()
 if True:
