@@ -178,11 +178,10 @@ __device__ __forceinline__ void st_level(const st_args &a, st_state &z, v4f (*br
     }
     // (a level whose rows do not exist yet sees them as land: landbits starts as all ones; rows that exist but are not
     // yet valid at this level are computed like any halo row)
-    const unsigned landA = (z.landbits >> (S + 1)) & 1u, landB = (z.landbits >> S) & 1u;
-    const unsigned mixA = (z.mixbits >> (S + 1)) & 1u, mixB = (z.mixbits >> S) & 1u;
     const v4f S0 = z.w[S - 1][K ^ 1][0], C0 = z.w[S - 1][K ^ 1][1], N0 = z.w[S - 1][K][0], N1 = z.w[S - 1][K][1];
     v4f oA, oB;
-    if (!(landA | landB | mixA | mixB)) {
+    unsigned landA = 0, landB = 0;
+    if (!(((z.landbits | z.mixbits) >> S) & 3u)) {           // (one two-bit field of the step's combined mask: the common case costs one scalar test)
         // both rows open ocean (wave-uniform): one block of 8 independent division chains
         const jacobi_row ka = { kA.x, z.cy, kA.z, kA.y, z.ry, kA.w }, kb = { kB.x, z.cy, kB.z, kB.y, z.ry, kB.w };
         const float wlA = dpp_from_prev_lane(C0.w), erA = dpp_from_next_lane(C0.x);
@@ -194,6 +193,8 @@ __device__ __forceinline__ void st_level(const st_args &a, st_state &z, v4f (*br
         oA = v4f{ a0.x, a0.y, a1.x, a1.y };
         oB = v4f{ b0.x, b0.y, b1.x, b1.y };
     } else {
+        landA = (z.landbits >> (S + 1)) & 1u; landB = (z.landbits >> S) & 1u;
+        const unsigned mixA = (z.mixbits >> (S + 1)) & 1u, mixB = (z.mixbits >> S) & 1u;
         const int sa = st_wrap(z.slot - S), sb = sa + 1 == ST_RING ? 0 : sa + 1;
         oA = landA ? (v4f)(0.0f) : st_row_any(N0, C0, S0, bA, kA, z.cy, z.ry, mixA != 0, cring[sa], lane);
         oB = landB ? (v4f)(0.0f) : st_row_any(N1, N0, C0, bB, kB, z.cy, z.ry, mixB != 0, cring[sb], lane);
