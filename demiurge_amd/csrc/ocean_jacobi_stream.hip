@@ -28,6 +28,13 @@
 #include "ocean_tb.h"
 #include <algorithm>
 
+// The DMG_ST_DBG experiments (st_args::dbg) are compiled in with -DST_EXPERIMENTS only: one scalar test and branch per level
+// visit costs the kernel 3 % (measured), so the shipped kernels carry none of them
+#ifdef ST_EXPERIMENTS
+#define ST_DBG(a, bit) (((a).dbg & (bit)) != 0)
+#else
+#define ST_DBG(a, bit) false
+#endif
 #define ST_MAXROWS 104            // output rows per unit: the window rows' classes fit two registers, and the coefficient
                                   // table of 104 + 22 rows leaves the wide form's LDS at 20448 bytes: 8 waves share 160 KB
 #define ST_RING 12                // ring slots (rows): 10 rows are in flight between level 0 and level 8, two arrive
@@ -162,7 +169,7 @@ __device__ __forceinline__ v4f st_row_any(const v4f N, const v4f C, const v4f S,
 
 // one level: sweep S of rows yA = e0 + 2t - S and yB = yA + 1 from level S-1's rows yA-1 .. yB+1 (the pair made one step ago
 // and the pair made in this step); K = t mod 2
-template <int S, int K, bool P>
+template <int S, int K, bool P, bool FAST = false>
 __device__ __forceinline__ void st_level(const st_args &a, st_state &z, v4f (*bring)[64], uint2 (*cring)[64], const v4f *ktab,
                                          int lane, int t, int yA, int r0, int r1, bool lane_ok, int xcol,
                                          const v4f bA, const v4f bB, v4f &bA_next, const v4f kA, const v4f kB, v4f &kA_next)
@@ -170,18 +177,18 @@ __device__ __forceinline__ void st_level(const st_args &a, st_state &z, v4f (*br
     // the next level's right-hand side and coefficients are read from the rings while this level computes.  Level S + 1
     // works one row further south: its second row is this level's first (whose operands are in registers already), only
     // its first row's are new
-    if (S < 8) {
+    if (S < 8 && !ST_DBG(a, 256)) {
         const int sa = st_wrap(z.slot - (S + 1));
         bA_next = bring[sa][lane];
         const int ra = max(2 * t - (S + 1), 0);               // window row of the next level's first row
         kA_next = ktab[st_kt<P>(ra)];                         // every lane reads the same 16 bytes: one broadcast
-    }
+    } else if (S < 8) { bA_next = bB; kA_next = kB; }         // (timing experiment: wrong results)
     // (a level whose rows do not exist yet sees them as land: landbits starts as all ones; rows that exist but are not
     // yet valid at this level are computed like any halo row)
     const v4f S0 = z.w[S - 1][K ^ 1][0], C0 = z.w[S - 1][K ^ 1][1], N0 = z.w[S - 1][K][0], N1 = z.w[S - 1][K][1];
     v4f oA, oB;
     unsigned landA = 0, landB = 0;
-    if (!(((z.landbits | z.mixbits) >> S) & 3u)) {           // (one two-bit field of the step's combined mask: the common case costs one scalar test)
+    if (FAST || !(((z.landbits | z.mixbits) >> S) & 3u)) {   // (one two-bit field of the step's combined mask: the common case costs one scalar test)
         // both rows open ocean (wave-uniform): one block of 8 independent division chains
         const jacobi_row ka = { kA.x, z.cy, kA.z, kA.y, z.ry, kA.w }, kb = { kB.x, z.cy, kB.z, kB.y, z.ry, kB.w };
         const float wlA = dpp_from_prev_lane(C0.w), erA = dpp_from_next_lane(C0.x);
@@ -200,7 +207,7 @@ __device__ __forceinline__ void st_level(const st_args &a, st_state &z, v4f (*br
         oB = landB ? (v4f)(0.0f) : st_row_any(N1, N0, C0, bB, kB, z.cy, z.ry, mixB != 0, cring[sb], lane);
     }
     if (S < 8) { z.w[S & 7][K][0] = oA; z.w[S & 7][K][1] = oB; }
-    else if (lane_ok && !(a.dbg & 2)) {                          // never re-read in this launch; land rows hold 0 in both buffers already
+    else if (lane_ok && !ST_DBG(a, 2)) {                          // never re-read in this launch; land rows hold 0 in both buffers already
         // only the unit's own rows [r0, r1): in its first steps level 8 runs on rows below r0, never stored
         if (!landA && yA >= r0 && yA < r1) __builtin_nontemporal_store(oA, reinterpret_cast<v4f *>(a.pout + (size_t)yA * a.W + xcol));
         if (!landB && yA + 1 >= r0 && yA + 1 < r1) __builtin_nontemporal_store(oB, reinterpret_cast<v4f *>(a.pout + (size_t)(yA + 1) * a.W + xcol));
@@ -223,7 +230,7 @@ __device__ __forceinline__ unsigned st_class(unsigned cls_lo, unsigned cls_hi, i
 template <bool P>
 __device__ __forceinline__ void st_fetch(const st_args &a, st_state &z, int set, int j, int e, int col, int colp, int tx = 0)
 {
-    const st_row m = st_map_row(a, (a.dbg & 1) ? (e & 63) : e);
+    const st_row m = st_map_row(a, ST_DBG(a, 1) ? (e & 63) : e);
     // the row's base address is wave-uniform (scalar arithmetic), the lane adds a 32-bit column offset: the loads take
     // the SGPR-base + VGPR-offset form and the 64-bit address arithmetic leaves the vector ALU
     const size_t rowoff = (size_t)m.l * a.W;
@@ -231,7 +238,7 @@ __device__ __forceinline__ void st_fetch(const st_args &a, st_state &z, int set,
     z.ps[set][j] = *reinterpret_cast<const v4f *>(a.pin + rowoff + coff);
     z.bs[set][j] = *reinterpret_cast<const v4f *>(a.b + rowoff + coff);
     z.cs[set][j] = *reinterpret_cast<const unsigned *>(a.code + rowoff + coff);
-    if (P && (a.dbg & 64)) z.ks[set][j] = a.rowclass32[(size_t)tx * a.L + m.l];          // every lane the same word
+    if (P && ST_DBG(a, 64)) z.ks[set][j] = a.rowclass32[(size_t)tx * a.L + m.l];          // every lane the same word
 }
 typedef const float __attribute__((address_space(4))) *st_kptr;
 
@@ -294,7 +301,7 @@ template <int K>
 __device__ __forceinline__ unsigned st_class_p(const st_args &a, const st_state &z, int j, int e)
 {
     const int yg = a.y_first + e;
-    if (!(a.dbg & 64)) return 2u;                            // the codes decide (st_arrive)
+    if (!ST_DBG(a, 64)) return 2u;                            // the codes decide (st_arrive)
     const bool inside = yg >= 0 && yg < a.H && e >= 0 && e < a.L;
     // (volatile: left to the scheduler, this read -- and with it the wait for the staging set's loads -- moves a whole step
     // up, to where the set before it has only just been taken)
@@ -320,14 +327,27 @@ __device__ __forceinline__ void st_step(const st_args &a, st_state &z, v4f (*bri
     // level 1: rows e_t - 1 (in the ring since the last step) and e_t (just written)
     const int s1 = st_wrap(z.slot - 1), r1w = max(2 * t - 1, 0);
     v4f b0 = bring[s1][lane], b1 = bring[z.slot][lane], k0 = ktab[st_kt<P>(r1w)], k1 = ktab[st_kt<P>(r1w + 1)], b2, k2;
-    st_level<1, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 1, e0 + TB_T, r1, lane_ok, xcol, b0, b1, b2, k0, k1, k2);
-    st_level<2, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 2, e0 + TB_T, r1, lane_ok, xcol, b2, b0, b1, k2, k0, k1);
-    st_level<3, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 3, e0 + TB_T, r1, lane_ok, xcol, b1, b2, b0, k1, k2, k0);
-    st_level<4, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 4, e0 + TB_T, r1, lane_ok, xcol, b0, b1, b2, k0, k1, k2);
-    st_level<5, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 5, e0 + TB_T, r1, lane_ok, xcol, b2, b0, b1, k2, k0, k1);
-    st_level<6, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 6, e0 + TB_T, r1, lane_ok, xcol, b1, b2, b0, k1, k2, k0);
-    st_level<7, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 7, e0 + TB_T, r1, lane_ok, xcol, b0, b1, b2, k0, k1, k2);
-    st_level<8, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 8, e0 + TB_T, r1, lane_ok, xcol, b2, b0, b1, k2, k0, k1);
+    // no land and no coast in any of the ten rows in flight (every step of a strip in open water): the eight levels without
+    // a test or a branch between them -- one block for the scheduler; a branch per level visit costs the kernel ~3 %
+    if (!((z.landbits | z.mixbits) & 0x3FFu)) {
+        st_level<1, K, P, true>(a, z, bring, cring, ktab, lane, t, e_t - 1, e0 + TB_T, r1, lane_ok, xcol, b0, b1, b2, k0, k1, k2);
+        st_level<2, K, P, true>(a, z, bring, cring, ktab, lane, t, e_t - 2, e0 + TB_T, r1, lane_ok, xcol, b2, b0, b1, k2, k0, k1);
+        st_level<3, K, P, true>(a, z, bring, cring, ktab, lane, t, e_t - 3, e0 + TB_T, r1, lane_ok, xcol, b1, b2, b0, k1, k2, k0);
+        st_level<4, K, P, true>(a, z, bring, cring, ktab, lane, t, e_t - 4, e0 + TB_T, r1, lane_ok, xcol, b0, b1, b2, k0, k1, k2);
+        st_level<5, K, P, true>(a, z, bring, cring, ktab, lane, t, e_t - 5, e0 + TB_T, r1, lane_ok, xcol, b2, b0, b1, k2, k0, k1);
+        st_level<6, K, P, true>(a, z, bring, cring, ktab, lane, t, e_t - 6, e0 + TB_T, r1, lane_ok, xcol, b1, b2, b0, k1, k2, k0);
+        st_level<7, K, P, true>(a, z, bring, cring, ktab, lane, t, e_t - 7, e0 + TB_T, r1, lane_ok, xcol, b0, b1, b2, k0, k1, k2);
+        st_level<8, K, P, true>(a, z, bring, cring, ktab, lane, t, e_t - 8, e0 + TB_T, r1, lane_ok, xcol, b2, b0, b1, k2, k0, k1);
+    } else {
+        st_level<1, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 1, e0 + TB_T, r1, lane_ok, xcol, b0, b1, b2, k0, k1, k2);
+        st_level<2, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 2, e0 + TB_T, r1, lane_ok, xcol, b2, b0, b1, k2, k0, k1);
+        st_level<3, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 3, e0 + TB_T, r1, lane_ok, xcol, b1, b2, b0, k1, k2, k0);
+        st_level<4, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 4, e0 + TB_T, r1, lane_ok, xcol, b0, b1, b2, k0, k1, k2);
+        st_level<5, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 5, e0 + TB_T, r1, lane_ok, xcol, b2, b0, b1, k2, k0, k1);
+        st_level<6, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 6, e0 + TB_T, r1, lane_ok, xcol, b1, b2, b0, k1, k2, k0);
+        st_level<7, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 7, e0 + TB_T, r1, lane_ok, xcol, b0, b1, b2, k0, k1, k2);
+        st_level<8, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 8, e0 + TB_T, r1, lane_ok, xcol, b2, b0, b1, k2, k0, k1);
+    }
     z.slot = z.slot + 2 == ST_RING ? 0 : z.slot + 2;
 }
 
@@ -456,7 +476,7 @@ __global__ __launch_bounds__(64, 2) void k_jacobi_stream_p(st_args a)
                 prof_q++;
             } else {
                 bool got = false;
-                if (a.dbg & 16) break;
+                if (ST_DBG(a, 16)) break;
                 const unsigned long long look0 = a.prof ? __builtin_amdgcn_s_memrealtime() : 0ull;
                 const int nwin = a.cap / 512;
                 const unsigned start = scan_from >> 8;
@@ -549,7 +569,7 @@ __global__ __launch_bounds__(64, 2) void k_jacobi_stream_p(st_args a)
         for (;;) {
             // a chapter of 64 window rows.  The levels read the coefficients of window rows [2t - 10, 2t + 67) in it: the
             // entries [2t + 16, 2t + 80) replace rows that left the window long ago
-            if (!(a.dbg & 128) || t == 0)
+            if (!ST_DBG(a, 128) || t == 0)
                 ktab[(2 * t + 16 + lane) & (STP_KT - 1)] = *reinterpret_cast<const v4f *>(a.jcoef + (size_t)st_map_row(a, e0 + 2 * t + 16 + lane).l * 8);
             const int t_chapter = t + 32;
             int nsteps;
@@ -557,8 +577,8 @@ __global__ __launch_bounds__(64, 2) void k_jacobi_stream_p(st_args a)
                 // the end row is in the word's low half: a 32-bit load (the unused upper register of a 64-bit one is handed
                 // out again at once, and overwriting it means waiting for this load and every staged load before it)
                 unsigned w = ~0u;
-                if (!(a.dbg & 8)) w = __hip_atomic_load(reinterpret_cast<const unsigned *>(&a.seg_word[id]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (!(a.dbg & 32)) __hip_atomic_store(&a.seg_cur[id], (unsigned)(e0 + 2 * (t + 2) + STP_BIAS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!ST_DBG(a, 8)) w = __hip_atomic_load(reinterpret_cast<const unsigned *>(&a.seg_word[id]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!ST_DBG(a, 32)) __hip_atomic_store(&a.seg_cur[id], (unsigned)(e0 + 2 * (t + 2) + STP_BIAS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 st_step<0, true>(a, z, bring, cring, ktab, lane, t, e0, 0, hi_known, 0u, 0u, col, colp, lane_ok, xcol, tx);
                 st_step<1, true>(a, z, bring, cring, ktab, lane, t + 1, e0, 0, hi_known, 0u, 0u, col, colp, lane_ok, xcol, tx);
                 t += 2;
@@ -660,7 +680,7 @@ __device__ __forceinline__ void stn_level(const st_args &a, stn_state &z, v2f (*
         oB = landB ? (v2f)(0.0f) : stn_row_any(N1, N0, C0, bB, kB, z.cy, z.ry, mixB != 0, cring[sb], lane, t);
     }
     if (S < 8) { z.w[S & 7][K][0] = oA; z.w[S & 7][K][1] = oB; }
-    else if (lane_ok && !(a.dbg & 2)) {
+    else if (lane_ok && !ST_DBG(a, 2)) {
         // only the unit's own rows [r0, r1): in its first steps level 8 runs on rows below r0 (window rows that exist but
         // are not yet valid at this level) -- computed like any halo row, never stored
         if (!landA && yA >= r0 && yA < r1) __builtin_nontemporal_store(oA, reinterpret_cast<v2f *>(a.pout + (size_t)yA * a.W + xcol));
@@ -670,7 +690,7 @@ __device__ __forceinline__ void stn_level(const st_args &a, stn_state &z, v2f (*
 
 __device__ __forceinline__ void stn_fetch(const st_args &a, stn_state &z, int set, int j, int e, int col, int colp)
 {
-    const st_row m = st_map_row(a, (a.dbg & 1) ? (e & 63) : e);
+    const st_row m = st_map_row(a, ST_DBG(a, 1) ? (e & 63) : e);
     const size_t off = (size_t)m.l * a.W + (m.shift ? colp : col);
     z.ps[set][j] = *reinterpret_cast<const v2f *>(a.pin + off);
     z.bs[set][j] = *reinterpret_cast<const v2f *>(a.b + off);
