@@ -95,6 +95,29 @@ __device__ __forceinline__ v2f st_value2(v2f pN, v2f pS, v2f pE, v2f pW, v2f b, 
     const v2f t = st_div2(pW + pE, k.cx, k.rx) + st_div2(pS + pN, k.cy, k.ry);
     return st_div2(t - b, k.beta, k.rb);
 }
+// the same from the two neighbour sums
+__device__ __forceinline__ v2f st_value2s(v2f we, v2f sn, v2f b, const jacobi_row &k)
+{
+    const v2f t = st_div2(we, k.cx, k.rx) + st_div2(sn, k.cy, k.ry);
+    return st_div2(t - b, k.beta, k.rb);
+}
+// Register layout of a row in the wide kernels: a lane's four cells c0..c3 sit in its two register pairs as (c0, c3) and
+// (c1, c2).  With the natural pairing (c0, c1), (c2, c3) the east/west operands of a pair straddle two pairs and cost
+// 2 DPP + 4 moves + 2 packed adds per row; here pW + pE of the inner cells is one packed add with the second operand's
+// halves swapped ((c0 + c2, c3 + c1): op_sel), and of the outer cells two adds with the DPP lane shift folded in
+// (prev lane's c3 + c1, next lane's c0 + c2): 3 instructions instead of 8, 10 of the 73 a level visit had.  North/south
+// operands and the right-hand side (stored in the ring in this order) are pairs as they are; rows are put into this
+// order when they arrive and back into memory order when level 8 stores them.
+struct st_we { v2f outer, inner; };
+__device__ __forceinline__ st_we st_we_sums(const v4f C)
+{
+    st_we r;
+    r.outer = v2f{ dpp_from_prev_lane(C.y) + C.z, dpp_from_next_lane(C.x) + C.w };
+    r.inner = C.xy + C.wz;
+    return r;
+}
+__device__ __forceinline__ v4f st_to_pairs(const v4f m) { return v4f{ m.x, m.w, m.y, m.z }; }     // memory order -> (c0, c3, c1, c2)
+__device__ __forceinline__ v4f st_to_memory(const v4f q) { return v4f{ q.x, q.z, q.w, q.y }; }
 // land neighbour -> centre value (OceanCurrents.cpp:470-473) as pK | (pC & mask): land holds exactly +0.0
 template <int BIT>
 __device__ __forceinline__ float st_sel(unsigned code, int tick, float pC, float pK)
@@ -133,13 +156,11 @@ __device__ __forceinline__ v4f st_row_any(const v4f N, const v4f C, const v4f S,
                                           const uint2 *crow, int lane)
 {
     const jacobi_row k = { kk.x, cy, kk.z, kk.y, ry, kk.w };
-    const float wl = dpp_from_prev_lane(C.w);                // west neighbour of C.x
-    const float er = dpp_from_next_lane(C.x);                // east neighbour of C.w
+    const st_we we = st_we_sums(C);
     v2f o0, o1;
     if (!mixed) {
-        const v2f Wlo = { wl, C.x }, Mid = { C.y, C.z }, Ehi = { C.w, er };
-        o0 = st_value2(N.xy, S.xy, Mid, Wlo, bb.xy, k);      // cells x, y: W = (wl, x), E = (y, z)
-        o1 = st_value2(N.zw, S.zw, Ehi, Mid, bb.zw, k);      // cells z, w: W = (y, z), E = (w, er)
+        o0 = st_value2s(we.outer, S.xy + N.xy, bb.xy, k);
+        o1 = st_value2s(we.inner, S.zw + N.zw, bb.zw, k);
     } else {
         // coast row.  Land holds exactly +0.0 at every level, so "a land neighbour reads the centre value"
         // (OceanCurrents.cpp:470-473) is pW' + pE' = (pW + pE) + n * pC with n = the number of land neighbours among the
@@ -150,15 +171,14 @@ __device__ __forceinline__ v4f st_row_any(const v4f N, const v4f C, const v4f S,
         // x = L * t - b (b is -0.0 on land, st_arrive) is then +0, which the divisions by Beta > 0 keep: land -> +0.0 (:481).
         // (A pressure of -0.0, which no sweep that started from +0.0 produces inside the division window of
         // demiurge_hip.h, would read back as +0.0 from an open neighbour pair here.)
-        const uint2 c = crow[lane];
+        const uint2 c = crow[lane];                           // bytes in pair order: c0, c3, c1, c2
         const v2f kwe0 = __builtin_amdgcn_cvt_pk_f32_fp8((int)c.x, false), kwe1 = __builtin_amdgcn_cvt_pk_f32_fp8((int)c.x, true);
         const v2f ksn0 = __builtin_amdgcn_cvt_pk_f32_fp8((int)c.y, false), ksn1 = __builtin_amdgcn_cvt_pk_f32_fp8((int)c.y, true);
         const v2f one = { 1.0f, 1.0f };
         v2f L0, L1;
         asm("v_pk_add_f32 %0, %1, %2 clamp" : "=v"(L0) : "v"(ksn0), "v"(one));
         asm("v_pk_add_f32 %0, %1, %2 clamp" : "=v"(L1) : "v"(ksn1), "v"(one));
-        const v2f Wlo = { wl, C.x }, Mid = { C.y, C.z }, Ehi = { C.w, er };
-        const v2f we0 = __builtin_elementwise_fma(kwe0, C.xy, Wlo + Mid), we1 = __builtin_elementwise_fma(kwe1, C.zw, Mid + Ehi);
+        const v2f we0 = __builtin_elementwise_fma(kwe0, C.xy, we.outer), we1 = __builtin_elementwise_fma(kwe1, C.zw, we.inner);
         const v2f sn0 = __builtin_elementwise_fma(ksn0, C.xy, S.xy + N.xy), sn1 = __builtin_elementwise_fma(ksn1, C.zw, S.zw + N.zw);
         const v2f t0 = st_div2(we0, k.cx, k.rx) + st_div2(sn0, k.cy, k.ry), t1 = st_div2(we1, k.cx, k.rx) + st_div2(sn1, k.cy, k.ry);
         o0 = st_div2(__builtin_elementwise_fma(L0, t0, -bb.xy), k.beta, k.rb);
@@ -191,12 +211,9 @@ __device__ __forceinline__ void st_level(const st_args &a, st_state &z, v4f (*br
     if (FAST || !(((z.landbits | z.mixbits) >> S) & 3u)) {   // (one two-bit field of the step's combined mask: the common case costs one scalar test)
         // both rows open ocean (wave-uniform): one block of 8 independent division chains
         const jacobi_row ka = { kA.x, z.cy, kA.z, kA.y, z.ry, kA.w }, kb = { kB.x, z.cy, kB.z, kB.y, z.ry, kB.w };
-        const float wlA = dpp_from_prev_lane(C0.w), erA = dpp_from_next_lane(C0.x);
-        const float wlB = dpp_from_prev_lane(N0.w), erB = dpp_from_next_lane(N0.x);
-        const v2f WloA = { wlA, C0.x }, MidA = { C0.y, C0.z }, EhiA = { C0.w, erA };
-        const v2f WloB = { wlB, N0.x }, MidB = { N0.y, N0.z }, EhiB = { N0.w, erB };
-        const v2f a0 = st_value2(N0.xy, S0.xy, MidA, WloA, bA.xy, ka), a1 = st_value2(N0.zw, S0.zw, EhiA, MidA, bA.zw, ka);
-        const v2f b0 = st_value2(N1.xy, C0.xy, MidB, WloB, bB.xy, kb), b1 = st_value2(N1.zw, C0.zw, EhiB, MidB, bB.zw, kb);
+        const st_we weA = st_we_sums(C0), weB = st_we_sums(N0);
+        const v2f a0 = st_value2s(weA.outer, S0.xy + N0.xy, bA.xy, ka), a1 = st_value2s(weA.inner, S0.zw + N0.zw, bA.zw, ka);
+        const v2f b0 = st_value2s(weB.outer, C0.xy + N1.xy, bB.xy, kb), b1 = st_value2s(weB.inner, C0.zw + N1.zw, bB.zw, kb);
         oA = v4f{ a0.x, a0.y, a1.x, a1.y };
         oB = v4f{ b0.x, b0.y, b1.x, b1.y };
     } else {
@@ -209,8 +226,8 @@ __device__ __forceinline__ void st_level(const st_args &a, st_state &z, v4f (*br
     if (S < 8) { z.w[S & 7][K][0] = oA; z.w[S & 7][K][1] = oB; }
     else if (lane_ok && !ST_DBG(a, 2)) {                          // never re-read in this launch; land rows hold 0 in both buffers already
         // only the unit's own rows [r0, r1): in its first steps level 8 runs on rows below r0, never stored
-        if (!landA && yA >= r0 && yA < r1) __builtin_nontemporal_store(oA, reinterpret_cast<v4f *>(a.pout + (size_t)yA * a.W + xcol));
-        if (!landB && yA + 1 >= r0 && yA + 1 < r1) __builtin_nontemporal_store(oB, reinterpret_cast<v4f *>(a.pout + (size_t)(yA + 1) * a.W + xcol));
+        if (!landA && yA >= r0 && yA < r1) __builtin_nontemporal_store(st_to_memory(oA), reinterpret_cast<v4f *>(a.pout + (size_t)yA * a.W + xcol));
+        if (!landB && yA + 1 >= r0 && yA + 1 < r1) __builtin_nontemporal_store(st_to_memory(oB), reinterpret_cast<v4f *>(a.pout + (size_t)(yA + 1) * a.W + xcol));
     }
 }
 
@@ -256,8 +273,9 @@ __device__ __forceinline__ void st_arrive(const st_args &a, st_state &z, v4f (*b
         v2f lo, hi;
         // (volatile + "memory": the scheduler must not hoist the set's reload above these moves either -- it did for one
         // of the two sets, whose p rows then went through copies and an early vmcnt wait on the loop's back edge)
-        asm volatile("v_mov_b64 %0, %1" : "=v"(lo) : "v"(z.ps[K][j].xy) : "memory");
-        asm volatile("v_mov_b64 %0, %1" : "=v"(hi) : "v"(z.ps[K][j].zw) : "memory");
+        // (v_pk_mov_b32: one half from each source pair -- the row goes into pair order (c0, c3), (c1, c2) on the way)
+        asm volatile("v_pk_mov_b32 %0, %1, %2 op_sel:[0,1]" : "=v"(lo) : "v"(z.ps[K][j].xy), "v"(z.ps[K][j].zw) : "memory");
+        asm volatile("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=v"(hi) : "v"(z.ps[K][j].xy), "v"(z.ps[K][j].zw) : "memory");
         z.w[0][K][j] = v4f{ lo.x, lo.y, hi.x, hi.y };
     }
     if (cls == 2u) {
@@ -282,18 +300,19 @@ __device__ __forceinline__ void st_arrive(const st_args &a, st_state &z, v4f (*b
             const unsigned c2 = c >> 2;
             const unsigned we = __builtin_amdgcn_perm(0u, 0x40383800u, c2 & 0x03030303u);
             const unsigned sn = __builtin_amdgcn_perm(0xB8B8B8B8u, 0x40383800u, (c & 0x03030303u) | (c2 & 0x04040404u));
-            cring[slot][lane] = uint2{ we, sn };
+            // bytes into pair order: c0, c3, c1, c2
+            cring[slot][lane] = uint2{ __builtin_amdgcn_perm(0u, we, 0x02010300u), __builtin_amdgcn_perm(0u, sn, 0x02010300u) };
             // the right-hand side of a land cell becomes -0.0: x = 0 * t - (-0.0) is then +0.0 whatever the sign of t
             v4f bq = z.bs[K][j];
             asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(bq.x) : "v"(code_mask<4>(c, 0)), "v"(0x80000000u), "v"(bq.x));
             asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(bq.y) : "v"(code_mask<12>(c, 0)), "v"(0x80000000u), "v"(bq.y));
             asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(bq.z) : "v"(code_mask<20>(c, 0)), "v"(0x80000000u), "v"(bq.z));
             asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(bq.w) : "v"(code_mask<28>(c, 0)), "v"(0x80000000u), "v"(bq.w));
-            bring[slot][lane] = bq;
+            bring[slot][lane] = st_to_pairs(bq);
             return;
         }
     }
-    bring[slot][lane] = z.bs[K][j];
+    bring[slot][lane] = st_to_pairs(z.bs[K][j]);
 }
 
 // class of the row in staging slot [K][j] (persistent form): rows beyond the grid or the stored band count as mixed
