@@ -176,8 +176,8 @@ __device__ __forceinline__ v4f st_row_any(const v4f N, const v4f C, const v4f S,
         const v2f ksn0 = __builtin_amdgcn_cvt_pk_f32_fp8((int)c.y, false), ksn1 = __builtin_amdgcn_cvt_pk_f32_fp8((int)c.y, true);
         const v2f one = { 1.0f, 1.0f };
         v2f L0, L1;
-        asm("v_pk_add_f32 %0, %1, %2 clamp" : "=v"(L0) : "v"(ksn0), "v"(one));
-        asm("v_pk_add_f32 %0, %1, %2 clamp" : "=v"(L1) : "v"(ksn1), "v"(one));
+        asm("v_pk_add_f32 %0, %1, %2 clamp" : "=v"(L0) : "v"(ksn0), "s"(one));
+        asm("v_pk_add_f32 %0, %1, %2 clamp" : "=v"(L1) : "v"(ksn1), "s"(one));
         const v2f we0 = __builtin_elementwise_fma(kwe0, C.xy, we.outer), we1 = __builtin_elementwise_fma(kwe1, C.zw, we.inner);
         const v2f sn0 = __builtin_elementwise_fma(ksn0, C.xy, S.xy + N.xy), sn1 = __builtin_elementwise_fma(ksn1, C.zw, S.zw + N.zw);
         const v2f t0 = st_div2(we0, k.cx, k.rx) + st_div2(sn0, k.cy, k.ry), t1 = st_div2(we1, k.cx, k.rx) + st_div2(sn1, k.cy, k.ry);
@@ -189,10 +189,11 @@ __device__ __forceinline__ v4f st_row_any(const v4f N, const v4f C, const v4f S,
 
 // one level: sweep S of rows yA = e0 + 2t - S and yB = yA + 1 from level S-1's rows yA-1 .. yB+1 (the pair made one step ago
 // and the pair made in this step); K = t mod 2
-template <int S, int K, bool P, bool FAST = false>
+// MODE 0: the pair's rows as their classes say (tests and branches); 1: both open water; 2: both through the coast formula
+template <int S, int K, bool P, int MODE = 0>
 __device__ __forceinline__ void st_level(const st_args &a, st_state &z, v4f (*bring)[64], uint2 (*cring)[64], const v4f *ktab,
                                          int lane, int t, int yA, int r0, int r1, bool lane_ok, int xcol,
-                                         const v4f bA, const v4f bB, v4f &bA_next, const v4f kA, const v4f kB, v4f &kA_next)
+                                         const v4f bA, const v4f bB, v4f &bA_next, const v4f kA, const v4f kB, v4f &kA_next, int kb = 0)
 {
     // the next level's right-hand side and coefficients are read from the rings while this level computes.  Level S + 1
     // works one row further south: its second row is this level's first (whose operands are in registers already), only
@@ -200,15 +201,22 @@ __device__ __forceinline__ void st_level(const st_args &a, st_state &z, v4f (*br
     if (S < 8 && !ST_DBG(a, 256)) {
         const int sa = st_wrap(z.slot - (S + 1));
         bA_next = bring[sa][lane];
-        const int ra = max(2 * t - (S + 1), 0);               // window row of the next level's first row
-        kA_next = ktab[st_kt<P>(ra)];                         // every lane reads the same 16 bytes: one broadcast
+        // coefficients of the next level's first row, window row 2t - (S + 1); every lane reads the same 16 bytes: one broadcast.
+        // Unit form: kb = byte offset of window row 2t - 8 in a VGPR, set once per step -- the level adds a constant (in the
+        // first four steps of a unit the offset is negative: the read lands in the ring in front of the table and is not used)
+        if (P) kA_next = ktab[st_kt<P>(max(2 * t - (S + 1), 0))];
+        else kA_next = *reinterpret_cast<const v4f *>(reinterpret_cast<const char *>(ktab) + kb + (8 - (S + 1)) * 16);
     } else if (S < 8) { bA_next = bB; kA_next = kB; }         // (timing experiment: wrong results)
     // (a level whose rows do not exist yet sees them as land: landbits starts as all ones; rows that exist but are not
     // yet valid at this level are computed like any halo row)
     const v4f S0 = z.w[S - 1][K ^ 1][0], C0 = z.w[S - 1][K ^ 1][1], N0 = z.w[S - 1][K][0], N1 = z.w[S - 1][K][1];
     v4f oA, oB;
     unsigned landA = 0, landB = 0;
-    if (FAST || !(((z.landbits | z.mixbits) >> S) & 3u)) {   // (one two-bit field of the step's combined mask: the common case costs one scalar test)
+    if (MODE == 2) {
+        const int sa = st_wrap(z.slot - S), sb = sa + 1 == ST_RING ? 0 : sa + 1;
+        oA = st_row_any(N0, C0, S0, bA, kA, z.cy, z.ry, true, cring[sa], lane);
+        oB = st_row_any(N1, N0, C0, bB, kB, z.cy, z.ry, true, cring[sb], lane);
+    } else if (MODE == 1 || !(((z.landbits | z.mixbits) >> S) & 3u)) {   // (one two-bit field of the step's combined mask: the common case costs one scalar test)
         // both rows open ocean (wave-uniform): one block of 8 independent division chains
         const jacobi_row ka = { kA.x, z.cy, kA.z, kA.y, z.ry, kA.w }, kb = { kB.x, z.cy, kB.z, kB.y, z.ry, kB.w };
         const st_we weA = st_we_sums(C0), weB = st_we_sums(N0);
@@ -312,6 +320,8 @@ __device__ __forceinline__ void st_arrive(const st_args &a, st_state &z, v4f (*b
             return;
         }
     }
+    // (an open row among coast rows goes through the coast formula with the rest of its step: counts of zero)
+    cring[slot][lane] = uint2{ 0u, 0u };                      // (a land row's entry is never read: no test)
     bring[slot][lane] = st_to_pairs(z.bs[K][j]);
 }
 
@@ -346,26 +356,39 @@ __device__ __forceinline__ void st_step(const st_args &a, st_state &z, v4f (*bri
     // level 1: rows e_t - 1 (in the ring since the last step) and e_t (just written)
     const int s1 = st_wrap(z.slot - 1), r1w = max(2 * t - 1, 0);
     v4f b0 = bring[s1][lane], b1 = bring[z.slot][lane], k0 = ktab[st_kt<P>(r1w)], k1 = ktab[st_kt<P>(r1w + 1)], b2, k2;
+    int kb = 0;
+    if (!P) asm volatile("v_mov_b32 %0, %1" : "=v"(kb) : "s"((2 * t - 8) * 16));
     // no land and no coast in any of the ten rows in flight (every step of a strip in open water): the eight levels without
     // a test or a branch between them -- one block for the scheduler; a branch per level visit costs the kernel ~3 %
     if (!((z.landbits | z.mixbits) & 0x3FFu)) {
-        st_level<1, K, P, true>(a, z, bring, cring, ktab, lane, t, e_t - 1, e0 + TB_T, r1, lane_ok, xcol, b0, b1, b2, k0, k1, k2);
-        st_level<2, K, P, true>(a, z, bring, cring, ktab, lane, t, e_t - 2, e0 + TB_T, r1, lane_ok, xcol, b2, b0, b1, k2, k0, k1);
-        st_level<3, K, P, true>(a, z, bring, cring, ktab, lane, t, e_t - 3, e0 + TB_T, r1, lane_ok, xcol, b1, b2, b0, k1, k2, k0);
-        st_level<4, K, P, true>(a, z, bring, cring, ktab, lane, t, e_t - 4, e0 + TB_T, r1, lane_ok, xcol, b0, b1, b2, k0, k1, k2);
-        st_level<5, K, P, true>(a, z, bring, cring, ktab, lane, t, e_t - 5, e0 + TB_T, r1, lane_ok, xcol, b2, b0, b1, k2, k0, k1);
-        st_level<6, K, P, true>(a, z, bring, cring, ktab, lane, t, e_t - 6, e0 + TB_T, r1, lane_ok, xcol, b1, b2, b0, k1, k2, k0);
-        st_level<7, K, P, true>(a, z, bring, cring, ktab, lane, t, e_t - 7, e0 + TB_T, r1, lane_ok, xcol, b0, b1, b2, k0, k1, k2);
-        st_level<8, K, P, true>(a, z, bring, cring, ktab, lane, t, e_t - 8, e0 + TB_T, r1, lane_ok, xcol, b2, b0, b1, k2, k0, k1);
+        st_level<1, K, P, 1>(a, z, bring, cring, ktab, lane, t, e_t - 1, e0 + TB_T, r1, lane_ok, xcol, b0, b1, b2, k0, k1, k2, kb);
+        st_level<2, K, P, 1>(a, z, bring, cring, ktab, lane, t, e_t - 2, e0 + TB_T, r1, lane_ok, xcol, b2, b0, b1, k2, k0, k1, kb);
+        st_level<3, K, P, 1>(a, z, bring, cring, ktab, lane, t, e_t - 3, e0 + TB_T, r1, lane_ok, xcol, b1, b2, b0, k1, k2, k0, kb);
+        st_level<4, K, P, 1>(a, z, bring, cring, ktab, lane, t, e_t - 4, e0 + TB_T, r1, lane_ok, xcol, b0, b1, b2, k0, k1, k2, kb);
+        st_level<5, K, P, 1>(a, z, bring, cring, ktab, lane, t, e_t - 5, e0 + TB_T, r1, lane_ok, xcol, b2, b0, b1, k2, k0, k1, kb);
+        st_level<6, K, P, 1>(a, z, bring, cring, ktab, lane, t, e_t - 6, e0 + TB_T, r1, lane_ok, xcol, b1, b2, b0, k1, k2, k0, kb);
+        st_level<7, K, P, 1>(a, z, bring, cring, ktab, lane, t, e_t - 7, e0 + TB_T, r1, lane_ok, xcol, b0, b1, b2, k0, k1, k2, kb);
+        st_level<8, K, P, 1>(a, z, bring, cring, ktab, lane, t, e_t - 8, e0 + TB_T, r1, lane_ok, xcol, b2, b0, b1, k2, k0, k1, kb);
+    } else if (!(z.landbits & 0x3FFu)) {
+        // coast among the ten rows, but no row that is land everywhere (coast rows come in long runs: 18 % of the survey
+        // terrain's steps): every row through the coast formula, open rows with counts of zero -- again no test, no branch
+        st_level<1, K, P, 2>(a, z, bring, cring, ktab, lane, t, e_t - 1, e0 + TB_T, r1, lane_ok, xcol, b0, b1, b2, k0, k1, k2, kb);
+        st_level<2, K, P, 2>(a, z, bring, cring, ktab, lane, t, e_t - 2, e0 + TB_T, r1, lane_ok, xcol, b2, b0, b1, k2, k0, k1, kb);
+        st_level<3, K, P, 2>(a, z, bring, cring, ktab, lane, t, e_t - 3, e0 + TB_T, r1, lane_ok, xcol, b1, b2, b0, k1, k2, k0, kb);
+        st_level<4, K, P, 2>(a, z, bring, cring, ktab, lane, t, e_t - 4, e0 + TB_T, r1, lane_ok, xcol, b0, b1, b2, k0, k1, k2, kb);
+        st_level<5, K, P, 2>(a, z, bring, cring, ktab, lane, t, e_t - 5, e0 + TB_T, r1, lane_ok, xcol, b2, b0, b1, k2, k0, k1, kb);
+        st_level<6, K, P, 2>(a, z, bring, cring, ktab, lane, t, e_t - 6, e0 + TB_T, r1, lane_ok, xcol, b1, b2, b0, k1, k2, k0, kb);
+        st_level<7, K, P, 2>(a, z, bring, cring, ktab, lane, t, e_t - 7, e0 + TB_T, r1, lane_ok, xcol, b0, b1, b2, k0, k1, k2, kb);
+        st_level<8, K, P, 2>(a, z, bring, cring, ktab, lane, t, e_t - 8, e0 + TB_T, r1, lane_ok, xcol, b2, b0, b1, k2, k0, k1, kb);
     } else {
-        st_level<1, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 1, e0 + TB_T, r1, lane_ok, xcol, b0, b1, b2, k0, k1, k2);
-        st_level<2, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 2, e0 + TB_T, r1, lane_ok, xcol, b2, b0, b1, k2, k0, k1);
-        st_level<3, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 3, e0 + TB_T, r1, lane_ok, xcol, b1, b2, b0, k1, k2, k0);
-        st_level<4, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 4, e0 + TB_T, r1, lane_ok, xcol, b0, b1, b2, k0, k1, k2);
-        st_level<5, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 5, e0 + TB_T, r1, lane_ok, xcol, b2, b0, b1, k2, k0, k1);
-        st_level<6, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 6, e0 + TB_T, r1, lane_ok, xcol, b1, b2, b0, k1, k2, k0);
-        st_level<7, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 7, e0 + TB_T, r1, lane_ok, xcol, b0, b1, b2, k0, k1, k2);
-        st_level<8, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 8, e0 + TB_T, r1, lane_ok, xcol, b2, b0, b1, k2, k0, k1);
+        st_level<1, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 1, e0 + TB_T, r1, lane_ok, xcol, b0, b1, b2, k0, k1, k2, kb);
+        st_level<2, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 2, e0 + TB_T, r1, lane_ok, xcol, b2, b0, b1, k2, k0, k1, kb);
+        st_level<3, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 3, e0 + TB_T, r1, lane_ok, xcol, b1, b2, b0, k1, k2, k0, kb);
+        st_level<4, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 4, e0 + TB_T, r1, lane_ok, xcol, b0, b1, b2, k0, k1, k2, kb);
+        st_level<5, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 5, e0 + TB_T, r1, lane_ok, xcol, b2, b0, b1, k2, k0, k1, kb);
+        st_level<6, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 6, e0 + TB_T, r1, lane_ok, xcol, b1, b2, b0, k1, k2, k0, kb);
+        st_level<7, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 7, e0 + TB_T, r1, lane_ok, xcol, b0, b1, b2, k0, k1, k2, kb);
+        st_level<8, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 8, e0 + TB_T, r1, lane_ok, xcol, b2, b0, b1, k2, k0, k1, kb);
     }
     z.slot = z.slot + 2 == ST_RING ? 0 : z.slot + 2;
 }
