@@ -866,7 +866,7 @@ static void st_cut(const dmg_ocean *o, int variant, int lo, int hi, int seg, int
                    int seg2 = 0, int split = 0)
 {
     const int ow = variant ? STN_OW : TB_OW;
-    static const float w_mixed = [] { const char *e = getenv("DMG_ST_WMIXED"); return e ? (float)atof(e) : 1.4f; }();    // experiments: the cost model's weights (1.4: fitted to per-unit timings, DMG_ST_PROF)
+    static const float w_mixed = [] { const char *e = getenv("DMG_ST_WMIXED"); return e ? (float)atof(e) : 1.4f; }();    // experiments: the cost model's weights (1.4: best of a sweep 1.0 .. 1.6 on the survey terrain; the per-unit timings fit 1.23 .. 1.40)
     static const float w_land = [] { const char *e = getenv("DMG_ST_WLAND"); return e ? (float)atof(e) : 0.1f; }();
     const std::vector<unsigned char> &table = variant ? o->rowclass_n_host : o->rowclass_host;
     const int tiles_x = (o->grid.W + ow - 1) / ow, L = o->L;
