@@ -193,20 +193,27 @@ __device__ __forceinline__ v4f st_row_any(const v4f N, const v4f C, const v4f S,
 template <int S, int K, bool P, int MODE = 0>
 __device__ __forceinline__ void st_level(const st_args &a, st_state &z, v4f (*bring)[64], uint2 (*cring)[64], const v4f *ktab,
                                          int lane, int t, int yA, int r0, int r1, bool lane_ok, int xcol,
-                                         const v4f bA, const v4f bB, v4f &bA_next, const v4f kA, const v4f kB, v4f &kA_next, int kb = 0)
+                                         v4f (&bq)[9], v4f (&kq)[9], int kb = 0)
 {
-    // the next level's right-hand side and coefficients are read from the rings while this level computes.  Level S + 1
-    // works one row further south: its second row is this level's first (whose operands are in registers already), only
-    // its first row's are new
-    if (S < 8 && !ST_DBG(a, 256)) {
-        const int sa = st_wrap(z.slot - (S + 1));
-        bA_next = bring[sa][lane];
-        // coefficients of the next level's first row, window row 2t - (S + 1); every lane reads the same 16 bytes: one broadcast.
+    // bq[k], kq[k]: right-hand side and coefficients of ring row (newest - k); this level's rows are k = S and k = S - 1
+    const v4f bA = bq[S], bB = bq[S - 1], kA = kq[S], kB = kq[S - 1];
+    // the rows the next levels need are read from the rings while this level computes.  Level S + 1 works one row further
+    // south: its second row is this level's first (already in registers), only its first row, k = S + 1, is new.
+    if (S < 8) {
+        // coefficients of row k = S + 1, window row 2t - (S + 1); every lane reads the same 16 bytes: one broadcast.
         // Unit form: kb = byte offset of window row 2t - 8 in a VGPR, set once per step -- the level adds a constant (in the
         // first four steps of a unit the offset is negative: the read lands in the ring in front of the table and is not used)
-        if (P) kA_next = ktab[st_kt<P>(max(2 * t - (S + 1), 0))];
-        else kA_next = *reinterpret_cast<const v4f *>(reinterpret_cast<const char *>(ktab) + kb + (8 - (S + 1)) * 16);
-    } else if (S < 8) { bA_next = bB; kA_next = kB; }         // (timing experiment: wrong results)
+        if (P) kq[S + 1] = ktab[st_kt<P>(max(2 * t - (S + 1), 0))];
+        else kq[S + 1] = *reinterpret_cast<const v4f *>(reinterpret_cast<const char *>(ktab) + kb + (8 - (S + 1)) * 16);
+    }
+    // right-hand sides: the ring slot of row k = S + 1 is odd for even S (slots advance by two per step), so the slot below it
+    // exists without a wrap: an even level reads rows S + 1 and S + 2 off one address, the odd levels after the first none
+    if (S == 1) bq[2] = bring[st_wrap(z.slot - 2)][lane];
+    else if (S < 8 && !(S & 1)) {
+        const v4f *pb = &bring[st_wrap(z.slot - (S + 1)) - 1][lane];
+        bq[S + 2] = pb[0];
+        bq[S + 1] = pb[64];
+    }
     // (a level whose rows do not exist yet sees them as land: landbits starts as all ones; rows that exist but are not
     // yet valid at this level are computed like any halo row)
     const v4f S0 = z.w[S - 1][K ^ 1][0], C0 = z.w[S - 1][K ^ 1][1], N0 = z.w[S - 1][K][0], N1 = z.w[S - 1][K][1];
@@ -355,40 +362,41 @@ __device__ __forceinline__ void st_step(const st_args &a, st_state &z, v4f (*bri
     st_fetch<P>(a, z, K, 1, e_t + 5, col, colp, tx);
     // level 1: rows e_t - 1 (in the ring since the last step) and e_t (just written)
     const int s1 = st_wrap(z.slot - 1), r1w = max(2 * t - 1, 0);
-    v4f b0 = bring[s1][lane], b1 = bring[z.slot][lane], k0 = ktab[st_kt<P>(r1w)], k1 = ktab[st_kt<P>(r1w + 1)], b2, k2;
+    v4f bq[9], kq[9];
+    bq[1] = bring[s1][lane]; bq[0] = bring[z.slot][lane]; kq[1] = ktab[st_kt<P>(r1w)]; kq[0] = ktab[st_kt<P>(r1w + 1)];
     int kb = 0;
     if (!P) asm volatile("v_mov_b32 %0, %1" : "=v"(kb) : "s"((2 * t - 8) * 16));
     // no land and no coast in any of the ten rows in flight (every step of a strip in open water): the eight levels without
     // a test or a branch between them -- one block for the scheduler; a branch per level visit costs the kernel ~3 %
     if (!((z.landbits | z.mixbits) & 0x3FFu)) {
-        st_level<1, K, P, 1>(a, z, bring, cring, ktab, lane, t, e_t - 1, e0 + TB_T, r1, lane_ok, xcol, b0, b1, b2, k0, k1, k2, kb);
-        st_level<2, K, P, 1>(a, z, bring, cring, ktab, lane, t, e_t - 2, e0 + TB_T, r1, lane_ok, xcol, b2, b0, b1, k2, k0, k1, kb);
-        st_level<3, K, P, 1>(a, z, bring, cring, ktab, lane, t, e_t - 3, e0 + TB_T, r1, lane_ok, xcol, b1, b2, b0, k1, k2, k0, kb);
-        st_level<4, K, P, 1>(a, z, bring, cring, ktab, lane, t, e_t - 4, e0 + TB_T, r1, lane_ok, xcol, b0, b1, b2, k0, k1, k2, kb);
-        st_level<5, K, P, 1>(a, z, bring, cring, ktab, lane, t, e_t - 5, e0 + TB_T, r1, lane_ok, xcol, b2, b0, b1, k2, k0, k1, kb);
-        st_level<6, K, P, 1>(a, z, bring, cring, ktab, lane, t, e_t - 6, e0 + TB_T, r1, lane_ok, xcol, b1, b2, b0, k1, k2, k0, kb);
-        st_level<7, K, P, 1>(a, z, bring, cring, ktab, lane, t, e_t - 7, e0 + TB_T, r1, lane_ok, xcol, b0, b1, b2, k0, k1, k2, kb);
-        st_level<8, K, P, 1>(a, z, bring, cring, ktab, lane, t, e_t - 8, e0 + TB_T, r1, lane_ok, xcol, b2, b0, b1, k2, k0, k1, kb);
+        st_level<1, K, P, 1>(a, z, bring, cring, ktab, lane, t, e_t - 1, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<2, K, P, 1>(a, z, bring, cring, ktab, lane, t, e_t - 2, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<3, K, P, 1>(a, z, bring, cring, ktab, lane, t, e_t - 3, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<4, K, P, 1>(a, z, bring, cring, ktab, lane, t, e_t - 4, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<5, K, P, 1>(a, z, bring, cring, ktab, lane, t, e_t - 5, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<6, K, P, 1>(a, z, bring, cring, ktab, lane, t, e_t - 6, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<7, K, P, 1>(a, z, bring, cring, ktab, lane, t, e_t - 7, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<8, K, P, 1>(a, z, bring, cring, ktab, lane, t, e_t - 8, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
     } else if (!(z.landbits & 0x3FFu)) {
         // coast among the ten rows, but no row that is land everywhere (coast rows come in long runs: 18 % of the survey
         // terrain's steps): every row through the coast formula, open rows with counts of zero -- again no test, no branch
-        st_level<1, K, P, 2>(a, z, bring, cring, ktab, lane, t, e_t - 1, e0 + TB_T, r1, lane_ok, xcol, b0, b1, b2, k0, k1, k2, kb);
-        st_level<2, K, P, 2>(a, z, bring, cring, ktab, lane, t, e_t - 2, e0 + TB_T, r1, lane_ok, xcol, b2, b0, b1, k2, k0, k1, kb);
-        st_level<3, K, P, 2>(a, z, bring, cring, ktab, lane, t, e_t - 3, e0 + TB_T, r1, lane_ok, xcol, b1, b2, b0, k1, k2, k0, kb);
-        st_level<4, K, P, 2>(a, z, bring, cring, ktab, lane, t, e_t - 4, e0 + TB_T, r1, lane_ok, xcol, b0, b1, b2, k0, k1, k2, kb);
-        st_level<5, K, P, 2>(a, z, bring, cring, ktab, lane, t, e_t - 5, e0 + TB_T, r1, lane_ok, xcol, b2, b0, b1, k2, k0, k1, kb);
-        st_level<6, K, P, 2>(a, z, bring, cring, ktab, lane, t, e_t - 6, e0 + TB_T, r1, lane_ok, xcol, b1, b2, b0, k1, k2, k0, kb);
-        st_level<7, K, P, 2>(a, z, bring, cring, ktab, lane, t, e_t - 7, e0 + TB_T, r1, lane_ok, xcol, b0, b1, b2, k0, k1, k2, kb);
-        st_level<8, K, P, 2>(a, z, bring, cring, ktab, lane, t, e_t - 8, e0 + TB_T, r1, lane_ok, xcol, b2, b0, b1, k2, k0, k1, kb);
+        st_level<1, K, P, 2>(a, z, bring, cring, ktab, lane, t, e_t - 1, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<2, K, P, 2>(a, z, bring, cring, ktab, lane, t, e_t - 2, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<3, K, P, 2>(a, z, bring, cring, ktab, lane, t, e_t - 3, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<4, K, P, 2>(a, z, bring, cring, ktab, lane, t, e_t - 4, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<5, K, P, 2>(a, z, bring, cring, ktab, lane, t, e_t - 5, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<6, K, P, 2>(a, z, bring, cring, ktab, lane, t, e_t - 6, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<7, K, P, 2>(a, z, bring, cring, ktab, lane, t, e_t - 7, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<8, K, P, 2>(a, z, bring, cring, ktab, lane, t, e_t - 8, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
     } else {
-        st_level<1, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 1, e0 + TB_T, r1, lane_ok, xcol, b0, b1, b2, k0, k1, k2, kb);
-        st_level<2, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 2, e0 + TB_T, r1, lane_ok, xcol, b2, b0, b1, k2, k0, k1, kb);
-        st_level<3, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 3, e0 + TB_T, r1, lane_ok, xcol, b1, b2, b0, k1, k2, k0, kb);
-        st_level<4, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 4, e0 + TB_T, r1, lane_ok, xcol, b0, b1, b2, k0, k1, k2, kb);
-        st_level<5, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 5, e0 + TB_T, r1, lane_ok, xcol, b2, b0, b1, k2, k0, k1, kb);
-        st_level<6, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 6, e0 + TB_T, r1, lane_ok, xcol, b1, b2, b0, k1, k2, k0, kb);
-        st_level<7, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 7, e0 + TB_T, r1, lane_ok, xcol, b0, b1, b2, k0, k1, k2, kb);
-        st_level<8, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 8, e0 + TB_T, r1, lane_ok, xcol, b2, b0, b1, k2, k0, k1, kb);
+        st_level<1, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 1, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<2, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 2, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<3, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 3, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<4, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 4, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<5, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 5, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<6, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 6, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<7, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 7, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<8, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 8, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
     }
     z.slot = z.slot + 2 == ST_RING ? 0 : z.slot + 2;
 }
