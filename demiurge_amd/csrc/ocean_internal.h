@@ -58,8 +58,9 @@ struct dmg_ocean {
     // neighbours like every other launch (timing them in isolation, with a host synchronisation after each, favoured
     // shapes that lose in steady state)
     struct tb_tune { int trials[6] = { 0, 0, 0, 0, 0, 0 }; float best_ms[6] = { 1e30f, 1e30f, 1e30f, 1e30f, 1e30f, 1e30f }; int chosen = -1;
-                     hipEvent_t ev0 = nullptr, ev1 = nullptr; int pending = -1; };
+                     hipEvent_t ev0 = nullptr, ev1 = nullptr; int pending = -1; int warm = 0; };
     std::map<std::pair<int, int>, tb_tune> tb_tuning;           // (out_lo, out_hi) -> which tile shape is fastest there
+    std::map<std::pair<int, int>, tb_tune> st_tuning;           // (out_lo, out_hi) -> which cut of the streaming kernel's units (ocean_jacobi_stream.hip)
     float *v[2] = { nullptr, nullptr };   // interleaved (vx,vy)
     int vcur = 0;
     // dmg_ocean_jacobi_sweeps_begin/_end: the interior part of a block's last launch, still to be issued

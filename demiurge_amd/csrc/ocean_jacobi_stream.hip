@@ -35,8 +35,9 @@
 #else
 #define ST_DBG(a, bit) false
 #endif
-#define ST_MAXROWS 104            // output rows per unit: the window rows' classes fit two registers, and the coefficient
-                                  // table of 104 + 22 rows leaves the wide form's LDS at 20448 bytes: 8 waves share 160 KB
+#define ST_MAXROWS 232            // output rows per unit of the wide form: 248 window rows' classes fit one register (four bytes per
+                                  // lane), and the coefficient table of 232 + 22 rows leaves its LDS at 19424 bytes: 8 waves share 160 KB
+#define STN_MAXROWS 104           // narrow form: two class registers
 #define ST_RING 12                // ring slots (rows): 10 rows are in flight between level 0 and level 8, two arrive
 
 struct st_args {
@@ -153,7 +154,7 @@ __device__ __forceinline__ int st_wrap(int slot) { return slot < 0 ? slot + ST_R
 
 // one row of one level, generic: open ocean or coast (wave-uniform choice); N, C, S = the level below's rows y+1, y, y-1
 __device__ __forceinline__ v4f st_row_any(const v4f N, const v4f C, const v4f S, const v4f bb, const v4f kk, float cy, float ry, bool mixed,
-                                          const uint2 *crow, int lane)
+                                          const unsigned *crow, int lane)
 {
     const jacobi_row k = { kk.x, cy, kk.z, kk.y, ry, kk.w };
     const st_we we = st_we_sums(C);
@@ -165,15 +166,16 @@ __device__ __forceinline__ v4f st_row_any(const v4f N, const v4f C, const v4f S,
         // coast row.  Land holds exactly +0.0 at every level, so "a land neighbour reads the centre value"
         // (OceanCurrents.cpp:470-473) is pW' + pE' = (pW + pE) + n * pC with n = the number of land neighbours among the
         // two -- exactly, in one rounding: n = 0 adds a zero, n = 1 leaves pK + pC (the other addend is the land cell's
-        // +0), n = 2 leaves 0 + 2 pC.  The counts travel as four fp8 values per word (0, 1, 2 are exact in E4M3),
-        // unpacked two at a time by v_cvt_pk_f32_fp8, and one v_pk_fma_f32 per pair replaces eight bit-field selects.
+        // +0), n = 2 leaves 0 + 2 pC.  The counts travel as eight fp4 values in one word (0, 1, 2 and -1 are exact in E2M1;
+        // one word per lane-row instead of two of fp8 frees 3 KB of LDS for a taller coefficient table), unpacked two at a
+        // time by v_cvt_scalef32_pk_f32_fp4, and one v_pk_fma_f32 per pair replaces eight bit-field selects.
         // A land centre carries the count -1 in the N/S word: L = clamp(n + 1) is 0 there and 1 on water, and
         // x = L * t - b (b is -0.0 on land, st_arrive) is then +0, which the divisions by Beta > 0 keep: land -> +0.0 (:481).
         // (A pressure of -0.0, which no sweep that started from +0.0 produces inside the division window of
         // demiurge_hip.h, would read back as +0.0 from an open neighbour pair here.)
-        const uint2 c = crow[lane];                           // bytes in pair order: c0, c3, c1, c2
-        const v2f kwe0 = __builtin_amdgcn_cvt_pk_f32_fp8((int)c.x, false), kwe1 = __builtin_amdgcn_cvt_pk_f32_fp8((int)c.x, true);
-        const v2f ksn0 = __builtin_amdgcn_cvt_pk_f32_fp8((int)c.y, false), ksn1 = __builtin_amdgcn_cvt_pk_f32_fp8((int)c.y, true);
+        const unsigned c = crow[lane];                        // byte 0: E/W counts of (c0, c3), 1: of (c1, c2), 2 and 3: N/S counts
+        const v2f kwe0 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(c, 1.0f, 0), kwe1 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(c, 1.0f, 1);
+        const v2f ksn0 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(c, 1.0f, 2), ksn1 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(c, 1.0f, 3);
         const v2f one = { 1.0f, 1.0f };
         v2f L0, L1;
         asm("v_pk_add_f32 %0, %1, %2 clamp" : "=v"(L0) : "v"(ksn0), "s"(one));
@@ -191,7 +193,7 @@ __device__ __forceinline__ v4f st_row_any(const v4f N, const v4f C, const v4f S,
 // and the pair made in this step); K = t mod 2
 // MODE 0: the pair's rows as their classes say (tests and branches); 1: both open water; 2: both through the coast formula
 template <int S, int K, bool P, int MODE = 0>
-__device__ __forceinline__ void st_level(const st_args &a, st_state &z, v4f (*bring)[64], uint2 (*cring)[64], const v4f *ktab,
+__device__ __forceinline__ void st_level(const st_args &a, st_state &z, v4f (*bring)[64], unsigned (*cring)[64], const v4f *ktab,
                                          int lane, int t, int yA, int r0, int r1, bool lane_ok, int xcol,
                                          v4f (&bq)[9], v4f (&kq)[9], int kb = 0)
 {
@@ -247,6 +249,12 @@ __device__ __forceinline__ void st_level(const st_args &a, st_state &z, v4f (*br
 }
 
 // class of window row i (0..127) from the two class registers (lane i holds rows i and 64 + i)
+// wide form: lane l holds the classes of window rows l, 64 + l, 128 + l, 192 + l as four bytes
+__device__ __forceinline__ unsigned st_class4(unsigned cls4, int i)
+{
+    if (i > 255) return 2u;                                  // the padding rows of the last step: never used
+    return ((unsigned)__builtin_amdgcn_readlane((int)cls4, i & 63) >> ((i >> 6) * 8)) & 0xFFu;
+}
 __device__ __forceinline__ unsigned st_class(unsigned cls_lo, unsigned cls_hi, int i)
 {
     if (i > 127) return 2u;                                  // the padding rows of the last step: never used
@@ -277,7 +285,7 @@ typedef const float __attribute__((address_space(4))) *st_kptr;
 // the row that has arrived in staging slot [K][j]: classify it, take its pressure into level 0, park its right-hand side
 // and codes in the rings
 template <int K>
-__device__ __forceinline__ void st_arrive(const st_args &a, st_state &z, v4f (*bring)[64], uint2 (*cring)[64], int lane,
+__device__ __forceinline__ void st_arrive(const st_args &a, st_state &z, v4f (*bring)[64], unsigned (*cring)[64], int lane,
                                           int j, int e, unsigned cls, int slot, unsigned &land, unsigned &mix)
 {
     land = cls == 1u; mix = 0;
@@ -311,12 +319,12 @@ __device__ __forceinline__ void st_arrive(const st_args &a, st_state &z, v4f (*b
         mix &= ~land;
         if (mix) {
             // code byte of a cell: bit 0 N, 1 S, 2 E, 3 W neighbour is land, bit 4 the cell itself.  v_perm_b32 as a byte
-            // table: {E,W} -> fp8 of their count; {N,S} likewise, and -1.0 for a land cell (E4M3: 0x38 = 1, 0x40 = 2, 0xB8 = -1)
+            // table: {E,W} -> fp4 code of their count; {N,S} likewise, and -1.0 for a land cell (E2M1: 2 = 1.0, 4 = 2.0, 0xA = -1.0)
             const unsigned c2 = c >> 2;
-            const unsigned we = __builtin_amdgcn_perm(0u, 0x40383800u, c2 & 0x03030303u);
-            const unsigned sn = __builtin_amdgcn_perm(0xB8B8B8B8u, 0x40383800u, (c & 0x03030303u) | (c2 & 0x04040404u));
-            // bytes into pair order: c0, c3, c1, c2
-            cring[slot][lane] = uint2{ __builtin_amdgcn_perm(0u, we, 0x02010300u), __builtin_amdgcn_perm(0u, sn, 0x02010300u) };
+            const unsigned we = __builtin_amdgcn_perm(0u, 0x04020200u, c2 & 0x03030303u);
+            const unsigned sn = __builtin_amdgcn_perm(0x0A0A0A0Au, 0x04020200u, (c & 0x03030303u) | (c2 & 0x04040404u));
+            // nibbles into pair order: bytes {we c0, we c1, sn c0, sn c1} | {we c3, we c2, sn c3, sn c2} << 4
+            cring[slot][lane] = __builtin_amdgcn_perm(sn, we, 0x05040100u) | (__builtin_amdgcn_perm(sn, we, 0x06070203u) << 4);
             // the right-hand side of a land cell becomes -0.0: x = 0 * t - (-0.0) is then +0.0 whatever the sign of t
             v4f bq = z.bs[K][j];
             asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(bq.x) : "v"(code_mask<4>(c, 0)), "v"(0x80000000u), "v"(bq.x));
@@ -328,7 +336,7 @@ __device__ __forceinline__ void st_arrive(const st_args &a, st_state &z, v4f (*b
         }
     }
     // (an open row among coast rows goes through the coast formula with the rest of its step: counts of zero)
-    cring[slot][lane] = uint2{ 0u, 0u };                      // (a land row's entry is never read: no test)
+    cring[slot][lane] = 0u;                                   // (a land row's entry is never read: no test)
     bring[slot][lane] = st_to_pairs(z.bs[K][j]);
 }
 
@@ -347,14 +355,14 @@ __device__ __forceinline__ unsigned st_class_p(const st_args &a, const st_state 
 }
 
 template <int K, bool P = false>
-__device__ __forceinline__ void st_step(const st_args &a, st_state &z, v4f (*bring)[64], uint2 (*cring)[64], const v4f *ktab, int lane, int t,
+__device__ __forceinline__ void st_step(const st_args &a, st_state &z, v4f (*bring)[64], unsigned (*cring)[64], const v4f *ktab, int lane, int t,
                                         int e0, int nsteps, int r1, unsigned cls_lo, unsigned cls_hi, int col, int colp, bool lane_ok, int xcol, int tx = 0)
 {
     const int e_t = e0 + 2 * t;                              // first row of the pair that has just arrived
     const int slotB = z.slot + 1;                            // (ST_RING is even: a pair never wraps)
     unsigned landA, mixA, landB, mixB;
-    st_arrive<K>(a, z, bring, cring, lane, 0, e_t, P ? st_class_p<K>(a, z, 0, e_t) : st_class(cls_lo, cls_hi, 2 * t), z.slot, landA, mixA);
-    st_arrive<K>(a, z, bring, cring, lane, 1, e_t + 1, P ? st_class_p<K>(a, z, 1, e_t + 1) : st_class(cls_lo, cls_hi, 2 * t + 1), slotB, landB, mixB);
+    st_arrive<K>(a, z, bring, cring, lane, 0, e_t, P ? st_class_p<K>(a, z, 0, e_t) : st_class4(cls_lo, 2 * t), z.slot, landA, mixA);
+    st_arrive<K>(a, z, bring, cring, lane, 1, e_t + 1, P ? st_class_p<K>(a, z, 1, e_t + 1) : st_class4(cls_lo, 2 * t + 1), slotB, landB, mixB);
     z.landbits = (z.landbits << 2) | (landA << 1) | landB;
     z.mixbits = (z.mixbits << 2) | (mixA << 1) | mixB;
     // the staging set is free again: the pair of step t + 2 (past the window's end the rows are clamped and unused)
@@ -405,7 +413,7 @@ __device__ __forceinline__ void st_step(const st_args &a, st_state &z, v4f (*bri
 __global__ __launch_bounds__(64, 2) void k_jacobi_stream(st_args a)
 {
     __shared__ v4f bring[ST_RING][64];
-    __shared__ uint2 cring[ST_RING][64];             // coast rows: land-neighbour counts {E/W, N/S} as 4 x fp8 each (st_row_any)
+    __shared__ unsigned cring[ST_RING][64];          // coast rows: land-neighbour counts, eight fp4 values per row and lane (st_row_any)
     __shared__ v4f ktab[ST_MAXROWS + 2 * TB_T + 6];   // coefficients {cx, 1/cx, Beta, 1/Beta} of every window row, filled once
     const int lane = threadIdx.x;
     const int4 u = a.units[blockIdx.x];
@@ -422,24 +430,27 @@ __global__ __launch_bounds__(64, 2) void k_jacobi_stream(st_args a)
     int colp = col + W / 2; if (colp >= W) colp -= W;
     const bool lane_ok = (lane >= TB_T / 4) && (lane < 64 - TB_T / 4) && (xcol < W);
 
+    // the first two steps' rows are requested before anything else: their round trip covers the tables' below
+    st_state z;
+    st_fetch<false>(a, z, 0, 0, e0, col, colp);
+    st_fetch<false>(a, z, 0, 1, e0 + 1, col, colp);
+    st_fetch<false>(a, z, 1, 0, e0 + 2, col, colp);          // (rows past the window are clamped into the band: harmless)
+    st_fetch<false>(a, z, 1, 1, e0 + 3, col, colp);
+
     // classes of the window rows: rows beyond the grid or the stored band count as mixed (their codes decide)
-    unsigned cls_lo = 2u, cls_hi = 2u;
+    unsigned cls_lo = 0x02020202u, cls_hi = 0u;              // (cls_lo: four classes per lane, st_class4)
     if (a.rowclass) {
-        int lu = e0 + lane, yg = a.y_first + lu;
-        if (yg >= 0 && yg < a.H && lu >= 0 && lu < a.L) cls_lo = a.rowclass[(size_t)tx * a.L + lu];
-        lu += 64; yg += 64;
-        if (yg >= 0 && yg < a.H && lu >= 0 && lu < a.L) cls_hi = a.rowclass[(size_t)tx * a.L + lu];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int lu = e0 + lane + 64 * q, yg = a.y_first + lu;
+            if (yg >= 0 && yg < a.H && lu >= 0 && lu < a.L) cls_lo = (cls_lo & ~(0xFFu << (8 * q))) | ((unsigned)a.rowclass[(size_t)tx * a.L + lu] << (8 * q));
+        }
     }
 
-    st_state z;
 #pragma unroll
     for (int s = 0; s < 8; s++)
 #pragma unroll
         for (int k = 0; k < 2; k++) { z.w[s][k][0] = (v4f)(0.0f); z.w[s][k][1] = (v4f)(0.0f); }
-#pragma unroll
-    for (int k = 0; k < 2; k++)
-#pragma unroll
-        for (int j = 0; j < 2; j++) { z.ps[k][j] = (v4f)(0.0f); z.bs[k][j] = (v4f)(0.0f); z.cs[k][j] = 0; }
     z.landbits = 0xFFFFFFFFu;                                // rows before the window: "land", so that a level idles until its rows exist
     z.mixbits = 0; z.slot = 0;
     for (int i = lane; i < 2 * nsteps + 2; i += 64)          // one 16-byte table entry per window row (two spare: the next level's prefetch)
@@ -448,10 +459,6 @@ __global__ __launch_bounds__(64, 2) void k_jacobi_stream(st_args a)
         const st_kptr cf = (st_kptr)(unsigned long long)a.jcoef;
         z.cy = cf[4]; z.ry = cf[5];
     }
-    st_fetch<false>(a, z, 0, 0, e0, col, colp);
-    st_fetch<false>(a, z, 0, 1, e0 + 1, col, colp);
-    st_fetch<false>(a, z, 1, 0, e0 + 2, col, colp);          // (rows past the window are clamped into the band: harmless)
-    st_fetch<false>(a, z, 1, 1, e0 + 3, col, colp);
     for (int t = 0; t < nsteps; t += 2) {
         st_step<0>(a, z, bring, cring, ktab, lane, t, e0, nsteps, r1, cls_lo, cls_hi, col, colp, lane_ok, xcol);
         st_step<1>(a, z, bring, cring, ktab, lane, t + 1, e0, nsteps, r1, cls_lo, cls_hi, col, colp, lane_ok, xcol);
@@ -503,7 +510,7 @@ __global__ void k_st_reset(unsigned long long *word, unsigned *cur, int *ctl, co
 __global__ __launch_bounds__(64, 2) void k_jacobi_stream_p(st_args a)
 {
     __shared__ v4f bring[ST_RING][64];
-    __shared__ uint2 cring[ST_RING][64];
+    __shared__ unsigned cring[ST_RING][64];
     __shared__ v4f ktab[STP_KT];                     // coefficients of window rows, a ring refilled every 64 rows
     const int lane = threadIdx.x;
     const int W = a.W;
@@ -908,7 +915,11 @@ static void st_cut(const dmg_ocean *o, int variant, int lo, int hi, int seg, int
                 const int depth = std::min(std::min(r - (r0 - TB_T), (r1 + TB_T - 1) - r), TB_T);   // levels that still need this row
                 cost += (c == 1 ? w_land : (c == 2 ? w_mixed : 1.0f)) * (float)depth;
             }
-            units.push_back(st_unit{ tx, r0, r1, cost + 4.0f });
+            // + what a unit costs before and after its rows: dispatch, the class and coefficient tables, the first loads' round
+            // trip, the last stores.  Per-unit timings (DMG_ST_PROF) fit duration = 0.152 us x cost + 22 us: ~140 cost units,
+            // not the 4 the first version assumed -- which made the simulation prefer many short units
+            static const float unit_cost = [] { const char *e = getenv("DMG_ST_UNITCOST"); return e ? (float)atof(e) : 140.0f; }();
+            units.push_back(st_unit{ tx, r0, r1, cost + unit_cost });
         }
         }
     }
@@ -1022,9 +1033,20 @@ static const dmg_ocean::tile_list *st_units(dmg_ocean *o, int variant, int lo, i
     else {
         float best_span = 1e30f;
         int best_seg = 0, best_seg2 = 0, best_split = 0;
-        for (int cand = 24; cand <= ST_MAXROWS; cand += 4) {
+        // what a cut is judged by: alpha * (makespan of the simulated dispatch) + (1 - alpha) * (its work / slots).  The chip's
+        // throughput is shared by the two waves of a SIMD -- when a slot idles, its neighbour speeds up -- so an idle tail costs
+        // less than its length and the work (taller units stream fewer fill rows) counts for more than the makespan alone says
+        static const float alpha_env = [] { const char *e = getenv("DMG_ST_ALPHA"); return e ? (float)atof(e) : -1.0f; }();
+        const float alpha = alpha_env >= 0.0f ? alpha_env : (seg == -2 ? 0.5f : 1.0f);                  // seg -2: the second automatic cut
+        auto judge = [&](std::vector<st_unit> &u) {
+            const float span = st_makespan(u, slots);
+            double total = 0;
+            for (const st_unit &x : u) total += x.cost;
+            return alpha * span + (1.0f - alpha) * (float)(total / slots);
+        };
+        for (int cand = 24; cand <= (variant == 1 ? STN_MAXROWS : ST_MAXROWS); cand += 4) {
             st_cut(o, variant, lo, hi, cand, part, zone_lo, zone_hi, units);
-            float span = st_makespan(units, slots);
+            float span = judge(units);
             if (span < best_span) { best_span = span; best.swap(units); best_seg = cand; best_seg2 = 0; best_split = hi; }
             // two tiers: the top eighth .. half of the rows in units a half, a third or a quarter as tall
             for (int frac = 1; frac <= 4 && cand >= 48; frac++)
@@ -1032,10 +1054,11 @@ static const dmg_ocean::tile_list *st_units(dmg_ocean *o, int variant, int lo, i
                     const int split = hi - ((hi - lo) * frac / 8 / cand) * cand, seg2 = ((cand / div + 3) / 4) * 4;
                     if (split <= lo || split >= hi || seg2 < 12) continue;
                     st_cut(o, variant, lo, hi, cand, part, zone_lo, zone_hi, units, seg2, split);
-                    span = st_makespan(units, slots);
+                    span = judge(units);
                     if (span < best_span) { best_span = span; best.swap(units); best_seg = cand; best_seg2 = seg2; best_split = split; }
                 }
         }
+        (void)st_makespan(best, slots);                    // (longest first)
         static const bool dbg = getenv("DMG_ST_DEBUG") != nullptr;
         if (dbg) {
             double total = 0;
@@ -1074,11 +1097,11 @@ static const dmg_ocean::tile_list *st_units(dmg_ocean *o, int variant, int lo, i
 int ocean_launch_stream(dmg_ocean *o, int lo, int hi, int part, int zone_lo, int zone_hi, int from, hipStream_t st, int seg, int variant)
 {
     if (seg <= 0) seg = st_unit_rows();                    // 0: chosen per geometry
-    if (seg > ST_MAXROWS) seg = ST_MAXROWS;
     static const int forced = [] { const char *e = getenv("DMG_ST_VARIANT"); return e ? atoi(e) : -1; }();     // experiments: 0 wide, 1 narrow
     if (variant < 0) variant = forced >= 0 ? forced : 0;   // default: the wide kernel (measured: 2.52 vs 2.51 M on the survey terrain, 1.97 vs 1.83 M without land)
     if (o->grid.W < STN_EW) variant = 0;
     if (variant == 2 && (part != 0 || !o->rowclass32 || o->L + STP_BIAS >= (1 << STP_FIELD) || (o->grid.W + TB_OW - 1) / TB_OW >= 4096)) variant = 0;   // the halves of a split launch keep their unit lists
+    if (variant != 2 && seg > (variant == 1 ? STN_MAXROWS : ST_MAXROWS)) seg = variant == 1 ? STN_MAXROWS : ST_MAXROWS;
     const dmg_ocean::tile_list *tl = st_units(o, variant, lo, hi, part, zone_lo, zone_hi, seg);
     if (!tl) return dmg_fail(DMG_ENOMEM, "unit list allocation failed");
     if (tl->n == 0) return DMG_OK;

@@ -315,6 +315,11 @@ void ocean_tb_free_lists(dmg_ocean *o)
         if (kv.second.ev1) (void)hipEventDestroy(kv.second.ev1);
     }
     o->tb_tuning.clear();
+    for (auto &kv : o->st_tuning) {
+        if (kv.second.ev0) (void)hipEventDestroy(kv.second.ev0);
+        if (kv.second.ev1) (void)hipEventDestroy(kv.second.ev1);
+    }
+    o->st_tuning.clear();
 }
 
 __global__ void k_tb_widen(const unsigned char *__restrict__ in, unsigned *__restrict__ out, size_t n)
