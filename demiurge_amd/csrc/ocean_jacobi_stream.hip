@@ -453,9 +453,15 @@ __global__ __launch_bounds__(64, 2) void k_jacobi_stream(st_args a)
         for (int k = 0; k < 2; k++) { z.w[s][k][0] = (v4f)(0.0f); z.w[s][k][1] = (v4f)(0.0f); }
     z.landbits = 0xFFFFFFFFu;                                // rows before the window: "land", so that a level idles until its rows exist
     z.mixbits = 0; z.slot = 0;
-    for (int i = lane; i < 2 * nsteps + 2; i += 64)          // one 16-byte table entry per window row (two spare: the next level's prefetch)
-        ktab[i] = *reinterpret_cast<const v4f *>(a.jcoef + (size_t)st_map_row(a, e0 + i).l * 8);
     {
+        // one 16-byte table entry per window row (two spare: the next level's prefetch): all of a lane's (up to four) loads in
+        // flight together -- a loop of load, wait, store costs a unit a memory round trip per 64 rows
+        const int n = 2 * nsteps + 2;
+        v4f kt[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) kt[q] = *reinterpret_cast<const v4f *>(a.jcoef + (size_t)st_map_row(a, e0 + min(lane + 64 * q, n - 1)).l * 8);
+#pragma unroll
+        for (int q = 0; q < 4; q++) if (lane + 64 * q < n) ktab[lane + 64 * q] = kt[q];
         const st_kptr cf = (st_kptr)(unsigned long long)a.jcoef;
         z.cy = cf[4]; z.ry = cf[5];
     }
