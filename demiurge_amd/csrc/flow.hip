@@ -269,6 +269,52 @@ __global__ void k_flow_scatter_pairs(const int *__restrict__ idx, const int *__r
     if (i < n) dst[idx[i]] = v[i];
 }
 
+// the reduced pass list as the host's growth wants it: 16 bytes per entry {height, from, s, lake} and per lake the range of
+// its entries (sorted by (lake, height, from)); a lake without passes keeps {0, 0}
+__global__ void k_flow_entries(const unsigned long long *__restrict__ key, const unsigned long long *__restrict__ pay, int4 *__restrict__ ent,
+                               int2 *__restrict__ span, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int lake = (int)(key[i] >> 32);
+    ent[i] = make_int4((int)(unsigned)key[i], (int)(pay[i] >> 32), (int)(unsigned)pay[i], lake);
+    if (i == 0 || (int)(key[i - 1] >> 32) != lake) span[lake].x = i;
+    if (i == n - 1 || (int)(key[i + 1] >> 32) != lake) span[lake].y = i + 1;
+}
+// connections[tolocation] = pass (FlowFilter.cpp:588): of the passes assigned to one cell the LAST one survives.
+// assigned[j] = entry index of the j-th connection the growth made
+__global__ void k_flow_lastpos(const int *__restrict__ assigned, const unsigned long long *__restrict__ pay, int *__restrict__ lastpos, int n)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) atomicMax(&lastpos[(unsigned)pay[assigned[j]]], j);
+}
+// the surviving connections: the cell drains into the connected lake's sink cell, the lake hangs below the lake of that cell
+__global__ void k_flow_connect(const int *__restrict__ assigned, const unsigned long long *__restrict__ key, const unsigned long long *__restrict__ pay,
+                               const int *__restrict__ sdist, const int *__restrict__ lastpos, const int *__restrict__ sink_cell,
+                               int *__restrict__ conn_from, int *__restrict__ lpar, int *__restrict__ loff, float *__restrict__ llvl, int n)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const int c = assigned[j];
+    const unsigned s = (unsigned)pay[c];
+    if (lastpos[s] != j) return;
+    const int from = (int)(pay[c] >> 32);
+    conn_from[s] = sink_cell[from];
+    lpar[from] = (int)(key[c] >> 32);
+    loff[from] = sdist[c] + 1;
+    llvl[from] = __uint_as_float((unsigned)key[c]);
+}
+__global__ void k_flow_lake_init(int *__restrict__ lpar, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) lpar[i] = i;
+}
+__global__ void k_flow_mark(const int *__restrict__ idx, unsigned char *__restrict__ flag, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flag[idx[i]] = 1;
+}
+
 // ---- lake tree: depth offset and water level of every lake by pointer jumping ---------------------------------------------
 // The connections make a forest over the lakes: a connected lake hangs below the lake it drains into, the river mouths
 // are the roots.  calculateflow's recursion reaches a lake at depth (parent's depth + depth of the cell it drains into
@@ -583,8 +629,11 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
     if (nmouth) DMG_HIP(hipMemcpyAsync(mouths.data(), mouths_d.p, (size_t)nmouth * 4, hipMemcpyDeviceToHost, st));
 
     int nuniq = 0;
-    std::vector<unsigned long long> hkey, hpay;
-    std::vector<int> hsdist;
+    struct Entry { float h; int from, s, lake; };                     // = the int4 k_flow_entries writes
+    struct Span { int cur, end; };                                     // per lake: next unread entry, end of its entries
+    std::vector<Entry> ent;
+    std::vector<Span> span(nlakes + 1, Span{ 0, 0 });
+    dev_buf dent, dspan;
     if (ncand) {
         typedef unsigned long long u64;
         size_t tb = 0, tb2 = 0;
@@ -607,11 +656,14 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
         DMG_HIP(hipcub::DeviceRadixSort::SortPairs(tmpst.p, tb, (u64 *)k0.p, (u64 *)k1.p, (u64 *)v0.p, (u64 *)v1.p, nuniq, 0, 64, st));
         DMG_ALLOC(sdist, (size_t)nuniq * 4);
         hipLaunchKernelGGL(k_flow_gather_dist, dim3((nuniq + 255) / 256), dim3(256), 0, st, (const u64 *)v1.p, dst[cur].i(), sdist.i(), nuniq);
+        // the host's view: entries as 16-byte records and every lake's range of them (the sink distances stay on the device)
+        DMG_ALLOC(dent, (size_t)std::max(nuniq, 1) * 16); DMG_ALLOC(dspan, (size_t)(nlakes + 1) * 8);
+        DMG_HIP(hipMemsetAsync(dspan.p, 0, (size_t)(nlakes + 1) * 8, st));
+        hipLaunchKernelGGL(k_flow_entries, dim3((nuniq + 255) / 256), dim3(256), 0, st, (const u64 *)k1.p, (const u64 *)v1.p, (int4 *)dent.p, (int2 *)dspan.p, nuniq);
         DMG_HIP(hipGetLastError());
-        hkey.resize(nuniq); hpay.resize(nuniq); hsdist.resize(nuniq);
-        DMG_HIP(hipMemcpyAsync(hkey.data(), k1.p, (size_t)nuniq * 8, hipMemcpyDeviceToHost, st));
-        DMG_HIP(hipMemcpyAsync(hpay.data(), v1.p, (size_t)nuniq * 8, hipMemcpyDeviceToHost, st));
-        DMG_HIP(hipMemcpyAsync(hsdist.data(), sdist.p, (size_t)nuniq * 4, hipMemcpyDeviceToHost, st));
+        ent.resize(nuniq);
+        DMG_HIP(hipMemcpyAsync(ent.data(), dent.p, (size_t)nuniq * 16, hipMemcpyDeviceToHost, st));
+        DMG_HIP(hipMemcpyAsync(span.data(), dspan.p, (size_t)(nlakes + 1) * 8, hipMemcpyDeviceToHost, st));
     }
     DMG_HIP(hipStreamSynchronize(st));
     std::sort(mouths.begin(), mouths.end());
@@ -619,20 +671,7 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
     if (timing) fprintf(stderr, "[flow] %d lakes, %d pass candidates -> %d lake pairs, %d river mouths\n", nlakes, ncand, nuniq, nmouth);
 
     // solvingConnections (:533-595) on the reduced list, all lakes by dense id: entry i = pass into lake `lake` at
-    // cell s from lake `from`; entries are sorted by (lake, height, from)
-    struct Entry { float h; int from, s, lake, sdist; };
-    std::vector<Entry> ent(nuniq);
-    struct Span { int cur, end; };                                     // per lake: next unread entry, end of its entries
-    std::vector<Span> span(nlakes + 1, Span{ 0, 0 });
-    for (int i = 0; i < nuniq; i++) {
-        unsigned hb = (unsigned)(hkey[i] & 0xFFFFFFFFull);
-        Entry e;
-        memcpy(&e.h, &hb, 4);
-        e.lake = (int)(hkey[i] >> 32); e.from = (int)(hpay[i] >> 32); e.s = (int)(hpay[i] & 0xFFFFFFFFull); e.sdist = hsdist[i];
-        ent[i] = e;
-        span[e.lake].end = i + 1;
-    }
-    for (int i = nuniq - 1; i >= 0; i--) span[ent[i].lake].cur = i;    // first entry of each lake
+    // cell s from lake `from`; entries are sorted by (lake, height, from) -- built on the device (k_flow_entries)
     lap("host: entry table");
     // the heap carries its keys (16 B) instead of indices into `ent`: a sift touches only the heap's own cache lines
     struct Cand { float h; int from, s, idx; };
@@ -674,66 +713,55 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
         push_next(top.from);
     }
     lap("host: prim growth");
-    // resolve the overwrites: per tolocation cell the LAST assigned entry survives (open-addressing table on s)
-    std::vector<int> live;
-    {
-        size_t cap2 = 16;
-        while (cap2 < assigned.size() * 2 + 16) cap2 <<= 1;
-        std::vector<int> slot(cap2, -1);                               // entry index
-        for (int c : assigned) {
-            size_t hsh = ((size_t)(unsigned)ent[c].s * 2654435761u) & (cap2 - 1);
-            while (slot[hsh] >= 0 && ent[slot[hsh]].s != ent[c].s) hsh = (hsh + 1) & (cap2 - 1);
-            slot[hsh] = c;
-        }
-        for (int c : slot) if (c >= 0) live.push_back(c);
-    }
-    lap("host: overwrite resolution");
-
-    // depth offset and water level of every lake that calculateflow's recursion reaches: river mouths at 0, a
-    // connected lake one below the cell it drains into.  The host only lists the surviving connections; the sums and
-    // maxima along the lake tree are taken on the device (k_lake_jump)
-    std::vector<int> conn_idx, conn_val, lpar(nlakes), loff(nlakes, 0);
-    std::vector<float> llvl(nlakes, 0.0f);
-    std::vector<unsigned char> is_mouth(nlakes, 0);
-    conn_idx.reserve(live.size()); conn_val.reserve(live.size());
-    for (int d = 0; d < nlakes; d++) lpar[d] = d;
-    for (int m : mouths) is_mouth[m] = 1;
-    for (int c : live) {
-        const Entry &e = ent[c];
-        conn_idx.push_back(e.s); conn_val.push_back(sink_cell[e.from]);
-        lpar[e.from] = e.lake; loff[e.from] = e.sdist + 1; llvl[e.from] = e.h;
-    }
-    lap("host: lake offsets");
-
-    dev_buf dlo, dcf, gdepth, dstart, order, acc, dci, dcv, dmax, dlevel;
+    // connections[tolocation] = pass (:588): per tolocation cell the LAST assigned entry survives; its lake hangs one below
+    // the cell it drains into (calculateflow's recursion: river mouths at depth 0).  Both on the device: the host only
+    // hands over the order in which the growth made its connections
+    dev_buf dlo, dcf, gdepth, dstart, order, acc, dmax, dlevel, dassigned, dpar0, dof0, dlv0, dmo;
     DMG_ALLOC(dlo, N * 4); DMG_ALLOC(dcf, N * 4); DMG_ALLOC(gdepth, N * 4); DMG_ALLOC(order, N * 4); DMG_ALLOC(acc, N * 4); DMG_ALLOC(dmax, 8);
     DMG_HIP(hipMemsetAsync(dlo.p, 0xFF, N * 4, st));         // -1
     DMG_HIP(hipMemsetAsync(dcf.p, 0xFF, N * 4, st));
     DMG_HIP(hipMemsetAsync(dmax.p, 0, 8, st));
+    if (nlakes) {
+        const unsigned lb0 = (unsigned)((nlakes + 255) / 256);
+        DMG_ALLOC(dpar0, (size_t)nlakes * 4); DMG_ALLOC(dof0, (size_t)nlakes * 4); DMG_ALLOC(dlv0, (size_t)nlakes * 4); DMG_ALLOC(dmo, (size_t)nlakes);
+        hipLaunchKernelGGL(k_flow_lake_init, dim3(lb0), dim3(256), 0, st, dpar0.i(), nlakes);
+        DMG_HIP(hipMemsetAsync(dof0.p, 0, (size_t)nlakes * 4, st));
+        DMG_HIP(hipMemsetAsync(dlv0.p, 0, (size_t)nlakes * 4, st));
+        DMG_HIP(hipMemsetAsync(dmo.p, 0, (size_t)nlakes, st));
+        if (nmouth) hipLaunchKernelGGL(k_flow_mark, dim3((nmouth + 255) / 256), dim3(256), 0, st, mouths_d.i(), (unsigned char *)dmo.p, nmouth);
+        const int na = (int)assigned.size();
+        if (na) {
+            typedef unsigned long long u64;
+            if ((rc = upload_vec(ctx, dassigned, assigned))) return rc;
+            DMG_HIP(hipMemsetAsync(tmp.p, 0xFF, N * 4, st));                  // last position per cell: -1
+            hipLaunchKernelGGL(k_flow_lastpos, dim3((na + 255) / 256), dim3(256), 0, st, dassigned.i(), (const u64 *)v1.p, tmp.i(), na);
+            hipLaunchKernelGGL(k_flow_connect, dim3((na + 255) / 256), dim3(256), 0, st, dassigned.i(), (const u64 *)k1.p, (const u64 *)v1.p, sdist.i(), tmp.i(),
+                               sinkc.i(), dcf.i(), dpar0.i(), dof0.i(), dlv0.f(), na);
+        }
+        DMG_HIP(hipGetLastError());
+    }
+    lap("connections (device)");
+
     const bool draw_lakes = (lakes & DMG_FLOW_LAKES) != 0;
     if (draw_lakes) {
         DMG_ALLOC(dlevel, N * 4);
         DMG_HIP(hipMemsetAsync(dlevel.p, 0xFF, N * 4, st));  // NaN: compares false
     }
     if (nlakes) {
-        dev_buf dp[2], dof[2], dlv[2], dmo;
-        if ((rc = upload_vec(ctx, dp[0], lpar)) || (rc = upload_vec(ctx, dof[0], loff)) || (rc = upload_vec(ctx, dlv[0], llvl)) ||
-            (rc = upload_vec(ctx, dmo, is_mouth))) return rc;
-        DMG_ALLOC(dp[1], (size_t)nlakes * 4); DMG_ALLOC(dof[1], (size_t)nlakes * 4); DMG_ALLOC(dlv[1], (size_t)nlakes * 4);
+        dev_buf dp1, dof1, dlv1;
+        DMG_ALLOC(dp1, (size_t)nlakes * 4); DMG_ALLOC(dof1, (size_t)nlakes * 4); DMG_ALLOC(dlv1, (size_t)nlakes * 4);
+        int *dp[2] = { dpar0.i(), dp1.i() }, *dof[2] = { dof0.i(), dof1.i() };
+        float *dlv[2] = { dlv0.f(), dlv1.f() };
         int rounds = 1;
         while ((1ll << rounds) < nlakes) rounds++;           // paths are at most nlakes long
         int b = 0;
         const unsigned lb = (unsigned)((nlakes + 255) / 256);
         for (int it = 0; it <= rounds; it++, b ^= 1)
-            hipLaunchKernelGGL(k_lake_jump, dim3(lb), dim3(256), 0, st, dp[b].i(), dof[b].i(), dlv[b].f(), dp[b ^ 1].i(), dof[b ^ 1].i(), dlv[b ^ 1].f(), nlakes);
-        hipLaunchKernelGGL(k_lake_scatter, dim3(lb), dim3(256), 0, st, dp[b].i(), dof[b].i(), dlv[b].f(), (const unsigned char *)dmo.p, sinkc.i(),
+            hipLaunchKernelGGL(k_lake_jump, dim3(lb), dim3(256), 0, st, dp[b], dof[b], dlv[b], dp[b ^ 1], dof[b ^ 1], dlv[b ^ 1], nlakes);
+        hipLaunchKernelGGL(k_lake_scatter, dim3(lb), dim3(256), 0, st, dp[b], dof[b], dlv[b], (const unsigned char *)dmo.p, sinkc.i(),
                            dlo.i(), draw_lakes ? dlevel.f() : nullptr, dmax.i() + 1, nlakes);
         DMG_HIP(hipGetLastError());
-        DMG_HIP(hipStreamSynchronize(st));                   // the six tables above are released here
-    }
-    if (!conn_idx.empty()) {
-        if ((rc = upload_vec(ctx, dci, conn_idx)) || (rc = upload_vec(ctx, dcv, conn_val))) return rc;
-        hipLaunchKernelGGL(k_flow_scatter_pairs, dim3(((int)conn_idx.size() + 255) / 256), dim3(256), 0, st, dci.i(), dcv.i(), dcf.i(), (int)conn_idx.size());
+        DMG_HIP(hipStreamSynchronize(st));                   // the tables above are released here
     }
     hipLaunchKernelGGL(k_flow_gdepth, dim3(nb), dim3(256), 0, st, label.i(), dst[cur].i(), dlo.i(), gdepth.i(), dmax.i(), N);
     DMG_HIP(hipGetLastError());
