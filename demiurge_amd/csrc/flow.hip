@@ -23,6 +23,9 @@
 #include <tuple>
 #include <unordered_map>
 #include <chrono>
+#include <sys/mman.h>
+#include <cstdlib>
+#include <new>
 
 // keypad order of FlowFilter::neighbours (:66-73): bits 1,2,3,4,6,7,8,9 <-> (dx,dy)
 __constant__ int c_ndx[8] = { -1, 0, 1, -1, 1, -1, 0, 1 };
@@ -513,6 +516,24 @@ struct PassLess {
 }  // namespace
 
 // Device-resident flow accumulation.  d_h: heights (W*H); d_sel: selection mask or nullptr; d_flow: result.
+// allocator for big host tables that are visited in random order: 2 MB-aligned and advised as huge pages
+template <class T> struct thp_allocator {
+    typedef T value_type;
+    thp_allocator() = default;
+    template <class U> thp_allocator(const thp_allocator<U> &) {}
+    T *allocate(size_t n)
+    {
+        void *p = nullptr;
+        const size_t bytes = std::max<size_t>(n * sizeof(T), 1);
+        if (posix_memalign(&p, (size_t)2 << 20, bytes)) throw std::bad_alloc();
+        (void)madvise(p, bytes, MADV_HUGEPAGE);
+        return (T *)p;
+    }
+    void deallocate(T *p, size_t) { free(p); }
+    template <class U> bool operator==(const thp_allocator<U> &) const { return true; }
+    template <class U> bool operator!=(const thp_allocator<U> &) const { return false; }
+};
+
 int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, const float *d_h, const float *d_sel,
                 float preblur, float exponent, float *d_flow, int lakes)
 {
@@ -631,8 +652,10 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
     int nuniq = 0;
     struct Entry { float h; int from, s, lake; };                     // = the int4 k_flow_entries writes
     struct Span { int cur, end; };                                     // per lake: next unread entry, end of its entries
-    std::vector<Entry> ent;
-    std::vector<Span> span(nlakes + 1, Span{ 0, 0 });
+    // the growth below visits these two tables in random order, a few hundred megabytes of them: transparent huge pages
+    // (where the host allows them) take the TLB miss out of every visit
+    std::vector<Entry, thp_allocator<Entry>> ent;
+    std::vector<Span, thp_allocator<Span>> span(nlakes + 1, Span{ 0, 0 });
     dev_buf dent, dspan;
     if (ncand) {
         typedef unsigned long long u64;
@@ -674,13 +697,60 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
     // cell s from lake `from`; entries are sorted by (lake, height, from) -- built on the device (k_flow_entries)
     lap("host: entry table");
     // the heap carries its keys (16 B) instead of indices into `ent`: a sift touches only the heap's own cache lines
-    struct Cand { float h; int from, s, idx; };
+    struct Cand { float h; int from, s, idx, lake; };                  // (lake: of the entry, so that a pop need not look it up)
     auto worse = [](const Cand &a, const Cand &b) {                    // priority_queue keeps the LOWEST (h, from, s) on top
         return std::tie(a.h, a.from, a.s) > std::tie(b.h, b.from, b.s);
     };
-    std::vector<Cand> heap_store;
-    heap_store.reserve((size_t)nlakes + 16);
-    std::priority_queue<Cand, std::vector<Cand>, decltype(worse)> candidates(worse, std::move(heap_store));
+    // The candidates, lowest (h, from, s) first.  One binary heap over a million 16-byte entries costs a pop ~8 cache
+    // misses on its way down (the growth spent most of its time there); here the candidates are spread over 2^18 buckets by
+    // the top bits of their height (a monotone key: equal heights share a bucket), each bucket a small heap of its own, and a
+    // three-level bitmap finds the lowest bucket in use: a pop stays inside one small, hot bucket.  Same total order, same
+    // sequence of pops as std::set<pass, comp> in solvingConnections.
+    struct cand_queue {
+        enum { BITS = 18 };
+        std::vector<std::vector<Cand>> bucket;
+        std::vector<unsigned long long> l0, l1;
+        unsigned long long l2 = 0;
+        size_t count = 0;
+        decltype(worse) cmp;
+        explicit cand_queue(decltype(worse) c) : bucket((size_t)1 << BITS), l0((size_t)1 << (BITS - 6), 0), l1((size_t)1 << (BITS - 12), 0), cmp(c) {}
+        static unsigned key(float h)
+        {
+            if (h == 0.0f) h = 0.0f;                                   // -0.0 compares equal to +0.0: one bucket
+            unsigned u;
+            memcpy(&u, &h, 4);
+            u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);            // monotone in h
+            return u >> (32 - BITS);
+        }
+        bool empty() const { return count == 0; }
+        void push(const Cand &c)
+        {
+            const unsigned b = key(c.h);
+            std::vector<Cand> &v = bucket[b];
+            v.push_back(c);
+            std::push_heap(v.begin(), v.end(), cmp);
+            l0[b >> 6] |= 1ull << (b & 63); l1[b >> 12] |= 1ull << ((b >> 6) & 63); l2 |= 1ull << (b >> 12);
+            count++;
+        }
+        unsigned lowest() const
+        {
+            const unsigned i2 = (unsigned)__builtin_ctzll(l2);
+            const unsigned i1 = (i2 << 6) | (unsigned)__builtin_ctzll(l1[i2]);
+            return (i1 << 6) | (unsigned)__builtin_ctzll(l0[i1]);
+        }
+        const Cand &top() const { return bucket[lowest()].front(); }
+        void pop()
+        {
+            const unsigned b = lowest();
+            std::vector<Cand> &v = bucket[b];
+            std::pop_heap(v.begin(), v.end(), cmp);
+            v.pop_back();
+            count--;
+            if (v.empty()) {
+                if (!(l0[b >> 6] &= ~(1ull << (b & 63))) && !(l1[b >> 12] &= ~(1ull << ((b >> 6) & 63)))) l2 &= ~(1ull << (b >> 12));
+            }
+        }
+    } candidates(worse);
     std::vector<char> placed(nlakes, 0);
     for (int m : mouths) placed[m] = 1;
     // The growth hops all over the map, so each visit of a lake is a chain of cache misses (its span, its first unread
@@ -694,7 +764,7 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
             if (placed[ent[i].from]) continue;
             // `if (Nthbit(c.from,10)) continue;` (:552): bit 10 of the neighbouring lake's cell index, first stage only
             if (initial && mouth_filter && (sink_cell[ent[i].from] & 512)) continue;
-            candidates.push(Cand{ ent[i].h, ent[i].from, ent[i].s, i });
+            candidates.push(Cand{ ent[i].h, ent[i].from, ent[i].s, i, lake });
             __builtin_prefetch(&span[ent[i].from]);
             break;
         }
@@ -705,11 +775,25 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
         const Cand top = candidates.top();
         candidates.pop();
         const int c = top.idx;
-        if (placed[top.from]) { push_next(ent[c].lake); continue; }
+        // What the next pops will need.  The growth is a chain of dependent cache misses (a lake's entry range, its next
+        // unread entry, the flag of that entry's lake), ~15 M of them; the candidates at the top of the lowest bucket's
+        // heap are (mostly) the next ones to be popped: their ranges are requested two to six pops ahead, and the entries
+        // those ranges point at one to two pops ahead
+        if (!candidates.empty()) {
+            const std::vector<Cand> &v = candidates.bucket[candidates.lowest()];
+            const size_t nv = v.size();
+            for (size_t k = 3; k < std::min<size_t>(nv, 7); k++) {
+                __builtin_prefetch(&span[v[k].lake]); __builtin_prefetch(&span[v[k].from]); __builtin_prefetch(&placed[v[k].from]);
+            }
+            for (size_t k = 0; k < std::min<size_t>(nv, 3); k++) {
+                __builtin_prefetch(&ent[span[v[k].lake].cur]); __builtin_prefetch(&ent[span[v[k].from].cur]);
+            }
+        }
+        if (placed[top.from]) { push_next(top.lake); continue; }
         placed[top.from] = 1;
         __builtin_prefetch(&ent[span[top.from].cur]);
         assigned.push_back(c);                                         // a later pass at the same cell replaces this one (:588)
-        push_next(ent[c].lake);                                        // (independent of the next line: disjoint lakes)
+        push_next(top.lake);                                           // (independent of the next line: disjoint lakes)
         push_next(top.from);
     }
     lap("host: prim growth");
