@@ -525,6 +525,10 @@ template <class T> struct thp_allocator {
     {
         void *p = nullptr;
         const size_t bytes = std::max<size_t>(n * sizeof(T), 1);
+        if (bytes < ((size_t)32 << 20)) {                              // small tables: the heap's recycled pages beat fresh huge ones
+            if (!(p = malloc(bytes))) throw std::bad_alloc();
+            return (T *)p;
+        }
         if (posix_memalign(&p, (size_t)2 << 20, bytes)) throw std::bad_alloc();
         (void)madvise(p, bytes, MADV_HUGEPAGE);
         return (T *)p;
@@ -707,15 +711,16 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
     // three-level bitmap finds the lowest bucket in use: a pop stays inside one small, hot bucket.  Same total order, same
     // sequence of pops as std::set<pass, comp> in solvingConnections.
     struct cand_queue {
-        enum { BITS = 18 };
+        const int BITS;                                                // 18, or 0 = one heap (small graphs: a vector per bucket costs more than it saves)
         std::vector<std::vector<Cand>> bucket;
         std::vector<unsigned long long> l0, l1;
         unsigned long long l2 = 0;
         size_t count = 0;
         decltype(worse) cmp;
-        explicit cand_queue(decltype(worse) c) : bucket((size_t)1 << BITS), l0((size_t)1 << (BITS - 6), 0), l1((size_t)1 << (BITS - 12), 0), cmp(c) {}
-        static unsigned key(float h)
+        cand_queue(decltype(worse) c, int bits) : BITS(bits), bucket((size_t)1 << bits), l0(bits ? (size_t)1 << (bits - 6) : 1, 0), l1(bits ? (size_t)1 << (bits - 12) : 1, 0), cmp(c) {}
+        unsigned key(float h) const
         {
+            if (!BITS) return 0;
             if (h == 0.0f) h = 0.0f;                                   // -0.0 compares equal to +0.0: one bucket
             unsigned u;
             memcpy(&u, &h, 4);
@@ -734,6 +739,7 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
         }
         unsigned lowest() const
         {
+            if (!BITS) return 0;
             const unsigned i2 = (unsigned)__builtin_ctzll(l2);
             const unsigned i1 = (i2 << 6) | (unsigned)__builtin_ctzll(l1[i2]);
             return (i1 << 6) | (unsigned)__builtin_ctzll(l0[i1]);
@@ -750,7 +756,7 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
                 if (!(l0[b >> 6] &= ~(1ull << (b & 63))) && !(l1[b >> 12] &= ~(1ull << ((b >> 6) & 63)))) l2 &= ~(1ull << (b >> 12));
             }
         }
-    } candidates(worse);
+    } candidates(worse, nlakes >= (1 << 20) ? 18 : 0);           // (a vector per bucket: 2^18 of them only where millions of lakes fill them)
     std::vector<char> placed(nlakes, 0);
     for (int m : mouths) placed[m] = 1;
     // The growth hops all over the map, so each visit of a lake is a chain of cache misses (its span, its first unread
@@ -769,6 +775,7 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
             break;
         }
     };
+    const bool far_tables = (size_t)nuniq * sizeof(Entry) > ((size_t)32 << 20);
     std::vector<int> assigned;                                         // connection events in order: connections[s] = entry
     for (int lake : mouths) push_next(lake, true);
     while (!candidates.empty()) {
@@ -779,7 +786,7 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
         // unread entry, the flag of that entry's lake), ~15 M of them; the candidates at the top of the lowest bucket's
         // heap are (mostly) the next ones to be popped: their ranges are requested two to six pops ahead, and the entries
         // those ranges point at one to two pops ahead
-        if (!candidates.empty()) {
+        if (far_tables && !candidates.empty()) {                        // (tables that fit the caches need no help: the look-ahead costs ~30 ns a pop)
             const std::vector<Cand> &v = candidates.bucket[candidates.lowest()];
             const size_t nv = v.size();
             for (size_t k = 3; k < std::min<size_t>(nv, 7); k++) {
