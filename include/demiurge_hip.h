@@ -150,8 +150,9 @@ int dmg_ocean_set_pressure(dmg_ocean *o, const float *pressure);
  * last bit may differ, and an infinite iterate becomes NaN one sweep earlier than with a true division.
  * Zeros: land holds +0.0 and the streaming kernel evaluates "a land neighbour reads the centre value" (:470-473) as
  * (pW + pE) + n * pC with n land neighbours among the two.  That is the shader's sum bit for bit, except that a pair of
- * open neighbours that both hold -0.0 next to a coast cell sums to +0.0 instead of -0.0 -- a value no solve produces
- * from the +0.0 start inside the window above (a starting pressure given through dmg_ocean_set_pressure may hold it). */
+ * open neighbours that both hold -0.0, in a 256-column strip within ten rows of a coast, sums to +0.0 instead of -0.0 --
+ * a value no solve produces from the +0.0 start inside the window above (a starting pressure given through
+ * dmg_ocean_set_pressure may hold it). */
 int dmg_ocean_jacobi(dmg_ocean *o, int iters, int zero_first);
 /* Band form: `n` (<= ghost) sweeps assuming the pressure ghost rows are current; afterwards the owned
  * rows are n sweeps ahead and the ghost rows are stale until the host refreshes them via dmg_ocean_halo. */
