@@ -349,3 +349,16 @@ def test_streaming_forms_forced_are_bitwise(form, canvas):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     kern = {"stream": "k_jacobi_stream ", "stream-n": "k_jacobi_stream_n", "stream-p": "k_jacobi_stream_p"}[form]
     assert kern.strip() in r.stdout and "bit-identical" in r.stdout, r.stdout[-2000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows", ["24", "100", "232"])
+def test_streaming_unit_heights_are_bitwise(rows):
+    """The unit form with its shortest, a middling and its tallest units (232 rows: the window rows' classes fill all four
+    bytes of the class register, the coefficient table all of its LDS), against single-sweep launches, bit for bit."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DMG_TB_SHAPE="stream", DMG_ST_ROWS=rows)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "stream_check.py"), "2048", "1024", "40", "survey", "globe"], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "bit-identical" in r.stdout and "k_jacobi_stream" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -1,0 +1,22 @@
+"""The 16384x8192 solve split into n latitude bands that all live on GPU 0 (dmg_multi, peer copies): what banding itself
+costs -- ghost-row redundancy, small launches, the exchange's synchronisation -- before any xGMI traffic.
+usage: python tools/bands_one_gpu.py [sweeps]"""
+import sys, time
+import numpy as np
+sys.path.insert(0, ".")
+from demiurge_amd import capi, synth
+
+W, H = 16384, 8192
+sweeps = int(sys.argv[1]) if len(sys.argv) > 1 else 1600
+grid = capi.make_grid(W, H)
+terrain, divw = synth.terrain(W, H), synth.divw(W, H)
+for n, ghost, order in ((1, 32, 0), (2, 32, 0), (2, 64, 0), (4, 32, 0), (4, 64, 0), (8, 32, 0), (8, 64, 0), (8, 128, 0), (8, 64, 1)):
+    flags = capi.MULTI_PEER | (capi.MULTI_OVERLAP_LAST_LAUNCH if order else capi.MULTI_EXCHANGE_THEN_SWEEP)
+    m = capi.Multi(grid, devices=[0] * n, ghost=ghost, params=capi.default_ocean_params(), flags=flags)
+    m.set_terrain(terrain); m.set_divw(divw)
+    m.jacobi(sweeps, zero_first=True); m.sync()
+    t0 = time.perf_counter()
+    m.jacobi(sweeps, zero_first=True); m.sync()
+    dt = time.perf_counter() - t0
+    print("bands %d ghost %3d order %s: %.1f ms  %.0f Mcell-steps/s" % (n, ghost, "overlap" if order else "exchange-then-sweep", dt * 1e3, W * H * sweeps / dt / 1e6), flush=True)
+    m.close()
