@@ -8,22 +8,30 @@
 // CU's other workgroup happens to be sweeping.  Here ONE wave streams a 256-column strip northwards, row by row, and
 // carries all 8 sweeps along as a software pipeline ("time skewing"):
 //
-//     step t:  row e_t = r0 - 8 + t arrives from HBM (level 0)
-//              level s (1..8) computes sweep s of row e_t - s from the three level s-1 rows e_t-s-1, e_t-s, e_t-s+1,
-//              the last of which level s-1 has produced in this very step
-//              level 8's row e_t - 8 is final and is stored
+//     step t:  rows e = r0 - 8 + 2t and e + 1 arrive from HBM (level 0; requested two steps earlier)
+//              level s (1..8) computes sweep s of rows e - s and e - s + 1 from the four level s-1 rows around them: the
+//              pair level s-1 made one step ago and the pair it has made in this very step
+//              level 8's rows e - 8, e - 7 are final and are stored
 //
-// A wave keeps, per level, the two previous rows in registers (a ring of three slots, the loop is unrolled by three so
-// that every slot is a fixed register), the right-hand side and the land codes of the 9 rows in flight in a private
-// LDS ring, and the per-row coefficients in SGPRs.  East/west neighbours are adjacent lanes (DPP), north/south are the
-// wave's own registers: no LDS exchange, no barrier, every wave has the same work, loads and stores trickle along with
-// the arithmetic.  A work unit is a strip segment of up to 112 rows: rows [r0-8, r1+8) are read, and level s is only
-// run where its rows are still needed ([r0-8+s, r1+8-s)), so the recomputation is 7/n of the work (n = rows per unit)
-// instead of 16/64.  Units whose rows are land everywhere are not dispatched; land rows inside a unit cost nothing.
+// A wave keeps, per level, the previous pair of rows in registers (two pairs per level, the loop body is two steps so
+// that every slot is a fixed register: 8 levels x 4 rows x 4 floats = 128 VGPRs), the right-hand side and the coast
+// rows' land-neighbour counts of the 12 rows in flight in a private LDS ring, and the per-row coefficients of its whole
+// window in an LDS table.  East/west neighbours are adjacent lanes (DPP), north/south are the wave's own registers: no
+// LDS exchange, no barrier, every wave has the same work, loads and stores trickle along with the arithmetic.  A work
+// unit is a strip segment of up to 232 rows: rows [r0-8, r1+8) are read, and level s is only run where its rows are
+// still needed ([r0-8+s, r1+8-s)), so the recomputation is 7/n of the work (n = rows per unit) instead of 16/64.  Units
+// whose rows are land everywhere are not dispatched; land rows inside a unit cost next to nothing.
+//
+// What a level visit costs (DESIGN.md 4.1b has the measurements): 50 packed instructions are the formula itself for
+// two rows of 256 cells; everything else was taken out piece by piece -- rows are held as cell pairs (c0,c3),(c1,c2) so
+// that pW + pE needs no register shuffling; coast rows go through counts of land neighbours (one packed fma per pair
+// instead of eight selects); steps without land or coast, and steps with coast but no all-land row, run their eight
+// levels without a test or a branch; one ring read per row and level.  Three forms share the code: units (the default),
+// narrow units (2 cells per lane, five waves per SIMD) and persistent waves with work stealing.
 //
 // Canvas topology exactly as in ocean_jacobi_tb.hip: columns wrap, rows beyond a pole are the same rows mirrored and
 // shifted by W/2 (offset(), src/Shader.h:86-95), rows beyond a non-pole edge are plain mirrors with the clamp bit
-// cleared.  Arithmetic: jacobi_value() of ocean_internal.h, the same instruction sequence as every other Jacobi kernel.
+// cleared.  Arithmetic: jacobi_value() of ocean_internal.h, the same operations in the same order as every other Jacobi kernel.
 #include "ocean_internal.h"
 #include "ocean_tb.h"
 #include <algorithm>
