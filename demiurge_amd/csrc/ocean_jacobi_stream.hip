@@ -158,13 +158,17 @@ struct st_state {
 #define STP_KT 128                // persistent form: the coefficient table is a ring over the window rows
 template <bool P> __device__ __forceinline__ int st_kt(int window_row) { return P ? (window_row & (STP_KT - 1)) : window_row; }
 
+// LDS coefficient entries: {cx, 1/cx, 1/Beta, Beta} -- with 1/Beta in the low half of its register pair the packed multiply
+// takes it as it is (from the high half the compiler first copies it into a pair of its own: two moves per level visit)
+__device__ __forceinline__ v4f st_kswap(const v4f k) { return v4f{ k.x, k.y, k.w, k.z }; }
+
 __device__ __forceinline__ int st_wrap(int slot) { return slot < 0 ? slot + ST_RING : slot; }
 
 // one row of one level, generic: open ocean or coast (wave-uniform choice); N, C, S = the level below's rows y+1, y, y-1
 __device__ __forceinline__ v4f st_row_any(const v4f N, const v4f C, const v4f S, const v4f bb, const v4f kk, float cy, float ry, bool mixed,
                                           const unsigned *crow, int lane)
 {
-    const jacobi_row k = { kk.x, cy, kk.z, kk.y, ry, kk.w };
+    const jacobi_row k = { kk.x, cy, kk.w, kk.y, ry, kk.z };
     const st_we we = st_we_sums(C);
     v2f o0, o1;
     if (!mixed) {
@@ -235,7 +239,7 @@ __device__ __forceinline__ void st_level(const st_args &a, st_state &z, v4f (*br
         oB = st_row_any(N1, N0, C0, bB, kB, z.cy, z.ry, true, cring[sb], lane);
     } else if (MODE == 1 || !(((z.landbits | z.mixbits) >> S) & 3u)) {   // (one two-bit field of the step's combined mask: the common case costs one scalar test)
         // both rows open ocean (wave-uniform): one block of 8 independent division chains
-        const jacobi_row ka = { kA.x, z.cy, kA.z, kA.y, z.ry, kA.w }, kb = { kB.x, z.cy, kB.z, kB.y, z.ry, kB.w };
+        const jacobi_row ka = { kA.x, z.cy, kA.w, kA.y, z.ry, kA.z }, kb = { kB.x, z.cy, kB.w, kB.y, z.ry, kB.z };
         const st_we weA = st_we_sums(C0), weB = st_we_sums(N0);
         const v2f a0 = st_value2s(weA.outer, S0.xy + N0.xy, bA.xy, ka), a1 = st_value2s(weA.inner, S0.zw + N0.zw, bA.zw, ka);
         const v2f b0 = st_value2s(weB.outer, C0.xy + N1.xy, bB.xy, kb), b1 = st_value2s(weB.inner, C0.zw + N1.zw, bB.zw, kb);
@@ -467,7 +471,7 @@ __global__ __launch_bounds__(64, 2) void k_jacobi_stream(st_args a)
         const int n = 2 * nsteps + 2;
         v4f kt[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) kt[q] = *reinterpret_cast<const v4f *>(a.jcoef + (size_t)st_map_row(a, e0 + min(lane + 64 * q, n - 1)).l * 8);
+        for (int q = 0; q < 4; q++) kt[q] = st_kswap(*reinterpret_cast<const v4f *>(a.jcoef + (size_t)st_map_row(a, e0 + min(lane + 64 * q, n - 1)).l * 8));
 #pragma unroll
         for (int q = 0; q < 4; q++) if (lane + 64 * q < n) ktab[lane + 64 * q] = kt[q];
         const st_kptr cf = (st_kptr)(unsigned long long)a.jcoef;
@@ -631,7 +635,7 @@ __global__ __launch_bounds__(64, 2) void k_jacobi_stream_p(st_args a)
             z.cy = cf[4]; z.ry = cf[5];
         }
         // window rows [0, 16): the first chapter's refill brings [16, 80)
-        if (lane < 16) ktab[lane] = *reinterpret_cast<const v4f *>(a.jcoef + (size_t)st_map_row(a, e0 + lane).l * 8);
+        if (lane < 16) ktab[lane] = st_kswap(*reinterpret_cast<const v4f *>(a.jcoef + (size_t)st_map_row(a, e0 + lane).l * 8));
         st_fetch<true>(a, z, 0, 0, e0, col, colp, tx);
         st_fetch<true>(a, z, 0, 1, e0 + 1, col, colp, tx);
         st_fetch<true>(a, z, 1, 0, e0 + 2, col, colp, tx);
@@ -641,7 +645,7 @@ __global__ __launch_bounds__(64, 2) void k_jacobi_stream_p(st_args a)
             // a chapter of 64 window rows.  The levels read the coefficients of window rows [2t - 10, 2t + 67) in it: the
             // entries [2t + 16, 2t + 80) replace rows that left the window long ago
             if (!ST_DBG(a, 128) || t == 0)
-                ktab[(2 * t + 16 + lane) & (STP_KT - 1)] = *reinterpret_cast<const v4f *>(a.jcoef + (size_t)st_map_row(a, e0 + 2 * t + 16 + lane).l * 8);
+                ktab[(2 * t + 16 + lane) & (STP_KT - 1)] = st_kswap(*reinterpret_cast<const v4f *>(a.jcoef + (size_t)st_map_row(a, e0 + 2 * t + 16 + lane).l * 8));
             const int t_chapter = t + 32;
             int nsteps;
             do {
