@@ -1002,18 +1002,73 @@ static void st_cut_cost(const dmg_ocean *o, int lo, int hi, float target, std::v
 }
 
 // makespan of the units on `slots` waves that each take the next unit when they are done (how the dispatcher hands
-// workgroups to free slots), units in descending cost order
-static float st_makespan(std::vector<st_unit> &units, int slots)
+// workgroups to free slots), units in descending cost order.
+//
+// Wide form (two waves per SIMD): the two waves of a SIMD do not share it evenly.  Per-unit timings with the hardware ids
+// (DMG_ST_PROF) show the dispatcher filling wave slot 0 of every SIMD with the launch's first 4 x CUs workgroups and slot 1
+// with the next, and the SIMD's arbiter serving the older wave first: of two equal units started together the first takes
+// 195 us and the second 248 us.  The model: the older (or only) wave of a SIMD advances at 1.25, the younger at 0.75 of the
+// even share; when a wave ends, the other one is the older from then on and the next unit of the list starts as the
+// younger.  Against a measured 455 / 361 us (no land / survey terrain) it predicts 435 / 357 us, where one speed for all
+// slots was 10 % optimistic about the tail and preferred cuts accordingly.
+static float st_makespan(std::vector<st_unit> &units, int slots, bool paired = false)
 {
     std::sort(units.begin(), units.end(), [](const st_unit &a, const st_unit &b) { return a.cost > b.cost; });
-    std::vector<float> heap((size_t)slots, 0.0f);          // min-heap of slot finish times
-    auto cmp = [](float a, float b) { return a > b; };
+    if (!paired || slots < 2) {
+        std::vector<float> heap((size_t)slots, 0.0f);      // min-heap of slot finish times
+        auto cmp = [](float a, float b) { return a > b; };
+        float span = 0.0f;
+        for (const st_unit &u : units) {
+            std::pop_heap(heap.begin(), heap.end(), cmp);
+            heap.back() += u.cost;
+            span = std::max(span, heap.back());
+            std::push_heap(heap.begin(), heap.end(), cmp);
+        }
+        return span;
+    }
+    static const float r_old_env = [] { const char *e = getenv("DMG_ST_ROLD"); return e ? (float)atof(e) : 1.25f; }();     // experiments (1.15 .. 1.35 choose the same or equally fast cuts)
+    const float r_old = r_old_env, r_young = 2.0f - r_old_env;
+    const int nsimd = slots / 2, n = (int)units.size();
+    struct simd { double rem[2]; double t; signed char busy[2]; signed char older; };
+    std::vector<simd> sm((size_t)nsimd, simd{ { 0.0, 0.0 }, 0.0, { 0, 0 }, 0 });
+    typedef std::pair<double, int> ev;                      // (time of the SIMD's next completion, SIMD)
+    std::vector<ev> heap;
+    heap.reserve((size_t)nsimd + 16);
+    auto later = [](const ev &a, const ev &b) { return a.first > b.first; };
+    auto schedule = [&](int s) {
+        simd &m = sm[s];
+        double dt;
+        if (m.busy[0] && m.busy[1]) dt = std::min(m.rem[m.older] / r_old, m.rem[1 - m.older] / r_young);
+        else if (m.busy[0] || m.busy[1]) dt = m.rem[m.busy[0] ? 0 : 1] / r_old;
+        else return;
+        heap.push_back(ev(m.t + dt, s));
+        std::push_heap(heap.begin(), heap.end(), later);
+    };
+    int next = 0;
+    for (int k = 0; k < 2; k++)
+        for (int s = 0; s < nsimd && next < n; s++) { sm[s].rem[k] = units[next++].cost; sm[s].busy[k] = 1; }
+    for (int s = 0; s < nsimd; s++) schedule(s);
     float span = 0.0f;
-    for (const st_unit &u : units) {
-        std::pop_heap(heap.begin(), heap.end(), cmp);
-        heap.back() += u.cost;
-        span = std::max(span, heap.back());
-        std::push_heap(heap.begin(), heap.end(), cmp);
+    while (!heap.empty()) {
+        std::pop_heap(heap.begin(), heap.end(), later);
+        const ev e = heap.back();
+        heap.pop_back();
+        simd &m = sm[e.second];
+        const double dt = e.first - m.t;
+        if (m.busy[0] && m.busy[1]) { m.rem[m.older] -= dt * r_old; m.rem[1 - m.older] -= dt * r_young; }
+        else if (m.busy[0] || m.busy[1]) m.rem[m.busy[0] ? 0 : 1] -= dt * r_old;
+        m.t = e.first;
+        for (int k = 0; k < 2; k++)
+            if (m.busy[k] && m.rem[k] <= 1e-6) {
+                m.busy[k] = 0;
+                span = std::max(span, (float)m.t);
+                if (m.busy[1 - k]) m.older = (signed char)(1 - k);
+                if (next < n) {
+                    m.rem[k] = units[next++].cost; m.busy[k] = 1;
+                    if (!m.busy[1 - k]) m.older = (signed char)k;
+                }
+            }
+        schedule(e.second);
     }
     return span;
 }
@@ -1057,7 +1112,7 @@ static const dmg_ocean::tile_list *st_units(dmg_ocean *o, int variant, int lo, i
         static const float alpha_env = [] { const char *e = getenv("DMG_ST_ALPHA"); return e ? (float)atof(e) : -1.0f; }();
         const float alpha = alpha_env >= 0.0f ? alpha_env : (seg == -2 ? 0.5f : 1.0f);                  // seg -2: the second automatic cut
         auto judge = [&](std::vector<st_unit> &u) {
-            const float span = st_makespan(u, slots);
+            const float span = st_makespan(u, slots, variant == 0);
             double total = 0;
             for (const st_unit &x : u) total += x.cost;
             return alpha * span + (1.0f - alpha) * (float)(total / slots);
