@@ -431,7 +431,11 @@ __global__ __launch_bounds__(64, 2) void k_jacobi_stream(st_args a)
     const int4 u = a.units[blockIdx.x];
     const int tx = __builtin_amdgcn_readfirstlane(u.x), r0 = __builtin_amdgcn_readfirstlane(u.y), r1 = __builtin_amdgcn_readfirstlane(u.z);
     const int W = a.W;
-    if (a.prof && lane == 0) a.prof[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+    if (a.prof && lane == 0) {
+        a.prof[3 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+        // where the unit ran: HW_ID (wave slot, SIMD, CU, SH, SE) and XCC_ID
+        a.prof[3 * blockIdx.x + 2] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) | (unsigned)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+    }
     // two window rows per step, and an even number of steps: the loop body is two steps with no branch in between, so that
     // every wait for a staged load is a counted vmcnt (a conditional second step makes the compiler wait for vmcnt(0))
     const int nsteps = (((r1 - r0) + 2 * TB_T + 3) / 4) * 2;
@@ -481,7 +485,7 @@ __global__ __launch_bounds__(64, 2) void k_jacobi_stream(st_args a)
         st_step<0>(a, z, bring, cring, ktab, lane, t, e0, nsteps, r1, cls_lo, cls_hi, col, colp, lane_ok, xcol);
         st_step<1>(a, z, bring, cring, ktab, lane, t + 1, e0, nsteps, r1, cls_lo, cls_hi, col, colp, lane_ok, xcol);
     }
-    if (a.prof && lane == 0) a.prof[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+    if (a.prof && lane == 0) a.prof[3 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
 }
 
 // =================================================================================================================
@@ -1200,7 +1204,7 @@ int ocean_launch_stream(dmg_ocean *o, int lo, int hi, int part, int zone_lo, int
     static const char *prof_path = getenv("DMG_ST_PROF");  // experiments: the first full-size launch writes one line per unit to this file
     static bool prof_done = false;
     const bool prof_now = prof_path && !prof_done && !variant && tl->n > 1024;
-    if (prof_now && hipMalloc((void **)&a.prof, (size_t)tl->n * 16) != hipSuccess) a.prof = nullptr;
+    if (prof_now && hipMalloc((void **)&a.prof, (size_t)tl->n * 24) != hipSuccess) a.prof = nullptr;
     static const int extra_lds = [] { const char *e = getenv("DMG_ST_EXTRA_LDS"); return e ? atoi(e) : 0; }();   // experiments: caps the waves per CU
     if (variant == 2) {
         const int total = tl->cap + tl->waves;
@@ -1229,19 +1233,20 @@ int ocean_launch_stream(dmg_ocean *o, int lo, int hi, int part, int zone_lo, int
     DMG_HIP(hipGetLastError());
     if (prof_now && a.prof) {
         prof_done = true;
-        std::vector<unsigned long long> tt((size_t)tl->n * 2);
+        std::vector<unsigned long long> tt((size_t)tl->n * 3);
         std::vector<int> uu((size_t)tl->n * 4);
         DMG_HIP(hipStreamSynchronize(st));
         DMG_HIP(hipMemcpy(tt.data(), a.prof, tt.size() * 8, hipMemcpyDeviceToHost));
         DMG_HIP(hipMemcpy(uu.data(), tl->d, uu.size() * 4, hipMemcpyDeviceToHost));
         (void)hipFree(a.prof);
         if (FILE *f = fopen(prof_path, "w")) {
-            fprintf(f, "tx,r0,r1,open,mixed,land,t0,t1\n");
+            fprintf(f, "tx,r0,r1,open,mixed,land,t0,t1,hwid,xcc\n");
             for (int i = 0; i < tl->n; i++) {
                 int cnt[3] = { 0, 0, 0 };
                 const unsigned char *cls = o->rowclass_host.empty() ? nullptr : o->rowclass_host.data() + (size_t)uu[4 * i] * o->L;
                 for (int r = uu[4 * i + 1] - TB_T; r < uu[4 * i + 2] + TB_T; r++) cnt[(cls && r >= 0 && r < o->L) ? cls[r] : 2]++;
-                fprintf(f, "%d,%d,%d,%d,%d,%d,%llu,%llu\n", uu[4 * i], uu[4 * i + 1], uu[4 * i + 2], cnt[0], cnt[2], cnt[1], tt[2 * i], tt[2 * i + 1]);
+                fprintf(f, "%d,%d,%d,%d,%d,%d,%llu,%llu,%llu,%llu\n", uu[4 * i], uu[4 * i + 1], uu[4 * i + 2], cnt[0], cnt[2], cnt[1], tt[3 * i], tt[3 * i + 1],
+                        tt[3 * i + 2] & 0xFFFFFFFFull, tt[3 * i + 2] >> 32);
             }
             fclose(f);
         }
