@@ -172,6 +172,7 @@ def lib():
         "dmg_ocean_speed_shade": (c_int, [vp, c_float, vp]),
         "dmg_noise_params_default": (None, [ctypes.POINTER(NoiseParams)]),
         "dmg_noise_seed_offset": (c_int, [c_int, ctypes.POINTER(c_float)]),
+        "dmg_div2_split": (c_int, [vp, c_float, ctypes.POINTER(c_float), ctypes.POINTER(c_float)]),
         "dmg_gradient_noise": (c_int, [vp, PG, vp, vp, ctypes.POINTER(NoiseParams)]),
         "dmg_ocean_generate_terrain": (c_int, [vp, ctypes.POINTER(NoiseParams)]),
         "dmg_tectonics_create": (c_int, [vp, PG, vp, ctypes.POINTER(vp)]),
@@ -281,6 +282,12 @@ class Context:
 
     def sync(self):
         check(lib().dmg_sync(self.h))
+
+    def div2_split(self, c):
+        """(h, l) with x / c == fma(x, h, x * l): the streaming Jacobi kernel's two-operation divisor of the row constant c"""
+        h, l = ctypes.c_float(), ctypes.c_float()
+        check(lib().dmg_div2_split(self.h, ctypes.c_float(float(c)), ctypes.byref(h), ctypes.byref(l)))
+        return np.float32(h.value), np.float32(l.value)
 
     def name(self):
         b = ctypes.create_string_buffer(160)

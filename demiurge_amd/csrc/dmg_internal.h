@@ -28,6 +28,10 @@ __device__ __forceinline__ bool dmg_div_rc_exact_for(float x)
     return x == 0.0f || (a >= 0x1p-100f && a <= 0x1p100f);
 }
 
+// div2.hip: exact two-operation divisors, x / c[i] == fma(x, h[i], x * l[i]); ok[i] = 0 where no such pair exists
+struct dmg_ctx;
+int dmg_div2_splits(dmg_ctx *ctx, const float *c, int n, float *h, float *l, unsigned char *ok);
+
 struct dmg_ctx {
     // scratch blocks handed back by finished calls, by size.  The filters that loop (erosion: ~45 temporaries per
     // flow solve, 1000 solves) would otherwise pay hipMalloc + a device-synchronising hipFree for each of them every

@@ -272,6 +272,8 @@ int dmg_ocean_create(dmg_ctx *ctx, const dmg_grid *grid, const dmg_ocean_params 
     alloc((void **)&o->rowtab, sizeof(float) * ROWTAB_FIELDS * o->L);
     alloc((void **)&o->jcoef, sizeof(float) * 8 * o->L);
     alloc((void **)&o->jcoefp, sizeof(float) * 4 * (o->L + 32));
+    alloc((void **)&o->jcoef2, sizeof(float) * 8 * o->L);
+    alloc((void **)&o->rowbad, (size_t)o->L);
     alloc((void **)&o->oob_flag, sizeof(int));
     if (e != hipSuccess) {
         dmg_ocean_destroy(o);
@@ -297,7 +299,7 @@ void dmg_ocean_destroy(dmg_ocean *o)
     (void)hipSetDevice(o->ctx->device);
     (void)hipStreamSynchronize(o->ctx->stream);
     for (void *p : { (void *)o->p[0], (void *)o->p[1], (void *)o->divw, (void *)o->img, (void *)o->code, (void *)o->code8,
-                     (void *)o->v[0], (void *)o->v[1], (void *)o->rowtab, (void *)o->jcoef, (void *)o->jcoefp, (void *)o->oob_flag, (void *)o->rowclass, (void *)o->rowclass_n, (void *)o->rowclass32 })
+                     (void *)o->v[0], (void *)o->v[1], (void *)o->rowtab, (void *)o->jcoef, (void *)o->jcoefp, (void *)o->jcoef2, (void *)o->rowbad, (void *)o->oob_flag, (void *)o->rowclass, (void *)o->rowclass_n, (void *)o->rowclass32 })
         if (p) (void)hipFree(p);
     ocean_tb_free_lists(o);
     dmg_ctx *ctx = o->ctx;

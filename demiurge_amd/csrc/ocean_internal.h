@@ -49,6 +49,7 @@ struct dmg_ocean {
         unsigned *seg_cur0 = nullptr, *seg_cur = nullptr;
         int *seg_ctl = nullptr;
         int cap = 0, waves = 0;
+        int cut_seg = 0, cut_seg2 = 0, cut_split = 0;   // streaming kernel: the cut of a launch's rows into units (the halves of a split launch share the whole launch's)
     };
     // (out_lo, out_hi, rows per wave, part, zone_lo, zone_hi) of a launch -> tiles that are not land everywhere; part 0 = all
     // tile rows, 1 = tile rows touching the send zones [out_lo, zone_lo) / [zone_hi, out_hi), 2 = the tile rows in between
@@ -69,6 +70,10 @@ struct dmg_ocean {
     float *rowtab = nullptr;       // ROWTAB_FIELDS arrays of L floats
     float *jcoefp = nullptr;       // [L + 32][4] = cx, 1/cx, Beta, 1/Beta of local rows -16 .. L+15, rows beyond the grid mirrored (scalar loads, no mapping)
     float *jcoef = nullptr;        // [L][8] = cx, 1/cx, Beta, 1/Beta, cy, 1/cy, -, -: a row's Jacobi coefficients in one 16-byte load (ocean_jacobi_stream.hip)
+    float *jcoef2 = nullptr;       // [L][8] = the same rows as exact two-operation divisors: (h, l) of cx, of Beta, of cy with x / c == fma(x, h, x * l) (div2.hip)
+    unsigned char *rowbad = nullptr; // [L] 1 = no exact pair for the row's cx or Beta: jcoef2 holds (c, 1/c) there and the kernel takes the three-operation form for that row
+    bool div2_ok = false;          // cy has an exact pair (the rows' own divisors are handled row by row)
+    int div2_nbad = 0;             // rows flagged in rowbad
     const float *jac_cx = nullptr, *jac_cy = nullptr, *jac_beta = nullptr;
     const float *jac_rx = nullptr, *jac_ry = nullptr, *jac_rb = nullptr;
     bool have_terrain = false;

@@ -59,6 +59,7 @@ struct st_args {
     int spole, npole;
     const unsigned char *rowclass;  // [tiles_x][L]: 0 open ocean, 1 land everywhere, 2 mixed; or null
     const int4 *units;              // {tile column, first output row, end output row, -}
+    const unsigned char *rowbad;    // DV = 1: [L] 1 = the row's divisors have no exact two-operation pair (its table entry holds (c, r)); or null
     const float *jcoef_cy;          // {cy, 1/cy}: the same for every row
     // persistent form (k_jacobi_stream_p): segment table and queue, see there
     unsigned long long *seg_word;   // [cap + waves]: stp_word(strip, first row, end row); the end row only ever moves down (compare-and-swap by a thief)
@@ -92,8 +93,20 @@ __device__ __forceinline__ st_row st_map_row(const st_args &a, int local_unclamp
 // pair -- v_pk_mul_f32 + 2 v_pk_fma_f32 with the row constants as SGPR operands.  Written on explicit 2-vectors so that
 // the pairing is (cell, cell+1): the N/S operands are then already register pairs and the E/W pairs cost 2 DPP + 4 moves
 // per 4 cells; four independent chains per lane-row interleave without wait states.
+//
+// DV = 1: the division in two operations.  For a constant c with 1/c = h + l (h = RN(1/c), l = RN(1/c - h)) Brisebarre and
+// Muller's u = RN(x * l); q = RN(x * h + u) is the correctly rounded x * (1/c) = RN(x / c) for every x -- for most constants;
+// which ones is decided per constant.  div2.hip decides it by trying all 2^23 significands of x on the device when an ocean's
+// row tables are built (and tries the neighbouring splits for the ~1 % of constants whose standard split fails for a single
+// significand): every row constant of every BASELINE grid has such a pair, so a cell costs 10 packed operations instead of
+// 13.  The pair sits where (c, r) sit in the Markstein form: c = h, r = l.  About one constant in a thousand has no exact
+// pair at all (two significands that pull l in opposite directions): the table keeps (c, r) for such a row, its class byte
+// carries a flag (bit 2), and the steps that have it among their ten rows in flight take the tested path, where that row
+// goes through the Markstein form (DV = 2: pixelwidth2.y, the same for every row, still as a pair).
+template <int DV = 0>
 __device__ __forceinline__ v2f st_div2(v2f x, float c, float r)
 {
+    if (DV == 1) return __builtin_elementwise_fma(x, (v2f)c, x * r);
     const v2f q = x * r;
     const v2f e = __builtin_elementwise_fma((v2f)(-c), q, x);
     return __builtin_elementwise_fma(e, (v2f)r, q);
@@ -105,10 +118,11 @@ __device__ __forceinline__ v2f st_value2(v2f pN, v2f pS, v2f pE, v2f pW, v2f b, 
     return st_div2(t - b, k.beta, k.rb);
 }
 // the same from the two neighbour sums
+template <int DV = 0>
 __device__ __forceinline__ v2f st_value2s(v2f we, v2f sn, v2f b, const jacobi_row &k)
 {
-    const v2f t = st_div2(we, k.cx, k.rx) + st_div2(sn, k.cy, k.ry);
-    return st_div2(t - b, k.beta, k.rb);
+    const v2f t = st_div2<DV>(we, k.cx, k.rx) + st_div2<(DV != 0)>(sn, k.cy, k.ry);
+    return st_div2<DV>(t - b, k.beta, k.rb);
 }
 // Register layout of a row in the wide kernels: a lane's four cells c0..c3 sit in its two register pairs as (c0, c3) and
 // (c1, c2).  With the natural pairing (c0, c1), (c2, c3) the east/west operands of a pair straddle two pairs and cost
@@ -152,6 +166,7 @@ struct st_state {
     unsigned cs[2][2];
     unsigned ks[2][2];              // persistent form: the row's class travels with its loads
     unsigned landbits, mixbits;     // bit j: row (newest - j) is land everywhere / has coast; newest = second row of this step's pair
+    unsigned badbits;               // DV = 1: ... its divisors have no exact two-operation pair (the table holds (c, r) for it)
     int slot;                       // ring slot of the first row of this step's pair (row offset mod ST_RING)
     float cy, ry;                   // the same for every row (pixelsize().y, src/Shader.h:71-74): two SGPRs
 };
@@ -165,6 +180,7 @@ __device__ __forceinline__ v4f st_kswap(const v4f k) { return v4f{ k.x, k.y, k.w
 __device__ __forceinline__ int st_wrap(int slot) { return slot < 0 ? slot + ST_RING : slot; }
 
 // one row of one level, generic: open ocean or coast (wave-uniform choice); N, C, S = the level below's rows y+1, y, y-1
+template <int DV = 0>
 __device__ __forceinline__ v4f st_row_any(const v4f N, const v4f C, const v4f S, const v4f bb, const v4f kk, float cy, float ry, bool mixed,
                                           const unsigned *crow, int lane)
 {
@@ -172,8 +188,8 @@ __device__ __forceinline__ v4f st_row_any(const v4f N, const v4f C, const v4f S,
     const st_we we = st_we_sums(C);
     v2f o0, o1;
     if (!mixed) {
-        o0 = st_value2s(we.outer, S.xy + N.xy, bb.xy, k);
-        o1 = st_value2s(we.inner, S.zw + N.zw, bb.zw, k);
+        o0 = st_value2s<DV>(we.outer, S.xy + N.xy, bb.xy, k);
+        o1 = st_value2s<DV>(we.inner, S.zw + N.zw, bb.zw, k);
     } else {
         // coast row.  Land holds exactly +0.0 at every level, so "a land neighbour reads the centre value"
         // (OceanCurrents.cpp:470-473) is pW' + pE' = (pW + pE) + n * pC with n = the number of land neighbours among the
@@ -194,9 +210,9 @@ __device__ __forceinline__ v4f st_row_any(const v4f N, const v4f C, const v4f S,
         asm("v_pk_add_f32 %0, %1, %2 clamp" : "=v"(L1) : "v"(ksn1), "s"(one));
         const v2f we0 = __builtin_elementwise_fma(kwe0, C.xy, we.outer), we1 = __builtin_elementwise_fma(kwe1, C.zw, we.inner);
         const v2f sn0 = __builtin_elementwise_fma(ksn0, C.xy, S.xy + N.xy), sn1 = __builtin_elementwise_fma(ksn1, C.zw, S.zw + N.zw);
-        const v2f t0 = st_div2(we0, k.cx, k.rx) + st_div2(sn0, k.cy, k.ry), t1 = st_div2(we1, k.cx, k.rx) + st_div2(sn1, k.cy, k.ry);
-        o0 = st_div2(__builtin_elementwise_fma(L0, t0, -bb.xy), k.beta, k.rb);
-        o1 = st_div2(__builtin_elementwise_fma(L1, t1, -bb.zw), k.beta, k.rb);
+        const v2f t0 = st_div2<DV>(we0, k.cx, k.rx) + st_div2<(DV != 0)>(sn0, k.cy, k.ry), t1 = st_div2<DV>(we1, k.cx, k.rx) + st_div2<(DV != 0)>(sn1, k.cy, k.ry);
+        o0 = st_div2<DV>(__builtin_elementwise_fma(L0, t0, -bb.xy), k.beta, k.rb);
+        o1 = st_div2<DV>(__builtin_elementwise_fma(L1, t1, -bb.zw), k.beta, k.rb);
     }
     return v4f{ o0.x, o0.y, o1.x, o1.y };
 }
@@ -204,7 +220,7 @@ __device__ __forceinline__ v4f st_row_any(const v4f N, const v4f C, const v4f S,
 // one level: sweep S of rows yA = e0 + 2t - S and yB = yA + 1 from level S-1's rows yA-1 .. yB+1 (the pair made one step ago
 // and the pair made in this step); K = t mod 2
 // MODE 0: the pair's rows as their classes say (tests and branches); 1: both open water; 2: both through the coast formula
-template <int S, int K, bool P, int MODE = 0>
+template <int S, int K, bool P, int MODE = 0, int DV = 0>
 __device__ __forceinline__ void st_level(const st_args &a, st_state &z, v4f (*bring)[64], unsigned (*cring)[64], const v4f *ktab,
                                          int lane, int t, int yA, int r0, int r1, bool lane_ok, int xcol,
                                          v4f (&bq)[9], v4f (&kq)[9], int kb = 0)
@@ -235,22 +251,31 @@ __device__ __forceinline__ void st_level(const st_args &a, st_state &z, v4f (*br
     unsigned landA = 0, landB = 0;
     if (MODE == 2) {
         const int sa = st_wrap(z.slot - S), sb = sa + 1 == ST_RING ? 0 : sa + 1;
-        oA = st_row_any(N0, C0, S0, bA, kA, z.cy, z.ry, true, cring[sa], lane);
-        oB = st_row_any(N1, N0, C0, bB, kB, z.cy, z.ry, true, cring[sb], lane);
-    } else if (MODE == 1 || !(((z.landbits | z.mixbits) >> S) & 3u)) {   // (one two-bit field of the step's combined mask: the common case costs one scalar test)
+        oA = st_row_any<DV>(N0, C0, S0, bA, kA, z.cy, z.ry, true, cring[sa], lane);
+        oB = st_row_any<DV>(N1, N0, C0, bB, kB, z.cy, z.ry, true, cring[sb], lane);
+    } else if (MODE == 1 || !(((z.landbits | z.mixbits | (DV ? z.badbits : 0u)) >> S) & 3u)) {   // (one two-bit field of the step's combined mask: the common case costs one scalar test)
         // both rows open ocean (wave-uniform): one block of 8 independent division chains
         const jacobi_row ka = { kA.x, z.cy, kA.w, kA.y, z.ry, kA.z }, kb = { kB.x, z.cy, kB.w, kB.y, z.ry, kB.z };
         const st_we weA = st_we_sums(C0), weB = st_we_sums(N0);
-        const v2f a0 = st_value2s(weA.outer, S0.xy + N0.xy, bA.xy, ka), a1 = st_value2s(weA.inner, S0.zw + N0.zw, bA.zw, ka);
-        const v2f b0 = st_value2s(weB.outer, C0.xy + N1.xy, bB.xy, kb), b1 = st_value2s(weB.inner, C0.zw + N1.zw, bB.zw, kb);
+        const v2f a0 = st_value2s<DV>(weA.outer, S0.xy + N0.xy, bA.xy, ka), a1 = st_value2s<DV>(weA.inner, S0.zw + N0.zw, bA.zw, ka);
+        const v2f b0 = st_value2s<DV>(weB.outer, C0.xy + N1.xy, bB.xy, kb), b1 = st_value2s<DV>(weB.inner, C0.zw + N1.zw, bB.zw, kb);
         oA = v4f{ a0.x, a0.y, a1.x, a1.y };
         oB = v4f{ b0.x, b0.y, b1.x, b1.y };
     } else {
         landA = (z.landbits >> (S + 1)) & 1u; landB = (z.landbits >> S) & 1u;
         const unsigned mixA = (z.mixbits >> (S + 1)) & 1u, mixB = (z.mixbits >> S) & 1u;
         const int sa = st_wrap(z.slot - S), sb = sa + 1 == ST_RING ? 0 : sa + 1;
-        oA = landA ? (v4f)(0.0f) : st_row_any(N0, C0, S0, bA, kA, z.cy, z.ry, mixA != 0, cring[sa], lane);
-        oB = landB ? (v4f)(0.0f) : st_row_any(N1, N0, C0, bB, kB, z.cy, z.ry, mixB != 0, cring[sb], lane);
+        if (DV && ((z.badbits >> S) & 3u)) {
+            // a row whose divisors have no exact pair (one in a thousand): Markstein form for that row
+            const unsigned badA = (z.badbits >> (S + 1)) & 1u, badB = (z.badbits >> S) & 1u;
+            oA = landA ? (v4f)(0.0f) : (badA ? st_row_any<2>(N0, C0, S0, bA, kA, z.cy, z.ry, mixA != 0, cring[sa], lane)
+                                             : st_row_any<DV>(N0, C0, S0, bA, kA, z.cy, z.ry, mixA != 0, cring[sa], lane));
+            oB = landB ? (v4f)(0.0f) : (badB ? st_row_any<2>(N1, N0, C0, bB, kB, z.cy, z.ry, mixB != 0, cring[sb], lane)
+                                             : st_row_any<DV>(N1, N0, C0, bB, kB, z.cy, z.ry, mixB != 0, cring[sb], lane));
+        } else {
+        oA = landA ? (v4f)(0.0f) : st_row_any<DV>(N0, C0, S0, bA, kA, z.cy, z.ry, mixA != 0, cring[sa], lane);
+        oB = landB ? (v4f)(0.0f) : st_row_any<DV>(N1, N0, C0, bB, kB, z.cy, z.ry, mixB != 0, cring[sb], lane);
+        }
     }
     if (S < 8) { z.w[S & 7][K][0] = oA; z.w[S & 7][K][1] = oB; }
     else if (lane_ok && !ST_DBG(a, 2)) {                          // never re-read in this launch; land rows hold 0 in both buffers already
@@ -300,6 +325,7 @@ template <int K>
 __device__ __forceinline__ void st_arrive(const st_args &a, st_state &z, v4f (*bring)[64], unsigned (*cring)[64], int lane,
                                           int j, int e, unsigned cls, int slot, unsigned &land, unsigned &mix)
 {
+    cls &= 3u;                                               // (bit 2: the row's divisors have no exact pair, st_step)
     land = cls == 1u; mix = 0;
     // (a land row's pressure is +0 in memory: k_zero_land.)  A real move, opaque to the register coalescer: merged with the
     // staging registers, level 0's rows stay live past the point where the set is reloaded, the reload gets other
@@ -366,17 +392,20 @@ __device__ __forceinline__ unsigned st_class_p(const st_args &a, const st_state 
     return inside ? c : 2u;
 }
 
-template <int K, bool P = false>
+template <int K, bool P = false, int DV = 0>
 __device__ __forceinline__ void st_step(const st_args &a, st_state &z, v4f (*bring)[64], unsigned (*cring)[64], const v4f *ktab, int lane, int t,
                                         int e0, int nsteps, int r1, unsigned cls_lo, unsigned cls_hi, int col, int colp, bool lane_ok, int xcol, int tx = 0)
 {
     const int e_t = e0 + 2 * t;                              // first row of the pair that has just arrived
     const int slotB = z.slot + 1;                            // (ST_RING is even: a pair never wraps)
     unsigned landA, mixA, landB, mixB;
-    st_arrive<K>(a, z, bring, cring, lane, 0, e_t, P ? st_class_p<K>(a, z, 0, e_t) : st_class4(cls_lo, 2 * t), z.slot, landA, mixA);
-    st_arrive<K>(a, z, bring, cring, lane, 1, e_t + 1, P ? st_class_p<K>(a, z, 1, e_t + 1) : st_class4(cls_lo, 2 * t + 1), slotB, landB, mixB);
+    const unsigned clsA = P ? st_class_p<K>(a, z, 0, e_t) : st_class4(cls_lo, 2 * t), clsB = P ? st_class_p<K>(a, z, 1, e_t + 1) : st_class4(cls_lo, 2 * t + 1);
+    st_arrive<K>(a, z, bring, cring, lane, 0, e_t, clsA, z.slot, landA, mixA);
+    st_arrive<K>(a, z, bring, cring, lane, 1, e_t + 1, clsB, slotB, landB, mixB);
     z.landbits = (z.landbits << 2) | (landA << 1) | landB;
     z.mixbits = (z.mixbits << 2) | (mixA << 1) | mixB;
+    if (DV) z.badbits = (z.badbits << 2) | ((clsA >> 1) & 2u) | ((clsB >> 2) & 1u);
+    const unsigned special = DV ? z.badbits : 0u;           // rows that need the tested path like an all-land row does
     // the staging set is free again: the pair of step t + 2 (past the window's end the rows are clamped and unused)
     st_fetch<P>(a, z, K, 0, e_t + 4, col, colp, tx);
     st_fetch<P>(a, z, K, 1, e_t + 5, col, colp, tx);
@@ -388,40 +417,41 @@ __device__ __forceinline__ void st_step(const st_args &a, st_state &z, v4f (*bri
     if (!P) asm volatile("v_mov_b32 %0, %1" : "=v"(kb) : "s"((2 * t - 8) * 16));
     // no land and no coast in any of the ten rows in flight (every step of a strip in open water): the eight levels without
     // a test or a branch between them -- one block for the scheduler; a branch per level visit costs the kernel ~3 %
-    if (!((z.landbits | z.mixbits) & 0x3FFu)) {
-        st_level<1, K, P, 1>(a, z, bring, cring, ktab, lane, t, e_t - 1, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
-        st_level<2, K, P, 1>(a, z, bring, cring, ktab, lane, t, e_t - 2, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
-        st_level<3, K, P, 1>(a, z, bring, cring, ktab, lane, t, e_t - 3, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
-        st_level<4, K, P, 1>(a, z, bring, cring, ktab, lane, t, e_t - 4, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
-        st_level<5, K, P, 1>(a, z, bring, cring, ktab, lane, t, e_t - 5, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
-        st_level<6, K, P, 1>(a, z, bring, cring, ktab, lane, t, e_t - 6, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
-        st_level<7, K, P, 1>(a, z, bring, cring, ktab, lane, t, e_t - 7, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
-        st_level<8, K, P, 1>(a, z, bring, cring, ktab, lane, t, e_t - 8, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
-    } else if (!(z.landbits & 0x3FFu)) {
+    if (!((z.landbits | z.mixbits | special) & 0x3FFu)) {
+        st_level<1, K, P, 1, DV>(a, z, bring, cring, ktab, lane, t, e_t - 1, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<2, K, P, 1, DV>(a, z, bring, cring, ktab, lane, t, e_t - 2, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<3, K, P, 1, DV>(a, z, bring, cring, ktab, lane, t, e_t - 3, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<4, K, P, 1, DV>(a, z, bring, cring, ktab, lane, t, e_t - 4, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<5, K, P, 1, DV>(a, z, bring, cring, ktab, lane, t, e_t - 5, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<6, K, P, 1, DV>(a, z, bring, cring, ktab, lane, t, e_t - 6, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<7, K, P, 1, DV>(a, z, bring, cring, ktab, lane, t, e_t - 7, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<8, K, P, 1, DV>(a, z, bring, cring, ktab, lane, t, e_t - 8, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
+    } else if (!((z.landbits | special) & 0x3FFu)) {
         // coast among the ten rows, but no row that is land everywhere (coast rows come in long runs: 18 % of the survey
         // terrain's steps): every row through the coast formula, open rows with counts of zero -- again no test, no branch
-        st_level<1, K, P, 2>(a, z, bring, cring, ktab, lane, t, e_t - 1, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
-        st_level<2, K, P, 2>(a, z, bring, cring, ktab, lane, t, e_t - 2, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
-        st_level<3, K, P, 2>(a, z, bring, cring, ktab, lane, t, e_t - 3, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
-        st_level<4, K, P, 2>(a, z, bring, cring, ktab, lane, t, e_t - 4, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
-        st_level<5, K, P, 2>(a, z, bring, cring, ktab, lane, t, e_t - 5, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
-        st_level<6, K, P, 2>(a, z, bring, cring, ktab, lane, t, e_t - 6, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
-        st_level<7, K, P, 2>(a, z, bring, cring, ktab, lane, t, e_t - 7, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
-        st_level<8, K, P, 2>(a, z, bring, cring, ktab, lane, t, e_t - 8, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<1, K, P, 2, DV>(a, z, bring, cring, ktab, lane, t, e_t - 1, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<2, K, P, 2, DV>(a, z, bring, cring, ktab, lane, t, e_t - 2, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<3, K, P, 2, DV>(a, z, bring, cring, ktab, lane, t, e_t - 3, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<4, K, P, 2, DV>(a, z, bring, cring, ktab, lane, t, e_t - 4, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<5, K, P, 2, DV>(a, z, bring, cring, ktab, lane, t, e_t - 5, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<6, K, P, 2, DV>(a, z, bring, cring, ktab, lane, t, e_t - 6, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<7, K, P, 2, DV>(a, z, bring, cring, ktab, lane, t, e_t - 7, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<8, K, P, 2, DV>(a, z, bring, cring, ktab, lane, t, e_t - 8, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
     } else {
-        st_level<1, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 1, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
-        st_level<2, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 2, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
-        st_level<3, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 3, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
-        st_level<4, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 4, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
-        st_level<5, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 5, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
-        st_level<6, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 6, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
-        st_level<7, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 7, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
-        st_level<8, K, P>(a, z, bring, cring, ktab, lane, t, e_t - 8, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<1, K, P, 0, DV>(a, z, bring, cring, ktab, lane, t, e_t - 1, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<2, K, P, 0, DV>(a, z, bring, cring, ktab, lane, t, e_t - 2, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<3, K, P, 0, DV>(a, z, bring, cring, ktab, lane, t, e_t - 3, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<4, K, P, 0, DV>(a, z, bring, cring, ktab, lane, t, e_t - 4, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<5, K, P, 0, DV>(a, z, bring, cring, ktab, lane, t, e_t - 5, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<6, K, P, 0, DV>(a, z, bring, cring, ktab, lane, t, e_t - 6, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<7, K, P, 0, DV>(a, z, bring, cring, ktab, lane, t, e_t - 7, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<8, K, P, 0, DV>(a, z, bring, cring, ktab, lane, t, e_t - 8, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
     }
     z.slot = z.slot + 2 == ST_RING ? 0 : z.slot + 2;
 }
 
 // one wave per unit; two waves per SIMD leave 256 registers each: all issue slots of a SIMD belong to two fat waves
+template <int DV>
 __global__ __launch_bounds__(64, 2) void k_jacobi_stream(st_args a)
 {
     __shared__ v4f bring[ST_RING][64];
@@ -462,13 +492,17 @@ __global__ __launch_bounds__(64, 2) void k_jacobi_stream(st_args a)
             if (yg >= 0 && yg < a.H && lu >= 0 && lu < a.L) cls_lo = (cls_lo & ~(0xFFu << (8 * q))) | ((unsigned)a.rowclass[(size_t)tx * a.L + lu] << (8 * q));
         }
     }
+    if (DV && a.rowbad) {                                    // (mirrored and clamped rows have their image's divisors)
+#pragma unroll
+        for (int q = 0; q < 4; q++) cls_lo |= ((unsigned)a.rowbad[st_map_row(a, e0 + lane + 64 * q).l] & 1u) << (8 * q + 2);
+    }
 
 #pragma unroll
     for (int s = 0; s < 8; s++)
 #pragma unroll
         for (int k = 0; k < 2; k++) { z.w[s][k][0] = (v4f)(0.0f); z.w[s][k][1] = (v4f)(0.0f); }
     z.landbits = 0xFFFFFFFFu;                                // rows before the window: "land", so that a level idles until its rows exist
-    z.mixbits = 0; z.slot = 0;
+    z.mixbits = 0; z.slot = 0; z.badbits = 0;
     {
         // one 16-byte table entry per window row (two spare: the next level's prefetch): all of a lane's (up to four) loads in
         // flight together -- a loop of load, wait, store costs a unit a memory round trip per 64 rows
@@ -482,8 +516,8 @@ __global__ __launch_bounds__(64, 2) void k_jacobi_stream(st_args a)
         z.cy = cf[4]; z.ry = cf[5];
     }
     for (int t = 0; t < nsteps; t += 2) {
-        st_step<0>(a, z, bring, cring, ktab, lane, t, e0, nsteps, r1, cls_lo, cls_hi, col, colp, lane_ok, xcol);
-        st_step<1>(a, z, bring, cring, ktab, lane, t + 1, e0, nsteps, r1, cls_lo, cls_hi, col, colp, lane_ok, xcol);
+        st_step<0, false, DV>(a, z, bring, cring, ktab, lane, t, e0, nsteps, r1, cls_lo, cls_hi, col, colp, lane_ok, xcol);
+        st_step<1, false, DV>(a, z, bring, cring, ktab, lane, t + 1, e0, nsteps, r1, cls_lo, cls_hi, col, colp, lane_ok, xcol);
     }
     if (a.prof && lane == 0) a.prof[3 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
 }
@@ -633,7 +667,7 @@ __global__ __launch_bounds__(64, 2) void k_jacobi_stream_p(st_args a)
 #pragma unroll
             for (int j = 0; j < 2; j++) { z.ps[k][j] = (v4f)(0.0f); z.bs[k][j] = (v4f)(0.0f); z.cs[k][j] = 0; z.ks[k][j] = 2u; }
         z.landbits = 0xFFFFFFFFu;
-        z.mixbits = 0; z.slot = 0;
+        z.mixbits = 0; z.slot = 0; z.badbits = 0;
         {
             const st_kptr cf = (st_kptr)(unsigned long long)a.jcoef;
             z.cy = cf[4]; z.ry = cf[5];
@@ -1091,6 +1125,7 @@ static const dmg_ocean::tile_list *st_units(dmg_ocean *o, int variant, int lo, i
     const int slots = std::max(o->ctx->num_cu, 1) * (variant == 1 ? 20 : 8);     // five (96 VGPRs) / two waves per SIMD
     std::vector<st_unit> units, best;
     int p_waves = 0;
+    int cut_seg = 0, cut_seg2 = 0, cut_split = 0;         // the cut this list was made with (st_cut's seg, seg2, split)
     if (variant == 2) {
         // persistent form: about one segment per wave (the waves balance the rest among themselves); a strip's rows that
         // are land everywhere at either end of a cut are trimmed as for the units
@@ -1106,7 +1141,25 @@ static const dmg_ocean::tile_list *st_units(dmg_ocean *o, int variant, int lo, i
         if (dbg) fprintf(stderr, "[stream] rows [%d,%d): persistent, %d waves, %zu segments of cost %.0f (total %.0f, longest %.0f, shortest %.0f)\n", lo, hi, p_waves,
                          best.size(), target, total, best.empty() ? 0.0f : best.front().cost, best.empty() ? 0.0f : best.back().cost);
     }
-    else if (seg > 0) { st_cut(o, variant, lo, hi, seg, part, zone_lo, zone_hi, best); (void)st_makespan(best, slots); }
+    else if (part) {
+        // The two halves of a split launch are halves of ONE cut: the one the whole launch over these rows uses (chosen
+        // with every unit in play), filtered by the edge predicate.  (Each half choosing its own unit heights left the
+        // rows between the two choices to neither of them.)
+        const dmg_ocean::tile_list *whole = st_units(o, variant, lo, hi, 0, 0, 0, seg);
+        if (!whole) return nullptr;
+        cut_seg = whole->cut_seg; cut_seg2 = whole->cut_seg2; cut_split = whole->cut_split;
+        if (cut_seg <= 0) { cut_seg = variant == 1 ? STN_MAXROWS : ST_MAXROWS; cut_seg2 = 0; cut_split = hi; }   // (a launch with no live unit)
+        st_cut(o, variant, lo, hi, cut_seg, part, zone_lo, zone_hi, best, cut_seg2, cut_split);
+        (void)st_makespan(best, slots);
+        // both halves built: together they must be the whole launch's units, each exactly once
+        auto other = o->tb_lists.find(std::make_tuple(lo, hi, std::get<2>(key), 3 - part, zone_lo, zone_hi));
+        if (other != o->tb_lists.end() && other->second.n + (int)best.size() != whole->n) {
+            dmg_fail(DMG_ESTATE, "split launch over rows [%d, %d): %d + %zu units in the two parts, %d in the whole launch", lo, hi,
+                     other->second.n, best.size(), whole->n);
+            return nullptr;
+        }
+    }
+    else if (seg > 0) { st_cut(o, variant, lo, hi, seg, part, zone_lo, zone_hi, best); (void)st_makespan(best, slots); cut_seg = seg; cut_split = hi; }
     else {
         float best_span = 1e30f;
         int best_seg = 0, best_seg2 = 0, best_split = 0;
@@ -1136,6 +1189,7 @@ static const dmg_ocean::tile_list *st_units(dmg_ocean *o, int variant, int lo, i
                 }
         }
         (void)st_makespan(best, slots);                    // (longest first)
+        cut_seg = best_seg; cut_seg2 = best_seg2; cut_split = best_split;
         static const bool dbg = getenv("DMG_ST_DEBUG") != nullptr;
         if (dbg) {
             double total = 0;
@@ -1185,6 +1239,7 @@ static const dmg_ocean::tile_list *st_units(dmg_ocean *o, int variant, int lo, i
     for (const st_unit &u : best) { flat.push_back(u.tx); flat.push_back(u.r0); flat.push_back(u.r1); flat.push_back(0); }
     dmg_ocean::tile_list tl;
     tl.n = (int)best.size();
+    tl.cut_seg = cut_seg; tl.cut_seg2 = cut_seg2; tl.cut_split = cut_split;
     if (tl.n && hipMalloc((void **)&tl.d, flat.size() * sizeof(int)) != hipSuccess) return nullptr;
     if (tl.n && hipMemcpy(tl.d, flat.data(), flat.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
     if (variant == 2 && tl.n) {
@@ -1223,7 +1278,11 @@ int ocean_launch_stream(dmg_ocean *o, int lo, int hi, int part, int zone_lo, int
     a.pout = o->p[from ^ 1];
     a.b = o->divw;
     a.code = o->code;
-    a.jcoef = variant == 1 ? o->jcoefp : o->jcoef;
+    // the division form: two operations per quotient where every row constant of this band has an exact pair (div2.hip)
+    static const bool div2_env = [] { const char *e = getenv("DMG_JACOBI_DIV2"); return !e || atoi(e) != 0; }();
+    const bool div2 = variant == 0 && div2_env && o->div2_ok && o->jcoef2;
+    a.jcoef = variant == 1 ? o->jcoefp : (div2 ? o->jcoef2 : o->jcoef);
+    a.rowbad = div2 && o->div2_nbad ? o->rowbad : nullptr;
     a.jcoef_cy = o->jcoef + 4;                           // row 0's {cy, 1/cy}: the same for every row
     a.W = o->grid.W; a.L = o->L;
     a.y_first = o->y0 - o->gs; a.H = o->grid.H;
@@ -1265,7 +1324,8 @@ int ocean_launch_stream(dmg_ocean *o, int lo, int hi, int part, int zone_lo, int
         }
     }
     else if (variant) hipLaunchKernelGGL(k_jacobi_stream_n, dim3((unsigned)tl->n), dim3(64), (size_t)extra_lds, st, a);
-    else hipLaunchKernelGGL(k_jacobi_stream, dim3((unsigned)tl->n), dim3(64), (size_t)extra_lds, st, a);
+    else if (div2) hipLaunchKernelGGL(k_jacobi_stream<1>, dim3((unsigned)tl->n), dim3(64), (size_t)extra_lds, st, a);
+    else hipLaunchKernelGGL(k_jacobi_stream<0>, dim3((unsigned)tl->n), dim3(64), (size_t)extra_lds, st, a);
     DMG_HIP(hipGetLastError());
     if (prof_now && a.prof) {
         prof_done = true;

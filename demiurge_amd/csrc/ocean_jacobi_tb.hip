@@ -553,14 +553,16 @@ int ocean_launch_tb(dmg_ocean *o, int lo, int hi, int n, int part, int zone_lo, 
 int ocean_tb_tile_rows(dmg_ocean *o, int lo, int hi)
 {
     tb_shape f = tb_forced_shape();
-    if (f.R < 0) return 96;
+    // the streaming forms cut a launch into units of two heights, trimmed to their water rows: there is no tile-row grid
+    // for a host to plan edge chains on (bands.py falls back to the plain order); _begin/_end split along unit boundaries
+    if (f.R < 0) return 0;
     if (f.R) return f.R * f.NW - 2 * TB_T;
     if (ocean_tb_tuning_open(o, lo, hi)) return 0;
-    static const int rows_of[TB_NCAND] = { 8 * 8 - 2 * TB_T, 6 * 8 - 2 * TB_T, 4 * 8 - 2 * TB_T, 96, 32, 96 };   // streaming: rows per unit
+    static const int rows_of[TB_NCAND] = { 8 * 8 - 2 * TB_T, 6 * 8 - 2 * TB_T, 4 * 8 - 2 * TB_T, 0, 0, 0 };   // streaming forms: no tile-row grid
     auto it = o->tb_tuning.find(std::make_pair(lo, hi));
     if (it != o->tb_tuning.end() && it->second.chosen >= 0) return rows_of[it->second.chosen];
     const int tiles88 = ((o->grid.W + TB_OW - 1) / TB_OW) * ((hi - lo + 47) / 48);
-    return (tiles88 > 4096 && ocean_stream_enabled()) ? 96 : rows_of[0];
+    return (tiles88 > 4096 && ocean_stream_enabled()) ? 0 : rows_of[0];
 }
 
 // true while the per-geometry shape tuner (ocean_launch_tb) would still time a candidate for a whole 8-sweep launch

@@ -64,5 +64,32 @@ int ocean_upload_row_tables(dmg_ocean *o)
     }
     DMG_HIP(hipMemcpyAsync(o->jcoef, jc.data(), jc.size() * sizeof(float), hipMemcpyHostToDevice, o->ctx->stream));
     DMG_HIP(hipStreamSynchronize(o->ctx->stream));
+    {   // the same divisors as exact two-operation pairs (div2.hip): [L][8] = (h, l) of cx, of Beta, of cy.  A row whose cx or
+        // Beta has no exact pair keeps (c, 1/c) for both and is flagged in rowbad; without a pair for cy (one constant for
+        // the whole grid) the streaming kernel keeps the three-operation form everywhere.
+        std::vector<float> c((size_t)2 * L + 1), h(c.size()), lo(c.size());
+        std::vector<unsigned char> ok(c.size());
+        for (int l = 0; l < L; l++) { c[l] = jc[(size_t)l * 8 + 0]; c[(size_t)L + l] = jc[(size_t)l * 8 + 2]; }
+        c[(size_t)2 * L] = jc[4];
+        int rc = dmg_div2_splits(o->ctx, c.data(), (int)c.size(), h.data(), lo.data(), ok.data());
+        if (rc) return rc;
+        o->div2_ok = ok[(size_t)2 * L] != 0;
+        o->div2_nbad = 0;
+        std::vector<float> j2((size_t)L * 8, 0.0f);
+        std::vector<unsigned char> bad((size_t)L, 0);
+        // tests only: DMG_DIV2_FORCE_BAD=<k> treats every k-th grid row as if it had no pair (rows without one are one in a
+        // thousand: small grids may have none, and the path that handles them has to be exercised)
+        static const int force_bad = [] { const char *e = getenv("DMG_DIV2_FORCE_BAD"); return e ? atoi(e) : 0; }();
+        for (int l = 0; l < L; l++) {
+            float *e = &j2[(size_t)l * 8];
+            const bool forced = force_bad > 0 && ((o->y0 - o->gs + l) % force_bad) == 0;
+            if (ok[l] && ok[(size_t)L + l] && !forced) { e[0] = h[l]; e[1] = lo[l]; e[2] = h[(size_t)L + l]; e[3] = lo[(size_t)L + l]; }
+            else { for (int k = 0; k < 4; k++) e[k] = jc[(size_t)l * 8 + k]; bad[l] = 1; o->div2_nbad++; }
+            e[4] = h[(size_t)2 * L]; e[5] = lo[(size_t)2 * L];
+        }
+        DMG_HIP(hipMemcpyAsync(o->jcoef2, j2.data(), j2.size() * sizeof(float), hipMemcpyHostToDevice, o->ctx->stream));
+        DMG_HIP(hipMemcpyAsync(o->rowbad, bad.data(), bad.size(), hipMemcpyHostToDevice, o->ctx->stream));
+        DMG_HIP(hipStreamSynchronize(o->ctx->stream));
+    }
     return DMG_OK;
 }

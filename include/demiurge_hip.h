@@ -152,8 +152,16 @@ int dmg_ocean_set_pressure(dmg_ocean *o, const float *pressure);
  * (pW + pE) + n * pC with n land neighbours among the two.  That is the shader's sum bit for bit, except that a pair of
  * open neighbours that both hold -0.0, in a 256-column strip within ten rows of a coast, sums to +0.0 instead of -0.0 --
  * a value no solve produces from the +0.0 start inside the window above (a starting pressure given through
- * dmg_ocean_set_pressure may hold it). */
+ * dmg_ocean_set_pressure may hold it).
+ * Since round 3 the streaming kernel forms these quotients in two operations where that is exact: for a divisor c with
+ * 1/c = h + l it computes fma(x, h, x * l), after every one of the 2^23 significands of x has been checked on the device to
+ * give the correctly rounded x / c for that (c, h, l) (dmg_div2_split; rows whose divisors have no such pair keep the
+ * three-operation form).  Same window, same results: the IEEE quotient. */
 int dmg_ocean_jacobi(dmg_ocean *o, int iters, int zero_first);
+/* The pair (h, l) the streaming Jacobi kernel uses to divide by the row constant c (pixelwidth2 and Beta of
+ * OceanCurrents.cpp:478-480): x / c == fma(x, h, x * l) for every finite x whose products neither underflow nor
+ * overflow, verified exhaustively on the device.  DMG_EINVAL if c has no such pair (about one constant in a thousand). */
+int dmg_div2_split(dmg_ctx *ctx, float c, float *h, float *l);
 /* Band form: `n` (<= ghost) sweeps assuming the pressure ghost rows are current; afterwards the owned
  * rows are n sweeps ahead and the ghost rows are stale until the host refreshes them via dmg_ocean_halo. */
 int dmg_ocean_jacobi_sweeps(dmg_ocean *o, int n);

@@ -362,3 +362,68 @@ def test_streaming_unit_heights_are_bitwise(rows):
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "stream_check.py"), "2048", "1024", "40", "survey", "globe"], cwd=root, env=env,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "bit-identical" in r.stdout and "k_jacobi_stream" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def _stream_worker(env_extra, cases, timeout=900):
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **env_extra)
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "stream_worker.py")] + cases, cwd=root, env=env,
+                       capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0 and "bit-identical" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+    return r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form", ["stream", "stream-n", "stream-p"])
+def test_streaming_forms_forced_vs_oracle(form):
+    """every form of the streaming kernel, forced for all 8-sweep launches, against the ORACLE on
+    coast-heavy inputs with random starting pressure (tests/stream_worker.py: 20 random geometries, salt-and-pepper land
+    at 2048x1024 on globe and belt, band splits with ghost 8 and 16), and against the reference's own llvmpipe output
+    after its full 5000 sweeps (256x128 golden, 625 streaming launches)."""
+    out = _stream_worker({"DMG_TB_SHAPE": form}, ["random", "pepper", "golden", "bands"])
+    kern = {"stream": "k_jacobi_stream", "stream-n": "k_jacobi_stream_n", "stream-p": "k_jacobi_stream_p"}[form]
+    assert "'%s'" % kern in out, out[-1500:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"DMG_JACOBI_DIV2": "0"}, {"DMG_DIV2_FORCE_BAD": "7"}, {"DMG_DIV2_FORCE_BAD": "1"}],
+                         ids=["three-op-division", "every-7th-row-without-pair", "no-row-with-pair"])
+def test_streaming_division_forms_vs_oracle(env):
+    """The default streaming kernel divides by the row constants in two operations (div2.hip).  Its other forms give the
+    same bits: the three-operation division everywhere (DMG_JACOBI_DIV2=0), and rows that have no exact pair -- one in a
+    thousand at 16384x8192, forced here for every 7th row and for every row -- which take the three-operation form row by
+    row inside the two-operation kernel."""
+    _stream_worker(dict(env, DMG_TB_SHAPE="stream"), ["random", "pepper", "golden"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form", ["stream", "auto"])
+def test_streaming_split_launches_vs_oracle(form):
+    """the two halves of a split launch (_begin / exchange / _end) are halves of one cut.  Band splits
+    through _begin/_end with the streaming kernel forced and with the default choice, including 16384-wide bands (above
+    4096 tiles, where the unit heights are chosen per launch geometry), against the oracle."""
+    _stream_worker({"DMG_TB_SHAPE": form} if form != "auto" else {}, ["split"], timeout=1500)
+
+
+def test_div2_pairs_are_exact(dev):
+    """dmg_div2_split: the (h, l) the streaming kernel divides with give the correctly rounded quotient -- here on a
+    random sample of numerators in float64 arithmetic (the library itself tries all 2^23 significands on the device
+    before it hands a pair out), for the Jacobi constants of a 16384x8192 globe including two whose standard pair fails
+    for one significand, and a constant that has no pair at all."""
+    capi, ctx = dev
+    rng = np.random.default_rng(5)
+    consts = [np.float32(3.7252903e-05), np.float32(float.fromhex("0x1.ba8f1ep+21")), np.float32(float.fromhex("0x1.dfc9b6p-16")),
+              np.float32(1.0), np.float32(3.0), np.float32(0.1), np.float32(123456.789)]
+    x = np.concatenate([rng.uniform(1, 2, 2_000_000), rng.uniform(1, 2, 1000) * 2.0 ** rng.integers(-60, 60, 1000)]).astype(np.float32)
+    for c in consts:
+        h, l = ctx.div2_split(c)
+        # fma(x, h, x * l) evaluated exactly: x*l rounded to fp32, then x*h + u in float64 (exact: 48 + 24 bits) rounded once
+        u = (x * l).astype(np.float32)
+        q = (x.astype(np.float64) * np.float64(h) + u.astype(np.float64)).astype(np.float32)
+        want = (x.astype(np.float64) / np.float64(c)).astype(np.float32)
+        assert np.array_equal(q, want), (float(c), int((q != want).sum()))
+    with pytest.raises(capi.DmgError):
+        ctx.div2_split(np.float32(float.fromhex("0x1.a9407ep+16")))     # two significands pull l in opposite directions
+    with pytest.raises(capi.DmgError):
+        ctx.div2_split(np.float32(-2.0))
