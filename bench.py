@@ -16,10 +16,11 @@ ONE JSON line on rank 0.  Besides the contract's fields:
                     (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, collected by a child of this run) / its HIP-event duration,
                     `frac` = that / 8 TB/s  (<= 1).  The SURVEY 8d figure -- 16 algorithmic bytes per cell-sweep, which a
                     temporally blocked kernel undercuts ~10x -- is kept as `algorithmic_x_peak`; `fp32` is the vector-ALU
-                    side (19 flop per cell-sweep against the 157.3 TFLOP/s fp32 peak), the kernel's other roof.
+                    side (13 flop per executed cell-sweep, water cells only, against the 157.3 TFLOP/s fp32 peak).
   roofline_single   a second, short timed leg with one sweep per launch: the HBM-bound form the north_star's ">= 60 % of
                     HBM roofline" is stated for; achieved = 16 B x cells / launch duration.
-  all_ocean         the same solve on a terrain without land (nothing to skip: the kernel's worst case)
+  all_ocean         the same solve on a terrain without land (nothing to skip: the kernel's worst case), with its fp32 side
+  other_exchange_order   N > 1: one more solve in the exchange order that was not asked for (--order)
   check             64 sweeps by the default kernel against 64 single-sweep launches, compared bit for bit (untimed)
   cpu_baseline      the reference GLSL on llvmpipe on this host (oracle/_ref), else the C port
 """
@@ -35,6 +36,10 @@ import tempfile
 import time
 from pathlib import Path
 
+# dmg_multi's overlapped order runs two streams per band; HIP's default of four hardware queues serialises them on this
+# runtime (profiles/r03_overlap_probe.log).  Read when HIP initialises, so set before torch is imported.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 
 ROOT = Path(__file__).resolve().parent
@@ -43,7 +48,8 @@ sys.path.insert(0, str(ROOT))
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 FP32_PEAK_TFLOPS = 157.3       # vector fp32 peak (same guide)
 ALGO_BYTES_PER_CELL_STEP = 16  # read p, read divw, read terrain, write p'
-FLOP_PER_CELL_STEP = 19        # the shader's statement: 4 add/sub + 3 divisions of (1 mul + 2 fma) each, an fma = 2
+FLOP_PER_CELL_STEP = 13        # what the default kernel executes per cell-sweep: 4 add/sub + 3 divisions of (1 mul + 1 fma) each, an fma = 2
+                               # (round 2's three-operation division: 19)
 
 
 def parse():
@@ -193,16 +199,6 @@ def measure_traffic(args, kernels):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def committed_traffic(kernel, W, H):
-    try:
-        t = json.load(open(ROOT / "profiles" / "pmc_traffic.json")).get(kernel)
-        if t and (t["W"], t["H"]) == (W, H):
-            return t["hbm_bytes_per_launch"], "committed " + t.get("source", "profiles/pmc_traffic.json")
-    except Exception:
-        pass
-    return None, None
-
-
 def main():
     args = parse()
     if args.cpu_baseline_only:
@@ -304,6 +300,18 @@ def main():
                     bytes_per_exchange=(s1["exchange_bytes"] - s0["exchange_bytes"]) / max(s1["exchanges"] - s0["exchanges"], 1),
                     note="rank 0's HIP events around each exchange on its compute stream: transfer + the wait for the neighbours")
     m.close()
+    other = None
+    if world > 1 and not args.no_extra_legs:
+        # the same solve once more in the other exchange order (every rank takes part): the first multi-GPU run yields both
+        other_name = "exchange-then-sweep" if args.order == "overlap" else "overlap"
+        keep = order
+        order = capi.MULTI_EXCHANGE_THEN_SWEEP if args.order == "overlap" else capi.MULTI_OVERLAP_LAST_LAUNCH
+        mo2 = make(args.kernel, args.terrain)
+        dt2, ev2, _, _, _, _ = timed(mo2, sweeps, 1, 1)
+        mo2.close()
+        order = keep
+        other = {"order": other_name, "value": float(W) * H * sweeps / dt2 / 1e6, "unit": "Mcell-steps/s", "ms_per_step": dt2 * 1e3,
+                 "sample": "1 solve after 1 warm-up"}
 
     if rank != 0:
         if world > 1:
@@ -314,7 +322,9 @@ def main():
     value = cell_steps / dt / 1e6
     algo_bytes = ALGO_BYTES_PER_CELL_STEP * band_cells * sweeps_per_launch
     algo_gbs = algo_bytes / launch_s / 1e9
-    tflops = FLOP_PER_CELL_STEP * band_cells * sweeps_per_launch / launch_s / 1e12
+    # the kernel skips cells that are land (they hold +0): the arithmetic side counts the water cells only
+    water = 1.0 if args.terrain != "survey" else float((synth.terrain(W, H) <= 0).mean())
+    tflops = FLOP_PER_CELL_STEP * band_cells * water * sweeps_per_launch / launch_s / 1e12
     out = {
         "metric": "Mcell-steps/s, ocean Jacobi stencil @%dx%d fp32" % (W, H),
         "value": value, "unit": "Mcell-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -332,18 +342,17 @@ def main():
     if extra:
         traffic, traffic_src = measure_traffic(args, ["k_jacobi_stream", "k_jacobi_tb8", "k_jacobi_sweep_v4"])
 
-    def traffic_of(k):
+    def traffic_of(k):          # measured in this run, or nothing: a committed figure would be another build's
         if k in traffic:
             return traffic[k]["hbm_bytes_per_launch"], traffic_src
-        t, src = committed_traffic(k, W, H) if (world == 1 and args.terrain == "survey") else (None, None)
-        return t, (src if t else traffic_src)
+        return None, traffic_src
 
     tb, tsrc = traffic_of(kname)
     roof = {"kernel": kname, "launch_us": launch_s * 1e6, "sweeps_per_launch": sweeps_per_launch, "unit": "GB/s", "peak": HBM_PEAK_GBS,
             "traffic": tb, "traffic_source": tsrc,
             "algorithmic_bytes_per_launch": algo_bytes, "algorithmic_GBps": algo_gbs, "algorithmic_x_peak": algo_gbs / HBM_PEAK_GBS,
-            "fp32": {"flop_per_cell_sweep": FLOP_PER_CELL_STEP, "achieved": tflops, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": tflops / FP32_PEAK_TFLOPS}}
+            "fp32": {"flop_per_cell_sweep": FLOP_PER_CELL_STEP, "cells_counted": "water cells (%.1f %% of the grid): land is skipped" % (100 * water),
+                     "achieved": tflops, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP32_PEAK_TFLOPS}}
     if sweeps_per_launch > 1:
         roof["bound"] = "hbm"
         if tb:
@@ -360,6 +369,8 @@ def main():
     out["roofline"] = roof
     if exch:
         out["halo_exchange"] = exch
+    if other:
+        out["other_exchange_order"] = other
 
     if extra:
         # ---- one sweep per launch: the HBM-bound form the north_star's 60 % target is stated for ----
@@ -387,7 +398,9 @@ def main():
         mo = make("auto", "ocean")
         dto, evo, lo_, swo, _, _ = timed(mo, sweeps, 1, 1)
         out["all_ocean"] = {"value": float(W) * H * sweeps / dto / 1e6, "unit": "Mcell-steps/s", "ms_per_step": dto * 1e3,
-                            "launch_us": evo / lo_ * 1e3, "kernel": mo.band(0).kernel_name(), "sample": "1 solve after 1 warm-up"}
+                            "launch_us": evo / lo_ * 1e3, "kernel": mo.band(0).kernel_name(), "sample": "1 solve after 1 warm-up",
+                            "fp32_TFLOPs": FLOP_PER_CELL_STEP * float(W) * H * sweeps / dto / 1e12,
+                            "fp32_frac": FLOP_PER_CELL_STEP * float(W) * H * sweeps / dto / 1e12 / FP32_PEAK_TFLOPS}
         mo.close()
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)

@@ -3,6 +3,14 @@
 
 static thread_local std::string g_last_error;
 
+// HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  dmg_multi's overlapped order runs two
+// streams per band that wait on each other's events once per block, and with four queues that pattern is pathological on
+// this runtime (ROCm 7.2: a 2 x 1024-row rehearsal takes 18 ms instead of 11; with 2 or with 8 queues it takes 11, and the
+// RCCL kernels run beside the Jacobi kernels: profiles/r03_overlap_probe.log).  The variable is read when the HIP runtime
+// initialises, so the library asks for eight queues when it is loaded -- unless the host has set the variable itself, and
+// without effect if the host initialised HIP before loading the library (INTEGRATION.md says so).
+__attribute__((constructor)) static void dmg_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
 int dmg_fail(int code, const char *fmt, ...)
 {
     char buf[1024];
@@ -82,12 +90,15 @@ int dmg_trim(dmg_ctx *c)
 static void ctx_free(dmg_ctx *c);
 
 // A context outlives the handles created on it: destroying it first is allowed and takes effect when the last of them
-// is destroyed (the recorded round-1 abort was a dmg_ocean destroyed after its context).
+// is destroyed (the recorded round-1 abort was a dmg_ocean destroyed after its context).  One count decides: the owner
+// holds a reference from dmg_create on, dmg_destroy gives it back, and whoever brings the count to zero frees -- no flag
+// that a release on another thread (band threads, host adapters) could miss between its test and its set.
 void dmg_destroy(dmg_ctx *c)
 {
     if (!c) return;
-    if (c->children.load() > 0) { c->destroy_requested = true; return; }
-    ctx_free(c);
+    bool expected = false;
+    if (!c->destroy_requested.compare_exchange_strong(expected, true)) return;      // (a second dmg_destroy of the same context is ignored)
+    dmg_ctx_release(c);
 }
 
 static void ctx_free(dmg_ctx *c)
@@ -150,7 +161,7 @@ void dmg_ctx_retain(dmg_ctx *ctx) { if (ctx) ctx->children.fetch_add(1); }
 void dmg_ctx_release(dmg_ctx *ctx)
 {
     if (!ctx) return;
-    if (ctx->children.fetch_sub(1) == 1 && ctx->destroy_requested) ctx_free(ctx);
+    if (ctx->children.fetch_sub(1) == 1) ctx_free(ctx);
 }
 
 // ---- scratch pool (see dmg_ctx::scratch_pool) ----

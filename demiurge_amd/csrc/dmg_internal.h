@@ -46,8 +46,9 @@ struct dmg_ctx {
     char name[128] = {0};
     // handles created on this context (dmg_ocean, dmg_tectonics, dmg_climate, dmg_erosion, dmg_multi) keep it alive:
     // dmg_destroy with live children only marks it, the last child's destroy releases it (dmg_ctx_release)
-    std::atomic<int> children{0};
-    bool destroy_requested = false;
+    // (the count starts at one: the owner's reference, given back by dmg_destroy)
+    std::atomic<int> children{1};
+    std::atomic<bool> destroy_requested{false};
 };
 void dmg_ctx_retain(dmg_ctx *ctx);
 void dmg_ctx_release(dmg_ctx *ctx);

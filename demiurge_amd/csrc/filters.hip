@@ -974,11 +974,11 @@ int dmg_fields_exchange(dmg_field *const *bands, int n, int rows)
 {
     DMG_CHECK_ARG(bands != nullptr && n >= 1 && rows >= 1);
     if (n == 1) return DMG_OK;
+    for (int i = 0; i < n; i++) DMG_CHECK_ARG(bands[i] != nullptr && bands[i]->rank == i && bands[i]->count == n);   // before any event exists
     std::vector<hipEvent_t> done(n, nullptr), copied(n, nullptr);
     int rc = DMG_OK;
     auto cleanup = [&] { for (hipEvent_t e : done) if (e) (void)hipEventDestroy(e); for (hipEvent_t e : copied) if (e) (void)hipEventDestroy(e); };
     for (int i = 0; i < n && !rc; i++) {
-        DMG_CHECK_ARG(bands[i] != nullptr && bands[i]->rank == i && bands[i]->count == n);
         if (hipSetDevice(bands[i]->ctx->device) != hipSuccess || hipEventCreateWithFlags(&done[i], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&copied[i], hipEventDisableTiming) != hipSuccess || hipEventRecord(done[i], bands[i]->ctx->stream) != hipSuccess)
             rc = dmg_fail(DMG_EHIP, "dmg_fields_exchange: event set-up failed");

@@ -22,6 +22,7 @@
 #include <condition_variable>
 #include <functional>
 #include <memory>
+#include <chrono>
 #include <mutex>
 #include <thread>
 
@@ -50,6 +51,7 @@ struct band_team {
     int bar_count = 0;
     long long bar_gen = 0;
     bool failed = false;             // a band has returned an error in this run(): barriers let everybody go
+    std::function<void(int)> on_fail;    // called once by the band that failed, before the others are let go
 
     void start(int n_)
     {
@@ -71,6 +73,7 @@ struct band_team {
                     }
                     int r = f(i);
                     std::string e = r ? dmg_last_error() : "";
+                    if ((r == DMG_EHIP || r == DMG_ENOMEM) && on_fail) on_fail(i);    // (a refused argument is collective and leaves nothing queued)
                     {
                         std::lock_guard<std::mutex> lk(mtx);
                         rc[i] = r;
@@ -94,7 +97,11 @@ struct band_team {
     // runs f(i) for every band; returns the first failure (message copied into the caller's dmg_last_error)
     int run(const std::function<int(int)> &f)
     {
-        if (n <= 1) return n == 1 ? f(0) : DMG_OK;
+        if (n <= 1) {
+            const int r = n == 1 ? f(0) : DMG_OK;
+            if ((r == DMG_EHIP || r == DMG_ENOMEM) && on_fail) { const std::string keep = dmg_last_error(); on_fail(0); return dmg_fail(r, "%s", keep.c_str()); }
+            return r;
+        }
         {
             std::lock_guard<std::mutex> lk(mtx);
             job = f;
@@ -141,6 +148,15 @@ struct dmg_multi {
     std::vector<dmg_ocean *> oc;
     std::vector<ncclComm_t> comm;    // RCCL: one per local band (loopback: one in all)
     std::vector<hipEvent_t> ev_done, ev_copied;    // PEER: per band
+    // DMG_MULTI_OVERLAP_LAST_LAUNCH: a second, high-priority stream per band carries the exchange while the band's own
+    // stream sweeps the interior units of the block's last launch
+    std::vector<hipStream_t> comm_stream;
+    std::vector<hipEvent_t> ev_edge, ev_xchg;      // per band: a whole launch done (own stream) / ghost rows refreshed (second stream)
+    std::atomic<bool> dead{false};   // a band failed and the communicators were aborted: only dmg_multi_destroy remains
+    int timeout_ms = 120000;         // RCCL transports: how long a host-side wait may take before the communicators are aborted
+    int fail_band = -1;              // tests (DMG_MULTI_FAIL=<band>:<n>): that band gives up in front of its n-th exchange
+    long long fail_at = 0;
+    std::vector<long long> n_band_exchanges;
     std::vector<int *> d_red;        // per band: one device word for reductions
     band_team team;
     // halo-exchange time: event pairs on band 0's stream around every exchange, folded into the sum when read
@@ -168,15 +184,63 @@ static int multi_fold_events(dmg_multi *m)
     return DMG_OK;
 }
 
+// A band has failed, or a wait has run out: abort the local communicators so that receives still queued on the streams end
+// instead of waiting for a peer that will never send (ncclCommAbort tears the communicator's kernels down), and mark the
+// handle dead.  The bands of other processes notice through their own timed waits (multi_wait).
+static void multi_abort(dmg_multi *m)
+{
+    bool was = false;
+    if (!m->dead.compare_exchange_strong(was, true)) return;
+    for (ncclComm_t &c : m->comm)
+        if (c) { (void)ncclCommAbort(c); c = nullptr; }
+}
+
+// wait for band i's streams.  With RCCL a peer that has died leaves a receive kernel spinning forever, so the wait polls,
+// watches the communicator's asynchronous error state, and gives up after timeout_ms (DMG_MULTI_TIMEOUT_MS): it aborts
+// the communicators and returns an error instead of hanging the caller.
+static int multi_wait(dmg_multi *m, int i)
+{
+    dmg_ctx *c = m->ctx_of(i);
+    DMG_HIP(hipSetDevice(c->device));
+    const bool rccl = (m->transport == DMG_MULTI_RCCL || m->transport == DMG_MULTI_RCCL_LOOPBACK) && !m->comm.empty();
+    if (!rccl || m->dead.load()) { DMG_HIP(hipStreamSynchronize(c->stream)); return DMG_OK; }
+    const auto t0 = std::chrono::steady_clock::now();
+    ncclComm_t comm = m->comm[m->transport == DMG_MULTI_RCCL_LOOPBACK ? 0 : i];
+    for (long long spin = 0;; spin++) {
+        const hipError_t q = hipStreamQuery(c->stream);
+        if (q == hipSuccess) return DMG_OK;
+        if (q != hipErrorNotReady) return dmg_fail(DMG_EHIP, "band %d: stream failed: %s", m->first + i, hipGetErrorString(q));
+        if ((spin & 63) == 63) {
+            ncclResult_t async = ncclSuccess;
+            if (comm && ncclCommGetAsyncError(comm, &async) == ncclSuccess && async != ncclSuccess && async != ncclInProgress) {
+                multi_abort(m);
+                return dmg_fail(DMG_EHIP, "band %d: RCCL reports %s; communicators aborted", m->first + i, ncclGetErrorString(async));
+            }
+            const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+            if (ms > m->timeout_ms) {
+                multi_abort(m);
+                return dmg_fail(DMG_EHIP, "band %d: no progress for %d ms (a neighbour band has probably failed); communicators aborted "
+                                          "(DMG_MULTI_TIMEOUT_MS)", m->first + i, m->timeout_ms);
+            }
+        }
+        if (spin > 2000) std::this_thread::sleep_for(std::chrono::microseconds(20));
+        else std::this_thread::yield();
+    }
+}
+
 // ---- one halo exchange of `field` (rows deep) as seen by local band i; every band thread calls it ----
-static int band_exchange(dmg_multi *m, int i, int field, int rows, int buffer = -1)
+// `on`: the stream that carries it (default: the band's own)
+static int band_exchange(dmg_multi *m, int i, int field, int rows, int buffer = -1, hipStream_t on = nullptr)
 {
     dmg_ocean *o = m->oc[i];
     dmg_ctx *c = m->ctx_of(i);
     const int g = m->first + i;
     MTRACE("band %d: exchange field %d rows %d transport %d", g, field, rows, m->transport);
+    if (m->dead.load()) return dmg_fail(DMG_ESTATE, "this dmg_multi has lost a band: destroy it");
+    if (g == m->fail_band && ++m->n_band_exchanges[i] == m->fail_at)
+        return dmg_fail(DMG_EHIP, "band %d: failure injected in front of exchange %lld (DMG_MULTI_FAIL)", g, m->fail_at);
     DMG_HIP(hipSetDevice(c->device));
-    hipStream_t st = c->stream;
+    hipStream_t st = on ? on : c->stream;
     std::pair<hipEvent_t, hipEvent_t> ev{ nullptr, nullptr };
     if (i == 0) {                                            // band 0 times the exchange on its stream
         if (m->ev_used.size() >= 2048) { int rc = multi_fold_events(m); if (rc) return rc; }
@@ -192,18 +256,24 @@ static int band_exchange(dmg_multi *m, int i, int field, int rows, int buffer = 
     };
     int rc;
     if (m->transport == DMG_MULTI_RCCL) {
-        // grouped sends and receives on this band's stream; RCCL pairs them with the neighbour's calls
+        // grouped sends and receives on this band's stream; RCCL pairs them with the neighbour's calls.  Whatever happens
+        // inside the group, the group is closed: a thread left in group mode would have its later RCCL calls deferred
         DMG_NCCL(ncclGroupStart());
-        for (int side = 0; side < 2; side++) {
+        ncclResult_t first = ncclSuccess;
+        rc = DMG_OK;
+        for (int side = 0; side < 2 && !rc && first == ncclSuccess; side++) {
             const int peer = side == DMG_SIDE_SOUTH ? g - 1 : g + 1;
             if (peer < 0 || peer >= m->world) continue;
             void *send, *recv; size_t bytes;
-            if ((rc = slab(o, side, &send, &recv, &bytes))) { (void)ncclGroupEnd(); return rc; }
-            DMG_NCCL(ncclSend(send, bytes / 4, ncclFloat, peer, m->comm[i], st));
-            DMG_NCCL(ncclRecv(recv, bytes / 4, ncclFloat, peer, m->comm[i], st));
+            if ((rc = slab(o, side, &send, &recv, &bytes))) break;
+            first = ncclSend(send, bytes / 4, ncclFloat, peer, m->comm[i], st);
+            if (first == ncclSuccess) first = ncclRecv(recv, bytes / 4, ncclFloat, peer, m->comm[i], st);
             if (i == 0) m->exchange_bytes += 2 * (long long)bytes;
         }
-        DMG_NCCL(ncclGroupEnd());
+        const ncclResult_t closed = ncclGroupEnd();
+        if (rc) return rc;
+        if (first != ncclSuccess || closed != ncclSuccess)
+            return dmg_fail(DMG_EHIP, "band %d: RCCL send/recv failed: %s", g, ncclGetErrorString(first != ncclSuccess ? first : closed));
     } else if (m->transport == DMG_MULTI_RCCL_LOOPBACK) {
         // every band on one stream, one communicator of size 1: once every band's thread has enqueued its block, band 0's
         // thread walks the boundaries and sends each slab to the process's own rank (send and receive of a pair are
@@ -211,19 +281,21 @@ static int band_exchange(dmg_multi *m, int i, int field, int rows, int buffer = 
         TEAM_BARRIER(m);
         if (i == 0) {
             DMG_NCCL(ncclGroupStart());
-            for (int b = 0; b + 1 < m->n; b++) {
+            ncclResult_t first = ncclSuccess;
+            rc = DMG_OK;
+            for (int b = 0; b + 1 < m->n && !rc && first == ncclSuccess; b++) {
                 void *s_lo, *r_lo, *s_hi, *r_hi; size_t by;
-                if ((rc = slab(m->oc[b], DMG_SIDE_NORTH, &s_lo, &r_lo, &by)) || (rc = slab(m->oc[b + 1], DMG_SIDE_SOUTH, &s_hi, &r_hi, &by))) {
-                    (void)ncclGroupEnd();
-                    return rc;
-                }
-                DMG_NCCL(ncclSend(s_lo, by / 4, ncclFloat, 0, m->comm[0], st));      // band b's top rows ...
-                DMG_NCCL(ncclRecv(r_hi, by / 4, ncclFloat, 0, m->comm[0], st));      // ... into band b+1's south ghost
-                DMG_NCCL(ncclSend(s_hi, by / 4, ncclFloat, 0, m->comm[0], st));
-                DMG_NCCL(ncclRecv(r_lo, by / 4, ncclFloat, 0, m->comm[0], st));
+                if ((rc = slab(m->oc[b], DMG_SIDE_NORTH, &s_lo, &r_lo, &by)) || (rc = slab(m->oc[b + 1], DMG_SIDE_SOUTH, &s_hi, &r_hi, &by))) break;
+                first = ncclSend(s_lo, by / 4, ncclFloat, 0, m->comm[0], st);                               // band b's top rows ...
+                if (first == ncclSuccess) first = ncclRecv(r_hi, by / 4, ncclFloat, 0, m->comm[0], st);     // ... into band b+1's south ghost
+                if (first == ncclSuccess) first = ncclSend(s_hi, by / 4, ncclFloat, 0, m->comm[0], st);
+                if (first == ncclSuccess) first = ncclRecv(r_lo, by / 4, ncclFloat, 0, m->comm[0], st);
                 m->exchange_bytes += 2 * (long long)by;
             }
-            DMG_NCCL(ncclGroupEnd());
+            const ncclResult_t closed = ncclGroupEnd();
+            if (rc) return rc;
+            if (first != ncclSuccess || closed != ncclSuccess)
+                return dmg_fail(DMG_EHIP, "RCCL loopback send/recv failed: %s", ncclGetErrorString(first != ncclSuccess ? first : closed));
         }
         TEAM_BARRIER(m);
     } else {
@@ -254,6 +326,41 @@ static int band_exchange(dmg_multi *m, int i, int field, int rows, int buffer = 
     return DMG_OK;
 }
 
+// A block whose last launch is split: the edge units of that launch and the exchange behind them on the band's second
+// stream, the interior units on the band's own stream at the same time; the own stream waits for the exchange in front of
+// the next block.
+static int band_block_overlapped(dmg_multi *m, int i, int field, int rows, int n)
+{
+    dmg_ocean *o = m->oc[i];
+    dmg_ctx *c = m->ctx_of(i);
+    int rc;
+    DMG_HIP(hipSetDevice(c->device));
+    hipStream_t cs = m->comm_stream[m->shared_ctx ? 0 : i];
+    if ((rc = ocean_jacobi_sweeps_begin(o, n, cs))) return rc;             // launches 1 .. m-1 (own stream), edge units of launch m (second stream)
+    if (!o->pending.active) {
+        // the launch was issued whole on the own stream (its shape is still being tuned, or it has no blocked form): the
+        // exchange waits for it
+        DMG_HIP(hipEventRecord(m->ev_edge[i], c->stream));
+        DMG_HIP(hipStreamWaitEvent(cs, m->ev_edge[i], 0));
+    }
+    if (!m->shared_ctx) {
+        if ((rc = band_exchange(m, i, field, rows, -1, cs))) return rc;   // behind the edge units
+        DMG_HIP(hipEventRecord(m->ev_xchg[i], cs));
+        if ((rc = dmg_ocean_jacobi_sweeps_end(o))) return rc;             // interior units: own stream, meanwhile
+        DMG_HIP(hipStreamWaitEvent(c->stream, m->ev_xchg[i], 0));         // the next block reads the refreshed ghost rows
+        return DMG_OK;
+    }
+    // loopback: every band on one pair of streams.  band_exchange (band 0's thread, between two barriers) queues the whole
+    // exchange behind every band's edge units; band 0 orders the streams once everybody has queued its interior units
+    if ((rc = band_exchange(m, i, field, rows, -1, cs))) return rc;
+    if (i == 0) DMG_HIP(hipEventRecord(m->ev_xchg[0], cs));
+    if ((rc = dmg_ocean_jacobi_sweeps_end(o))) return rc;
+    TEAM_BARRIER(m);                                                       // every band's interior units are queued
+    if (i == 0) DMG_HIP(hipStreamWaitEvent(c->stream, m->ev_xchg[0], 0));
+    TEAM_BARRIER(m);                                                       // nobody queues the next block in front of that wait
+    return DMG_OK;
+}
+
 // max over all bands of a per-band integer (the advect reach): one ncclAllReduce, or the host when one process holds all
 static int band_allreduce_max(dmg_multi *m, int i, int *value, std::vector<int> &scratch)
 {
@@ -263,8 +370,7 @@ static int band_allreduce_max(dmg_multi *m, int i, int *value, std::vector<int> 
         DMG_HIP(hipMemcpyAsync(m->d_red[i], value, sizeof(int), hipMemcpyHostToDevice, c->stream));
         DMG_NCCL(ncclAllReduce(m->d_red[i], m->d_red[i], 1, ncclInt, ncclMax, m->comm[i], c->stream));
         DMG_HIP(hipMemcpyAsync(value, m->d_red[i], sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        DMG_HIP(hipStreamSynchronize(c->stream));
-        return DMG_OK;
+        return multi_wait(m, i);
     }
     scratch[i] = *value;                                     // one process: the bands meet on the host
     TEAM_BARRIER(m);
@@ -292,11 +398,12 @@ static int band_jacobi(dmg_multi *m, int i, int iters, int zero_first)
             if ((rc = band_exchange(m, i, DMG_F_PRESSURE, m->ghost))) return rc;
             if ((rc = dmg_ocean_jacobi_sweeps(o, n))) return rc;
         } else if (done + n < iters) {
-            // the rows the neighbours wait for exist once the edge units of the block's last launch have run: they
-            // travel while the interior units are swept (dmg_ocean_jacobi_sweeps_begin/_end)
-            if ((rc = dmg_ocean_jacobi_sweeps_begin(o, n))) return rc;
-            if ((rc = band_exchange(m, i, DMG_F_PRESSURE, m->ghost))) return rc;
-            if ((rc = dmg_ocean_jacobi_sweeps_end(o))) return rc;
+            // the rows the neighbours wait for exist once the edge units of the block's last launch have run: those units
+            // and the exchange behind them go to the band's second, high-priority stream, the interior units run on the
+            // band's own stream at the same time -- they read the previous iterate and write neither the rows in flight
+            // nor the ghost rows being filled -- and the own stream waits for the exchange only in front of the next
+            // block.  (Filter.cpp:125-166: still one worker per band.)
+            if ((rc = band_block_overlapped(m, i, DMG_F_PRESSURE, m->ghost, n))) return rc;
         } else if ((rc = dmg_ocean_jacobi_sweeps(o, n))) return rc;
         done += n;
     }
@@ -350,6 +457,10 @@ static void multi_free(dmg_multi *m)
     }
     for (hipEvent_t e : m->ev_done) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : m->ev_copied) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : m->ev_edge) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : m->ev_xchg) if (e) (void)hipEventDestroy(e);
+    for (size_t i = 0; i < m->comm_stream.size(); i++)
+        if (m->comm_stream[i]) { (void)hipSetDevice(m->ctx_of((int)i)->device); (void)hipStreamSynchronize(m->comm_stream[i]); (void)hipStreamDestroy(m->comm_stream[i]); }
     for (ncclComm_t c : m->comm) if (c) (void)ncclCommDestroy(c);
     for (dmg_ctx *c : m->ctx) if (c) dmg_destroy(c);
     delete m;
@@ -361,6 +472,35 @@ static int multi_common(dmg_multi *m, const dmg_grid *grid, const dmg_ocean_para
     if (params) m->prm = *params; else dmg_ocean_params_default(&m->prm);
     m->ghost = ghost;
     m->order = (flags & DMG_MULTI_OVERLAP_LAST_LAUNCH) ? DMG_MULTI_OVERLAP_LAST_LAUNCH : DMG_MULTI_EXCHANGE_THEN_SWEEP;
+    if (const char *e = getenv("DMG_MULTI_TIMEOUT_MS")) { const int v = atoi(e); if (v > 0) m->timeout_ms = v; }
+    if (const char *e = getenv("DMG_MULTI_FAIL")) {          // tests: "<band>:<n>"
+        int b = -1; long long k = 0;
+        if (sscanf(e, "%d:%lld", &b, &k) == 2 && b >= 0 && k > 0) { m->fail_band = b; m->fail_at = k; }
+    }
+    return DMG_OK;
+}
+
+// the second stream of every local band (one in all for the loopback transport) and its events; the failure hook
+static int multi_streams(dmg_multi *m)
+{
+    const int ns = m->shared_ctx ? 1 : m->n;
+    m->comm_stream.assign((size_t)ns, nullptr); m->ev_edge.assign((size_t)m->n, nullptr); m->ev_xchg.assign((size_t)m->n, nullptr);
+    m->n_band_exchanges.assign((size_t)m->n, 0);
+    for (int i = 0; i < m->n; i++) {
+        DMG_HIP(hipSetDevice(m->ctx_of(i)->device));
+        if (i < ns) {
+            int lo = 0, hi = 0;
+            DMG_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));  // (hi = greatest priority, numerically lowest)
+            static const bool normal = [] { const char *e = getenv("DMG_MULTI_COMM_PRIORITY"); return e && atoi(e) == 0; }();   // experiments
+            DMG_HIP(hipStreamCreateWithPriority(&m->comm_stream[i], hipStreamNonBlocking, normal ? lo : hi));
+        }
+        // experiments (DMG_MULTI_EVENT_FLAGS=2): the join event with an agent-scope release too.  The default keeps the
+        // system-scope release: what it orders was written by a neighbour GPU or a copy engine
+        static const int evf = [] { const char *e = getenv("DMG_MULTI_EVENT_FLAGS"); return e ? atoi(e) : 1; }();
+        DMG_HIP(hipEventCreateWithFlags(&m->ev_edge[i], hipEventDisableTiming));
+        DMG_HIP(hipEventCreateWithFlags(&m->ev_xchg[i], hipEventDisableTiming | (evf >= 2 ? hipEventReleaseToDevice : 0)));
+    }
+    m->team.on_fail = [m](int) { multi_abort(m); };
     return DMG_OK;
 }
 
@@ -428,6 +568,7 @@ int dmg_multi_create(int n_bands, const int *device_ids, const dmg_grid *grid, c
         DMG_HIP(hipSetDevice(device_ids[0]));
         DMG_NCCL(ncclCommInitAll(m->comm.data(), 1, device_ids));
     }
+    if ((rc = multi_streams(m.get()))) return rc;
     // one host thread per band, like the reference's one worker per filter
     m->team.start(n_bands);
     *out = m.release();
@@ -457,6 +598,7 @@ int dmg_multi_create_rank(int rank, int n_ranks, const void *id128, int device_i
         m->comm.assign(1, nullptr);
         DMG_NCCL(ncclCommInitRank(&m->comm[0], n_ranks, id, rank));
     }
+    if ((rc = multi_streams(m.get()))) return rc;
     m->team.start(1);
     *out = m.release();
     return DMG_OK;
@@ -498,17 +640,19 @@ int dmg_multi_generate_terrain(dmg_multi *m, const dmg_noise_params *params)
     MULTI_FOR_BANDS(dmg_ocean_generate_terrain(o, params));
 }
 int dmg_multi_get(dmg_multi *m, float *vx, float *vy, float *pressure, float *divw) { MULTI_FOR_BANDS(dmg_ocean_get(o, vx, vy, pressure, divw)); }
-int dmg_multi_sync(dmg_multi *m) { MULTI_FOR_BANDS(dmg_sync(m->ctx_of(i))); }
+int dmg_multi_sync(dmg_multi *m) { MULTI_FOR_BANDS(multi_wait(m, i)); }
 
 int dmg_multi_jacobi(dmg_multi *m, int iters, int zero_first)
 {
     DMG_CHECK_ARG(m != nullptr && iters >= 0);
+    if (m->dead.load()) return dmg_fail(DMG_ESTATE, "this dmg_multi has lost a band: destroy it");
     return m->team.run([&](int i) { return band_jacobi(m, i, iters, zero_first); });
 }
 
 int dmg_multi_step(dmg_multi *m, int n_outer)
 {
     DMG_CHECK_ARG(m != nullptr && n_outer >= 0);
+    if (m->dead.load()) return dmg_fail(DMG_ESTATE, "this dmg_multi has lost a band: destroy it");
     std::vector<int> scratch((size_t)m->n, 0);
     return m->team.run([&](int i) { return band_step(m, i, n_outer, scratch); });
 }

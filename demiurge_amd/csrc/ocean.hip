@@ -302,6 +302,7 @@ void dmg_ocean_destroy(dmg_ocean *o)
                      (void *)o->v[0], (void *)o->v[1], (void *)o->rowtab, (void *)o->jcoef, (void *)o->jcoefp, (void *)o->jcoef2, (void *)o->rowbad, (void *)o->oob_flag, (void *)o->rowclass, (void *)o->rowclass_n, (void *)o->rowclass32 })
         if (p) (void)hipFree(p);
     ocean_tb_free_lists(o);
+    if (o->ev_fork) (void)hipEventDestroy(o->ev_fork);
     dmg_ctx *ctx = o->ctx;
     delete o;
     dmg_ctx_release(ctx);
@@ -409,7 +410,14 @@ int dmg_ocean_jacobi_sweeps(dmg_ocean *o, int n)
 //           nor write the rows being sent.
 // Both parts belong to one tiling of the same launch: results are bit-identical to dmg_ocean_jacobi_sweeps(o, n).
 // Without the blocked kernel (or with a single band) _begin does the whole block and _end nothing.
-int dmg_ocean_jacobi_sweeps_begin(dmg_ocean *o, int n)
+int dmg_ocean_jacobi_sweeps_begin(dmg_ocean *o, int n) { return ocean_jacobi_sweeps_begin(o, n, nullptr); }
+
+// edge_stream: the stream that carries the edge units of the block's last launch (null: the context's).  On a stream of
+// its own the edge part starts together with the interior part (dmg_ocean_jacobi_sweeps_end, on the context's stream) as soon
+// as the block's launch before it is done -- both read the previous iterate and write disjoint rows of the new one -- so the
+// split costs no chip time, and whatever the caller queues behind the edge part on that stream (the halo exchange) runs
+// while the interior is still being swept.
+extern "C++" int ocean_jacobi_sweeps_begin(dmg_ocean *o, int n, hipStream_t edge_stream)
 {
     DMG_CHECK_ARG(o != nullptr && n >= 0);
     if (!o->have_terrain) return dmg_fail(DMG_ESTATE, "dmg_ocean_set_terrain must come first");
@@ -436,7 +444,14 @@ int dmg_ocean_jacobi_sweeps_begin(dmg_ocean *o, int n)
         o->n_launches++; o->n_sweeps += last;
         return DMG_OK;
     }
-    rc = ocean_launch_tb(o, lo, hi, last, 1, zone_lo, zone_hi);
+    if (edge_stream && edge_stream != o->ctx->stream) {
+        // (kernel -> kernel on one device: an agent-scope release is all the edge units need)
+        static const int evf = [] { const char *e = getenv("DMG_MULTI_EVENT_FLAGS"); return e ? atoi(e) : 1; }();
+        if (!o->ev_fork) DMG_HIP(hipEventCreateWithFlags(&o->ev_fork, hipEventDisableTiming | (evf >= 1 ? hipEventReleaseToDevice : 0)));
+        DMG_HIP(hipEventRecord(o->ev_fork, o->ctx->stream));             // everything this launch reads has been written
+        DMG_HIP(hipStreamWaitEvent(edge_stream, o->ev_fork, 0));
+    }
+    rc = ocean_launch_tb(o, lo, hi, last, 1, zone_lo, zone_hi, -1, edge_stream);
     if (rc) return rc;
     o->pending.active = true;
     o->pending.lo = lo; o->pending.hi = hi; o->pending.n = last; o->pending.zone_lo = zone_lo; o->pending.zone_hi = zone_hi;

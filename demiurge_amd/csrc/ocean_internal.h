@@ -66,6 +66,7 @@ struct dmg_ocean {
     int vcur = 0;
     // dmg_ocean_jacobi_sweeps_begin/_end: the interior part of a block's last launch, still to be issued
     struct { bool active = false; int lo = 0, hi = 0, n = 0, zone_lo = 0, zone_hi = 0; } pending;
+    hipEvent_t ev_fork = nullptr;  // ocean_jacobi_sweeps_begin with an edge stream: the launch before the split one is done
     int *oob_flag = nullptr;       // device word: advect out-of-band flag / reduction scratch
     float *rowtab = nullptr;       // ROWTAB_FIELDS arrays of L floats
     float *jcoefp = nullptr;       // [L + 32][4] = cx, 1/cx, Beta, 1/Beta of local rows -16 .. L+15, rows beyond the grid mirrored (scalar loads, no mapping)
@@ -92,6 +93,7 @@ static inline int no_pending(const dmg_ocean *o, const char *what)
 }
 
 int ocean_upload_row_tables(dmg_ocean *o);
+int ocean_jacobi_sweeps_begin(dmg_ocean *o, int n, hipStream_t edge_stream);   // dmg_ocean_jacobi_sweeps_begin with the edge units on a stream of their own (ocean.hip)
 int ocean_build_codes(dmg_ocean *o);
 int ocean_build_codes8(dmg_ocean *o);
 int ocean_zero_land(dmg_ocean *o);            // p := +0 on land in BOTH ping-pong buffers (invariant of the blocked kernel)

@@ -68,6 +68,7 @@ struct st_args {
     int nseg0, cap;
     const unsigned *rowclass32;     // rowclass, one 32-bit word per entry
     unsigned long long *prof;       // experiments only (DMG_ST_PROF): {start, end} of every unit on the 100 MHz s_memrealtime clock, or null
+    unsigned long long *stepprof;   // experiments only (-DST_EXPERIMENTS, DMG_ST_STEPPROF): s_memrealtime at the top of the first 64 steps of every unit
     int dbg;                        // experiments only (DMG_ST_DBG bits): 1 = every unit re-reads 64 rows (cache hits), 2 = no stores, 4 = plain instead of nontemporal stores;
                                     // persistent form: 8 = owners do not re-read their end row, 16 = no stealing, 32 = owners do not publish progress,
                                     // 64 = row classes from the table instead of from the codes, 128 = no coefficient refills (timing only: wrong results)
@@ -476,6 +477,10 @@ __global__ __launch_bounds__(64, 2) void k_jacobi_stream(st_args a)
     int colp = col + W / 2; if (colp >= W) colp -= W;
     const bool lane_ok = (lane >= TB_T / 4) && (lane < 64 - TB_T / 4) && (xcol < W);
 
+    // (Measured and dropped, round 3: requesting the window's next 8 .. 32 rows up front -- LDS-DMA loads into a scrap of
+    // LDS -- so that the pipeline's own requests hit the L2 while it fills.  Bit-identical, and slower: a 16384 x 1024 band's
+    // launch went from 67 to 71 / 74 / 80 us.  A unit's fixed cost is not memory latency: with every load pointed at cached
+    // rows and the stores dropped the same launch still takes 58 us; see DESIGN.md 4.1b, "what a unit's first steps cost".)
     // the first two steps' rows are requested before anything else: their round trip covers the tables' below
     st_state z;
     st_fetch<false>(a, z, 0, 0, e0, col, colp);
@@ -516,10 +521,16 @@ __global__ __launch_bounds__(64, 2) void k_jacobi_stream(st_args a)
         z.cy = cf[4]; z.ry = cf[5];
     }
     for (int t = 0; t < nsteps; t += 2) {
+#ifdef ST_EXPERIMENTS
+        if (a.stepprof && lane == 0 && t < 126) a.stepprof[(size_t)blockIdx.x * 64 + t / 2] = __builtin_amdgcn_s_memrealtime();
+#endif
         st_step<0, false, DV>(a, z, bring, cring, ktab, lane, t, e0, nsteps, r1, cls_lo, cls_hi, col, colp, lane_ok, xcol);
         st_step<1, false, DV>(a, z, bring, cring, ktab, lane, t + 1, e0, nsteps, r1, cls_lo, cls_hi, col, colp, lane_ok, xcol);
     }
     if (a.prof && lane == 0) a.prof[3 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+#ifdef ST_EXPERIMENTS
+    if (a.stepprof && lane == 0) a.stepprof[(size_t)blockIdx.x * 64 + 63] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // =================================================================================================================
@@ -921,7 +932,7 @@ static int st_unit_rows()                                 // DMG_ST_ROWS=<n>: fi
     static const int rows = [] {
         const char *e = getenv("DMG_ST_ROWS");
         int v = e ? atoi(e) : 0;
-        return v >= 8 && v <= ST_MAXROWS ? v : 0;
+        return v >= 1 && v <= ST_MAXROWS ? v : 0;
     }();
     return rows;
 }
@@ -1296,6 +1307,13 @@ int ocean_launch_stream(dmg_ocean *o, int lo, int hi, int part, int zone_lo, int
     static const int dbg = [] { const char *e = getenv("DMG_ST_DBG"); return e ? atoi(e) : 0; }();
     a.dbg = dbg;
     a.prof = nullptr;
+    a.stepprof = nullptr;
+#ifdef ST_EXPERIMENTS
+    static const char *stepprof_path = getenv("DMG_ST_STEPPROF");
+    static int stepprof_count = 0;
+    const bool stepprof_now = stepprof_path && !variant && tl->n > 1024 && ++stepprof_count == 40;    // the 40th full-size launch
+    if (stepprof_now && (hipMalloc((void **)&a.stepprof, (size_t)tl->n * 64 * 8) != hipSuccess || hipMemset(a.stepprof, 0, (size_t)tl->n * 64 * 8) != hipSuccess)) a.stepprof = nullptr;
+#endif
     static const char *prof_path = getenv("DMG_ST_PROF");  // experiments: the first full-size launch writes one line per unit to this file
     static bool prof_done = false;
     const bool prof_now = prof_path && !prof_done && !variant && tl->n > 1024;
@@ -1327,6 +1345,18 @@ int ocean_launch_stream(dmg_ocean *o, int lo, int hi, int part, int zone_lo, int
     else if (div2) hipLaunchKernelGGL(k_jacobi_stream<1>, dim3((unsigned)tl->n), dim3(64), (size_t)extra_lds, st, a);
     else hipLaunchKernelGGL(k_jacobi_stream<0>, dim3((unsigned)tl->n), dim3(64), (size_t)extra_lds, st, a);
     DMG_HIP(hipGetLastError());
+#ifdef ST_EXPERIMENTS
+    if (a.stepprof) {
+        std::vector<unsigned long long> tt((size_t)tl->n * 64);
+        DMG_HIP(hipStreamSynchronize(st));
+        DMG_HIP(hipMemcpy(tt.data(), a.stepprof, tt.size() * 8, hipMemcpyDeviceToHost));
+        (void)hipFree(a.stepprof);
+        if (FILE *f = fopen(stepprof_path, "w")) {
+            for (int i = 0; i < tl->n; i++) { for (int k = 0; k < 64; k++) fprintf(f, "%llu%c", tt[(size_t)i * 64 + k], k == 63 ? '\n' : ','); }
+            fclose(f);
+        }
+    }
+#endif
     if (prof_now && a.prof) {
         prof_done = true;
         std::vector<unsigned long long> tt((size_t)tl->n * 3);

@@ -503,7 +503,10 @@ int ocean_launch_tb(dmg_ocean *o, int lo, int hi, int n, int part, int zone_lo, 
         const int tiles88 = ((a.W + TB_OW - 1) / TB_OW) * ((hi - lo + 47) / 48);
         // thousands of tiles: the chip is full either way and the streaming kernel does the least work
         sh = stream_ok ? tb_shape{ -1000, -1 } : tb_shape{ 8, 8 };   // -1000: the streaming kernel's default unit height
-        if (tiles88 <= 4096 && n == TB_T && a.rowclass) {
+        // (a band of a split grid does not time candidates: its launches share the GPU with its second stream's edge units
+        // and exchanges -- and on a one-GPU rehearsal with the other bands -- so the timings mean nothing; and the tile shapes
+        // only win on grids too small to be worth splitting)
+        if (tiles88 <= 4096 && n == TB_T && a.rowclass && o->count == 1) {
             tune = &o->tb_tuning[std::make_pair(lo, hi)];
             if (tune->chosen < 0 && !part) {
                 if (!tune->ev0 && (hipEventCreate(&tune->ev0) != hipSuccess || hipEventCreate(&tune->ev1) != hipSuccess))
@@ -570,7 +573,7 @@ bool ocean_tb_tuning_open(dmg_ocean *o, int lo, int hi)
 {
     if (tb_forced_shape().R) return false;
     static const bool use_cls = getenv("DMG_TB_NOCLASS") == nullptr;
-    if (!use_cls || !o->rowclass) return false;
+    if (!use_cls || !o->rowclass || o->count > 1) return false;
     const int tiles88 = ((o->grid.W + TB_OW - 1) / TB_OW) * ((hi - lo + 47) / 48);
     if (tiles88 > 4096) return false;
     auto it = o->tb_tuning.find(std::make_pair(lo, hi));

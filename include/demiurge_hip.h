@@ -222,7 +222,10 @@ int dmg_ocean_advect_reach(dmg_ocean *o, int *rows);
 int dmg_ocean_get(dmg_ocean *o, float *vx, float *vy, float *pressure, float *divw);
 
 /* Checkpoint / resume (the reference has none; its solve runs 10000 outer steps, :155): the band's owned rows of
- * v, pressure and divw as NumPy files <prefix>.v.npy (rows,W,2), <prefix>.pressure.npy, <prefix>.divw.npy. */
+ * v, pressure and divw as NumPy files <prefix>.gN.v.npy (rows,W,2), <prefix>.gN.pressure.npy, <prefix>.gN.divw.npy of a
+ * generation N, and a sidecar <prefix>.meta that names the generation a restore reads.  A checkpoint writes generation
+ * N + 1 beside N, replaces the sidecar with one rename and then removes N: a crash at any point leaves a complete set.
+ * A restore that fails (missing or truncated file, another canvas) leaves the handle unchanged. */
 int dmg_ocean_checkpoint(dmg_ocean *o, const char *prefix);
 int dmg_ocean_restore(dmg_ocean *o, const char *prefix);      /* after dmg_ocean_set_terrain, same grid and band */
 

@@ -227,9 +227,10 @@ def test_checkpoint_resume(dev, tmp_path):
     b.checkpoint(tmp_path / "ck")
     mid = b.get()
     b.close()
-    v = np.load(tmp_path / "ck.v.npy")                      # plain NumPy files
+    v = np.load(tmp_path / "ck.g1.v.npy")                   # plain NumPy files, generation 1
     assert v.shape == (H, W, 2) and v.dtype == np.float32 and np.array_equal(v, mid["v"])
-    assert np.array_equal(np.load(tmp_path / "ck.pressure.npy"), mid["pressure"])
+    assert np.array_equal(np.load(tmp_path / "ck.g1.pressure.npy"), mid["pressure"])
+    assert "generation 1" in (tmp_path / "ck.meta").read_text()
     c = capi.Ocean(ctx, grid, params=prm)
     c.set_terrain(img)
     c.restore(tmp_path / "ck")
@@ -243,6 +244,29 @@ def test_checkpoint_resume(dev, tmp_path):
     with pytest.raises(capi.DmgError):
         d.restore(tmp_path / "ck")                          # shape mismatch is refused
     d.close()
+    # a checkpoint never damages the one before it.  A second checkpoint writes generation 2, flips the sidecar,
+    # removes generation 1; a crash in the middle of a third (its arrays half written, the sidecar not yet replaced)
+    # leaves generation 2 restorable; a restore that fails leaves the handle as it was.
+    e = capi.Ocean(ctx, grid, params=prm)
+    e.set_terrain(img)
+    e.restore(tmp_path / "ck")
+    e.step(1)
+    e.checkpoint(tmp_path / "ck")
+    names = sorted(f.name for f in tmp_path.iterdir() if f.name.startswith("ck."))
+    assert names == ["ck.g2.divw.npy", "ck.g2.pressure.npy", "ck.g2.v.npy", "ck.meta"], names
+    (tmp_path / "ck.g3.v.npy").write_bytes(b"\x93NUMPY half a file")          # the crash
+    (tmp_path / "ck.g3.pressure.npy.tmp").write_bytes(b"junk")
+    f2 = capi.Ocean(ctx, grid, params=prm)
+    f2.set_terrain(img)
+    f2.restore(tmp_path / "ck")
+    assert all(np.array_equal(f2.get()[k], ref[k]) for k in ("vx", "vy", "pressure", "divw"))       # generation 2 = two outer steps
+    before = f2.get()
+    (tmp_path / "ck.g2.divw.npy").write_bytes((tmp_path / "ck.g2.divw.npy").read_bytes()[:1000])     # truncated array
+    with pytest.raises(capi.DmgError):
+        f2.restore(tmp_path / "ck")
+    after = f2.get()
+    assert all(np.array_equal(before[k], after[k]) for k in before)                                  # untouched
+    e.close(); f2.close()
 
 
 @pytest.mark.gpu

@@ -1,7 +1,12 @@
 """The 16384x8192 solve split into n latitude bands that all live on GPU 0 (dmg_multi, peer copies): what banding itself
 costs -- ghost-row redundancy, small launches, the exchange's synchronisation -- before any xGMI traffic.
-usage: python tools/bands_one_gpu.py [sweeps]"""
-import sys, time
+usage: python tools/bands_one_gpu.py [sweeps [transport]]      transport: peer (default) | loopback (RCCL to the process's own rank)
+Both exchange orders for every split: "overlap" puts the exchange on each band's second (high-priority) stream between the
+two halves of the block's last launch.  All bands share one GPU here, so 2 n streams compete for its hardware queues:
+GPU_MAX_HW_QUEUES is raised to 8 unless the caller has set it (with HIP's default of 4 the streams of different bands are
+multiplexed onto one queue and serialise)."""
+import os, sys, time
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import numpy as np
 sys.path.insert(0, ".")
 from demiurge_amd import capi, synth
@@ -10,8 +15,10 @@ W, H = 16384, 8192
 sweeps = int(sys.argv[1]) if len(sys.argv) > 1 else 1600
 grid = capi.make_grid(W, H)
 terrain, divw = synth.terrain(W, H), synth.divw(W, H)
-for n, ghost, order in ((1, 32, 0), (2, 32, 0), (2, 64, 0), (4, 32, 0), (4, 64, 0), (8, 32, 0), (8, 64, 0), (8, 128, 0), (8, 64, 1)):
-    flags = capi.MULTI_PEER | (capi.MULTI_OVERLAP_LAST_LAUNCH if order else capi.MULTI_EXCHANGE_THEN_SWEEP)
+transport = capi.MULTI_RCCL_LOOPBACK if (len(sys.argv) > 2 and sys.argv[2] == "loopback") else capi.MULTI_PEER
+for n, ghost, order in ((1, 32, 0), (2, 32, 0), (2, 32, 1), (2, 64, 0), (2, 64, 1), (4, 32, 0), (4, 32, 1), (4, 64, 0), (4, 64, 1), (8, 32, 0), (8, 32, 1),
+                        (8, 64, 0), (8, 64, 1), (8, 128, 0), (8, 128, 1)):
+    flags = transport | (capi.MULTI_OVERLAP_LAST_LAUNCH if order else capi.MULTI_EXCHANGE_THEN_SWEEP)
     m = capi.Multi(grid, devices=[0] * n, ghost=ghost, params=capi.default_ocean_params(), flags=flags)
     m.set_terrain(terrain); m.set_divw(divw)
     m.jacobi(sweeps, zero_first=True); m.sync()
