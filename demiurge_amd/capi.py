@@ -225,6 +225,13 @@ def lib():
         "dmg_multi_band_count": (c_int, [vp]),
         "dmg_multi_band": (c_int, [vp, c_int, ctypes.POINTER(vp)]),
         "dmg_multi_get_stats": (c_int, [vp, ctypes.POINTER(MultiStats)]),
+        "dmg_multi_climate_create": (c_int, [c_int, ctypes.POINTER(c_int), PG, vp, vp, c_int, c_int, ctypes.POINTER(vp)]),
+        "dmg_multi_climate_create_rank": (c_int, [c_int, c_int, vp, c_int, PG, vp, vp, c_int, c_int, ctypes.POINTER(vp)]),
+        "dmg_multi_climate_destroy": (None, [vp]),
+        "dmg_multi_climate_steps": (c_int, [vp, c_int, c_int]),
+        "dmg_multi_climate_set_terrain": (c_int, [vp, vp]),
+        "dmg_multi_climate_get": (c_int, [vp, vp]),
+        "dmg_multi_climate_sync": (c_int, [vp]),
         "dmg_multi_timer_start": (c_int, [vp]),
         "dmg_multi_timer_stop": (c_int, [vp, ctypes.POINTER(c_float)]),
     }
@@ -246,8 +253,17 @@ def _f32(a):
     return a
 
 
+class _Ptr(ctypes.c_void_p):
+    """the address of a NumPy array, holding the array: `_p(_f32(x))` may have made a contiguous copy that nothing else
+    refers to, and a bare integer address would let it be collected before the C call reads it"""
+
+
 def _p(a):
-    return None if a is None else a.ctypes.data
+    if a is None:
+        return None
+    r = _Ptr(a.ctypes.data)
+    r._keep = a
+    return r
 
 
 class Context:
@@ -417,6 +433,50 @@ class Climate:
         if self.h:
             lib().dmg_climate_destroy(self.h)
             self.h = None
+
+
+class MultiClimate:
+    """dmg_multi_climate: the climate year cycle over latitude bands driven by the library (threads, streams and
+    transports of dmg_multi).  devices=[...]: one process drives the bands; rank/world/unique_id: one process per GPU."""
+
+    def __init__(self, grid, T, terrain, devices=None, ghost=8, flags=MULTI_AUTO, rank=None, world=None, unique_id=None, device=0):
+        T, terrain = _f32(T), _f32(terrain)
+        self.shape = T.shape
+        h = ctypes.c_void_p()
+        if devices is not None:
+            ids = (ctypes.c_int * len(devices))(*devices)
+            check(lib().dmg_multi_climate_create(len(devices), ids, ctypes.byref(grid), _p(T), _p(terrain), ghost, flags, ctypes.byref(h)))
+        else:
+            buf = ctypes.create_string_buffer(unique_id, 128) if unique_id is not None else None
+            check(lib().dmg_multi_climate_create_rank(rank, world, buf, device, ctypes.byref(grid), _p(T), _p(terrain), ghost, flags, ctypes.byref(h)))
+        self.h = h
+
+    def steps(self, first_step, n_steps):
+        check(lib().dmg_multi_climate_steps(self.h, first_step, n_steps))
+
+    def set_terrain(self, terrain):
+        t = _f32(terrain)                                      # (held until the call returns: _p hands out a bare address)
+        check(lib().dmg_multi_climate_set_terrain(self.h, _p(t)))
+
+    def sync(self):
+        check(lib().dmg_multi_climate_sync(self.h))
+
+    def get(self, out=None):
+        if out is None:
+            out = np.zeros(self.shape, np.float32)
+        check(lib().dmg_multi_climate_get(self.h, _p(out)))
+        return out
+
+    def close(self):
+        if self.h:
+            lib().dmg_multi_climate_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Erosion:

@@ -81,6 +81,7 @@ int dmg_trim(dmg_ctx *c)
 {
     DMG_CHECK_ARG(c != nullptr);
     DMG_HIP(hipStreamSynchronize(c->stream));
+    std::lock_guard<std::mutex> lk(c->scratch_mu);
     for (auto &kv : c->scratch_pool) (void)hipFree(kv.second);
     c->scratch_pool.clear();
     c->scratch_pool_bytes = 0;
@@ -167,7 +168,9 @@ void dmg_ctx_release(dmg_ctx *ctx)
 // ---- scratch pool (see dmg_ctx::scratch_pool) ----
 hipError_t dmg_scratch_alloc(dmg_ctx *ctx, size_t bytes, void **out)
 {
+    bool parked = false;
     if (ctx) {
+        std::lock_guard<std::mutex> lk(ctx->scratch_mu);
         auto it = ctx->scratch_pool.find(bytes);
         if (it != ctx->scratch_pool.end()) {
             *out = it->second;
@@ -175,9 +178,10 @@ hipError_t dmg_scratch_alloc(dmg_ctx *ctx, size_t bytes, void **out)
             ctx->scratch_pool_bytes -= bytes;
             return hipSuccess;
         }
+        parked = !ctx->scratch_pool.empty();
     }
     hipError_t e = hipMalloc(out, bytes);
-    if (e != hipSuccess && ctx && !ctx->scratch_pool.empty()) {      // out of memory with blocks parked: release them, retry
+    if (e != hipSuccess && ctx && parked) {                          // out of memory with blocks parked: release them, retry
         (void)hipGetLastError();
         (void)dmg_trim(ctx);
         e = hipMalloc(out, bytes);
@@ -187,7 +191,13 @@ hipError_t dmg_scratch_alloc(dmg_ctx *ctx, size_t bytes, void **out)
 
 void dmg_scratch_free(dmg_ctx *ctx, void *p, size_t bytes)
 {
-    if (!ctx || ctx->scratch_pool_bytes + bytes > ctx->scratch_cap) { (void)hipFree(p); return; }   // hipFree synchronises
-    ctx->scratch_pool.emplace(bytes, p);
-    ctx->scratch_pool_bytes += bytes;
+    if (ctx) {
+        std::lock_guard<std::mutex> lk(ctx->scratch_mu);
+        if (ctx->scratch_pool_bytes + bytes <= ctx->scratch_cap) {
+            ctx->scratch_pool.emplace(bytes, p);
+            ctx->scratch_pool_bytes += bytes;
+            return;
+        }
+    }
+    (void)hipFree(p);                                                // hipFree synchronises
 }

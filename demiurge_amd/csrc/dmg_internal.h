@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "../../include/demiurge_hip.h"
@@ -38,6 +39,7 @@ struct dmg_ctx {
     // round.  One context = one stream = one caller thread at a time, so reuse is ordered by the stream itself.
     std::multimap<size_t, void *> scratch_pool;
     size_t scratch_pool_bytes = 0, scratch_cap = 0;
+    std::mutex scratch_mu;          // the loopback transport of dmg_multi runs several band threads on ONE context: the pool's bookkeeping is theirs to share
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -110,3 +112,13 @@ inline void dmg_row_pixelsize(const dmg_grid &g, int y, float *dx, float *dy)
 
 // Validates the geometry this backend supports; fills topology.
 int dmg_check_grid(const dmg_grid *g, dmg_topology *t);
+
+// device-side hand-over between the tools of a coupled run (world.hip): no host round trips between the stages
+struct dmg_erosion;
+struct dmg_climate;
+struct dmg_tectonics;
+int erosion_create_from(dmg_ctx *ctx, const dmg_grid *grid, const float *h, bool on_device, int N, float exponent, float slope_exponent, float factor,
+                        int lakes, dmg_erosion **out);
+const float *erosion_heights_device(const dmg_erosion *e);
+int climate_set_terrain_device(dmg_climate *k, const float *d_terrain);
+const float *tectonics_terrain_device(const dmg_tectonics *t);

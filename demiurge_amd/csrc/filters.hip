@@ -581,6 +581,15 @@ int dmg_climate_set_terrain(dmg_climate *k, const float *terrain)
     return DMG_OK;
 }
 
+// the same from a FULL-grid array on the climate's device, ordered on its stream (no host round trip, no synchronisation)
+extern "C++" int climate_set_terrain_device(dmg_climate *k, const float *d_terrain)
+{
+    DMG_CHECK_ARG(k != nullptr && d_terrain != nullptr);
+    DMG_HIP(hipSetDevice(k->ctx->device));
+    DMG_HIP(hipMemcpyAsync(k->terr.p, d_terrain + k->voff(), (size_t)k->grid.W * k->L * 4, hipMemcpyDeviceToDevice, k->ctx->stream));
+    return DMG_OK;
+}
+
 // ghost slabs of the temperature field, as dmg_ocean_halo
 int dmg_climate_halo(dmg_climate *k, int side, int rows, void **send, void **recv, size_t *bytes)
 {
@@ -654,6 +663,14 @@ struct dmg_erosion {
 int dmg_erosion_create(dmg_ctx *ctx, const dmg_grid *grid, const float *h, int N, float exponent, float slope_exponent, float factor,
                        int lakes, dmg_erosion **out)
 {
+    return erosion_create_from(ctx, grid, h, false, N, exponent, slope_exponent, factor, lakes, out);
+}
+
+// h: the terrain on the host, or (on_device) a W x H array on ctx's device, ordered on ctx's stream: a coupled driver
+// (world.hip) hands the tectonics render target over without a host round trip
+extern "C++" int erosion_create_from(dmg_ctx *ctx, const dmg_grid *grid, const float *h, bool on_device, int N, float exponent, float slope_exponent,
+                                     float factor, int lakes, dmg_erosion **out)
+{
     DMG_CHECK_ARG(ctx != nullptr && h != nullptr && N >= 1 && out != nullptr);
     *out = nullptr;
     dmg_topology topo;
@@ -670,11 +687,11 @@ int dmg_erosion_create(dmg_ctx *ctx, const dmg_grid *grid, const float *h, int N
     e->exponent = exponent; e->slope_exponent = slope_exponent; e->factor = factor; e->lakes = lakes;
     DMG_ALLOC(e->terrain, n * 4); DMG_ALLOC(e->height, n * 4); DMG_ALLOC(e->next, n * 4); DMG_ALLOC(e->updrift, n * 4); DMG_ALLOC(e->flow, n * 4);
     if ((rc = upload_rows(ctx, e->ddx, dxr)) || (rc = upload_rows(ctx, e->ddy, dyr))) return rc;
-    DMG_HIP(hipMemcpyAsync(e->terrain.p, h, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    DMG_HIP(hipMemcpyAsync(e->terrain.p, h, n * 4, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_erosion_prepare, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, e->terrain.f(), e->updrift.f(),
                        e->height.f(), (float)N, n);
     DMG_HIP(hipGetLastError());
-    DMG_HIP(hipStreamSynchronize(ctx->stream));      // the caller's buffer may go away
+    if (!on_device) DMG_HIP(hipStreamSynchronize(ctx->stream));      // the caller's buffer may go away
     e->cur = e->height.f(); e->nxt = e->next.f();
     dmg_ctx_retain(ctx);
     *out = e.release();
@@ -704,6 +721,8 @@ int dmg_erosion_rounds(dmg_erosion *e, int n_rounds)
     }
     return DMG_OK;
 }
+
+extern "C++" const float *erosion_heights_device(const dmg_erosion *e) { return e->cur; }    // the scaled heights of the current round, on the device
 
 int dmg_erosion_get(dmg_erosion *e, float *h)
 {

@@ -145,7 +145,8 @@ struct dmg_multi {
     dmg_grid grid{};
     dmg_ocean_params prm{};
     std::vector<dmg_ctx *> ctx;
-    std::vector<dmg_ocean *> oc;
+    std::vector<dmg_ocean *> oc;     // the bands of an ocean (dmg_multi_create*), or ...
+    std::vector<dmg_climate *> cl;   // ... the bands of a climate field (dmg_multi_climate_create*): same streams, threads and transports
     std::vector<ncclComm_t> comm;    // RCCL: one per local band (loopback: one in all)
     std::vector<hipEvent_t> ev_done, ev_copied;    // PEER: per band
     // DMG_MULTI_OVERLAP_LAST_LAUNCH: a second, high-priority stream per band carries the exchange while the band's own
@@ -232,7 +233,6 @@ static int multi_wait(dmg_multi *m, int i)
 // `on`: the stream that carries it (default: the band's own)
 static int band_exchange(dmg_multi *m, int i, int field, int rows, int buffer = -1, hipStream_t on = nullptr)
 {
-    dmg_ocean *o = m->oc[i];
     dmg_ctx *c = m->ctx_of(i);
     const int g = m->first + i;
     MTRACE("band %d: exchange field %d rows %d transport %d", g, field, rows, m->transport);
@@ -250,7 +250,9 @@ static int band_exchange(dmg_multi *m, int i, int field, int rows, int buffer = 
         } else { ev = m->ev_free.back(); m->ev_free.pop_back(); }
         DMG_HIP(hipEventRecord(ev.first, st));
     }
-    auto slab = [&](dmg_ocean *oo, int side, void **send, void **recv, size_t *bytes) {
+    auto slab = [&](int band, int side, void **send, void **recv, size_t *bytes) {
+        if (!m->cl.empty()) return dmg_climate_halo(m->cl[band], side, rows, send, recv, bytes);      // the temperature field's ghost rows
+        dmg_ocean *oo = m->oc[band];
         return (field == DMG_F_PRESSURE && buffer >= 0) ? dmg_ocean_pressure_halo(oo, buffer, side, rows, send, recv, bytes)
                                                         : dmg_ocean_halo(oo, field, side, rows, send, recv, bytes);
     };
@@ -265,7 +267,7 @@ static int band_exchange(dmg_multi *m, int i, int field, int rows, int buffer = 
             const int peer = side == DMG_SIDE_SOUTH ? g - 1 : g + 1;
             if (peer < 0 || peer >= m->world) continue;
             void *send, *recv; size_t bytes;
-            if ((rc = slab(o, side, &send, &recv, &bytes))) break;
+            if ((rc = slab(i, side, &send, &recv, &bytes))) break;
             first = ncclSend(send, bytes / 4, ncclFloat, peer, m->comm[i], st);
             if (first == ncclSuccess) first = ncclRecv(recv, bytes / 4, ncclFloat, peer, m->comm[i], st);
             if (i == 0) m->exchange_bytes += 2 * (long long)bytes;
@@ -285,7 +287,7 @@ static int band_exchange(dmg_multi *m, int i, int field, int rows, int buffer = 
             rc = DMG_OK;
             for (int b = 0; b + 1 < m->n && !rc && first == ncclSuccess; b++) {
                 void *s_lo, *r_lo, *s_hi, *r_hi; size_t by;
-                if ((rc = slab(m->oc[b], DMG_SIDE_NORTH, &s_lo, &r_lo, &by)) || (rc = slab(m->oc[b + 1], DMG_SIDE_SOUTH, &s_hi, &r_hi, &by))) break;
+                if ((rc = slab(b, DMG_SIDE_NORTH, &s_lo, &r_lo, &by)) || (rc = slab(b + 1, DMG_SIDE_SOUTH, &s_hi, &r_hi, &by))) break;
                 first = ncclSend(s_lo, by / 4, ncclFloat, 0, m->comm[0], st);                               // band b's top rows ...
                 if (first == ncclSuccess) first = ncclRecv(r_hi, by / 4, ncclFloat, 0, m->comm[0], st);     // ... into band b+1's south ghost
                 if (first == ncclSuccess) first = ncclSend(s_hi, by / 4, ncclFloat, 0, m->comm[0], st);
@@ -307,7 +309,7 @@ static int band_exchange(dmg_multi *m, int i, int field, int rows, int buffer = 
             const int j = side == DMG_SIDE_SOUTH ? i - 1 : i + 1;
             if (j < 0 || j >= m->n) continue;
             void *send, *recv, *nsend, *nrecv; size_t bytes, nbytes;
-            if ((rc = slab(o, side, &send, &recv, &bytes)) || (rc = slab(m->oc[j], side ^ 1, &nsend, &nrecv, &nbytes))) return rc;
+            if ((rc = slab(i, side, &send, &recv, &bytes)) || (rc = slab(j, side ^ 1, &nsend, &nrecv, &nbytes))) return rc;
             if (m->ctx_of(j) != c) DMG_HIP(hipStreamWaitEvent(st, m->ev_done[j], 0));
             DMG_HIP(hipMemcpyPeerAsync(recv, c->device, nsend, m->ctx_of(j)->device, bytes, st));
             if (i == 0) m->exchange_bytes += (long long)bytes;
@@ -451,10 +453,10 @@ static void multi_free(dmg_multi *m)
     m->team.stop();
     for (auto &p : m->ev_used) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (auto &p : m->ev_free) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
-    for (size_t i = 0; i < m->oc.size(); i++) {
-        if (i < m->d_red.size() && m->d_red[i]) { (void)hipSetDevice(m->ctx_of((int)i)->device); (void)hipFree(m->d_red[i]); }
-        if (m->oc[i]) dmg_ocean_destroy(m->oc[i]);
-    }
+    for (size_t i = 0; i < m->d_red.size(); i++)
+        if (m->d_red[i] && m->ctx_of((int)i)) { (void)hipSetDevice(m->ctx_of((int)i)->device); (void)hipFree(m->d_red[i]); }
+    for (dmg_ocean *o : m->oc) if (o) dmg_ocean_destroy(o);
+    for (dmg_climate *k : m->cl) if (k) dmg_climate_destroy(k);
     for (hipEvent_t e : m->ev_done) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : m->ev_copied) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : m->ev_edge) if (e) (void)hipEventDestroy(e);
@@ -516,8 +518,11 @@ int dmg_multi_unique_id(void *id128)
     return DMG_OK;
 }
 
-int dmg_multi_create(int n_bands, const int *device_ids, const dmg_grid *grid, const dmg_ocean_params *params, int ghost, int flags,
-                     dmg_multi **out)
+// make_band(m, local index, global band index, bands in all): creates that band's object on m->ctx_of(local index)
+typedef std::function<int(dmg_multi *, int, int, int)> band_factory;
+
+static int multi_create_local(int n_bands, const int *device_ids, const dmg_grid *grid, const dmg_ocean_params *params, int ghost, int flags,
+                              const band_factory &make_band, dmg_multi **out)
 {
     DMG_CHECK_ARG(out != nullptr && n_bands >= 1 && n_bands <= 64 && device_ids != nullptr && grid != nullptr && ghost >= 1);
     *out = nullptr;
@@ -537,12 +542,12 @@ int dmg_multi_create(int n_bands, const int *device_ids, const dmg_grid *grid, c
     if (rc) return rc;
     m->world = n_bands; m->first = 0; m->n = n_bands; m->transport = transport;
     m->shared_ctx = transport == DMG_MULTI_RCCL_LOOPBACK;
-    m->ctx.assign(n_bands, nullptr); m->oc.assign(n_bands, nullptr); m->d_red.assign(n_bands, nullptr);
+    m->ctx.assign(n_bands, nullptr); m->d_red.assign(n_bands, nullptr);
     m->ev_done.assign(n_bands, nullptr); m->ev_copied.assign(n_bands, nullptr);
     for (int i = 0; i < n_bands; i++) {
         if (!m->shared_ctx || i == 0)
             if ((rc = dmg_create(device_ids[i], nullptr, DMG_PRIVATE_STREAM, &m->ctx[i]))) return rc;
-        if ((rc = dmg_ocean_create(m->ctx_of(i), grid, &m->prm, i, n_bands, ghost, &m->oc[i]))) return rc;
+        if ((rc = make_band(m.get(), i, i, n_bands))) return rc;
         DMG_HIP(hipSetDevice(device_ids[i]));
         DMG_HIP(hipMalloc((void **)&m->d_red[i], sizeof(int)));
         DMG_HIP(hipEventCreateWithFlags(&m->ev_done[i], hipEventDisableTiming));
@@ -575,8 +580,8 @@ int dmg_multi_create(int n_bands, const int *device_ids, const dmg_grid *grid, c
     return DMG_OK;
 }
 
-int dmg_multi_create_rank(int rank, int n_ranks, const void *id128, int device_id, const dmg_grid *grid, const dmg_ocean_params *params,
-                          int ghost, int flags, dmg_multi **out)
+static int multi_create_rank(int rank, int n_ranks, const void *id128, int device_id, const dmg_grid *grid, const dmg_ocean_params *params,
+                             int ghost, int flags, const band_factory &make_band, dmg_multi **out)
 {
     DMG_CHECK_ARG(out != nullptr && n_ranks >= 1 && rank >= 0 && rank < n_ranks && grid != nullptr && ghost >= 1);
     DMG_CHECK_ARG(n_ranks == 1 || id128 != nullptr);
@@ -586,10 +591,10 @@ int dmg_multi_create_rank(int rank, int n_ranks, const void *id128, int device_i
     int rc = multi_common(m.get(), grid, params, ghost, flags);
     if (rc) return rc;
     m->world = n_ranks; m->first = rank; m->n = 1; m->transport = DMG_MULTI_RCCL;
-    m->ctx.assign(1, nullptr); m->oc.assign(1, nullptr); m->d_red.assign(1, nullptr);
+    m->ctx.assign(1, nullptr); m->d_red.assign(1, nullptr);
     m->ev_done.assign(1, nullptr); m->ev_copied.assign(1, nullptr);
     if ((rc = dmg_create(device_id, nullptr, DMG_PRIVATE_STREAM, &m->ctx[0]))) return rc;
-    if ((rc = dmg_ocean_create(m->ctx[0], grid, &m->prm, rank, n_ranks, ghost, &m->oc[0]))) return rc;
+    if ((rc = make_band(m.get(), 0, rank, n_ranks))) return rc;
     DMG_HIP(hipSetDevice(device_id));
     DMG_HIP(hipMalloc((void **)&m->d_red[0], sizeof(int)));
     if (n_ranks > 1) {
@@ -604,13 +609,111 @@ int dmg_multi_create_rank(int rank, int n_ranks, const void *id128, int device_i
     return DMG_OK;
 }
 
+static band_factory ocean_band(const dmg_grid *grid, int ghost)
+{
+    return [grid, ghost](dmg_multi *m, int i, int g, int world) {
+        if (m->oc.size() < (size_t)m->ctx.size()) m->oc.resize(m->ctx.size(), nullptr);
+        return dmg_ocean_create(m->ctx_of(i), grid, &m->prm, g, world, ghost, &m->oc[i]);
+    };
+}
+
+int dmg_multi_create(int n_bands, const int *device_ids, const dmg_grid *grid, const dmg_ocean_params *params, int ghost, int flags,
+                     dmg_multi **out)
+{
+    return multi_create_local(n_bands, device_ids, grid, params, ghost, flags, ocean_band(grid, ghost), out);
+}
+
+int dmg_multi_create_rank(int rank, int n_ranks, const void *id128, int device_id, const dmg_grid *grid, const dmg_ocean_params *params,
+                          int ghost, int flags, dmg_multi **out)
+{
+    return multi_create_rank(rank, n_ranks, id128, device_id, grid, params, ghost, flags, ocean_band(grid, ghost), out);
+}
+
+// ---- the climate year cycle over latitude bands --------------------------------------------------
+// Temperature::run (src/filter/Temperature.cpp:47-162) steps the field 500 000 times: of config 5's stages it is the one
+// that can use eight GPUs.  The bands are dmg_climate_create_band handles (filters.hip: up to `ghost` steps between halo
+// refreshes, the computed region shrinking a row per step); threads, streams, transports and failure handling are
+// dmg_multi's -- the exchange is the very band_exchange of the ocean, on the temperature field's slabs.
+static band_factory climate_band(const dmg_grid *grid, const float *T, const float *terrain, int ghost)
+{
+    return [grid, T, terrain, ghost](dmg_multi *m, int i, int g, int world) {
+        if (m->cl.size() < (size_t)m->ctx.size()) m->cl.resize(m->ctx.size(), nullptr);
+        return dmg_climate_create_band(m->ctx_of(i), grid, T, terrain, g, world, world > 1 ? ghost : 0, &m->cl[i]);
+    };
+}
+
+int dmg_multi_climate_create(int n_bands, const int *device_ids, const dmg_grid *grid, const float *T, const float *terrain, int ghost, int flags,
+                             dmg_multi_climate **out)
+{
+    DMG_CHECK_ARG(T != nullptr && terrain != nullptr && out != nullptr);
+    dmg_multi *m = nullptr;
+    int rc = multi_create_local(n_bands, device_ids, grid, nullptr, ghost, flags, climate_band(grid, T, terrain, ghost), &m);
+    *out = reinterpret_cast<dmg_multi_climate *>(m);
+    return rc;
+}
+
+int dmg_multi_climate_create_rank(int rank, int n_ranks, const void *id128, int device_id, const dmg_grid *grid, const float *T, const float *terrain,
+                                  int ghost, int flags, dmg_multi_climate **out)
+{
+    DMG_CHECK_ARG(T != nullptr && terrain != nullptr && out != nullptr);
+    dmg_multi *m = nullptr;
+    int rc = multi_create_rank(rank, n_ranks, id128, device_id, grid, nullptr, ghost, flags, climate_band(grid, T, terrain, ghost), &m);
+    *out = reinterpret_cast<dmg_multi_climate *>(m);
+    return rc;
+}
+
+void dmg_multi_climate_destroy(dmg_multi_climate *h) { multi_free(reinterpret_cast<dmg_multi *>(h)); }
+
+// n_steps of the energy-balance model from step index first_step on (the orbital phase is 2 pi / 15000 * step, :146); the
+// ghost rows are refreshed every `ghost` steps.  Asynchronous on the bands' streams.
+int dmg_multi_climate_steps(dmg_multi_climate *h, int first_step, int n_steps)
+{
+    dmg_multi *m = reinterpret_cast<dmg_multi *>(h);
+    DMG_CHECK_ARG(m != nullptr && !m->cl.empty() && n_steps >= 0);
+    if (m->dead.load()) return dmg_fail(DMG_ESTATE, "this handle has lost a band: destroy it");
+    return m->team.run([&](int i) -> int {
+        dmg_climate *k = m->cl[i];
+        if (m->world == 1) return dmg_climate_steps(k, first_step, n_steps);
+        int rc;
+        for (int done = 0; done < n_steps;) {
+            const int n = std::min(m->ghost, n_steps - done);
+            if ((rc = band_exchange(m, i, 0, m->ghost))) return rc;
+            if ((rc = dmg_climate_steps(k, first_step + done, n))) return rc;
+            done += n;
+        }
+        return DMG_OK;
+    });
+}
+
+int dmg_multi_climate_set_terrain(dmg_multi_climate *h, const float *terrain)
+{
+    dmg_multi *m = reinterpret_cast<dmg_multi *>(h);
+    DMG_CHECK_ARG(m != nullptr && !m->cl.empty() && terrain != nullptr);
+    return m->team.run([&](int i) { return dmg_climate_set_terrain(m->cl[i], terrain); });
+}
+
+// owned rows of this process's bands into the FULL-grid array; synchronises
+int dmg_multi_climate_get(dmg_multi_climate *h, float *T)
+{
+    dmg_multi *m = reinterpret_cast<dmg_multi *>(h);
+    DMG_CHECK_ARG(m != nullptr && !m->cl.empty() && T != nullptr);
+    return m->team.run([&](int i) -> int { int rc = multi_wait(m, i); return rc ? rc : dmg_climate_get(m->cl[i], T); });
+}
+
+int dmg_multi_climate_sync(dmg_multi_climate *h)
+{
+    dmg_multi *m = reinterpret_cast<dmg_multi *>(h);
+    DMG_CHECK_ARG(m != nullptr);
+    return m->team.run([&](int i) { return multi_wait(m, i); });
+}
+
 void dmg_multi_destroy(dmg_multi *m) { multi_free(m); }
 
 int dmg_multi_band_count(const dmg_multi *m) { return m ? m->n : 0; }
 
 int dmg_multi_band(dmg_multi *m, int local_index, dmg_ocean **out)
 {
-    DMG_CHECK_ARG(m != nullptr && out != nullptr && local_index >= 0 && local_index < m->n);
+    DMG_CHECK_ARG(m != nullptr && out != nullptr && local_index >= 0 && local_index < m->n && (int)m->oc.size() == m->n);
     *out = m->oc[local_index];
     return DMG_OK;
 }
@@ -623,7 +726,7 @@ int dmg_multi_set_order(dmg_multi *m, int order)
 }
 
 #define MULTI_FOR_BANDS(call)                                             \
-    DMG_CHECK_ARG(m != nullptr);                                          \
+    DMG_CHECK_ARG(m != nullptr && (int)m->oc.size() == m->n);             \
     return m->team.run([&](int i) -> int { dmg_ocean *o = m->oc[i]; (void)o; return call; })
 
 int dmg_multi_set_terrain(dmg_multi *m, const float *img) { DMG_CHECK_ARG(img != nullptr); MULTI_FOR_BANDS(dmg_ocean_set_terrain(o, img)); }
@@ -640,18 +743,18 @@ int dmg_multi_generate_terrain(dmg_multi *m, const dmg_noise_params *params)
     MULTI_FOR_BANDS(dmg_ocean_generate_terrain(o, params));
 }
 int dmg_multi_get(dmg_multi *m, float *vx, float *vy, float *pressure, float *divw) { MULTI_FOR_BANDS(dmg_ocean_get(o, vx, vy, pressure, divw)); }
-int dmg_multi_sync(dmg_multi *m) { MULTI_FOR_BANDS(multi_wait(m, i)); }
+int dmg_multi_sync(dmg_multi *m) { DMG_CHECK_ARG(m != nullptr); return m->team.run([&](int i) { return multi_wait(m, i); }); }
 
 int dmg_multi_jacobi(dmg_multi *m, int iters, int zero_first)
 {
-    DMG_CHECK_ARG(m != nullptr && iters >= 0);
+    DMG_CHECK_ARG(m != nullptr && iters >= 0 && (int)m->oc.size() == m->n);
     if (m->dead.load()) return dmg_fail(DMG_ESTATE, "this dmg_multi has lost a band: destroy it");
     return m->team.run([&](int i) { return band_jacobi(m, i, iters, zero_first); });
 }
 
 int dmg_multi_step(dmg_multi *m, int n_outer)
 {
-    DMG_CHECK_ARG(m != nullptr && n_outer >= 0);
+    DMG_CHECK_ARG(m != nullptr && n_outer >= 0 && (int)m->oc.size() == m->n);
     if (m->dead.load()) return dmg_fail(DMG_ESTATE, "this dmg_multi has lost a band: destroy it");
     std::vector<int> scratch((size_t)m->n, 0);
     return m->team.run([&](int i) { return band_step(m, i, n_outer, scratch); });
@@ -659,7 +762,7 @@ int dmg_multi_step(dmg_multi *m, int n_outer)
 
 int dmg_multi_exchange(dmg_multi *m, int field, int rows)
 {
-    DMG_CHECK_ARG(m != nullptr && rows >= 1 && rows <= m->ghost);
+    DMG_CHECK_ARG(m != nullptr && rows >= 1 && rows <= m->ghost && (int)m->oc.size() == m->n);
     if (m->world == 1) return DMG_OK;
     return m->team.run([&](int i) { return band_exchange(m, i, field, rows); });
 }
@@ -675,7 +778,7 @@ int dmg_multi_get_stats(dmg_multi *m, dmg_multi_stats *s)
     s->bands_total = m->world; s->bands_local = m->n; s->transport = m->transport; s->order = m->order; s->ghost = m->ghost;
     s->exchanges = m->n_exchanges; s->exchange_ms = m->exchange_ms; s->exchange_bytes = m->exchange_bytes;
     long long l = 0, sw = 0;
-    (void)dmg_ocean_counters(m->oc[0], &l, &sw);
+    if (!m->oc.empty()) (void)dmg_ocean_counters(m->oc[0], &l, &sw);
     s->jacobi_launches = l; s->jacobi_sweeps = sw;
     return DMG_OK;
 }

@@ -167,6 +167,11 @@ struct st_state {
     unsigned cs[2][2];
     unsigned ks[2][2];              // persistent form: the row's class travels with its loads
     unsigned landbits, mixbits;     // bit j: row (newest - j) is land everywhere / has coast; newest = second row of this step's pair
+    // units whose whole window (and the rows requested past it) lies inside the grid and the stored band fetch their rows
+    // through three row pointers that advance by one row per fetch (scalar adds) instead of mapping every row index
+    const float *nx_p, *nx_b;
+    const unsigned char *nx_c;
+    bool plain;
     unsigned badbits;               // DV = 1: ... its divisors have no exact two-operation pair (the table holds (c, r) for it)
     int slot;                       // ring slot of the first row of this step's pair (row offset mod ST_RING)
     float cy, ry;                   // the same for every row (pixelsize().y, src/Shader.h:71-74): two SGPRs
@@ -308,6 +313,15 @@ __device__ __forceinline__ unsigned st_class(unsigned cls_lo, unsigned cls_hi, i
 template <bool P>
 __device__ __forceinline__ void st_fetch(const st_args &a, st_state &z, int set, int j, int e, int col, int colp, int tx = 0)
 {
+    if (!P && z.plain && !ST_DBG(a, 1)) {
+        // (rows are fetched in order: e0, e0 + 1, ...; a step spends a third of its instructions outside its levels, most of
+        // them scalar address arithmetic -- per-step clocks)
+        z.ps[set][j] = *reinterpret_cast<const v4f *>(z.nx_p + (unsigned)col);
+        z.bs[set][j] = *reinterpret_cast<const v4f *>(z.nx_b + (unsigned)col);
+        z.cs[set][j] = *reinterpret_cast<const unsigned *>(z.nx_c + (unsigned)col);
+        z.nx_p += a.W; z.nx_b += a.W; z.nx_c += a.W;
+        return;
+    }
     const st_row m = st_map_row(a, ST_DBG(a, 1) ? (e & 63) : e);
     // the row's base address is wave-uniform (scalar arithmetic), the lane adds a 32-bit column offset: the loads take
     // the SGPR-base + VGPR-offset form and the 64-bit address arithmetic leaves the vector ALU
@@ -401,6 +415,14 @@ __device__ __forceinline__ void st_step(const st_args &a, st_state &z, v4f (*bri
     const int slotB = z.slot + 1;                            // (ST_RING is even: a pair never wraps)
     unsigned landA, mixA, landB, mixB;
     const unsigned clsA = P ? st_class_p<K>(a, z, 0, e_t) : st_class4(cls_lo, 2 * t), clsB = P ? st_class_p<K>(a, z, 1, e_t + 1) : st_class4(cls_lo, 2 * t + 1);
+#ifdef ST_EXPERIMENTS
+    // DMG_ST_STEPPROF: slots 22..42 = the clock when the even step's rows have arrived (its wait for the staged loads is over),
+    // slots 43..62 = when the even step's levels are done, of a unit's first 20 iterations (slots 0..21: top of the iteration)
+    if (!P && K == 0 && a.stepprof && lane == 0 && t < 40) {
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");          // (the even step's six loads are the oldest of the twelve in flight)
+        a.stepprof[(size_t)blockIdx.x * 64 + 22 + t / 2] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
     st_arrive<K>(a, z, bring, cring, lane, 0, e_t, clsA, z.slot, landA, mixA);
     st_arrive<K>(a, z, bring, cring, lane, 1, e_t + 1, clsB, slotB, landB, mixB);
     z.landbits = (z.landbits << 2) | (landA << 1) | landB;
@@ -418,7 +440,12 @@ __device__ __forceinline__ void st_step(const st_args &a, st_state &z, v4f (*bri
     if (!P) asm volatile("v_mov_b32 %0, %1" : "=v"(kb) : "s"((2 * t - 8) * 16));
     // no land and no coast in any of the ten rows in flight (every step of a strip in open water): the eight levels without
     // a test or a branch between them -- one block for the scheduler; a branch per level visit costs the kernel ~3 %
-    if (!((z.landbits | z.mixbits | special) & 0x3FFu)) {
+    // A unit's first eight steps fill the pipeline: level S has its first rows to compute at step S.  Those steps take the
+    // tested path whatever their rows are, and there a level that has nothing to do yet is skipped outright (round 3: per-step
+    // clocks showed a skipped level visit costing 0.25 us through the all-land path -- as much as a real one -- and a unit's
+    // eight fill steps 2.1 us each; with the skip a unit is ~7 us shorter)
+    const bool filled = P || t >= TB_T;
+    if (filled && !((z.landbits | z.mixbits | special) & 0x3FFu)) {
         st_level<1, K, P, 1, DV>(a, z, bring, cring, ktab, lane, t, e_t - 1, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
         st_level<2, K, P, 1, DV>(a, z, bring, cring, ktab, lane, t, e_t - 2, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
         st_level<3, K, P, 1, DV>(a, z, bring, cring, ktab, lane, t, e_t - 3, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
@@ -427,7 +454,7 @@ __device__ __forceinline__ void st_step(const st_args &a, st_state &z, v4f (*bri
         st_level<6, K, P, 1, DV>(a, z, bring, cring, ktab, lane, t, e_t - 6, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
         st_level<7, K, P, 1, DV>(a, z, bring, cring, ktab, lane, t, e_t - 7, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
         st_level<8, K, P, 1, DV>(a, z, bring, cring, ktab, lane, t, e_t - 8, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
-    } else if (!((z.landbits | special) & 0x3FFu)) {
+    } else if (filled && !((z.landbits | special) & 0x3FFu)) {
         // coast among the ten rows, but no row that is land everywhere (coast rows come in long runs: 18 % of the survey
         // terrain's steps): every row through the coast formula, open rows with counts of zero -- again no test, no branch
         st_level<1, K, P, 2, DV>(a, z, bring, cring, ktab, lane, t, e_t - 1, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
@@ -439,16 +466,19 @@ __device__ __forceinline__ void st_step(const st_args &a, st_state &z, v4f (*bri
         st_level<7, K, P, 2, DV>(a, z, bring, cring, ktab, lane, t, e_t - 7, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
         st_level<8, K, P, 2, DV>(a, z, bring, cring, ktab, lane, t, e_t - 8, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
     } else {
-        st_level<1, K, P, 0, DV>(a, z, bring, cring, ktab, lane, t, e_t - 1, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
-        st_level<2, K, P, 0, DV>(a, z, bring, cring, ktab, lane, t, e_t - 2, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
-        st_level<3, K, P, 0, DV>(a, z, bring, cring, ktab, lane, t, e_t - 3, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
-        st_level<4, K, P, 0, DV>(a, z, bring, cring, ktab, lane, t, e_t - 4, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
-        st_level<5, K, P, 0, DV>(a, z, bring, cring, ktab, lane, t, e_t - 5, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
-        st_level<6, K, P, 0, DV>(a, z, bring, cring, ktab, lane, t, e_t - 6, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
-        st_level<7, K, P, 0, DV>(a, z, bring, cring, ktab, lane, t, e_t - 7, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
-        st_level<8, K, P, 0, DV>(a, z, bring, cring, ktab, lane, t, e_t - 8, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
+        if (P || 1 <= t) st_level<1, K, P, 0, DV>(a, z, bring, cring, ktab, lane, t, e_t - 1, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
+        if (P || 2 <= t) st_level<2, K, P, 0, DV>(a, z, bring, cring, ktab, lane, t, e_t - 2, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
+        if (P || 3 <= t) st_level<3, K, P, 0, DV>(a, z, bring, cring, ktab, lane, t, e_t - 3, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
+        if (P || 4 <= t) st_level<4, K, P, 0, DV>(a, z, bring, cring, ktab, lane, t, e_t - 4, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
+        if (P || 5 <= t) st_level<5, K, P, 0, DV>(a, z, bring, cring, ktab, lane, t, e_t - 5, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
+        if (P || 6 <= t) st_level<6, K, P, 0, DV>(a, z, bring, cring, ktab, lane, t, e_t - 6, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
+        if (P || 7 <= t) st_level<7, K, P, 0, DV>(a, z, bring, cring, ktab, lane, t, e_t - 7, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
+        if (P || 8 <= t) st_level<8, K, P, 0, DV>(a, z, bring, cring, ktab, lane, t, e_t - 8, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
     }
     z.slot = z.slot + 2 == ST_RING ? 0 : z.slot + 2;
+#ifdef ST_EXPERIMENTS
+    if (!P && K == 0 && a.stepprof && lane == 0 && t < 40) a.stepprof[(size_t)blockIdx.x * 64 + 43 + t / 2] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // one wave per unit; two waves per SIMD leave 256 registers each: all issue slots of a SIMD belong to two fat waves
@@ -483,6 +513,11 @@ __global__ __launch_bounds__(64, 2) void k_jacobi_stream(st_args a)
     // rows and the stores dropped the same launch still takes 58 us; see DESIGN.md 4.1b, "what a unit's first steps cost".)
     // the first two steps' rows are requested before anything else: their round trip covers the tables' below
     st_state z;
+    {
+        const int e_last = e0 + 2 * nsteps + 5;             // the last row a step requests (st_step: e_t + 5)
+        z.plain = e0 >= 0 && e_last < a.L && a.y_first + e0 >= 0 && a.y_first + e_last < a.H;
+        z.nx_p = a.pin + (size_t)e0 * W; z.nx_b = a.b + (size_t)e0 * W; z.nx_c = a.code + (size_t)e0 * W;
+    }
     st_fetch<false>(a, z, 0, 0, e0, col, colp);
     st_fetch<false>(a, z, 0, 1, e0 + 1, col, colp);
     st_fetch<false>(a, z, 1, 0, e0 + 2, col, colp);          // (rows past the window are clamped into the band: harmless)
@@ -522,7 +557,7 @@ __global__ __launch_bounds__(64, 2) void k_jacobi_stream(st_args a)
     }
     for (int t = 0; t < nsteps; t += 2) {
 #ifdef ST_EXPERIMENTS
-        if (a.stepprof && lane == 0 && t < 126) a.stepprof[(size_t)blockIdx.x * 64 + t / 2] = __builtin_amdgcn_s_memrealtime();
+        if (a.stepprof && lane == 0 && t < 44) a.stepprof[(size_t)blockIdx.x * 64 + t / 2] = __builtin_amdgcn_s_memrealtime();
 #endif
         st_step<0, false, DV>(a, z, bring, cring, ktab, lane, t, e0, nsteps, r1, cls_lo, cls_hi, col, colp, lane_ok, xcol);
         st_step<1, false, DV>(a, z, bring, cring, ktab, lane, t + 1, e0, nsteps, r1, cls_lo, cls_hi, col, colp, lane_ok, xcol);
@@ -679,6 +714,7 @@ __global__ __launch_bounds__(64, 2) void k_jacobi_stream_p(st_args a)
             for (int j = 0; j < 2; j++) { z.ps[k][j] = (v4f)(0.0f); z.bs[k][j] = (v4f)(0.0f); z.cs[k][j] = 0; z.ks[k][j] = 2u; }
         z.landbits = 0xFFFFFFFFu;
         z.mixbits = 0; z.slot = 0; z.badbits = 0;
+        z.plain = false; z.nx_p = nullptr; z.nx_b = nullptr; z.nx_c = nullptr;
         {
             const st_kptr cf = (st_kptr)(unsigned long long)a.jcoef;
             z.cy = cf[4]; z.ry = cf[5];

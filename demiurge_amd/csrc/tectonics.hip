@@ -516,6 +516,8 @@ int dmg_tectonics_get_map(dmg_tectonics *t, float *rgba)
     return DMG_OK;
 }
 
+extern "C++" const float *tectonics_terrain_device(const dmg_tectonics *t) { return t->terrain; }    // the render target (W x H), on the device
+
 int dmg_tectonics_get_terrain(dmg_tectonics *t, float *terrain)
 {
     DMG_CHECK_ARG(t && terrain);

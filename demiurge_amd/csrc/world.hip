@@ -8,6 +8,11 @@
 //                                                                         its orbital phase M advancing step by step through the year
 // One-way coupling, as in the editor: erosion does not feed back into the plates (Tectonics rebuilds its plates from a
 // terrain only in its constructor, :15-58), the climate sees the eroded terrain's sign.
+//
+// Round 3: the terrain never leaves the device between the stages (four 512 MiB PCIe crossings per iteration
+// at 16384x8192).  Tectonics renders into its own device buffer, the erosion handle is created from that buffer with a
+// device copy, the climate takes the eroded heights with a device copy; the reference keeps all of it in textures
+// (cpufilter.cpp:106-216).  dmg_world_get downloads what the host asks for.
 #include "dmg_internal.h"
 #include <memory>
 
@@ -16,7 +21,7 @@ struct dmg_world {
     dmg_grid grid{};
     dmg_tectonics *tect = nullptr;
     dmg_climate *clim = nullptr;
-    std::vector<float> terrain, eroded;              // what the tectonics render pass left; after the erosion rounds (scaled by 1/N like the reference)
+    float *d_terrain = nullptr, *d_eroded = nullptr; // what the tectonics render pass left; after the erosion rounds (scaled by 1/N like the reference)
     long long climate_step = 0, iterations = 0;
 };
 
@@ -41,11 +46,22 @@ int dmg_world_create(dmg_ctx *ctx, const dmg_grid *grid, const float *terrain, c
     if (!w) return dmg_fail(DMG_ENOMEM, "out of host memory");
     w->ctx = ctx; w->grid = *grid;
     const size_t n = (size_t)grid->W * grid->H;
-    w->terrain.assign(terrain, terrain + n);
-    w->eroded = w->terrain;
-    int rc = dmg_tectonics_create(ctx, grid, terrain, &w->tect);
+    DMG_HIP(hipSetDevice(ctx->device));
+    if (hipMalloc((void **)&w->d_terrain, n * 4) != hipSuccess || hipMalloc((void **)&w->d_eroded, n * 4) != hipSuccess) {
+        (void)hipFree(w->d_terrain);
+        return dmg_fail(DMG_ENOMEM, "hipMalloc of two %zu-cell fields failed", n);
+    }
+    int rc = DMG_OK;
+    if (hipMemcpyAsync(w->d_terrain, terrain, n * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipMemcpyAsync(w->d_eroded, w->d_terrain, n * 4, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) rc = dmg_fail(DMG_EHIP, "terrain upload failed");
+    if (!rc) rc = dmg_tectonics_create(ctx, grid, terrain, &w->tect);
     if (!rc) rc = dmg_climate_create(ctx, grid, T0, terrain, &w->clim);
-    if (rc) { if (w->tect) dmg_tectonics_destroy(w->tect); return rc; }
+    if (rc) {
+        if (w->tect) dmg_tectonics_destroy(w->tect);
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(w->d_terrain); (void)hipFree(w->d_eroded);
+        return rc;
+    }
     dmg_ctx_retain(ctx);
     *out = w.release();
     return DMG_OK;
@@ -57,6 +73,9 @@ void dmg_world_destroy(dmg_world *w)
     dmg_ctx *ctx = w->ctx;
     if (w->clim) dmg_climate_destroy(w->clim);
     if (w->tect) dmg_tectonics_destroy(w->tect);
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(w->d_terrain); (void)hipFree(w->d_eroded);
     delete w;
     dmg_ctx_release(ctx);
 }
@@ -67,22 +86,25 @@ int dmg_world_step(dmg_world *w, const dmg_world_params *params)
     dmg_world_params p;
     if (params) p = *params; else dmg_world_params_default(&p);
     DMG_CHECK_ARG(p.tectonics_steps >= 0 && p.erosion_rounds >= 0 && p.climate_steps >= 0 && p.erosion_N >= 1);
+    DMG_HIP(hipSetDevice(w->ctx->device));
+    hipStream_t st = w->ctx->stream;
+    const size_t bytes = (size_t)w->grid.W * w->grid.H * 4;
     int rc;
     if (p.tectonics_steps > 0) {
         if ((rc = dmg_tectonics_step(w->tect, p.tectonics_steps))) return rc;
-        if ((rc = dmg_tectonics_get_terrain(w->tect, w->terrain.data()))) return rc;
+        DMG_HIP(hipMemcpyAsync(w->d_terrain, tectonics_terrain_device(w->tect), bytes, hipMemcpyDeviceToDevice, st));
     }
-    w->eroded = w->terrain;
     if (p.erosion_rounds > 0) {
         dmg_erosion *e = nullptr;
-        if ((rc = dmg_erosion_create(w->ctx, &w->grid, w->terrain.data(), p.erosion_N, p.exponent, p.slope_exponent, p.factor, p.lakes, &e))) return rc;
+        if ((rc = erosion_create_from(w->ctx, &w->grid, w->d_terrain, true, p.erosion_N, p.exponent, p.slope_exponent, p.factor, p.lakes, &e))) return rc;
         rc = dmg_erosion_rounds(e, p.erosion_rounds);
-        if (!rc) rc = dmg_erosion_get(e, w->eroded.data());
-        dmg_erosion_destroy(e);
+        if (!rc && hipMemcpyAsync(w->d_eroded, erosion_heights_device(e), bytes, hipMemcpyDeviceToDevice, st) != hipSuccess)
+            rc = dmg_fail(DMG_EHIP, "device copy of the eroded heights failed");
+        dmg_erosion_destroy(e);                          // (its buffers go back to the context's pool; the stream orders their reuse)
         if (rc) return rc;
-    }
+    } else DMG_HIP(hipMemcpyAsync(w->d_eroded, w->d_terrain, bytes, hipMemcpyDeviceToDevice, st));
     if (p.climate_steps > 0) {
-        if ((rc = dmg_climate_set_terrain(w->clim, w->eroded.data()))) return rc;
+        if ((rc = climate_set_terrain_device(w->clim, w->d_eroded))) return rc;
         if ((rc = dmg_climate_steps(w->clim, (int)w->climate_step, p.climate_steps))) return rc;
         w->climate_step += p.climate_steps;
     }
@@ -93,9 +115,11 @@ int dmg_world_step(dmg_world *w, const dmg_world_params *params)
 int dmg_world_get(dmg_world *w, float *terrain, float *eroded, float *T)
 {
     DMG_CHECK_ARG(w != nullptr);
-    const size_t n = (size_t)w->grid.W * w->grid.H;
-    if (terrain) memcpy(terrain, w->terrain.data(), n * sizeof(float));
-    if (eroded) memcpy(eroded, w->eroded.data(), n * sizeof(float));
+    DMG_HIP(hipSetDevice(w->ctx->device));
+    const size_t bytes = (size_t)w->grid.W * w->grid.H * 4;
+    if (terrain) DMG_HIP(hipMemcpyAsync(terrain, w->d_terrain, bytes, hipMemcpyDeviceToHost, w->ctx->stream));
+    if (eroded) DMG_HIP(hipMemcpyAsync(eroded, w->d_eroded, bytes, hipMemcpyDeviceToHost, w->ctx->stream));
+    DMG_HIP(hipStreamSynchronize(w->ctx->stream));
     if (T) return dmg_climate_get(w->clim, T);
     return DMG_OK;
 }

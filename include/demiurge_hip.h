@@ -283,6 +283,21 @@ typedef struct {
     long long jacobi_launches, jacobi_sweeps;     /* of band 0 */
 } dmg_multi_stats;
 int dmg_multi_get_stats(dmg_multi *m, dmg_multi_stats *s);  /* synchronises */
+/* The climate year cycle (Temperature::run, src/filter/Temperature.cpp:47-162: 500 000 steps) over latitude bands on
+ * several GPUs: the bands are dmg_climate_create_band handles, everything else -- one thread and two streams per band,
+ * the RCCL / peer / loopback transports, failure handling -- is dmg_multi's.  Flags and `ghost` as for dmg_multi_create;
+ * the ghost rows are refreshed every `ghost` steps.  T and terrain are FULL-grid arrays; results are bit-identical to
+ * dmg_climate_steps on one band. */
+typedef struct dmg_multi_climate dmg_multi_climate;
+int dmg_multi_climate_create(int n_bands, const int *device_ids, const dmg_grid *grid, const float *T, const float *terrain, int ghost, int flags,
+                             dmg_multi_climate **out);
+int dmg_multi_climate_create_rank(int rank, int n_ranks, const void *id128, int device_id, const dmg_grid *grid, const float *T,
+                                  const float *terrain, int ghost, int flags, dmg_multi_climate **out);
+void dmg_multi_climate_destroy(dmg_multi_climate *h);
+int dmg_multi_climate_steps(dmg_multi_climate *h, int first_step, int n_steps);   /* asynchronous on the bands' streams */
+int dmg_multi_climate_set_terrain(dmg_multi_climate *h, const float *terrain);    /* Temperature.cpp:131-132: only the sign matters */
+int dmg_multi_climate_get(dmg_multi_climate *h, float *T);                        /* owned rows of this process's bands; synchronises */
+int dmg_multi_climate_sync(dmg_multi_climate *h);
 int dmg_multi_timer_start(dmg_multi *m);                    /* HIP events on band 0's stream; _stop waits for every band */
 int dmg_multi_timer_stop(dmg_multi *m, float *elapsed_ms);
 

@@ -240,3 +240,33 @@ def test_multi_rccl_two_devices_smoke(dev):
         got = m.get(want=("pressure",))["pressure"]
         m.close()
         assert np.array_equal(got, ref), order
+
+
+@pytest.mark.parametrize("bands,ghost,transport", [(3, 8, "loopback"), (2, 5, "peer"), (4, 16, "loopback"), (1, 4, "rccl")])
+def test_multi_climate_year_cycle_on_a_fake_cluster(dev, bands, ghost, transport):
+    """the climate year cycle (Temperature.cpp:47-162) over latitude bands driven by the library -- the
+    bands are dmg_climate_create_band handles, the exchange is dmg_multi's band_exchange (RCCL calls through the loopback
+    communicator, peer copies, a one-band RCCL communicator) -- against one band, bit for bit, over several exchanges and a
+    terrain change in between"""
+    capi, ctx = dev
+    from demiurge_amd import synth
+    W, H, steps = 512, 256, 45
+    grid = capi.make_grid(W, H)
+    terrain = (synth.terrain(W, H) * 100).astype(np.float32)
+    T0 = (15 - 40 * np.abs(np.linspace(-1, 1, H, dtype=np.float32))[:, None] + 3 * synth.divw(W, H)).astype(np.float32)
+    flipped = np.ascontiguousarray(-terrain)                  # (a named array: the binding hands out a bare pointer)
+    k = capi.Climate(ctx, grid, T0, terrain)
+    k.steps(0, steps)
+    from demiurge_amd.capi import lib, check, _p
+    check(lib().dmg_climate_set_terrain(k.h, _p(flipped)))
+    k.steps(steps, 7)
+    ref = k.get()
+    k.close()
+    flags = {"loopback": capi.MULTI_RCCL_LOOPBACK, "peer": capi.MULTI_PEER, "rccl": capi.MULTI_RCCL}[transport]
+    m = capi.MultiClimate(grid, T0, terrain, devices=[0] * bands, ghost=ghost, flags=flags)
+    m.steps(0, steps)
+    m.set_terrain(flipped)
+    m.steps(steps, 7)
+    got = m.get()
+    m.close()
+    assert np.array_equal(got, ref)
