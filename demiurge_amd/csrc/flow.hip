@@ -22,7 +22,9 @@
 #include <set>
 #include <tuple>
 #include <unordered_map>
+#include <atomic>
 #include <chrono>
+#include <thread>
 #include <sys/mman.h>
 #include <cstdlib>
 #include <new>
@@ -506,6 +508,91 @@ __global__ void k_fill_f(float *p, float v, size_t n)
     if (i < n) p[i] = v;
 }
 
+
+// ---- the growth of the lake graph in parallel (round 3) -------------------------------------------------------------
+// solvingConnections (FlowFilter.cpp:533-595) grows a forest from the river mouths by always taking the lowest pass
+// (h, from, s) on the frontier: Prim's algorithm on a directed graph, 0.45 s of one host thread at 16384x8192.  Its
+// structure (measured: 2.4 M connections, the deepest lake ~1100 hops from its mouth, 1.5 M "cascades" of which the largest
+// holds 21 000 lakes): whenever the pass it takes is higher than every pass before, a CASCADE starts -- the lake behind
+// that pass and everything reachable from it over lower passes are placed before any higher pass is looked at.  The level
+// at which a lake is placed is its minimax distance d from the mouths (the lowest possible highest pass on a way to it):
+// the lakes of equal d are one cascade, cascades never compete for a lake, they follow each other in order of d, and inside
+// a cascade the growth is Prim from its first lake over the cascade's own lakes.  d is a fixed point that does not care
+// about order, d(F) = min over passes (L -> F) of max(d(L), rank of the pass): computed here on the device by frontier
+// relaxation with atomicMin; the cascades then run on all host cores, and the connections come out in the very order the
+// one-thread growth makes them (cascades by d, each in its own pop order).  Same forest, same bits (tests/test_flow.py).
+__device__ __forceinline__ unsigned flow_hkey(int hbits)
+{
+    float h = __int_as_float(hbits);
+    if (h == 0.0f) h = 0.0f;                                  // -0.0 == +0.0 in the growth's comparison
+    const unsigned u = __float_as_uint(h);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);       // monotone in h
+}
+__global__ void k_growth_keys(const int4 *__restrict__ ent, unsigned *__restrict__ ks, int *__restrict__ idx, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { ks[i] = (unsigned)ent[i].z; idx[i] = i; }
+}
+__global__ void k_growth_keys2(const int4 *__restrict__ ent, const int *__restrict__ idx, unsigned long long *__restrict__ khf, int n)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) { const int4 e = ent[idx[j]]; khf[j] = ((unsigned long long)flow_hkey(e.x) << 32) | (unsigned)e.y; }
+}
+__global__ void k_growth_rank(const int *__restrict__ order, unsigned *__restrict__ rank, int n)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) rank[order[r]] = (unsigned)r + 1u;             // ranks 1 .. n; 0 = a river mouth's level
+}
+__global__ void k_growth_init(unsigned *__restrict__ d, int *__restrict__ queued, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { d[i] = 0xFFFFFFFFu; queued[i] = 0; }
+}
+__global__ void k_growth_seed(const int *__restrict__ mouths, int nm, unsigned *__restrict__ d, int *__restrict__ frontier, int *__restrict__ count)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nm) { d[mouths[i]] = 0u; frontier[i] = mouths[i]; }
+    if (i == 0) { count[0] = nm; count[1] = 0; }
+}
+// one relaxation round: every lake of the frontier offers max(d(L), rank) to the lakes behind its passes.  A lake whose d
+// falls joins the next frontier once (queued).  Order of the two flags: a lake takes itself off the queue BEFORE it reads
+// its d, a lake that lowers another's d puts it on the queue AFTER the atomicMin -- so a lowering is never lost.
+__global__ __launch_bounds__(256) void k_growth_relax(const int *__restrict__ fin, const int *__restrict__ nin, int *__restrict__ fout, int *__restrict__ nout,
+                                                       unsigned *__restrict__ d, const int2 *__restrict__ span, const int *__restrict__ vstart,
+                                                       const int4 *__restrict__ ent, const unsigned *__restrict__ rank, int *__restrict__ queued)
+{
+    const int n = *nin;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
+        const int L = fin[t];
+        atomicExch(&queued[L], 0);
+        __threadfence();
+        const unsigned dl = __hip_atomic_load(&d[L], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int e1 = span[L].y;
+        for (int i = vstart[L]; i < e1; i++) {
+            const int F = ent[i].y;
+            const unsigned nd = max(dl, rank[i]);
+            if (nd < __hip_atomic_load(&d[F], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                const unsigned old = atomicMin(&d[F], nd);
+                if (nd < old) {
+                    __threadfence();
+                    if (atomicExch(&queued[F], 1) == 0) fout[atomicAdd(nout, 1)] = F;
+                }
+            }
+        }
+    }
+}
+// between two rounds: the frontier just written becomes the one to read, the other one's counter is cleared
+__global__ void k_growth_flip(int *__restrict__ count, int from) { count[from] = 0; }
+__global__ void k_growth_iota(int *__restrict__ v, int n) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) v[i] = i; }
+// the pass that opens the cascade of every lake in sorted order (only read at a cascade's first lake)
+__global__ void k_growth_heads(const unsigned *__restrict__ dsorted, const int *__restrict__ order, int *__restrict__ head, int n, int nent)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const unsigned x = dsorted[p];
+    head[p] = (x >= 1u && x <= (unsigned)nent) ? order[x - 1] : -1;
+}
+
 // ---- host ---------------------------------------------------------------------------------------------------------
 namespace {
 struct Pass { float h; int from; int tolocation; };
@@ -700,6 +787,147 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
     // solvingConnections (:533-595) on the reduced list, all lakes by dense id: entry i = pass into lake `lake` at
     // cell s from lake `from`; entries are sorted by (lake, height, from) -- built on the device (k_flow_entries)
     lap("host: entry table");
+    std::vector<int> assigned;                                         // connection events in order: connections[s] = entry
+    const bool mouth_filter_on = !(lakes & DMG_FLOW_FIX_MOUTH_FILTER);
+    // which growth: one host thread (small graphs: nothing to gain), or the cascades on all cores (k_growth_* above)
+    static const int growth_env = [] { const char *e = getenv("DMG_FLOW_GROWTH"); return !e ? 0 : (!strcmp(e, "serial") ? 1 : (!strcmp(e, "parallel") ? 2 : 0)); }();
+    const bool parallel_growth = nuniq > 0 && nmouth > 0 && (growth_env == 2 || (growth_env == 0 && nlakes >= 100000));
+    if (parallel_growth) {
+        typedef unsigned long long u64;
+        // (1) rank of every pass in the growth's total order (h, from, s): two stable radix sorts
+        dev_buf gks, gks2, gidx, gidx2, gkhf, gkhf2, gorder, grank, gd, gq, gfa, gfb, gcnt, gvs, gtmp, gds, gls, glid, ghead;
+        DMG_ALLOC(gks, (size_t)nuniq * 4); DMG_ALLOC(gks2, (size_t)nuniq * 4); DMG_ALLOC(gidx, (size_t)nuniq * 4); DMG_ALLOC(gidx2, (size_t)nuniq * 4);
+        DMG_ALLOC(gkhf, (size_t)nuniq * 8); DMG_ALLOC(gkhf2, (size_t)nuniq * 8); DMG_ALLOC(gorder, (size_t)nuniq * 4); DMG_ALLOC(grank, (size_t)nuniq * 4);
+        const unsigned eb = (unsigned)((nuniq + 255) / 256), lb = (unsigned)((nlakes + 255) / 256);
+        hipLaunchKernelGGL(k_growth_keys, dim3(eb), dim3(256), 0, st, (const int4 *)dent.p, (unsigned *)gks.p, gidx.i(), nuniq);
+        size_t t1 = 0, t2 = 0, t3 = 0;
+        (void)hipcub::DeviceRadixSort::SortPairs(nullptr, t1, (unsigned *)gks.p, (unsigned *)gks2.p, gidx.i(), gidx2.i(), nuniq, 0, 32, st);
+        (void)hipcub::DeviceRadixSort::SortPairs(nullptr, t2, (u64 *)gkhf.p, (u64 *)gkhf2.p, gidx2.i(), gorder.i(), nuniq, 0, 64, st);
+        (void)hipcub::DeviceRadixSort::SortPairs(nullptr, t3, (unsigned *)gks.p, (unsigned *)gks2.p, gidx.i(), gidx2.i(), nlakes, 0, 32, st);
+        DMG_ALLOC(gtmp, std::max(t1, std::max(t2, t3)) + 256);
+        DMG_HIP(hipcub::DeviceRadixSort::SortPairs(gtmp.p, t1, (unsigned *)gks.p, (unsigned *)gks2.p, gidx.i(), gidx2.i(), nuniq, 0, 32, st));      // by s
+        hipLaunchKernelGGL(k_growth_keys2, dim3(eb), dim3(256), 0, st, (const int4 *)dent.p, gidx2.i(), (u64 *)gkhf.p, nuniq);
+        DMG_HIP(hipcub::DeviceRadixSort::SortPairs(gtmp.p, t2, (u64 *)gkhf.p, (u64 *)gkhf2.p, gidx2.i(), gorder.i(), nuniq, 0, 64, st));           // stable by (h, from)
+        hipLaunchKernelGGL(k_growth_rank, dim3(eb), dim3(256), 0, st, gorder.i(), (unsigned *)grank.p, nuniq);
+        DMG_HIP(hipGetLastError());
+        // (2) where a lake's usable passes start: a river mouth's first look at its list drops the passes in front of the
+        // first one it can use -- neighbours that are mouths themselves and, with the reference's `Nthbit(c.from,10)` (:552),
+        // neighbours whose sink cell has bit 512 set -- for good (push_next(lake, initial) above)
+        std::vector<char> placed(nlakes, 0);
+        for (int m : mouths) placed[m] = 1;
+        std::vector<int> vstart((size_t)nlakes);
+        for (int l = 0; l < nlakes; l++) vstart[l] = span[l].cur;
+        for (int m : mouths) {
+            int i = span[m].cur;
+            for (; i < span[m].end; i++) {
+                if (placed[ent[i].from]) continue;
+                if (mouth_filter_on && (sink_cell[ent[i].from] & 512)) continue;
+                break;
+            }
+            vstart[m] = i;
+        }
+        if ((rc = upload_vec(ctx, gvs, vstart))) return rc;
+        // (3) minimax levels: frontier relaxation from the mouths until nothing falls any more
+        DMG_ALLOC(gd, (size_t)nlakes * 4); DMG_ALLOC(gq, (size_t)nlakes * 4); DMG_ALLOC(gfa, (size_t)nlakes * 4); DMG_ALLOC(gfb, (size_t)nlakes * 4); DMG_ALLOC(gcnt, 8);
+        hipLaunchKernelGGL(k_growth_init, dim3(lb), dim3(256), 0, st, (unsigned *)gd.p, gq.i(), nlakes);
+        hipLaunchKernelGGL(k_growth_seed, dim3((unsigned)((nmouth + 255) / 256)), dim3(256), 0, st, mouths_d.i(), nmouth, (unsigned *)gd.p, gfa.i(), gcnt.i());
+        int rounds = 0;
+        for (bool more = true; more;) {
+            for (int k = 0; k < 16; k++, rounds++) {
+                const int in = rounds & 1;
+                hipLaunchKernelGGL(k_growth_relax, dim3(512), dim3(256), 0, st, in ? gfb.i() : gfa.i(), gcnt.i() + in, in ? gfa.i() : gfb.i(), gcnt.i() + (in ^ 1),
+                                   (unsigned *)gd.p, (const int2 *)dspan.p, gvs.i(), (const int4 *)dent.p, (const unsigned *)grank.p, gq.i());
+                hipLaunchKernelGGL(k_growth_flip, dim3(1), dim3(1), 0, st, gcnt.i(), in);
+            }
+            int cnt[2] = { 0, 0 };
+            DMG_HIP(hipMemcpyAsync(cnt, gcnt.p, 8, hipMemcpyDeviceToHost, st));
+            DMG_HIP(hipStreamSynchronize(st));
+            more = cnt[rounds & 1] != 0;
+            if (rounds > 4 * nlakes + 64) return dmg_fail(DMG_ESTATE, "flow: the minimax levels of the lake graph did not settle");
+        }
+        // (4) lakes in order of their level; the pass that opens each lake's cascade
+        DMG_ALLOC(gds, (size_t)nlakes * 4); DMG_ALLOC(glid, (size_t)nlakes * 4); DMG_ALLOC(gls, (size_t)nlakes * 4); DMG_ALLOC(ghead, (size_t)nlakes * 4);
+        hipLaunchKernelGGL(k_growth_iota, dim3(lb), dim3(256), 0, st, glid.i(), nlakes);
+        DMG_HIP(hipcub::DeviceRadixSort::SortPairs(gtmp.p, t3, (unsigned *)gd.p, (unsigned *)gds.p, glid.i(), gls.i(), nlakes, 0, 32, st));
+        hipLaunchKernelGGL(k_growth_heads, dim3(lb), dim3(256), 0, st, (const unsigned *)gds.p, gorder.i(), ghead.i(), nlakes, nuniq);
+        DMG_HIP(hipGetLastError());
+        std::vector<unsigned> dl((size_t)nlakes), dsorted((size_t)nlakes);
+        std::vector<int> lsorted((size_t)nlakes), head((size_t)nlakes);
+        DMG_HIP(hipMemcpyAsync(dl.data(), gd.p, (size_t)nlakes * 4, hipMemcpyDeviceToHost, st));
+        DMG_HIP(hipMemcpyAsync(dsorted.data(), gds.p, (size_t)nlakes * 4, hipMemcpyDeviceToHost, st));
+        DMG_HIP(hipMemcpyAsync(lsorted.data(), gls.p, (size_t)nlakes * 4, hipMemcpyDeviceToHost, st));
+        DMG_HIP(hipMemcpyAsync(head.data(), ghead.p, (size_t)nlakes * 4, hipMemcpyDeviceToHost, st));
+        DMG_HIP(hipStreamSynchronize(st));
+        lap("growth: ranks + levels (device)");
+        // (5) the cascades, on all cores.  Sorted positions [p0, p1): the mouths (level 0), then the cascades by level, then
+        // the lakes no pass reaches.  A cascade of n lakes makes n connections, so its place in `assigned` is its place here.
+        size_t p0 = 0, p1 = (size_t)nlakes;
+        while (p0 < p1 && dsorted[p0] == 0u) p0++;
+        while (p1 > p0 && dsorted[p1 - 1] == 0xFFFFFFFFu) p1--;
+        assigned.assign(p1 - p0, -1);
+        std::vector<size_t> big;                                       // first positions of the cascades with more than one lake
+        for (size_t q = p0; q < p1;) {
+            size_t e = q + 1;
+            while (e < p1 && dsorted[e] == dsorted[q]) e++;
+            if (e - q > 1) big.push_back(q);
+            else assigned[q - p0] = head[q];
+            q = e;
+        }
+        std::atomic<size_t> next{0};
+        std::atomic<int> bad{0};
+        struct Cand { float h; int from, s, idx, lake; };
+        auto worse = [](const Cand &a, const Cand &b) { return std::tie(a.h, a.from, a.s) > std::tie(b.h, b.from, b.s); };
+        auto work = [&]() {
+            std::vector<Cand> heap;
+            for (;;) {
+                const size_t w = next.fetch_add(1);
+                if (w >= big.size()) break;
+                const size_t q = big[w];
+                const unsigned x = dsorted[q];
+                size_t e = q + 1;
+                while (e < p1 && dsorted[e] == x) e++;
+                const int ex = head[q];
+                if (ex < 0 || dl[ent[ex].from] != x) { bad++; continue; }
+                heap.clear();
+                size_t pos = q - p0;
+                auto push_next = [&](int lake) {
+                    Span &sp = span[lake];
+                    while (sp.cur < sp.end) {
+                        const int i = sp.cur++;
+                        const int f = ent[i].from;
+                        if (dl[f] != x || placed[f]) continue;             // (another cascade's lake is never looked at: its flag is another thread's)
+                        heap.push_back(Cand{ ent[i].h, f, ent[i].s, i, lake });
+                        std::push_heap(heap.begin(), heap.end(), worse);
+                        break;
+                    }
+                };
+                const int f0 = ent[ex].from;
+                placed[f0] = 1;
+                assigned[pos++] = ex;
+                push_next(f0);
+                while (!heap.empty()) {
+                    std::pop_heap(heap.begin(), heap.end(), worse);
+                    const Cand top = heap.back();
+                    heap.pop_back();
+                    if (placed[top.from]) { push_next(top.lake); continue; }
+                    placed[top.from] = 1;
+                    if (pos >= e - p0) { bad++; break; }
+                    assigned[pos++] = top.idx;
+                    push_next(top.lake);
+                    push_next(top.from);
+                }
+                if (pos != e - p0) bad++;
+            }
+        };
+        const unsigned nthreads = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+        std::vector<std::thread> pool;
+        for (unsigned k = 1; k < nthreads; k++) pool.emplace_back(work);
+        work();
+        for (auto &t : pool) t.join();
+        if (bad.load()) return dmg_fail(DMG_ESTATE, "flow: the parallel growth of the lake graph lost a lake (%d cascades inconsistent)", bad.load());
+        if (timing) fprintf(stderr, "[flow] parallel growth: %d relaxation rounds, %zu connections, %zu cascades with more than one lake, %u threads\n", rounds, assigned.size(),
+                            big.size(), nthreads);
+    } else {
     // the heap carries its keys (16 B) instead of indices into `ent`: a sift touches only the heap's own cache lines
     struct Cand { float h; int from, s, idx, lake; };                  // (lake: of the entry, so that a pop need not look it up)
     auto worse = [](const Cand &a, const Cand &b) {                    // priority_queue keeps the LOWEST (h, from, s) on top
@@ -762,7 +990,7 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
     // The growth hops all over the map, so each visit of a lake is a chain of cache misses (its span, its first unread
     // entry, the flag of that entry's lake).  The lake a candidate would place is known when the candidate is pushed:
     // its span is prefetched then, and its first entry when the candidate is popped, one lake's worth of work ahead.
-    const bool mouth_filter = !(lakes & DMG_FLOW_FIX_MOUTH_FILTER);
+    const bool mouth_filter = mouth_filter_on;
     auto push_next = [&](int lake, bool initial = false) {
         Span &sp = span[lake];
         while (sp.cur < sp.end) {
@@ -776,7 +1004,9 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
         }
     };
     const bool far_tables = (size_t)nuniq * sizeof(Entry) > ((size_t)32 << 20);
-    std::vector<int> assigned;                                         // connection events in order: connections[s] = entry
+    std::vector<int> stat_depth;
+    int stat_maxdepth = 0, stat_from = 0, stat_s = 0; long long stat_ncascade = 0, stat_cur = 0, stat_maxcascade = 0, stat_multi = 0, stat_inmulti = 0;
+    float stat_h = 0.0f; bool stat_have = false;
     for (int lake : mouths) push_next(lake, true);
     while (!candidates.empty()) {
         const Cand top = candidates.top();
@@ -798,10 +1028,24 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
         }
         if (placed[top.from]) { push_next(top.lake); continue; }
         placed[top.from] = 1;
+        if (timing) {                                                  // statistics for DESIGN.md (the growth's structure): hops and "cascades"
+            if (stat_depth.empty()) stat_depth.assign((size_t)nlakes, 0);
+            stat_depth[top.from] = stat_depth[top.lake] + 1;
+            stat_maxdepth = std::max(stat_maxdepth, stat_depth[top.from]);
+            const bool higher = !stat_have || std::tie(top.h, top.from, top.s) > std::tie(stat_h, stat_from, stat_s);
+            if (higher) { stat_have = true; stat_h = top.h; stat_from = top.from; stat_s = top.s; stat_ncascade++; stat_cur = 0; }
+            stat_cur++;
+            stat_maxcascade = std::max(stat_maxcascade, stat_cur);
+            if (stat_cur == 2) stat_multi++;
+            if (stat_cur >= 2) stat_inmulti += stat_cur == 2 ? 2 : 1;
+        }
         __builtin_prefetch(&ent[span[top.from].cur]);
         assigned.push_back(c);                                         // a later pass at the same cell replaces this one (:588)
         push_next(top.lake);                                           // (independent of the next line: disjoint lakes)
         push_next(top.from);
+    }
+    if (timing) fprintf(stderr, "[flow] growth: %zu connections, deepest lake %d hops from its river mouth; %lld cascades (a new highest pass = a new cascade), "
+                                "%lld of them with more than one lake holding %lld lakes, the largest %lld lakes\n", assigned.size(), stat_maxdepth, stat_ncascade, stat_multi, stat_inmulti, stat_maxcascade);
     }
     lap("host: prim growth");
     // connections[tolocation] = pass (:588): per tolocation cell the LAST assigned entry survives; its lake hangs one below

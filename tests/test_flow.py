@@ -246,3 +246,53 @@ def test_flow_lake_drawing(dev, oracle):
     got = ctx.flow_accumulate(capi.make_grid(W, H), h, 0.5, 1.0, lakes=1)
     assert (ref == 0).sum() > 50                          # the case has lakes
     assert np.array_equal(got, ref)
+
+
+def _flow_child(code, env_extra, timeout=900):
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **env_extra)
+    return subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+@pytest.mark.gpu
+def test_flow_suite_through_the_parallel_growth():
+    """the growth of the lake graph runs as independent cascades on all host cores above 100 000 lakes
+    (flow.hip, k_growth_*).  DMG_FLOW_GROWTH=parallel forces that path at every size: this file's oracle comparisons (flow,
+    lakes, selection, the mouth-filter flag, the erosion loops) once more through it, in a child process (the variable is
+    read once)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DMG_FLOW_GROWTH="parallel")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_flow.py"), "-q", "-m", "gpu", "-x", "-k",
+                        "matches_oracle or mouth_filter or selection or lake_drawing or round_by_round or conservation"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+_GROWTH_CHILD = """
+import sys, time, hashlib
+import numpy as np
+sys.path.insert(0, '.')
+from demiurge_amd import capi, synth
+ctx = capi.Context(0)
+for W, H, seed, amp in ((4096, 2048, 5, 3.0), (16384, 8192, 11, 6.0)):
+    h = (synth.terrain(W, H) * 100 + synth.lcg_uniform(W * H, seed).reshape(H, W) * amp).astype(np.float32)
+    for lakes in (0, 1):
+        t0 = time.perf_counter()
+        f = ctx.flow_accumulate(capi.make_grid(W, H), h, 0.5, 0.5, lakes=lakes)
+        print(W, H, lakes, hashlib.sha256(f.tobytes()).hexdigest(), '%.3f s' % (time.perf_counter() - t0), flush=True)
+ctx.close()
+"""
+
+
+@pytest.mark.gpu
+def test_flow_parallel_growth_equals_serial_at_size():
+    """the same flow fields, bit for bit (SHA-256), from the one-thread growth and from the cascades on all cores, at
+    BASELINE config 2's 4096x2048 and config 5's 16384x8192 (2.7 M lakes, 11 M lake pairs), with and without lake drawing"""
+    outs = {}
+    for mode in ("serial", "parallel"):
+        r = _flow_child(_GROWTH_CHILD, {"DMG_FLOW_GROWTH": mode})
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        outs[mode] = [l.split()[:4] for l in r.stdout.strip().splitlines()]
+    assert len(outs["serial"]) == 4 and outs["serial"] == outs["parallel"], (outs["serial"], outs["parallel"])
