@@ -709,11 +709,10 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
         DMG_HIP(hipStreamSynchronize(st));
         nlakes = last_dense + last_flag;
     }
-    std::vector<int> sink_cell(nlakes);
+    std::vector<int> sink_cell;                              // on the host only if a growth will read it (below, once the mouths are counted)
     if (nlakes) {
         DMG_ALLOC(sinkc, (size_t)nlakes * 4);
         hipLaunchKernelGGL(k_flow_sinkcells, dim3(nb), dim3(256), 0, st, label.i(), dense.i(), sinkc.i(), N);
-        DMG_HIP(hipMemcpyAsync(sink_cell.data(), sinkc.p, (size_t)nlakes * 4, hipMemcpyDeviceToHost, st));
     }
 
     // boundary cells -> pass candidates; reduce to the lowest pass per lake pair on the device:
@@ -738,6 +737,10 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
     if (ncand > cap) return dmg_fail(DMG_ENOMEM, "flow: %d pass candidates exceed the buffer", ncand);
     std::vector<int> mouths(nmouth);
     if (nmouth) DMG_HIP(hipMemcpyAsync(mouths.data(), mouths_d.p, (size_t)nmouth * 4, hipMemcpyDeviceToHost, st));
+    if (nmouth && ncand && nlakes) {                         // the growth's `Nthbit(c.from,10)` test (:552) reads the lakes' sink cells
+        sink_cell.resize((size_t)nlakes);
+        DMG_HIP(hipMemcpyAsync(sink_cell.data(), sinkc.p, (size_t)nlakes * 4, hipMemcpyDeviceToHost, st));
+    }
 
     int nuniq = 0;
     struct Entry { float h; int from, s, lake; };                     // = the int4 k_flow_entries writes
@@ -745,9 +748,13 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
     // the growth below visits these two tables in random order, a few hundred megabytes of them: transparent huge pages
     // (where the host allows them) take the TLB miss out of every visit
     std::vector<Entry, thp_allocator<Entry>> ent;
-    std::vector<Span, thp_allocator<Span>> span(nlakes + 1, Span{ 0, 0 });
+    std::vector<Span, thp_allocator<Span>> span((ncand && nmouth) ? (size_t)nlakes + 1 : (size_t)0, Span{ 0, 0 });   // (no mouths: no growth, no tables)
     dev_buf dent, dspan;
-    if (ncand) {
+    // Without a river mouth the growth has nowhere to start (solvingConnections, :533-595, begins at the mouths): no pass is
+    // ever looked at, so the reduction of the candidates to lake pairs is skipped.  Config 5 meets this case every
+    // iteration: the terrain the tectonics render pass leaves is the plate map (a handful of flat values, Tectonics.cpp:590),
+    // on which every cell is a lake of its own -- 134 M candidates at 16384x8192, 0.37 s of sorting that led nowhere.
+    if (ncand && nmouth) {
         typedef unsigned long long u64;
         size_t tb = 0, tb2 = 0;
         (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb, (u64 *)v0.p, (u64 *)v1.p, (u64 *)k0.p, (u64 *)k1.p, ncand, 0, 64, st);
@@ -930,7 +937,7 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
         if (bad.load()) return dmg_fail(DMG_ESTATE, "flow: the parallel growth of the lake graph lost a lake (%d cascades inconsistent)", bad.load());
         if (timing) fprintf(stderr, "[flow] parallel growth: %d relaxation rounds, %zu connections, %zu cascades with more than one lake, %u threads\n", rounds, assigned.size(),
                             (size_t)nbig.load(), nthreads);
-    } else {
+    } else if (nuniq > 0 && nmouth > 0) {
     // the heap carries its keys (16 B) instead of indices into `ent`: a sift touches only the heap's own cache lines
     struct Cand { float h; int from, s, idx, lake; };                  // (lake: of the entry, so that a pop need not look it up)
     auto worse = [](const Cand &a, const Cand &b) {                    // priority_queue keeps the LOWEST (h, from, s) on top
