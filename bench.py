@@ -228,18 +228,23 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     dist = None
-    unique_id = None
     if world > 1:
         import torch.distributed as dist
         if rehearsal:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=device)
+
+
+    def fresh_id():
+        """a new 128-byte RCCL id from rank 0 to everybody: one per communicator (an id serves ONE ncclCommInitRank round)"""
+        if world == 1:
+            return None
         idt = torch.zeros(128, dtype=torch.uint8, device="cpu" if rehearsal else device)
         if rank == 0:
             idt = torch.tensor(list(capi.Multi.unique_id()), dtype=torch.uint8, device=idt.device)
         dist.broadcast(idt, 0)                                        # the library's own RCCL communicator is built from it
-        unique_id = bytes(idt.cpu().tolist())
+        return bytes(idt.cpu().tolist())
 
     W, H, sweeps = args.width, args.height, args.sweeps
     ghost = max(1, min(args.ghost, H // world))
@@ -253,7 +258,7 @@ def main():
         if rehearsal and world > 1:
             m = capi.Multi(grid, devices=[0] * world, ghost=ghost, params=prm, flags=capi.MULTI_PEER | order)
         else:
-            m = capi.Multi(grid, rank=rank, world=world, unique_id=unique_id, device=dev_index, ghost=ghost, params=prm, flags=order)
+            m = capi.Multi(grid, rank=rank, world=world, unique_id=fresh_id(), device=dev_index, ghost=ghost, params=prm, flags=order)
         m.set_terrain(synth.terrain(W, H) if terrain == "survey" else -np.ones((H, W), np.float32))
         m.set_divw(synth.divw(W, H))
         return m

@@ -68,10 +68,11 @@ t.close()
 t0 = time.perf_counter(); ctx.erosion_run(g, h, 50, 2, 0.5, 1.0, 1.0); dt = time.perf_counter() - t0
 emit(config=5, line="erosion round 16384x8192 (incl. PCIe of the heights)", ms_per_round=dt / 2 * 1e3)
 T0 = np.full((H, W), 50, np.float32)
-ctx.temperature_steps(g, T0, h, 0, 1)
-t0 = time.perf_counter(); ctx.temperature_steps(g, T0, h, 0, 1); ta = time.perf_counter() - t0
-t0 = time.perf_counter(); ctx.temperature_steps(g, T0, h, 0, 21); tb = time.perf_counter() - t0
-emit(config=5, line="climate step 16384x8192", ms_per_step=(tb - ta) / 20 * 1e3)
+k = capi.Climate(ctx, g, T0, h)                                  # field resident on the device: a step costs its kernels
+k.steps(0, 10); ctx.sync()
+t0 = time.perf_counter(); k.steps(10, 100); ctx.sync(); dt = time.perf_counter() - t0
+k.close()
+emit(config=5, line="climate step 16384x8192 (field resident on the device)", ms_per_step=dt / 100 * 1e3)
 
 # config 5 through its entry point: one coupled iteration (tectonics step -> erosion round -> 10 climate steps)
 terr = (synth.terrain(W, H) * 100).astype(np.float32)
