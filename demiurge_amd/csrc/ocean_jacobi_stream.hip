@@ -1243,6 +1243,27 @@ static const dmg_ocean::tile_list *st_units(dmg_ocean *o, int variant, int lo, i
             for (const st_unit &u : best) total += u.cost;
             fprintf(stderr, "[stream] rows [%d,%d) part %d: %zu units, %d rows up to row %d then %d; predicted span %.0f, mean load %.0f (%.1f %% of the slots' time)\n",
                     lo, hi, part, best.size(), best_seg, best_split, best_seg2, best_span, total / slots, 100.0 * total / slots / best_span);
+            // which path the steps of these units take (host classes: 0 open, 1 land, 2 mixed), and how many of the rows that go
+            // through the coast formula in an all-coast step are open water
+            const std::vector<unsigned char> &table = variant ? o->rowclass_n_host : o->rowclass_host;
+            if (!table.empty()) {
+                long long n1 = 0, n2 = 0, n0 = 0, rows2 = 0, open2 = 0;
+                for (const st_unit &u : best) {
+                    const unsigned char *cls = table.data() + (size_t)u.tx * o->L;
+                    const int e0 = u.r0 - TB_T, nst = (((u.r1 - u.r0) + 2 * TB_T + 3) / 4) * 2;
+                    for (int t = TB_T; t < nst; t++) {
+                        bool land = false, mix = false; int nopen = 0;
+                        for (int k = 0; k < 10; k++) {
+                            const int r = e0 + 2 * t + 1 - k;
+                            const int c = (r >= 0 && r < o->L) ? cls[r] : 2;
+                            land |= c == 1; mix |= c == 2; nopen += c == 0;
+                        }
+                        if (land) n0++; else if (mix) { n2++; rows2 += 10; open2 += nopen; } else n1++;
+                    }
+                }
+                fprintf(stderr, "[stream]   steps past the fill: %.1f %% open (no test), %.1f %% all through the coast formula, %.1f %% tested; of the rows in flight in coast steps %.1f %% are open water\n",
+                        100.0 * n1 / (n1 + n2 + n0 + 1e-9), 100.0 * n2 / (n1 + n2 + n0 + 1e-9), 100.0 * n0 / (n1 + n2 + n0 + 1e-9), 100.0 * open2 / (rows2 + 1e-9));
+            }
         }
     }
     {

@@ -244,7 +244,11 @@ typedef struct dmg_multi dmg_multi;
 #define DMG_MULTI_TRANSPORT_MASK 15
 #define DMG_MULTI_EXCHANGE_THEN_SWEEP 0     /* order of a Jacobi block: refresh the ghost rows, then sweep (default) */
 #define DMG_MULTI_OVERLAP_LAST_LAUNCH 16    /* the exchange for the next block runs while the interior of this block's last
-                                               launch is swept (dmg_ocean_jacobi_sweeps_begin/_end) */
+                                               launch is swept: that launch's edge units and the exchange behind them go
+                                               to the band's second, high-priority stream, the interior units to its own
+                                               stream at the same time, and the own stream waits for the exchange in front
+                                               of the next block only.  Needs more than HIP's default four hardware
+                                               queues (GPU_MAX_HW_QUEUES; the library asks for 8 when it is loaded) */
 #define DMG_MULTI_ID_BYTES 128
 /* One process, n_bands bands; device_ids[i] = HIP device of band i (ids may repeat with DMG_MULTI_PEER / _LOOPBACK).
  * ghost = halo rows per band side: the Jacobi solve exchanges every `ghost` sweeps (rounded down to whole 8-sweep
@@ -256,6 +260,9 @@ int dmg_multi_create(int n_bands, const int *device_ids, const dmg_grid *grid, c
 int dmg_multi_unique_id(void *id128);
 int dmg_multi_create_rank(int rank, int n_ranks, const void *id128, int device_id, const dmg_grid *grid, const dmg_ocean_params *params,
                           int ghost, int flags, dmg_multi **out);
+/* A band that fails with a runtime error aborts the local RCCL communicators (queued receives end instead of waiting for a
+ * peer that will never send) and the handle then refuses everything but dmg_multi_destroy (DMG_ESTATE).  Host-side waits
+ * of the RCCL transports give up after DMG_MULTI_TIMEOUT_MS (environment, default 120000) with DMG_EHIP. */
 void dmg_multi_destroy(dmg_multi *m);
 int dmg_multi_set_order(dmg_multi *m, int order);          /* DMG_MULTI_EXCHANGE_THEN_SWEEP | DMG_MULTI_OVERLAP_LAST_LAUNCH, per call site */
 /* the dmg_ocean_* calls of the same names, on every local band (full-grid arrays; each band takes / fills its rows) */
