@@ -295,8 +295,8 @@ __device__ __forceinline__ void st_level(const st_args &a, st_state &z, v4f (*br
 // wide form: lane l holds the classes of window rows l, 64 + l, 128 + l, 192 + l as four bytes
 __device__ __forceinline__ unsigned st_class4(unsigned cls4, int i)
 {
-    if (i > 255) return 2u;                                  // the padding rows of the last step: never used
-    return ((unsigned)__builtin_amdgcn_readlane((int)cls4, i & 63) >> ((i >> 6) * 8)) & 0xFFu;
+    // (i < 256 always: a unit has at most ST_MAXROWS = 232 rows, its window 248, its steps' rows 2 t + 1 <= 251)
+    return ((unsigned)__builtin_amdgcn_readlane((int)cls4, i & 63) >> (((i >> 6) & 3) * 8)) & 0xFFu;
 }
 __device__ __forceinline__ unsigned st_class(unsigned cls_lo, unsigned cls_hi, int i)
 {
@@ -313,24 +313,28 @@ __device__ __forceinline__ unsigned st_class(unsigned cls_lo, unsigned cls_hi, i
 template <bool P>
 __device__ __forceinline__ void st_fetch(const st_args &a, st_state &z, int set, int j, int e, int col, int colp, int tx = 0)
 {
+    // Three scalar row bases and one 32-bit byte offset per lane: the loads take the SGPR-base + VGPR-offset form, whichever
+    // way the bases were found -- advanced by a row (plain units: rows are fetched in order e0, e0 + 1, ...; a step spends a
+    // third of its instructions outside its levels, most of them scalar address arithmetic: per-step clocks)
+    // or mapped (mirror beyond a pole or an edge, clamp beyond the stored band).  One set of load instructions for both:
+    // written as two branches that each load, the compiler merges them and builds every address in a VGPR pair.
+    const char *bp, *bb, *bc;
+    bool shift = false;
+    int ml = 0;
     if (!P && z.plain && !ST_DBG(a, 1)) {
-        // (rows are fetched in order: e0, e0 + 1, ...; a step spends a third of its instructions outside its levels, most of
-        // them scalar address arithmetic -- per-step clocks)
-        z.ps[set][j] = *reinterpret_cast<const v4f *>(z.nx_p + (unsigned)col);
-        z.bs[set][j] = *reinterpret_cast<const v4f *>(z.nx_b + (unsigned)col);
-        z.cs[set][j] = *reinterpret_cast<const unsigned *>(z.nx_c + (unsigned)col);
+        bp = reinterpret_cast<const char *>(z.nx_p); bb = reinterpret_cast<const char *>(z.nx_b); bc = reinterpret_cast<const char *>(z.nx_c);
         z.nx_p += a.W; z.nx_b += a.W; z.nx_c += a.W;
-        return;
+    } else {
+        const st_row m = st_map_row(a, ST_DBG(a, 1) ? (e & 63) : e);
+        const size_t rowoff = (size_t)m.l * a.W;
+        bp = reinterpret_cast<const char *>(a.pin + rowoff); bb = reinterpret_cast<const char *>(a.b + rowoff); bc = reinterpret_cast<const char *>(a.code + rowoff);
+        shift = m.shift; ml = m.l;
     }
-    const st_row m = st_map_row(a, ST_DBG(a, 1) ? (e & 63) : e);
-    // the row's base address is wave-uniform (scalar arithmetic), the lane adds a 32-bit column offset: the loads take
-    // the SGPR-base + VGPR-offset form and the 64-bit address arithmetic leaves the vector ALU
-    const size_t rowoff = (size_t)m.l * a.W;
-    const unsigned coff = (unsigned)(m.shift ? colp : col);
-    z.ps[set][j] = *reinterpret_cast<const v4f *>(a.pin + rowoff + coff);
-    z.bs[set][j] = *reinterpret_cast<const v4f *>(a.b + rowoff + coff);
-    z.cs[set][j] = *reinterpret_cast<const unsigned *>(a.code + rowoff + coff);
-    if (P && ST_DBG(a, 64)) z.ks[set][j] = a.rowclass32[(size_t)tx * a.L + m.l];          // every lane the same word
+    const unsigned cc = (unsigned)(shift ? colp : col);
+    z.ps[set][j] = *reinterpret_cast<const v4f *>(bp + cc * 4u);
+    z.bs[set][j] = *reinterpret_cast<const v4f *>(bb + cc * 4u);
+    z.cs[set][j] = *reinterpret_cast<const unsigned *>(bc + cc);
+    if (P && ST_DBG(a, 64)) z.ks[set][j] = a.rowclass32[(size_t)tx * a.L + ml];          // every lane the same word
 }
 typedef const float __attribute__((address_space(4))) *st_kptr;
 
