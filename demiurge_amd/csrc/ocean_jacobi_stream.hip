@@ -166,6 +166,7 @@ struct st_state {
     v4f ps[2][2], bs[2][2];
     unsigned cs[2][2];
     unsigned ks[2][2];              // persistent form: the row's class travels with its loads
+    unsigned fc[2][2];              // unit form: the class byte of the row in flight (looked up when its loads are issued: scalar)
     unsigned landbits, mixbits;     // bit j: row (newest - j) is land everywhere / has coast; newest = second row of this step's pair
     // units whose whole window (and the rows requested past it) lies inside the grid and the stored band fetch their rows
     // through three row pointers that advance by one row per fetch (scalar adds) instead of mapping every row index
@@ -311,7 +312,7 @@ __device__ __forceinline__ unsigned st_class(unsigned cls_lo, unsigned cls_hi, i
 // (Measured and dropped: pointing the loads a row does not need -- everything of a land row, the codes of an open-ocean
 // row -- at an already cached row saves ~10 % of the bytes but costs more in address arithmetic: 2.58 -> 2.49 M.)
 template <bool P>
-__device__ __forceinline__ void st_fetch(const st_args &a, st_state &z, int set, int j, int e, int col, int colp, int tx = 0)
+__device__ __forceinline__ void st_fetch(const st_args &a, st_state &z, int set, int j, int e, int col, int colp, int tx = 0, unsigned cls = 2u)
 {
     // Three scalar row bases and one 32-bit byte offset per lane: the loads take the SGPR-base + VGPR-offset form, whichever
     // way the bases were found -- advanced by a row (plain units: rows are fetched in order e0, e0 + 1, ...; a step spends a
@@ -330,6 +331,9 @@ __device__ __forceinline__ void st_fetch(const st_args &a, st_state &z, int set,
         bp = reinterpret_cast<const char *>(a.pin + rowoff); bb = reinterpret_cast<const char *>(a.b + rowoff); bc = reinterpret_cast<const char *>(a.code + rowoff);
         shift = m.shift; ml = m.l;
     }
+    // an open-water row's codes are never looked at (st_arrive): its load goes to the band's first row, which every wave
+    // keeps in the L2 -- the same instruction, a ninth of the row's bytes less from HBM
+    if (!P && (cls & 3u) == 0u) bc = reinterpret_cast<const char *>(a.code);
     const unsigned cc = (unsigned)(shift ? colp : col);
     z.ps[set][j] = *reinterpret_cast<const v4f *>(bp + cc * 4u);
     z.bs[set][j] = *reinterpret_cast<const v4f *>(bb + cc * 4u);
@@ -418,7 +422,7 @@ __device__ __forceinline__ void st_step(const st_args &a, st_state &z, v4f (*bri
     const int e_t = e0 + 2 * t;                              // first row of the pair that has just arrived
     const int slotB = z.slot + 1;                            // (ST_RING is even: a pair never wraps)
     unsigned landA, mixA, landB, mixB;
-    const unsigned clsA = P ? st_class_p<K>(a, z, 0, e_t) : st_class4(cls_lo, 2 * t), clsB = P ? st_class_p<K>(a, z, 1, e_t + 1) : st_class4(cls_lo, 2 * t + 1);
+    const unsigned clsA = P ? st_class_p<K>(a, z, 0, e_t) : z.fc[K][0], clsB = P ? st_class_p<K>(a, z, 1, e_t + 1) : z.fc[K][1];
 #ifdef ST_EXPERIMENTS
     // DMG_ST_STEPPROF: slots 22..42 = the clock when the even step's rows have arrived (its wait for the staged loads is over),
     // slots 43..62 = when the even step's levels are done, of a unit's first 20 iterations (slots 0..21: top of the iteration)
@@ -434,8 +438,9 @@ __device__ __forceinline__ void st_step(const st_args &a, st_state &z, v4f (*bri
     if (DV) z.badbits = (z.badbits << 2) | ((clsA >> 1) & 2u) | ((clsB >> 2) & 1u);
     const unsigned special = DV ? z.badbits : 0u;           // rows that need the tested path like an all-land row does
     // the staging set is free again: the pair of step t + 2 (past the window's end the rows are clamped and unused)
-    st_fetch<P>(a, z, K, 0, e_t + 4, col, colp, tx);
-    st_fetch<P>(a, z, K, 1, e_t + 5, col, colp, tx);
+    if (!P) { z.fc[K][0] = st_class4(cls_lo, 2 * t + 4); z.fc[K][1] = st_class4(cls_lo, 2 * t + 5); }
+    st_fetch<P>(a, z, K, 0, e_t + 4, col, colp, tx, P ? 2u : z.fc[K][0]);
+    st_fetch<P>(a, z, K, 1, e_t + 5, col, colp, tx, P ? 2u : z.fc[K][1]);
     // level 1: rows e_t - 1 (in the ring since the last step) and e_t (just written)
     const int s1 = st_wrap(z.slot - 1), r1w = max(2 * t - 1, 0);
     v4f bq[9], kq[9];
@@ -547,6 +552,7 @@ __global__ __launch_bounds__(64, 2) void k_jacobi_stream(st_args a)
         for (int k = 0; k < 2; k++) { z.w[s][k][0] = (v4f)(0.0f); z.w[s][k][1] = (v4f)(0.0f); }
     z.landbits = 0xFFFFFFFFu;                                // rows before the window: "land", so that a level idles until its rows exist
     z.mixbits = 0; z.slot = 0; z.badbits = 0;
+    z.fc[0][0] = st_class4(cls_lo, 0); z.fc[0][1] = st_class4(cls_lo, 1); z.fc[1][0] = st_class4(cls_lo, 2); z.fc[1][1] = st_class4(cls_lo, 3);
     {
         // one 16-byte table entry per window row (two spare: the next level's prefetch): all of a lane's (up to four) loads in
         // flight together -- a loop of load, wait, store costs a unit a memory round trip per 64 rows
