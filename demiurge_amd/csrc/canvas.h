@@ -107,7 +107,15 @@ struct dev_buf {
     hipError_t alloc(dmg_ctx *ctx, size_t n)
     {
         owner = ctx;
+        // sizes that depend on the data (lakes, passes, lake pairs: different every erosion round) are rounded up to three
+        // significant bits, so that a round finds the blocks the round before it parked: the pool matches sizes exactly, and a
+        // miss is a hipMalloc now and a hipFree (which synchronises) later
         bytes = (n + 255) & ~(size_t)255;
+        if (bytes > 1024) {
+            int m = 63 - __builtin_clzll((unsigned long long)bytes);
+            const size_t step = (size_t)1 << (m - 2);
+            bytes = (bytes + step - 1) & ~(step - 1);
+        }
         return dmg_scratch_alloc(ctx, bytes, &p);
     }
     float *f() const { return (float *)p; }

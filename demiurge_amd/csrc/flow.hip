@@ -198,43 +198,79 @@ __global__ void k_flow_sinkcells(const int *__restrict__ label, const int *__res
     if (i < n && label[i] == (int)i) sink_cell[dense[i]] = (int)i;
 }
 
+// Appending to one list from every cell: atomics on ONE address are served one wave-instruction at a time, ~5 ns each,
+// whether 64 lanes or one take part (k_flow_passes with an atomicAdd per candidate: 0.47 ms at 4096x2048, 10 ms at
+// 16384x8192 -- and exactly the same with one add per wave).  So a block of 256 threads looks at FLOW_ITEMS cells per
+// thread, keeps what it finds in registers, and takes all its slots with a single add.  Called by every thread of the
+// block, once.
+#define FLOW_ITEMS 16
+__device__ __forceinline__ int block_append_base(int c, int *count)
+{
+    __shared__ int s_tot[4], s_base;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int inc = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+    if (lane == 63) s_tot[w] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) { const int t = s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3]; s_base = t ? atomicAdd(count, t) : 0; }
+    __syncthreads();
+    int off = s_base;
+    for (int k = 0; k < w; k++) off += s_tot[k];
+    return off + inc - c;
+}
+
 // ---- pass candidates --------------------------------------------------------------------------------------------
 // One candidate per boundary cell s: the lowest neighbour that belongs to another catchment (:470-492).
 //   key = (dense id of the lake of s) << 32 | (dense id of the neighbouring lake)     val = (pass height bits) << 32 | s
 // heights are > 0, so their fp32 bit patterns order like the values; dense ids order like the sink cell indices.
-__global__ void k_flow_passes(flow_canvas fc, const float *__restrict__ h, const int *__restrict__ label, const int *__restrict__ dense,
-                              const unsigned short *__restrict__ mask, unsigned long long *__restrict__ key,
-                              unsigned long long *__restrict__ val, int *__restrict__ count, int cap)
+__global__ __launch_bounds__(256) void k_flow_passes(flow_canvas fc, const float *__restrict__ h, const int *__restrict__ label, const int *__restrict__ dense,
+                                                     const unsigned short *__restrict__ mask, unsigned long long *__restrict__ key,
+                                                     unsigned long long *__restrict__ val, int *__restrict__ count, int cap)
 {
-    int W = fc.c.W, H = fc.c.H;
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)W * H) return;
-    int lake = label[i];
-    if (lake < 0) return;
-    int x0 = (int)(i % W), y0 = (int)(i / W);
-    float minpass = INFINITY;
-    int nlake = -1;
+    const int W = fc.c.W, H = fc.c.H;
+    const size_t N = (size_t)W * H;
+    int found[FLOW_ITEMS];                              // the neighbour cell the pass leads to, or -1
+    float pass[FLOW_ITEMS];
+    int c = 0;
 #pragma unroll
-    for (int k = 0; k < 8; k++) {                       // FlowFilter::neighbours order, strict '<' keeps the first
-        int x = x0 + c_ndx[k], y = y0 + c_ndy[k];
-        if (fc.wrap) x = (x + W) % W; else if (x < 0 || x >= W) continue;
-        if (y < 0 || y >= H) continue;
-        int n = y * W + x;
-        int ln = label[n];
-        if (ln < 0 || ln == lake) continue;             // the adjacency pass: another lake's id (:417-439)
-        float bd = h[n];
-        if (bd > 0.0f && bd < minpass) { minpass = bd; nlake = n; }     // :476-481
+    for (int t = 0; t < FLOW_ITEMS; t++) {
+        const size_t i = ((size_t)blockIdx.x * FLOW_ITEMS + t) * 256 + threadIdx.x;
+        const int lake = i < N ? label[i] : -1;
+        float minpass = INFINITY;
+        int nlake = -1;
+        if (lake >= 0) {
+            const int x0 = (int)(i % W), y0 = (int)(i / W);
+#pragma unroll
+            for (int k = 0; k < 8; k++) {               // FlowFilter::neighbours order, strict '<' keeps the first
+                int x = x0 + c_ndx[k], y = y0 + c_ndy[k];
+                if (fc.wrap) x = (x + W) % W; else if (x < 0 || x >= W) continue;
+                if (y < 0 || y >= H) continue;
+                const int n = y * W + x;
+                const int ln = label[n];
+                if (ln < 0 || ln == lake) continue;     // the adjacency pass: another lake's id (:417-439)
+                const float bd = h[n];
+                if (bd > 0.0f && bd < minpass) { minpass = bd; nlake = n; }     // :476-481
+            }
+        }
+        if (nlake >= 0 && (mask[label[nlake]] & 512u)) nlake = -1;             // never towards a river-mouth lake (:484)
+        found[t] = nlake; pass[t] = minpass;
+        c += nlake >= 0;
     }
-    if (nlake < 0) return;
-    int lid = label[nlake];
-    if (mask[lid] & 512u) return;                       // never towards a river-mouth lake (:484)
-    int slot = atomicAdd(count, 1);
-    if (slot < cap) {
-        key[slot] = ((unsigned long long)(unsigned)dense[lake] << 32) | (unsigned)dense[lid];
-        val[slot] = ((unsigned long long)__float_as_uint(fmaxf(minpass, h[i])) << 32) | (unsigned)i;
+    int slot = block_append_base(c, count);             // (the order of the candidates does not matter: they are sorted next)
+#pragma unroll
+    for (int t = 0; t < FLOW_ITEMS; t++) {
+        if (found[t] < 0) continue;
+        const size_t i = ((size_t)blockIdx.x * FLOW_ITEMS + t) * 256 + threadIdx.x;
+        if (slot < cap) {
+            key[slot] = ((unsigned long long)(unsigned)dense[label[i]] << 32) | (unsigned)dense[label[found[t]]];
+            val[slot] = ((unsigned long long)__float_as_uint(fmaxf(pass[t], h[i])) << 32) | (unsigned)i;
+        }
+        slot++;
     }
 }
 
+// segment heads of the (lake, from)-sorted candidates
 __global__ void k_flow_heads(const unsigned long long *__restrict__ key, unsigned char *__restrict__ flag, int n)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -259,13 +295,20 @@ __global__ void k_flow_gather_dist(const unsigned long long *__restrict__ pay, c
 }
 
 // river-mouth lakes = sinks (bit 16) next to the ocean (bit 512), compacted
-__global__ void k_flow_mouths(const unsigned short *__restrict__ mask, const int *__restrict__ dense, int *__restrict__ out,
-                              int *__restrict__ count, size_t n)
+__global__ __launch_bounds__(256) void k_flow_mouths(const unsigned short *__restrict__ mask, const int *__restrict__ dense, int *__restrict__ out,
+                                                     int *__restrict__ count, size_t n)
 {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    unsigned m = mask[i];
-    if (m != 0xFFFFu && (m & 16u) && (m & 512u)) out[atomicAdd(count, 1)] = dense[i];
+    unsigned hit = 0;
+#pragma unroll
+    for (int t = 0; t < FLOW_ITEMS; t++) {
+        const size_t i = ((size_t)blockIdx.x * FLOW_ITEMS + t) * 256 + threadIdx.x;
+        const unsigned m = i < n ? mask[i] : 0u;
+        if (m != 0xFFFFu && (m & 16u) && (m & 512u)) hit |= 1u << t;
+    }
+    int slot = block_append_base(__popc(hit), count);
+#pragma unroll
+    for (int t = 0; t < FLOW_ITEMS; t++)
+        if (hit & (1u << t)) out[slot++] = dense[((size_t)blockIdx.x * FLOW_ITEMS + t) * 256 + threadIdx.x];
 }
 
 __global__ void k_flow_scatter_pairs(const int *__restrict__ idx, const int *__restrict__ v, int *__restrict__ dst, int n)
@@ -350,15 +393,30 @@ __global__ void k_lake_scatter(const int *__restrict__ root, const int *__restri
 }
 
 // ---- upstream-area accumulation by depth level --------------------------------------------------------------------
-__global__ void k_flow_gdepth(const int *__restrict__ label, const int *__restrict__ dist, const int *__restrict__ lake_off,
-                              int *__restrict__ gdepth, int *__restrict__ maxd, size_t n)
+__global__ __launch_bounds__(256) void k_flow_gdepth(const int *__restrict__ label, const int *__restrict__ dist, const int *__restrict__ lake_off,
+                                                     int *__restrict__ gdepth, int *__restrict__ maxd, size_t n)
 {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    int l = label[i], g = -1;
-    if (l >= 0 && lake_off[l] >= 0) g = dist[i] + lake_off[l];
-    gdepth[i] = g;
-    if (g > 0) atomicMax(maxd, g);
+    // the deepest cell: one atomic per block of FLOW_ITEMS x 256 cells (see block_append_base: one per wave took 0.63 ms at 4096x2048)
+    __shared__ int s_max[4];
+    int m = -1;
+#pragma unroll
+    for (int t = 0; t < FLOW_ITEMS; t++) {
+        const size_t i = ((size_t)blockIdx.x * FLOW_ITEMS + t) * 256 + threadIdx.x;
+        if (i >= n) continue;
+        const int l = label[i];
+        int g = -1;
+        if (l >= 0 && lake_off[l] >= 0) g = dist[i] + lake_off[l];
+        gdepth[i] = g;
+        m = max(m, g);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+        if (m > 0) atomicMax(maxd, m);
+    }
 }
 
 __global__ void k_flow_iota(unsigned *__restrict__ v, size_t n)
@@ -683,6 +741,9 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
         hipLaunchKernelGGL(k_flow_jump, dim3(nb), dim3(256), 0, st, par[cur].i(), dst[cur].i(), par[cur ^ 1].i(), dst[cur ^ 1].i(), N, changed.i());
         DMG_HIP(hipGetLastError());
         cur ^= 1;
+        // (a round past the last one changes nothing: rivers of 2^8 cells and more are the rule, so the first rounds run
+        // without asking; a readback costs more than the round)
+        if (it < 7 && N >= ((size_t)1 << 20)) continue;
         int ch = 0;
         DMG_HIP(hipMemcpyAsync(&ch, changed.p, 4, hipMemcpyDeviceToHost, st));
         DMG_HIP(hipStreamSynchronize(st));
@@ -722,7 +783,8 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
     DMG_ALLOC(k0, (size_t)cap * 8); DMG_ALLOC(v0, (size_t)cap * 8); DMG_ALLOC(k1, (size_t)cap * 8); DMG_ALLOC(v1, (size_t)cap * 8);
     DMG_ALLOC(nsel, 8);
     DMG_HIP(hipMemsetAsync(count.p, 0, 4, st));
-    hipLaunchKernelGGL(k_flow_passes, dim3(nb), dim3(256), 0, st, fc, d_h, label.i(), dense.i(), (const unsigned short *)mask.p,
+    const unsigned nbi = (unsigned)((N + (size_t)256 * FLOW_ITEMS - 1) / ((size_t)256 * FLOW_ITEMS));     // blocks of FLOW_ITEMS x 256 cells
+    hipLaunchKernelGGL(k_flow_passes, dim3(nbi), dim3(256), 0, st, fc, d_h, label.i(), dense.i(), (const unsigned short *)mask.p,
                        (unsigned long long *)k0.p, (unsigned long long *)v0.p, count.i(), cap);
     DMG_HIP(hipGetLastError());
     int ncand = 0;
@@ -730,7 +792,7 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
     // river mouths (dense ids), compacted (order restored on the host)
     DMG_ALLOC(mouths_d, (size_t)std::max(nlakes, 1) * 4);
     DMG_HIP(hipMemsetAsync(nsel.p, 0, 8, st));
-    hipLaunchKernelGGL(k_flow_mouths, dim3(nb), dim3(256), 0, st, (const unsigned short *)mask.p, dense.i(), mouths_d.i(), nsel.i(), N);
+    hipLaunchKernelGGL(k_flow_mouths, dim3(nbi), dim3(256), 0, st, (const unsigned short *)mask.p, dense.i(), mouths_d.i(), nsel.i(), N);
     int nmouth = 0;
     DMG_HIP(hipMemcpyAsync(&nmouth, nsel.p, 4, hipMemcpyDeviceToHost, st));
     DMG_HIP(hipStreamSynchronize(st));
@@ -1108,7 +1170,7 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
         DMG_HIP(hipGetLastError());
         DMG_HIP(hipStreamSynchronize(st));                   // the tables above are released here
     }
-    hipLaunchKernelGGL(k_flow_gdepth, dim3(nb), dim3(256), 0, st, label.i(), dst[cur].i(), dlo.i(), gdepth.i(), dmax.i(), N);
+    hipLaunchKernelGGL(k_flow_gdepth, dim3(nbi), dim3(256), 0, st, label.i(), dst[cur].i(), dlo.i(), gdepth.i(), dmax.i(), N);
     DMG_HIP(hipGetLastError());
     int max_depth = 0;
     DMG_HIP(hipMemcpyAsync(&max_depth, dmax.p, 4, hipMemcpyDeviceToHost, st));
@@ -1153,7 +1215,14 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
         DMG_HIP(hipMemsetAsync(dtick.p, 0, 8, st));
         DMG_HIP(hipMemsetAsync(acc.p, 0xFF, N * 4, st));                  // FLOW_NOT_READY everywhere
         const int waves = (n_reached + 63) / 64;
-        const int blocks = std::min((waves + 3) / 4, std::max(ctx->num_cu, 1) * 8);      // persistent: what the chip holds at once
+        // The persistent grid is SMALL: 128 blocks = 512 waves.  Every wave that holds a ticket polls, and the polls of waves far
+        // from the front compete with the loads that matter: with what the chip holds at once (8 192 waves) the sums of a
+        // 16384x8192 round took 45 ms, with 512 waves 30 ms (4096x2048: 4.5 -> 3.4 ms; 128 waves are too few: 36 ms).
+        // Measured and dropped in the same sitting: a lane that walks on downstream with the sum it has just published
+        // (computing the next cell itself, one round of loads per hop instead of a store and a poll) -- as many rounds saved as
+        // each round got longer; a round is one coherent load's trip to the memory side, ~1 us, either way.
+        static const int nblocks_env = [] { const char *e = getenv("DMG_FLOW_NBLOCKS"); return e ? atoi(e) : 0; }();
+        const int blocks = std::min((waves + 3) / 4, nblocks_env > 0 ? nblocks_env : 128);
         hipLaunchKernelGGL(k_flow_dataflow, dim3(blocks), dim3(256), 0, st, fc, order.i(), n_reached, (const unsigned short *)mask.p, dcf.i(),
                            down.f(), (unsigned *)acc.p, dtick.i(), dtick.i() + 1);
         DMG_HIP(hipGetLastError());
