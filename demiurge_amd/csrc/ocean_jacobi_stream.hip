@@ -1231,7 +1231,10 @@ static const dmg_ocean::tile_list *st_units(dmg_ocean *o, int variant, int lo, i
             for (const st_unit &x : u) total += x.cost;
             return alpha * span + (1.0f - alpha) * (float)(total / slots);
         };
-        for (int cand = 24; cand <= (variant == 1 ? STN_MAXROWS : ST_MAXROWS); cand += 4) {
+        // (every height up to 48 rows: a band of a thousand rows has ~25 rows per wave slot, and one row more or less per unit
+        // decides whether the launch's single round fills the slots or spills into a second)
+        static const int fine_env = [] { const char *e = getenv("DMG_ST_FINE"); return e ? atoi(e) : 1; }();
+        for (int cand = fine_env ? 20 : 24; cand <= (variant == 1 ? STN_MAXROWS : ST_MAXROWS); cand += (fine_env && cand < 48) ? 1 : 4) {
             st_cut(o, variant, lo, hi, cand, part, zone_lo, zone_hi, units);
             float span = judge(units);
             if (span < best_span) { best_span = span; best.swap(units); best_seg = cand; best_seg2 = 0; best_split = hi; }
