@@ -38,6 +38,152 @@ __global__ __launch_bounds__(256) void k_blur13(canvas c, const float *__restric
     dst[(size_t)y * c.W + x] = color;
 }
 
+// The same pass when the direction lies along one axis -- the only two directions Blur::step uses, (0, r) and (r, 0)
+// (BlurMenu.cpp:97-117).  k_blur13 evaluates offset() and the texture unit seven times per cell, ~1000 instructions, and is
+// bound by them (83 us for 4096x2048, 0.8 TB/s); along an axis most of that is the same for every tap, and some of it for
+// every cell of the row:
+//   DIR 0, (r, 0): dp.y = +-(k * 0) / H = +-0, so every tap keeps py = st.y: no pole branch, and the two rows, their weight
+//          and their addresses are the cell's own.  The x offsets (k r / cos|lat|) / W are three divisions per ROW: threads
+//          0..2 of the block (one block = one row segment) leave them in LDS.
+//   DIR 1, (0, r): dp.x = +-0, so px is the cell's own unless the tap crosses a pole, where it is the cell's px mirrored
+//          (Shader.h:88,93): two candidate columns pairs and weights per cell, chosen per tap.  The y offsets (k r) / H do
+//          not even depend on the row.
+// Every operation that remains is the one k_blur13 does, in its order, on the same values (negating a dividend negates the
+// quotient; adding a signed zero to a positive coordinate returns it): bit-identical, and tests/test_gpu_filters.py holds the
+// two against each other as well as against the goldens.
+struct blur_x { int i0, i1; float wx; };
+__device__ __forceinline__ blur_x blur_xpart(float px, int W)
+{
+    const float fu = __fsub_rn(__fmul_rn(px, (float)W), 0.5f), flu = floorf(fu);
+    blur_x r;
+    r.wx = __fsub_rn(fu, flu);
+    r.i0 = min(max((int)flu, 0), W - 1); r.i1 = min(max((int)flu + 1, 0), W - 1);
+    return r;
+}
+struct blur_y { int j0, j1; float wy; };
+__device__ __forceinline__ blur_y blur_ypart(float py, int H)
+{
+    const float fv = __fsub_rn(__fmul_rn(py, (float)H), 0.5f), flv = floorf(fv);
+    blur_y r;
+    r.wy = __fsub_rn(fv, flv);
+    r.j0 = min(max((int)flv, 0), H - 1); r.j1 = min(max((int)flv + 1, 0), H - 1);
+    return r;
+}
+__device__ __forceinline__ float blur_tap(const float *__restrict__ t, int W, const blur_x &bx, const blur_y &by)
+{
+    const float *r0 = t + (size_t)by.j0 * W, *r1 = t + (size_t)by.j1 * W;
+    const float t00 = r0[bx.i0], t10 = r0[bx.i1], t01 = r1[bx.i0], t11 = r1[bx.i1];
+    const float a = fmaf(bx.wx, __fsub_rn(t10, t00), t00);       // (d_fetch_linear)
+    const float b = fmaf(bx.wx, __fsub_rn(t11, t01), t01);
+    return fmaf(by.wy, __fsub_rn(b, a), a);
+}
+// (an offset longer than the globe is tall crosses both poles: the literal form, kept out of line)
+__device__ __noinline__ float blur_tap_literal(canvas c, const float *__restrict__ src, float sx, float sy, float dpx, float dpy)
+{
+    float qx, qy;
+    d_offset(c, sx, sy, dpx, dpy, &qx, &qy);
+    return d_fetch_linear(src, c.W, c.H, qx, qy);
+}
+// BLUR_CPT cells per thread, 256 columns apart.  Measured at 4096x2048: one cell per thread 58 us (r, 0) / 70 us (0, r), four
+// cells per thread 61 / 74 us -- the pass is not bound by its instructions any more (358 of k_blur13's 1093 are left in the
+// (r, 0) form) nor by a block's latency chain, but by its 28 four-byte loads per cell through the vector memory path
+// (940 MB of L1 traffic per pass; the HBM side is 67 MB)
+#define BLUR_CPT 1
+template <int DIR>
+__global__ __launch_bounds__(256) void k_blur13_axis(canvas c, const float *__restrict__ src, float *__restrict__ dst,
+                                                     const float *__restrict__ phifactor, float r)
+{
+    __shared__ float s_off[3];
+    const int y = c.row0 + (int)blockIdx.y;
+    if (threadIdx.x < 3) {
+        const float k = threadIdx.x == 0 ? 1.411764705882353f : (threadIdx.x == 1 ? 3.2941176470588234f : 5.176470588235294f);
+        float o = __fmul_rn(k, r);
+        if (DIR == 0) o = __fdiv_rn(o, phifactor[y]);
+        s_off[threadIdx.x] = __fdiv_rn(o, DIR == 0 ? (float)c.W : (float)c.H);
+    }
+    __syncthreads();
+    const float w0 = 0.1964825501511404f, w[3] = { 0.2969069646728344f, 0.09447039785044732f, 0.010381362401148057f };
+    const float sy = d_sty(c, y);
+    const float off[3] = { s_off[0], s_off[1], s_off[2] };
+    float color[BLUR_CPT];
+    if (DIR == 0) {
+        const blur_y by = blur_ypart(sy, c.H);
+#pragma unroll
+        for (int j = 0; j < BLUR_CPT; j++) {
+            const int x = min((int)(blockIdx.x * (256 * BLUR_CPT) + 256 * j + threadIdx.x), c.W - 1);    // (a column past the edge repeats the last: not stored)
+            const float sx = d_stx(c, x);
+            color[j] = __fadd_rn(0.0f, __fmul_rn(d_fetch_linear(src, c.W, c.H, sx, sy), w0));
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+#pragma unroll
+                for (int sgn = 0; sgn < 2; sgn++) {
+                    float px = __fadd_rn(sx, sgn ? -off[k] : off[k]);
+                    if (c.lonwrap) { px = d_mod(__fadd_rn(px, 1.0f), 1.0f); px = d_mod(__fadd_rn(px, 1.0f), 1.0f); }
+                    color[j] = __fadd_rn(color[j], __fmul_rn(blur_tap(src, c.W, blur_xpart(px, c.W), by), w[k]));
+                }
+        }
+    } else {
+        // the rows, their weights and whether a tap crosses a pole are the same for the whole row
+        blur_y by[6];
+        int crossed[6];
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+#pragma unroll
+            for (int sgn = 0; sgn < 2; sgn++) {
+                float py = __fadd_rn(sy, sgn ? -off[k] : off[k]);
+                int cr = 0;
+                if (c.spole && py < 0.0f) { py = -py; cr++; }
+                if (c.npole && py > 1.0f) { py = __fsub_rn(2.0f, py); cr++; }
+                crossed[2 * k + sgn] = cr;
+                by[2 * k + sgn] = blur_ypart(py, c.H);
+            }
+        const bool any_crossed = (crossed[0] | crossed[1] | crossed[2] | crossed[3] | crossed[4] | crossed[5]) != 0;
+#pragma unroll
+        for (int j = 0; j < BLUR_CPT; j++) {
+            const int x = min((int)(blockIdx.x * (256 * BLUR_CPT) + 256 * j + threadIdx.x), c.W - 1);
+            const float sx = d_stx(c, x);
+            color[j] = __fadd_rn(0.0f, __fmul_rn(d_fetch_linear(src, c.W, c.H, sx, sy), w0));
+            float px1 = sx;
+            if (c.lonwrap) px1 = d_mod(__fadd_rn(px1, 1.0f), 1.0f);
+            const blur_x plain = blur_xpart(c.lonwrap ? d_mod(__fadd_rn(px1, 1.0f), 1.0f) : px1, c.W);
+            blur_x mirrored = plain;
+            if (any_crossed) {                                   // (the same for every cell of the row: no divergence)
+                float px = d_pole_lon(__fadd_rn(__fmul_rn(px1, __fsub_rn(c.c3, c.c2)), c.c2));
+                px = __fdiv_rn(__fsub_rn(px, c.c2), __fsub_rn(c.c3, c.c2));
+                if (c.lonwrap) px = d_mod(__fadd_rn(px, 1.0f), 1.0f);
+                mirrored = blur_xpart(px, c.W);
+            }
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+#pragma unroll
+                for (int sgn = 0; sgn < 2; sgn++) {
+                    const int t = 2 * k + sgn;
+                    float v;
+                    if (crossed[t] == 2) {
+                        const float kk = k == 0 ? 1.411764705882353f : (k == 1 ? 3.2941176470588234f : 5.176470588235294f);
+                        v = blur_tap_literal(c, src, sx, sy, sgn ? -0.0f : 0.0f, sgn ? -__fmul_rn(kk, r) : __fmul_rn(kk, r));
+                    } else v = blur_tap(src, c.W, crossed[t] ? mirrored : plain, by[t]);
+                    color[j] = __fadd_rn(color[j], __fmul_rn(v, w[k]));
+                }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < BLUR_CPT; j++) {
+        const int x = (int)(blockIdx.x * (256 * BLUR_CPT) + 256 * j + threadIdx.x);
+        if (x < c.W) dst[(size_t)y * c.W + x] = color[j];
+    }
+}
+
+// one pass of blur13 in direction (dirx, diry): the axis forms where they apply
+static void launch_blur13(hipStream_t st, dim3 g, const canvas &c, const float *src, float *dst, const float *pf, float dirx, float diry)
+{
+    static const bool literal = getenv("DMG_BLUR_LITERAL") != nullptr;       // tests: the general kernel for every pass
+    const dim3 ga((unsigned)((c.W + 256 * BLUR_CPT - 1) / (256 * BLUR_CPT)), g.y);
+    if (!literal && diry == 0.0f && dirx > 0.0f) hipLaunchKernelGGL(k_blur13_axis<0>, ga, dim3(256), 0, st, c, src, dst, pf, dirx);
+    else if (!literal && dirx == 0.0f && diry > 0.0f) hipLaunchKernelGGL(k_blur13_axis<1>, ga, dim3(256), 0, st, c, src, dst, pf, diry);
+    else hipLaunchKernelGGL(k_blur13, g, dim3(256), 0, st, c, src, dst, pf, dirx, diry);
+}
+
 // Blur::Blur radius schedule (BlurMenu.cpp:27,79-94), fp32 with the reference's implicit double sqrt
 static std::vector<float> blur_rlist(float radius)
 {
@@ -380,8 +526,8 @@ int blur_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, fl
     dim3 g((grid.W + 255) / 256, grid.H);
     size_t i = 0;
     do {                                             // Blur::step (:97-117)
-        hipLaunchKernelGGL(k_blur13, g, dim3(256), 0, ctx->stream, c, d_field, d_tmp, dpf.f(), 0.0f, rl[i]);   // (0, r)
-        hipLaunchKernelGGL(k_blur13, g, dim3(256), 0, ctx->stream, c, d_tmp, d_field, dpf.f(), rl[i], 0.0f);   // (r, 0)
+        launch_blur13(ctx->stream, g, c, d_field, d_tmp, dpf.f(), 0.0f, rl[i]);   // (0, r)
+        launch_blur13(ctx->stream, g, c, d_tmp, d_field, dpf.f(), rl[i], 0.0f);   // (r, 0)
         DMG_HIP(hipGetLastError());
         i++;
     } while (!(i > rl.size() - 1));                  // `i>rlist.size()-1` (:111)
@@ -1050,8 +1196,7 @@ int dmg_field_blur_pass(dmg_field *f, float r, int vertical)
     canvas c = make_canvas(f->grid, f->topo);
     c.row0 = f->y0;
     dim3 g((f->grid.W + 255) / 256, f->y1 - f->y0);
-    hipLaunchKernelGGL(k_blur13, g, dim3(256), 0, f->ctx->stream, c, (const float *)f->virt(f->cur), f->virt(f->cur ^ 1), f->dpf.f(),
-                       vertical ? 0.0f : r, vertical ? r : 0.0f);
+    launch_blur13(f->ctx->stream, g, c, (const float *)f->virt(f->cur), f->virt(f->cur ^ 1), f->dpf.f(), vertical ? 0.0f : r, vertical ? r : 0.0f);
     DMG_HIP(hipGetLastError());
     f->cur ^= 1;
     return DMG_OK;

@@ -42,6 +42,42 @@ def test_blur_config1_size(dev, oracle):
     assert np.array_equal(out, oracle.blur(oracle.grid(W, H), f, 1.0))
 
 
+BLUR_CASES = [  # (W, H, canvas, radius): full globe (pole crossings at the large radii), a belt, a polar cap, a window
+    (256, 128, None, 1.0), (256, 128, None, 7.5), (200, 100, None, 40.0), (334, 111, None, 3.0), (128, 64, None, 300.0),
+    (256, 128, (-1.0, 1.2, -np.pi, np.pi), 5.0), (192, 96, (0.9, np.pi / 2, -np.pi, np.pi), 12.0), (160, 120, (-0.4, 0.3, 0.2, 1.4), 6.0),
+]
+
+
+def _blur_cases(capi):
+    rng = np.random.default_rng(20261004)
+    for W, H, cv, r in BLUR_CASES:
+        coords = capi.FULL_GLOBE if cv is None else tuple(np.float32(v) for v in cv)
+        yield W, H, coords, r, (rng.standard_normal((H, W)) * 100).astype(np.float32)
+
+
+def test_blur_axis_kernels_equal_the_literal_kernel_and_the_oracle(dev, oracle):
+    """Blur::step's two directions go through the axis forms of blur13 (k_blur13_axis); DMG_BLUR_LITERAL=1 (read once per
+    process: a child) sends every pass through the general kernel.  Same bits, and the oracle's, on random fields."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    capi, ctx = dev
+    mine = []
+    for W, H, coords, r, f in _blur_cases(capi):
+        out = ctx.blur(capi.make_grid(W, H, coords), f, r)
+        assert np.array_equal(out, oracle.blur(oracle.grid(W, H, coords, 42000.0), f, r)), (W, H, coords, r)
+        mine.append(hashlib.sha256(out.tobytes()).hexdigest())
+    code = ("import sys, hashlib\nsys.path.insert(0, %r); sys.path.insert(0, %r)\nimport numpy as np\nfrom demiurge_amd import capi\n"
+            "import test_gpu_filters as t\nctx = capi.Context(0)\n"
+            "for W, H, coords, r, f in t._blur_cases(capi):\n    print(hashlib.sha256(ctx.blur(capi.make_grid(W, H, coords), f, r).tobytes()).hexdigest())\n"
+            % (str(Path(__file__).resolve().parents[1]), str(Path(__file__).resolve().parent)))
+    res = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DMG_BLUR_LITERAL="1"), capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert res.stdout.split() == mine
+
+
 def test_temperature(dev, oracle):
     capi, ctx = dev
     G = load_golden("temperature_128x64_full")
