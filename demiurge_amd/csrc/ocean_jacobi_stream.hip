@@ -141,6 +141,14 @@ __device__ __forceinline__ st_we st_we_sums(const v4f C)
     return r;
 }
 __device__ __forceinline__ v4f st_to_pairs(const v4f m) { return v4f{ m.x, m.w, m.y, m.z }; }     // memory order -> (c0, c3, c1, c2)
+// a row of right-hand sides into its ring slot in pair order: two ds_write2_b32 straight from the registers the load filled
+// (as one 16-byte store the row first goes through six moves into four consecutive registers)
+__device__ __forceinline__ void st_park_pairs(v4f *dst, const v4f m)
+{
+    typedef __attribute__((address_space(3))) v4f lds_v4f;
+    const unsigned addr = (unsigned)(__SIZE_TYPE__)(lds_v4f *)dst;
+    asm volatile("ds_write2_b32 %0, %1, %2 offset1:1\n\tds_write2_b32 %0, %3, %4 offset0:2 offset1:3" :: "v"(addr), "v"(m.x), "v"(m.w), "v"(m.y), "v"(m.z) : "memory");
+}
 __device__ __forceinline__ v4f st_to_memory(const v4f q) { return v4f{ q.x, q.z, q.w, q.y }; }
 // land neighbour -> centre value (OceanCurrents.cpp:470-473) as pK | (pC & mask): land holds exactly +0.0
 template <int BIT>
@@ -349,7 +357,9 @@ __device__ __forceinline__ void st_arrive(const st_args &a, st_state &z, v4f (*b
                                           int j, int e, unsigned cls, int slot, unsigned &land, unsigned &mix)
 {
     cls &= 3u;                                               // (bit 2: the row's divisors have no exact pair, st_step)
-    land = cls == 1u; mix = 0;
+    // (the flags as integer arithmetic on scalars: written as comparisons they come out as lane masks, turned into 0 / 1 in a
+    // VGPR and read back with v_readfirstlane)
+    land = cls & 1u; mix = 0;                                // classes are 0, 1, 2
     // (a land row's pressure is +0 in memory: k_zero_land.)  A real move, opaque to the register coalescer: merged with the
     // staging registers, level 0's rows stay live past the point where the set is reloaded, the reload gets other
     // registers, and the copies the compiler then puts on the loop's back edge wait for loads that were only just issued
@@ -375,8 +385,9 @@ __device__ __forceinline__ void st_arrive(const st_args &a, st_state &z, v4f (*b
         // holds +0.0"; the bit-field selects of the other kernels did not care (pK | pC with pK == pC)
         if (yg == -1 && !a.spole) c &= ~0x01010101u;
         if (yg == a.H && !a.npole) c &= ~0x02020202u;
-        mix = __builtin_amdgcn_ballot_w64((c & 0x1F1F1F1Fu) != 0) != 0;
-        land = __builtin_amdgcn_ballot_w64((c & 0x10101010u) != 0x10101010u) == 0;
+        const unsigned long long bm = __builtin_amdgcn_ballot_w64((c & 0x1F1F1F1Fu) != 0), bl = __builtin_amdgcn_ballot_w64((c & 0x10101010u) != 0x10101010u);
+        mix = (unsigned)((bm | (0ull - bm)) >> 63);          // any lane with a code bit
+        land = (unsigned)((bl | (0ull - bl)) >> 63) ^ 1u;    // no lane with a water cell
         mix &= ~land;
         if (mix) {
             // code byte of a cell: bit 0 N, 1 S, 2 E, 3 W neighbour is land, bit 4 the cell itself.  v_perm_b32 as a byte
@@ -392,13 +403,13 @@ __device__ __forceinline__ void st_arrive(const st_args &a, st_state &z, v4f (*b
             asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(bq.y) : "v"(code_mask<12>(c, 0)), "v"(0x80000000u), "v"(bq.y));
             asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(bq.z) : "v"(code_mask<20>(c, 0)), "v"(0x80000000u), "v"(bq.z));
             asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(bq.w) : "v"(code_mask<28>(c, 0)), "v"(0x80000000u), "v"(bq.w));
-            bring[slot][lane] = st_to_pairs(bq);
+            st_park_pairs(&bring[slot][lane], bq);
             return;
         }
     }
     // (an open row among coast rows goes through the coast formula with the rest of its step: counts of zero)
     cring[slot][lane] = 0u;                                   // (a land row's entry is never read: no test)
-    bring[slot][lane] = st_to_pairs(z.bs[K][j]);
+    st_park_pairs(&bring[slot][lane], z.bs[K][j]);
 }
 
 // class of the row in staging slot [K][j] (persistent form): rows beyond the grid or the stored band count as mixed
