@@ -3,8 +3,12 @@
 set -o pipefail
 R=${R:-r03}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+# PART=tests: the GPU test suite alone (a gpurun call is at most 1200 s); PART=profiles (default): everything else
+if [ "${PART:-profiles}" = tests ]; then
 timeout -k 10 1100 python -u -m pytest tests -m gpu -q > gpurun_out/${R}_pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/${R}_pytest_gpu.log; tail -3 gpurun_out/${R}_pytest_gpu.log
 grep -q "GPU core dump\|Memory access fault" gpurun_out/${R}_pytest_gpu.log && exit 9
+exit 0
+fi
 python bench.py > gpurun_out/${R}_bench_default.json.log 2> gpurun_out/${R}_bench_default.err; tail -c 600 gpurun_out/${R}_bench_default.json.log
 rm -rf gpurun_out/${R}_stats
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${R}_stats -o x -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra-legs > gpurun_out/${R}_stream_bench_profiled.json.log 2>&1
@@ -19,6 +23,8 @@ rm -f gpurun_out/${R}_band_sizes.jsonl
 for h in 8192 4096 2048 1024; do python bench.py --height $h --steps 2 --warmup 1 --no-cpu-baseline --no-extra-legs 2>/dev/null | cut -c1-420 >> gpurun_out/${R}_band_sizes.jsonl; done
 python tools/config_lines.py > gpurun_out/${R}_config_lines.jsonl 2> gpurun_out/${R}_config_lines.err; tail -4 gpurun_out/${R}_config_lines.jsonl | cut -c1-200
 DMG_FLOW_TIMING=1 python tools/flow_timing.py > gpurun_out/${R}_flow_timing.log 2>&1; tail -13 gpurun_out/${R}_flow_timing.log
+python tools/config2_phases.py 1000 > gpurun_out/${R}_config2_phases.log 2>&1; cat gpurun_out/${R}_config2_phases.log
+for n in 8 4 2; do python tools/band_probe.py $n 32 2>&1 | grep bands; done > gpurun_out/${R}_band_probe.log; cat gpurun_out/${R}_band_probe.log
 timeout -k 10 300 python tools/bands_one_gpu.py 1600 loopback > gpurun_out/${R}_bands_one_gpu_loopback.log 2>&1; grep bands gpurun_out/${R}_bands_one_gpu_loopback.log
 rm -f gpurun_out/${R}_overlap_probe.log
 for o in plain overlap; do
