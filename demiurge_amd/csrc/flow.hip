@@ -623,6 +623,14 @@ __global__ __launch_bounds__(256) void k_growth_relax(const int *__restrict__ fi
                                                        unsigned *__restrict__ d, const int2 *__restrict__ span, const int *__restrict__ vstart,
                                                        const int4 *__restrict__ ent, const unsigned *__restrict__ rank, int *__restrict__ stamp, int round)
 {
+    // the next frontier is collected per block in LDS and appended with ONE add on the global counter (block_append_base's
+    // reason: an add per lake on one address costs ~5 ns per wave-instruction, serialised; the order inside a frontier
+    // does not matter, the levels are a fixed point)
+    constexpr int QCAP = 2048;
+    __shared__ int q[QCAP];
+    __shared__ int qn, qbase;
+    if (threadIdx.x == 0) qn = 0;
+    __syncthreads();
     const int n = *nin;
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
         const int L = fin[t];
@@ -633,10 +641,19 @@ __global__ __launch_bounds__(256) void k_growth_relax(const int *__restrict__ fi
             const unsigned nd = max(dl, rank[i]);
             if (nd < __hip_atomic_load(&d[F], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                 const unsigned old = atomicMin(&d[F], nd);
-                if (nd < old && atomicMax(&stamp[F], round + 1) < round + 1) fout[atomicAdd(nout, 1)] = F;
+                if (nd < old && atomicMax(&stamp[F], round + 1) < round + 1) {
+                    const int k = atomicAdd(&qn, 1);
+                    if (k < QCAP) q[k] = F;
+                    else fout[atomicAdd(nout, 1)] = F;      // (the block's queue is full: straight to the list)
+                }
             }
         }
     }
+    __syncthreads();
+    const int m = min(qn, QCAP);
+    if (threadIdx.x == 0 && m > 0) qbase = atomicAdd(nout, m);
+    __syncthreads();
+    for (int i = threadIdx.x; i < m; i += blockDim.x) fout[qbase + i] = q[i];
 }
 // between two rounds: the frontier just written becomes the one to read, the other one's counter is cleared
 __global__ void k_growth_flip(int *__restrict__ count, int from) { count[from] = 0; }
