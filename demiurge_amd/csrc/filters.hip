@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256) void k_temperature_taps(canvas c, const float 
 struct temp_consts { float ref_t4, r_t4, r_15000, r_c_land, r_c_ocean; };
 
 // one cell of the step (Temperature.cpp:97-133) from its own value, the terrain height and the nine Laplacian taps
-__device__ __forceinline__ float temperature_update(float Tc, float terr, const float s[9], float asr, float den, float rden,
+__device__ __forceinline__ float temperature_update(float Tc, bool land, const float s[9], float asr, float den, float rden,
                                                     const temp_consts &k)
 {
     float A_ = s[0], B_ = s[1], C_ = s[2], D_ = s[3], E_ = s[4], F_ = s[5], G_ = s[6], H_ = s[7], I_ = s[8];
@@ -312,7 +312,6 @@ __device__ __forceinline__ float temperature_update(float Tc, float terr, const 
     if (isnan(delta_y)) delta_y = 0.0f;
     float OLR = __fmul_rn(olr_q, 0.93f);
     float change = __fadd_rn(__fsub_rn(asr, OLR), __fmul_rn(__fmul_rn(0.55f, 1e6f), __fadd_rn(delta_x, delta_y)));   // :128
-    const bool land = terr > 0.0f;
     const float Cc = land ? 1.5e7f : 7e7f;          // atmosphere + (terrain>0 ? atmosphere*0.5 : 4*1.5*atmosphere), atmosphere = 1e7 (:131-132)
     const float rCc = land ? k.r_c_land : k.r_c_ocean;
     float n1 = __fmul_rn(change, __fmul_rn(3.154f, 1e7f));                        // :133, the two factors merged
@@ -349,14 +348,25 @@ __global__ __launch_bounds__(256) void k_temperature(canvas c, const float *__re
         }
     }
     size_t p = (size_t)y * c.W + x;
-    out[p] = temperature_update(T[p], terrain[p], s, asr[y], den, rdenrow[y], k);
+    out[p] = temperature_update(T[p], terrain[p] > 0.0f, s, asr[y], den, rdenrow[y], k);
+}
+
+// land4[i]: bit j = cell 4 i + j lies above sea level.  The step reads the terrain only for that sign (Temperature.cpp:131-132):
+// one byte per four cells instead of sixteen -- a third of the step's HBM bytes (12 -> 8.25 B per cell).
+__global__ void k_land_mask4(const float *__restrict__ terrain, unsigned char *__restrict__ land4, size_t n4)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const float4 t = reinterpret_cast<const float4 *>(terrain)[i];
+    land4[i] = (unsigned char)((t.x > 0.0f ? 1 : 0) | (t.y > 0.0f ? 2 : 0) | (t.z > 0.0f ? 4 : 0) | (t.w > 0.0f ? 8 : 0));
 }
 
 // Four consecutive cells per thread for the rows whose tap displacements were verified (W % 4 == 0): every tap is one
 // 16-byte load at (tap row, x + displacement) -- unaligned in general, which the global load unit takes -- unless the
-// four cells straddle the seam or the clamped edge, and the index arithmetic is paid once per four cells.
+// four cells straddle the seam or the clamped edge, and the index arithmetic is paid once per four cells.  A tap that is
+// the cell itself (the middle one, on every row seen so far) is not loaded again.
 __global__ __launch_bounds__(256) void k_temperature_v4(canvas c, const float *__restrict__ T, float *__restrict__ out,
-                                                        const float *__restrict__ terrain, const float *__restrict__ asr,
+                                                        const unsigned char *__restrict__ land4, const float *__restrict__ asr,
                                                         const float *__restrict__ dyrow, const float *__restrict__ rdenrow, temp_consts k,
                                                         const int *__restrict__ shift, const int *__restrict__ srow,
                                                         const int *__restrict__ literal_row)
@@ -368,10 +378,15 @@ __global__ __launch_bounds__(256) void k_temperature_v4(canvas c, const float *_
     float dy = dyrow[y];
     float den = __fmul_rn(4.0f, __fmul_rn(dy, dy));
     float s[4][9];
+    const size_t p = (size_t)y * W + x0;
+    const float4 Tc = *reinterpret_cast<const float4 *>(T + p);
+    const unsigned lm = land4[p >> 2];
 #pragma unroll
     for (int t = 0; t < 9; t++) {
         const int sh = shift[y * 9 + t];
-        const float *row = T + (size_t)srow[y * 9 + t] * W;
+        const int sr = srow[y * 9 + t];
+        if (sh == 0 && sr == y) { s[0][t] = Tc.x; s[1][t] = Tc.y; s[2][t] = Tc.z; s[3][t] = Tc.w; continue; }   // (row-uniform)
+        const float *row = T + (size_t)sr * W;
         int i = x0 + sh;
         if (c.lonwrap && i >= W) i -= W;             // sh is a forward distance in [0, W)
         if (i >= 0 && i + 3 < W) {
@@ -383,14 +398,12 @@ __global__ __launch_bounds__(256) void k_temperature_v4(canvas c, const float *_
             for (int j = 0; j < 4; j++) s[j][t] = row[temperature_shifted(c, x0 + j, sh)];
         }
     }
-    const size_t p = (size_t)y * W + x0;
-    const float4 Tc = *reinterpret_cast<const float4 *>(T + p), terr = *reinterpret_cast<const float4 *>(terrain + p);
     const float a = asr[y], rden = rdenrow[y];
     float4 o;
-    o.x = temperature_update(Tc.x, terr.x, s[0], a, den, rden, k);
-    o.y = temperature_update(Tc.y, terr.y, s[1], a, den, rden, k);
-    o.z = temperature_update(Tc.z, terr.z, s[2], a, den, rden, k);
-    o.w = temperature_update(Tc.w, terr.w, s[3], a, den, rden, k);
+    o.x = temperature_update(Tc.x, (lm & 1u) != 0, s[0], a, den, rden, k);
+    o.y = temperature_update(Tc.y, (lm & 2u) != 0, s[1], a, den, rden, k);
+    o.z = temperature_update(Tc.z, (lm & 4u) != 0, s[2], a, den, rden, k);
+    o.w = temperature_update(Tc.w, (lm & 8u) != 0, s[3], a, den, rden, k);
     *reinterpret_cast<float4 *>(out + p) = o;
 }
 
@@ -573,7 +586,7 @@ struct dmg_climate {
     dmg_ctx *ctx = nullptr;
     dmg_grid grid{};
     dmg_topology topo{};
-    dev_buf a, b, terr, dlat, dcos, ddy, drden, dasr, dshift, dsrow, dlit;
+    dev_buf a, b, terr, land4, dlat, dcos, ddy, drden, dasr, dshift, dsrow, dlit;
     dev_buf dlitrows;
     int n_literal = 0;                               // rows that keep the literal taps (their indices in dlitrows)
     std::vector<int> lit_rows;                       // the same list on the host (ascending), to launch the rows of a range
@@ -626,6 +639,11 @@ int dmg_climate_create_band(dmg_ctx *ctx, const dmg_grid *grid, const float *T, 
     DMG_HIP(hipMemcpyAsync(k->a.p, T + src_off, n * 4, hipMemcpyHostToDevice, ctx->stream));
     DMG_HIP(hipMemcpyAsync(k->b.p, T + src_off, n * 4, hipMemcpyHostToDevice, ctx->stream));      // (rows a band step does not write keep a defined value)
     DMG_HIP(hipMemcpyAsync(k->terr.p, terrain + src_off, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (grid->W % 4 == 0) {
+        DMG_ALLOC(k->land4, n / 4);
+        hipLaunchKernelGGL(k_land_mask4, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, ctx->stream, k->terr.f(), (unsigned char *)k->land4.p, n / 4);
+        DMG_HIP(hipGetLastError());
+    }
     DMG_HIP(hipStreamSynchronize(ctx->stream));      // the caller's buffers may go away
     k->cur = k->a.f(); k->nxt = k->b.f();
     dmg_ctx_retain(ctx);
@@ -676,6 +694,7 @@ int dmg_climate_steps(dmg_climate *k, int first_step, int n_steps)
         k->taps_ready = true;
     }
     const float *terr_v = k->terr.f() - k->voff();
+    const unsigned char *land4_v = k->land4.p ? (const unsigned char *)k->land4.p - k->voff() / 4 : nullptr;
     for (int i = first_step, s = 1; i < first_step + n_steps; i++, s++) {
         // rows whose nine taps are current s steps after the last halo refresh: the region shrinks a row per step on
         // every side that has a neighbour band (the whole grid when there is none)
@@ -687,7 +706,7 @@ int dmg_climate_steps(dmg_climate *k, int first_step, int n_steps)
         float M = (float)(M_PI * 2 / 15000 * i);     // glUniform1f(id, M_PI*2/15000*i) (:146)
         hipLaunchKernelGGL(k_temperature_rows, dim3((H + 255) / 256), dim3(256), 0, ctx->stream, c, k->dlat.f(), M, sin_gamma, k->dasr.f());
         if (W % 4 == 0) {                            // tabled rows four cells per thread, the few literal rows one cell per thread
-            hipLaunchKernelGGL(k_temperature_v4, dim3((W / 4 + 255) / 256, nrows), dim3(256), 0, ctx->stream, c, cur_v, nxt_v, terr_v,
+            hipLaunchKernelGGL(k_temperature_v4, dim3((W / 4 + 255) / 256, nrows), dim3(256), 0, ctx->stream, c, cur_v, nxt_v, land4_v,
                                k->dasr.f(), k->ddy.f(), k->drden.f(), tc, (const int *)k->dshift.p, (const int *)k->dsrow.p, (const int *)k->dlit.p);
             const int l0 = (int)(std::lower_bound(k->lit_rows.begin(), k->lit_rows.end(), lo) - k->lit_rows.begin());
             const int l1 = (int)(std::lower_bound(k->lit_rows.begin(), k->lit_rows.end(), hi) - k->lit_rows.begin());
@@ -723,6 +742,11 @@ int dmg_climate_set_terrain(dmg_climate *k, const float *terrain)
     DMG_CHECK_ARG(k != nullptr && terrain != nullptr);
     DMG_HIP(hipSetDevice(k->ctx->device));
     DMG_HIP(hipMemcpyAsync(k->terr.p, terrain + k->voff(), (size_t)k->grid.W * k->L * 4, hipMemcpyHostToDevice, k->ctx->stream));
+    if (k->land4.p) {
+        const size_t n4 = (size_t)k->grid.W * k->L / 4;
+        hipLaunchKernelGGL(k_land_mask4, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, k->ctx->stream, k->terr.f(), (unsigned char *)k->land4.p, n4);
+        DMG_HIP(hipGetLastError());
+    }
     DMG_HIP(hipStreamSynchronize(k->ctx->stream));
     return DMG_OK;
 }
@@ -733,6 +757,11 @@ extern "C++" int climate_set_terrain_device(dmg_climate *k, const float *d_terra
     DMG_CHECK_ARG(k != nullptr && d_terrain != nullptr);
     DMG_HIP(hipSetDevice(k->ctx->device));
     DMG_HIP(hipMemcpyAsync(k->terr.p, d_terrain + k->voff(), (size_t)k->grid.W * k->L * 4, hipMemcpyDeviceToDevice, k->ctx->stream));
+    if (k->land4.p) {
+        const size_t n4 = (size_t)k->grid.W * k->L / 4;
+        hipLaunchKernelGGL(k_land_mask4, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, k->ctx->stream, k->terr.f(), (unsigned char *)k->land4.p, n4);
+        DMG_HIP(hipGetLastError());
+    }
     return DMG_OK;
 }
 

@@ -28,4 +28,4 @@ for _ in range(3):
     k.steps(7, 40)
     best = min(best, ctx.timer_stop() / 40)
 k.close()
-print("%dx%d climate step: %.3f ms (%.0f GB/s at 12 B per cell)  literal=%s" % (W, H, best, W * H * 12 / best / 1e6, os.environ.get("DMG_TEMPERATURE_LITERAL", "0")))
+print("%dx%d climate step: %.3f ms (%.0f GB/s at 8.25 B per cell)  literal=%s" % (W, H, best, W * H * 8.25 / best / 1e6, os.environ.get("DMG_TEMPERATURE_LITERAL", "0")))
