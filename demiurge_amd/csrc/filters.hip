@@ -365,6 +365,11 @@ __global__ void k_land_mask4(const float *__restrict__ terrain, unsigned char *_
 // 16-byte load at (tap row, x + displacement) -- unaligned in general, which the global load unit takes -- unless the
 // four cells straddle the seam or the clamped edge, and the index arithmetic is paid once per four cells.  A tap that is
 // the cell itself (the middle one, on every row seen so far) is not loaded again.
+// (Measured and dropped, round 3: the three tap rows of a 1024-cell block staged in LDS -- aligned 16-byte loads, a tile
+// de-interleaved by column mod 4, taps as conflict-free ds_read_b32 -- bit-identical, and slower: 0.77 ms against 0.51 on
+// the same box; without its halo columns 0.56, without the tap reads 0.60, with neither 0.39.  The unaligned tap loads
+// mostly hit the L1 / L2 of a CU that has just streamed the neighbouring rows; a barrier per block, half-rate 4-byte LDS
+// reads and a halo fetched by one wave cost more than they save.)
 __global__ __launch_bounds__(256) void k_temperature_v4(canvas c, const float *__restrict__ T, float *__restrict__ out,
                                                         const unsigned char *__restrict__ land4, const float *__restrict__ asr,
                                                         const float *__restrict__ dyrow, const float *__restrict__ rdenrow, temp_consts k,
