@@ -66,9 +66,10 @@ def parse():
     ap.add_argument("--terrain", choices=["survey", "ocean"], default="survey",
                     help="survey: the ~40%% land field of SURVEY.md 8d (the metric's workload); ocean: no land at all "
                          "(worst case for the kernel, which skips work on land)")
-    ap.add_argument("--order", choices=["exchange-then-sweep", "overlap"], default="exchange-then-sweep",
-                    help="N>1: refresh the ghost rows, then sweep a block; or send them while the interior of the block's "
-                         "last launch is swept")
+    ap.add_argument("--order", choices=["exchange-then-sweep", "overlap"], default="overlap",
+                    help="N>1: send the ghost rows while the interior of the block's last launch is swept (its edge units "
+                         "first, alone; default: with an emulated link of 50-100 us it is 2-6 %% faster, with none 5 %% "
+                         "slower, profiles/r03_fake_link.log), or refresh them, then sweep a block")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="headline leg only (no single-sweep / all-ocean / PMC / check)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)

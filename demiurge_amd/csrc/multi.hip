@@ -155,6 +155,8 @@ struct dmg_multi {
     std::vector<hipEvent_t> ev_edge, ev_xchg;      // per band: a whole launch done (own stream) / ghost rows refreshed (second stream)
     std::atomic<bool> dead{false};   // a band failed and the communicators were aborted: only dmg_multi_destroy remains
     int timeout_ms = 120000;         // RCCL transports: how long a host-side wait may take before the communicators are aborted
+    int fake_link_us = 0;            // experiments (DMG_MULTI_FAKE_LINK_US=<us>): every exchange is followed, on its stream, by a kernel that
+                                     // waits that long -- a link slower than a local copy, to see what the overlapped order hides of it
     int fail_band = -1;              // tests (DMG_MULTI_FAIL=<band>:<n>): that band gives up in front of its n-th exchange
     long long fail_at = 0;
     std::vector<long long> n_band_exchanges;
@@ -231,6 +233,13 @@ static int multi_wait(dmg_multi *m, int i)
 
 // ---- one halo exchange of `field` (rows deep) as seen by local band i; every band thread calls it ----
 // `on`: the stream that carries it (default: the band's own)
+// experiments: one wave that holds its stream for `ticks` of the 100 MHz clock (DMG_MULTI_FAKE_LINK_US)
+__global__ void k_multi_fake_link(unsigned long long ticks)
+{
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
 static int band_exchange(dmg_multi *m, int i, int field, int rows, int buffer = -1, hipStream_t on = nullptr)
 {
     dmg_ctx *c = m->ctx_of(i);
@@ -319,6 +328,8 @@ static int band_exchange(dmg_multi *m, int i, int field, int rows, int buffer = 
         for (int j : { i - 1, i + 1 })                       // the neighbours have read my rows before I overwrite them
             if (j >= 0 && j < m->n && m->ctx_of(j) != c) DMG_HIP(hipStreamWaitEvent(st, m->ev_copied[j], 0));
     }
+    if (m->fake_link_us > 0 && (m->transport != DMG_MULTI_RCCL_LOOPBACK || i == 0))
+        hipLaunchKernelGGL(k_multi_fake_link, dim3(1), dim3(64), 0, st, (unsigned long long)m->fake_link_us * 100ull);
     if (i == 0) {
         DMG_HIP(hipEventRecord(ev.second, st));
         m->ev_used.push_back(ev);
@@ -478,6 +489,10 @@ static int multi_common(dmg_multi *m, const dmg_grid *grid, const dmg_ocean_para
     if (const char *e = getenv("DMG_MULTI_FAIL")) {          // tests: "<band>:<n>"
         int b = -1; long long k = 0;
         if (sscanf(e, "%d:%lld", &b, &k) == 2 && b >= 0 && k > 0) { m->fail_band = b; m->fail_at = k; }
+    }
+    if (const char *e = getenv("DMG_MULTI_FAKE_LINK_US")) {
+        const int us = atoi(e);
+        if (us > 0 && us <= 100000) m->fake_link_us = us;
     }
     return DMG_OK;
 }

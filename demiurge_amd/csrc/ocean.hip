@@ -303,6 +303,7 @@ void dmg_ocean_destroy(dmg_ocean *o)
         if (p) (void)hipFree(p);
     ocean_tb_free_lists(o);
     if (o->ev_fork) (void)hipEventDestroy(o->ev_fork);
+    if (o->ev_edge) (void)hipEventDestroy(o->ev_edge);
     dmg_ctx *ctx = o->ctx;
     delete o;
     dmg_ctx_release(ctx);
@@ -453,6 +454,18 @@ extern "C++" int ocean_jacobi_sweeps_begin(dmg_ocean *o, int n, hipStream_t edge
     }
     rc = ocean_launch_tb(o, lo, hi, last, 1, zone_lo, zone_hi, -1, edge_stream);
     if (rc) return rc;
+    // Edge first: the interior units start when the edge units are done, not beside them.  Beside a full launch the edge
+    // units -- a tenth of the launch's units -- take as long as the launch itself (47-74 us on a 1024-row band: they share
+    // every SIMD with an interior wave), so the exchange behind them started when the interior was nearly through and
+    // hid nothing (profiles/r03_fake_link.log).  Alone on the chip, as units of 8 rows (st_cut's edge_seg), they are done
+    // in ~25 us, and the exchange then has the whole interior to hide behind.  DMG_MULTI_EDGE_FIRST=0: side by side.
+    static const bool edge_first = [] { const char *e = getenv("DMG_MULTI_EDGE_FIRST"); return !e || atoi(e) != 0; }();
+    o->edge_wait = false;
+    if (edge_first && edge_stream && edge_stream != o->ctx->stream) {
+        if (!o->ev_edge) DMG_HIP(hipEventCreateWithFlags(&o->ev_edge, hipEventDisableTiming));
+        DMG_HIP(hipEventRecord(o->ev_edge, edge_stream));
+        o->edge_wait = true;
+    }
     o->pending.active = true;
     o->pending.lo = lo; o->pending.hi = hi; o->pending.n = last; o->pending.zone_lo = zone_lo; o->pending.zone_hi = zone_hi;
     o->cur ^= 1;                                         // the slabs handed out from now on are the new iterate's
@@ -466,6 +479,7 @@ int dmg_ocean_jacobi_sweeps_end(dmg_ocean *o)
     if (!o->pending.active) return DMG_OK;
     DMG_HIP(hipSetDevice(o->ctx->device));
     o->cur ^= 1;                                         // read the previous iterate, write the one made current by _begin
+    if (o->edge_wait) { DMG_HIP(hipStreamWaitEvent(o->ctx->stream, o->ev_edge, 0)); o->edge_wait = false; }
     int rc = ocean_launch_tb(o, o->pending.lo, o->pending.hi, o->pending.n, 2, o->pending.zone_lo, o->pending.zone_hi);
     o->cur ^= 1;
     o->pending.active = false;

@@ -50,6 +50,7 @@ struct dmg_ocean {
         int *seg_ctl = nullptr;
         int cap = 0, waves = 0;
         int cut_seg = 0, cut_seg2 = 0, cut_split = 0;   // streaming kernel: the cut of a launch's rows into units (the halves of a split launch share the whole launch's)
+        long long cut_rows = 0;                          // rows its units write, summed (the halves of a split launch are checked against their cut)
     };
     // (out_lo, out_hi, rows per wave, part, zone_lo, zone_hi) of a launch -> tiles that are not land everywhere; part 0 = all
     // tile rows, 1 = tile rows touching the send zones [out_lo, zone_lo) / [zone_hi, out_hi), 2 = the tile rows in between
@@ -67,6 +68,8 @@ struct dmg_ocean {
     // dmg_ocean_jacobi_sweeps_begin/_end: the interior part of a block's last launch, still to be issued
     struct { bool active = false; int lo = 0, hi = 0, n = 0, zone_lo = 0, zone_hi = 0; } pending;
     hipEvent_t ev_fork = nullptr;  // ocean_jacobi_sweeps_begin with an edge stream: the launch before the split one is done
+    hipEvent_t ev_edge = nullptr;  // ... the edge units of the split launch are done (the interior units start behind them: edge first)
+    bool edge_wait = false;
     int *oob_flag = nullptr;       // device word: advect out-of-band flag / reduction scratch
     float *rowtab = nullptr;       // ROWTAB_FIELDS arrays of L floats
     float *jcoefp = nullptr;       // [L + 32][4] = cx, 1/cx, Beta, 1/Beta of local rows -16 .. L+15, rows beyond the grid mirrored (scalar loads, no mapping)

@@ -1002,7 +1002,7 @@ struct st_unit { int tx, r0, r1; float cost; };
 // to its first / last row that is not land everywhere; empty ones are dropped.  cost ~ the unit's level-rows, a coast row
 // counted 1.4 times an open one and a land row a tenth (what the kernel spends on them).
 static void st_cut(const dmg_ocean *o, int variant, int lo, int hi, int seg, int part, int zone_lo, int zone_hi, std::vector<st_unit> &units,
-                   int seg2 = 0, int split = 0)
+                   int seg2 = 0, int split = 0, int edge_seg = 0)
 {
     const int ow = variant ? STN_OW : TB_OW;
     static const float w_mixed = [] { const char *e = getenv("DMG_ST_WMIXED"); return e ? (float)atof(e) : 1.4f; }();    // experiments: the cost model's weights (1.4: best of a sweep 1.0 .. 1.6 on the survey terrain; the per-unit timings fit 1.23 .. 1.40)
@@ -1014,9 +1014,21 @@ static void st_cut(const dmg_ocean *o, int variant, int lo, int hi, int seg, int
     // rows [lo, split) in segments of `seg` rows, the rest in (shorter) segments of `seg2` rows: the short units fill
     // the last round of the dispatch
     if (!seg2) split = hi;
+    // edge_seg > 0 (the halves of a split launch): the send zones [lo, zone_lo) and [zone_hi, hi) are cut into units of edge_seg
+    // rows of their own and the rows between them as the whole launch cuts them, anchored at zone_lo.  An edge unit of 8 rows
+    // is done in ~25 us, one of 28 in ~45: the exchange behind the edge units starts that much earlier, and what it can hide
+    // behind is the interior units of one launch (~57 us on a 1024-row band) -- see profiles/r03_fake_link.log
+    const bool zones = edge_seg > 0 && zone_lo >= lo && zone_hi <= hi && zone_lo <= zone_hi;
+    const int mid_lo = zones ? zone_lo : lo, mid_hi = zones ? zone_hi : hi;
     for (int s0 = lo; s0 < hi;) {
-        const int h = s0 < split ? seg : seg2;
-        const int s1 = std::min(s0 + h, s0 < split ? split : hi);
+        int s1;
+        if (s0 < mid_lo) s1 = std::min(s0 + edge_seg, mid_lo);
+        else if (s0 >= mid_hi) s1 = std::min(s0 + edge_seg, hi);
+        else {
+            const int h = s0 < split ? seg : seg2;
+            s1 = std::min(std::min(s0 + h, s0 < split ? split : hi), mid_hi);
+            if (s1 <= s0) s1 = std::min(s0 + seg, mid_hi);                  // (a split that lies below the middle zone)
+        }
         const int s0_this = s0;
         s0 = s1;
         {
@@ -1217,14 +1229,22 @@ static const dmg_ocean::tile_list *st_units(dmg_ocean *o, int variant, int lo, i
         if (!whole) return nullptr;
         cut_seg = whole->cut_seg; cut_seg2 = whole->cut_seg2; cut_split = whole->cut_split;
         if (cut_seg <= 0) { cut_seg = variant == 1 ? STN_MAXROWS : ST_MAXROWS; cut_seg2 = 0; cut_split = hi; }   // (a launch with no live unit)
-        st_cut(o, variant, lo, hi, cut_seg, part, zone_lo, zone_hi, best, cut_seg2, cut_split);
+        static const int edge_seg = [] { const char *e = getenv("DMG_ST_EDGE_SEG"); const int v = e ? atoi(e) : 8; return v >= 4 && v <= ST_MAXROWS ? v : 0; }();
+        st_cut(o, variant, lo, hi, cut_seg, part, zone_lo, zone_hi, best, cut_seg2, cut_split, edge_seg);
         (void)st_makespan(best, slots);
-        // both halves built: together they must be the whole launch's units, each exactly once
+        // both halves built: together they must be the units of ONE cut of the launch's rows, each exactly once
         auto other = o->tb_lists.find(std::make_tuple(lo, hi, std::get<2>(key), 3 - part, zone_lo, zone_hi));
-        if (other != o->tb_lists.end() && other->second.n + (int)best.size() != whole->n) {
-            dmg_fail(DMG_ESTATE, "split launch over rows [%d, %d): %d + %zu units in the two parts, %d in the whole launch", lo, hi,
-                     other->second.n, best.size(), whole->n);
-            return nullptr;
+        if (other != o->tb_lists.end()) {
+            std::vector<st_unit> all;
+            st_cut(o, variant, lo, hi, cut_seg, 0, zone_lo, zone_hi, all, cut_seg2, cut_split, edge_seg);
+            long long rows_all = 0, rows_parts = 0;
+            for (const st_unit &u : all) rows_all += u.r1 - u.r0;
+            for (const st_unit &u : best) rows_parts += u.r1 - u.r0;
+            if (other->second.n + (int)best.size() != (int)all.size() || other->second.cut_rows + rows_parts != rows_all) {
+                dmg_fail(DMG_ESTATE, "split launch over rows [%d, %d): %d + %zu units in the two parts, %zu in the cut they are halves of", lo, hi,
+                         other->second.n, best.size(), all.size());
+                return nullptr;
+            }
         }
     }
     else if (seg > 0) { st_cut(o, variant, lo, hi, seg, part, zone_lo, zone_hi, best); (void)st_makespan(best, slots); cut_seg = seg; cut_split = hi; }
@@ -1332,6 +1352,8 @@ static const dmg_ocean::tile_list *st_units(dmg_ocean *o, int variant, int lo, i
     dmg_ocean::tile_list tl;
     tl.n = (int)best.size();
     tl.cut_seg = cut_seg; tl.cut_seg2 = cut_seg2; tl.cut_split = cut_split;
+    tl.cut_rows = 0;
+    for (const st_unit &u : best) tl.cut_rows += u.r1 - u.r0;
     if (tl.n && hipMalloc((void **)&tl.d, flat.size() * sizeof(int)) != hipSuccess) return nullptr;
     if (tl.n && hipMemcpy(tl.d, flat.data(), flat.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
     if (variant == 2 && tl.n) {
