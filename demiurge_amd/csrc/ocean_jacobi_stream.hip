@@ -1015,7 +1015,7 @@ static void st_cut(const dmg_ocean *o, int variant, int lo, int hi, int seg, int
     // the last round of the dispatch
     if (!seg2) split = hi;
     // edge_seg > 0 (the halves of a split launch): the send zones [lo, zone_lo) and [zone_hi, hi) are cut into units of edge_seg
-    // rows of their own and the rows between them as the whole launch cuts them, anchored at zone_lo.  An edge unit of 8 rows
+    // rows of their own (4: measured 4 .. 32) and the rows between them as the whole launch cuts them, anchored at zone_lo.  An edge unit of 8 rows
     // is done in ~25 us, one of 28 in ~45: the exchange behind the edge units starts that much earlier, and what it can hide
     // behind is the interior units of one launch (~57 us on a 1024-row band) -- see profiles/r03_fake_link.log
     const bool zones = edge_seg > 0 && zone_lo >= lo && zone_hi <= hi && zone_lo <= zone_hi;
@@ -1229,7 +1229,7 @@ static const dmg_ocean::tile_list *st_units(dmg_ocean *o, int variant, int lo, i
         if (!whole) return nullptr;
         cut_seg = whole->cut_seg; cut_seg2 = whole->cut_seg2; cut_split = whole->cut_split;
         if (cut_seg <= 0) { cut_seg = variant == 1 ? STN_MAXROWS : ST_MAXROWS; cut_seg2 = 0; cut_split = hi; }   // (a launch with no live unit)
-        static const int edge_seg = [] { const char *e = getenv("DMG_ST_EDGE_SEG"); const int v = e ? atoi(e) : 8; return v >= 4 && v <= ST_MAXROWS ? v : 0; }();
+        static const int edge_seg = [] { const char *e = getenv("DMG_ST_EDGE_SEG"); const int v = e ? atoi(e) : 4; return v >= 2 && v <= ST_MAXROWS ? v : 0; }();
         st_cut(o, variant, lo, hi, cut_seg, part, zone_lo, zone_hi, best, cut_seg2, cut_split, edge_seg);
         (void)st_makespan(best, slots);
         // both halves built: together they must be the units of ONE cut of the launch's rows, each exactly once
