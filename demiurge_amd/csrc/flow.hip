@@ -1248,7 +1248,11 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
         // 16384x8192 round took 45 ms, with 512 waves 30 ms (4096x2048: 4.5 -> 3.4 ms; 128 waves are too few: 36 ms).
         // Measured and dropped in the same sitting: a lane that walks on downstream with the sum it has just published
         // (computing the next cell itself, one round of loads per hop instead of a store and a poll) -- as many rounds saved as
-        // each round got longer; a round is one coherent load's trip to the memory side, ~1 us, either way.
+        // each round got longer; a round is one coherent load's trip to the memory side, ~1 us, either way.  Nor is there a
+        // shorter trip to be had by keeping the whole grid on ONE XCD (workgroups elsewhere leaving at once) and talking through
+        // that XCD's L2: workgroup-scope loads (sc0) are served by the CU's own L1 and never see another CU's sum, with or
+        // without a `buffer_inv sc0` in front; `buffer_inv sc1` works at 50 ms per solve; agent-scope loads of sums stored at
+        // workgroup scope work, and take as long as before (4.0 ms on one XCD against 3.2 ms on eight).
         static const int nblocks_env = [] { const char *e = getenv("DMG_FLOW_NBLOCKS"); return e ? atoi(e) : 0; }();
         const int blocks = std::min((waves + 3) / 4, nblocks_env > 0 ? nblocks_env : 128);
         hipLaunchKernelGGL(k_flow_dataflow, dim3(blocks), dim3(256), 0, st, fc, order.i(), n_reached, (const unsigned short *)mask.p, dcf.i(),
