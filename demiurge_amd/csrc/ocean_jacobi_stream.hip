@@ -181,10 +181,6 @@ struct st_state {
     const float *nx_p, *nx_b;
     const unsigned char *nx_c;
     bool plain;
-#ifdef ST_EXPERIMENTS
-    int x_stride;                   // DMG_ST_DBG & 256: rows of a strip 1 KB apart (a strip-major layout's access shape; results are garbage)
-    float *x_out;
-#endif
     unsigned badbits;               // DV = 1: ... its divisors have no exact two-operation pair (the table holds (c, r) for it)
     int slot;                       // ring slot of the first row of this step's pair (row offset mod ST_RING)
     float cy, ry;                   // the same for every row (pixelsize().y, src/Shader.h:71-74): two SGPRs
@@ -299,13 +295,8 @@ __device__ __forceinline__ void st_level(const st_args &a, st_state &z, v4f (*br
     if (S < 8) { z.w[S & 7][K][0] = oA; z.w[S & 7][K][1] = oB; }
     else if (lane_ok && !ST_DBG(a, 2)) {                          // never re-read in this launch; land rows hold 0 in both buffers already
         // only the unit's own rows [r0, r1): in its first steps level 8 runs on rows below r0, never stored
-#ifdef ST_EXPERIMENTS
-        if (!landA && yA >= r0 && yA < r1) __builtin_nontemporal_store(st_to_memory(oA), reinterpret_cast<v4f *>(z.x_out + (size_t)yA * z.x_stride + (ST_DBG(a, 256) ? 4 * lane : xcol)));
-        if (!landB && yA + 1 >= r0 && yA + 1 < r1) __builtin_nontemporal_store(st_to_memory(oB), reinterpret_cast<v4f *>(z.x_out + (size_t)(yA + 1) * z.x_stride + (ST_DBG(a, 256) ? 4 * lane : xcol)));
-#else
         if (!landA && yA >= r0 && yA < r1) __builtin_nontemporal_store(st_to_memory(oA), reinterpret_cast<v4f *>(a.pout + (size_t)yA * a.W + xcol));
         if (!landB && yA + 1 >= r0 && yA + 1 < r1) __builtin_nontemporal_store(st_to_memory(oB), reinterpret_cast<v4f *>(a.pout + (size_t)(yA + 1) * a.W + xcol));
-#endif
     }
 }
 
@@ -341,11 +332,7 @@ __device__ __forceinline__ void st_fetch(const st_args &a, st_state &z, int set,
     int ml = 0;
     if (!P && z.plain && !ST_DBG(a, 1)) {
         bp = reinterpret_cast<const char *>(z.nx_p); bb = reinterpret_cast<const char *>(z.nx_b); bc = reinterpret_cast<const char *>(z.nx_c);
-#ifdef ST_EXPERIMENTS
-        z.nx_p += z.x_stride; z.nx_b += z.x_stride; z.nx_c += z.x_stride;
-#else
         z.nx_p += a.W; z.nx_b += a.W; z.nx_c += a.W;
-#endif
     } else {
         const st_row m = st_map_row(a, ST_DBG(a, 1) ? (e & 63) : e);
         const size_t rowoff = (size_t)m.l * a.W;
@@ -550,15 +537,6 @@ __global__ __launch_bounds__(64, 2) void k_jacobi_stream(st_args a)
         const int e_last = e0 + 2 * nsteps + 5;             // the last row a step requests (st_step: e_t + 5)
         z.plain = e0 >= 0 && e_last < a.L && a.y_first + e0 >= 0 && a.y_first + e_last < a.H;
         z.nx_p = a.pin + (size_t)e0 * W; z.nx_b = a.b + (size_t)e0 * W; z.nx_c = a.code + (size_t)e0 * W;
-#ifdef ST_EXPERIMENTS
-        z.x_stride = W; z.x_out = a.pout;
-        if (ST_DBG(a, 256) && z.plain) {
-            const size_t tile = (size_t)min(tx, W / 256 - 1) * a.L * 256;
-            z.x_stride = 256; z.x_out = a.pout + tile;
-            z.nx_p = a.pin + tile + (size_t)e0 * 256; z.nx_b = a.b + tile + (size_t)e0 * 256; z.nx_c = a.code + tile + (size_t)e0 * 256;
-            col = colp = 4 * lane;
-        }
-#endif
     }
     st_fetch<false>(a, z, 0, 0, e0, col, colp);
     st_fetch<false>(a, z, 0, 1, e0 + 1, col, colp);
