@@ -317,6 +317,9 @@ __device__ __forceinline__ unsigned st_class(unsigned cls_lo, unsigned cls_hi, i
 // the compiler can then count them, and the wait in front of a step's arrival is a counted vmcnt that leaves the other
 // staging set's loads (and the stores) in flight -- with class-dependent loads it falls back to vmcnt(0) and the
 // prefetch distance collapses to nothing.  (Land rows inside a live unit are few; their loads are wasted bytes.)
+// (Measured and dropped, round 3: keeping the last three steps' requests -- six rows past the window, never used -- on the window's
+// last row: 3 % of a 180-row unit's load bytes, 12 % of a 28-row unit's, and 1 % slower at every size: a compare and three pointer
+// adjustments per request cost more than rows that mostly come out of the Infinity Cache.)
 // (Measured and dropped: pointing the loads a row does not need -- everything of a land row, the codes of an open-ocean
 // row -- at an already cached row saves ~10 % of the bytes but costs more in address arithmetic: 2.58 -> 2.49 M.)
 template <bool P>
