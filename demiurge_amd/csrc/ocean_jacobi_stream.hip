@@ -320,8 +320,9 @@ __device__ __forceinline__ unsigned st_class(unsigned cls_lo, unsigned cls_hi, i
 // (Measured and dropped, round 3: keeping the last three steps' requests -- six rows past the window, never used -- on the window's
 // last row: 3 % of a 180-row unit's load bytes, 12 % of a 28-row unit's, and 1 % slower at every size: a compare and three pointer
 // adjustments per request cost more than rows that mostly come out of the Infinity Cache.)
-// (Measured and dropped: pointing the loads a row does not need -- everything of a land row, the codes of an open-ocean
-// row -- at an already cached row saves ~10 % of the bytes but costs more in address arithmetic: 2.58 -> 2.49 M.)
+// (Round 2 measured pointing the loads a row does not need -- everything of a land row, the codes of an open-ocean row -- at an
+// already cached row as a loss, 2.58 -> 2.49 M: address arithmetic in VGPR pairs.  With scalar row bases the codes of an open
+// row ARE redirected now, below; a land row's loads are not: such rows are few inside a live unit.)
 template <bool P>
 __device__ __forceinline__ void st_fetch(const st_args &a, st_state &z, int set, int j, int e, int col, int colp, int tx = 0, unsigned cls = 2u)
 {
