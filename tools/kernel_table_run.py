@@ -1,0 +1,23 @@
+"""The tools' kernels once each at 16384x8192, for a profiler (tools/kernel_table.py reads its kernel stats)."""
+import sys
+sys.path.insert(0, ".")
+import numpy as np
+from demiurge_amd import capi, synth
+ctx = capi.Context(0)
+W, H = 16384, 8192
+g = capi.make_grid(W, H)
+terrain = synth.terrain(W, H)
+o = capi.Ocean(ctx, g)
+o.set_terrain(terrain); o.set_divw(synth.divw(W, H))
+prm_single = capi.default_ocean_params(); prm_single.jacobi_kernel = capi.JACOBI_SINGLE
+o.step(); o.step(); ctx.sync()
+o.close()
+o1 = capi.Ocean(ctx, g, params=prm_single)
+o1.set_terrain(terrain); o1.set_divw(synth.divw(W, H)); o1.zero_pressure(); o1.jacobi_sweeps(40); ctx.sync(); o1.close()
+h = (terrain * 100 + synth.lcg_uniform(W * H, 5).reshape(H, W) * 3).astype(np.float32)
+T0 = (synth.lcg_uniform(W * H, 41).reshape(H, W) * 60).astype(np.float32)
+k = capi.Climate(ctx, g, T0, h); k.steps(0, 20); ctx.sync(); k.close()
+ctx.erosion_run(g, h, 50, 1, 0.5, 1.0, 1.0)
+ctx.blur(g, h, 3.0)
+t = capi.Tectonics(ctx, g, h); t.step(2); ctx.sync(); t.close()
+print("done")
