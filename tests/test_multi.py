@@ -195,6 +195,36 @@ def test_multi_band_failure_returns_everywhere(transport, order):
     assert "failure injected" in r.stdout and "second call refused" in r.stdout and "closed" in r.stdout, r.stdout[-2000:]
 
 
+_LINK_CHILD = """
+import sys, hashlib
+import numpy as np
+sys.path.insert(0, '.')
+from demiurge_amd import capi, synth
+W, H = 16384, 2048
+grid = capi.make_grid(W, H)
+for flags in (capi.MULTI_RCCL_LOOPBACK, capi.MULTI_PEER):
+    for order in (capi.MULTI_EXCHANGE_THEN_SWEEP, capi.MULTI_OVERLAP_LAST_LAUNCH):
+        m = capi.Multi(grid, devices=[0] * 2, ghost=32, flags=flags | order)
+        m.set_terrain(synth.terrain(W, H)); m.set_divw(synth.divw(W, H))
+        m.jacobi(200, zero_first=True)
+        print(hashlib.sha256(m.get(want=('pressure',))['pressure'].tobytes()).hexdigest())
+        m.close()
+"""
+
+
+def test_multi_slow_link_changes_no_bit():
+    """The edge-first overlapped order exists to hide a link slower than a local copy.  DMG_MULTI_FAKE_LINK_US holds every
+    exchange's stream for that long (the emulation behind profiles/r03_fake_link.log): whatever the interior units, the edge
+    units and the exchange do meanwhile, the result is the one without a link, in both orders and both one-GPU transports."""
+    fast = _multi_child(_LINK_CHILD, {})
+    slow = _multi_child(_LINK_CHILD, {"DMG_MULTI_FAKE_LINK_US": "150"})
+    assert fast.returncode == 0 and slow.returncode == 0, fast.stderr[-1500:] + slow.stderr[-1500:]
+    import re
+    sha = lambda out: [l for l in out.split() if re.fullmatch(r"[0-9a-f]{64}", l)]        # (RCCL prints a banner of its own)
+    a, b = sha(fast.stdout), sha(slow.stdout)
+    assert len(a) == 4 and len(set(a)) == 1 and a == b, (a, b)
+
+
 def test_multi_wait_times_out_instead_of_hanging():
     """the host-side waits of the RCCL transports poll with a deadline: with an absurdly short one (1 ms against a solve
     of several hundred) the wait gives up, aborts the communicator and reports it -- what a rank does whose neighbour has
