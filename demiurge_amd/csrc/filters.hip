@@ -212,10 +212,15 @@ static std::vector<float> blur_rlist(float radius)
 __device__ __forceinline__ float d_sign(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
 
 // QDay(phi, M) (:69-95) -> absorbed solar radiation of the row, ASR = (1-0.30)*QDay (:102,:122)
-__global__ void k_temperature_rows(canvas c, const float *__restrict__ lat, float M, float sin_gamma, float *__restrict__ asr)
+// (one launch for a batch of steps: blockIdx.y = the step within the batch; M = (float)(M_PI*2/15000*i), the host's
+// expression in the host's double arithmetic, :146)
+#define TEMP_ROWS_BATCH 64
+__global__ void k_temperature_rows(canvas c, const float *__restrict__ lat, int first_step, float sin_gamma, float *__restrict__ asr_batch)
 {
     int y = blockIdx.x * blockDim.x + threadIdx.x;
     if (y >= c.H) return;
+    const float M = (float)(M_PI * 2 / 15000 * (first_step + (int)blockIdx.y));
+    float *asr = asr_batch + (size_t)blockIdx.y * c.H;
     float phi = lat[y];
     const float eccentricity = 0.017f;
     const float omega = 0.0f, omega2 = 77.05f / 180.0f * DMG_PI;
@@ -637,7 +642,7 @@ int dmg_climate_create_band(dmg_ctx *ctx, const dmg_grid *grid, const float *T, 
     if (!k) return dmg_fail(DMG_ENOMEM, "out of host memory");
     k->ctx = ctx; k->grid = *grid; k->topo = topo;
     k->rank = band_rank; k->count = band_count; k->ghost = ghost; k->y0 = by0; k->y1 = by1; k->gs = bgs; k->gn = bgn; k->L = bL;
-    DMG_ALLOC(k->a, n * 4); DMG_ALLOC(k->b, n * 4); DMG_ALLOC(k->terr, n * 4); DMG_ALLOC(k->dasr, (size_t)H * 4);
+    DMG_ALLOC(k->a, n * 4); DMG_ALLOC(k->b, n * 4); DMG_ALLOC(k->terr, n * 4); DMG_ALLOC(k->dasr, (size_t)H * 4 * TEMP_ROWS_BATCH);
     DMG_ALLOC(k->dshift, (size_t)H * 9 * sizeof(int)); DMG_ALLOC(k->dsrow, (size_t)H * 9 * sizeof(int)); DMG_ALLOC(k->dlit, (size_t)H * sizeof(int));
     if ((rc = upload_rows(ctx, k->dlat, lat)) || (rc = upload_rows(ctx, k->dcos, cosphi)) || (rc = upload_rows(ctx, k->ddy, dyr)) ||
         (rc = upload_rows(ctx, k->drden, rden))) return rc;
@@ -708,19 +713,23 @@ int dmg_climate_steps(dmg_climate *k, int first_step, int n_steps)
         c.row0 = lo;
         const float *cur_v = k->cur - k->voff();
         float *nxt_v = k->nxt - k->voff();
-        float M = (float)(M_PI * 2 / 15000 * i);     // glUniform1f(id, M_PI*2/15000*i) (:146)
-        hipLaunchKernelGGL(k_temperature_rows, dim3((H + 255) / 256), dim3(256), 0, ctx->stream, c, k->dlat.f(), M, sin_gamma, k->dasr.f());
+        // glUniform1f(id, M_PI*2/15000*i) (:146) and the rows' absorbed radiation for it: a batch of steps per launch
+        const int in_batch = (i - first_step) % TEMP_ROWS_BATCH;
+        if (in_batch == 0)
+            hipLaunchKernelGGL(k_temperature_rows, dim3((H + 255) / 256, std::min(TEMP_ROWS_BATCH, first_step + n_steps - i)), dim3(256), 0, ctx->stream,
+                               c, k->dlat.f(), i, sin_gamma, k->dasr.f());
+        const float *asr_i = k->dasr.f() + (size_t)in_batch * H;
         if (W % 4 == 0) {                            // tabled rows four cells per thread, the few literal rows one cell per thread
             hipLaunchKernelGGL(k_temperature_v4, dim3((W / 4 + 255) / 256, nrows), dim3(256), 0, ctx->stream, c, cur_v, nxt_v, land4_v,
-                               k->dasr.f(), k->ddy.f(), k->drden.f(), tc, (const int *)k->dshift.p, (const int *)k->dsrow.p, (const int *)k->dlit.p);
+                               asr_i, k->ddy.f(), k->drden.f(), tc, (const int *)k->dshift.p, (const int *)k->dsrow.p, (const int *)k->dlit.p);
             const int l0 = (int)(std::lower_bound(k->lit_rows.begin(), k->lit_rows.end(), lo) - k->lit_rows.begin());
             const int l1 = (int)(std::lower_bound(k->lit_rows.begin(), k->lit_rows.end(), hi) - k->lit_rows.begin());
             if (l1 > l0)
                 hipLaunchKernelGGL(k_temperature, dim3((W + 255) / 256, l1 - l0), dim3(256), 0, ctx->stream, c, cur_v, nxt_v, terr_v,
-                                   k->dasr.f(), k->dcos.f(), k->ddy.f(), k->drden.f(), tc, (const int *)k->dshift.p, (const int *)k->dsrow.p,
+                                   asr_i, k->dcos.f(), k->ddy.f(), k->drden.f(), tc, (const int *)k->dshift.p, (const int *)k->dsrow.p,
                                    (const int *)k->dlit.p, (const int *)k->dlitrows.p + l0);
         } else {
-            hipLaunchKernelGGL(k_temperature, dim3((W + 255) / 256, nrows), dim3(256), 0, ctx->stream, c, cur_v, nxt_v, terr_v, k->dasr.f(),
+            hipLaunchKernelGGL(k_temperature, dim3((W + 255) / 256, nrows), dim3(256), 0, ctx->stream, c, cur_v, nxt_v, terr_v, asr_i,
                                k->dcos.f(), k->ddy.f(), k->drden.f(), tc, (const int *)k->dshift.p, (const int *)k->dsrow.p, (const int *)k->dlit.p,
                                (const int *)nullptr);
         }
