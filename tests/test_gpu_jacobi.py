@@ -263,8 +263,9 @@ def test_blocked_full_size_bitwise(dev, oracle):
     W, H = 16384, 8192
     grid = capi.make_grid(W, H)
     img, b = synth.terrain(W, H), synth.divw(W, H)
-    blocked = run_jacobi(capi, ctx, grid, img, b, 12, block=12, kernel=capi.JACOBI_BLOCKED)
-    ref = oracle.ocean_jacobi(ogrid(oracle, grid), img, b, 12, rows=True)
+    # five 8-sweep launches of the streaming kernel (the default above 4096 tiles) and a 4-sweep launch, against the oracle
+    blocked = run_jacobi(capi, ctx, grid, img, b, 44, block=44, kernel=capi.JACOBI_BLOCKED)
+    ref = oracle.ocean_jacobi(ogrid(oracle, grid), img, b, 44, rows=True, nthreads=16)
     assert np.array_equal(blocked, ref)
 
 
