@@ -48,13 +48,16 @@ class WorldParams(ctypes.Structure):
 
 class MultiStats(ctypes.Structure):
     _fields_ = [("bands_total", ctypes.c_int), ("bands_local", ctypes.c_int), ("transport", ctypes.c_int), ("order", ctypes.c_int),
-                ("ghost", ctypes.c_int), ("exchanges", ctypes.c_longlong), ("exchange_ms", ctypes.c_double),
+                ("ghost", ctypes.c_int), ("warnings", ctypes.c_int), ("exchanges", ctypes.c_longlong), ("exchange_ms", ctypes.c_double),
                 ("exchange_bytes", ctypes.c_longlong), ("jacobi_launches", ctypes.c_longlong), ("jacobi_sweeps", ctypes.c_longlong)]
 
 
-MULTI_AUTO, MULTI_RCCL, MULTI_PEER, MULTI_RCCL_LOOPBACK = 0, 1, 2, 3
+MULTI_AUTO, MULTI_RCCL, MULTI_PEER, MULTI_RCCL_LOOPBACK, MULTI_STORE = 0, 1, 2, 3, 4
 MULTI_EXCHANGE_THEN_SWEEP, MULTI_OVERLAP_LAST_LAUNCH = 0, 16
-MULTI_TRANSPORT_NAMES = {1: "rccl", 2: "peer-copies", 3: "rccl-loopback"}
+MULTI_TRANSPORT_NAMES = {1: "rccl", 2: "peer-copies", 3: "rccl-loopback", 4: "store"}
+MULTI_STORE_BLOB_BYTES = 192
+MULTI_WARN_HWQ_FALLBACK = 1
+F_PRESSURE, F_DIVW, F_TERRAIN, F_V, F_VADVECT = 0, 1, 2, 3, 4
 
 
 class NoiseParams(ctypes.Structure):
@@ -112,6 +115,7 @@ def lib():
     sig = {
         "dmg_version": (c_int, []),
         "dmg_last_error": (ctypes.c_char_p, []),
+        "dmg_runtime_init": (c_int, []),
         "dmg_create": (c_int, [c_int, vp, c_int, ctypes.POINTER(vp)]),
         "dmg_destroy": (None, [vp]),
         "dmg_sync": (c_int, [vp]),
@@ -148,6 +152,7 @@ def lib():
         "dmg_ocean_divergence": (c_int, [vp]),
         "dmg_ocean_subdiv": (c_int, [vp]),
         "dmg_ocean_advect_reach": (c_int, [vp, ctypes.POINTER(c_int)]),
+        "dmg_ocean_advect_prepare": (c_int, [vp, c_int]),
         "dmg_ocean_get": (c_int, [vp, vp, vp, vp, vp]),
         "dmg_ocean_checkpoint": (c_int, [vp, ctypes.c_char_p]),
         "dmg_ocean_restore": (c_int, [vp, ctypes.c_char_p]),
@@ -211,6 +216,10 @@ def lib():
         "dmg_multi_unique_id": (c_int, [vp]),
         "dmg_multi_create_rank": (c_int, [c_int, c_int, vp, c_int, PG, PP, c_int, c_int, ctypes.POINTER(vp)]),
         "dmg_multi_destroy": (None, [vp]),
+        "dmg_multi_store_blob": (c_int, [vp, vp]),
+        "dmg_multi_store_connect": (c_int, [vp, vp, c_int]),
+        "dmg_multi_climate_store_blob": (c_int, [vp, vp]),
+        "dmg_multi_climate_store_connect": (c_int, [vp, vp, c_int]),
         "dmg_multi_set_order": (c_int, [vp, c_int]),
         "dmg_multi_set_terrain": (c_int, [vp, vp]),
         "dmg_multi_generate_terrain": (c_int, [vp, ctypes.POINTER(NoiseParams)]),
@@ -649,6 +658,9 @@ class Ocean:
         check(lib().dmg_ocean_advect_reach(self.h, ctypes.byref(r)))
         return r.value
 
+    def advect_prepare(self, reach):
+        check(lib().dmg_ocean_advect_prepare(self.h, reach))
+
     def checkpoint(self, prefix):
         check(lib().dmg_ocean_checkpoint(self.h, str(prefix).encode()))
 
@@ -787,6 +799,17 @@ class Multi:
         buf = ctypes.create_string_buffer(128)
         check(lib().dmg_multi_unique_id(buf))
         return buf.raw
+
+    def store_blob(self):
+        """MULTI_STORE, one process per GPU, no RCCL id: this rank's memory handles (all-gather them, then store_connect)"""
+        buf = ctypes.create_string_buffer(MULTI_STORE_BLOB_BYTES)
+        check(lib().dmg_multi_store_blob(self.h, buf))
+        return buf.raw
+
+    def store_connect(self, blobs):
+        """blobs: the store_blob() bytes of every rank, in rank order"""
+        raw = b"".join(blobs)
+        check(lib().dmg_multi_store_connect(self.h, ctypes.create_string_buffer(raw, len(raw)), len(blobs)))
 
     def close(self):
         if self.h:

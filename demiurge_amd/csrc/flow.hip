@@ -789,7 +789,7 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
     }
     std::vector<int> sink_cell;                              // on the host only if a growth will read it (below, once the mouths are counted)
     if (nlakes) {
-        DMG_ALLOC(sinkc, (size_t)nlakes * 4);
+        DMG_ALLOC_VAR(sinkc, (size_t)nlakes * 4);
         hipLaunchKernelGGL(k_flow_sinkcells, dim3(nb), dim3(256), 0, st, label.i(), dense.i(), sinkc.i(), N);
     }
 
@@ -797,7 +797,7 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
     // sort by (height, s), stable sort by (lake, from), keep segment heads, then order each lake's passes by height
     int cap = (int)std::min<size_t>(N, (size_t)1 << 28);
     dev_buf k0, v0, k1, v1, flags, nsel, tmpst, sdist, mouths_d;
-    DMG_ALLOC(k0, (size_t)cap * 8); DMG_ALLOC(v0, (size_t)cap * 8); DMG_ALLOC(k1, (size_t)cap * 8); DMG_ALLOC(v1, (size_t)cap * 8);
+    DMG_ALLOC_VAR(k0, (size_t)cap * 8); DMG_ALLOC_VAR(v0, (size_t)cap * 8); DMG_ALLOC_VAR(k1, (size_t)cap * 8); DMG_ALLOC_VAR(v1, (size_t)cap * 8);
     DMG_ALLOC(nsel, 8);
     DMG_HIP(hipMemsetAsync(count.p, 0, 4, st));
     const unsigned nbi = (unsigned)((N + (size_t)256 * FLOW_ITEMS - 1) / ((size_t)256 * FLOW_ITEMS));     // blocks of FLOW_ITEMS x 256 cells
@@ -807,7 +807,7 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
     int ncand = 0;
     DMG_HIP(hipMemcpyAsync(&ncand, count.p, 4, hipMemcpyDeviceToHost, st));
     // river mouths (dense ids), compacted (sorted below, on the device)
-    DMG_ALLOC(mouths_d, (size_t)std::max(nlakes, 1) * 4);
+    DMG_ALLOC_VAR(mouths_d, (size_t)std::max(nlakes, 1) * 4);
     DMG_HIP(hipMemsetAsync(nsel.p, 0, 8, st));
     hipLaunchKernelGGL(k_flow_mouths, dim3(nbi), dim3(256), 0, st, (const unsigned short *)mask.p, dense.i(), mouths_d.i(), nsel.i(), N);
     int nmouth = 0;
@@ -822,9 +822,9 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
         int bits = 1;
         while ((1ll << bits) < (long long)nlakes + 1) bits++;
         size_t mb = 0;
-        DMG_ALLOC(mouths_s, (size_t)nmouth * 4);
+        DMG_ALLOC_VAR(mouths_s, (size_t)nmouth * 4);
         (void)hipcub::DeviceRadixSort::SortKeys(nullptr, mb, (const unsigned *)mouths_d.p, (unsigned *)mouths_s.p, nmouth, 0, bits, st);
-        DMG_ALLOC(mouths_tmp, mb + 256);
+        DMG_ALLOC_VAR(mouths_tmp, mb + 256);
         DMG_HIP(hipcub::DeviceRadixSort::SortKeys(mouths_tmp.p, mb, (const unsigned *)mouths_d.p, (unsigned *)mouths_s.p, nmouth, 0, bits, st));
         DMG_HIP(hipMemcpyAsync(mouths.data(), mouths_s.p, (size_t)nmouth * 4, hipMemcpyDeviceToHost, st));
     }
@@ -849,9 +849,9 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
         typedef unsigned long long u64;
         size_t tb = 0, tb2 = 0;
         (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb, (u64 *)v0.p, (u64 *)v1.p, (u64 *)k0.p, (u64 *)k1.p, ncand, 0, 64, st);
-        DMG_ALLOC(flags, (size_t)ncand);
+        DMG_ALLOC_VAR(flags, (size_t)ncand);
         (void)hipcub::DeviceSelect::Flagged(nullptr, tb2, (u64 *)k0.p, (unsigned char *)flags.p, (u64 *)k1.p, nsel.i(), ncand, st);
-        DMG_ALLOC(tmpst, std::max(tb, tb2) + 256);
+        DMG_ALLOC_VAR(tmpst, std::max(tb, tb2) + 256);
         // 1) by (height, s): (v0,k0) -> (v1,k1)
         DMG_HIP(hipcub::DeviceRadixSort::SortPairs(tmpst.p, tb, (u64 *)v0.p, (u64 *)v1.p, (u64 *)k0.p, (u64 *)k1.p, ncand, 0, 64, st));
         // 2) stable by (lake, from): (k1,v1) -> (k0,v0); within a lake pair the lowest (height, s) comes first
@@ -865,10 +865,10 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
         hipLaunchKernelGGL(k_flow_pack, dim3((nuniq + 255) / 256), dim3(256), 0, st, (const u64 *)k1.p, (const u64 *)v1.p,
                            (u64 *)k0.p, (u64 *)v0.p, nuniq);
         DMG_HIP(hipcub::DeviceRadixSort::SortPairs(tmpst.p, tb, (u64 *)k0.p, (u64 *)k1.p, (u64 *)v0.p, (u64 *)v1.p, nuniq, 0, 64, st));
-        DMG_ALLOC(sdist, (size_t)nuniq * 4);
+        DMG_ALLOC_VAR(sdist, (size_t)nuniq * 4);
         hipLaunchKernelGGL(k_flow_gather_dist, dim3((nuniq + 255) / 256), dim3(256), 0, st, (const u64 *)v1.p, dst[cur].i(), sdist.i(), nuniq);
         // the host's view: entries as 16-byte records and every lake's range of them (the sink distances stay on the device)
-        DMG_ALLOC(dent, (size_t)std::max(nuniq, 1) * 16); DMG_ALLOC(dspan, (size_t)(nlakes + 1) * 8);
+        DMG_ALLOC_VAR(dent, (size_t)std::max(nuniq, 1) * 16); DMG_ALLOC_VAR(dspan, (size_t)(nlakes + 1) * 8);
         DMG_HIP(hipMemsetAsync(dspan.p, 0, (size_t)(nlakes + 1) * 8, st));
         hipLaunchKernelGGL(k_flow_entries, dim3((nuniq + 255) / 256), dim3(256), 0, st, (const u64 *)k1.p, (const u64 *)v1.p, (int4 *)dent.p, (int2 *)dspan.p, nuniq);
         DMG_HIP(hipGetLastError());
@@ -892,15 +892,15 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
         typedef unsigned long long u64;
         // (1) rank of every pass in the growth's total order (h, from, s): two stable radix sorts
         dev_buf gks, gks2, gidx, gidx2, gkhf, gkhf2, gorder, grank, gd, gq, gfa, gfb, gcnt, gvs, gtmp, gds, gls, glid, ghead;
-        DMG_ALLOC(gks, (size_t)nuniq * 4); DMG_ALLOC(gks2, (size_t)nuniq * 4); DMG_ALLOC(gidx, (size_t)nuniq * 4); DMG_ALLOC(gidx2, (size_t)nuniq * 4);
-        DMG_ALLOC(gkhf, (size_t)nuniq * 8); DMG_ALLOC(gkhf2, (size_t)nuniq * 8); DMG_ALLOC(gorder, (size_t)nuniq * 4); DMG_ALLOC(grank, (size_t)nuniq * 4);
+        DMG_ALLOC_VAR(gks, (size_t)nuniq * 4); DMG_ALLOC_VAR(gks2, (size_t)nuniq * 4); DMG_ALLOC_VAR(gidx, (size_t)nuniq * 4); DMG_ALLOC_VAR(gidx2, (size_t)nuniq * 4);
+        DMG_ALLOC_VAR(gkhf, (size_t)nuniq * 8); DMG_ALLOC_VAR(gkhf2, (size_t)nuniq * 8); DMG_ALLOC_VAR(gorder, (size_t)nuniq * 4); DMG_ALLOC_VAR(grank, (size_t)nuniq * 4);
         const unsigned eb = (unsigned)((nuniq + 255) / 256), lb = (unsigned)((nlakes + 255) / 256);
         hipLaunchKernelGGL(k_growth_keys, dim3(eb), dim3(256), 0, st, (const int4 *)dent.p, (unsigned *)gks.p, gidx.i(), nuniq);
         size_t t1 = 0, t2 = 0, t3 = 0;
         (void)hipcub::DeviceRadixSort::SortPairs(nullptr, t1, (unsigned *)gks.p, (unsigned *)gks2.p, gidx.i(), gidx2.i(), nuniq, 0, 32, st);
         (void)hipcub::DeviceRadixSort::SortPairs(nullptr, t2, (u64 *)gkhf.p, (u64 *)gkhf2.p, gidx2.i(), gorder.i(), nuniq, 0, 64, st);
         (void)hipcub::DeviceRadixSort::SortPairs(nullptr, t3, (unsigned *)gks.p, (unsigned *)gks2.p, gidx.i(), gidx2.i(), nlakes, 0, 32, st);
-        DMG_ALLOC(gtmp, std::max(t1, std::max(t2, t3)) + 256);
+        DMG_ALLOC_VAR(gtmp, std::max(t1, std::max(t2, t3)) + 256);
         DMG_HIP(hipcub::DeviceRadixSort::SortPairs(gtmp.p, t1, (unsigned *)gks.p, (unsigned *)gks2.p, gidx.i(), gidx2.i(), nuniq, 0, 32, st));      // by s
         hipLaunchKernelGGL(k_growth_keys2, dim3(eb), dim3(256), 0, st, (const int4 *)dent.p, gidx2.i(), (u64 *)gkhf.p, nuniq);
         DMG_HIP(hipcub::DeviceRadixSort::SortPairs(gtmp.p, t2, (u64 *)gkhf.p, (u64 *)gkhf2.p, gidx2.i(), gorder.i(), nuniq, 0, 64, st));           // stable by (h, from)
@@ -924,7 +924,7 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
         }
         if ((rc = upload_vec(ctx, gvs, vstart))) return rc;
         // (3) minimax levels: frontier relaxation from the mouths until nothing falls any more
-        DMG_ALLOC(gd, (size_t)nlakes * 4); DMG_ALLOC(gq, (size_t)nlakes * 4); DMG_ALLOC(gfa, (size_t)nlakes * 4); DMG_ALLOC(gfb, (size_t)nlakes * 4); DMG_ALLOC(gcnt, 8);
+        DMG_ALLOC_VAR(gd, (size_t)nlakes * 4); DMG_ALLOC_VAR(gq, (size_t)nlakes * 4); DMG_ALLOC_VAR(gfa, (size_t)nlakes * 4); DMG_ALLOC_VAR(gfb, (size_t)nlakes * 4); DMG_ALLOC(gcnt, 8);
         hipLaunchKernelGGL(k_growth_init, dim3(lb), dim3(256), 0, st, (unsigned *)gd.p, gq.i(), nlakes);
         hipLaunchKernelGGL(k_growth_seed, dim3((unsigned)((nmouth + 255) / 256)), dim3(256), 0, st, mouths_d.i(), nmouth, (unsigned *)gd.p, gfa.i(), gcnt.i());
         int rounds = 0;
@@ -942,7 +942,7 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
             if (rounds > 4 * nlakes + 64) return dmg_fail(DMG_ESTATE, "flow: the minimax levels of the lake graph did not settle");
         }
         // (4) lakes in order of their level; the pass that opens each lake's cascade
-        DMG_ALLOC(gds, (size_t)nlakes * 4); DMG_ALLOC(glid, (size_t)nlakes * 4); DMG_ALLOC(gls, (size_t)nlakes * 4); DMG_ALLOC(ghead, (size_t)nlakes * 4);
+        DMG_ALLOC_VAR(gds, (size_t)nlakes * 4); DMG_ALLOC_VAR(glid, (size_t)nlakes * 4); DMG_ALLOC_VAR(gls, (size_t)nlakes * 4); DMG_ALLOC_VAR(ghead, (size_t)nlakes * 4);
         hipLaunchKernelGGL(k_growth_iota, dim3(lb), dim3(256), 0, st, glid.i(), nlakes);
         DMG_HIP(hipcub::DeviceRadixSort::SortPairs(gtmp.p, t3, (unsigned *)gd.p, (unsigned *)gds.p, glid.i(), gls.i(), nlakes, 0, 32, st));
         hipLaunchKernelGGL(k_growth_heads, dim3(lb), dim3(256), 0, st, (const unsigned *)gds.p, gorder.i(), ghead.i(), nlakes, nuniq);
@@ -1158,7 +1158,7 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
     DMG_HIP(hipMemsetAsync(dmax.p, 0, 8, st));
     if (nlakes) {
         const unsigned lb0 = (unsigned)((nlakes + 255) / 256);
-        DMG_ALLOC(dpar0, (size_t)nlakes * 4); DMG_ALLOC(dof0, (size_t)nlakes * 4); DMG_ALLOC(dlv0, (size_t)nlakes * 4); DMG_ALLOC(dmo, (size_t)nlakes);
+        DMG_ALLOC_VAR(dpar0, (size_t)nlakes * 4); DMG_ALLOC_VAR(dof0, (size_t)nlakes * 4); DMG_ALLOC_VAR(dlv0, (size_t)nlakes * 4); DMG_ALLOC_VAR(dmo, (size_t)nlakes);
         hipLaunchKernelGGL(k_flow_lake_init, dim3(lb0), dim3(256), 0, st, dpar0.i(), nlakes);
         DMG_HIP(hipMemsetAsync(dof0.p, 0, (size_t)nlakes * 4, st));
         DMG_HIP(hipMemsetAsync(dlv0.p, 0, (size_t)nlakes * 4, st));
@@ -1184,7 +1184,7 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
     }
     if (nlakes) {
         dev_buf dp1, dof1, dlv1;
-        DMG_ALLOC(dp1, (size_t)nlakes * 4); DMG_ALLOC(dof1, (size_t)nlakes * 4); DMG_ALLOC(dlv1, (size_t)nlakes * 4);
+        DMG_ALLOC_VAR(dp1, (size_t)nlakes * 4); DMG_ALLOC_VAR(dof1, (size_t)nlakes * 4); DMG_ALLOC_VAR(dlv1, (size_t)nlakes * 4);
         int *dp[2] = { dpar0.i(), dp1.i() }, *dof[2] = { dof0.i(), dof1.i() };
         float *dlv[2] = { dlv0.f(), dlv1.f() };
         int rounds = 1;
@@ -1218,7 +1218,7 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
     DMG_ALLOC(sorttmp, sort_bytes + 256);
     DMG_HIP(hipcub::DeviceRadixSort::SortPairs(sorttmp.p, sort_bytes, (const unsigned *)gdepth.p, (unsigned *)sdepth.p, (const unsigned *)iota.p,
                                                (unsigned *)order.p, (int)N, 0, depth_bits, st));
-    DMG_ALLOC(dstart, (size_t)(levels + 1) * 4);
+    DMG_ALLOC_VAR(dstart, (size_t)(levels + 1) * 4);
     hipLaunchKernelGGL(k_flow_level_starts, dim3((levels + 256) / 256), dim3(256), 0, st, (const unsigned *)sdepth.p, N, dstart.i(), levels);
     DMG_HIP(hipGetLastError());
     std::vector<int> start(levels + 1, 0);

@@ -14,6 +14,17 @@
 //                           communicator of size 1 that sends every slab to the process's own rank.
 //   dmg_multi_create_rank   one process per GPU (torchrun, MPI): each rank owns one band and a ncclCommInitRank
 //                           communicator built from a 128-byte id that the host distributes.
+// Transports of the halo slabs (dmg_ocean_halo: contiguous rows):
+//   RCCL            grouped ncclSend/ncclRecv on the band's stream: one RCCL kernel per exchange
+//   RCCL loopback   the same calls towards the process's own rank (tests on a one-GPU box)
+//   peer copies     hipMemcpyPeerAsync pulled by the receiver, ordered by events and two host barriers (one process)
+//   store           direct stores ("peer-mapped direct stores for the halo with RCCL kept for setup and
+//                   reductions"): a copy kernel of the SENDER writes its edge rows straight into a landing slot in the
+//                   neighbour's memory -- a peer-mapped pointer in one process, a hipIpc mapping between processes -- and then
+//                   a sequence number into the neighbour's flag word; the receiver's stream runs a kernel that waits for that
+//                   number and moves the slot into its ghost rows.  No RCCL kernel, no host barrier, no event between the
+//                   GPUs: what orders the two streams is the flag.  Two slots per side, used alternately: a sender can only be
+//                   one exchange ahead of its neighbour, because its next exchange needs the neighbour's rows of this one.
 // Results are bit-identical to one band whatever the split and the transport: the bands run the same kernels on the same
 // rows, and a ghost row is a copy of the neighbour's row.
 #include "ocean_internal.h"
@@ -51,7 +62,12 @@ struct band_team {
     int bar_count = 0;
     long long bar_gen = 0;
     bool failed = false;             // a band has returned an error in this run(): barriers let everybody go
-    std::function<void(int)> on_fail;    // called once by the band that failed, before the others are let go
+    // A band that fails with a runtime error calls on_fail from its own thread: it may only MARK the handle (an atomic flag
+    // that the other bands' waits poll).  Whatever tears shared state down -- ncclCommAbort, which the siblings may be inside
+    // of at that moment -- runs in after_fail, on the caller's thread, once every band thread has returned.
+    std::function<void(int)> on_fail;
+    std::function<void()> after_fail;
+    bool runtime_failure = false;
 
     void start(int n_)
     {
@@ -73,11 +89,13 @@ struct band_team {
                     }
                     int r = f(i);
                     std::string e = r ? dmg_last_error() : "";
-                    if ((r == DMG_EHIP || r == DMG_ENOMEM) && on_fail) on_fail(i);    // (a refused argument is collective and leaves nothing queued)
+                    const bool runtime = r == DMG_EHIP || r == DMG_ENOMEM;   // (a refused argument is collective and leaves nothing queued)
+                    if (runtime && on_fail) on_fail(i);
                     {
                         std::lock_guard<std::mutex> lk(mtx);
                         rc[i] = r;
                         err[i] = e;
+                        if (runtime) runtime_failure = true;
                         if (r) { failed = true; cv_bar.notify_all(); }     // nobody waits for a band that has given up
                         if (--remaining == 0) cv_done.notify_all();
                     }
@@ -99,7 +117,12 @@ struct band_team {
     {
         if (n <= 1) {
             const int r = n == 1 ? f(0) : DMG_OK;
-            if ((r == DMG_EHIP || r == DMG_ENOMEM) && on_fail) { const std::string keep = dmg_last_error(); on_fail(0); return dmg_fail(r, "%s", keep.c_str()); }
+            if (r == DMG_EHIP || r == DMG_ENOMEM) {
+                const std::string keep = dmg_last_error();
+                if (on_fail) on_fail(0);
+                if (after_fail) after_fail();
+                return dmg_fail(r, "%s", keep.c_str());
+            }
             return r;
         }
         {
@@ -107,12 +130,14 @@ struct band_team {
             job = f;
             remaining = n;
             failed = false;
+            runtime_failure = false;
             bar_count = 0;
             generation++;
         }
         cv_go.notify_all();
         std::unique_lock<std::mutex> lk(mtx);
         cv_done.wait(lk, [&] { return remaining == 0; });
+        if (runtime_failure && after_fail) { lk.unlock(); after_fail(); lk.lock(); }     // every band thread is parked again
         for (int i = 0; i < n; i++)                          // the band that failed first, not one that was merely let go
             if (rc[i] && rc[i] != DMG_ESTATE) return dmg_fail(rc[i], "band %d: %s", i, err[i].c_str());
         for (int i = 0; i < n; i++)
@@ -134,6 +159,41 @@ struct band_team {
 
 }  // namespace
 
+// ---- the store transport's per-band state ----
+// my landing slots [side][slot] and flag words [side] (what the neighbours write), the neighbours' (what I write)
+struct store_side {
+    unsigned char *land = nullptr;       // my two landing slots for this side, slot_bytes each
+    unsigned *flag = nullptr;            // my flag word for this side: the sequence number of the last slab that has landed whole
+    unsigned char *r_land = nullptr;     // the neighbour's landing slots for ITS side that faces me
+    unsigned *r_flag = nullptr;
+    unsigned *counter = nullptr;         // device word: blocks of a push kernel that are done
+    unsigned seq = 0;                    // slabs exchanged over this boundary so far (both neighbours count alike)
+};
+struct store_band {
+    unsigned char *land_base = nullptr;  // one allocation: 2 sides x 2 slots
+    unsigned *flag_base = nullptr;       // fine-grained (uncached) device memory: 2 flag words, 256 B apart
+    unsigned *counters = nullptr;
+    int *err_host = nullptr;             // host-mapped: a landing kernel gave up waiting for its flag
+    int *err_dev = nullptr;
+    void *ipc_land[2] = { nullptr, nullptr }, *ipc_flag[2] = { nullptr, nullptr };   // mappings opened with hipIpcOpenMemHandle (one process per GPU)
+    store_side side[2];
+};
+// what a rank publishes so that its neighbours can map its landing slots and flags (dmg_multi_store_blob / _connect)
+struct store_blob {
+    hipIpcMemHandle_t land, flag;
+    unsigned long long slot_bytes;
+    int rank, device;
+    char pad[DMG_MULTI_STORE_BLOB_BYTES - 2 * sizeof(hipIpcMemHandle_t) - sizeof(unsigned long long) - 2 * sizeof(int)];
+};
+static_assert(sizeof(store_blob) == DMG_MULTI_STORE_BLOB_BYTES, "store_blob layout");
+
+// progress of a band's exchanges: an event per exchange in a ring; a host-side wait only gives up when no new one completes
+struct band_beat {
+    enum { RING = 128 };
+    hipEvent_t ring[RING] = {};
+    long long issued = 0, seen = 0;
+};
+
 struct dmg_multi {
     int world = 1;                   // bands in the whole job
     int first = 0;                   // global index of this process's first band
@@ -141,32 +201,43 @@ struct dmg_multi {
     int transport = DMG_MULTI_PEER;
     int order = DMG_MULTI_EXCHANGE_THEN_SWEEP;
     int ghost = 1;
+    int warnings = 0;                // DMG_MULTI_WARN_*
     bool shared_ctx = false;         // loopback: every band on ctx[0] (one stream)
+    bool same_device = false;        // one process, and two neighbouring bands share a GPU (tests, rehearsals)
     dmg_grid grid{};
     dmg_ocean_params prm{};
     std::vector<dmg_ctx *> ctx;
     std::vector<dmg_ocean *> oc;     // the bands of an ocean (dmg_multi_create*), or ...
     std::vector<dmg_climate *> cl;   // ... the bands of a climate field (dmg_multi_climate_create*): same streams, threads and transports
-    std::vector<ncclComm_t> comm;    // RCCL: one per local band (loopback: one in all)
+    std::vector<ncclComm_t> comm;    // RCCL: one per local band (loopback: one in all); store, one process per GPU: set-up and the reach all-reduce
     std::vector<hipEvent_t> ev_done, ev_copied;    // PEER: per band
     // DMG_MULTI_OVERLAP_LAST_LAUNCH: a second, high-priority stream per band carries the exchange while the band's own
-    // stream sweeps the interior units of the block's last launch
+    // stream sweeps the interior units of the block's last launch.  Bands of one process that share a GPU share that stream
+    // (comm_owner[i] = the band that owns band i's): a device then holds n + 1 streams instead of 2 n
     std::vector<hipStream_t> comm_stream;
+    std::vector<int> comm_owner;
     std::vector<hipEvent_t> ev_edge, ev_xchg;      // per band: a whole launch done (own stream) / ghost rows refreshed (second stream)
-    std::atomic<bool> dead{false};   // a band failed and the communicators were aborted: only dmg_multi_destroy remains
-    int timeout_ms = 120000;         // RCCL transports: how long a host-side wait may take before the communicators are aborted
+    std::atomic<bool> dead{false};   // a band failed: only dmg_multi_destroy remains (the communicators are aborted once the band threads have drained)
+    int timeout_ms = 120000;         // how long a host-side wait, or a landing kernel, may go without progress before the handle is given up
     int fake_link_us = 0;            // experiments (DMG_MULTI_FAKE_LINK_US=<us>): every exchange is followed, on its stream, by a kernel that
                                      // waits that long -- a link slower than a local copy, to see what the overlapped order hides of it
-    int fail_band = -1;              // tests (DMG_MULTI_FAIL=<band>:<n>): that band gives up in front of its n-th exchange
+    int fail_band = -1;              // tests (DMG_MULTI_FAIL=<band>:<n>[:<order>]): that band gives up in front of its n-th exchange
     long long fail_at = 0;
+    int fail_order = -1;             //   ... only while the handle runs this exchange order (-1: any)
     std::vector<long long> n_band_exchanges;
     std::vector<int *> d_red;        // per band: one device word for reductions
+    std::vector<store_band> store;   // DMG_MULTI_STORE: per local band
+    size_t slot_bytes = 0;
+    bool store_connected = false;
+    std::vector<band_beat> beat;
     band_team team;
     // halo-exchange time: event pairs on band 0's stream around every exchange, folded into the sum when read
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_free, ev_used;
     double exchange_ms = 0.0;
     long long n_exchanges = 0, exchange_bytes = 0;
     dmg_ctx *ctx_of(int i) const { return shared_ctx ? ctx[0] : ctx[i]; }
+    hipStream_t cs_of(int i) const { return comm_stream[shared_ctx ? 0 : comm_owner[i]]; }
+    bool uses_rccl_data() const { return transport == DMG_MULTI_RCCL || transport == DMG_MULTI_RCCL_LOOPBACK; }
 };
 
 static bool multi_trace() { static const bool on = getenv("DMG_MULTI_TRACE") != nullptr; return on; }
@@ -187,41 +258,61 @@ static int multi_fold_events(dmg_multi *m)
     return DMG_OK;
 }
 
-// A band has failed, or a wait has run out: abort the local communicators so that receives still queued on the streams end
-// instead of waiting for a peer that will never send (ncclCommAbort tears the communicator's kernels down), and mark the
-// handle dead.  The bands of other processes notice through their own timed waits (multi_wait).
-static void multi_abort(dmg_multi *m)
+// A band has failed, or a wait has run out.  From a band's thread: only the flag -- the other bands' waits poll it and return.
+static void multi_mark_dead(dmg_multi *m) { m->dead.store(true); }
+// Once every band thread has returned (band_team::after_fail): abort the local communicators, so that receives still queued
+// on the streams end instead of waiting for a peer that will never send (ncclCommAbort tears the communicator's kernels
+// down).  The bands of other processes notice through their own timed waits (multi_wait).
+static void multi_abort_comms(dmg_multi *m)
 {
-    bool was = false;
-    if (!m->dead.compare_exchange_strong(was, true)) return;
+    m->dead.store(true);
     for (ncclComm_t &c : m->comm)
         if (c) { (void)ncclCommAbort(c); c = nullptr; }
 }
 
-// wait for band i's streams.  With RCCL a peer that has died leaves a receive kernel spinning forever, so the wait polls,
-// watches the communicator's asynchronous error state, and gives up after timeout_ms (DMG_MULTI_TIMEOUT_MS): it aborts
-// the communicators and returns an error instead of hanging the caller.
-static int multi_wait(dmg_multi *m, int i)
+// Host-side wait for band i: until its exchange number `target` has completed (target > 0), or until its stream is idle
+// (target == 0).  With RCCL a peer that has died leaves a receive kernel spinning forever, and the store transport's landing
+// kernels give up by themselves and say so in a host-mapped word: the wait polls, watches both, and gives up when NO PROGRESS
+// has been made for timeout_ms (DMG_MULTI_TIMEOUT_MS) -- progress being a newly completed exchange of this band (band_beat),
+// not wall time: a long queue of asynchronous work (dmg_multi_climate_steps: 500 000 steps) is not a failure.
+static int multi_wait_for(dmg_multi *m, int i, long long target)
 {
     dmg_ctx *c = m->ctx_of(i);
     DMG_HIP(hipSetDevice(c->device));
-    const bool rccl = (m->transport == DMG_MULTI_RCCL || m->transport == DMG_MULTI_RCCL_LOOPBACK) && !m->comm.empty();
-    if (!rccl || m->dead.load()) { DMG_HIP(hipStreamSynchronize(c->stream)); return DMG_OK; }
-    const auto t0 = std::chrono::steady_clock::now();
-    ncclComm_t comm = m->comm[m->transport == DMG_MULTI_RCCL_LOOPBACK ? 0 : i];
+    band_beat &b = m->beat[i];
+    const bool watched = (m->uses_rccl_data() && !m->comm.empty()) || m->transport == DMG_MULTI_STORE;
+    if (!watched && target == 0) { DMG_HIP(hipStreamSynchronize(c->stream)); return DMG_OK; }
+    auto t0 = std::chrono::steady_clock::now();
+    ncclComm_t comm = m->comm.empty() ? nullptr : m->comm[m->transport == DMG_MULTI_RCCL_LOOPBACK ? 0 : i];
     for (long long spin = 0;; spin++) {
-        const hipError_t q = hipStreamQuery(c->stream);
-        if (q == hipSuccess) return DMG_OK;
-        if (q != hipErrorNotReady) return dmg_fail(DMG_EHIP, "band %d: stream failed: %s", m->first + i, hipGetErrorString(q));
+        while (b.seen < b.issued) {                          // exchanges complete in issue order per stream
+            const hipError_t q = hipEventQuery(b.ring[(b.seen + 1) % band_beat::RING]);
+            if (q == hipErrorNotReady) break;
+            if (q != hipSuccess) return dmg_fail(DMG_EHIP, "band %d: an exchange failed: %s", m->first + i, hipGetErrorString(q));
+            b.seen++;
+            t0 = std::chrono::steady_clock::now();
+        }
+        if (target > 0) { if (b.seen >= target) return DMG_OK; }
+        else {
+            const hipError_t q = hipStreamQuery(c->stream);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady) return dmg_fail(DMG_EHIP, "band %d: stream failed: %s", m->first + i, hipGetErrorString(q));
+        }
+        if (m->dead.load()) return dmg_fail(DMG_ESTATE, "stopped: this dmg_multi has lost a band");
         if ((spin & 63) == 63) {
+            if (m->transport == DMG_MULTI_STORE && (int)m->store.size() > i && m->store[i].err_host && *(volatile int *)m->store[i].err_host) {
+                multi_mark_dead(m);
+                return dmg_fail(DMG_EHIP, "band %d: a neighbour's rows did not arrive within %d ms (store transport; the neighbour band has "
+                                          "probably failed)", m->first + i, m->timeout_ms);
+            }
             ncclResult_t async = ncclSuccess;
-            if (comm && ncclCommGetAsyncError(comm, &async) == ncclSuccess && async != ncclSuccess && async != ncclInProgress) {
-                multi_abort(m);
+            if (watched && m->uses_rccl_data() && comm && ncclCommGetAsyncError(comm, &async) == ncclSuccess && async != ncclSuccess && async != ncclInProgress) {
+                multi_mark_dead(m);
                 return dmg_fail(DMG_EHIP, "band %d: RCCL reports %s; communicators aborted", m->first + i, ncclGetErrorString(async));
             }
             const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
-            if (ms > m->timeout_ms) {
-                multi_abort(m);
+            if (watched && ms > m->timeout_ms) {
+                multi_mark_dead(m);
                 return dmg_fail(DMG_EHIP, "band %d: no progress for %d ms (a neighbour band has probably failed); communicators aborted "
                                           "(DMG_MULTI_TIMEOUT_MS)", m->first + i, m->timeout_ms);
             }
@@ -229,10 +320,30 @@ static int multi_wait(dmg_multi *m, int i)
         if (spin > 2000) std::this_thread::sleep_for(std::chrono::microseconds(20));
         else std::this_thread::yield();
     }
+    if (m->transport == DMG_MULTI_STORE && (int)m->store.size() > i && m->store[i].err_host && *(volatile int *)m->store[i].err_host) {
+        multi_mark_dead(m);
+        return dmg_fail(DMG_EHIP, "band %d: a neighbour's rows did not arrive within %d ms (store transport; the neighbour band has probably "
+                                  "failed)", m->first + i, m->timeout_ms);
+    }
+    return DMG_OK;
+}
+static int multi_wait(dmg_multi *m, int i) { return multi_wait_for(m, i, 0); }
+
+// one more exchange of band i has been queued on `st`: its event goes into the ring.  The ring never holds two records of one
+// slot in flight -- a host thread more than RING exchanges ahead of its GPU waits here (with the same watchdog) -- so every
+// slot between `seen` and `issued` belongs to exactly one exchange and multi_wait_for can tell progress from a hang
+static int band_beat_record(dmg_multi *m, int i, hipStream_t st)
+{
+    band_beat &b = m->beat[i];
+    const long long q = b.issued + 1;
+    if (q > band_beat::RING) { int rc = multi_wait_for(m, i, q - band_beat::RING); if (rc) return rc; }
+    hipEvent_t &e = b.ring[q % band_beat::RING];
+    if (!e) DMG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    DMG_HIP(hipEventRecord(e, st));
+    b.issued = q;
+    return DMG_OK;
 }
 
-// ---- one halo exchange of `field` (rows deep) as seen by local band i; every band thread calls it ----
-// `on`: the stream that carries it (default: the band's own)
 // experiments: one wave that holds its stream for `ticks` of the 100 MHz clock (DMG_MULTI_FAKE_LINK_US)
 __global__ void k_multi_fake_link(unsigned long long ticks)
 {
@@ -240,13 +351,160 @@ __global__ void k_multi_fake_link(unsigned long long ticks)
     while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
 }
 
+// ---- store transport: the two kernels ----
+// push: `n` bytes from my rows into the neighbour's landing slot, then -- when every block's stores have reached the
+// neighbour's memory -- the sequence number into its flag word.  dst and flag are peer-mapped (or IPC-mapped) pointers into
+// another GPU's memory: the stores travel over xGMI as posted writes.
+__global__ __launch_bounds__(256) void k_store_push(const unsigned char *__restrict__ src, unsigned char *__restrict__ dst, size_t n,
+                                                    unsigned *flag, unsigned seq, unsigned *counter)
+{
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (size_t)gridDim.x * blockDim.x;
+    if ((((size_t)src | (size_t)dst | n) & 15) == 0) {
+        const uint4 *s4 = (const uint4 *)src; uint4 *d4 = (uint4 *)dst;
+        for (size_t k = tid; k < n / 16; k += nthr) d4[k] = s4[k];
+    } else {
+        const unsigned *s1 = (const unsigned *)src; unsigned *d1 = (unsigned *)dst;      // (rows are whole floats)
+        for (size_t k = tid; k < n / 4; k += nthr) d1[k] = s1[k];
+    }
+    __threadfence_system();                                  // my stores are visible to the neighbour's GPU before ...
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned done = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1;
+        if (done == gridDim.x) {                             // ... the last block to finish publishes the slab
+            __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence_system();
+            __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+// land: wait until the neighbour's slab number `seq` is in the slot, then move it into the ghost rows.  Every block polls the
+// flag by itself (one lane, with s_sleep between reads) and gives up after `ticks` of the 100 MHz clock: it then raises the
+// band's error word and copies nothing -- every wave reaches its end whatever the neighbour does.
+__global__ __launch_bounds__(256) void k_store_land(const unsigned *flag, unsigned seq, const unsigned char *__restrict__ src,
+                                                    unsigned char *__restrict__ dst, size_t n, unsigned long long ticks, int *err)
+{
+    __shared__ int ok;
+    if (threadIdx.x == 0) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        int good = 1;
+        while ((int)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
+            if (__builtin_amdgcn_s_memrealtime() - t0 > ticks) { good = 0; break; }
+            __builtin_amdgcn_s_sleep(32);
+        }
+        if (!good) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        ok = good;
+    }
+    __syncthreads();
+    if (!ok) return;
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);                 // (system scope: what the neighbour stored, not what a cache remembers)
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (size_t)gridDim.x * blockDim.x;
+    if ((((size_t)src | (size_t)dst | n) & 15) == 0) {
+        const uint4 *s4 = (const uint4 *)src; uint4 *d4 = (uint4 *)dst;
+        for (size_t k = tid; k < n / 16; k += nthr) d4[k] = s4[k];
+    } else {
+        const unsigned *s1 = (const unsigned *)src; unsigned *d1 = (unsigned *)dst;
+        for (size_t k = tid; k < n / 4; k += nthr) d1[k] = s1[k];
+    }
+}
+
+static void store_free(dmg_multi *m)
+{
+    for (size_t i = 0; i < m->store.size(); i++) {
+        store_band &sb = m->store[i];
+        if (m->ctx_of((int)i)) (void)hipSetDevice(m->ctx_of((int)i)->device);
+        for (int s = 0; s < 2; s++) {
+            if (sb.ipc_land[s]) (void)hipIpcCloseMemHandle(sb.ipc_land[s]);
+            if (sb.ipc_flag[s]) (void)hipIpcCloseMemHandle(sb.ipc_flag[s]);
+        }
+        if (sb.land_base) (void)hipFree(sb.land_base);
+        if (sb.flag_base) (void)hipFree(sb.flag_base);
+        if (sb.counters) (void)hipFree(sb.counters);
+        if (sb.err_host) (void)hipHostFree(sb.err_host);
+    }
+    m->store.clear();
+}
+
+// landing slots, flags, counters and the error word of local band i (on its device)
+static int store_alloc(dmg_multi *m, int i)
+{
+    store_band &sb = m->store[i];
+    DMG_HIP(hipSetDevice(m->ctx_of(i)->device));
+    if (hipMalloc((void **)&sb.land_base, 4 * m->slot_bytes) != hipSuccess)
+        return dmg_fail(DMG_ENOMEM, "store transport: hipMalloc of the landing slots (%zu bytes) failed", 4 * m->slot_bytes);
+    // the flag words are written by another GPU while a kernel of this one polls them: fine-grained, uncached device memory
+    if (hipExtMallocWithFlags((void **)&sb.flag_base, 4096, hipDeviceMallocUncached) != hipSuccess) {
+        (void)hipGetLastError();
+        if (hipExtMallocWithFlags((void **)&sb.flag_base, 4096, hipDeviceMallocFinegrained) != hipSuccess)
+            return dmg_fail(DMG_ENOMEM, "store transport: no fine-grained device memory for the flag words");
+    }
+    DMG_HIP(hipMemset(sb.flag_base, 0, 4096));
+    DMG_HIP(hipMalloc((void **)&sb.counters, 256));
+    DMG_HIP(hipMemset(sb.counters, 0, 256));
+    DMG_HIP(hipHostMalloc((void **)&sb.err_host, sizeof(int), hipHostMallocMapped));
+    *sb.err_host = 0;
+    DMG_HIP(hipHostGetDevicePointer((void **)&sb.err_dev, sb.err_host, 0));
+    for (int s = 0; s < 2; s++) {
+        sb.side[s].land = sb.land_base + (size_t)s * 2 * m->slot_bytes;
+        sb.side[s].flag = sb.flag_base + s * 64;
+        sb.side[s].counter = sb.counters + s * 16;
+    }
+    return DMG_OK;
+}
+
+// one process: the neighbours' slots and flags are plain pointers (peer access is enabled for bands on distinct GPUs)
+static int store_connect_local(dmg_multi *m)
+{
+    for (int i = 0; i < m->n; i++)
+        for (int s = 0; s < 2; s++) {
+            const int j = s == DMG_SIDE_SOUTH ? i - 1 : i + 1;
+            if (j < 0 || j >= m->n) continue;
+            m->store[i].side[s].r_land = m->store[j].side[s ^ 1].land;
+            m->store[i].side[s].r_flag = m->store[j].side[s ^ 1].flag;
+        }
+    m->store_connected = true;
+    return DMG_OK;
+}
+
+static int store_make_blob(dmg_multi *m, store_blob *b)
+{
+    memset(b, 0, sizeof *b);
+    DMG_HIP(hipSetDevice(m->ctx[0]->device));
+    DMG_HIP(hipIpcGetMemHandle(&b->land, m->store[0].land_base));
+    DMG_HIP(hipIpcGetMemHandle(&b->flag, m->store[0].flag_base));
+    b->slot_bytes = m->slot_bytes; b->rank = m->first; b->device = m->ctx[0]->device;
+    return DMG_OK;
+}
+
+// one process per GPU: map the two neighbours' landing slots and flags from the blobs of all ranks
+static int store_connect_rank(dmg_multi *m, const store_blob *all)
+{
+    DMG_HIP(hipSetDevice(m->ctx[0]->device));
+    store_band &sb = m->store[0];
+    for (int s = 0; s < 2; s++) {
+        const int j = s == DMG_SIDE_SOUTH ? m->first - 1 : m->first + 1;
+        if (j < 0 || j >= m->world) continue;
+        const store_blob &nb = all[j];
+        if (nb.rank != j || nb.slot_bytes != m->slot_bytes)
+            return dmg_fail(DMG_EINVAL, "store transport: rank %d's blob does not match (rank %d, slots of %llu bytes, mine %zu)", j, nb.rank,
+                            nb.slot_bytes, m->slot_bytes);
+        DMG_HIP(hipIpcOpenMemHandle(&sb.ipc_land[s], nb.land, hipIpcMemLazyEnablePeerAccess));
+        DMG_HIP(hipIpcOpenMemHandle(&sb.ipc_flag[s], nb.flag, hipIpcMemLazyEnablePeerAccess));
+        sb.side[s].r_land = (unsigned char *)sb.ipc_land[s] + (size_t)(s ^ 1) * 2 * m->slot_bytes;
+        sb.side[s].r_flag = (unsigned *)sb.ipc_flag[s] + (s ^ 1) * 64;
+    }
+    m->store_connected = true;
+    return DMG_OK;
+}
+
+// ---- one halo exchange of `field` (rows deep) as seen by local band i; every band thread calls it ----
+// `on`: the stream that carries it (default: the band's own)
 static int band_exchange(dmg_multi *m, int i, int field, int rows, int buffer = -1, hipStream_t on = nullptr)
 {
     dmg_ctx *c = m->ctx_of(i);
     const int g = m->first + i;
     MTRACE("band %d: exchange field %d rows %d transport %d", g, field, rows, m->transport);
     if (m->dead.load()) return dmg_fail(DMG_ESTATE, "this dmg_multi has lost a band: destroy it");
-    if (g == m->fail_band && ++m->n_band_exchanges[i] == m->fail_at)
+    if (g == m->fail_band && (m->fail_order < 0 || m->fail_order == m->order) && ++m->n_band_exchanges[i] == m->fail_at)
         return dmg_fail(DMG_EHIP, "band %d: failure injected in front of exchange %lld (DMG_MULTI_FAIL)", g, m->fail_at);
     DMG_HIP(hipSetDevice(c->device));
     hipStream_t st = on ? on : c->stream;
@@ -309,6 +567,50 @@ static int band_exchange(dmg_multi *m, int i, int field, int rows, int buffer = 
                 return dmg_fail(DMG_EHIP, "RCCL loopback send/recv failed: %s", ncclGetErrorString(first != ncclSuccess ? first : closed));
         }
         TEAM_BARRIER(m);
+    } else if (m->transport == DMG_MULTI_STORE) {
+        // direct stores: my edge rows into the neighbours' landing slots (push), theirs from my slots into my ghost rows (land).
+        // A slab larger than a slot (the advect halo of a fast ocean) travels in pieces; a piece is pushed only after the piece
+        // before it has landed here, which is what keeps a sender from overwriting a slot its neighbour has not emptied.
+        if (!m->store_connected) return dmg_fail(DMG_ESTATE, "store transport: dmg_multi_store_connect has not been called");
+        store_band &sb = m->store[i];
+        void *send[2] = { nullptr, nullptr }, *recv[2] = { nullptr, nullptr }; size_t bytes[2] = { 0, 0 };
+        for (int side = 0; side < 2; side++) {
+            const int peer = side == DMG_SIDE_SOUTH ? g - 1 : g + 1;
+            if (peer < 0 || peer >= m->world) continue;
+            if ((rc = slab(i, side, &send[side], &recv[side], &bytes[side]))) return rc;
+        }
+        // (every boundary of the job carries the same number of bytes, so every band walks the same number of pieces -- the
+        // barriers below need that; a band at the end of the row has one side only)
+        const unsigned long long ticks = (unsigned long long)m->timeout_ms * 100000ull;
+        const size_t total = (size_t)rows * m->grid.W * (m->cl.empty() && (field == DMG_F_V || field == DMG_F_VADVECT) ? 8 : 4);
+        for (int side = 0; side < 2; side++)
+            if (bytes[side] && bytes[side] != total) return dmg_fail(DMG_EINVAL, "store transport: a slab of %zu bytes where %zu were expected", bytes[side], total);
+        for (size_t off = 0; off < total; off += m->slot_bytes) {
+            const size_t piece = std::min(m->slot_bytes, total - off);
+            for (int side = 0; side < 2; side++) {
+                if (!bytes[side]) continue;
+                store_side &ss = sb.side[side];
+                const unsigned q = ++ss.seq;
+                const unsigned blocks = (unsigned)std::min<size_t>(128, (piece + 65535) / 65536 * 4);
+                hipLaunchKernelGGL(k_store_push, dim3(blocks), dim3(256), 0, st, (const unsigned char *)send[side] + off,
+                                   ss.r_land + (size_t)(q & 1) * m->slot_bytes, piece, ss.r_flag, q, ss.counter);
+                DMG_HIP(hipGetLastError());
+                if (i == 0) m->exchange_bytes += 2 * (long long)piece;
+            }
+            // bands of one process that share a GPU: nobody's landing kernel is queued before everybody's push is -- a landing
+            // kernel polls for a push that, on a shared hardware queue, could otherwise sit behind it
+            if (m->same_device) TEAM_BARRIER(m);
+            for (int side = 0; side < 2; side++) {
+                if (!bytes[side]) continue;
+                store_side &ss = sb.side[side];
+                const unsigned q = ss.seq;
+                const unsigned blocks = (unsigned)std::min<size_t>(64, (piece + 65535) / 65536 * 2);
+                hipLaunchKernelGGL(k_store_land, dim3(blocks), dim3(256), 0, st, ss.flag, q, ss.land + (size_t)(q & 1) * m->slot_bytes,
+                                   (unsigned char *)recv[side] + off, piece, ticks, sb.err_dev);
+                DMG_HIP(hipGetLastError());
+            }
+            if (m->same_device) TEAM_BARRIER(m);
+        }
     } else {
         // peer copies: I pull my ghost rows from the neighbours' owned rows on MY stream, once they have finished the
         // block that produces them; they continue once I have read their rows
@@ -335,6 +637,7 @@ static int band_exchange(dmg_multi *m, int i, int field, int rows, int buffer = 
         m->ev_used.push_back(ev);
         m->n_exchanges++;
     }
+    if (m->transport != DMG_MULTI_PEER && m->world > 1 && (rc = band_beat_record(m, i, st))) return rc;
     MTRACE("band %d: exchange done", g);
     return DMG_OK;
 }
@@ -348,7 +651,7 @@ static int band_block_overlapped(dmg_multi *m, int i, int field, int rows, int n
     dmg_ctx *c = m->ctx_of(i);
     int rc;
     DMG_HIP(hipSetDevice(c->device));
-    hipStream_t cs = m->comm_stream[m->shared_ctx ? 0 : i];
+    hipStream_t cs = m->cs_of(i);
     if ((rc = ocean_jacobi_sweeps_begin(o, n, cs))) return rc;             // launches 1 .. m-1 (own stream), edge units of launch m (second stream)
     if (!o->pending.active) {
         // the launch was issued whole on the own stream (its shape is still being tuned, or it has no blocked form): the
@@ -378,7 +681,9 @@ static int band_block_overlapped(dmg_multi *m, int i, int field, int rows, int n
 static int band_allreduce_max(dmg_multi *m, int i, int *value, std::vector<int> &scratch)
 {
     dmg_ctx *c = m->ctx_of(i);
-    if (m->transport == DMG_MULTI_RCCL) {
+    if (m->n < m->world && m->comm.empty())
+        return dmg_fail(DMG_ESTATE, "this handle was created without an RCCL id: the advect reach cannot be all-reduced (dmg_multi_step needs one)");
+    if (m->transport == DMG_MULTI_RCCL || m->n < m->world) {
         DMG_HIP(hipSetDevice(c->device));
         DMG_HIP(hipMemcpyAsync(m->d_red[i], value, sizeof(int), hipMemcpyHostToDevice, c->stream));
         DMG_NCCL(ncclAllReduce(m->d_red[i], m->d_red[i], 1, ncclInt, ncclMax, m->comm[i], c->stream));
@@ -437,10 +742,16 @@ static int band_step(dmg_multi *m, int i, int n_outer, std::vector<int> &scratch
         int reach = 0;
         if ((rc = dmg_ocean_advect_reach(o, &reach))) return rc;
         if ((rc = band_allreduce_max(m, i, &reach, scratch))) return rc;
-        if (reach > g)
-            return dmg_fail(DMG_EINVAL, "advect reaches %d rows but the bands keep %d ghost rows: create the dmg_multi with "
-                                        "ghost >= %d (every band stopped before the step, nothing was changed)", reach, g, reach);
-        if ((rc = band_exchange(m, i, DMG_F_V, g))) return rc;
+        if (reach > g) {
+            // currents have developed (|v| = 10 at H = 8192 reaches ~96 rows, :294-299): this advect gathers from a copy of v
+            // that is `reach` rows deep (dmg_ocean_advect_prepare; grown on demand), whose ghost rows travel like any other
+            // field's.  Still all or nobody: the reach is the same on every band, and so is the answer to "does it fit"
+            if (reach > m->grid.H / m->world)
+                return dmg_fail(DMG_EINVAL, "advect reaches %d rows but a band owns only %d: a halo must come from ONE neighbour; use "
+                                            "fewer bands (every band stopped before the step, nothing was changed)", reach, m->grid.H / m->world);
+            if ((rc = dmg_ocean_advect_prepare(o, reach))) return rc;
+            if ((rc = band_exchange(m, i, DMG_F_VADVECT, reach))) return rc;
+        } else if ((rc = band_exchange(m, i, DMG_F_V, g))) return rc;
         if ((rc = dmg_ocean_advect(o))) return rc;                                   // :158
         for (int done = 0; done < m->prm.diffusion_iters;) {                          // :160, in blocks of `ghost` sweeps
             const int n = std::min(g, m->prm.diffusion_iters - done);
@@ -466,14 +777,22 @@ static void multi_free(dmg_multi *m)
     for (auto &p : m->ev_free) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (size_t i = 0; i < m->d_red.size(); i++)
         if (m->d_red[i] && m->ctx_of((int)i)) { (void)hipSetDevice(m->ctx_of((int)i)->device); (void)hipFree(m->d_red[i]); }
+    for (size_t i = 0; i < m->comm_stream.size(); i++)       // (nothing of this handle may still be running when its memory goes)
+        if (m->comm_stream[i] && m->ctx_of((int)i)) { (void)hipSetDevice(m->ctx_of((int)i)->device); (void)hipStreamSynchronize(m->comm_stream[i]); }
+    for (size_t i = 0; i < m->ctx.size(); i++)
+        if (m->ctx[i]) { (void)hipSetDevice(m->ctx[i]->device); (void)hipStreamSynchronize(m->ctx[i]->stream); }
     for (dmg_ocean *o : m->oc) if (o) dmg_ocean_destroy(o);
     for (dmg_climate *k : m->cl) if (k) dmg_climate_destroy(k);
+    store_free(m);
+    for (band_beat &b : m->beat) for (hipEvent_t e : b.ring) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : m->ev_done) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : m->ev_copied) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : m->ev_edge) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : m->ev_xchg) if (e) (void)hipEventDestroy(e);
     for (size_t i = 0; i < m->comm_stream.size(); i++)
-        if (m->comm_stream[i]) { (void)hipSetDevice(m->ctx_of((int)i)->device); (void)hipStreamSynchronize(m->comm_stream[i]); (void)hipStreamDestroy(m->comm_stream[i]); }
+        if (m->comm_stream[i] && (m->comm_owner.empty() || m->comm_owner[i] == (int)i)) {
+            (void)hipSetDevice(m->ctx_of((int)i)->device); (void)hipStreamSynchronize(m->comm_stream[i]); (void)hipStreamDestroy(m->comm_stream[i]);
+        }
     for (ncclComm_t c : m->comm) if (c) (void)ncclCommDestroy(c);
     for (dmg_ctx *c : m->ctx) if (c) dmg_destroy(c);
     delete m;
@@ -487,8 +806,27 @@ static int multi_common(dmg_multi *m, const dmg_grid *grid, const dmg_ocean_para
     m->order = (flags & DMG_MULTI_OVERLAP_LAST_LAUNCH) ? DMG_MULTI_OVERLAP_LAST_LAUNCH : DMG_MULTI_EXCHANGE_THEN_SWEEP;
     if (const char *e = getenv("DMG_MULTI_TIMEOUT_MS")) { const int v = atoi(e); if (v > 0) m->timeout_ms = v; }
     if (const char *e = getenv("DMG_MULTI_FAIL")) {          // tests: "<band>:<n>"
-        int b = -1; long long k = 0;
-        if (sscanf(e, "%d:%lld", &b, &k) == 2 && b >= 0 && k > 0) { m->fail_band = b; m->fail_at = k; }
+        int b = -1, ord = -1; long long k = 0;
+        const int got = sscanf(e, "%d:%lld:%d", &b, &k, &ord);
+        if (got >= 2 && b >= 0 && k > 0) { m->fail_band = b; m->fail_at = k; m->fail_order = got == 3 ? ord : -1; }
+    }
+    if (m->order == DMG_MULTI_OVERLAP_LAST_LAUNCH) {
+        // The overlapped order runs two streams per band that wait on each other's events once per block.  HIP maps a process's
+        // streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), read when the runtime initialises; with four the pattern is
+        // pathological on this runtime (18 ms instead of 11 for a 2 x 1024-row rehearsal, profiles/r03_overlap_hwqueues.log).
+        // The library does not touch its host's environment: the host sets the variable before its first HIP call -- or calls
+        // dmg_runtime_init() there -- and a handle that finds fewer than eight queues asked for falls back to exchange-then-sweep
+        // and says so (dmg_multi_get_stats: warnings & DMG_MULTI_WARN_HWQ_FALLBACK; stderr once).
+        const char *q = getenv("GPU_MAX_HW_QUEUES");
+        if (!q || atoi(q) < 8) {
+            m->order = DMG_MULTI_EXCHANGE_THEN_SWEEP;
+            m->warnings |= DMG_MULTI_WARN_HWQ_FALLBACK;
+            static std::atomic<bool> said{false};
+            bool was = false;
+            if (said.compare_exchange_strong(was, true))
+                fprintf(stderr, "demiurge_hip: DMG_MULTI_OVERLAP_LAST_LAUNCH needs GPU_MAX_HW_QUEUES >= 8 in the environment before HIP initialises "
+                                "(dmg_runtime_init); it is %s: using exchange-then-sweep\n", q ? q : "unset");
+        }
     }
     if (const char *e = getenv("DMG_MULTI_FAKE_LINK_US")) {
         const int us = atoi(e);
@@ -502,10 +840,18 @@ static int multi_streams(dmg_multi *m)
 {
     const int ns = m->shared_ctx ? 1 : m->n;
     m->comm_stream.assign((size_t)ns, nullptr); m->ev_edge.assign((size_t)m->n, nullptr); m->ev_xchg.assign((size_t)m->n, nullptr);
+    m->comm_owner.assign((size_t)m->n, 0);
     m->n_band_exchanges.assign((size_t)m->n, 0);
+    m->beat.resize((size_t)m->n);
+    static const bool share = [] { const char *e = getenv("DMG_MULTI_SHARE_COMM_STREAM"); return !e || atoi(e) != 0; }();   // experiments: 0 = one per band
     for (int i = 0; i < m->n; i++) {
         DMG_HIP(hipSetDevice(m->ctx_of(i)->device));
-        if (i < ns) {
+        int owner = i;
+        if (share && !m->shared_ctx)
+            for (int j = 0; j < i; j++) if (m->ctx[j]->device == m->ctx[i]->device) { owner = j; break; }
+        m->comm_owner[i] = m->shared_ctx ? 0 : owner;
+        if (i < ns && owner != i) m->comm_stream[i] = m->comm_stream[owner];
+        else if (i < ns) {
             int lo = 0, hi = 0;
             DMG_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));  // (hi = greatest priority, numerically lowest)
             static const bool normal = [] { const char *e = getenv("DMG_MULTI_COMM_PRIORITY"); return e && atoi(e) == 0; }();   // experiments
@@ -517,7 +863,8 @@ static int multi_streams(dmg_multi *m)
         DMG_HIP(hipEventCreateWithFlags(&m->ev_edge[i], hipEventDisableTiming));
         DMG_HIP(hipEventCreateWithFlags(&m->ev_xchg[i], hipEventDisableTiming | (evf >= 2 ? hipEventReleaseToDevice : 0)));
     }
-    m->team.on_fail = [m](int) { multi_abort(m); };
+    m->team.on_fail = [m](int) { multi_mark_dead(m); };
+    m->team.after_fail = [m] { multi_abort_comms(m); };
     return DMG_OK;
 }
 
@@ -551,12 +898,27 @@ static int multi_create_local(int n_bands, const int *device_ids, const dmg_grid
                                     "DMG_MULTI_PEER or DMG_MULTI_RCCL_LOOPBACK for several bands on one GPU");
     if (transport == DMG_MULTI_RCCL_LOOPBACK)
         for (int i = 1; i < n_bands; i++) DMG_CHECK_ARG(device_ids[i] == device_ids[0]);
+    DMG_CHECK_ARG(transport == DMG_MULTI_RCCL || transport == DMG_MULTI_PEER || transport == DMG_MULTI_RCCL_LOOPBACK || transport == DMG_MULTI_STORE);
     std::unique_ptr<dmg_multi, void (*)(dmg_multi *)> m(new (std::nothrow) dmg_multi, multi_free);
     if (!m) return dmg_fail(DMG_ENOMEM, "out of host memory");
     int rc = multi_common(m.get(), grid, params, ghost, flags);
     if (rc) return rc;
     m->world = n_bands; m->first = 0; m->n = n_bands; m->transport = transport;
     m->shared_ctx = transport == DMG_MULTI_RCCL_LOOPBACK;
+    for (int i = 0; i + 1 < n_bands; i++) m->same_device = m->same_device || device_ids[i] == device_ids[i + 1];
+    {
+        // More than four bands of one process on ONE GPU in the overlapped order (a rehearsal of eight devices on one): the
+        // device then runs 9 .. 16 streams that wait on each other once per block, and the time of a solve grows with the number
+        // of hardware queues they are spread over -- 8 bands x 160 sweeps: 11 ms with GPU_MAX_HW_QUEUES=4, 47 ms with 8, 57 ms
+        // with 16, 9 ms in the plain order (profiles/r04_peer_stall.log): the queues outnumber what the GPU's scheduler keeps
+        // resident and it time-slices them.  A real device holds two streams.  Such a handle runs exchange-then-sweep and says so.
+        int most = 0;
+        for (int i = 0; i < n_bands; i++) { int c = 0; for (int j = 0; j < n_bands; j++) c += device_ids[j] == device_ids[i]; most = std::max(most, c); }
+        if (most > 4 && m->order == DMG_MULTI_OVERLAP_LAST_LAUNCH && transport != DMG_MULTI_RCCL_LOOPBACK && !getenv("DMG_MULTI_FORCE_OVERLAP")) {
+            m->order = DMG_MULTI_EXCHANGE_THEN_SWEEP;
+            m->warnings |= DMG_MULTI_WARN_SHARED_GPU_FALLBACK;
+        }
+    }
     m->ctx.assign(n_bands, nullptr); m->d_red.assign(n_bands, nullptr);
     m->ev_done.assign(n_bands, nullptr); m->ev_copied.assign(n_bands, nullptr);
     for (int i = 0; i < n_bands; i++) {
@@ -568,7 +930,7 @@ static int multi_create_local(int n_bands, const int *device_ids, const dmg_grid
         DMG_HIP(hipEventCreateWithFlags(&m->ev_done[i], hipEventDisableTiming));
         DMG_HIP(hipEventCreateWithFlags(&m->ev_copied[i], hipEventDisableTiming));
     }
-    if (transport == DMG_MULTI_PEER)                         // let the copy engines reach the neighbour's memory directly
+    if (transport == DMG_MULTI_PEER || transport == DMG_MULTI_STORE)     // let copy engines / kernels reach the neighbour's memory directly
         for (int i = 0; i + 1 < n_bands; i++) {
             const int a = device_ids[i], b = device_ids[i + 1];
             if (a == b) continue;
@@ -578,8 +940,15 @@ static int multi_create_local(int n_bands, const int *device_ids, const dmg_grid
                 (void)hipSetDevice(a); (void)hipDeviceEnablePeerAccess(b, 0);
                 (void)hipSetDevice(b); (void)hipDeviceEnablePeerAccess(a, 0);
                 (void)hipGetLastError();                     // "already enabled" is fine
-            }
+            } else if (transport == DMG_MULTI_STORE)
+                return dmg_fail(DMG_EHIP, "store transport: device %d cannot access device %d's memory", a, b);
         }
+    if (transport == DMG_MULTI_STORE && n_bands > 1) {
+        m->store.resize((size_t)n_bands);
+        m->slot_bytes = ((size_t)ghost * grid->W * 8 + 255) & ~(size_t)255;     // (v is the widest field: 8 bytes per cell)
+        for (int i = 0; i < n_bands; i++) if ((rc = store_alloc(m.get(), i))) return rc;
+        if ((rc = store_connect_local(m.get()))) return rc;
+    }
     if (transport == DMG_MULTI_RCCL) {
         m->comm.assign(n_bands, nullptr);
         DMG_NCCL(ncclCommInitAll(m->comm.data(), n_bands, device_ids));
@@ -599,24 +968,53 @@ static int multi_create_rank(int rank, int n_ranks, const void *id128, int devic
                              int ghost, int flags, const band_factory &make_band, dmg_multi **out)
 {
     DMG_CHECK_ARG(out != nullptr && n_ranks >= 1 && rank >= 0 && rank < n_ranks && grid != nullptr && ghost >= 1);
-    DMG_CHECK_ARG(n_ranks == 1 || id128 != nullptr);
     *out = nullptr;
     std::unique_ptr<dmg_multi, void (*)(dmg_multi *)> m(new (std::nothrow) dmg_multi, multi_free);
     if (!m) return dmg_fail(DMG_ENOMEM, "out of host memory");
     int rc = multi_common(m.get(), grid, params, ghost, flags);
     if (rc) return rc;
-    m->world = n_ranks; m->first = rank; m->n = 1; m->transport = DMG_MULTI_RCCL;
+    int transport = flags & DMG_MULTI_TRANSPORT_MASK;
+    if (transport == DMG_MULTI_AUTO) transport = DMG_MULTI_RCCL;
+    if (transport != DMG_MULTI_RCCL && transport != DMG_MULTI_STORE)
+        return dmg_fail(DMG_EINVAL, "one process per GPU: DMG_MULTI_RCCL or DMG_MULTI_STORE (the peer-copy and loopback transports are one-process forms)");
+    if (n_ranks > 1 && transport == DMG_MULTI_RCCL && id128 == nullptr) return dmg_fail(DMG_EINVAL, "DMG_MULTI_RCCL needs the id of dmg_multi_unique_id");
+    m->world = n_ranks; m->first = rank; m->n = 1; m->transport = transport;
     m->ctx.assign(1, nullptr); m->d_red.assign(1, nullptr);
     m->ev_done.assign(1, nullptr); m->ev_copied.assign(1, nullptr);
     if ((rc = dmg_create(device_id, nullptr, DMG_PRIVATE_STREAM, &m->ctx[0]))) return rc;
     if ((rc = make_band(m.get(), 0, rank, n_ranks))) return rc;
     DMG_HIP(hipSetDevice(device_id));
     DMG_HIP(hipMalloc((void **)&m->d_red[0], sizeof(int)));
-    if (n_ranks > 1) {
+    if (n_ranks > 1 && id128 != nullptr) {
         ncclUniqueId id;
         memcpy(&id, id128, sizeof id);
         m->comm.assign(1, nullptr);
         DMG_NCCL(ncclCommInitRank(&m->comm[0], n_ranks, id, rank));
+    }
+    if (transport == DMG_MULTI_STORE && n_ranks > 1) {
+        // landing slots and flags of this rank; the neighbours map them through hipIpc handles.  With an RCCL communicator the
+        // handles travel by one ncclAllGather here (RCCL stays for set-up and for the reach all-reduce); without one (id128 ==
+        // NULL: a host with its own bootstrap, or two processes on one GPU in the tests) the host all-gathers
+        // dmg_multi_store_blob's bytes itself and hands them to dmg_multi_store_connect
+        m->store.resize(1);
+        m->slot_bytes = ((size_t)ghost * grid->W * 8 + 255) & ~(size_t)255;     // (v is the widest field: 8 bytes per cell)
+        if ((rc = store_alloc(m.get(), 0))) return rc;
+        if (!m->comm.empty()) {
+            store_blob mine;
+            if ((rc = store_make_blob(m.get(), &mine))) return rc;
+            unsigned char *d_all = nullptr;
+            DMG_HIP(hipMalloc((void **)&d_all, sizeof(store_blob) * (size_t)n_ranks));
+            std::vector<store_blob> all((size_t)n_ranks);
+            hipStream_t st = m->ctx[0]->stream;
+            hipError_t e = hipMemcpyAsync(d_all + sizeof(store_blob) * (size_t)rank, &mine, sizeof mine, hipMemcpyHostToDevice, st);
+            ncclResult_t r = e == hipSuccess ? ncclAllGather(d_all + sizeof(store_blob) * (size_t)rank, d_all, sizeof(store_blob), ncclChar, m->comm[0], st) : ncclSuccess;
+            if (e == hipSuccess && r == ncclSuccess) e = hipMemcpyAsync(all.data(), d_all, sizeof(store_blob) * (size_t)n_ranks, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess && r == ncclSuccess) e = hipStreamSynchronize(st);
+            (void)hipFree(d_all);
+            if (r != ncclSuccess) return dmg_fail(DMG_EHIP, "store transport: ncclAllGather of the handles failed: %s", ncclGetErrorString(r));
+            if (e != hipSuccess) return dmg_fail(DMG_EHIP, "store transport: handle exchange failed: %s", hipGetErrorString(e));
+            if ((rc = store_connect_rank(m.get(), all.data()))) return rc;
+        }
     }
     if ((rc = multi_streams(m.get()))) return rc;
     m->team.start(1);
@@ -724,6 +1122,33 @@ int dmg_multi_climate_sync(dmg_multi_climate *h)
 
 void dmg_multi_destroy(dmg_multi *m) { multi_free(m); }
 
+// store transport, one process per GPU, no RCCL communicator (id128 == NULL at creation): the host carries the handles.
+// Every rank: _blob -> all-gather the DMG_MULTI_STORE_BLOB_BYTES bytes of all ranks, in rank order -> _connect.
+int dmg_multi_store_blob(dmg_multi *m, void *blob)
+{
+    DMG_CHECK_ARG(m != nullptr && blob != nullptr);
+    if (m->transport != DMG_MULTI_STORE || m->n != 1 || m->store.empty()) return dmg_fail(DMG_ESTATE, "dmg_multi_store_blob: a DMG_MULTI_STORE rank of a job of several");
+    store_blob b;
+    int rc = store_make_blob(m, &b);
+    if (rc) return rc;
+    memcpy(blob, &b, sizeof b);
+    return DMG_OK;
+}
+
+int dmg_multi_store_connect(dmg_multi *m, const void *blobs, int n_ranks)
+{
+    DMG_CHECK_ARG(m != nullptr && blobs != nullptr && n_ranks == m->world);
+    if (m->transport != DMG_MULTI_STORE || m->n != 1 || m->store.empty()) return dmg_fail(DMG_ESTATE, "dmg_multi_store_connect: a DMG_MULTI_STORE rank of a job of several");
+    if (m->store_connected) return dmg_fail(DMG_ESTATE, "dmg_multi_store_connect: already connected");
+    std::vector<store_blob> all((size_t)n_ranks);
+    memcpy(all.data(), blobs, sizeof(store_blob) * (size_t)n_ranks);
+    return store_connect_rank(m, all.data());
+}
+
+// the climate handles share everything with the ocean's: the same two calls under their names
+int dmg_multi_climate_store_blob(dmg_multi_climate *h, void *blob) { return dmg_multi_store_blob(reinterpret_cast<dmg_multi *>(h), blob); }
+int dmg_multi_climate_store_connect(dmg_multi_climate *h, const void *blobs, int n_ranks) { return dmg_multi_store_connect(reinterpret_cast<dmg_multi *>(h), blobs, n_ranks); }
+
 int dmg_multi_band_count(const dmg_multi *m) { return m ? m->n : 0; }
 
 int dmg_multi_band(dmg_multi *m, int local_index, dmg_ocean **out)
@@ -757,7 +1182,12 @@ int dmg_multi_generate_terrain(dmg_multi *m, const dmg_noise_params *params)
     DMG_CHECK_ARG(params != nullptr);
     MULTI_FOR_BANDS(dmg_ocean_generate_terrain(o, params));
 }
-int dmg_multi_get(dmg_multi *m, float *vx, float *vy, float *pressure, float *divw) { MULTI_FOR_BANDS(dmg_ocean_get(o, vx, vy, pressure, divw)); }
+int dmg_multi_get(dmg_multi *m, float *vx, float *vy, float *pressure, float *divw)
+{
+    // (the watched wait first: dmg_ocean_get synchronises its stream without a deadline)
+    DMG_CHECK_ARG(m != nullptr && (int)m->oc.size() == m->n);
+    return m->team.run([&](int i) -> int { int rc = multi_wait(m, i); return rc ? rc : dmg_ocean_get(m->oc[i], vx, vy, pressure, divw); });
+}
 int dmg_multi_sync(dmg_multi *m) { DMG_CHECK_ARG(m != nullptr); return m->team.run([&](int i) { return multi_wait(m, i); }); }
 
 int dmg_multi_jacobi(dmg_multi *m, int iters, int zero_first)
@@ -791,6 +1221,7 @@ int dmg_multi_get_stats(dmg_multi *m, dmg_multi_stats *s)
     if ((rc = multi_fold_events(m))) return rc;
     memset(s, 0, sizeof *s);
     s->bands_total = m->world; s->bands_local = m->n; s->transport = m->transport; s->order = m->order; s->ghost = m->ghost;
+    s->warnings = m->warnings;
     s->exchanges = m->n_exchanges; s->exchange_ms = m->exchange_ms; s->exchange_bytes = m->exchange_bytes;
     long long l = 0, sw = 0;
     if (!m->oc.empty()) (void)dmg_ocean_counters(m->oc[0], &l, &sw);

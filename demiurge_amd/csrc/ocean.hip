@@ -299,7 +299,7 @@ void dmg_ocean_destroy(dmg_ocean *o)
     (void)hipSetDevice(o->ctx->device);
     (void)hipStreamSynchronize(o->ctx->stream);
     for (void *p : { (void *)o->p[0], (void *)o->p[1], (void *)o->divw, (void *)o->img, (void *)o->code, (void *)o->code8,
-                     (void *)o->v[0], (void *)o->v[1], (void *)o->rowtab, (void *)o->jcoef, (void *)o->jcoefp, (void *)o->jcoef2, (void *)o->rowbad, (void *)o->oob_flag, (void *)o->rowclass, (void *)o->rowclass_n, (void *)o->rowclass32 })
+                     (void *)o->v[0], (void *)o->v[1], (void *)o->rowtab, (void *)o->jcoef, (void *)o->jcoefp, (void *)o->jcoef2, (void *)o->rowbad, (void *)o->oob_flag, (void *)o->rowclass, (void *)o->rowclass_n, (void *)o->rowclass32, (void *)o->vadv })
         if (p) (void)hipFree(p);
     ocean_tb_free_lists(o);
     if (o->ev_fork) (void)hipEventDestroy(o->ev_fork);
@@ -580,6 +580,20 @@ int dmg_ocean_halo(dmg_ocean *o, int field, int side, int rows, void **send, voi
 {
     DMG_CHECK_ARG(o != nullptr && send != nullptr && recv != nullptr && bytes != nullptr);
     DMG_CHECK_ARG(side == DMG_SIDE_SOUTH || side == DMG_SIDE_NORTH);
+    if (field == DMG_F_VADVECT) {
+        // the deeper gather source of the next advect (dmg_ocean_advect_prepare): same shape as the other fields' slabs
+        if (!o->adv_ready) return dmg_fail(DMG_ESTATE, "DMG_F_VADVECT: dmg_ocean_advect_prepare must come first");
+        DMG_CHECK_ARG(rows >= 1 && rows <= o->adv_rows);
+        const size_t row = (size_t)o->grid.W * 2;
+        const int own = o->y1 - o->y0;
+        *send = *recv = nullptr; *bytes = 0;
+        if (side == DMG_SIDE_SOUTH && o->adv_gs) {
+            *send = o->vadv + row * o->adv_gs; *recv = o->vadv + row * (o->adv_gs - rows); *bytes = row * rows * sizeof(float);
+        } else if (side == DMG_SIDE_NORTH && o->adv_gn) {
+            *send = o->vadv + row * (o->adv_gs + own - rows); *recv = o->vadv + row * (o->adv_gs + own); *bytes = row * rows * sizeof(float);
+        }
+        return DMG_OK;
+    }
     DMG_CHECK_ARG(rows >= 1 && rows <= o->ghost);
     float *base; int comps = 1;
     switch (field) {

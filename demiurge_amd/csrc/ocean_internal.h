@@ -71,6 +71,12 @@ struct dmg_ocean {
     hipEvent_t ev_edge = nullptr;  // ... the edge units of the split launch are done (the interior units start behind them: edge first)
     bool edge_wait = false;
     int *oob_flag = nullptr;       // device word: advect out-of-band flag / reduction scratch
+    // advect with a back-trace longer than `ghost` rows (dmg_ocean_advect_prepare): the gather source of this step, v of rows
+    // [y0 - adv_gs, y1 + adv_gn) -- own rows copied from v, the rows beyond them exchanged as field DMG_F_VADVECT
+    float *vadv = nullptr;
+    size_t vadv_cap = 0;           // bytes allocated
+    int adv_rows = 0, adv_gs = 0, adv_gn = 0;
+    bool adv_ready = false;        // prepared for the next dmg_ocean_advect (which clears it)
     float *rowtab = nullptr;       // ROWTAB_FIELDS arrays of L floats
     float *jcoefp = nullptr;       // [L + 32][4] = cx, 1/cx, Beta, 1/Beta of local rows -16 .. L+15, rows beyond the grid mirrored (scalar loads, no mapping)
     float *jcoef = nullptr;        // [L][8] = cx, 1/cx, Beta, 1/Beta, cy, 1/cy, -, -: a row's Jacobi coefficients in one 16-byte load (ocean_jacobi_stream.hip)

@@ -25,6 +25,8 @@ struct pass_args {
     int y_first;                     // grid row of local row 0
     int row_lo;                      // first local row computed by the launch (blockIdx.y = 0)
     int *oob_flag;                   // advect: set to 1 when a departure point needs rows outside the band's storage
+    const float2 *vg;                // advect: the rows the back-trace gathers from (v itself, or the deeper copy of
+    int g_y_first, g_L;              //         dmg_ocean_advect_prepare): g_L rows from grid row g_y_first on
     // pixelsize(st_o).x*.y of the virtual rows y = -1 / y = H: on a non-pole edge offset() leaves st_o.y outside
     // [0,1] (only the texture fetch clamps), so get_velocity()'s d_o is evaluated beyond the grid (:380-381,:392)
     float area_below, area_above;
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(256) void k_advect(pass_args a, float k04)
     cart = rotate3(-arclength, rotdir, cart);                                      // :308
     float lon_n = glsl::atan2(cart.y, cart.x), lat_n = glsl::asin(cart.z);                   // cartesian_to_spheric
     float cu = (lon_n - a.c2) / (a.c3 - a.c2), cv = (lat_n - a.c0) / (a.c1 - a.c0);   // spheric_to_tex
-    float2 nv = fetch_linear2(a.vin, W, a.H, cu, cv, a.y_first, a.L, a.oob_flag);  // :315
+    float2 nv = fetch_linear2(a.vg, W, a.H, cu, cv, a.g_y_first, a.g_L, a.oob_flag);  // :315
     vec3 par_n, yc_n;
     tangent_basis(lon_n, lat_n, &par_n, &yc_n);
     vec3 testv = v3(par_n.x * nv.x + yc_n.x * nv.y, par_n.y * nv.x + yc_n.y * nv.y, par_n.z * nv.x + yc_n.z * nv.y);
@@ -308,6 +310,7 @@ static pass_args make_args(dmg_ocean *o)
     a.c0 = o->grid.coords[0]; a.c1 = o->grid.coords[1]; a.c2 = o->grid.coords[2]; a.c3 = o->grid.coords[3];
     a.scalar_rhs = (o->prm.quirks & DMG_QUIRK_DIFFUSION_SCALAR_RHS) ? 1 : 0;
     a.oob_flag = o->oob_flag;
+    a.vg = a.vin; a.g_y_first = a.y_first; a.g_L = a.L;
     a.l_south_clamp = (!o->topo.spole && o->y0 == 0) ? o->gs : -1;
     a.l_north_clamp = (!o->topo.npole && o->y1 == o->grid.H) ? o->gs + (o->y1 - o->y0) - 1 : -1;
     float dx, dy;
@@ -443,11 +446,48 @@ int dmg_ocean_subdiv(dmg_ocean *o)
     return DMG_OK;
 }
 
+// A back-trace longer than the band's `ghost` rows (|v| = 10 at H = 8192 reaches ~96 rows, OceanCurrents.cpp:294-299): the
+// next dmg_ocean_advect gathers from a copy of v that is `reach` rows deep on each side that has a neighbour.  This call
+// (re)allocates it if needed and copies the owned rows in; the host then refreshes its ghost rows like any other field's
+// (dmg_ocean_halo with DMG_F_VADVECT, rows = reach) and calls dmg_ocean_advect.  Asynchronous on the context's stream.
+int dmg_ocean_advect_prepare(dmg_ocean *o, int reach)
+{
+    int rc = require_terrain(o, "dmg_ocean_advect_prepare");
+    if (rc) return rc;
+    DMG_CHECK_ARG(reach >= 1);
+    const int own = o->y1 - o->y0, W = o->grid.W;
+    if (reach > o->grid.H / o->count)
+        return dmg_fail(DMG_EINVAL, "advect reaches %d rows but a band owns only %d: a ghost slab must come from ONE neighbour "
+                                    "(use fewer bands)", reach, o->grid.H / o->count);
+    o->adv_rows = reach;
+    o->adv_gs = o->rank > 0 ? reach : 0;
+    o->adv_gn = o->rank < o->count - 1 ? reach : 0;
+    const int cap_rows = own + 2 * ((reach + 31) & ~31);   // (grown in steps of 32 rows per side: the reach creeps up as currents develop)
+    const size_t need = (size_t)cap_rows * W * sizeof(float2);
+    if (need > o->vadv_cap) {
+        DMG_HIP(hipStreamSynchronize(o->ctx->stream));     // (the old copy may still be read by a queued advect)
+        if (o->vadv) (void)hipFree(o->vadv);
+        o->vadv = nullptr; o->vadv_cap = 0;
+        if (hipMalloc((void **)&o->vadv, need) != hipSuccess)
+            return dmg_fail(DMG_ENOMEM, "advect halo of %d rows: hipMalloc(%zu) failed", reach, need);
+        o->vadv_cap = need;
+    }
+    DMG_HIP(hipMemcpyAsync(o->vadv + (size_t)o->adv_gs * W * 2, o->v[o->vcur] + (size_t)o->gs * W * 2, (size_t)own * W * sizeof(float2),
+                           hipMemcpyDeviceToDevice, o->ctx->stream));
+    o->adv_ready = true;
+    return DMG_OK;
+}
+
 int dmg_ocean_advect(dmg_ocean *o)
 {
     int rc = require_terrain(o, "dmg_ocean_advect");
     if (rc) return rc;
     pass_args a = make_args(o);
+    const int stored = o->adv_ready ? o->adv_rows : o->ghost;
+    if (o->adv_ready) {                                    // the deeper gather source of dmg_ocean_advect_prepare, this step only
+        a.vg = (const float2 *)o->vadv; a.g_y_first = o->y0 - o->adv_gs; a.g_L = o->adv_gs + (o->y1 - o->y0) + o->adv_gn;
+        o->adv_ready = false;
+    }
     float k04 = powf(0.4f, 1.0f / 24.0f);                  // pow(vec2(0.4),vec2(1.0/24)) (:348), a constant
     if (o->count > 1) DMG_HIP(hipMemsetAsync(o->oob_flag, 0, sizeof(int), o->ctx->stream));
     rc = launch_rows(o, k_advect, a, o->gs, o->gs + (o->y1 - o->y0), k04);
@@ -458,7 +498,8 @@ int dmg_ocean_advect(dmg_ocean *o)
         DMG_HIP(hipStreamSynchronize(o->ctx->stream));
         if (flag)                                          // the result sits in the scratch buffer: v itself is untouched
             return dmg_fail(DMG_EINVAL, "advect: a departure point lies more than %d rows outside the band; create the "
-                                        "ocean with ghost >= dmg_ocean_advect_reach()", o->ghost);
+                                        "ocean with ghost >= dmg_ocean_advect_reach(), or hand it deeper rows through "
+                                        "dmg_ocean_advect_prepare", stored);
     }
     o->vcur ^= 1;                                          // v->swap(v_scratch) (:359)
     return DMG_OK;

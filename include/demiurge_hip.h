@@ -88,12 +88,19 @@ enum { DMG_JACOBI_AUTO = 0, DMG_JACOBI_SINGLE = 1, DMG_JACOBI_BLOCKED = 2 };
 #define DMG_QUIRK_LLVMPIPE_RASTER 2
 
 /* field ids for dmg_ocean_halo */
-enum { DMG_F_PRESSURE = 0, DMG_F_DIVW = 1, DMG_F_TERRAIN = 2, DMG_F_V = 3 /* interleaved (vx,vy), 8 B per cell */ };
+enum { DMG_F_PRESSURE = 0, DMG_F_DIVW = 1, DMG_F_TERRAIN = 2, DMG_F_V = 3 /* interleaved (vx,vy), 8 B per cell */,
+       DMG_F_VADVECT = 4 /* the deeper copy of v that dmg_ocean_advect_prepare sets up for one advect */ };
 enum { DMG_SIDE_SOUTH = 0, DMG_SIDE_NORTH = 1 };   /* south = towards row 0 */
 
 /* ---- library / context ------------------------------------------------- */
 int dmg_version(void);
 const char *dmg_last_error(void);
+/* Optional, and only useful BEFORE the process's first HIP call (in a host that links or loads the library early): asks the HIP
+ * runtime for eight hardware queues (setenv GPU_MAX_HW_QUEUES=8 unless the host has set the variable), which dmg_multi's
+ * overlapped exchange order needs (two streams per band; with HIP's default of four they serialise).  A host that initialises HIP
+ * first sets the variable itself.  The library never edits the environment on its own.  Returns DMG_OK, or DMG_ESTATE when the
+ * variable is already set to less than 8. */
+int dmg_runtime_init(void);
 
 /* Binds HIP device `device_id`.  Work is enqueued on `stream`: an existing hipStream_t of the host program
  * (NULL = the device's default stream, which is what e.g. torch.cuda.current_stream() is unless changed), or,
@@ -216,6 +223,11 @@ int dmg_ocean_divergence(dmg_ocean *o);                        /* :363-435  divw
 int dmg_ocean_subdiv(dmg_ocean *o);                            /* :511-622  v <- v - grad p, coastline snapping */
 /* rows of velocity halo this band's next advect needs (back-trace distance |v|*timestep, :298-299) */
 int dmg_ocean_advect_reach(dmg_ocean *o, int *rows);
+/* When that exceeds `ghost` (at H = 8192 the reference's own wind forcing, :341-348, drives |v| to ~10: 96 rows): the next
+ * dmg_ocean_advect gathers from a copy of v `reach` rows deep.  _prepare allocates it (grown on demand, in steps of 32 rows)
+ * and copies the owned rows in; the host then refreshes its ghost rows through dmg_ocean_halo(o, DMG_F_VADVECT, side, reach,
+ * ...) and calls dmg_ocean_advect.  reach may not exceed the rows a band owns.  dmg_multi_step does all of this itself. */
+int dmg_ocean_advect_prepare(dmg_ocean *o, int reach);
 
 /* Results back to the host (Texture::uploadData side of the adapter): owned rows only are written,
  * into FULL-grid arrays at their grid position (so ranks can fill one array); NULL skips a field. */
@@ -241,6 +253,11 @@ typedef struct dmg_multi dmg_multi;
 #define DMG_MULTI_PEER 2            /* hipMemcpyPeerAsync + events: one process; also several bands on one GPU */
 #define DMG_MULTI_RCCL_LOOPBACK 3   /* tests on a one-GPU box: all bands on one device and stream, every slab sent through a
                                        communicator of size 1 to the process's own rank -- the RCCL calls run for real */
+#define DMG_MULTI_STORE 4           /* direct stores: the sender's copy kernel writes its edge rows straight into a landing slot in the
+                                       neighbour's memory (peer-mapped pointer in one process, hipIpc mapping between processes) and
+                                       then a sequence number into the neighbour's flag word; the receiver's stream waits for the number
+                                       and moves the slot into its ghost rows.  No RCCL kernel, host barrier or event per exchange; RCCL
+                                       is kept for set-up (the handles' all-gather) and the advect reach all-reduce */
 #define DMG_MULTI_TRANSPORT_MASK 15
 #define DMG_MULTI_EXCHANGE_THEN_SWEEP 0     /* order of a Jacobi block: refresh the ghost rows, then sweep (default) */
 #define DMG_MULTI_OVERLAP_LAST_LAUNCH 16    /* the exchange for the next block runs while the interior of this block's last
@@ -251,9 +268,14 @@ typedef struct dmg_multi dmg_multi;
                                                the own stream waits for the exchange in front of the next block only.
                                                Pays ~28 us per block for the edge units and hides ~57 us of exchange on a
                                                1024-row band: ahead of exchange-then-sweep from ~35 us of link time on.
-                                               Needs more than HIP's default four hardware
-                                               queues (GPU_MAX_HW_QUEUES; the library asks for 8 when it is loaded) */
+                                               Needs GPU_MAX_HW_QUEUES >= 8 in the environment before the process's first HIP
+                                               call (dmg_runtime_init); a handle that does not find it falls back to
+                                               exchange-then-sweep and reports DMG_MULTI_WARN_HWQ_FALLBACK in its stats */
 #define DMG_MULTI_ID_BYTES 128
+#define DMG_MULTI_STORE_BLOB_BYTES 192
+#define DMG_MULTI_WARN_HWQ_FALLBACK 1   /* dmg_multi_stats.warnings: the overlapped order was asked for with fewer than 8 hardware queues */
+#define DMG_MULTI_WARN_SHARED_GPU_FALLBACK 2   /* ... or with more than four bands of one process on one GPU (a rehearsal): 9+ streams
+                                                  of one device that wait on each other are time-sliced by its scheduler */
 /* One process, n_bands bands; device_ids[i] = HIP device of band i (ids may repeat with DMG_MULTI_PEER / _LOOPBACK).
  * ghost = halo rows per band side: the Jacobi solve exchanges every `ghost` sweeps (rounded down to whole 8-sweep
  * launches), and advect may reach at most `ghost` rows (dmg_multi_step checks this on all bands before it moves). */
@@ -264,9 +286,17 @@ int dmg_multi_create(int n_bands, const int *device_ids, const dmg_grid *grid, c
 int dmg_multi_unique_id(void *id128);
 int dmg_multi_create_rank(int rank, int n_ranks, const void *id128, int device_id, const dmg_grid *grid, const dmg_ocean_params *params,
                           int ghost, int flags, dmg_multi **out);
-/* A band that fails with a runtime error aborts the local RCCL communicators (queued receives end instead of waiting for a
- * peer that will never send) and the handle then refuses everything but dmg_multi_destroy (DMG_ESTATE).  Host-side waits
- * of the RCCL transports give up after DMG_MULTI_TIMEOUT_MS (environment, default 120000) with DMG_EHIP. */
+/* DMG_MULTI_STORE with one process per GPU: with an id the ranks exchange their memory handles over RCCL inside
+ * dmg_multi_create_rank and nothing more is needed.  A host with a bootstrap of its own passes id128 == NULL (no RCCL
+ * communicator: dmg_multi_jacobi works, dmg_multi_step -- which all-reduces the advect reach -- does not), then has every
+ * rank call _blob, gathers the DMG_MULTI_STORE_BLOB_BYTES bytes of all ranks in rank order, and hands them to _connect. */
+int dmg_multi_store_blob(dmg_multi *m, void *blob);
+int dmg_multi_store_connect(dmg_multi *m, const void *blobs, int n_ranks);
+/* A band that fails with a runtime error marks the handle, which then refuses everything but dmg_multi_destroy (DMG_ESTATE);
+ * once the band threads have returned the local RCCL communicators are aborted (queued receives end instead of waiting for a
+ * peer that will never send).  Host-side waits of the RCCL and store transports give up, with DMG_EHIP, when no exchange of
+ * their band has completed for DMG_MULTI_TIMEOUT_MS (environment, default 120000): a long queue that is progressing is not a
+ * failure.  The store transport's landing kernels give up after the same time by themselves. */
 void dmg_multi_destroy(dmg_multi *m);
 int dmg_multi_set_order(dmg_multi *m, int order);          /* DMG_MULTI_EXCHANGE_THEN_SWEEP | DMG_MULTI_OVERLAP_LAST_LAUNCH, per call site */
 /* the dmg_ocean_* calls of the same names, on every local band (full-grid arrays; each band takes / fills its rows) */
@@ -288,6 +318,7 @@ int dmg_multi_band_count(const dmg_multi *m);               /* bands in this pro
 int dmg_multi_band(dmg_multi *m, int local_index, dmg_ocean **out);   /* borrow a band (checkpoints, dmg_ocean_speed_shade ...) */
 typedef struct {
     int bands_total, bands_local, transport, order, ghost;
+    int warnings;                    /* DMG_MULTI_WARN_* */
     long long exchanges;             /* halo exchanges since creation */
     double exchange_ms;              /* their time on band 0's stream (HIP events around each exchange) */
     long long exchange_bytes;        /* bytes band 0 sent + received */
@@ -309,6 +340,8 @@ int dmg_multi_climate_steps(dmg_multi_climate *h, int first_step, int n_steps); 
 int dmg_multi_climate_set_terrain(dmg_multi_climate *h, const float *terrain);    /* Temperature.cpp:131-132: only the sign matters */
 int dmg_multi_climate_get(dmg_multi_climate *h, float *T);                        /* owned rows of this process's bands; synchronises */
 int dmg_multi_climate_sync(dmg_multi_climate *h);
+int dmg_multi_climate_store_blob(dmg_multi_climate *h, void *blob);                          /* as dmg_multi_store_blob / _connect */
+int dmg_multi_climate_store_connect(dmg_multi_climate *h, const void *blobs, int n_ranks);
 int dmg_multi_timer_start(dmg_multi *m);                    /* HIP events on band 0's stream; _stop waits for every band */
 int dmg_multi_timer_stop(dmg_multi *m, float *elapsed_ms);
 

@@ -1,6 +1,11 @@
+import os
 import subprocess
 import sys
 from pathlib import Path
+
+# dmg_multi's overlapped exchange order needs eight hardware queues, asked for before HIP initialises; the
+# library does not edit the environment itself
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np
 import pytest

@@ -82,24 +82,61 @@ def test_ocean_step_bands_gloo_hip(tmp_path):
     assert np.array_equal(got, ref)
 
 
+def _bench_rehearsal(extra_env, extra_args=()):
+    import json, os, subprocess, sys
+    env = dict(os.environ, DMG_BENCH_REHEARSAL="1", **extra_env)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+           "--width", "2048", "--height", "1024", "--sweeps", "96", "--no-cpu-baseline", *extra_args]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=str(ROOT))
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return r, lines, (json.loads(lines[0]) if len(lines) == 1 else None)
+
+
 @pytest.mark.gpu
 def test_bench_multi_rank_rehearsal(tmp_path):
     """bench.py launched exactly as the driver launches it for N=2 (torch.distributed.run, one process per rank), with
     the rehearsal switch for a one-GPU box: rendezvous, RCCL-id broadcast, barrier and max-over-ranks run over gloo, and
-    each rank drives both bands on GPU 0 through the library's one-process dmg_multi (RCCL refuses two ranks per GPU)"""
-    import json, os, subprocess, sys
-    env = dict(os.environ, DMG_BENCH_REHEARSAL="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(free_port()), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
-           "--width", "2048", "--height", "1024", "--sweeps", "96", "--no-cpu-baseline"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=str(ROOT))
+    each rank drives both bands on GPU 0 through the library's one-process dmg_multi (RCCL refuses two ranks per GPU).
+    One timed leg per exchange order and transport; the headline is the fastest, the others are listed."""
+    r, lines, d = _bench_rehearsal({})
     assert r.returncode == 0, r.stderr[-2000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
-    d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and d["roofline"]["sweeps_per_launch"] == 8.0
     assert "2 latitude bands" in d["config"]["parallelism"]
-    assert d["halo_exchange"]["exchanges"] >= 3 and 0 < d["halo_exchange"]["share_of_stream_time"] < 1
+    assert d["halo_exchange"]["exchanges"] >= 3 and 0 < d["halo_exchange"]["share_of_stream_time"]
+    legs = d["legs"]
+    assert [(l["transport"], l["order"]) for l in legs] == [("rccl", "exchange-then-sweep"), ("rccl", "overlap"), ("store", "exchange-then-sweep"),
+                                                             ("store", "overlap")]
+    assert all(l.get("value", 0) > 0 for l in legs), legs
+    assert d["value"] == max(l["value"] for l in legs) and isinstance(d["other_exchange_order"], dict)
+
+
+@pytest.mark.gpu
+def test_bench_prints_its_line_when_the_overlapped_legs_fail(tmp_path):
+    """the first multi-GPU run must not lose its measurement to a leg that has never run between two
+    devices.  DMG_MULTI_FAIL=1:3:16 makes band 1 of every handle in the OVERLAPPED order give up in front of its third
+    exchange: those legs fail on every rank (each inside its own try/except, on a handle that is destroyed afterwards), the
+    exchange-then-sweep legs before and after them stand, and rank 0 prints its one line with the failures as strings."""
+    r, lines, d = _bench_rehearsal({"DMG_MULTI_FAIL": "1:3:16", "DMG_MULTI_TIMEOUT_MS": "3000"})
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2000:]
+    assert len(lines) == 1, r.stdout
+    legs = {(l["transport"], l["order"]): l for l in d["legs"]}
+    assert len(legs) == 4
+    for t in ("rccl", "store"):
+        assert legs[(t, "exchange-then-sweep")].get("value", 0) > 0, legs
+        assert "error" in legs[(t, "overlap")] and "injected" in legs[(t, "overlap")]["error"] or "failed" in legs[(t, "overlap")]["error"], legs
+    assert d["value"] > 0 and "exchange-then-sweep" in d["config"]["parallelism"]
+    assert isinstance(d["other_exchange_order"], str) and "failed" in d["other_exchange_order"]
+
+
+@pytest.mark.gpu
+def test_bench_prints_a_line_even_when_every_leg_fails(tmp_path):
+    """... and when nothing works the line still appears (value null, the reasons spelled out) with a non-zero exit status"""
+    r, lines, d = _bench_rehearsal({"DMG_MULTI_FAIL": "1:2", "DMG_MULTI_TIMEOUT_MS": "3000"}, ("--transport", "rccl"))
+    assert r.returncode != 0
+    assert len(lines) == 1, r.stdout + r.stderr[-1500:]
+    assert d["value"] is None and "no leg completed" in d["error"] and len(d["legs"]) == 2
 
 
 @pytest.mark.gpu
