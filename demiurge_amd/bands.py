@@ -1,4 +1,12 @@
-"""Latitude-band driver: one process per GPU, pressure ghost rows refreshed with point-to-point exchanges.
+"""Latitude-band driver over torch.distributed -- TEST AND BENCH TOOLING since round 2, not a product path.
+
+The library drives its bands itself (demiurge_amd/csrc/multi.hip, dmg_multi: threads, streams, RCCL / peer-copy / direct-store
+transports, failure handling, the deep advect halo).  This module is what round 1 used before that existed; it stays as (i) the
+multi-process gloo tests' driver (tests/test_bands_gloo.py: CPU with the oracle, GPU with the library), (ii) an example of a
+host that brings its own transport to dmg_ocean bands (dmg_ocean_halo), and (iii) the only place the pipelined edge chain
+(jacobi_solve_pipelined, needs the tile kernels' row grid) lives -- an experiment that dmg_multi's edge-first order replaced.
+
+Latitude-band driver: one process per GPU, pressure ghost rows refreshed with point-to-point exchanges.
 
 The reference has no distributed piece; this is the only communication the backend
 introduces.  A band owns H/n contiguous rows x full W, so the longitude wrap and the pole reflection stay

@@ -4,13 +4,15 @@ This module is plumbing for the tests and bench.py; the product is the shared li
 loudly when the library is missing or no MI355X is visible -- there is no CPU fallback.
 """
 import ctypes
+import os
 import weakref
 from pathlib import Path
 
 import numpy as np
 
 _HERE = Path(__file__).resolve().parent
-LIB_PATH = _HERE / "libdemiurge_hip.so"
+# (DMG_LIB: another build of the same library, for A/B measurements of two builds in one GPU call -- tools only)
+LIB_PATH = Path(os.environ["DMG_LIB"]) if os.environ.get("DMG_LIB") else _HERE / "libdemiurge_hip.so"
 ROOT = _HERE.parent
 
 OK, EINVAL, ENOMEM, EHIP, ENODEVICE, ESTATE = 0, -1, -2, -3, -4, -5
@@ -201,6 +203,11 @@ def lib():
         "dmg_world_destroy": (None, [vp]),
         "dmg_world_step": (c_int, [vp, ctypes.POINTER(WorldParams)]),
         "dmg_world_get": (c_int, [vp, vp, vp, vp]),
+        "dmg_multi_world_create": (c_int, [c_int, ctypes.POINTER(c_int), PG, vp, vp, c_int, c_int, ctypes.POINTER(vp)]),
+        "dmg_multi_world_create_rank": (c_int, [c_int, c_int, vp, c_int, PG, vp, vp, c_int, c_int, ctypes.POINTER(vp)]),
+        "dmg_multi_world_destroy": (None, [vp]),
+        "dmg_multi_world_step": (c_int, [vp, ctypes.POINTER(WorldParams)]),
+        "dmg_multi_world_get": (c_int, [vp, vp, vp, vp]),
         "dmg_field_create": (c_int, [vp, PG, c_int, c_int, c_int, ctypes.POINTER(vp)]),
         "dmg_field_destroy": (None, [vp]),
         "dmg_field_set": (c_int, [vp, vp]),
@@ -719,6 +726,43 @@ class World:
         t, e, T = (np.empty((H, W), np.float32) for _ in range(3))
         check(lib().dmg_world_get(self.h, _p(t), _p(e), _p(T)))
         return dict(terrain=t, eroded=e, T=T)
+
+
+class MultiWorld:
+    """dmg_multi_world: BASELINE config 5 on N GPUs -- tectonics and erosion on the first band's GPU (or as replicas, one process per
+    GPU), the climate year cycle in latitude bands"""
+
+    def __init__(self, grid, terrain, T0, devices=None, ghost=8, flags=MULTI_AUTO, rank=None, world=None, unique_id=None, device=0):
+        self.grid = grid
+        terrain, T0 = _f32(terrain), _f32(T0)
+        h = ctypes.c_void_p()
+        if devices is not None:
+            ids = (ctypes.c_int * len(devices))(*devices)
+            check(lib().dmg_multi_world_create(len(devices), ids, ctypes.byref(grid), _p(terrain), _p(T0), ghost, flags, ctypes.byref(h)))
+        else:
+            buf = ctypes.create_string_buffer(unique_id, 128) if unique_id is not None else None
+            check(lib().dmg_multi_world_create_rank(rank, world, buf, device, ctypes.byref(grid), _p(terrain), _p(T0), ghost, flags, ctypes.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            lib().dmg_multi_world_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def step(self, params=None):
+        check(lib().dmg_multi_world_step(self.h, ctypes.byref(params) if params is not None else None))
+
+    def get(self):
+        H, W = self.grid.H, self.grid.W
+        out = {k: np.zeros((H, W), np.float32) for k in ("terrain", "eroded", "T")}
+        check(lib().dmg_multi_world_get(self.h, _p(out["terrain"]), _p(out["eroded"]), _p(out["T"])))
+        return out
 
 
 class Field:

@@ -121,4 +121,5 @@ int erosion_create_from(dmg_ctx *ctx, const dmg_grid *grid, const float *h, bool
                         int lakes, dmg_erosion **out);
 const float *erosion_heights_device(const dmg_erosion *e);
 int climate_set_terrain_device(dmg_climate *k, const float *d_terrain);
+int climate_set_terrain_peer(dmg_climate *k, const float *d_full, int src_device, hipEvent_t ready);
 const float *tectonics_terrain_device(const dmg_tectonics *t);

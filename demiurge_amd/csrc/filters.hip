@@ -779,6 +779,24 @@ extern "C++" int climate_set_terrain_device(dmg_climate *k, const float *d_terra
     return DMG_OK;
 }
 
+// the same for a band whose terrain lives as a FULL-grid array on ANOTHER GPU (dmg_multi_world: tectonics and erosion run on the
+// first band's device): a peer copy of the band's rows on the band's stream, which first waits for `ready` (the producer's event)
+extern "C++" int climate_set_terrain_peer(dmg_climate *k, const float *d_full, int src_device, hipEvent_t ready)
+{
+    DMG_CHECK_ARG(k != nullptr && d_full != nullptr);
+    DMG_HIP(hipSetDevice(k->ctx->device));
+    if (ready) DMG_HIP(hipStreamWaitEvent(k->ctx->stream, ready, 0));
+    const size_t bytes = (size_t)k->grid.W * k->L * 4;
+    if (src_device == k->ctx->device) DMG_HIP(hipMemcpyAsync(k->terr.p, d_full + k->voff(), bytes, hipMemcpyDeviceToDevice, k->ctx->stream));
+    else DMG_HIP(hipMemcpyPeerAsync(k->terr.p, k->ctx->device, d_full + k->voff(), src_device, bytes, k->ctx->stream));
+    if (k->land4.p) {
+        const size_t n4 = (size_t)k->grid.W * k->L / 4;
+        hipLaunchKernelGGL(k_land_mask4, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, k->ctx->stream, k->terr.f(), (unsigned char *)k->land4.p, n4);
+        DMG_HIP(hipGetLastError());
+    }
+    return DMG_OK;
+}
+
 // ghost slabs of the temperature field, as dmg_ocean_halo
 int dmg_climate_halo(dmg_climate *k, int side, int rows, void **send, void **recv, size_t *bytes)
 {

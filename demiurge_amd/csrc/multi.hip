@@ -1122,6 +1122,170 @@ int dmg_multi_climate_sync(dmg_multi_climate *h)
 
 void dmg_multi_destroy(dmg_multi *m) { multi_free(m); }
 
+// ---- BASELINE config 5 on N GPUs -----------------------------------------------------------------
+// dmg_world's sequence -- Tectonics::run steps -> cpufilter::run rounds -> Temperature::run steps (world.hip) -- with the
+// stage that can use a node spread over it: the climate year cycle (Temperature.cpp:140-150: 500 000 steps) runs in latitude
+// bands through dmg_multi_climate's threads, streams and transports.  Tectonics' rotated gathers and FlowFilter's lake graph
+// are global ("replicas only"):
+//   one process (dmg_multi_world_create)        they run once, on the first band's GPU; every band pulls ITS rows of the eroded
+//                                               terrain from there with one peer copy per iteration (the climate reads the
+//                                               terrain's sign only, Temperature.cpp:131-132) behind an event
+//   one process per GPU (.._create_rank)        every rank runs them on its own GPU -- replicas, bit-identical by determinism,
+//                                               nothing to broadcast -- and owns one climate band
+struct dmg_multi_world {
+    dmg_ctx *ctx0 = nullptr;
+    dmg_grid grid{};
+    dmg_tectonics *tect = nullptr;
+    float *d_terrain = nullptr, *d_eroded = nullptr;
+    dmg_multi *clim = nullptr;
+    hipEvent_t ev_ready = nullptr;                   // the eroded terrain of this iteration is complete (ctx0's stream)
+    std::vector<hipEvent_t> ev_taken;                // band i has copied its rows (its stream): the next iteration may overwrite them
+    long long climate_step = 0, iterations = 0;
+};
+
+static void multi_world_free(dmg_multi_world *w)
+{
+    if (!w) return;
+    if (w->clim) multi_free(w->clim);
+    if (w->tect) dmg_tectonics_destroy(w->tect);
+    if (w->ctx0) {
+        (void)hipSetDevice(w->ctx0->device);
+        (void)hipStreamSynchronize(w->ctx0->stream);
+        if (w->d_terrain) (void)hipFree(w->d_terrain);
+        if (w->d_eroded) (void)hipFree(w->d_eroded);
+        if (w->ev_ready) (void)hipEventDestroy(w->ev_ready);
+        for (hipEvent_t e : w->ev_taken) if (e) (void)hipEventDestroy(e);
+        dmg_destroy(w->ctx0);
+    }
+    delete w;
+}
+
+static int multi_world_common(dmg_multi_world *w, int device, const dmg_grid *grid, const float *terrain)
+{
+    int rc = dmg_create(device, nullptr, DMG_PRIVATE_STREAM, &w->ctx0);
+    if (rc) return rc;
+    w->grid = *grid;
+    const size_t n = (size_t)grid->W * grid->H;
+    DMG_HIP(hipSetDevice(device));
+    if (hipMalloc((void **)&w->d_terrain, n * 4) != hipSuccess || hipMalloc((void **)&w->d_eroded, n * 4) != hipSuccess)
+        return dmg_fail(DMG_ENOMEM, "hipMalloc of two %zu-cell fields failed", n);
+    DMG_HIP(hipMemcpyAsync(w->d_terrain, terrain, n * 4, hipMemcpyHostToDevice, w->ctx0->stream));
+    DMG_HIP(hipMemcpyAsync(w->d_eroded, w->d_terrain, n * 4, hipMemcpyDeviceToDevice, w->ctx0->stream));
+    DMG_HIP(hipStreamSynchronize(w->ctx0->stream));
+    DMG_HIP(hipEventCreateWithFlags(&w->ev_ready, hipEventDisableTiming));
+    return dmg_tectonics_create(w->ctx0, grid, terrain, &w->tect);
+}
+
+int dmg_multi_world_create(int n_bands, const int *device_ids, const dmg_grid *grid, const float *terrain, const float *T0, int ghost, int flags,
+                           dmg_multi_world **out)
+{
+    DMG_CHECK_ARG(out != nullptr && n_bands >= 1 && device_ids != nullptr && grid != nullptr && terrain != nullptr && T0 != nullptr);
+    *out = nullptr;
+    std::unique_ptr<dmg_multi_world, void (*)(dmg_multi_world *)> w(new (std::nothrow) dmg_multi_world, multi_world_free);
+    if (!w) return dmg_fail(DMG_ENOMEM, "out of host memory");
+    int rc = multi_world_common(w.get(), device_ids[0], grid, terrain);
+    if (rc) return rc;
+    if ((rc = multi_create_local(n_bands, device_ids, grid, nullptr, ghost, flags, climate_band(grid, T0, terrain, ghost), &w->clim))) return rc;
+    for (int i = 0; i < n_bands; i++) {                        // the bands read the first band's GPU
+        if (device_ids[i] == device_ids[0]) continue;
+        int ok = 0;
+        (void)hipDeviceCanAccessPeer(&ok, device_ids[i], device_ids[0]);
+        if (ok) { (void)hipSetDevice(device_ids[i]); (void)hipDeviceEnablePeerAccess(device_ids[0], 0); (void)hipGetLastError(); }
+    }
+    w->ev_taken.assign((size_t)n_bands, nullptr);
+    for (int i = 0; i < n_bands; i++) {
+        DMG_HIP(hipSetDevice(device_ids[i]));
+        DMG_HIP(hipEventCreateWithFlags(&w->ev_taken[i], hipEventDisableTiming));
+    }
+    *out = w.release();
+    return DMG_OK;
+}
+
+int dmg_multi_world_create_rank(int rank, int n_ranks, const void *id128, int device_id, const dmg_grid *grid, const float *terrain, const float *T0,
+                                int ghost, int flags, dmg_multi_world **out)
+{
+    DMG_CHECK_ARG(out != nullptr && grid != nullptr && terrain != nullptr && T0 != nullptr);
+    *out = nullptr;
+    std::unique_ptr<dmg_multi_world, void (*)(dmg_multi_world *)> w(new (std::nothrow) dmg_multi_world, multi_world_free);
+    if (!w) return dmg_fail(DMG_ENOMEM, "out of host memory");
+    int rc = multi_world_common(w.get(), device_id, grid, terrain);
+    if (rc) return rc;
+    if ((rc = multi_create_rank(rank, n_ranks, id128, device_id, grid, nullptr, ghost, flags, climate_band(grid, T0, terrain, ghost), &w->clim))) return rc;
+    w->ev_taken.assign(1, nullptr);
+    DMG_HIP(hipSetDevice(device_id));
+    DMG_HIP(hipEventCreateWithFlags(&w->ev_taken[0], hipEventDisableTiming));
+    *out = w.release();
+    return DMG_OK;
+}
+
+void dmg_multi_world_destroy(dmg_multi_world *w) { multi_world_free(w); }
+
+int dmg_multi_world_step(dmg_multi_world *w, const dmg_world_params *params)
+{
+    DMG_CHECK_ARG(w != nullptr);
+    dmg_world_params p;
+    if (params) p = *params; else dmg_world_params_default(&p);
+    DMG_CHECK_ARG(p.tectonics_steps >= 0 && p.erosion_rounds >= 0 && p.climate_steps >= 0 && p.erosion_N >= 1);
+    dmg_multi *m = w->clim;
+    if (m->dead.load()) return dmg_fail(DMG_ESTATE, "this handle has lost a band: destroy it");
+    DMG_HIP(hipSetDevice(w->ctx0->device));
+    hipStream_t st = w->ctx0->stream;
+    const size_t bytes = (size_t)w->grid.W * w->grid.H * 4;
+    int rc;
+    // the stages that do not shard (world.hip has the same sequence; tectonics/Tectonics.cpp:156-275, cpufilter.cpp:41-222)
+    if (p.tectonics_steps > 0) {
+        if ((rc = dmg_tectonics_step(w->tect, p.tectonics_steps))) return rc;
+        DMG_HIP(hipMemcpyAsync(w->d_terrain, tectonics_terrain_device(w->tect), bytes, hipMemcpyDeviceToDevice, st));
+    }
+    for (hipEvent_t e : w->ev_taken)                     // every band has taken its rows of the iteration before
+        if (w->iterations > 0 && e) DMG_HIP(hipStreamWaitEvent(st, e, 0));
+    if (p.erosion_rounds > 0) {
+        dmg_erosion *e = nullptr;
+        if ((rc = erosion_create_from(w->ctx0, &w->grid, w->d_terrain, true, p.erosion_N, p.exponent, p.slope_exponent, p.factor, p.lakes, &e))) return rc;
+        rc = dmg_erosion_rounds(e, p.erosion_rounds);
+        if (!rc && hipMemcpyAsync(w->d_eroded, erosion_heights_device(e), bytes, hipMemcpyDeviceToDevice, st) != hipSuccess)
+            rc = dmg_fail(DMG_EHIP, "device copy of the eroded heights failed");
+        dmg_erosion_destroy(e);
+        if (rc) return rc;
+    } else DMG_HIP(hipMemcpyAsync(w->d_eroded, w->d_terrain, bytes, hipMemcpyDeviceToDevice, st));
+    DMG_HIP(hipEventRecord(w->ev_ready, st));
+    // the climate's bands: each pulls its rows of the eroded terrain (behind the event), then steps; asynchronous
+    if (p.climate_steps > 0) {
+        const int first = (int)w->climate_step, n_steps = p.climate_steps;
+        rc = m->team.run([&](int i) -> int {
+            dmg_climate *k = m->cl[i];
+            int r = climate_set_terrain_peer(k, w->d_eroded, w->ctx0->device, w->ev_ready);
+            if (r) return r;
+            DMG_HIP(hipEventRecord(w->ev_taken[i], m->ctx_of(i)->stream));
+            if (m->world == 1) return dmg_climate_steps(k, first, n_steps);
+            for (int done = 0; done < n_steps;) {
+                const int n = std::min(m->ghost, n_steps - done);
+                if ((r = band_exchange(m, i, 0, m->ghost))) return r;
+                if ((r = dmg_climate_steps(k, first + done, n))) return r;
+                done += n;
+            }
+            return DMG_OK;
+        });
+        if (rc) return rc;
+        w->climate_step += p.climate_steps;
+    }
+    w->iterations++;
+    return DMG_OK;
+}
+
+// terrain / eroded: full-grid arrays from the GPU that computed them; T: the owned rows of this process's bands
+int dmg_multi_world_get(dmg_multi_world *w, float *terrain, float *eroded, float *T)
+{
+    DMG_CHECK_ARG(w != nullptr);
+    DMG_HIP(hipSetDevice(w->ctx0->device));
+    const size_t bytes = (size_t)w->grid.W * w->grid.H * 4;
+    if (terrain) DMG_HIP(hipMemcpyAsync(terrain, w->d_terrain, bytes, hipMemcpyDeviceToHost, w->ctx0->stream));
+    if (eroded) DMG_HIP(hipMemcpyAsync(eroded, w->d_eroded, bytes, hipMemcpyDeviceToHost, w->ctx0->stream));
+    DMG_HIP(hipStreamSynchronize(w->ctx0->stream));
+    if (T) return dmg_multi_climate_get(reinterpret_cast<dmg_multi_climate *>(w->clim), T);
+    return DMG_OK;
+}
+
 // store transport, one process per GPU, no RCCL communicator (id128 == NULL at creation): the host carries the handles.
 // Every rank: _blob -> all-gather the DMG_MULTI_STORE_BLOB_BYTES bytes of all ranks, in rank order -> _connect.
 int dmg_multi_store_blob(dmg_multi *m, void *blob)

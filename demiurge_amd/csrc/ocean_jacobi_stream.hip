@@ -47,6 +47,9 @@
                                   // lane), and the coefficient table of 232 + 22 rows leaves its LDS at 19424 bytes: 8 waves share 160 KB
 #define STN_MAXROWS 104           // narrow form: two class registers
 #define ST_RING 12                // ring slots (rows): 10 rows are in flight between level 0 and level 8, two arrive
+#ifndef ST_OPEN_UNITS
+#define ST_OPEN_UNITS 1           // units whose whole window is plain open water run st_open_unit (0: every unit generic, round 3's kernel)
+#endif
 
 struct st_args {
     const float *pin;
@@ -234,11 +237,13 @@ __device__ __forceinline__ v4f st_row_any(const v4f N, const v4f C, const v4f S,
 
 // one level: sweep S of rows yA = e0 + 2t - S and yB = yA + 1 from level S-1's rows yA-1 .. yB+1 (the pair made one step ago
 // and the pair made in this step); K = t mod 2
-// MODE 0: the pair's rows as their classes say (tests and branches); 1: both open water; 2: both through the coast formula
+// MODE 0: the pair's rows as their classes say (tests and branches); 1: both open water; 2: both through the coast formula;
+// 3: both open water and known to be rows the unit writes (st_open_unit): level 8 stores them through a scalar base and the
+// lane's byte offsets sA, sB, without a range test
 template <int S, int K, bool P, int MODE = 0, int DV = 0>
 __device__ __forceinline__ void st_level(const st_args &a, st_state &z, v4f (*bring)[64], unsigned (*cring)[64], const v4f *ktab,
                                          int lane, int t, int yA, int r0, int r1, bool lane_ok, int xcol,
-                                         v4f (&bq)[9], v4f (&kq)[9], int kb = 0)
+                                         v4f (&bq)[9], v4f (&kq)[9], int kb = 0, const char *sbase = nullptr, unsigned sA = 0, unsigned sB = 0)
 {
     // bq[k], kq[k]: right-hand side and coefficients of ring row (newest - k); this level's rows are k = S and k = S - 1
     const v4f bA = bq[S], bB = bq[S - 1], kA = kq[S], kB = kq[S - 1];
@@ -268,7 +273,7 @@ __device__ __forceinline__ void st_level(const st_args &a, st_state &z, v4f (*br
         const int sa = st_wrap(z.slot - S), sb = sa + 1 == ST_RING ? 0 : sa + 1;
         oA = st_row_any<DV>(N0, C0, S0, bA, kA, z.cy, z.ry, true, cring[sa], lane);
         oB = st_row_any<DV>(N1, N0, C0, bB, kB, z.cy, z.ry, true, cring[sb], lane);
-    } else if (MODE == 1 || !(((z.landbits | z.mixbits | (DV ? z.badbits : 0u)) >> S) & 3u)) {   // (one two-bit field of the step's combined mask: the common case costs one scalar test)
+    } else if (MODE == 1 || MODE == 3 || !(((z.landbits | z.mixbits | (DV ? z.badbits : 0u)) >> S) & 3u)) {   // (one two-bit field of the step's combined mask: the common case costs one scalar test)
         // both rows open ocean (wave-uniform): one block of 8 independent division chains
         const jacobi_row ka = { kA.x, z.cy, kA.w, kA.y, z.ry, kA.z }, kb = { kB.x, z.cy, kB.w, kB.y, z.ry, kB.z };
         const st_we weA = st_we_sums(C0), weB = st_we_sums(N0);
@@ -293,6 +298,15 @@ __device__ __forceinline__ void st_level(const st_args &a, st_state &z, v4f (*br
         }
     }
     if (S < 8) { z.w[S & 7][K][0] = oA; z.w[S & 7][K][1] = oB; }
+    else if (MODE == 3) {
+        // (a use outside the branch: left alone, the compiler sinks all of level 8 into the `lane_ok` region, where its
+        // neighbour-lane adds no longer fuse with their DPP moves)
+        asm volatile("" :: "v"(oA), "v"(oB));
+        if (lane_ok && !ST_DBG(a, 2)) {
+            __builtin_nontemporal_store(st_to_memory(oA), reinterpret_cast<v4f *>(const_cast<char *>(sbase) + sA));
+            __builtin_nontemporal_store(st_to_memory(oB), reinterpret_cast<v4f *>(const_cast<char *>(sbase) + sB));
+        }
+    }
     else if (lane_ok && !ST_DBG(a, 2)) {                          // never re-read in this launch; land rows hold 0 in both buffers already
         // only the unit's own rows [r0, r1): in its first steps level 8 runs on rows below r0, never stored
         if (!landA && yA >= r0 && yA < r1) __builtin_nontemporal_store(st_to_memory(oA), reinterpret_cast<v4f *>(a.pout + (size_t)yA * a.W + xcol));
@@ -505,6 +519,126 @@ __device__ __forceinline__ void st_step(const st_args &a, st_state &z, v4f (*bri
 #endif
 }
 
+// ---- open-water units (round 4; measured, NOT the default: DMG_ST_OPEN_UNITS=1 switches them on) -----------------------
+// A step's eight levels are 386 instructions, 350 of them the formula; around them a generic step spends another ~180 -- row
+// classes looked up and tested, three row pointers advanced and an open row's code load redirected, land / coast / divisor
+// histories built and the mode chosen, stores range-tested: mostly scalar.  Round 3 read the kernel as bound by instruction
+// issue of every kind and named exactly these instructions as the next lever.  The host knows what the rows are: a unit whose
+// whole window is plain open water with exact divisor pairs, inside the grid and the stored band (75-80 % of the survey
+// terrain's live rows at any unit height, every interior unit of an all-ocean grid) is flagged in the unit list and runs
+// through this program instead: a row is two loads through one scalar base per array and a lane offset built from a scalar row
+// offset (its codes are never looked at), its arrival two packed moves and two LDS writes, level 8 stores without a range
+// test, nothing is classified or tested, no count ring, no histories: ~440 instead of ~590 instructions per step.  A region of
+// its own -- no step ever changes form -- because the same path INSIDE the generic loop (as a fourth alternative per step, or
+// as a six-step block with literal ring slots) pushed the register allocation of a 251-VGPR kernel over the edge: 113-257
+// spilled registers, and a scratch reload waits with vmcnt(0), which drains the two-steps-ahead loads: 3.6 -> 1.7 M.
+// The same level code on the same values: bit-identical (tests/stream_worker.py `open`, eight variants).
+// What it measured (profiles/r04_open_units.txt, same-box A/B, all-ocean 16384x8192): scalar instructions per launch 40.4 M ->
+// 13.6 M, vector 119.2 M -> 113.4 M, the waves' summed cycles -16 % -- and the LAUNCH not a percent shorter (368.9 vs 364.9 us;
+// survey terrain 280.0 vs 271.8 us).  The kernel is not issue-bound: its launches move 1.36 (survey) / ~1.9 GB (all-ocean) at
+// 5.0-5.1 TB/s where whole 1-KB rows fetched once reach 5.5-5.6 TB/s (MI355X_MICROARCH.md), a 16384x1024 band 0.33 GB in
+// 65 us likewise; waves that finish their arithmetic sooner wait for the same bytes.  What is left to gain is bytes
+// (DESIGN.md 8), not instructions; the program stays in the file, tested, for the day the bytes come down.
+template <int K, int DV, int PHASE>      // PHASE 0: the pipeline fills (level S starts at step S); 1: steady; 2: the unit's last steps (level 8 range-tested)
+__device__ __forceinline__ void st_open_step(const st_args &a, st_state &z, v4f (*bring)[64], const v4f *ktab, int lane, int t, int e_t, int r0, int r1,
+                                             bool lane_ok, int xcol, unsigned col4, unsigned &rowb, const char *pb, const char *bb, const char *sb)
+{
+    // arrival: pressure into level 0 in pair order (opaque moves: st_arrive says why), the right-hand side into its ring slots
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        v2f lo, hi;
+        asm volatile("v_pk_mov_b32 %0, %1, %2 op_sel:[0,1]" : "=v"(lo) : "v"(z.ps[K][j].xy), "v"(z.ps[K][j].zw) : "memory");
+        asm volatile("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=v"(hi) : "v"(z.ps[K][j].xy), "v"(z.ps[K][j].zw) : "memory");
+        z.w[0][K][j] = v4f{ lo.x, lo.y, hi.x, hi.y };
+        st_park_pairs(&bring[z.slot + j][lane], z.bs[K][j]);
+    }
+    // the pair of step t + 2
+    const unsigned voA = rowb + col4, voB = voA + (unsigned)a.W * 4u;
+    z.ps[K][0] = *reinterpret_cast<const v4f *>(pb + voA); z.bs[K][0] = *reinterpret_cast<const v4f *>(bb + voA);
+    z.ps[K][1] = *reinterpret_cast<const v4f *>(pb + voB); z.bs[K][1] = *reinterpret_cast<const v4f *>(bb + voB);
+    rowb += (unsigned)a.W * 8u;
+    const int s1 = st_wrap(z.slot - 1);
+    v4f bq[9], kq[9];
+    int kb = 0;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(kb) : "s"((2 * t - 8) * 16));
+    bq[1] = bring[s1][lane]; bq[0] = bring[z.slot][lane];
+    kq[1] = ktab[max(2 * t - 1, 0)]; kq[0] = ktab[max(2 * t - 1, 0) + 1];
+    unsigned (*nocring)[64] = nullptr;
+    constexpr int M = PHASE == 1 ? 3 : 1;
+    if (PHASE != 0 || 1 <= t) st_level<1, K, false, M, DV>(a, z, bring, nocring, ktab, lane, t, e_t - 1, r0, r1, lane_ok, xcol, bq, kq, kb);
+    if (PHASE != 0 || 2 <= t) st_level<2, K, false, M, DV>(a, z, bring, nocring, ktab, lane, t, e_t - 2, r0, r1, lane_ok, xcol, bq, kq, kb);
+    if (PHASE != 0 || 3 <= t) st_level<3, K, false, M, DV>(a, z, bring, nocring, ktab, lane, t, e_t - 3, r0, r1, lane_ok, xcol, bq, kq, kb);
+    if (PHASE != 0 || 4 <= t) st_level<4, K, false, M, DV>(a, z, bring, nocring, ktab, lane, t, e_t - 4, r0, r1, lane_ok, xcol, bq, kq, kb);
+    if (PHASE != 0 || 5 <= t) st_level<5, K, false, M, DV>(a, z, bring, nocring, ktab, lane, t, e_t - 5, r0, r1, lane_ok, xcol, bq, kq, kb);
+    if (PHASE != 0 || 6 <= t) st_level<6, K, false, M, DV>(a, z, bring, nocring, ktab, lane, t, e_t - 6, r0, r1, lane_ok, xcol, bq, kq, kb);
+    if (PHASE != 0 || 7 <= t) st_level<7, K, false, M, DV>(a, z, bring, nocring, ktab, lane, t, e_t - 7, r0, r1, lane_ok, xcol, bq, kq, kb);
+    // (voA, voB address rows e_t + 4, e_t + 5; level 8's rows are e_t - 8, e_t - 7: sb = pout - 12 rows)
+    if (PHASE != 0) st_level<8, K, false, M, DV>(a, z, bring, nocring, ktab, lane, t, e_t - 8, r0, r1, lane_ok, xcol, bq, kq, kb, sb, voA, voB);
+    z.slot = z.slot + 2 == ST_RING ? 0 : z.slot + 2;
+}
+
+template <int DV>
+__device__ __forceinline__ void st_open_unit(const st_args &a, v4f (*bring)[64], v4f *ktab, int lane, int tx, int r0, int r1)
+{
+    const int W = a.W;
+    const int nsteps = (((r1 - r0) + 2 * TB_T + 3) / 4) * 2;
+    const int e0 = r0 - TB_T;
+    int col = tx * TB_OW - TB_T + 4 * lane;
+    const int xcol = col;
+    col %= W; if (col < 0) col += W;
+    const bool lane_ok = (lane >= TB_T / 4) && (lane < 64 - TB_T / 4) && (xcol < W);
+    const unsigned col4 = (unsigned)col * 4u;
+    const char *pb = reinterpret_cast<const char *>(a.pin), *bb = reinterpret_cast<const char *>(a.b);
+    const char *sb = reinterpret_cast<const char *>(a.pout) - (size_t)12 * W * 4;
+    unsigned rowb = (unsigned)e0 * (unsigned)W * 4u;          // (the host flags a unit open only if its window and the rows requested past it lie inside the band)
+    st_state z;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const unsigned voA = rowb + col4, voB = voA + (unsigned)W * 4u;
+        z.ps[k][0] = *reinterpret_cast<const v4f *>(pb + voA); z.bs[k][0] = *reinterpret_cast<const v4f *>(bb + voA);
+        z.ps[k][1] = *reinterpret_cast<const v4f *>(pb + voB); z.bs[k][1] = *reinterpret_cast<const v4f *>(bb + voB);
+        rowb += (unsigned)W * 8u;
+    }
+#pragma unroll
+    for (int s = 0; s < 8; s++)
+#pragma unroll
+        for (int k = 0; k < 2; k++) { z.w[s][k][0] = (v4f)(0.0f); z.w[s][k][1] = (v4f)(0.0f); }
+    z.landbits = 0; z.mixbits = 0; z.badbits = 0; z.slot = 0; z.plain = true;
+    {
+        const int n = 2 * nsteps + 2;
+        v4f kt[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) kt[q] = st_kswap(*reinterpret_cast<const v4f *>(a.jcoef + (size_t)(e0 + min(lane + 64 * q, n - 1)) * 8));
+#pragma unroll
+        for (int q = 0; q < 4; q++) if (lane + 64 * q < n) ktab[lane + 64 * q] = kt[q];
+        const st_kptr cf = (st_kptr)(unsigned long long)a.jcoef;
+        z.cy = cf[4]; z.ry = cf[5];
+    }
+    int t = 0;
+    for (; t < TB_T; t += 2) {
+        st_open_step<0, DV, 0>(a, z, bring, ktab, lane, t, e0 + 2 * t, r0, r1, lane_ok, xcol, col4, rowb, pb, bb, sb);
+        st_open_step<1, DV, 0>(a, z, bring, ktab, lane, t + 1, e0 + 2 * t + 2, r0, r1, lane_ok, xcol, col4, rowb, pb, bb, sb);
+    }
+    // steady: both steps' level-8 rows are rows the unit writes: e0 + 2 (t + 1) - 8 + 1 < r1.  The first pair is peeled off the
+    // loop: a step waits for the loads of two steps ago with a counted vmcnt, and the count the compiler can prove at the loop's
+    // head is the smaller of its two predecessors' -- coming from the fill steps, which store nothing, it would be vmcnt(4)
+    // (the loads of ONE step ago must be back too) for every iteration instead of vmcnt(8)
+    if (t + 2 <= nsteps && e0 + 2 * t - 5 < r1) {
+        st_open_step<0, DV, 1>(a, z, bring, ktab, lane, t, e0 + 2 * t, r0, r1, lane_ok, xcol, col4, rowb, pb, bb, sb);
+        st_open_step<1, DV, 1>(a, z, bring, ktab, lane, t + 1, e0 + 2 * t + 2, r0, r1, lane_ok, xcol, col4, rowb, pb, bb, sb);
+        t += 2;
+        asm volatile("" ::: "memory");
+    }
+    for (; t + 2 <= nsteps && e0 + 2 * t - 5 < r1; t += 2) {
+        st_open_step<0, DV, 1>(a, z, bring, ktab, lane, t, e0 + 2 * t, r0, r1, lane_ok, xcol, col4, rowb, pb, bb, sb);
+        st_open_step<1, DV, 1>(a, z, bring, ktab, lane, t + 1, e0 + 2 * t + 2, r0, r1, lane_ok, xcol, col4, rowb, pb, bb, sb);
+    }
+    for (; t < nsteps; t += 2) {
+        st_open_step<0, DV, 2>(a, z, bring, ktab, lane, t, e0 + 2 * t, r0, r1, lane_ok, xcol, col4, rowb, pb, bb, sb);
+        st_open_step<1, DV, 2>(a, z, bring, ktab, lane, t + 1, e0 + 2 * t + 2, r0, r1, lane_ok, xcol, col4, rowb, pb, bb, sb);
+    }
+}
+
 // one wave per unit; two waves per SIMD leave 256 registers each: all issue slots of a SIMD belong to two fat waves
 template <int DV>
 __global__ __launch_bounds__(64, 2) void k_jacobi_stream(st_args a)
@@ -516,6 +650,15 @@ __global__ __launch_bounds__(64, 2) void k_jacobi_stream(st_args a)
     const int4 u = a.units[blockIdx.x];
     const int tx = __builtin_amdgcn_readfirstlane(u.x), r0 = __builtin_amdgcn_readfirstlane(u.y), r1 = __builtin_amdgcn_readfirstlane(u.z);
     const int W = a.W;
+    if (ST_OPEN_UNITS && !ST_DBG(a, 1) && (__builtin_amdgcn_readfirstlane(u.w) & 1)) {       // an open-water unit (st_units flags it)
+        if (a.prof && lane == 0) {
+            a.prof[3 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+            a.prof[3 * blockIdx.x + 2] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) | (unsigned)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+        }
+        st_open_unit<DV>(a, bring, ktab, lane, tx, r0, r1);
+        if (a.prof && lane == 0) a.prof[3 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+        return;
+    }
     if (a.prof && lane == 0) {
         a.prof[3 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
         // where the unit ran: HW_ID (wave slot, SIMD, CU, SH, SE) and XCC_ID
@@ -1059,6 +1202,14 @@ static void st_cut(const dmg_ocean *o, int variant, int lo, int hi, int seg, int
             // trip, the last stores.  Per-unit timings (DMG_ST_PROF) fit duration = 0.152 us x cost + 22 us: ~140 cost units,
             // not the 4 the first version assumed -- which made the simulation prefer many short units
             static const float unit_cost = [] { const char *e = getenv("DMG_ST_UNITCOST"); return e ? (float)atof(e) : 140.0f; }();
+            // an open-water unit (st_open_unit: no row of its window is anything but open water) spends ~440 instead of ~590
+            // instructions per step
+            static const float w_openunit = [] { const char *e = getenv("DMG_ST_WOPEN"); return e ? (float)atof(e) : 1.0f; }();     // (experiments; 0.78 is what their instruction count suggests and what made the cut worse)
+            if (cls && !variant && w_openunit != 1.0f) {
+                bool all_open = r0 - TB_T >= 0 && r1 + TB_T + 6 <= L;
+                for (int r = r0 - TB_T; all_open && r < r1 + TB_T + 6; r++) all_open = cls[r] == 0;
+                if (all_open) cost *= w_openunit;
+            }
             units.push_back(st_unit{ tx, r0, r1, cost + unit_cost });
         }
         }
@@ -1352,7 +1503,28 @@ static const dmg_ocean::tile_list *st_units(dmg_ocean *o, int variant, int lo, i
     }
     std::vector<int> flat;
     flat.reserve(best.size() * 4);
-    for (const st_unit &u : best) { flat.push_back(u.tx); flat.push_back(u.r0); flat.push_back(u.r1); flat.push_back(0); }
+    // a unit is an open-water unit (bit 0 of its fourth word; st_open_unit) if every row of its window, and every row its
+    // steps request past the window, is plain open water with exact divisor pairs inside the grid and the stored band
+    static const bool open_units = [] { const char *e = getenv("DMG_ST_OPEN_UNITS"); return e && atoi(e) != 0; }();     // (measured: no gain; off by default)
+    const std::vector<unsigned char> &ctab = o->rowclass_host;
+    int n_open = 0;
+    for (const st_unit &u : best) {
+        int flag = 0;
+        if (open_units && variant == 0 && !ctab.empty()) {
+            const int e0 = u.r0 - TB_T, nst = (((u.r1 - u.r0) + 2 * TB_T + 3) / 4) * 2, e_last = e0 + 2 * nst + 5;
+            const int y_first = o->y0 - o->gs;
+            bool ok = e0 >= 0 && e_last < o->L && y_first + e0 >= 0 && y_first + e_last < o->grid.H;
+            const unsigned char *cls = ctab.data() + (size_t)u.tx * o->L;
+            for (int r = e0; ok && r <= e0 + 2 * nst + 1; r++) ok = cls[r] == 0 && (o->rowbad_host.empty() || !o->rowbad_host[r]);
+            flag = ok ? 1 : 0;
+        }
+        n_open += flag;
+        flat.push_back(u.tx); flat.push_back(u.r0); flat.push_back(u.r1); flat.push_back(flag);
+    }
+    {
+        static const bool dbg = getenv("DMG_ST_DEBUG") != nullptr;
+        if (dbg) fprintf(stderr, "[stream] rows [%d,%d) part %d: %d of %zu units are open-water units\n", lo, hi, part, n_open, best.size());
+    }
     dmg_ocean::tile_list tl;
     tl.n = (int)best.size();
     tl.cut_seg = cut_seg; tl.cut_seg2 = cut_seg2; tl.cut_split = cut_split;

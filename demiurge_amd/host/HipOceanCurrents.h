@@ -11,7 +11,9 @@ public:
     // pressure = OceanCurrentsMenu::pressure (reference OceanCurrents.h:21); n_outer replaces the reference's
     // hard-coded 10000 / while(true) (OceanCurrents.cpp:155,212); the iteration counts are its literals (:50,:701)
     // devices: the GPUs the solve is split over, one latitude band each ({0} = one GPU; {0,0} = two bands on GPU 0, a
-    // rehearsal); ghost = halo rows per band side (sweeps between exchanges, and the longest advect back-trace allowed)
+    // rehearsal); ghost = halo rows per band side = sweeps between exchanges.  (Not a limit on the currents: an advect whose
+    // back-trace -- |v| * 24 h, OceanCurrents.cpp:294-299, ~96 rows at H = 8192 once the wind has spun the ocean up -- is longer
+    // than that gathers from a deeper copy of v that dmg_multi_step exchanges for that step, grown on demand.)
     HipOceanCurrents(Project *p, float pressure, int n_outer = 10000, int jacobi_iters = 5000, int diffusion_iters = 50,
                      std::vector<int> devices = { 0 }, int ghost = 32)
         : pressure_(pressure), n_outer_(n_outer), jacobi_iters_(jacobi_iters), diffusion_iters_(diffusion_iters),

@@ -514,6 +514,20 @@ int dmg_world_step(dmg_world *w, const dmg_world_params *params_or_null);
 /* terrain = what the tectonics render pass left; eroded = after the erosion rounds (scaled by 1/N like the reference's
  * terrain texture); T = the climate field.  NULL skips. */
 int dmg_world_get(dmg_world *w, float *terrain, float *eroded, float *T);
+/* The same on N GPUs (BASELINE config 5): the stage that shards -- the climate year cycle, Temperature.cpp:140-150,
+ * 500 000 steps -- runs in latitude bands through dmg_multi_climate (flags and ghost as for dmg_multi_climate_create); the global
+ * stages (Tectonics' rotated gathers, FlowFilter's lake graph: "replicas only") run once on the first band's GPU, every band
+ * pulling its rows of the eroded terrain from there with one peer copy per iteration (_create: one process), or as a replica on
+ * every rank's own GPU (_create_rank: one process per GPU; nothing to broadcast).  Bit-identical to dmg_world.  _step is
+ * asynchronous on the bands' streams; _get synchronises (T: the owned rows of this process's bands, into the full-grid array). */
+typedef struct dmg_multi_world dmg_multi_world;
+int dmg_multi_world_create(int n_bands, const int *device_ids, const dmg_grid *grid, const float *terrain, const float *T0, int ghost, int flags,
+                           dmg_multi_world **out);
+int dmg_multi_world_create_rank(int rank, int n_ranks, const void *id128, int device_id, const dmg_grid *grid, const float *terrain,
+                                const float *T0, int ghost, int flags, dmg_multi_world **out);
+void dmg_multi_world_destroy(dmg_multi_world *w);
+int dmg_multi_world_step(dmg_multi_world *w, const dmg_world_params *params_or_null);
+int dmg_multi_world_get(dmg_multi_world *w, float *terrain, float *eroded, float *T);
 
 #ifdef __cplusplus
 }

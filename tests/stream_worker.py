@@ -168,6 +168,26 @@ def case_split(capi, ctx, oracle, names):
     return ok
 
 
+def case_open(capi, ctx, oracle, names):
+    """open-water units (round 4: units whose whole window is plain open water run a program of their own, st_open_unit):
+    grids without land (every interior unit), the survey continents (open and generic units side by side, open units next to
+    coast units), odd heights (units of odd row counts: the tail steps), a belt (no pole rows), random start -- against the
+    oracle.  DMG_ST_ROWS in the environment picks the unit height."""
+    from demiurge_amd import synth
+    rng = np.random.default_rng(41)
+    ok = True
+    for W, H, iters, terrain, coords in ((2048, 512, 24, "ocean", capi.FULL_GLOBE), (1000, 333, 40, "ocean", BELT), (4096, 1024, 24, "survey", capi.FULL_GLOBE),
+                                         (2048, 777, 16, "survey", BELT), (512, 301, 29, "ocean", capi.FULL_GLOBE)):
+        grid = capi.make_grid(W, H, coords)
+        img = synth.terrain(W, H) if terrain == "survey" else -np.ones((H, W), f32)
+        b = rng.standard_normal((H, W)).astype(f32)
+        p0 = rng.standard_normal((H, W)).astype(f32)
+        ref = oracle.ocean_jacobi(ogrid(oracle, grid), img, b, iters, p0=p0, rows=True, nthreads=16)
+        ok &= same("open units %dx%d x%d %s %s" % (W, H, iters, terrain, "belt" if coords is BELT else "globe"),
+                   solve(capi, ctx, grid, img, b, iters, p0=p0, names=names), ref)
+    return ok
+
+
 def main():
     import oracle
     from demiurge_amd import capi
@@ -175,7 +195,7 @@ def main():
     names = set()
     ok = True
     for c in sys.argv[1:]:
-        ok &= {"random": case_random, "pepper": case_pepper, "golden": case_golden, "bands": case_bands, "split": case_split}[c](capi, ctx, oracle, names)
+        ok &= {"random": case_random, "pepper": case_pepper, "golden": case_golden, "bands": case_bands, "split": case_split, "open": case_open}[c](capi, ctx, oracle, names)
     print("kernels:", sorted(names), "DMG_TB_SHAPE =", os.environ.get("DMG_TB_SHAPE"), flush=True)
     ctx.close()
     if not ok:

@@ -399,6 +399,24 @@ def test_streaming_division_forms_vs_oracle(env):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("env", [{}, {"DMG_ST_ROWS": "24"}, {"DMG_ST_ROWS": "25"}, {"DMG_ST_ROWS": "100"}, {"DMG_ST_ROWS": "232"}, {"DMG_ST_OPEN_UNITS": "0"},
+                                 {"DMG_DIV2_FORCE_BAD": "50"}, {"DMG_JACOBI_DIV2": "0"}],
+                         ids=["auto-height", "24-rows", "25-rows", "100-rows", "232-rows", "without-open-units", "every-50th-row-without-pair", "three-op-division"])
+def test_streaming_open_water_units_vs_oracle(env):
+    """Round 4: units whose whole window is plain open water (the host flags them from the class table) can run a program of
+    their own -- no classes, no code loads, no histories, no range tests (st_open_unit; DMG_ST_OPEN_UNITS=1: measured to gain
+    nothing on a kernel that turned out to be bound by its bytes, so not the default).  Grids without land, the survey
+    continents (open units next to coast units), odd heights, a belt canvas, random starting pressure, at unit heights from 24
+    to 232 rows (even and odd: the tail steps), beside rows without an exact divisor pair (never inside an open unit) and in
+    the three-operation division form: against the oracle.  With the open units switched off the same cases give the same bits."""
+    out = _stream_worker(dict({"DMG_ST_OPEN_UNITS": "1"}, **dict(env, DMG_TB_SHAPE="stream", DMG_ST_DEBUG="1")), ["open"])
+    assert "'k_jacobi_stream'" in out, out[-1500:]
+    if env.get("DMG_ST_OPEN_UNITS") != "0":
+        import re
+        assert any(int(m) > 0 for m in re.findall(r"(\d+) of \d+ units are open-water units", out)), out[-1500:]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("form", ["stream", "auto"])
 def test_streaming_split_launches_vs_oracle(form):
     """the two halves of a split launch (_begin / exchange / _end) are halves of one cut.  Band splits

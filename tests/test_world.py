@@ -47,22 +47,52 @@ def test_world_is_the_sequence_of_its_tools(dev):
     t.close(); k.close()
 
 
+@pytest.mark.parametrize("bands,ghost,transport", [(3, 4, "MULTI_PEER"), (4, 8, "MULTI_STORE"), (2, 3, "MULTI_RCCL_LOOPBACK"), (1, 4, "MULTI_PEER")])
+def test_multi_world_on_a_fake_cluster_equals_world(dev, bands, ghost, transport):
+    """config 5 on N GPUs.  dmg_multi_world keeps tectonics and erosion on the first band's GPU and runs the
+    climate year cycle (Temperature.cpp:140-150) in latitude bands that pull their rows of the eroded terrain by device copies:
+    bands on GPU 0 (peer copies, the store transport, RCCL loopback), several iterations, more climate steps than ghost rows
+    -- bit-identical to the one-GPU dmg_world"""
+    capi, ctx = dev
+    W, H = 512, 256
+    grid = capi.make_grid(W, H)
+    terrain, T0 = inputs(W, H)
+    p = capi.World.default_params()
+    p.tectonics_steps, p.erosion_rounds, p.climate_steps = 2, 2, 11
+    w = capi.World(ctx, grid, terrain, T0)
+    for _ in range(3):
+        w.step(p)
+    ref = w.get()
+    w.close()
+    m = capi.MultiWorld(grid, terrain, T0, devices=[0] * bands, ghost=ghost, flags=getattr(capi, transport))
+    for _ in range(3):
+        m.step(p)
+    got = m.get()
+    m.close()
+    for k in ("terrain", "eroded", "T"):
+        assert np.array_equal(got[k], ref[k]), k
+
+
 def test_config5_at_size(dev):
-    """16384x8192: one coupled iteration (tectonics step -> erosion round -> climate steps): finite, deterministic, the
-    stages' invariants hold at the BASELINE size"""
+    """16384x8192: one coupled iteration (tectonics step -> erosion round -> climate steps) on one GPU (dmg_world) and as the
+    8-band split of BASELINE config 5 (dmg_multi_world: the bands on this box's one GPU, the store transport): finite, the two
+    bit-identical (which is also determinism), the stages' invariants hold at the BASELINE size"""
     capi, ctx = dev
     W, H = 16384, 8192
     grid = capi.make_grid(W, H)
     terrain, T0 = inputs(W, H)
     p = capi.World.default_params()
-    p.tectonics_steps, p.erosion_rounds, p.climate_steps = 1, 1, 3
+    p.tectonics_steps, p.erosion_rounds, p.climate_steps = 1, 1, 12
     runs = []
-    for _ in range(2):
-        w = capi.World(ctx, grid, terrain, T0)
-        w.step(p)
-        runs.append(w.get())
-        w.close()
-        ctx.trim()
+    w = capi.World(ctx, grid, terrain, T0)
+    w.step(p)
+    runs.append(w.get())
+    w.close()
+    ctx.trim()
+    m = capi.MultiWorld(grid, terrain, T0, devices=[0] * 8, ghost=8, flags=capi.MULTI_STORE)
+    m.step(p)
+    runs.append(m.get())
+    m.close()
     a, b = runs
     for k in ("terrain", "eroded", "T"):
         assert np.array_equal(a[k], b[k]), k                     # deterministic

@@ -1,6 +1,6 @@
 """The tools' kernels once each at 16384x8192, for a profiler (tools/kernel_table.py reads its kernel stats)."""
 import sys
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from demiurge_amd import capi, synth
 ctx = capi.Context(0)
