@@ -391,21 +391,44 @@ __global__ __launch_bounds__(256) void k_temperature_v4(canvas c, const float *_
     const size_t p = (size_t)y * W + x0;
     const float4 Tc = *reinterpret_cast<const float4 *>(T + p);
     const unsigned lm = land4[p >> 2];
+    // Round 4 (profiles/r04_kernel_counters.txt: the step is bound by its vector instructions, 146 per cell, 61 of them the
+    // taps' index arithmetic -- wrap, bounds and a 64-bit address per tap and thread).  The nine displacements and source rows
+    // are the same for the whole row (scalars); a thread whose four cells stay clear of the seam for the row's widest
+    // displacement -- all but the first and last few of a row -- takes every tap as ONE 16-byte load at a scalar row base plus
+    // a lane offset: one vector add per tap.  The others keep the checked form.  Same loads, same values.
+    int sh[9], sr[9], smin = 0, smax = 0;
 #pragma unroll
     for (int t = 0; t < 9; t++) {
-        const int sh = shift[y * 9 + t];
-        const int sr = srow[y * 9 + t];
-        if (sh == 0 && sr == y) { s[0][t] = Tc.x; s[1][t] = Tc.y; s[2][t] = Tc.z; s[3][t] = Tc.w; continue; }   // (row-uniform)
-        const float *row = T + (size_t)sr * W;
-        int i = x0 + sh;
-        if (c.lonwrap && i >= W) i -= W;             // sh is a forward distance in [0, W)
-        if (i >= 0 && i + 3 < W) {
-            float4 v;
-            __builtin_memcpy(&v, row + i, 16);
-            s[0][t] = v.x; s[1][t] = v.y; s[2][t] = v.z; s[3][t] = v.w;
-        } else {
+        sr[t] = srow[y * 9 + t];
+        int d = shift[y * 9 + t];                    // a forward distance in [0, W) on a full-longitude grid, signed otherwise
+        if (c.lonwrap && d > W / 2) d -= W;
+        sh[t] = d;
+        smin = min(smin, d); smax = max(smax, d);
+    }
+    if (x0 + smin >= 0 && x0 + smax + 3 < W) {
 #pragma unroll
-            for (int j = 0; j < 4; j++) s[j][t] = row[temperature_shifted(c, x0 + j, sh)];
+        for (int t = 0; t < 9; t++) {
+            if (sh[t] == 0 && sr[t] == y) { s[0][t] = Tc.x; s[1][t] = Tc.y; s[2][t] = Tc.z; s[3][t] = Tc.w; continue; }   // (row-uniform)
+            float4 v;
+            __builtin_memcpy(&v, reinterpret_cast<const char *>(T + (size_t)sr[t] * W + sh[t]) + (unsigned)x0 * 4u, 16);
+            s[0][t] = v.x; s[1][t] = v.y; s[2][t] = v.z; s[3][t] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 9; t++) {
+            const int shf = shift[y * 9 + t];
+            if (shf == 0 && sr[t] == y) { s[0][t] = Tc.x; s[1][t] = Tc.y; s[2][t] = Tc.z; s[3][t] = Tc.w; continue; }
+            const float *row = T + (size_t)sr[t] * W;
+            int i = x0 + shf;
+            if (c.lonwrap && i >= W) i -= W;         // shf is a forward distance in [0, W)
+            if (i >= 0 && i + 3 < W) {
+                float4 v;
+                __builtin_memcpy(&v, row + i, 16);
+                s[0][t] = v.x; s[1][t] = v.y; s[2][t] = v.z; s[3][t] = v.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) s[j][t] = row[temperature_shifted(c, x0 + j, shf)];
+            }
         }
     }
     const float a = asr[y], rden = rdenrow[y];

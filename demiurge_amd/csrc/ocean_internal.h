@@ -49,6 +49,7 @@ struct dmg_ocean {
         unsigned *seg_cur0 = nullptr, *seg_cur = nullptr;
         int *seg_ctl = nullptr;
         int cap = 0, waves = 0;
+        int n_flip = 0;                                  // streaming kernel: units of this list that stream southwards (they need the mirrored row tables)
         int cut_seg = 0, cut_seg2 = 0, cut_split = 0;   // streaming kernel: the cut of a launch's rows into units (the halves of a split launch share the whole launch's)
         long long cut_rows = 0;                          // rows its units write, summed (the halves of a split launch are checked against their cut)
     };
@@ -81,6 +82,9 @@ struct dmg_ocean {
     float *jcoefp = nullptr;       // [L + 32][4] = cx, 1/cx, Beta, 1/Beta of local rows -16 .. L+15, rows beyond the grid mirrored (scalar loads, no mapping)
     float *jcoef = nullptr;        // [L][8] = cx, 1/cx, Beta, 1/Beta, cy, 1/cy, -, -: a row's Jacobi coefficients in one 16-byte load (ocean_jacobi_stream.hip)
     float *jcoef2 = nullptr;       // [L][8] = the same rows as exact two-operation divisors: (h, l) of cx, of Beta, of cy with x / c == fma(x, h, x * l) (div2.hip)
+    // the streaming kernel's mirrored view of the band (units that stream southwards): the row tables reversed, built on first use
+    float *jcoef_f = nullptr, *jcoef2_f = nullptr;
+    unsigned char *rowbad_f = nullptr, *rowclass_f = nullptr;
     std::vector<unsigned char> rowbad_host;   // the same flags on the host (empty: no row is flagged), for the unit lists
     unsigned char *rowbad = nullptr; // [L] 1 = no exact pair for the row's cx or Beta: jcoef2 holds (c, 1/c) there and the kernel takes the three-operation form for that row
     bool div2_ok = false;          // cy has an exact pair (the rows' own divisors are handled row by row)

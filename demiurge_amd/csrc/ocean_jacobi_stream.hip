@@ -47,6 +47,9 @@
                                   // lane), and the coefficient table of 232 + 22 rows leaves its LDS at 19424 bytes: 8 waves share 160 KB
 #define STN_MAXROWS 104           // narrow form: two class registers
 #define ST_RING 12                // ring slots (rows): 10 rows are in flight between level 0 and level 8, two arrive
+#ifndef ST_FLIP_DEFAULT
+#define ST_FLIP_DEFAULT 1         // every other segment of a cut streams southwards (DMG_ST_FLIP=0/1 overrides)
+#endif
 #ifndef ST_OPEN_UNITS
 #define ST_OPEN_UNITS 1           // units whose whole window is plain open water run st_open_unit (0: every unit generic, round 3's kernel)
 #endif
@@ -58,6 +61,8 @@ struct st_args {
     const unsigned char *code;
     const float *jcoef;             // [L][8] = cx, rx, beta, rb, cy, ry, -, -  per local row (r* = correctly rounded reciprocals)
     int W, L;
+    long rs;                        // elements from a local row to the next: W -- or -W for the units that stream southwards (below)
+    int flipped;                    // 1: this is the mirrored view of the band that the southward units run on
     int y_first, H;                 // grid row of local row 0; grid height
     int spole, npole;
     const unsigned char *rowclass;  // [tiles_x][L]: 0 open ocean, 1 land everywhere, 2 mixed; or null
@@ -309,8 +314,8 @@ __device__ __forceinline__ void st_level(const st_args &a, st_state &z, v4f (*br
     }
     else if (lane_ok && !ST_DBG(a, 2)) {                          // never re-read in this launch; land rows hold 0 in both buffers already
         // only the unit's own rows [r0, r1): in its first steps level 8 runs on rows below r0, never stored
-        if (!landA && yA >= r0 && yA < r1) __builtin_nontemporal_store(st_to_memory(oA), reinterpret_cast<v4f *>(a.pout + (size_t)yA * a.W + xcol));
-        if (!landB && yA + 1 >= r0 && yA + 1 < r1) __builtin_nontemporal_store(st_to_memory(oB), reinterpret_cast<v4f *>(a.pout + (size_t)(yA + 1) * a.W + xcol));
+        if (!landA && yA >= r0 && yA < r1) __builtin_nontemporal_store(st_to_memory(oA), reinterpret_cast<v4f *>(a.pout + (long)yA * a.rs + xcol));
+        if (!landB && yA + 1 >= r0 && yA + 1 < r1) __builtin_nontemporal_store(st_to_memory(oB), reinterpret_cast<v4f *>(a.pout + (long)(yA + 1) * a.rs + xcol));
     }
 }
 
@@ -350,10 +355,10 @@ __device__ __forceinline__ void st_fetch(const st_args &a, st_state &z, int set,
     int ml = 0;
     if (!P && z.plain && !ST_DBG(a, 1)) {
         bp = reinterpret_cast<const char *>(z.nx_p); bb = reinterpret_cast<const char *>(z.nx_b); bc = reinterpret_cast<const char *>(z.nx_c);
-        z.nx_p += a.W; z.nx_b += a.W; z.nx_c += a.W;
+        z.nx_p += a.rs; z.nx_b += a.rs; z.nx_c += a.rs;
     } else {
         const st_row m = st_map_row(a, ST_DBG(a, 1) ? (e & 63) : e);
-        const size_t rowoff = (size_t)m.l * a.W;
+        const long rowoff = (long)m.l * a.rs;
         bp = reinterpret_cast<const char *>(a.pin + rowoff); bb = reinterpret_cast<const char *>(a.b + rowoff); bc = reinterpret_cast<const char *>(a.code + rowoff);
         shift = m.shift; ml = m.l;
     }
@@ -393,7 +398,8 @@ __device__ __forceinline__ void st_arrive(const st_args &a, st_state &z, v4f (*b
     if (cls == 2u) {
         unsigned c = z.cs[K][j];
         const st_row m = st_map_row(a, e);
-        if (m.flip) c = (c & 0xFCFCFCFCu) | ((c & 0x01010101u) << 1) | ((c & 0x02020202u) >> 1);   // mirrored row: swap N/S bits
+        // mirrored row: swap N/S bits -- and so for every row of a unit that streams southwards (its north is the band's south)
+        if (m.flip != (a.flipped != 0)) c = (c & 0xFCFCFCFCu) | ((c & 0x01010101u) << 1) | ((c & 0x02020202u) >> 1);
         // a non-pole edge row's clamp bit only says "the tap lands on the cell itself"; its mirror row is in the window
         const int yg = a.y_first + e;
         if (yg == 0 && !a.spole) c &= ~0x02020202u;
@@ -640,15 +646,33 @@ __device__ __forceinline__ void st_open_unit(const st_args &a, v4f (*bring)[64],
 }
 
 // one wave per unit; two waves per SIMD leave 256 registers each: all issue slots of a SIMD belong to two fat waves
+// Units that stream SOUTHWARDS (round 4).  The kernel is bound by its bytes (above), and a unit of n rows reads n + 16: the
+// eight rows beyond each end are read again by the unit above and the unit below -- 9 % of a 180-row unit's reads, 36 % of a
+// 28-row unit's (a 1024-row band of an 8-GPU split).  A unit that streams northwards reads its lower halo FIRST and its upper
+// halo LAST; its neighbour above, streaming northwards too, reads those same rows first, a whole unit's time earlier or
+// later: by then they have left the L2.  So every other segment of the cut streams the other way: a northward unit and the
+// southward unit above it END on the same sixteen rows, that southward unit and the northward unit above IT START on the same
+// sixteen rows -- at the same time when they were dispatched together (a band's single round), behind the same L2 (units of
+// a strip share an XCD: st_units' XCD-aware order) -- and one of the two finds them in the cache.
+// A southward unit is the same program on the mirrored band: the kernel takes a second view of the band (`a_dn`: pointers to
+// the last row, a negative row stride, the row tables reversed, y_first and the poles mirrored, a unit's rows counted from
+// the top) and a unit's flag picks the view.  The formula is symmetric in north and south -- (pS + pN) and the land-neighbour
+// counts commute -- and the code bits are swapped on arrival like a mirrored row's: the same bits, by construction and by
+// tests/stream_worker.py (every case runs with and without DMG_ST_FLIP).
+// Measured (profiles/r04_southward_units.txt, one build, DMG_ST_FLIP=0/1, two repetitions each): 16384x8192 survey 3.931 / 3.938 ->
+// 3.959 / 3.970 M (+0.8 %), all-ocean 2.933 / 2.943 -> 2.997 / 2.998 M (+2.0 %), 16384x2048 +0.5 / +1.5 %, a 16384x1024 band
+// +0.2 % / within its noise (the middle band of an 8-way split with its ghost rows: 59.8 -> 59.3 us per launch).  Small, never a
+// loss: the default.  What it says about the small band: its 36 % of re-read halo rows are not what it waits for.
 template <int DV>
-__global__ __launch_bounds__(64, 2) void k_jacobi_stream(st_args a)
+__global__ __launch_bounds__(64, 2) void k_jacobi_stream(st_args a_up, st_args a_dn)
 {
     __shared__ v4f bring[ST_RING][64];
     __shared__ unsigned cring[ST_RING][64];          // coast rows: land-neighbour counts, eight fp4 values per row and lane (st_row_any)
     __shared__ v4f ktab[ST_MAXROWS + 2 * TB_T + 6];   // coefficients {cx, 1/cx, Beta, 1/Beta} of every window row, filled once
     const int lane = threadIdx.x;
-    const int4 u = a.units[blockIdx.x];
+    const int4 u = a_up.units[blockIdx.x];
     const int tx = __builtin_amdgcn_readfirstlane(u.x), r0 = __builtin_amdgcn_readfirstlane(u.y), r1 = __builtin_amdgcn_readfirstlane(u.z);
+    const st_args &a = (__builtin_amdgcn_readfirstlane(u.w) & 2) ? a_dn : a_up;                // bit 1: a unit that streams southwards (its rows are the mirrored view's)
     const int W = a.W;
     if (ST_OPEN_UNITS && !ST_DBG(a, 1) && (__builtin_amdgcn_readfirstlane(u.w) & 1)) {       // an open-water unit (st_units flags it)
         if (a.prof && lane == 0) {
@@ -683,7 +707,7 @@ __global__ __launch_bounds__(64, 2) void k_jacobi_stream(st_args a)
     {
         const int e_last = e0 + 2 * nsteps + 5;             // the last row a step requests (st_step: e_t + 5)
         z.plain = e0 >= 0 && e_last < a.L && a.y_first + e0 >= 0 && a.y_first + e_last < a.H;
-        z.nx_p = a.pin + (size_t)e0 * W; z.nx_b = a.b + (size_t)e0 * W; z.nx_c = a.code + (size_t)e0 * W;
+        z.nx_p = a.pin + (long)e0 * a.rs; z.nx_b = a.b + (long)e0 * a.rs; z.nx_c = a.code + (long)e0 * a.rs;
     }
     st_fetch<false>(a, z, 0, 0, e0, col, colp);
     st_fetch<false>(a, z, 0, 1, e0 + 1, col, colp);
@@ -1142,7 +1166,7 @@ static int st_unit_rows()                                 // DMG_ST_ROWS=<n>: fi
 }
 
 namespace {
-struct st_unit { int tx, r0, r1; float cost; };
+struct st_unit { int tx, r0, r1; float cost; int flip = 0; };    // flip: the unit streams southwards (k_jacobi_stream's second view)
 }
 
 // Units of a launch over local rows [lo, hi) for one unit height: every strip cut into segments of `seg` rows, each trimmed
@@ -1167,7 +1191,11 @@ static void st_cut(const dmg_ocean *o, int variant, int lo, int hi, int seg, int
     // behind is the interior units of one launch (~57 us on a 1024-row band) -- see profiles/r03_fake_link.log
     const bool zones = edge_seg > 0 && zone_lo >= lo && zone_hi <= hi && zone_lo <= zone_hi;
     const int mid_lo = zones ? zone_lo : lo, mid_hi = zones ? zone_hi : hi;
-    for (int s0 = lo; s0 < hi;) {
+    // every other segment streams southwards (k_jacobi_stream): neighbouring units then start, or end, on the rows they share
+    static const int flip_env = [] { const char *e = getenv("DMG_ST_FLIP"); return e ? atoi(e) : -1; }();
+    const bool flipping = variant == 0 && (flip_env >= 0 ? flip_env != 0 : ST_FLIP_DEFAULT != 0);
+    int segi = 0;
+    for (int s0 = lo; s0 < hi; segi++) {
         int s1;
         if (s0 < mid_lo) s1 = std::min(s0 + edge_seg, mid_lo);
         else if (s0 >= mid_hi) s1 = std::min(s0 + edge_seg, hi);
@@ -1210,7 +1238,7 @@ static void st_cut(const dmg_ocean *o, int variant, int lo, int hi, int seg, int
                 for (int r = r0 - TB_T; all_open && r < r1 + TB_T + 6; r++) all_open = cls[r] == 0;
                 if (all_open) cost *= w_openunit;
             }
-            units.push_back(st_unit{ tx, r0, r1, cost + unit_cost });
+            units.push_back(st_unit{ tx, r0, r1, cost + unit_cost, (flipping && (segi & 1)) ? 1 : 0 });
         }
         }
     }
@@ -1507,7 +1535,7 @@ static const dmg_ocean::tile_list *st_units(dmg_ocean *o, int variant, int lo, i
     // steps request past the window, is plain open water with exact divisor pairs inside the grid and the stored band
     static const bool open_units = [] { const char *e = getenv("DMG_ST_OPEN_UNITS"); return e && atoi(e) != 0; }();     // (measured: no gain; off by default)
     const std::vector<unsigned char> &ctab = o->rowclass_host;
-    int n_open = 0;
+    int n_open = 0, n_flip = 0;
     for (const st_unit &u : best) {
         int flag = 0;
         if (open_units && variant == 0 && !ctab.empty()) {
@@ -1519,14 +1547,16 @@ static const dmg_ocean::tile_list *st_units(dmg_ocean *o, int variant, int lo, i
             flag = ok ? 1 : 0;
         }
         n_open += flag;
-        flat.push_back(u.tx); flat.push_back(u.r0); flat.push_back(u.r1); flat.push_back(flag);
+        if (u.flip && !flag) { flat.push_back(u.tx); flat.push_back(o->L - u.r1); flat.push_back(o->L - u.r0); flat.push_back(2); n_flip++; }   // the mirrored view's rows
+        else { flat.push_back(u.tx); flat.push_back(u.r0); flat.push_back(u.r1); flat.push_back(flag); }
     }
     {
         static const bool dbg = getenv("DMG_ST_DEBUG") != nullptr;
-        if (dbg) fprintf(stderr, "[stream] rows [%d,%d) part %d: %d of %zu units are open-water units\n", lo, hi, part, n_open, best.size());
+        if (dbg) fprintf(stderr, "[stream] rows [%d,%d) part %d: %d of %zu units are open-water units, %d stream southwards\n", lo, hi, part, n_open, best.size(), n_flip);
     }
     dmg_ocean::tile_list tl;
     tl.n = (int)best.size();
+    tl.n_flip = n_flip;
     tl.cut_seg = cut_seg; tl.cut_seg2 = cut_seg2; tl.cut_split = cut_split;
     tl.cut_rows = 0;
     for (const st_unit &u : best) tl.cut_rows += u.r1 - u.r0;
@@ -1549,6 +1579,41 @@ static const dmg_ocean::tile_list *st_units(dmg_ocean *o, int variant, int lo, i
             hipMemcpy(tl.seg_cur0, c0.data(), c0.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return nullptr;
     }
     return &(o->tb_lists[key] = tl);
+}
+
+// the row tables of the mirrored view (k_jacobi_stream's southward units): local row l' of that view is row L - 1 - l'
+static int ocean_stream_flipped_tables(dmg_ocean *o)
+{
+    if (o->jcoef_f) return DMG_OK;
+    const int L = o->L;
+    const size_t nj = (size_t)L * 8;
+    std::vector<float> j(nj), jf(nj);
+    auto flip_j = [&](const float *src, float **dst) -> int {
+        DMG_HIP(hipMemcpy(j.data(), src, nj * sizeof(float), hipMemcpyDeviceToHost));
+        for (int l = 0; l < L; l++) memcpy(&jf[(size_t)l * 8], &j[(size_t)(L - 1 - l) * 8], 8 * sizeof(float));
+        DMG_HIP(hipMalloc((void **)dst, nj * sizeof(float)));
+        DMG_HIP(hipMemcpy(*dst, jf.data(), nj * sizeof(float), hipMemcpyHostToDevice));
+        return DMG_OK;
+    };
+    DMG_HIP(hipStreamSynchronize(o->ctx->stream));
+    int rc;
+    if ((rc = flip_j(o->jcoef, &o->jcoef_f)) || (rc = flip_j(o->jcoef2, &o->jcoef2_f))) return rc;
+    {
+        std::vector<unsigned char> b((size_t)L, 0), bf((size_t)L);
+        DMG_HIP(hipMemcpy(b.data(), o->rowbad, (size_t)L, hipMemcpyDeviceToHost));
+        for (int l = 0; l < L; l++) bf[l] = b[L - 1 - l];
+        DMG_HIP(hipMalloc((void **)&o->rowbad_f, (size_t)L));
+        DMG_HIP(hipMemcpy(o->rowbad_f, bf.data(), (size_t)L, hipMemcpyHostToDevice));
+    }
+    if (!o->rowclass_host.empty()) {
+        const size_t n = o->rowclass_host.size(), tiles_x = n / (size_t)L;
+        std::vector<unsigned char> cf(n);
+        for (size_t tx = 0; tx < tiles_x; tx++)
+            for (int l = 0; l < L; l++) cf[tx * L + l] = o->rowclass_host[tx * L + (L - 1 - l)];
+        DMG_HIP(hipMalloc((void **)&o->rowclass_f, n));
+        DMG_HIP(hipMemcpy(o->rowclass_f, cf.data(), n, hipMemcpyHostToDevice));
+    }
+    return DMG_OK;
 }
 
 // 8 sweeps over local rows [lo, hi) from p[from] into p[from ^ 1]; seg = rows per unit (0: the default)
@@ -1575,6 +1640,7 @@ int ocean_launch_stream(dmg_ocean *o, int lo, int hi, int part, int zone_lo, int
     a.rowbad = div2 && o->div2_nbad ? o->rowbad : nullptr;
     a.jcoef_cy = o->jcoef + 4;                           // row 0's {cy, 1/cy}: the same for every row
     a.W = o->grid.W; a.L = o->L;
+    a.rs = o->grid.W; a.flipped = 0;
     a.y_first = o->y0 - o->gs; a.H = o->grid.H;
     a.spole = o->topo.spole ? 1 : 0; a.npole = o->topo.npole ? 1 : 0;
     static const bool use_cls = getenv("DMG_TB_NOCLASS") == nullptr;
@@ -1621,8 +1687,25 @@ int ocean_launch_stream(dmg_ocean *o, int lo, int hi, int part, int zone_lo, int
         }
     }
     else if (variant) hipLaunchKernelGGL(k_jacobi_stream_n, dim3((unsigned)tl->n), dim3(64), (size_t)extra_lds, st, a);
-    else if (div2) hipLaunchKernelGGL(k_jacobi_stream<1>, dim3((unsigned)tl->n), dim3(64), (size_t)extra_lds, st, a);
-    else hipLaunchKernelGGL(k_jacobi_stream<0>, dim3((unsigned)tl->n), dim3(64), (size_t)extra_lds, st, a);
+    else {
+        // the mirrored view of the band for the units that stream southwards: pointers to the last stored row, a negative row
+        // stride, the row tables reversed (built once per ocean and terrain), grid rows and poles mirrored
+        st_args ad = a;
+        if (tl->n_flip) {
+            int rc = ocean_stream_flipped_tables(o);
+            if (rc) return rc;
+            const long last = (long)(o->L - 1) * o->grid.W;
+            ad.pin = a.pin + last; ad.pout = a.pout + last; ad.b = a.b + last; ad.code = a.code + last;
+            ad.rs = -(long)o->grid.W; ad.flipped = 1;
+            ad.jcoef = div2 ? o->jcoef2_f : o->jcoef_f;
+            ad.rowbad = a.rowbad ? o->rowbad_f : nullptr;
+            ad.rowclass = a.rowclass ? o->rowclass_f : nullptr;
+            ad.y_first = o->grid.H - a.y_first - o->L;
+            ad.spole = a.npole; ad.npole = a.spole;
+        }
+        if (div2) hipLaunchKernelGGL(k_jacobi_stream<1>, dim3((unsigned)tl->n), dim3(64), (size_t)extra_lds, st, a, ad);
+        else hipLaunchKernelGGL(k_jacobi_stream<0>, dim3((unsigned)tl->n), dim3(64), (size_t)extra_lds, st, a, ad);
+    }
     DMG_HIP(hipGetLastError());
 #ifdef ST_EXPERIMENTS
     if (a.stepprof) {

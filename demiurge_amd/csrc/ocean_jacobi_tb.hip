@@ -310,6 +310,9 @@ void ocean_tb_free_lists(dmg_ocean *o)
         for (void *q : { (void *)kv.second.d, (void *)kv.second.seg_word0, (void *)kv.second.seg_word, (void *)kv.second.seg_cur0, (void *)kv.second.seg_cur, (void *)kv.second.seg_ctl })
             if (q) (void)hipFree(q);
     o->tb_lists.clear();
+    // (the streaming kernel's mirrored row tables: the classes change with the terrain, the lists go with it)
+    for (void *q : { (void *)o->jcoef_f, (void *)o->jcoef2_f, (void *)o->rowbad_f, (void *)o->rowclass_f }) if (q) (void)hipFree(q);
+    o->jcoef_f = o->jcoef2_f = nullptr; o->rowbad_f = o->rowclass_f = nullptr;
     for (auto &kv : o->tb_tuning) {
         if (kv.second.ev0) (void)hipEventDestroy(kv.second.ev0);
         if (kv.second.ev1) (void)hipEventDestroy(kv.second.ev1);

@@ -372,7 +372,7 @@ def _stream_worker(env_extra, cases, timeout=900):
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "stream_worker.py")] + cases, cwd=root, env=env,
                        capture_output=True, text=True, timeout=timeout)
     assert r.returncode == 0 and "bit-identical" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
-    return r.stdout
+    return r.stdout + r.stderr
 
 
 @pytest.mark.gpu
@@ -414,6 +414,23 @@ def test_streaming_open_water_units_vs_oracle(env):
     if env.get("DMG_ST_OPEN_UNITS") != "0":
         import re
         assert any(int(m) > 0 for m in re.findall(r"(\d+) of \d+ units are open-water units", out)), out[-1500:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flip", ["0", "1"])
+def test_streaming_southward_units_vs_oracle(flip):
+    """Round 4: every other segment of the streaming kernel's cut can stream SOUTHWARDS -- the same program on a mirrored view of
+    the band (negative row stride, reversed row tables, mirrored poles, code bits swapped on arrival) -- so that neighbouring
+    units start, or end, on the halo rows they share and one of them finds those rows in the L2.  With and without it: the
+    random geometries (poles, belts, odd sizes, all-land and all-water rows), salt-and-pepper coasts, the 5000-sweep golden
+    against llvmpipe, band splits and split launches, open-water grids at several unit heights -- against the oracle."""
+    env = {"DMG_TB_SHAPE": "stream", "DMG_ST_FLIP": flip, "DMG_ST_DEBUG": "1"}
+    out = _stream_worker(env, ["random", "pepper", "golden", "bands", "split", "open"], timeout=1500)
+    import re
+    n = sum(int(m) for m in re.findall(r"(\d+) stream southwards", out))
+    assert (n > 0) == (flip == "1"), out[-1500:]
+    _stream_worker(dict(env, DMG_ST_ROWS="24"), ["open", "pepper"])
+    _stream_worker(dict(env, DMG_DIV2_FORCE_BAD="7"), ["random"])
 
 
 @pytest.mark.gpu

@@ -82,14 +82,17 @@ def test_config5_at_size(dev):
     grid = capi.make_grid(W, H)
     terrain, T0 = inputs(W, H)
     p = capi.World.default_params()
-    p.tectonics_steps, p.erosion_rounds, p.climate_steps = 1, 1, 12
+    # (three climate steps: the reference's explicit scheme is unstable at this resolution -- its diffusion number is ~10 where
+    # the limit is 1/4 -- five steps reach 5e4 at the poles and forty overflow fp32, identically in both forms; with one ghost row
+    # the bands exchange before every step)
+    p.tectonics_steps, p.erosion_rounds, p.climate_steps = 1, 1, 3
     runs = []
     w = capi.World(ctx, grid, terrain, T0)
     w.step(p)
     runs.append(w.get())
     w.close()
     ctx.trim()
-    m = capi.MultiWorld(grid, terrain, T0, devices=[0] * 8, ghost=8, flags=capi.MULTI_STORE)
+    m = capi.MultiWorld(grid, terrain, T0, devices=[0] * 8, ghost=1, flags=capi.MULTI_STORE)
     m.step(p)
     runs.append(m.get())
     m.close()

@@ -36,7 +36,7 @@ for f in glob.glob(d + "/stats/**/*kernel_stats.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         stats[r["Name"]] = (float(r["AverageNs"]) / 1e3, int(r["Calls"]))
 sq1, sq2, fe, wr = pmc("sq1"), pmc("sq2"), pmc("fetch"), pmc("write")
-print("%-20s %-28s %8s %9s %7s %9s %7s | %9s %6s %6s %6s %6s | %s" % ("kernel", "what", "us", "HBM MB", "of 8TB", "must MB", "of 8TB", "VALU/cell", "valu", "sca", "wait", "stall", "reading"))
+print("%-20s %-28s %8s %9s %7s %9s %7s | %9s %6s %6s %6s %6s %6s %5s | %s" % ("kernel", "what", "us", "HBM MB", "of 8TB", "must MB", "of 8TB", "VALU/cell", "valu", "sca", "wait", "stall", "SIMD", "waves", "reading"))
 for sub, what, b in kernels:
     us = next((v[0] for k, v in stats.items() if sub in k), None)
     if us is None:
@@ -47,12 +47,17 @@ for sub, what, b in kernels:
     g = lambda n: (of(sq2, sub, n) / wc) if wc and of(sq2, sub, n) is not None else float("nan")
     valu_n = of(sq1, sub, "SQ_INSTS_VALU")
     must = b * N
-    fr_h = hbm / us / 1e6 / 8000 if hbm else float("nan")
-    fr_m = must / us / 1e6 / 8000
+    fr_h = hbm / us / 1e6 / 8.0 if hbm else float("nan")        # bytes per us = 1e6 bytes per s: / 1e6 = TB/s, / 8 = of the peak
+    fr_m = must / us / 1e6 / 8.0
     valu, sca, wait, stall = g("SQ_ACTIVE_INST_VALU"), g("SQ_ACTIVE_INST_SCA"), g("SQ_WAIT_ANY"), g("SQ_WAIT_INST_ANY")
-    if fr_h >= 0.55: reading = "HBM-bound (at the ~0.7-0.79 a copy reaches)"
-    elif valu >= 0.45: reading = "vector-issue-bound (waves execute a VALU instruction most of the time they are not parked)"
-    elif wait >= 0.5: reading = "latency-bound: waves parked in s_waitcnt (gathers / dependent loads), neither roof near"
-    else: reading = "mixed: issue + waits"
-    print("%-20s %-28s %8.1f %9.0f %7.2f %9.0f %7.2f | %9.1f %6.2f %6.2f %6.2f %6.2f | %s" %
-          (sub.rstrip("("), what, us, (hbm or 0) / 1e6, fr_h, must / 1e6, fr_m, (valu_n or 0) * 64 / N, valu, sca, wait, stall, reading))
+    # the chip's view: SQ cycle counters tick once per four clocks; 1024 SIMDs at 2.4 GHz
+    av = of(sq2, sub, "SQ_ACTIVE_INST_VALU")
+    simd_busy = av * 4.0 / (us * 2400.0 * 1024.0) if av else float("nan")
+    waves = wc * 4.0 / (us * 2400.0 * 1024.0) if wc else float("nan")     # resident waves per SIMD, averaged over the launch
+    if fr_h >= 0.55: reading = "HBM: at the ceiling of its access shape (a copy reaches 0.79, 1-KB rows 0.69-0.70)"
+    elif simd_busy >= 0.55: reading = "vector ALU: the SIMDs execute a vector instruction most of the time"
+    elif wait >= 0.5: reading = "latency: waves parked in s_waitcnt on gathers / dependent loads, neither roof near"
+    elif stall >= 0.45: reading = "issue stalls: dependent long-latency (transcendental) chains"
+    else: reading = "between: ALU %.0f %%, HBM %.0f %% of their roofs" % (100 * simd_busy, 100 * fr_h / 0.7)
+    print("%-20s %-28s %8.1f %9.0f %7.2f %9.0f %7.2f | %9.1f %6.2f %6.2f %6.2f %6.2f %6.2f %5.1f | %s" %
+          (sub.rstrip("("), what, us, (hbm or 0) / 1e6, fr_h, must / 1e6, fr_m, (valu_n or 0) * 64 / N, valu, sca, wait, stall, simd_busy, waves, reading))

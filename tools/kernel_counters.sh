@@ -15,4 +15,5 @@ python tools/kernel_counters.py $D > $R/gpurun_out/r04_kernel_counters.txt 2>&1
 python tools/kernel_table.py $D/stats > $R/gpurun_out/r04_kernel_table.txt 2>&1
 cat $R/gpurun_out/r04_kernel_counters.txt
 # the traces are large: keep the tables only
+# (the traces are ~60 MB: only the tables are merged back)
 rm -rf $D/sq1 $D/sq2 $D/fetch $D/write

@@ -15,8 +15,11 @@ o.close()
 o1 = capi.Ocean(ctx, g, params=prm_single)
 o1.set_terrain(terrain); o1.set_divw(synth.divw(W, H)); o1.zero_pressure(); o1.jacobi_sweeps(40); ctx.sync(); o1.close()
 h = (terrain * 100 + synth.lcg_uniform(W * H, 5).reshape(H, W) * 3).astype(np.float32)
-T0 = (synth.lcg_uniform(W * H, 41).reshape(H, W) * 60).astype(np.float32)
-k = capi.Climate(ctx, g, T0, h); k.steps(0, 20); ctx.sync(); k.close()
+# (a smooth field and a dozen steps: the reference's explicit scheme is unstable at this resolution, and a field of infinities takes
+# the IEEE-division fallback in every cell -- tools/climate_time_probe.py)
+lat = np.linspace(-1, 1, H, dtype=np.float32)[:, None]
+T0 = (15 - 40 * np.abs(lat) + 3 * np.sin(np.linspace(0, 12 * np.pi, W, dtype=np.float32))[None, :]).astype(np.float32)
+k = capi.Climate(ctx, g, T0, h); k.steps(0, 12); ctx.sync(); k.close()
 ctx.erosion_run(g, h, 50, 1, 0.5, 1.0, 1.0)
 ctx.blur(g, h, 3.0)
 t = capi.Tectonics(ctx, g, h); t.step(2); ctx.sync(); t.close()
