@@ -53,6 +53,8 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+HBM_ROWS_GBS = 5550.0          # what whole 1-KB rows fetched once from all over a large buffer reach (same guide: 5.5-5.6 TB/s):
+                               # the streaming kernel's access shape (a wave reads 1 KB of a row, the next row is 64 KB further on)
 FP32_PEAK_TFLOPS = 157.3       # vector fp32 peak (same guide)
 FP32_ISSUABLE_TFLOPS = 106.0   # what packed FMAs really issue at two waves per SIMD (tools/pk_probe.hip, profiles/r03_valu_issue_probe.log)
 ALGO_BYTES_PER_CELL_STEP = 16  # read p, read divw, read terrain, write p'
@@ -541,9 +543,16 @@ def main():
         if tb:
             roof["achieved"] = tb / launch_s / 1e9
             roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
+            roof["shape_ceiling"] = HBM_ROWS_GBS
+            roof["frac_of_shape_ceiling"] = roof["achieved"] / HBM_ROWS_GBS
             roof["note"] = ("8 sweeps per launch on chip: `achieved` is the HBM traffic the launch really moves (PMC) over its "
-                            "duration; the kernel sits between that roof and the fp32 vector roof (`fp32`).  The SURVEY 8d "
-                            "model (16 B per cell-sweep) stops bounding a kernel that does 8 sweeps per HBM pass: `algorithmic_x_peak`")
+                            "duration.  Round 4 measured what binds it: a program with a third fewer instructions per step finishes "
+                            "its waves 16 % sooner and the launch no sooner -- it waits for its bytes, fetched as 1-KB pieces of rows "
+                            "64 KB apart, for which this part reaches 5.5-5.6 TB/s (`shape_ceiling`), not the 8 TB/s of `peak`.  "
+                            "Fewer bytes per launch therefore LOWER `frac` while the solve gets faster (round 3: 1.475 -> 1.364 GB, "
+                            "round 4: -> 1.33 GB).  The SURVEY 8d model (16 B per cell-sweep) stops bounding a kernel that does "
+                            "8 sweeps per HBM pass: `algorithmic_x_peak`; the HBM-bound form the 60 % target is stated for is "
+                            "`roofline_single`")
         else:
             roof["achieved"], roof["frac"] = None, None
             roof["note"] = "no PMC traffic for this configuration (%s); see algorithmic_x_peak and fp32" % tsrc

@@ -354,10 +354,20 @@ __global__ void k_multi_fake_link(unsigned long long ticks)
 // ---- store transport: the two kernels ----
 // push: `n` bytes from my rows into the neighbour's landing slot, then -- when every block's stores have reached the
 // neighbour's memory -- the sequence number into its flag word.  dst and flag are peer-mapped (or IPC-mapped) pointers into
-// another GPU's memory: the stores travel over xGMI as posted writes.
-__global__ __launch_bounds__(256) void k_store_push(const unsigned char *__restrict__ src, unsigned char *__restrict__ dst, size_t n,
-                                                    unsigned *flag, unsigned seq, unsigned *counter)
+// another GPU's memory: the stores travel over xGMI as posted writes.  One launch carries both sides of a band (blockIdx.y).
+struct store_job {                       // one side of an exchange, as a kernel argument
+    const unsigned char *src; unsigned char *dst; size_t n;
+    unsigned *flag; unsigned seq; unsigned *counter;
+    unsigned long long ticks; int *err;
+};
+struct store_jobs { store_job side[2]; };    // blockIdx.y picks the side: both sides of a band travel in ONE launch
+
+__global__ __launch_bounds__(256) void k_store_push(store_jobs jobs)
 {
+    const store_job &j = jobs.side[blockIdx.y];
+    const unsigned char *__restrict__ src = j.src;
+    unsigned char *__restrict__ dst = j.dst;
+    const size_t n = j.n;
     const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (size_t)gridDim.x * blockDim.x;
     if ((((size_t)src | (size_t)dst | n) & 15) == 0) {
         const uint4 *s4 = (const uint4 *)src; uint4 *d4 = (uint4 *)dst;
@@ -369,34 +379,37 @@ __global__ __launch_bounds__(256) void k_store_push(const unsigned char *__restr
     __threadfence_system();                                  // my stores are visible to the neighbour's GPU before ...
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned done = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1;
-        if (done == gridDim.x) {                             // ... the last block to finish publishes the slab
-            __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned done = __hip_atomic_fetch_add(j.counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1;
+        if (done == gridDim.x) {                             // ... the last block of this side to finish publishes the slab
+            __hip_atomic_store(j.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __threadfence_system();
-            __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(j.flag, j.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
 // land: wait until the neighbour's slab number `seq` is in the slot, then move it into the ghost rows.  Every block polls the
 // flag by itself (one lane, with s_sleep between reads) and gives up after `ticks` of the 100 MHz clock: it then raises the
 // band's error word and copies nothing -- every wave reaches its end whatever the neighbour does.
-__global__ __launch_bounds__(256) void k_store_land(const unsigned *flag, unsigned seq, const unsigned char *__restrict__ src,
-                                                    unsigned char *__restrict__ dst, size_t n, unsigned long long ticks, int *err)
+__global__ __launch_bounds__(256) void k_store_land(store_jobs jobs)
 {
+    const store_job &j = jobs.side[blockIdx.y];
     __shared__ int ok;
     if (threadIdx.x == 0) {
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         int good = 1;
-        while ((int)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
-            if (__builtin_amdgcn_s_memrealtime() - t0 > ticks) { good = 0; break; }
+        while ((int)(__hip_atomic_load(j.flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - j.seq) < 0) {
+            if (__builtin_amdgcn_s_memrealtime() - t0 > j.ticks) { good = 0; break; }
             __builtin_amdgcn_s_sleep(32);
         }
-        if (!good) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (!good) __hip_atomic_store(j.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         ok = good;
     }
     __syncthreads();
     if (!ok) return;
     __atomic_thread_fence(__ATOMIC_ACQUIRE);                 // (system scope: what the neighbour stored, not what a cache remembers)
+    const unsigned char *__restrict__ src = j.src;
+    unsigned char *__restrict__ dst = j.dst;
+    const size_t n = j.n;
     const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (size_t)gridDim.x * blockDim.x;
     if ((((size_t)src | (size_t)dst | n) & 15) == 0) {
         const uint4 *s4 = (const uint4 *)src; uint4 *d4 = (uint4 *)dst;
@@ -587,26 +600,27 @@ static int band_exchange(dmg_multi *m, int i, int field, int rows, int buffer = 
             if (bytes[side] && bytes[side] != total) return dmg_fail(DMG_EINVAL, "store transport: a slab of %zu bytes where %zu were expected", bytes[side], total);
         for (size_t off = 0; off < total; off += m->slot_bytes) {
             const size_t piece = std::min(m->slot_bytes, total - off);
+            store_jobs pj{}, lj{};
+            int ns = 0;
             for (int side = 0; side < 2; side++) {
                 if (!bytes[side]) continue;
                 store_side &ss = sb.side[side];
                 const unsigned q = ++ss.seq;
-                const unsigned blocks = (unsigned)std::min<size_t>(128, (piece + 65535) / 65536 * 4);
-                hipLaunchKernelGGL(k_store_push, dim3(blocks), dim3(256), 0, st, (const unsigned char *)send[side] + off,
-                                   ss.r_land + (size_t)(q & 1) * m->slot_bytes, piece, ss.r_flag, q, ss.counter);
-                DMG_HIP(hipGetLastError());
+                pj.side[ns] = store_job{ (const unsigned char *)send[side] + off, ss.r_land + (size_t)(q & 1) * m->slot_bytes, piece, ss.r_flag, q, ss.counter, 0ull, nullptr };
+                lj.side[ns] = store_job{ ss.land + (size_t)(q & 1) * m->slot_bytes, (unsigned char *)recv[side] + off, piece, ss.flag, q, nullptr, ticks, sb.err_dev };
+                ns++;
                 if (i == 0) m->exchange_bytes += 2 * (long long)piece;
+            }
+            const unsigned pblocks = (unsigned)std::min<size_t>(128, (piece + 65535) / 65536 * 4), lblocks = (unsigned)std::min<size_t>(64, (piece + 65535) / 65536 * 2);
+            if (ns) {
+                hipLaunchKernelGGL(k_store_push, dim3(pblocks, (unsigned)ns), dim3(256), 0, st, pj);
+                DMG_HIP(hipGetLastError());
             }
             // bands of one process that share a GPU: nobody's landing kernel is queued before everybody's push is -- a landing
             // kernel polls for a push that, on a shared hardware queue, could otherwise sit behind it
             if (m->same_device) TEAM_BARRIER(m);
-            for (int side = 0; side < 2; side++) {
-                if (!bytes[side]) continue;
-                store_side &ss = sb.side[side];
-                const unsigned q = ss.seq;
-                const unsigned blocks = (unsigned)std::min<size_t>(64, (piece + 65535) / 65536 * 2);
-                hipLaunchKernelGGL(k_store_land, dim3(blocks), dim3(256), 0, st, ss.flag, q, ss.land + (size_t)(q & 1) * m->slot_bytes,
-                                   (unsigned char *)recv[side] + off, piece, ticks, sb.err_dev);
+            if (ns) {
+                hipLaunchKernelGGL(k_store_land, dim3(lblocks, (unsigned)ns), dim3(256), 0, st, lj);
                 DMG_HIP(hipGetLastError());
             }
             if (m->same_device) TEAM_BARRIER(m);

@@ -3,7 +3,8 @@ of the 16384x8192 grid over 8 GPUs) driven by dmg_multi over the RCCL loopback t
 so that what the exchange costs, and what the overlapped order hides of it, shows as it would on a rank that has the GPU to
 itself.  Run it under `rocprofv3 --kernel-trace` and feed the trace to tools/overlap_trace.py.
 usage: python tools/overlap_probe.py <order: plain|overlap> [rows per band [bands [sweeps [ghost]]]]"""
-import sys, time
+import os, sys, time
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # the overlapped order needs eight hardware queues, asked for before HIP starts
 import numpy as np
 sys.path.insert(0, ".")
 from demiurge_amd import capi, synth

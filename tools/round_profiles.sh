@@ -1,7 +1,7 @@
 # the evidence set of a round: run on the GPU box (gpurun -- 'bash tools/round_profiles.sh'), then copy what is to be judged
 # from gpurun_out/ into profiles/.  R = round tag.
 set -o pipefail
-R=${R:-r03}
+R=${R:-r04}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 # PART=tests: the GPU test suite alone (a gpurun call is at most 1200 s); PART=profiles (default): everything else
 if [ "${PART:-profiles}" = tests ]; then
@@ -26,6 +26,8 @@ DMG_FLOW_TIMING=1 python tools/flow_timing.py > gpurun_out/${R}_flow_timing.log 
 python tools/config2_phases.py 1000 > gpurun_out/${R}_config2_phases.log 2>&1; cat gpurun_out/${R}_config2_phases.log
 for n in 8 4 2; do python tools/band_probe.py $n 32 2>&1 | grep bands; done > gpurun_out/${R}_band_probe.log; cat gpurun_out/${R}_band_probe.log
 timeout -k 10 300 python tools/bands_one_gpu.py 1600 loopback > gpurun_out/${R}_bands_one_gpu_loopback.log 2>&1; grep bands gpurun_out/${R}_bands_one_gpu_loopback.log
+timeout -k 10 300 python tools/bands_one_gpu.py 1600 store > gpurun_out/${R}_bands_one_gpu_store.log 2>&1; grep bands gpurun_out/${R}_bands_one_gpu_store.log
+timeout -k 10 300 python tools/bands_one_gpu.py 1600 peer > gpurun_out/${R}_bands_one_gpu_peer.log 2>&1; grep bands gpurun_out/${R}_bands_one_gpu_peer.log
 rm -f gpurun_out/${R}_overlap_probe.log
 for o in plain overlap; do
   python tools/overlap_probe.py $o 1024 2 640 32 2>&1 | grep order >> gpurun_out/${R}_overlap_probe.log
