@@ -73,6 +73,27 @@ def test_multi_world_on_a_fake_cluster_equals_world(dev, bands, ghost, transport
         assert np.array_equal(got[k], ref[k]), k
 
 
+def test_multi_world_single_rank_form(dev):
+    """the one-process-per-GPU form with one rank (replicas: every rank runs tectonics and erosion itself, the climate band is
+    its own): equals dmg_world"""
+    capi, ctx = dev
+    W, H = 256, 128
+    grid = capi.make_grid(W, H)
+    terrain, T0 = inputs(W, H)
+    p = capi.World.default_params()
+    p.tectonics_steps, p.erosion_rounds, p.climate_steps = 1, 1, 7
+    w = capi.World(ctx, grid, terrain, T0)
+    w.step(p); w.step(p)
+    ref = w.get()
+    w.close()
+    m = capi.MultiWorld(grid, terrain, T0, rank=0, world=1, unique_id=None, device=0, ghost=4)
+    m.step(p); m.step(p)
+    got = m.get()
+    m.close()
+    for k in ("terrain", "eroded", "T"):
+        assert np.array_equal(got[k], ref[k]), k
+
+
 def test_config5_at_size(dev):
     """16384x8192: one coupled iteration (tectonics step -> erosion round -> climate steps) on one GPU (dmg_world) and as the
     8-band split of BASELINE config 5 (dmg_multi_world: the bands on this box's one GPU, the store transport): finite, the two
