@@ -1169,6 +1169,34 @@ namespace {
 struct st_unit { int tx, r0, r1; float cost; int flip = 0; };    // flip: the unit streams southwards (k_jacobi_stream's second view)
 }
 
+// what the dispatch simulation charges a unit of rows [r0, r1) of a strip (cls: the strip's row classes, or null): its
+// level-rows, a coast row counted 1.4 times an open one and a land row a tenth (what the kernel spends on them), plus what a
+// unit costs before and after its rows
+static float st_unit_cost(const unsigned char *cls, int L, int r0, int r1, int variant)
+{
+    static const float w_mixed = [] { const char *e = getenv("DMG_ST_WMIXED"); return e ? (float)atof(e) : 1.4f; }();    // experiments: the cost model's weights (1.4: best of a sweep 1.0 .. 1.6 on the survey terrain; the per-unit timings fit 1.23 .. 1.40)
+    static const float w_land = [] { const char *e = getenv("DMG_ST_WLAND"); return e ? (float)atof(e) : 0.1f; }();
+    float cost = 0.0f;
+    for (int r = r0 - TB_T; r < r1 + TB_T; r++) {
+        const int c = (cls && r >= 0 && r < L) ? cls[r] : 2;
+        const int depth = std::min(std::min(r - (r0 - TB_T), (r1 + TB_T - 1) - r), TB_T);   // levels that still need this row
+        cost += (c == 1 ? w_land : (c == 2 ? w_mixed : 1.0f)) * (float)depth;
+    }
+    // + what a unit costs before and after its rows: dispatch, the class and coefficient tables, the first loads' round
+    // trip, the last stores.  Per-unit timings (DMG_ST_PROF) fit duration = 0.152 us x cost + 22 us: ~140 cost units,
+    // not the 4 the first version assumed -- which made the simulation prefer many short units
+    static const float unit_cost = [] { const char *e = getenv("DMG_ST_UNITCOST"); return e ? (float)atof(e) : 140.0f; }();
+    // an open-water unit (st_open_unit: no row of its window is anything but open water) spends ~440 instead of ~590
+    // instructions per step
+    static const float w_openunit = [] { const char *e = getenv("DMG_ST_WOPEN"); return e ? (float)atof(e) : 1.0f; }();     // (experiments; 0.78 is what their instruction count suggests and what made the cut worse)
+    if (cls && !variant && w_openunit != 1.0f) {
+        bool all_open = r0 - TB_T >= 0 && r1 + TB_T + 6 <= L;
+        for (int r = r0 - TB_T; all_open && r < r1 + TB_T + 6; r++) all_open = cls[r] == 0;
+        if (all_open) cost *= w_openunit;
+    }
+    return cost + unit_cost;
+}
+
 // Units of a launch over local rows [lo, hi) for one unit height: every strip cut into segments of `seg` rows, each trimmed
 // to its first / last row that is not land everywhere; empty ones are dropped.  cost ~ the unit's level-rows, a coast row
 // counted 1.4 times an open one and a land row a tenth (what the kernel spends on them).
@@ -1176,8 +1204,6 @@ static void st_cut(const dmg_ocean *o, int variant, int lo, int hi, int seg, int
                    int seg2 = 0, int split = 0, int edge_seg = 0)
 {
     const int ow = variant ? STN_OW : TB_OW;
-    static const float w_mixed = [] { const char *e = getenv("DMG_ST_WMIXED"); return e ? (float)atof(e) : 1.4f; }();    // experiments: the cost model's weights (1.4: best of a sweep 1.0 .. 1.6 on the survey terrain; the per-unit timings fit 1.23 .. 1.40)
-    static const float w_land = [] { const char *e = getenv("DMG_ST_WLAND"); return e ? (float)atof(e) : 0.1f; }();
     const std::vector<unsigned char> &table = variant ? o->rowclass_n_host : o->rowclass_host;
     const int tiles_x = (o->grid.W + ow - 1) / ow, L = o->L;
     const bool classes = !table.empty();
@@ -1220,26 +1246,115 @@ static void st_cut(const dmg_ocean *o, int variant, int lo, int hi, int seg, int
                 const bool edge = r0 < zone_lo || r1 > zone_hi;
                 if (edge != (part == 1)) continue;
             }
-            float cost = 0.0f;
-            for (int r = r0 - TB_T; r < r1 + TB_T; r++) {
-                const int c = (cls && r >= 0 && r < L) ? cls[r] : 2;
-                const int depth = std::min(std::min(r - (r0 - TB_T), (r1 + TB_T - 1) - r), TB_T);   // levels that still need this row
-                cost += (c == 1 ? w_land : (c == 2 ? w_mixed : 1.0f)) * (float)depth;
-            }
-            // + what a unit costs before and after its rows: dispatch, the class and coefficient tables, the first loads' round
-            // trip, the last stores.  Per-unit timings (DMG_ST_PROF) fit duration = 0.152 us x cost + 22 us: ~140 cost units,
-            // not the 4 the first version assumed -- which made the simulation prefer many short units
-            static const float unit_cost = [] { const char *e = getenv("DMG_ST_UNITCOST"); return e ? (float)atof(e) : 140.0f; }();
-            // an open-water unit (st_open_unit: no row of its window is anything but open water) spends ~440 instead of ~590
-            // instructions per step
-            static const float w_openunit = [] { const char *e = getenv("DMG_ST_WOPEN"); return e ? (float)atof(e) : 1.0f; }();     // (experiments; 0.78 is what their instruction count suggests and what made the cut worse)
-            if (cls && !variant && w_openunit != 1.0f) {
-                bool all_open = r0 - TB_T >= 0 && r1 + TB_T + 6 <= L;
-                for (int r = r0 - TB_T; all_open && r < r1 + TB_T + 6; r++) all_open = cls[r] == 0;
-                if (all_open) cost *= w_openunit;
-            }
+            const float cost = st_unit_cost(cls, L, r0, r1, variant), unit_cost = 0.0f;
             units.push_back(st_unit{ tx, r0, r1, cost + unit_cost, (flipping && (segi & 1)) ? 1 : 0 });
         }
+        }
+    }
+}
+
+// A cut for launches of about one round (round 4).  A band of a thousand rows has about as many units as the chip has wave
+// slots, so the launch lasts as long as its SLOWEST unit -- and with one height for every strip the slowest are the coast
+// units (a coast row costs 1.4 of an open one): of a 16384 x 1024 band's 1831 units the median takes 59 us, the launch 65
+// (DMG_ST_PROF), while 11 % of the slots stay empty.  Here the middle zone of the launch is cut strip by strip into `want`
+// units of about EQUAL COST: every stretch of water (land runs of 24 rows and more are left out) starts as one unit, and the
+// stretch whose units are the most expensive gets one more until `want` are dealt out; a stretch's units then split its rows
+// at equal cumulative cost.  The send zones of a split launch keep their short units (st_cut).  Which cut a launch takes
+// is still decided by the simulated dispatch (st_units): this one is a candidate at one, two and three rounds' worth of units.
+static void st_cut_balanced(const dmg_ocean *o, int lo, int hi, int want, int part, int zone_lo, int zone_hi, std::vector<st_unit> &units, int edge_seg = 0)
+{
+    const std::vector<unsigned char> &table = o->rowclass_host;
+    const int tiles_x = (o->grid.W + TB_OW - 1) / TB_OW, L = o->L;
+    const bool classes = !table.empty();
+    static const int flip_env = [] { const char *e = getenv("DMG_ST_FLIP"); return e ? atoi(e) : -1; }();
+    const bool flipping = flip_env >= 0 ? flip_env != 0 : ST_FLIP_DEFAULT != 0;
+    const bool zones = edge_seg > 0 && zone_lo >= lo && zone_hi <= hi && zone_lo <= zone_hi;
+    const int mid_lo = zones ? zone_lo : lo, mid_hi = zones ? zone_hi : hi;
+    units.clear();
+    int n_all = 0;                                           // units of the whole launch so far (a part keeps only its own, but both parts cut alike)
+    auto emit = [&](int tx, const unsigned char *cls, int r0, int r1, int flip) {
+        if (cls) {
+            while (r0 < r1 && cls[r0] == 1) r0++;
+            while (r1 > r0 && cls[r1 - 1] == 1) r1--;
+        }
+        if (r0 >= r1) return;
+        n_all++;
+        if (part) {
+            const bool edge = r0 < zone_lo || r1 > zone_hi;
+            if (edge != (part == 1)) return;
+        }
+        units.push_back(st_unit{ tx, r0, r1, st_unit_cost(cls, L, r0, r1, 0), flip });
+    };
+    // the send zones: short units of their own, as in st_cut
+    if (zones)
+        for (int tx = 0; tx < tiles_x; tx++) {
+            const unsigned char *cls = classes ? table.data() + (size_t)tx * L : nullptr;
+            int k = 0;
+            for (int s0 = lo; s0 < mid_lo; s0 += edge_seg, k++) emit(tx, cls, s0, std::min(s0 + edge_seg, mid_lo), flipping && (k & 1));
+            for (int s0 = mid_hi; s0 < hi; s0 += edge_seg, k++) emit(tx, cls, s0, std::min(s0 + edge_seg, hi), flipping && (k & 1));
+        }
+    // stretches of water in the middle zone
+    struct stretch { int tx, r0, r1, k; double cost; };
+    std::vector<stretch> st;
+    auto roww = [&](const unsigned char *cls, int r) { const int c = cls ? cls[r] : 0; return c == 1 ? 0.1 : (c == 2 ? 1.4 : 1.0); };
+    for (int tx = 0; tx < tiles_x; tx++) {
+        const unsigned char *cls = classes ? table.data() + (size_t)tx * L : nullptr;
+        int r = mid_lo;
+        while (r < mid_hi) {
+            while (r < mid_hi && cls && cls[r] == 1) r++;
+            if (r >= mid_hi) break;
+            const int s0 = r;
+            int last = r;
+            double c = 0.0;
+            while (r < mid_hi) {
+                if (cls && cls[r] == 1) {
+                    int e = r;
+                    while (e < mid_hi && cls[e] == 1) e++;
+                    if (e - r >= 24 || e == mid_hi) break;
+                }
+                c += roww(cls, r);
+                if (!cls || cls[r] != 1) last = r;
+                r++;
+            }
+            st.push_back(stretch{ tx, s0, last + 1, std::max(1, (last + 1 - s0 + ST_MAXROWS - 1) / ST_MAXROWS), c });
+            r = std::max(r, last + 1);
+        }
+    }
+    if (st.empty()) return;
+    // a unit of a stretch costs about (its share of the rows) x 8 levels + the fill of its window + the fixed part
+    const double fixed = 140.0 + 16.0 * 4.5;
+    auto per_unit = [&](const stretch &x) { return x.cost * 8.0 / x.k + fixed; };
+    int have = 0;
+    for (const stretch &x : st) have += x.k;
+    want -= n_all;                                           // (the send zones' units are part of the round)
+    {
+        auto worse = [&](int a, int b) { return per_unit(st[a]) < per_unit(st[b]); };
+        std::vector<int> heap(st.size());
+        for (size_t i = 0; i < st.size(); i++) heap[i] = (int)i;
+        std::make_heap(heap.begin(), heap.end(), worse);
+        while (have < want) {
+            std::pop_heap(heap.begin(), heap.end(), worse);
+            stretch &x = st[heap.back()];
+            if ((x.r1 - x.r0) / (x.k + 1) < 12) break;           // (units shorter than their own fill: the most expensive stretch cannot be helped further)
+            x.k++; have++;
+            std::push_heap(heap.begin(), heap.end(), worse);
+        }
+    }
+    for (const stretch &x : st) {
+        const unsigned char *cls = classes ? table.data() + (size_t)x.tx * L : nullptr;
+        int r = x.r0;
+        double acc = 0.0;
+        for (int u = 0; u < x.k; u++) {
+            const int u0 = r;
+            const double upto = x.cost * (u + 1) / x.k;
+            while (r < x.r1 && (u == x.k - 1 || acc + 0.5 * roww(cls, r) <= upto) && r - u0 < ST_MAXROWS) { acc += roww(cls, r); r++; }
+            if (u == x.k - 1 && r < x.r1) {                       // (the row limit cut the last unit short: the rest as further units)
+                emit(x.tx, cls, u0, r, flipping && (u & 1));
+                for (int q = r; q < x.r1; q += ST_MAXROWS) emit(x.tx, cls, q, std::min(q + ST_MAXROWS, x.r1), 0);
+                r = x.r1;
+                break;
+            }
+            emit(x.tx, cls, u0, r, flipping && (u & 1));
         }
     }
 }
@@ -1411,15 +1526,19 @@ static const dmg_ocean::tile_list *st_units(dmg_ocean *o, int variant, int lo, i
         const dmg_ocean::tile_list *whole = st_units(o, variant, lo, hi, 0, 0, 0, seg);
         if (!whole) return nullptr;
         cut_seg = whole->cut_seg; cut_seg2 = whole->cut_seg2; cut_split = whole->cut_split;
-        if (cut_seg <= 0) { cut_seg = variant == 1 ? STN_MAXROWS : ST_MAXROWS; cut_seg2 = 0; cut_split = hi; }   // (a launch with no live unit)
+        if (cut_seg == 0) { cut_seg = variant == 1 ? STN_MAXROWS : ST_MAXROWS; cut_seg2 = 0; cut_split = hi; }   // (a launch with no live unit)
         static const int edge_seg = [] { const char *e = getenv("DMG_ST_EDGE_SEG"); const int v = e ? atoi(e) : 4; return v >= 2 && v <= ST_MAXROWS ? v : 0; }();
-        st_cut(o, variant, lo, hi, cut_seg, part, zone_lo, zone_hi, best, cut_seg2, cut_split, edge_seg);
+        auto cut_as_whole = [&](int which, std::vector<st_unit> &out) {      // (cut_seg < 0: the balanced cut, -cut_seg units in all)
+            if (cut_seg < 0) st_cut_balanced(o, lo, hi, -cut_seg, which, zone_lo, zone_hi, out, edge_seg);
+            else st_cut(o, variant, lo, hi, cut_seg, which, zone_lo, zone_hi, out, cut_seg2, cut_split, edge_seg);
+        };
+        cut_as_whole(part, best);
         (void)st_makespan(best, slots);
         // both halves built: together they must be the units of ONE cut of the launch's rows, each exactly once
         auto other = o->tb_lists.find(std::make_tuple(lo, hi, std::get<2>(key), 3 - part, zone_lo, zone_hi));
         if (other != o->tb_lists.end()) {
             std::vector<st_unit> all;
-            st_cut(o, variant, lo, hi, cut_seg, 0, zone_lo, zone_hi, all, cut_seg2, cut_split, edge_seg);
+            cut_as_whole(0, all);
             long long rows_all = 0, rows_parts = 0;
             for (const st_unit &u : all) rows_all += u.r1 - u.r0;
             for (const st_unit &u : best) rows_parts += u.r1 - u.r0;
@@ -1462,14 +1581,31 @@ static const dmg_ocean::tile_list *st_units(dmg_ocean *o, int variant, int lo, i
                     if (span < best_span) { best_span = span; best.swap(units); best_seg = cand; best_seg2 = seg2; best_split = split; }
                 }
         }
+        // ... and the strip-by-strip cut into units of equal cost (st_cut_balanced), at one, two and three rounds' worth of units
+        static const int bal_env = [] { const char *e = getenv("DMG_ST_BALANCED"); return e ? atoi(e) : 1; }();     // how many rounds' worth at most (0: off)
+        // (only on launches of at most ST_BALANCED_ROWS rows whose best fixed-height cut is itself about one round -- the band of an
+        // 8-way split.  There it is worth 5-9 % (16384 x 1024: 65.0 -> 59.5 / 61.6 us on two boxes; the middle band of the 8-way split
+        // 62.3 -> 59.3 us).  On taller launches the simulation's preference is not the chip's: 16384 x 2048 in one round of 2048
+        // equal-cost units takes 94 us against 87 for 1981 units of 52 rows -- strips whose units no longer cover the same rows at
+        // the same time stop sharing their halo columns in the L2 -- although the 4-way middle band gains 4.5 %;
+        // profiles/r04_balanced_cut.txt)
+        static const int bal_rows = [] { const char *e = getenv("DMG_ST_BALANCED_ROWS"); return e ? atoi(e) : 1200; }();
+        if (bal_env && variant == 0 && !o->rowclass_host.empty() && (int)best.size() <= slots + slots / 10 && hi - lo <= bal_rows)
+            for (int rounds = 1; rounds <= bal_env; rounds++) {
+                st_cut_balanced(o, lo, hi, rounds * slots, part, zone_lo, zone_hi, units);
+                if (units.empty()) continue;
+                const float span = judge(units);
+                if (span < best_span) { best_span = span; best.swap(units); best_seg = -rounds * slots; best_seg2 = 0; best_split = hi; }
+            }
         (void)st_makespan(best, slots);                    // (longest first)
         cut_seg = best_seg; cut_seg2 = best_seg2; cut_split = best_split;
         static const bool dbg = getenv("DMG_ST_DEBUG") != nullptr;
         if (dbg) {
             double total = 0;
             for (const st_unit &u : best) total += u.cost;
-            fprintf(stderr, "[stream] rows [%d,%d) part %d: %zu units, %d rows up to row %d then %d; predicted span %.0f, mean load %.0f (%.1f %% of the slots' time)\n",
-                    lo, hi, part, best.size(), best_seg, best_split, best_seg2, best_span, total / slots, 100.0 * total / slots / best_span);
+            fprintf(stderr, "[stream] rows [%d,%d) part %d: %zu units, %s %d rows up to row %d then %d; predicted span %.0f, mean load %.0f (%.1f %% of the slots' time)\n",
+                    lo, hi, part, best.size(), best_seg < 0 ? "balanced cut of" : "", best_seg < 0 ? -best_seg : best_seg, best_split, best_seg2, best_span, total / slots,
+                    100.0 * total / slots / best_span);
             // which path the steps of these units take (host classes: 0 open, 1 land, 2 mixed), and how many of the rows that go
             // through the coast formula in an all-coast step are open water
             const std::vector<unsigned char> &table = variant ? o->rowclass_n_host : o->rowclass_host;
