@@ -1591,11 +1591,14 @@ static const dmg_ocean::tile_list *st_units(dmg_ocean *o, int variant, int lo, i
         // profiles/r04_balanced_cut.txt)
         static const int bal_rows = [] { const char *e = getenv("DMG_ST_BALANCED_ROWS"); return e ? atoi(e) : 1200; }();
         if (bal_env && variant == 0 && !o->rowclass_host.empty() && (int)best.size() <= slots + slots / 10 && hi - lo <= bal_rows)
-            for (int rounds = 1; rounds <= bal_env; rounds++) {
-                st_cut_balanced(o, lo, hi, rounds * slots, part, zone_lo, zone_hi, units);
+            for (int eighths = 6; eighths <= 8 * bal_env; eighths += (eighths < 8 ? 1 : 8)) {      // 3/4, 7/8, 1 (, 2, 3) rounds' worth of units
+                const int want = slots * eighths / 8;
+                st_cut_balanced(o, lo, hi, want, part, zone_lo, zone_hi, units);
                 if (units.empty()) continue;
                 const float span = judge(units);
-                if (span < best_span) { best_span = span; best.swap(units); best_seg = -rounds * slots; best_seg2 = 0; best_split = hi; }
+                static const bool dbgc = getenv("DMG_ST_DEBUG") != nullptr;
+                if (dbgc) fprintf(stderr, "[stream]   balanced cut of %d units: predicted span %.0f (best so far %.0f)\n", want, span, best_span);
+                if (span < best_span) { best_span = span; best.swap(units); best_seg = -want; best_seg2 = 0; best_split = hi; }
             }
         (void)st_makespan(best, slots);                    // (longest first)
         cut_seg = best_seg; cut_seg2 = best_seg2; cut_split = best_split;
