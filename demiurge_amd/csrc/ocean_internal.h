@@ -49,6 +49,9 @@ struct dmg_ocean {
         unsigned *seg_cur0 = nullptr, *seg_cur = nullptr;
         int *seg_ctl = nullptr;
         int cap = 0, waves = 0;
+        int twin = 0;                                    // streaming kernel: the list holds pairs of twin units (two entries per workgroup, k_jacobi_stream_twin)
+        size_t n_units = 0;                              // units in the list (2 n for twin units)
+        int cut_twin = 0;
         int n_flip = 0;                                  // streaming kernel: units of this list that stream southwards (they need the mirrored row tables)
         int cut_seg = 0, cut_seg2 = 0, cut_split = 0;   // streaming kernel: the cut of a launch's rows into units (the halves of a split launch share the whole launch's)
         long long cut_rows = 0;                          // rows its units write, summed (the halves of a split launch are checked against their cut)

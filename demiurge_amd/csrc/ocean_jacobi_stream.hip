@@ -50,6 +50,9 @@
 #ifndef ST_FLIP_DEFAULT
 #define ST_FLIP_DEFAULT 1         // every other segment of a cut streams southwards (DMG_ST_FLIP=0/1 overrides)
 #endif
+#ifndef ST_TWIN_DEFAULT
+#define ST_TWIN_DEFAULT 1         // launches of about one round are cut into twin units (DMG_ST_TWIN=0/1 overrides; 2: whatever the simulation says)
+#endif
 #ifndef ST_OPEN_UNITS
 #define ST_OPEN_UNITS 1           // units whose whole window is plain open water run st_open_unit (0: every unit generic, round 3's kernel)
 #endif
@@ -450,9 +453,52 @@ __device__ __forceinline__ unsigned st_class_p(const st_args &a, const st_state 
     return inside ? c : 2u;
 }
 
-template <int K, bool P = false, int DV = 0>
+// ---- twin units (round 4): two units of a strip that START on the same seam and stream away from it ------------------------
+// A unit of n rows streams n + 16: eight rows beyond each end, on which its levels shrink back to the rows it writes -- a
+// 28-row unit (the band of an 8-way split has ~28 rows per wave slot) runs 22 steps for 14 steps' worth of rows.  The halo
+// exists because the unit's neighbour computes ITS rows somewhere else at some other time.  Two waves of one workgroup that
+// start on the two sides of a seam row at the same moment need no halo between them: the northward wave's level s needs, of
+// the other side, only level s-1 of the ONE row below the seam, which is the southward wave's first row of that level (and
+// the other way round), made in the same or the previous step.  So the two hand each other their first row of every level
+// through 2 KB of LDS while their pipelines fill -- the pipeline of such a unit is full after FOUR steps instead of eight
+// (level s has its first row at step s/2: there is no shrinking edge to wait for), it streams n + 8 rows, and after step 3 the
+// two waves never meet again.  At step t (0..3): level 2t makes the unit's rows (0, 1); its row 0 goes to the partner, a
+// barrier, and the partner's is this wave's row -1 of level 2t, which level 2t + 1 needs for row 0 in this same step; that row
+// 0 goes over likewise, and the partner's becomes row -1 of level 2t + 1 for level 2t + 2 in the next step.  Eight barriers
+// per unit, all in its first four steps.  The southward wave is the same program on the mirrored view (above).
+// Same operations on the same values as a unit with a halo: bit-identical (tests/stream_worker.py `twin`).
+template <int S, int K>
+__device__ __forceinline__ void st_twin_hand_over(st_state &z, v4f (*xme)[64], const v4f (*xpeer)[64], int lane, bool second)
+{
+    // (LDS only: the wait leaves the wave's global loads in flight, which __syncthreads()'s fence need not)
+    if (!second) {
+        xme[0][lane] = z.w[S][K][0];
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        z.w[S][K ^ 1][1] = xpeer[0][lane];
+    } else {
+        xme[1][lane] = z.w[S][K][1];
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        z.w[S][K][0] = xpeer[1][lane];
+    }
+}
+template <int S, int K, int DV>
+__device__ __forceinline__ void st_twin_level(const st_args &a, st_state &z, v4f (*bring)[64], unsigned (*cring)[64], const v4f *ktab,
+                                              int lane, int t, int e_t, int r0, int r1, bool lane_ok, int xcol, v4f (&bq)[9], v4f (&kq)[9], int kb,
+                                              v4f (*xme)[64], const v4f (*xpeer)[64])
+{
+    if (S <= 2 * t + 1) {
+        st_level<S, K, false, 0, DV>(a, z, bring, cring, ktab, lane, t, e_t - S, r0, r1, lane_ok, xcol, bq, kq, kb);
+        if (S < 8) {
+            if (S == 2 * t) st_twin_hand_over<S & 7, K>(z, xme, xpeer, lane, false);
+            else if (S == 2 * t + 1) st_twin_hand_over<S & 7, K>(z, xme, xpeer, lane, true);
+        }
+    }
+}
+
+template <int K, bool P = false, int DV = 0, int TW = 0>
 __device__ __forceinline__ void st_step(const st_args &a, st_state &z, v4f (*bring)[64], unsigned (*cring)[64], const v4f *ktab, int lane, int t,
-                                        int e0, int nsteps, int r1, unsigned cls_lo, unsigned cls_hi, int col, int colp, bool lane_ok, int xcol, int tx = 0)
+                                        int e0, int nsteps, int r1, unsigned cls_lo, unsigned cls_hi, int col, int colp, bool lane_ok, int xcol, int tx = 0,
+                                        v4f (*xme)[64] = nullptr, const v4f (*xpeer)[64] = nullptr)
 {
     const int e_t = e0 + 2 * t;                              // first row of the pair that has just arrived
     const int slotB = z.slot + 1;                            // (ST_RING is even: a pair never wraps)
@@ -468,6 +514,7 @@ __device__ __forceinline__ void st_step(const st_args &a, st_state &z, v4f (*bri
 #endif
     st_arrive<K>(a, z, bring, cring, lane, 0, e_t, clsA, z.slot, landA, mixA);
     st_arrive<K>(a, z, bring, cring, lane, 1, e_t + 1, clsB, slotB, landB, mixB);
+    if (TW && K == 0 && t == 0) st_twin_hand_over<0, K>(z, xme, xpeer, lane, false);      // "level 0": the partner's first row is this unit's row -1
     z.landbits = (z.landbits << 2) | (landA << 1) | landB;
     z.mixbits = (z.mixbits << 2) | (mixA << 1) | mixB;
     if (DV) z.badbits = (z.badbits << 2) | ((clsA >> 1) & 2u) | ((clsB >> 2) & 1u);
@@ -477,7 +524,9 @@ __device__ __forceinline__ void st_step(const st_args &a, st_state &z, v4f (*bri
     st_fetch<P>(a, z, K, 0, e_t + 4, col, colp, tx, P ? 2u : z.fc[K][0]);
     st_fetch<P>(a, z, K, 1, e_t + 5, col, colp, tx, P ? 2u : z.fc[K][1]);
     // level 1: rows e_t - 1 (in the ring since the last step) and e_t (just written)
-    const int s1 = st_wrap(z.slot - 1), r1w = max(2 * t - 1, 0);
+    // (a twin unit's level 1 computes window row 0 in step 0: its table index is not clamped -- row -1's entry is the 16 bytes in
+    // front of the table, read and not used)
+    const int s1 = st_wrap(z.slot - 1), r1w = TW ? 2 * t - 1 : max(2 * t - 1, 0);
     v4f bq[9], kq[9];
     bq[1] = bring[s1][lane]; bq[0] = bring[z.slot][lane]; kq[1] = ktab[st_kt<P>(r1w)]; kq[0] = ktab[st_kt<P>(r1w + 1)];
     int kb = 0;
@@ -488,36 +537,46 @@ __device__ __forceinline__ void st_step(const st_args &a, st_state &z, v4f (*bri
     // tested path whatever their rows are, and there a level that has nothing to do yet is skipped outright (round 3: per-step
     // clocks showed a skipped level visit costing 0.25 us through the all-land path -- as much as a real one -- and a unit's
     // eight fill steps 2.1 us each; with the skip a unit is ~7 us shorter)
-    const bool filled = P || t >= TB_T;
+    const bool filled = P || t >= (TW ? TB_T / 2 : TB_T);
+    const int r0 = TW ? e0 : e0 + TB_T;                      // the unit's first output row
     if (filled && !((z.landbits | z.mixbits | special) & 0x3FFu)) {
-        st_level<1, K, P, 1, DV>(a, z, bring, cring, ktab, lane, t, e_t - 1, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
-        st_level<2, K, P, 1, DV>(a, z, bring, cring, ktab, lane, t, e_t - 2, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
-        st_level<3, K, P, 1, DV>(a, z, bring, cring, ktab, lane, t, e_t - 3, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
-        st_level<4, K, P, 1, DV>(a, z, bring, cring, ktab, lane, t, e_t - 4, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
-        st_level<5, K, P, 1, DV>(a, z, bring, cring, ktab, lane, t, e_t - 5, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
-        st_level<6, K, P, 1, DV>(a, z, bring, cring, ktab, lane, t, e_t - 6, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
-        st_level<7, K, P, 1, DV>(a, z, bring, cring, ktab, lane, t, e_t - 7, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
-        st_level<8, K, P, 1, DV>(a, z, bring, cring, ktab, lane, t, e_t - 8, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<1, K, P, 1, DV>(a, z, bring, cring, ktab, lane, t, e_t - 1, r0, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<2, K, P, 1, DV>(a, z, bring, cring, ktab, lane, t, e_t - 2, r0, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<3, K, P, 1, DV>(a, z, bring, cring, ktab, lane, t, e_t - 3, r0, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<4, K, P, 1, DV>(a, z, bring, cring, ktab, lane, t, e_t - 4, r0, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<5, K, P, 1, DV>(a, z, bring, cring, ktab, lane, t, e_t - 5, r0, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<6, K, P, 1, DV>(a, z, bring, cring, ktab, lane, t, e_t - 6, r0, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<7, K, P, 1, DV>(a, z, bring, cring, ktab, lane, t, e_t - 7, r0, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<8, K, P, 1, DV>(a, z, bring, cring, ktab, lane, t, e_t - 8, r0, r1, lane_ok, xcol, bq, kq, kb);
     } else if (filled && !((z.landbits | special) & 0x3FFu)) {
         // coast among the ten rows, but no row that is land everywhere (coast rows come in long runs: 18 % of the survey
         // terrain's steps): every row through the coast formula, open rows with counts of zero -- again no test, no branch
-        st_level<1, K, P, 2, DV>(a, z, bring, cring, ktab, lane, t, e_t - 1, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
-        st_level<2, K, P, 2, DV>(a, z, bring, cring, ktab, lane, t, e_t - 2, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
-        st_level<3, K, P, 2, DV>(a, z, bring, cring, ktab, lane, t, e_t - 3, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
-        st_level<4, K, P, 2, DV>(a, z, bring, cring, ktab, lane, t, e_t - 4, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
-        st_level<5, K, P, 2, DV>(a, z, bring, cring, ktab, lane, t, e_t - 5, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
-        st_level<6, K, P, 2, DV>(a, z, bring, cring, ktab, lane, t, e_t - 6, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
-        st_level<7, K, P, 2, DV>(a, z, bring, cring, ktab, lane, t, e_t - 7, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
-        st_level<8, K, P, 2, DV>(a, z, bring, cring, ktab, lane, t, e_t - 8, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<1, K, P, 2, DV>(a, z, bring, cring, ktab, lane, t, e_t - 1, r0, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<2, K, P, 2, DV>(a, z, bring, cring, ktab, lane, t, e_t - 2, r0, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<3, K, P, 2, DV>(a, z, bring, cring, ktab, lane, t, e_t - 3, r0, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<4, K, P, 2, DV>(a, z, bring, cring, ktab, lane, t, e_t - 4, r0, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<5, K, P, 2, DV>(a, z, bring, cring, ktab, lane, t, e_t - 5, r0, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<6, K, P, 2, DV>(a, z, bring, cring, ktab, lane, t, e_t - 6, r0, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<7, K, P, 2, DV>(a, z, bring, cring, ktab, lane, t, e_t - 7, r0, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<8, K, P, 2, DV>(a, z, bring, cring, ktab, lane, t, e_t - 8, r0, r1, lane_ok, xcol, bq, kq, kb);
+    } else if (TW) {
+        st_twin_level<1, K, DV>(a, z, bring, cring, ktab, lane, t, e_t, r0, r1, lane_ok, xcol, bq, kq, kb, xme, xpeer);
+        st_twin_level<2, K, DV>(a, z, bring, cring, ktab, lane, t, e_t, r0, r1, lane_ok, xcol, bq, kq, kb, xme, xpeer);
+        st_twin_level<3, K, DV>(a, z, bring, cring, ktab, lane, t, e_t, r0, r1, lane_ok, xcol, bq, kq, kb, xme, xpeer);
+        st_twin_level<4, K, DV>(a, z, bring, cring, ktab, lane, t, e_t, r0, r1, lane_ok, xcol, bq, kq, kb, xme, xpeer);
+        st_twin_level<5, K, DV>(a, z, bring, cring, ktab, lane, t, e_t, r0, r1, lane_ok, xcol, bq, kq, kb, xme, xpeer);
+        st_twin_level<6, K, DV>(a, z, bring, cring, ktab, lane, t, e_t, r0, r1, lane_ok, xcol, bq, kq, kb, xme, xpeer);
+        st_twin_level<7, K, DV>(a, z, bring, cring, ktab, lane, t, e_t, r0, r1, lane_ok, xcol, bq, kq, kb, xme, xpeer);
+        st_twin_level<8, K, DV>(a, z, bring, cring, ktab, lane, t, e_t, r0, r1, lane_ok, xcol, bq, kq, kb, xme, xpeer);
     } else {
-        if (P || 1 <= t) st_level<1, K, P, 0, DV>(a, z, bring, cring, ktab, lane, t, e_t - 1, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
-        if (P || 2 <= t) st_level<2, K, P, 0, DV>(a, z, bring, cring, ktab, lane, t, e_t - 2, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
-        if (P || 3 <= t) st_level<3, K, P, 0, DV>(a, z, bring, cring, ktab, lane, t, e_t - 3, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
-        if (P || 4 <= t) st_level<4, K, P, 0, DV>(a, z, bring, cring, ktab, lane, t, e_t - 4, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
-        if (P || 5 <= t) st_level<5, K, P, 0, DV>(a, z, bring, cring, ktab, lane, t, e_t - 5, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
-        if (P || 6 <= t) st_level<6, K, P, 0, DV>(a, z, bring, cring, ktab, lane, t, e_t - 6, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
-        if (P || 7 <= t) st_level<7, K, P, 0, DV>(a, z, bring, cring, ktab, lane, t, e_t - 7, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
-        if (P || 8 <= t) st_level<8, K, P, 0, DV>(a, z, bring, cring, ktab, lane, t, e_t - 8, e0 + TB_T, r1, lane_ok, xcol, bq, kq, kb);
+        if (P || 1 <= t) st_level<1, K, P, 0, DV>(a, z, bring, cring, ktab, lane, t, e_t - 1, r0, r1, lane_ok, xcol, bq, kq, kb);
+        if (P || 2 <= t) st_level<2, K, P, 0, DV>(a, z, bring, cring, ktab, lane, t, e_t - 2, r0, r1, lane_ok, xcol, bq, kq, kb);
+        if (P || 3 <= t) st_level<3, K, P, 0, DV>(a, z, bring, cring, ktab, lane, t, e_t - 3, r0, r1, lane_ok, xcol, bq, kq, kb);
+        if (P || 4 <= t) st_level<4, K, P, 0, DV>(a, z, bring, cring, ktab, lane, t, e_t - 4, r0, r1, lane_ok, xcol, bq, kq, kb);
+        if (P || 5 <= t) st_level<5, K, P, 0, DV>(a, z, bring, cring, ktab, lane, t, e_t - 5, r0, r1, lane_ok, xcol, bq, kq, kb);
+        if (P || 6 <= t) st_level<6, K, P, 0, DV>(a, z, bring, cring, ktab, lane, t, e_t - 6, r0, r1, lane_ok, xcol, bq, kq, kb);
+        if (P || 7 <= t) st_level<7, K, P, 0, DV>(a, z, bring, cring, ktab, lane, t, e_t - 7, r0, r1, lane_ok, xcol, bq, kq, kb);
+        if (P || 8 <= t) st_level<8, K, P, 0, DV>(a, z, bring, cring, ktab, lane, t, e_t - 8, r0, r1, lane_ok, xcol, bq, kq, kb);
     }
     z.slot = z.slot + 2 == ST_RING ? 0 : z.slot + 2;
 #ifdef ST_EXPERIMENTS
@@ -758,6 +817,87 @@ __global__ __launch_bounds__(64, 2) void k_jacobi_stream(st_args a_up, st_args a
 #ifdef ST_EXPERIMENTS
     if (a.stepprof && lane == 0) a.stepprof[(size_t)blockIdx.x * 64 + 63] = __builtin_amdgcn_s_memrealtime();
 #endif
+}
+
+// Twin units (st_step's TW form, described there): a workgroup of two waves per pair -- wave 0 the unit above the seam (the
+// plain view), wave 1 the unit below it (the mirrored view); a_up.units holds two entries per workgroup.  The window of a twin
+// unit starts ON its first row (no halo towards the seam); ST_TWIN_MAXROWS keeps the two waves' tables and the 4 KB they
+// trade rows through within a quarter of a CU's LDS: four workgroups, eight waves, two per SIMD as before.
+#define ST_TWIN_MAXROWS 104
+template <int DV>
+__global__ __launch_bounds__(128, 2) void k_jacobi_stream_twin(st_args a_up, st_args a_dn)
+{
+    __shared__ v4f bring2[2][ST_RING][64];
+    __shared__ unsigned cring2[2][ST_RING][64];
+    __shared__ v4f ktab2[2][ST_TWIN_MAXROWS + TB_T + 8];
+    __shared__ v4f xch[2][2][64];                     // [wave][first row of an even / an odd level][lane]
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    v4f (*bring)[64] = bring2[wave];
+    unsigned (*cring)[64] = cring2[wave];
+    v4f *ktab = ktab2[wave];
+    const int4 u = a_up.units[2 * blockIdx.x + wave];
+    const int tx = __builtin_amdgcn_readfirstlane(u.x), r0 = __builtin_amdgcn_readfirstlane(u.y), r1 = __builtin_amdgcn_readfirstlane(u.z);
+    const st_args &a = wave ? a_dn : a_up;
+    const int W = a.W;
+    if (a.prof && lane == 0) {
+        a.prof[3 * (2 * blockIdx.x + wave)] = __builtin_amdgcn_s_memrealtime();
+        a.prof[3 * (2 * blockIdx.x + wave) + 2] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) | (unsigned)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+    }
+    // (at least four steps, whatever the unit's rows: the partner's pipeline fills through this wave's first four)
+    const int nsteps = (((r1 - r0) + TB_T + 3) / 4) * 2;
+    const int e0 = r0;                                // the window starts on the seam
+    int col = tx * TB_OW - TB_T + 4 * lane;
+    const int xcol = col;
+    col %= W; if (col < 0) col += W;
+    int colp = col + W / 2; if (colp >= W) colp -= W;
+    const bool lane_ok = (lane >= TB_T / 4) && (lane < 64 - TB_T / 4) && (xcol < W);
+    st_state z;
+    {
+        const int e_last = e0 + 2 * nsteps + 5;
+        z.plain = e0 >= 0 && e_last < a.L && a.y_first + e0 >= 0 && a.y_first + e_last < a.H;
+        z.nx_p = a.pin + (long)e0 * a.rs; z.nx_b = a.b + (long)e0 * a.rs; z.nx_c = a.code + (long)e0 * a.rs;
+    }
+    st_fetch<false>(a, z, 0, 0, e0, col, colp);
+    st_fetch<false>(a, z, 0, 1, e0 + 1, col, colp);
+    st_fetch<false>(a, z, 1, 0, e0 + 2, col, colp);
+    st_fetch<false>(a, z, 1, 1, e0 + 3, col, colp);
+    unsigned cls_lo = 0x02020202u, cls_hi = 0u;
+    if (a.rowclass) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int lu = e0 + lane + 64 * q, yg = a.y_first + lu;
+            if (yg >= 0 && yg < a.H && lu >= 0 && lu < a.L) cls_lo = (cls_lo & ~(0xFFu << (8 * q))) | ((unsigned)a.rowclass[(size_t)tx * a.L + lu] << (8 * q));
+        }
+    }
+    if (DV && a.rowbad) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) cls_lo |= ((unsigned)a.rowbad[st_map_row(a, e0 + lane + 64 * q).l] & 1u) << (8 * q + 2);
+    }
+#pragma unroll
+    for (int s = 0; s < 8; s++)
+#pragma unroll
+        for (int k = 0; k < 2; k++) { z.w[s][k][0] = (v4f)(0.0f); z.w[s][k][1] = (v4f)(0.0f); }
+    z.landbits = 0xFFFFFFFFu;
+    z.mixbits = 0; z.slot = 0; z.badbits = 0;
+    z.fc[0][0] = st_class4(cls_lo, 0); z.fc[0][1] = st_class4(cls_lo, 1); z.fc[1][0] = st_class4(cls_lo, 2); z.fc[1][1] = st_class4(cls_lo, 3);
+    {
+        const int n = 2 * nsteps + 2;
+        v4f kt[2];
+#pragma unroll
+        for (int q = 0; q < 2; q++) kt[q] = st_kswap(*reinterpret_cast<const v4f *>(a.jcoef + (size_t)st_map_row(a, e0 + min(lane + 64 * q, n - 1)).l * 8));
+#pragma unroll
+        for (int q = 0; q < 2; q++) if (lane + 64 * q < n) ktab[lane + 64 * q] = kt[q];
+        const st_kptr cf = (st_kptr)(unsigned long long)a.jcoef;
+        z.cy = cf[4]; z.ry = cf[5];
+    }
+    v4f (*xme)[64] = xch[wave];
+    const v4f (*xpeer)[64] = xch[wave ^ 1];
+    for (int t = 0; t < nsteps; t += 2) {
+        st_step<0, false, DV, 1>(a, z, bring, cring, ktab, lane, t, e0, nsteps, r1, cls_lo, cls_hi, col, colp, lane_ok, xcol, 0, xme, xpeer);
+        st_step<1, false, DV, 1>(a, z, bring, cring, ktab, lane, t + 1, e0, nsteps, r1, cls_lo, cls_hi, col, colp, lane_ok, xcol, 0, xme, xpeer);
+    }
+    if (a.prof && lane == 0) a.prof[3 * (2 * blockIdx.x + wave) + 1] = __builtin_amdgcn_s_memrealtime();
 }
 
 // =================================================================================================================
@@ -1166,20 +1306,23 @@ static int st_unit_rows()                                 // DMG_ST_ROWS=<n>: fi
 }
 
 namespace {
-struct st_unit { int tx, r0, r1; float cost; int flip = 0; };    // flip: the unit streams southwards (k_jacobi_stream's second view)
+struct st_unit { int tx, r0, r1; float cost; int flip = 0;         // flip: the unit streams southwards (k_jacobi_stream's second view)
+                 int rlo = -1;                                     // >= 0: a pair of twin units (k_jacobi_stream_twin) -- rows [r0, r1) northwards and [rlo, r0) southwards from the seam r0
+                 int first() const { return rlo >= 0 ? rlo : r0; } };
 }
 
 // what the dispatch simulation charges a unit of rows [r0, r1) of a strip (cls: the strip's row classes, or null): its
 // level-rows, a coast row counted 1.4 times an open one and a land row a tenth (what the kernel spends on them), plus what a
 // unit costs before and after its rows
-static float st_unit_cost(const unsigned char *cls, int L, int r0, int r1, int variant)
+static float st_unit_cost(const unsigned char *cls, int L, int r0, int r1, int variant, int twin = 0)    // twin 1: no halo below r0 (a unit that starts on a seam), 2: none above r1
 {
     static const float w_mixed = [] { const char *e = getenv("DMG_ST_WMIXED"); return e ? (float)atof(e) : 1.4f; }();    // experiments: the cost model's weights (1.4: best of a sweep 1.0 .. 1.6 on the survey terrain; the per-unit timings fit 1.23 .. 1.40)
     static const float w_land = [] { const char *e = getenv("DMG_ST_WLAND"); return e ? (float)atof(e) : 0.1f; }();
     float cost = 0.0f;
-    for (int r = r0 - TB_T; r < r1 + TB_T; r++) {
+    for (int r = twin == 1 ? r0 : r0 - TB_T; r < (twin == 2 ? r1 : r1 + TB_T); r++) {
         const int c = (cls && r >= 0 && r < L) ? cls[r] : 2;
-        const int depth = std::min(std::min(r - (r0 - TB_T), (r1 + TB_T - 1) - r), TB_T);   // levels that still need this row
+        const int below = twin == 1 ? TB_T : r - (r0 - TB_T), above = twin == 2 ? TB_T : (r1 + TB_T - 1) - r;
+        const int depth = std::min(std::min(below, above), TB_T);   // levels that still need this row
         cost += (c == 1 ? w_land : (c == 2 ? w_mixed : 1.0f)) * (float)depth;
     }
     // + what a unit costs before and after its rows: dispatch, the class and coefficient tables, the first loads' round
@@ -1261,7 +1404,9 @@ static void st_cut(const dmg_ocean *o, int variant, int lo, int hi, int seg, int
 // stretch whose units are the most expensive gets one more until `want` are dealt out; a stretch's units then split its rows
 // at equal cumulative cost.  The send zones of a split launch keep their short units (st_cut).  Which cut a launch takes
 // is still decided by the simulated dispatch (st_units): this one is a candidate at one, two and three rounds' worth of units.
-static void st_cut_balanced(const dmg_ocean *o, int lo, int hi, int want, int part, int zone_lo, int zone_hi, std::vector<st_unit> &units, int edge_seg = 0)
+// twin: the stretches are cut into PAIRS of units that start on a common seam (k_jacobi_stream_twin; `want` still counts units)
+static void st_cut_balanced(const dmg_ocean *o, int lo, int hi, int want, int part, int zone_lo, int zone_hi, std::vector<st_unit> &units, int edge_seg = 0,
+                            bool twin = false)
 {
     const std::vector<unsigned char> &table = o->rowclass_host;
     const int tiles_x = (o->grid.W + TB_OW - 1) / TB_OW, L = o->L;
@@ -1284,6 +1429,22 @@ static void st_cut_balanced(const dmg_ocean *o, int lo, int hi, int want, int pa
             if (edge != (part == 1)) return;
         }
         units.push_back(st_unit{ tx, r0, r1, st_unit_cost(cls, L, r0, r1, 0), flip });
+    };
+    // a pair of twin units around the seam: rows [rlo, seam) southwards, [seam, r1) northwards; only their far ends are trimmed
+    auto emit_twin = [&](int tx, const unsigned char *cls, int rlo, int seam, int r1) {
+        if (cls) {
+            while (rlo < seam && cls[rlo] == 1) rlo++;
+            while (r1 > seam && cls[r1 - 1] == 1) r1--;
+        }
+        if (rlo >= r1) return;
+        n_all += 2;
+        if (part) {
+            const bool edge = rlo < zone_lo || r1 > zone_hi;
+            if (edge != (part == 1)) return;
+        }
+        st_unit u{ tx, seam, r1, std::max(st_unit_cost(cls, L, seam, r1, 0, 1), st_unit_cost(cls, L, rlo, seam, 0, 2)), 0 };
+        u.rlo = rlo;
+        units.push_back(u);
     };
     // the send zones: short units of their own, as in st_cut
     if (zones)
@@ -1316,13 +1477,15 @@ static void st_cut_balanced(const dmg_ocean *o, int lo, int hi, int want, int pa
                 if (!cls || cls[r] != 1) last = r;
                 r++;
             }
-            st.push_back(stretch{ tx, s0, last + 1, std::max(1, (last + 1 - s0 + ST_MAXROWS - 1) / ST_MAXROWS), c });
+            if (twin) st.push_back(stretch{ tx, s0, last + 1, 2 * std::max(1, (last + 1 - s0 + 2 * ST_TWIN_MAXROWS - 1) / (2 * ST_TWIN_MAXROWS)), c });
+            else st.push_back(stretch{ tx, s0, last + 1, std::max(1, (last + 1 - s0 + ST_MAXROWS - 1) / ST_MAXROWS), c });
             r = std::max(r, last + 1);
         }
     }
     if (st.empty()) return;
     // a unit of a stretch costs about (its share of the rows) x 8 levels + the fill of its window + the fixed part
-    const double fixed = 140.0 + 16.0 * 4.5;
+    const double fixed = 140.0 + (twin ? 8.0 : 16.0) * 4.5;
+    const int inc = twin ? 2 : 1;
     auto per_unit = [&](const stretch &x) { return x.cost * 8.0 / x.k + fixed; };
     int have = 0;
     for (const stretch &x : st) have += x.k;
@@ -1335,8 +1498,8 @@ static void st_cut_balanced(const dmg_ocean *o, int lo, int hi, int want, int pa
         while (have < want) {
             std::pop_heap(heap.begin(), heap.end(), worse);
             stretch &x = st[heap.back()];
-            if ((x.r1 - x.r0) / (x.k + 1) < 12) break;           // (units shorter than their own fill: the most expensive stretch cannot be helped further)
-            x.k++; have++;
+            if ((x.r1 - x.r0) / (x.k + inc) < (twin ? 8 : 12)) break;   // (units shorter than their own fill: the most expensive stretch cannot be helped further)
+            x.k += inc; have += inc;
             std::push_heap(heap.begin(), heap.end(), worse);
         }
     }
@@ -1344,6 +1507,23 @@ static void st_cut_balanced(const dmg_ocean *o, int lo, int hi, int want, int pa
         const unsigned char *cls = classes ? table.data() + (size_t)x.tx * L : nullptr;
         int r = x.r0;
         double acc = 0.0;
+        if (twin) {
+            // the stretch's k units end at rows c[1] .. c[k] of equal cumulative cost; units 2j (southwards) and 2j + 1 (northwards) meet on c[2j + 1]
+            std::vector<int> c((size_t)x.k + 1, x.r1);
+            c[0] = x.r0;
+            bool capped = false;
+            for (int u = 0; u < x.k; u++) {
+                const int u0 = r;
+                const double upto = x.cost * (u + 1) / x.k;
+                while (r < x.r1 && (u == x.k - 1 || acc + 0.5 * roww(cls, r) <= upto)) { acc += roww(cls, r); r++; }
+                c[u + 1] = r;
+                capped |= r - u0 > ST_TWIN_MAXROWS;
+            }
+            if (capped)                                           // (a unit of mostly land grew past the row limit: equal rows instead)
+                for (int u = 1; u < x.k; u++) c[u] = x.r0 + (int)((long long)(x.r1 - x.r0) * u / x.k);
+            for (int j = 0; j + 1 < x.k; j += 2) emit_twin(x.tx, cls, c[j], c[j + 1], c[j + 2]);
+            continue;
+        }
         for (int u = 0; u < x.k; u++) {
             const int u0 = r;
             const double upto = x.cost * (u + 1) / x.k;
@@ -1504,6 +1684,7 @@ static const dmg_ocean::tile_list *st_units(dmg_ocean *o, int variant, int lo, i
     std::vector<st_unit> units, best;
     int p_waves = 0;
     int cut_seg = 0, cut_seg2 = 0, cut_split = 0;         // the cut this list was made with (st_cut's seg, seg2, split)
+    int cut_twin = 0;                                     // ... a balanced cut into twin units
     if (variant == 2) {
         // persistent form: about one segment per wave (the waves balance the rest among themselves); a strip's rows that
         // are land everywhere at either end of a cut are trimmed as for the units
@@ -1525,26 +1706,27 @@ static const dmg_ocean::tile_list *st_units(dmg_ocean *o, int variant, int lo, i
         // rows between the two choices to neither of them.)
         const dmg_ocean::tile_list *whole = st_units(o, variant, lo, hi, 0, 0, 0, seg);
         if (!whole) return nullptr;
-        cut_seg = whole->cut_seg; cut_seg2 = whole->cut_seg2; cut_split = whole->cut_split;
+        cut_seg = whole->cut_seg; cut_seg2 = whole->cut_seg2; cut_split = whole->cut_split; cut_twin = whole->cut_twin;
         if (cut_seg == 0) { cut_seg = variant == 1 ? STN_MAXROWS : ST_MAXROWS; cut_seg2 = 0; cut_split = hi; }   // (a launch with no live unit)
         static const int edge_seg = [] { const char *e = getenv("DMG_ST_EDGE_SEG"); const int v = e ? atoi(e) : 4; return v >= 2 && v <= ST_MAXROWS ? v : 0; }();
         auto cut_as_whole = [&](int which, std::vector<st_unit> &out) {      // (cut_seg < 0: the balanced cut, -cut_seg units in all)
-            if (cut_seg < 0) st_cut_balanced(o, lo, hi, -cut_seg, which, zone_lo, zone_hi, out, edge_seg);
+            if (cut_seg < 0) st_cut_balanced(o, lo, hi, -cut_seg, which, zone_lo, zone_hi, out, edge_seg, cut_twin != 0);
             else st_cut(o, variant, lo, hi, cut_seg, which, zone_lo, zone_hi, out, cut_seg2, cut_split, edge_seg);
         };
         cut_as_whole(part, best);
         (void)st_makespan(best, slots);
+        auto units_of = [](const std::vector<st_unit> &v) { size_t n = 0; for (const st_unit &u : v) n += u.rlo >= 0 ? 2 : 1; return n; };
         // both halves built: together they must be the units of ONE cut of the launch's rows, each exactly once
         auto other = o->tb_lists.find(std::make_tuple(lo, hi, std::get<2>(key), 3 - part, zone_lo, zone_hi));
         if (other != o->tb_lists.end()) {
             std::vector<st_unit> all;
             cut_as_whole(0, all);
             long long rows_all = 0, rows_parts = 0;
-            for (const st_unit &u : all) rows_all += u.r1 - u.r0;
-            for (const st_unit &u : best) rows_parts += u.r1 - u.r0;
-            if (other->second.n + (int)best.size() != (int)all.size() || other->second.cut_rows + rows_parts != rows_all) {
-                dmg_fail(DMG_ESTATE, "split launch over rows [%d, %d): %d + %zu units in the two parts, %zu in the cut they are halves of", lo, hi,
-                         other->second.n, best.size(), all.size());
+            for (const st_unit &u : all) rows_all += u.r1 - u.first();
+            for (const st_unit &u : best) rows_parts += u.r1 - u.first();
+            if (other->second.n_units + units_of(best) != units_of(all) || other->second.cut_rows + rows_parts != rows_all) {
+                dmg_fail(DMG_ESTATE, "split launch over rows [%d, %d): %zu + %zu units in the two parts, %zu in the cut they are halves of", lo, hi,
+                         other->second.n_units, units_of(best), units_of(all));
                 return nullptr;
             }
         }
@@ -1600,7 +1782,18 @@ static const dmg_ocean::tile_list *st_units(dmg_ocean *o, int variant, int lo, i
                 if (dbgc) fprintf(stderr, "[stream]   balanced cut of %d units: predicted span %.0f (best so far %.0f)\n", want, span, best_span);
                 if (span < best_span) { best_span = span; best.swap(units); best_seg = -want; best_seg2 = 0; best_split = hi; }
             }
-        (void)st_makespan(best, slots);                    // (longest first)
+        // ... and into twin units (pairs that start on a common seam and need no halo between them: k_jacobi_stream_twin), one round's worth
+        static const int twin_env = [] { const char *e = getenv("DMG_ST_TWIN"); return e ? atoi(e) : ST_TWIN_DEFAULT; }();
+        if (twin_env && bal_env && variant == 0 && !o->rowclass_host.empty() && (int)best.size() <= slots + slots / 10 && hi - lo <= bal_rows) {
+            st_cut_balanced(o, lo, hi, slots, part, zone_lo, zone_hi, units, 0, true);
+            if (!units.empty()) {
+                const float span = st_makespan(units, slots / 2);          // (a pair holds two of the slots)
+                static const bool dbgc = getenv("DMG_ST_DEBUG") != nullptr;
+                if (dbgc) fprintf(stderr, "[stream]   balanced cut into %zu pairs of twin units: predicted span %.0f (best so far %.0f)\n", units.size(), span, best_span);
+                if (span < best_span || twin_env > 1) { best_span = span; best.swap(units); best_seg = -slots; best_seg2 = 0; best_split = hi; cut_twin = 1; }
+            }
+        }
+        (void)st_makespan(best, cut_twin ? slots / 2 : slots);      // (longest first)
         cut_seg = best_seg; cut_seg2 = best_seg2; cut_split = best_split;
         static const bool dbg = getenv("DMG_ST_DEBUG") != nullptr;
         if (dbg) {
@@ -1612,7 +1805,7 @@ static const dmg_ocean::tile_list *st_units(dmg_ocean *o, int variant, int lo, i
             // which path the steps of these units take (host classes: 0 open, 1 land, 2 mixed), and how many of the rows that go
             // through the coast formula in an all-coast step are open water
             const std::vector<unsigned char> &table = variant ? o->rowclass_n_host : o->rowclass_host;
-            if (!table.empty()) {
+            if (!table.empty() && !cut_twin) {
                 long long n1 = 0, n2 = 0, n0 = 0, rows2 = 0, open2 = 0;
                 for (const st_unit &u : best) {
                     const unsigned char *cls = table.data() + (size_t)u.tx * o->L;
@@ -1674,9 +1867,17 @@ static const dmg_ocean::tile_list *st_units(dmg_ocean *o, int variant, int lo, i
     // steps request past the window, is plain open water with exact divisor pairs inside the grid and the stored band
     static const bool open_units = [] { const char *e = getenv("DMG_ST_OPEN_UNITS"); return e && atoi(e) != 0; }();     // (measured: no gain; off by default)
     const std::vector<unsigned char> &ctab = o->rowclass_host;
-    int n_open = 0, n_flip = 0;
+    int n_open = 0, n_flip = 0, n_twin = 0;
+    for (const st_unit &u : best) n_twin += u.rlo >= 0;
+    if (n_twin && n_twin != (int)best.size()) { dmg_fail(DMG_ESTATE, "a unit list mixes twin units with plain ones"); return nullptr; }
     for (const st_unit &u : best) {
         int flag = 0;
+        if (u.rlo >= 0) {                                  // the unit above the seam, then the one below it in the mirrored view's rows
+            flat.push_back(u.tx); flat.push_back(u.r0); flat.push_back(u.r1); flat.push_back(4);
+            flat.push_back(u.tx); flat.push_back(o->L - u.r0); flat.push_back(o->L - u.rlo); flat.push_back(4 | 2);
+            n_flip++;
+            continue;
+        }
         if (open_units && variant == 0 && !ctab.empty()) {
             const int e0 = u.r0 - TB_T, nst = (((u.r1 - u.r0) + 2 * TB_T + 3) / 4) * 2, e_last = e0 + 2 * nst + 5;
             const int y_first = o->y0 - o->gs;
@@ -1695,10 +1896,12 @@ static const dmg_ocean::tile_list *st_units(dmg_ocean *o, int variant, int lo, i
     }
     dmg_ocean::tile_list tl;
     tl.n = (int)best.size();
+    tl.twin = n_twin ? 1 : 0;
+    tl.n_units = (size_t)(n_twin ? 2 * tl.n : tl.n);
     tl.n_flip = n_flip;
-    tl.cut_seg = cut_seg; tl.cut_seg2 = cut_seg2; tl.cut_split = cut_split;
+    tl.cut_seg = cut_seg; tl.cut_seg2 = cut_seg2; tl.cut_split = cut_split; tl.cut_twin = cut_twin;
     tl.cut_rows = 0;
-    for (const st_unit &u : best) tl.cut_rows += u.r1 - u.r0;
+    for (const st_unit &u : best) tl.cut_rows += u.r1 - u.first();
     if (tl.n && hipMalloc((void **)&tl.d, flat.size() * sizeof(int)) != hipSuccess) return nullptr;
     if (tl.n && hipMemcpy(tl.d, flat.data(), flat.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
     if (variant == 2 && tl.n) {
@@ -1800,8 +2003,8 @@ int ocean_launch_stream(dmg_ocean *o, int lo, int hi, int part, int zone_lo, int
 #endif
     static const char *prof_path = getenv("DMG_ST_PROF");  // experiments: the first full-size launch writes one line per unit to this file
     static bool prof_done = false;
-    const bool prof_now = prof_path && !prof_done && !variant && tl->n > 1024;
-    if (prof_now && hipMalloc((void **)&a.prof, (size_t)tl->n * 24) != hipSuccess) a.prof = nullptr;
+    const bool prof_now = prof_path && !prof_done && !variant && tl->n_units > 1024;
+    if (prof_now && hipMalloc((void **)&a.prof, tl->n_units * 24) != hipSuccess) a.prof = nullptr;
     static const int extra_lds = [] { const char *e = getenv("DMG_ST_EXTRA_LDS"); return e ? atoi(e) : 0; }();   // experiments: caps the waves per CU
     if (variant == 2) {
         const int total = tl->cap + tl->waves;
@@ -1830,7 +2033,7 @@ int ocean_launch_stream(dmg_ocean *o, int lo, int hi, int part, int zone_lo, int
         // the mirrored view of the band for the units that stream southwards: pointers to the last stored row, a negative row
         // stride, the row tables reversed (built once per ocean and terrain), grid rows and poles mirrored
         st_args ad = a;
-        if (tl->n_flip) {
+        if (tl->n_flip || tl->twin) {
             int rc = ocean_stream_flipped_tables(o);
             if (rc) return rc;
             const long last = (long)(o->L - 1) * o->grid.W;
@@ -1842,7 +2045,12 @@ int ocean_launch_stream(dmg_ocean *o, int lo, int hi, int part, int zone_lo, int
             ad.y_first = o->grid.H - a.y_first - o->L;
             ad.spole = a.npole; ad.npole = a.spole;
         }
-        if (div2) hipLaunchKernelGGL(k_jacobi_stream<1>, dim3((unsigned)tl->n), dim3(64), (size_t)extra_lds, st, a, ad);
+        if (tl->twin) {
+            o->last_kernel = "k_jacobi_stream_twin";
+            if (div2) hipLaunchKernelGGL(k_jacobi_stream_twin<1>, dim3((unsigned)tl->n), dim3(128), 0, st, a, ad);
+            else hipLaunchKernelGGL(k_jacobi_stream_twin<0>, dim3((unsigned)tl->n), dim3(128), 0, st, a, ad);
+        }
+        else if (div2) hipLaunchKernelGGL(k_jacobi_stream<1>, dim3((unsigned)tl->n), dim3(64), (size_t)extra_lds, st, a, ad);
         else hipLaunchKernelGGL(k_jacobi_stream<0>, dim3((unsigned)tl->n), dim3(64), (size_t)extra_lds, st, a, ad);
     }
     DMG_HIP(hipGetLastError());
@@ -1860,15 +2068,16 @@ int ocean_launch_stream(dmg_ocean *o, int lo, int hi, int part, int zone_lo, int
 #endif
     if (prof_now && a.prof) {
         prof_done = true;
-        std::vector<unsigned long long> tt((size_t)tl->n * 3);
-        std::vector<int> uu((size_t)tl->n * 4);
+        const int n_units = (int)tl->n_units;
+        std::vector<unsigned long long> tt((size_t)n_units * 3);
+        std::vector<int> uu((size_t)n_units * 4);
         DMG_HIP(hipStreamSynchronize(st));
         DMG_HIP(hipMemcpy(tt.data(), a.prof, tt.size() * 8, hipMemcpyDeviceToHost));
         DMG_HIP(hipMemcpy(uu.data(), tl->d, uu.size() * 4, hipMemcpyDeviceToHost));
         (void)hipFree(a.prof);
         if (FILE *f = fopen(prof_path, "w")) {
             fprintf(f, "tx,r0,r1,open,mixed,land,t0,t1,hwid,xcc\n");
-            for (int i = 0; i < tl->n; i++) {
+            for (int i = 0; i < n_units; i++) {
                 int cnt[3] = { 0, 0, 0 };
                 const unsigned char *cls = o->rowclass_host.empty() ? nullptr : o->rowclass_host.data() + (size_t)uu[4 * i] * o->L;
                 for (int r = uu[4 * i + 1] - TB_T; r < uu[4 * i + 2] + TB_T; r++) cnt[(cls && r >= 0 && r < o->L) ? cls[r] : 2]++;

@@ -3,7 +3,7 @@ DMG_TB_SHAPE (read once per process, hence a child process), against the ORACLE 
 on coast-heavy inputs -- isolated land cells, random starting pressure, band splits with split launches.
 Exit code 0 = everything bit-identical.
 
-usage: python tests/stream_worker.py <case> [...]      cases: random, pepper, golden, bands, split
+usage: python tests/stream_worker.py <case> [...]      cases: random, pepper, golden, bands, split, open, twin
 """
 import os
 import sys
@@ -188,6 +188,44 @@ def case_open(capi, ctx, oracle, names):
     return ok
 
 
+def case_twin(capi, ctx, oracle, names):
+    """twin units (round 4: pairs of units that start on a common seam and hand each other their first row of every level
+    while their pipelines fill, k_jacobi_stream_twin): seams in open water, on coast rows and next to rows that are land
+    everywhere, pairs with an empty or a one-row side (short stretches of water between wide land), poles and belts, odd
+    heights, random start, one to five launches -- against the oracle.  Launches of up to 1200 rows take the twin cut
+    whenever the simulated dispatch prefers it; DMG_ST_TWIN=2 in the environment forces it."""
+    from demiurge_amd import synth
+    rng = np.random.default_rng(43)
+    ok = True
+    cases = [(2048, 512, 24, "ocean", capi.FULL_GLOBE), (1000, 333, 40, "ocean", BELT), (4096, 1024, 24, "survey", capi.FULL_GLOBE),
+             (2048, 777, 16, "survey", BELT), (512, 301, 29, "ocean", capi.FULL_GLOBE), (1024, 200, 16, "stripes", capi.FULL_GLOBE),
+             (512, 64, 8, "stripes", BELT), (16384, 1024, 16, "survey", capi.FULL_GLOBE), (768, 1100, 13, "pepper", capi.FULL_GLOBE)]
+    for W, H, iters, terrain, coords in cases:
+        grid = capi.make_grid(W, H, coords)
+        if terrain == "survey":
+            img = synth.terrain(W, H).copy()
+        elif terrain == "stripes":
+            # bands of land of 1 .. 40 rows between bands of water of 1 .. 30 rows, different from strip to strip
+            img = -np.ones((H, W), f32)
+            for x0 in range(0, W, 240):
+                y = int(rng.integers(0, 12))
+                while y < H:
+                    y += int(rng.integers(1, 31))
+                    h = int(rng.integers(1, 41))
+                    img[y:y + h, x0:x0 + 240] = 1.0
+                    y += h
+        elif terrain == "pepper":
+            img = np.where(rng.random((H, W)) < 0.15, 1.0, -1.0).astype(f32)
+        else:
+            img = -np.ones((H, W), f32)
+        b = rng.standard_normal((H, W)).astype(f32)
+        p0 = rng.standard_normal((H, W)).astype(f32)
+        ref = oracle.ocean_jacobi(ogrid(oracle, grid), img, b, iters, p0=p0, rows=True, nthreads=16)
+        ok &= same("twin units %dx%d x%d %s %s" % (W, H, iters, terrain, "belt" if coords is BELT else "globe"),
+                   solve(capi, ctx, grid, img, b, iters, p0=p0, names=names), ref)
+    return ok
+
+
 def main():
     import oracle
     from demiurge_amd import capi
@@ -195,7 +233,7 @@ def main():
     names = set()
     ok = True
     for c in sys.argv[1:]:
-        ok &= {"random": case_random, "pepper": case_pepper, "golden": case_golden, "bands": case_bands, "split": case_split, "open": case_open}[c](capi, ctx, oracle, names)
+        ok &= {"random": case_random, "pepper": case_pepper, "golden": case_golden, "bands": case_bands, "split": case_split, "open": case_open, "twin": case_twin}[c](capi, ctx, oracle, names)
     print("kernels:", sorted(names), "DMG_TB_SHAPE =", os.environ.get("DMG_TB_SHAPE"), flush=True)
     ctx.close()
     if not ok:
