@@ -196,9 +196,9 @@ def measure_traffic(args, kernels):
             for row in csv.DictReader(open(files[0])):
                 if row["Counter_Name"] != counter:
                     continue
-                for k in kernels:
-                    if k in row["Kernel_Name"]:
-                        vals.setdefault((k, counter), []).append(float(row["Counter_Value"]))
+                hits = [k for k in kernels if k in row["Kernel_Name"]]
+                if hits:                                  # (the longest name: k_jacobi_stream_twin is not k_jacobi_stream)
+                    vals.setdefault((max(hits, key=len), counter), []).append(float(row["Counter_Value"]))
         for k in kernels:
             f, w = vals.get((k, "FETCH_SIZE")), vals.get((k, "WRITE_SIZE"))
             if not f or not w:
@@ -522,7 +522,7 @@ def main():
     # ---- HBM traffic of both kernels, measured by a profiled child of this run ----
     traffic, traffic_src = ({}, "not collected")
     if extra:
-        traffic, traffic_src = measure_traffic(args, ["k_jacobi_stream", "k_jacobi_tb8", "k_jacobi_sweep_v4"])
+        traffic, traffic_src = measure_traffic(args, ["k_jacobi_stream", "k_jacobi_stream_twin", "k_jacobi_tb8", "k_jacobi_sweep_v4"])
 
     def traffic_of(k):          # measured in this run, or nothing: a committed figure would be another build's
         if k in traffic:

@@ -1784,7 +1784,10 @@ static const dmg_ocean::tile_list *st_units(dmg_ocean *o, int variant, int lo, i
             }
         // ... and into twin units (pairs that start on a common seam and need no halo between them: k_jacobi_stream_twin), one round's worth
         static const int twin_env = [] { const char *e = getenv("DMG_ST_TWIN"); return e ? atoi(e) : ST_TWIN_DEFAULT; }();
-        if (twin_env && bal_env && variant == 0 && !o->rowclass_host.empty() && (int)best.size() <= slots + slots / 10 && hi - lo <= bal_rows) {
+        // (up to the band of a 4-way split: at 16384 x 2048 one round of twin units takes 80.0 us against 82.0 on the survey terrain and 96.6
+        // against 116.9 without land; from 4096 rows on a round's units would be taller than ST_TWIN_MAXROWS and the simulation prefers the plain cut)
+        static const int twin_rows = [] { const char *e = getenv("DMG_ST_TWIN_ROWS"); return e ? atoi(e) : 2400; }();
+        if (twin_env && bal_env && variant == 0 && !o->rowclass_host.empty() && hi - lo <= twin_rows) {
             st_cut_balanced(o, lo, hi, slots, part, zone_lo, zone_hi, units, 0, true);
             if (!units.empty()) {
                 const float span = st_makespan(units, slots / 2);          // (a pair holds two of the slots)
@@ -1873,6 +1876,7 @@ static const dmg_ocean::tile_list *st_units(dmg_ocean *o, int variant, int lo, i
     for (const st_unit &u : best) {
         int flag = 0;
         if (u.rlo >= 0) {                                  // the unit above the seam, then the one below it in the mirrored view's rows
+            if (u.r1 - u.r0 > ST_TWIN_MAXROWS || u.r0 - u.rlo > ST_TWIN_MAXROWS) { dmg_fail(DMG_ESTATE, "a twin unit of more than %d rows", ST_TWIN_MAXROWS); return nullptr; }
             flat.push_back(u.tx); flat.push_back(u.r0); flat.push_back(u.r1); flat.push_back(4);
             flat.push_back(u.tx); flat.push_back(o->L - u.r0); flat.push_back(o->L - u.rlo); flat.push_back(4 | 2);
             n_flip++;

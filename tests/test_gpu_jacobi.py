@@ -382,9 +382,27 @@ def test_streaming_forms_forced_vs_oracle(form):
     coast-heavy inputs with random starting pressure (tests/stream_worker.py: 20 random geometries, salt-and-pepper land
     at 2048x1024 on globe and belt, band splits with ghost 8 and 16), and against the reference's own llvmpipe output
     after its full 5000 sweeps (256x128 golden, 625 streaming launches)."""
-    out = _stream_worker({"DMG_TB_SHAPE": form}, ["random", "pepper", "golden", "bands"])
+    # (DMG_ST_TWIN=0: the plain units; the twin units that small launches take by default have their own test below)
+    out = _stream_worker({"DMG_TB_SHAPE": form, "DMG_ST_TWIN": "0"}, ["random", "pepper", "golden", "bands"])
     kern = {"stream": "k_jacobi_stream", "stream-n": "k_jacobi_stream_n", "stream-p": "k_jacobi_stream_p"}[form]
     assert "'%s'" % kern in out, out[-1500:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{}, {"DMG_JACOBI_DIV2": "0"}, {"DMG_DIV2_FORCE_BAD": "7"}, {"DMG_ST_TWIN": "1"}],
+                         ids=["forced", "three-op-division", "every-7th-row-without-pair", "where-the-simulation-prefers-them"])
+def test_streaming_twin_units_vs_oracle(env):
+    """Round 4: launches of about one round (the band of an 8-way or 4-way split, every small grid) are cut into TWIN units --
+    two waves of one workgroup that start on the two sides of a seam row and stream away from it, handing each other their
+    first row of every level through LDS while their pipelines fill: no halo rows between them (k_jacobi_stream_twin).
+    Forced for every launch of up to 2400 rows (DMG_ST_TWIN=2) and as the default choice: seams in open water, on coast rows,
+    next to rows that are land everywhere, pairs with an empty or a one-row side, poles and belts, odd heights, 16384 x 1024
+    (the 8-way band itself), the 20 random geometries, salt-and-pepper coasts, the 5000-sweep golden against llvmpipe, band
+    splits with whole and with split launches (the interior half of a split launch is twin units, its send zones plain
+    ones) -- against the oracle, in both division forms and beside rows without an exact divisor pair."""
+    e = dict({"DMG_TB_SHAPE": "stream", "DMG_ST_TWIN": "2"}, **env)
+    out = _stream_worker(e, ["twin", "random", "golden", "bands", "split"] + (["pepper"] if not env else []), timeout=1500)
+    assert "'k_jacobi_stream_twin'" in out, out[-1500:]
 
 
 @pytest.mark.gpu
@@ -395,7 +413,7 @@ def test_streaming_division_forms_vs_oracle(env):
     same bits: the three-operation division everywhere (DMG_JACOBI_DIV2=0), and rows that have no exact pair -- one in a
     thousand at 16384x8192, forced here for every 7th row and for every row -- which take the three-operation form row by
     row inside the two-operation kernel."""
-    _stream_worker(dict(env, DMG_TB_SHAPE="stream"), ["random", "pepper", "golden"])
+    _stream_worker(dict(env, DMG_TB_SHAPE="stream", DMG_ST_TWIN="0"), ["random", "pepper", "golden"])
 
 
 @pytest.mark.gpu
@@ -409,7 +427,7 @@ def test_streaming_open_water_units_vs_oracle(env):
     continents (open units next to coast units), odd heights, a belt canvas, random starting pressure, at unit heights from 24
     to 232 rows (even and odd: the tail steps), beside rows without an exact divisor pair (never inside an open unit) and in
     the three-operation division form: against the oracle.  With the open units switched off the same cases give the same bits."""
-    out = _stream_worker(dict({"DMG_ST_OPEN_UNITS": "1"}, **dict(env, DMG_TB_SHAPE="stream", DMG_ST_DEBUG="1")), ["open"])
+    out = _stream_worker(dict({"DMG_ST_OPEN_UNITS": "1", "DMG_ST_TWIN": "0"}, **dict(env, DMG_TB_SHAPE="stream", DMG_ST_DEBUG="1")), ["open"])
     assert "'k_jacobi_stream'" in out, out[-1500:]
     if env.get("DMG_ST_OPEN_UNITS") != "0":
         import re
@@ -424,7 +442,7 @@ def test_streaming_southward_units_vs_oracle(flip):
     units start, or end, on the halo rows they share and one of them finds those rows in the L2.  With and without it: the
     random geometries (poles, belts, odd sizes, all-land and all-water rows), salt-and-pepper coasts, the 5000-sweep golden
     against llvmpipe, band splits and split launches, open-water grids at several unit heights -- against the oracle."""
-    env = {"DMG_TB_SHAPE": "stream", "DMG_ST_FLIP": flip, "DMG_ST_DEBUG": "1"}
+    env = {"DMG_TB_SHAPE": "stream", "DMG_ST_FLIP": flip, "DMG_ST_DEBUG": "1", "DMG_ST_TWIN": "0"}       # (twin units: their own test)
     out = _stream_worker(env, ["random", "pepper", "golden", "bands", "split", "open"], timeout=1500)
     import re
     n = sum(int(m) for m in re.findall(r"(\d+) stream southwards", out))
