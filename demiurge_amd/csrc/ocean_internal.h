@@ -50,7 +50,8 @@ struct dmg_ocean {
         int *seg_ctl = nullptr;
         int cap = 0, waves = 0;
         int twin = 0;                                    // streaming kernel: the list holds pairs of twin units (two entries per workgroup, k_jacobi_stream_twin)
-        size_t n_units = 0;                              // units in the list (2 n for twin units)
+        size_t n_units = 0;                              // entries in the list (2 n for twin units)
+        size_t n_cut_units = 0;                          // ... that are units of the cut (not place holders)
         int cut_twin = 0;
         int n_flip = 0;                                  // streaming kernel: units of this list that stream southwards (they need the mirrored row tables)
         int cut_seg = 0, cut_seg2 = 0, cut_split = 0;   // streaming kernel: the cut of a launch's rows into units (the halves of a split launch share the whole launch's)

@@ -509,7 +509,7 @@ __device__ __forceinline__ void st_step(const st_args &a, st_state &z, v4f (*bri
     // slots 43..62 = when the even step's levels are done, of a unit's first 20 iterations (slots 0..21: top of the iteration)
     if (!P && K == 0 && a.stepprof && lane == 0 && t < 40) {
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");          // (the even step's six loads are the oldest of the twelve in flight)
-        a.stepprof[(size_t)blockIdx.x * 64 + 22 + t / 2] = __builtin_amdgcn_s_memrealtime();
+        a.stepprof[(size_t)(TW ? 2 * blockIdx.x + (threadIdx.x >> 6) : blockIdx.x) * 64 + 22 + t / 2] = __builtin_amdgcn_s_memrealtime();
     }
 #endif
     st_arrive<K>(a, z, bring, cring, lane, 0, e_t, clsA, z.slot, landA, mixA);
@@ -580,7 +580,7 @@ __device__ __forceinline__ void st_step(const st_args &a, st_state &z, v4f (*bri
     }
     z.slot = z.slot + 2 == ST_RING ? 0 : z.slot + 2;
 #ifdef ST_EXPERIMENTS
-    if (!P && K == 0 && a.stepprof && lane == 0 && t < 40) a.stepprof[(size_t)blockIdx.x * 64 + 43 + t / 2] = __builtin_amdgcn_s_memrealtime();
+    if (!P && K == 0 && a.stepprof && lane == 0 && t < 40) a.stepprof[(size_t)(TW ? 2 * blockIdx.x + (threadIdx.x >> 6) : blockIdx.x) * 64 + 43 + t / 2] = __builtin_amdgcn_s_memrealtime();
 #endif
 }
 
@@ -836,9 +836,14 @@ __global__ __launch_bounds__(128, 2) void k_jacobi_stream_twin(st_args a_up, st_
     v4f (*bring)[64] = bring2[wave];
     unsigned (*cring)[64] = cring2[wave];
     v4f *ktab = ktab2[wave];
+#ifdef ST_EXPERIMENTS
+    const unsigned long long t_entry = __builtin_amdgcn_s_memrealtime();
+#endif
     const int4 u = a_up.units[2 * blockIdx.x + wave];
     const int tx = __builtin_amdgcn_readfirstlane(u.x), r0 = __builtin_amdgcn_readfirstlane(u.y), r1 = __builtin_amdgcn_readfirstlane(u.z);
-    const st_args &a = wave ? a_dn : a_up;
+    const int uflags = __builtin_amdgcn_readfirstlane(u.w);
+    if (uflags & 8) return;                            // a workgroup that only holds its place in the list (st_place_twins): both its entries say so
+    const st_args &a = (uflags & 2) ? a_dn : a_up;     // (either unit of a pair can be the workgroup's first wave)
     const int W = a.W;
     if (a.prof && lane == 0) {
         a.prof[3 * (2 * blockIdx.x + wave)] = __builtin_amdgcn_s_memrealtime();
@@ -894,10 +899,16 @@ __global__ __launch_bounds__(128, 2) void k_jacobi_stream_twin(st_args a_up, st_
     v4f (*xme)[64] = xch[wave];
     const v4f (*xpeer)[64] = xch[wave ^ 1];
     for (int t = 0; t < nsteps; t += 2) {
+#ifdef ST_EXPERIMENTS
+        if (a.stepprof && lane == 0 && t < 44) a.stepprof[(size_t)(2 * blockIdx.x + wave) * 64 + t / 2] = __builtin_amdgcn_s_memrealtime();
+#endif
         st_step<0, false, DV, 1>(a, z, bring, cring, ktab, lane, t, e0, nsteps, r1, cls_lo, cls_hi, col, colp, lane_ok, xcol, 0, xme, xpeer);
         st_step<1, false, DV, 1>(a, z, bring, cring, ktab, lane, t + 1, e0, nsteps, r1, cls_lo, cls_hi, col, colp, lane_ok, xcol, 0, xme, xpeer);
     }
     if (a.prof && lane == 0) a.prof[3 * (2 * blockIdx.x + wave) + 1] = __builtin_amdgcn_s_memrealtime();
+#ifdef ST_EXPERIMENTS
+    if (a.stepprof && lane == 0) { a.stepprof[(size_t)(2 * blockIdx.x + wave) * 64 + 63] = __builtin_amdgcn_s_memrealtime(); a.stepprof[(size_t)(2 * blockIdx.x + wave) * 64 + 62] = t_entry; }
+#endif
 }
 
 // =================================================================================================================
@@ -1308,7 +1319,79 @@ static int st_unit_rows()                                 // DMG_ST_ROWS=<n>: fi
 namespace {
 struct st_unit { int tx, r0, r1; float cost; int flip = 0;         // flip: the unit streams southwards (k_jacobi_stream's second view)
                  int rlo = -1;                                     // >= 0: a pair of twin units (k_jacobi_stream_twin) -- rows [r0, r1) northwards and [rlo, r0) southwards from the seam r0
+                 float cost_n = 0.0f, cost_s = 0.0f;               // twin pair: the northward and the southward unit's cost (cost = 16 x the dearer)
+                 int south_first = 0;                              // twin pair: the southward unit is the workgroup's first wave (st_place_twins)
+                 int dummy = 0;                                    // a workgroup that ends at once (keeps its successors on the CUs st_place_twins meant them for)
                  int first() const { return rlo >= 0 ? rlo : r0; } };
+}
+
+// What the steps of a unit are made of, as the kernel will run them (st_step): a step whose ten rows in flight are all open
+// water runs its eight levels as one block without a test; one with coast rows but no row that is land everywhere runs every
+// row through the coast formula; every other step -- the pipeline's fill, a land row in flight -- takes the tested path, level by
+// level and row by row.  cls: the strip's row classes (null: all mixed), rows outside [0, L) and outside the grid count as mixed
+// as in the kernel; flip: the unit runs on the mirrored view (rows r0, r1 are that view's); twin: its window starts on r0.
+struct st_features { int fast = 0, coast = 0, tested = 0; int t_open = 0, t_mixed = 0, t_land = 0;     // tested: steps past the fill; t_*: their level-rows by class
+                     int f_open = 0, f_mixed = 0, f_land = 0; };                                    // the fill steps' level-rows
+static st_features st_unit_features(const unsigned char *cls, int L, int y_first, int H, int r0, int r1, bool flip, bool twin)
+{
+    st_features f;
+    const int e0 = twin ? r0 : r0 - TB_T, nsteps = (((r1 - r0) + (twin ? TB_T : 2 * TB_T) + 3) / 4) * 2;
+    const int yf = flip ? H - y_first - L : y_first;
+    auto cl = [&](int lu) -> int {
+        if (lu < e0) return 1;                              // rows before the window: "land" (st_state::landbits)
+        const int yg = yf + lu;
+        if (!cls || lu < 0 || lu >= L || yg < 0 || yg >= H) return 2;
+        return cls[flip ? L - 1 - lu : lu];
+    };
+    for (int t = 0; t < nsteps; t++) {
+        const int newest = e0 + 2 * t + 1;
+        bool land = false, mix = false;
+        for (int k = 0; k < 10; k++) { const int c = cl(newest - k); land |= c == 1; mix |= c == 2; }
+        const bool filled = t >= (twin ? TB_T / 2 : TB_T);
+        if (filled && !land && !mix) f.fast++;
+        else if (filled && !land) f.coast++;
+        else {
+            if (filled) f.tested++;
+            for (int S = 1; S <= 8; S++) {
+                if (twin ? S > 2 * t + 1 : S > t) continue;
+                for (int k = S - 1; k <= S; k++) {
+                    const int c = cl(newest - 1 - k);
+                    if (filled) (c == 0 ? f.t_open : (c == 2 ? f.t_mixed : f.t_land))++;
+                    else (c == 0 ? f.f_open : (c == 2 ? f.f_mixed : f.f_land))++;
+                }
+            }
+        }
+    }
+    return f;
+}
+
+// A unit's predicted time in "open-water steps", from what its steps are made of.  The weights are the marginal costs that
+// per-unit timings of a 16384 x 1024 band give when regressed on these counts (DMG_ST_PROF, six launches of two cuts, younger
+// and older wave of a SIMD apart; profiles/r04_twin_units.txt): a step through the coast formula 1.6 .. 1.7 open-water steps;
+// a tested step (a land row in flight) per row and level it visits 0.05 for an open row, 0.14 for a coast row and 0.11 for a
+// LAND row -- a land row computes nothing, but a level visit on the tested path costs its tests and branches whatever its
+// rows are, which is what round 3's step clocks showed for skipped levels; the fill steps 0.37 + the same per row and level
+// (step clocks: 1.0 + 0.12 us per level-row against 2.7 us for a full step).  r0, r1 in the band's own numbering; flip: the
+// unit streams southwards; twin: its window starts on its first row (no halo there).
+struct st_weights {
+    float coast, t_open, t_mixed, t_land;
+    static const st_weights &get()
+    {
+        static const st_weights w = [] {
+            auto env = [](const char *name, float dflt) { const char *e = getenv(name); return e ? (float)atof(e) : dflt; };
+            return st_weights{ env("DMG_ST_WCOAST", 1.7f), env("DMG_ST_WTOPEN", 0.05f), env("DMG_ST_WTMIXED", 0.14f), env("DMG_ST_WTLAND", 0.11f) };
+        }();
+        return w;
+    }
+};
+static float st_exact_cost(const dmg_ocean *o, int tx, int r0, int r1, bool flip, bool twin)
+{
+    const st_weights &w = st_weights::get();
+    const unsigned char *cls = o->rowclass_host.empty() ? nullptr : o->rowclass_host.data() + (size_t)tx * o->L;
+    const st_features f = st_unit_features(cls, o->L, o->y0 - o->gs, o->grid.H, flip ? o->L - r1 : r0, flip ? o->L - r0 : r1, flip, twin);
+    const float fill_steps = twin ? 4.0f : 8.0f;
+    return 0.7f + (float)f.fast + w.coast * (float)f.coast + 0.37f * fill_steps + w.t_open * (float)(f.t_open + f.f_open) + w.t_mixed * (float)(f.t_mixed + f.f_mixed) +
+           w.t_land * (float)(f.t_land + f.f_land);
 }
 
 // what the dispatch simulation charges a unit of rows [r0, r1) of a strip (cls: the strip's row classes, or null): its
@@ -1442,8 +1525,9 @@ static void st_cut_balanced(const dmg_ocean *o, int lo, int hi, int want, int pa
             const bool edge = rlo < zone_lo || r1 > zone_hi;
             if (edge != (part == 1)) return;
         }
-        st_unit u{ tx, seam, r1, std::max(st_unit_cost(cls, L, seam, r1, 0, 1), st_unit_cost(cls, L, rlo, seam, 0, 2)), 0 };
-        u.rlo = rlo;
+        const float cn = st_exact_cost(o, tx, seam, r1, false, true), cs = st_exact_cost(o, tx, rlo, seam, true, true);
+        st_unit u{ tx, seam, r1, 16.0f * std::max(cn, cs), 0 };
+        u.rlo = rlo; u.cost_n = cn; u.cost_s = cs;
         units.push_back(u);
     };
     // the send zones: short units of their own, as in st_cut
@@ -1457,7 +1541,36 @@ static void st_cut_balanced(const dmg_ocean *o, int lo, int hi, int want, int pa
     // stretches of water in the middle zone
     struct stretch { int tx, r0, r1, k; double cost; };
     std::vector<stretch> st;
-    auto roww = [&](const unsigned char *cls, int r) { const int c = cls ? cls[r] : 0; return c == 1 ? 0.1 : (c == 2 ? 1.4 : 1.0); };
+    static const double w_mixed = [] { const char *e = getenv("DMG_ST_WMIXED"); return e ? atof(e) : 1.4; }();
+    // twin units: what a row adds to its unit is what the STEP it arrives in costs (st_exact_cost's weights: its ten rows in flight
+    // decide the step's form), so that a stretch's weight, the number of units it is given and its first cut are priced the way
+    // the finished units will be.  (Priced row by row -- a coast row 1.4, a land row 0.1 -- the stretches along the coasts got
+    // too few units: forcing the coast weight to 2.4 brought the 8-way band from 52.9 to 48.1 us, profiles/r04_twin_units.txt.)
+    std::vector<float> step_w;
+    if (twin && classes) {
+        const st_weights &w = st_weights::get();
+        step_w.assign((size_t)tiles_x * L, 1.0f);
+        for (int tx = 0; tx < tiles_x; tx++) {
+            const unsigned char *cls = table.data() + (size_t)tx * L;
+            auto cl = [&](int r) { return r >= 0 && r < L ? (int)cls[r] : 2; };
+            for (int r = std::max(lo - 1, 0); r < std::min(hi + 1, L); r++) {
+                bool land = false, mix = false;
+                for (int k = 0; k < 10; k++) { const int c = cl(r - k); land |= c == 1; mix |= c == 2; }
+                float v;
+                if (land) {
+                    v = 0.0f;
+                    for (int S = 1; S <= 8; S++)
+                        for (int k = S; k <= S + 1; k++) { const int c = cl(r - k); v += c == 0 ? w.t_open : (c == 2 ? w.t_mixed : w.t_land); }
+                } else v = mix ? w.coast : 1.0f;
+                step_w[(size_t)tx * L + r] = v;
+            }
+        }
+    }
+    auto roww = [&](const unsigned char *cls, int r) -> double {
+        if (!step_w.empty()) return step_w[(size_t)(cls - table.data()) + r];
+        const int c = cls ? cls[r] : 0;
+        return c == 1 ? 0.1 : (c == 2 ? w_mixed : 1.0);
+    };
     for (int tx = 0; tx < tiles_x; tx++) {
         const unsigned char *cls = classes ? table.data() + (size_t)tx * L : nullptr;
         int r = mid_lo;
@@ -1507,23 +1620,7 @@ static void st_cut_balanced(const dmg_ocean *o, int lo, int hi, int want, int pa
         const unsigned char *cls = classes ? table.data() + (size_t)x.tx * L : nullptr;
         int r = x.r0;
         double acc = 0.0;
-        if (twin) {
-            // the stretch's k units end at rows c[1] .. c[k] of equal cumulative cost; units 2j (southwards) and 2j + 1 (northwards) meet on c[2j + 1]
-            std::vector<int> c((size_t)x.k + 1, x.r1);
-            c[0] = x.r0;
-            bool capped = false;
-            for (int u = 0; u < x.k; u++) {
-                const int u0 = r;
-                const double upto = x.cost * (u + 1) / x.k;
-                while (r < x.r1 && (u == x.k - 1 || acc + 0.5 * roww(cls, r) <= upto)) { acc += roww(cls, r); r++; }
-                c[u + 1] = r;
-                capped |= r - u0 > ST_TWIN_MAXROWS;
-            }
-            if (capped)                                           // (a unit of mostly land grew past the row limit: equal rows instead)
-                for (int u = 1; u < x.k; u++) c[u] = x.r0 + (int)((long long)(x.r1 - x.r0) * u / x.k);
-            for (int j = 0; j + 1 < x.k; j += 2) emit_twin(x.tx, cls, c[j], c[j + 1], c[j + 2]);
-            continue;
-        }
+        if (twin) continue;                                   // (below)
         for (int u = 0; u < x.k; u++) {
             const int u0 = r;
             const double upto = x.cost * (u + 1) / x.k;
@@ -1535,6 +1632,124 @@ static void st_cut_balanced(const dmg_ocean *o, int lo, int hi, int want, int pa
                 break;
             }
             emit(x.tx, cls, u0, r, flipping && (u & 1));
+        }
+    }
+    if (twin) {
+        // Twin units.  A stretch's k units end at rows c[1] .. c[k]; units 2j (southwards) and 2j + 1 (northwards) meet on the
+        // seam c[2j + 1].  What a unit costs is not a sum over its rows -- one coast row puts the five steps it is in flight for
+        // through the coast formula, a land row makes them tested steps, a unit's steps come in pairs -- so units are priced as
+        // the kernel will run them (st_exact_cost), the stretches are packed under a common limit (below), and the boundaries are
+        // then moved, up to four rows at a time, towards the dearer of the two units they separate.
+        struct cutline { std::vector<int> c; float worst = 0.0f; };
+        auto unit_cost = [&](const stretch &x, const std::vector<int> &c, int u) -> float {
+            const unsigned char *cls = classes ? table.data() + (size_t)x.tx * L : nullptr;
+            int a = c[u], b = c[u + 1];
+            if (u & 1) { while (cls && b > a && cls[b - 1] == 1) b--; }      // (the far ends are trimmed: emit_twin)
+            else { while (cls && a < b && cls[a] == 1) a++; }
+            return st_exact_cost(o, x.tx, a, b, !(u & 1), true);
+        };
+        auto first_cut = [&](const stretch &x, std::vector<int> &c) {
+            const unsigned char *cls = classes ? table.data() + (size_t)x.tx * L : nullptr;
+            c.assign((size_t)x.k + 1, x.r1);
+            c[0] = x.r0;
+            int r = x.r0;
+            double acc = 0.0;
+            bool capped = false;
+            for (int u = 0; u < x.k; u++) {
+                const int u0 = r;
+                const double upto = x.cost * (u + 1) / x.k;
+                while (r < x.r1 && (u == x.k - 1 || acc + 0.5 * roww(cls, r) <= upto)) { acc += roww(cls, r); r++; }
+                c[u + 1] = r;
+                capped |= r - u0 > ST_TWIN_MAXROWS;
+            }
+            if (capped)                                           // (a unit of mostly land grew past the row limit: equal rows instead)
+                for (int u = 1; u < x.k; u++) c[u] = x.r0 + (int)((long long)(x.r1 - x.r0) * u / x.k);
+        };
+        auto refine = [&](const stretch &x, cutline &cl) {
+            std::vector<int> &c = cl.c;
+            std::vector<float> cost((size_t)x.k);
+            for (int u = 0; u < x.k; u++) cost[u] = unit_cost(x, c, u);
+            for (int sweep = 0; sweep < 48; sweep++) {
+                bool moved = false;
+                for (int b = 1; b < x.k; b++) {
+                    // (a unit's steps come in pairs, four rows: its cost is a staircase in its rows, so moves of up to four rows are tried)
+                    const int dir = cost[b - 1] > cost[b] ? -1 : 1;          // shrink the dearer unit
+                    const int old = c[b];
+                    float best_max = std::max(cost[b - 1], cost[b]) - 1e-4f, best_a = 0.0f, best_b = 0.0f;
+                    int best_nb = old;
+                    for (int step = 1; step <= 4; step++) {
+                        const int nb = old + dir * step;
+                        if (nb - c[b - 1] < 1 || c[b + 1] - nb < 1 || nb - c[b - 1] > ST_TWIN_MAXROWS || c[b + 1] - nb > ST_TWIN_MAXROWS) break;
+                        c[b] = nb;
+                        const float ca = unit_cost(x, c, b - 1), cb = unit_cost(x, c, b);
+                        if (std::max(ca, cb) < best_max) { best_max = std::max(ca, cb); best_a = ca; best_b = cb; best_nb = nb; }
+                    }
+                    c[b] = best_nb;
+                    if (best_nb != old) { cost[b - 1] = best_a; cost[b] = best_b; moved = true; }
+                }
+                if (!moved) break;
+            }
+            cl.worst = 0.0f;
+            for (int u = 0; u < x.k; u++) cl.worst = std::max(cl.worst, cost[u]);
+        };
+        std::vector<cutline> cuts(st.size());
+        // How many units a stretch gets: the smallest limit T is looked for (bisection) under which the stretches, each packed
+        // greedily into units that cost at most T -- a unit grows by four rows, one iteration of the kernel's loop, while it stays
+        // under T -- need no more than `want` units together.  (Dealt out by the stretches' summed row weights, the stretches along
+        // the coasts came away with too few: their units end on land, and a unit that ends on land has five tested steps
+        // whatever its height -- forcing the coast weight to 2.4 in that deal brought the 8-way band from 52.9 to 48.1 us.)
+        static const int pack_env = [] { const char *e = getenv("DMG_ST_PACK"); return e ? atoi(e) : 1; }();
+        auto cost_rows = [&](const stretch &x, int a, int b, int u) -> float {
+            const unsigned char *cls = classes ? table.data() + (size_t)x.tx * L : nullptr;
+            if (u & 1) { while (cls && b > a && cls[b - 1] == 1) b--; }
+            else { while (cls && a < b && cls[a] == 1) a++; }
+            return st_exact_cost(o, x.tx, a, b, !(u & 1), true);
+        };
+        auto pack = [&](const stretch &x, float T, std::vector<int> *c) -> int {
+            int r = x.r0, u = 0;
+            if (c) { c->clear(); c->push_back(r); }
+            while (r < x.r1) {
+                int n = std::min(4, x.r1 - r);
+                while (r + n < x.r1 && n + 4 <= ST_TWIN_MAXROWS && cost_rows(x, r, std::min(r + n + 4, x.r1), u) <= T) n = std::min(n + 4, x.r1 - r);
+                if (x.r1 - (r + n) < 3) n = x.r1 - r;                     // (no sliver at the end)
+                r += n; u++;
+                if (c) c->push_back(r);
+            }
+            if (u & 1) { u++; if (c) c->push_back(x.r1); }               // (pairs: an empty unit as the last one's partner)
+            return u;
+        };
+        if (pack_env) {
+            float t_lo = 8.0f, t_hi = 8.0f;
+            for (const stretch &x : st) t_hi = std::max(t_hi, cost_rows(x, x.r0, std::min(x.r1, x.r0 + ST_TWIN_MAXROWS), 1));
+            auto total = [&](float T) { long n = 0; for (const stretch &x : st) n += pack(x, T, nullptr); return n; };
+            if (total(t_hi) <= want)
+                for (int it = 0; it < 12; it++) {
+                    const float mid = 0.5f * (t_lo + t_hi);
+                    if (total(mid) <= want) t_hi = mid; else t_lo = mid;
+                }
+            long have_units = 0;
+            for (size_t i = 0; i < st.size(); i++) { st[i].k = pack(st[i], t_hi, &cuts[i].c); refine(st[i], cuts[i]); have_units += st[i].k; }
+            // (units grow four rows at a time and come in pairs: the limit that fits leaves some of the round unused -- those go, a
+            // pair at a time, to the stretch whose dearest unit is the dearest, while that makes it cheaper)
+            std::vector<char> done(st.size(), 0);
+            while (have_units + 2 <= want) {
+                size_t w = st.size();
+                for (size_t i = 0; i < st.size(); i++) if (!done[i] && (w == st.size() || cuts[i].worst > cuts[w].worst)) w = i;
+                if (w == st.size()) break;
+                stretch x = st[w];
+                if ((x.r1 - x.r0) / (x.k + 2) < 4) { done[w] = 1; continue; }
+                x.k += 2;
+                cutline c2;
+                first_cut(x, c2.c); refine(x, c2);
+                if (c2.worst < cuts[w].worst - 1e-4f) { st[w] = x; cuts[w] = c2; have_units += 2; }
+                else done[w] = 1;
+            }
+        }
+        else for (size_t i = 0; i < st.size(); i++) { first_cut(st[i], cuts[i].c); refine(st[i], cuts[i]); }
+        for (size_t i = 0; i < st.size(); i++) {
+            const stretch &x = st[i];
+            const unsigned char *cls = classes ? table.data() + (size_t)x.tx * L : nullptr;
+            for (int j = 0; j + 1 < x.k; j += 2) emit_twin(x.tx, cls, cuts[i].c[j], cuts[i].c[j + 1], cuts[i].c[j + 2]);
         }
     }
 }
@@ -1669,6 +1884,84 @@ static float st_makespan(std::vector<st_unit> &units, int slots, bool paired = f
     return span;
 }
 
+// Where the workgroups of a one-round launch of twin units run, and next to whom.  Per-unit timings with the hardware ids
+// (DMG_ST_PROF, profiles/r04_twin_units.txt; 256 of 256 CUs alike): workgroup i of a launch of 128-thread workgroups runs on
+// XCD (i + const) mod 8 and on the CU that also gets workgroups i + 256, i + 512, i + 768 (four fit: LDS), and the CU deals their
+// eight waves w0 .. w7 (two per workgroup, in order) to its SIMDs as  S, S+1 | S+1, S+2 | S+2, S+3 | S+3, S  -- so w1 and w2
+// share a SIMD, w3 and w4, w5 and w6, w7 and w0, the first of each couple being the older wave there, the one the SIMD's
+// arbiter serves first.  A SIMD is done when both its waves are: a launch of one round lasts as long as the SIMD with the
+// most work, and with the workgroups in longest-first order that is the one whose older wave came from the dearest quarter
+// of the list and its younger wave from the next (predicted sums 34.6 .. 45.0 around a median of 38.0, and the twelve units
+// that ended last all sat on such SIMDs).  Here the list is ORDERED for that hardware: every XCD gets the pairs of a contiguous
+// range of strips (neighbouring strips share halo columns in its L2, as before); within it the dearest pairs become the CUs'
+// first workgroups, the cheapest their fourth, matched dearest with cheapest, the second and third likewise; and within a CU the
+// order of the two units inside each workgroup (which of them is the first wave) is chosen, all 16 ways tried, so that the
+// four SIMDs' sums are as equal as they can be, the older wave the dearer one where that costs nothing.  If the dispatcher
+// ever deals differently the order is merely arbitrary -- no worse than any other.  Lists of fewer than four workgroups per CU
+// are padded with workgroups that end at once, so that position i + 256 k stays on CU i.
+static void st_place_twins(std::vector<st_unit> &units, int num_cu, int tiles_x)
+{
+    const int C = std::max(num_cu, 8) / 8 * 8, per_x = C / 8;          // CUs, CUs per XCD
+    const int n = (int)units.size();
+    const int R = (n + C - 1) / C;                                      // workgroups per CU
+    if (n == 0 || R > 4) return;
+    std::vector<st_unit> sorted = units;
+    std::sort(sorted.begin(), sorted.end(), [](const st_unit &a, const st_unit &b) { return a.tx != b.tx ? a.tx < b.tx : a.r0 < b.r0; });
+    st_unit dummy{ 0, 0, 0, 0.0f, 0 };
+    dummy.rlo = 0; dummy.dummy = 1;
+    std::vector<st_unit> out((size_t)R * C, dummy);
+    double couple_lo = 1e30, couple_hi = 0.0;
+    for (int x = 0; x < 8; x++) {
+        // this XCD's pairs: a contiguous eighth of the list in strip order
+        const int g0 = (int)((long long)n * x / 8), g1 = (int)((long long)n * (x + 1) / 8);
+        std::vector<st_unit> g(sorted.begin() + g0, sorted.begin() + g1);
+        const int m = (int)g.size();
+        if (!m) continue;
+        // Every workgroup's dearer unit is its SECOND wave: the couples of a CU are then (dearer unit of workgroup r, cheaper unit of
+        // workgroup r + 1), cyclically, the dearer one the older wave of its SIMD.  The CU's workgroups are chosen as a cycle whose
+        // couples all come close to the mean sum: start from the unused pair with the dearest unit, follow it with the pair whose
+        // cheaper unit complements that best, and so on; the last one also has to suit the first.
+        auto hi = [](const st_unit &u) { return std::max(u.cost_n, u.cost_s); };
+        auto lo = [](const st_unit &u) { return std::min(u.cost_n, u.cost_s); };
+        double target = 0.0;
+        for (const st_unit &u : g) target += u.cost_n + u.cost_s;
+        target /= m;                                                    // the mean couple
+        std::vector<char> used((size_t)m, 0);
+        int left = m;
+        for (int t = 0; t < per_x && left > 0; t++) {
+            const int len = std::min(left, (left + (per_x - t) - 1) / (per_x - t));      // this CU's share of what is left (at most R)
+            int cyc[4] = { -1, -1, -1, -1 };
+            for (int r = 0; r < len; r++) {
+                int pick = -1;
+                double best_d = 1e30;
+                for (int i = 0; i < m; i++) {
+                    if (used[i]) continue;
+                    double dd;
+                    if (r == 0) dd = -hi(g[i]);                        // the dearest unit left opens the cycle
+                    else {
+                        dd = std::fabs(hi(g[cyc[r - 1]]) + lo(g[i]) - target);
+                        if (r == len - 1) dd = std::max(dd, std::fabs(hi(g[i]) + lo(g[cyc[0]]) - target));
+                    }
+                    if (dd < best_d) { best_d = dd; pick = i; }
+                }
+                cyc[r] = pick; used[pick] = 1; left--;
+            }
+            for (int r = 0; r < len; r++) {
+                st_unit u = g[cyc[r]];
+                u.south_first = u.cost_s < u.cost_n ? 1 : 0;           // the cheaper unit first
+                out[(size_t)r * C + 8 * t + x] = u;
+                const double couple = hi(g[cyc[r]]) + lo(g[cyc[(r + 1) % len]]);
+                couple_lo = std::min(couple_lo, couple); couple_hi = std::max(couple_hi, couple);
+            }
+        }
+    }
+    // (trailing dummies are dropped: nothing follows them)
+    while (!out.empty() && out.back().dummy) out.pop_back();
+    static const bool dbg = getenv("DMG_ST_DEBUG") != nullptr;
+    if (dbg) fprintf(stderr, "[stream]   %d pairs placed on %d CUs, %d per CU: the SIMDs' predicted sums %.1f .. %.1f steps\n", n, C, R, couple_lo, couple_hi);
+    units.swap(out);
+}
+
 // The unit list of a launch geometry.  A launch has only 2 x 4 x CUs wave slots and its units all take about the same
 // time, so the chip works in "rounds": 2.49 rounds of 96-row units cost as much as 3.  The unit height is therefore chosen
 // per geometry (and terrain) by simulating the dispatch for every candidate height -- taller units recompute less
@@ -1715,7 +2008,7 @@ static const dmg_ocean::tile_list *st_units(dmg_ocean *o, int variant, int lo, i
         };
         cut_as_whole(part, best);
         (void)st_makespan(best, slots);
-        auto units_of = [](const std::vector<st_unit> &v) { size_t n = 0; for (const st_unit &u : v) n += u.rlo >= 0 ? 2 : 1; return n; };
+        auto units_of = [](const std::vector<st_unit> &v) { size_t n = 0; for (const st_unit &u : v) n += u.dummy ? 0 : (u.rlo >= 0 ? 2 : 1); return n; };
         // both halves built: together they must be the units of ONE cut of the launch's rows, each exactly once
         auto other = o->tb_lists.find(std::make_tuple(lo, hi, std::get<2>(key), 3 - part, zone_lo, zone_hi));
         if (other != o->tb_lists.end()) {
@@ -1724,9 +2017,9 @@ static const dmg_ocean::tile_list *st_units(dmg_ocean *o, int variant, int lo, i
             long long rows_all = 0, rows_parts = 0;
             for (const st_unit &u : all) rows_all += u.r1 - u.first();
             for (const st_unit &u : best) rows_parts += u.r1 - u.first();
-            if (other->second.n_units + units_of(best) != units_of(all) || other->second.cut_rows + rows_parts != rows_all) {
+            if (other->second.n_cut_units + units_of(best) != units_of(all) || other->second.cut_rows + rows_parts != rows_all) {
                 dmg_fail(DMG_ESTATE, "split launch over rows [%d, %d): %zu + %zu units in the two parts, %zu in the cut they are halves of", lo, hi,
-                         other->second.n_units, units_of(best), units_of(all));
+                         other->second.n_cut_units, units_of(best), units_of(all));
                 return nullptr;
             }
         }
@@ -1791,9 +2084,28 @@ static const dmg_ocean::tile_list *st_units(dmg_ocean *o, int variant, int lo, i
             st_cut_balanced(o, lo, hi, slots, part, zone_lo, zone_hi, units, 0, true);
             if (!units.empty()) {
                 const float span = st_makespan(units, slots / 2);          // (a pair holds two of the slots)
+                // (the twin units' costs are st_exact_cost's: the cut they are compared with is priced the same way)
+                std::vector<st_unit> ref = best;
+                for (st_unit &u : ref) u.cost = 16.0f * st_exact_cost(o, u.tx, u.r0, u.r1, u.flip != 0, false);
+                const float ref_span = ref.empty() ? 1e30f : st_makespan(ref, slots, true);
                 static const bool dbgc = getenv("DMG_ST_DEBUG") != nullptr;
-                if (dbgc) fprintf(stderr, "[stream]   balanced cut into %zu pairs of twin units: predicted span %.0f (best so far %.0f)\n", units.size(), span, best_span);
-                if (span < best_span || twin_env > 1) { best_span = span; best.swap(units); best_seg = -slots; best_seg2 = 0; best_split = hi; cut_twin = 1; }
+                if (dbgc) {
+                    double sum = 0; float lo_c = 1e30f;
+                    for (const st_unit &u : units) { sum += u.cost; lo_c = std::min(lo_c, u.cost); }
+                    fprintf(stderr, "[stream]   balanced cut into %zu pairs of twin units: predicted span %.0f (dearest pair %.0f, mean %.0f, cheapest %.0f); the best plain cut priced alike: %.0f\n",
+                            units.size(), span, units.front().cost, sum / units.size(), lo_c, ref_span);
+                    for (size_t i = 0; i < units.size() && i < 12; i++) {
+                        const st_unit &u = units[i];
+                        const unsigned char *cls = o->rowclass_host.data() + (size_t)u.tx * o->L;
+                        const st_features fn = st_unit_features(cls, o->L, o->y0 - o->gs, o->grid.H, u.r0, u.r1, false, true);
+                        const st_features fs = st_unit_features(cls, o->L, o->y0 - o->gs, o->grid.H, o->L - u.r0, o->L - u.rlo, true, true);
+                        fprintf(stderr, "[stream]     pair %zu: strip %d rows [%d, %d | %d) cost %.0f; north: %d fast %d coast %d tested (%d/%d/%d) fill (%d/%d/%d) = %.1f; south: %d fast %d coast %d tested (%d/%d/%d) fill (%d/%d/%d) = %.1f\n",
+                                i, u.tx, u.rlo, u.r0, u.r1, u.cost, fn.fast, fn.coast, fn.tested, fn.t_open, fn.t_mixed, fn.t_land, fn.f_open, fn.f_mixed, fn.f_land,
+                                st_exact_cost(o, u.tx, u.r0, u.r1, false, true), fs.fast, fs.coast, fs.tested, fs.t_open, fs.t_mixed, fs.t_land, fs.f_open, fs.f_mixed, fs.f_land,
+                                st_exact_cost(o, u.tx, u.rlo, u.r0, true, true));
+                    }
+                }
+                if (span < ref_span || twin_env > 1) { best_span = span; best.swap(units); best_seg = -slots; best_seg2 = 0; best_split = hi; cut_twin = 1; }
             }
         }
         (void)st_makespan(best, cut_twin ? slots / 2 : slots);      // (longest first)
@@ -1835,7 +2147,10 @@ static const dmg_ocean::tile_list *st_units(dmg_ocean *o, int variant, int lo, i
         // two (+0.7 % on the survey terrain, +1.0 % without land in a same-box A/B; wider cost buckets disturb longest-first
         // and lose).  DMG_ST_XCC=0 keeps the sorted order.
         static const int xcc_mode = [] { const char *e = getenv("DMG_ST_XCC"); return e ? atoi(e) : 1; }();
-        if (xcc_mode && variant == 0 && !best.empty()) {
+        static const int place_mode = [] { const char *e = getenv("DMG_ST_PLACE"); return e ? atoi(e) : 1; }();
+        const bool twins = !best.empty() && best.front().rlo >= 0;
+        if (twins && place_mode && (int)best.size() <= slots / 2) st_place_twins(best, o->ctx->num_cu, (o->grid.W + TB_OW - 1) / TB_OW);
+        else if (xcc_mode && variant == 0 && !best.empty()) {
             const int tiles_x = (o->grid.W + TB_OW - 1) / TB_OW;
             const float top = best.front().cost;
             std::vector<st_unit> out;
@@ -1875,10 +2190,11 @@ static const dmg_ocean::tile_list *st_units(dmg_ocean *o, int variant, int lo, i
     if (n_twin && n_twin != (int)best.size()) { dmg_fail(DMG_ESTATE, "a unit list mixes twin units with plain ones"); return nullptr; }
     for (const st_unit &u : best) {
         int flag = 0;
-        if (u.rlo >= 0) {                                  // the unit above the seam, then the one below it in the mirrored view's rows
+        if (u.rlo >= 0) {                                  // the unit above the seam and the one below it in the mirrored view's rows
             if (u.r1 - u.r0 > ST_TWIN_MAXROWS || u.r0 - u.rlo > ST_TWIN_MAXROWS) { dmg_fail(DMG_ESTATE, "a twin unit of more than %d rows", ST_TWIN_MAXROWS); return nullptr; }
-            flat.push_back(u.tx); flat.push_back(u.r0); flat.push_back(u.r1); flat.push_back(4);
-            flat.push_back(u.tx); flat.push_back(o->L - u.r0); flat.push_back(o->L - u.rlo); flat.push_back(4 | 2);
+            const int north[4] = { u.tx, u.r0, u.r1, u.dummy ? 4 | 8 : 4 }, south[4] = { u.tx, o->L - u.r0, o->L - u.rlo, u.dummy ? 4 | 2 | 8 : 4 | 2 };
+            flat.insert(flat.end(), u.south_first ? south : north, (u.south_first ? south : north) + 4);
+            flat.insert(flat.end(), u.south_first ? north : south, (u.south_first ? north : south) + 4);
             n_flip++;
             continue;
         }
@@ -1902,6 +2218,8 @@ static const dmg_ocean::tile_list *st_units(dmg_ocean *o, int variant, int lo, i
     tl.n = (int)best.size();
     tl.twin = n_twin ? 1 : 0;
     tl.n_units = (size_t)(n_twin ? 2 * tl.n : tl.n);
+    tl.n_cut_units = 0;
+    for (const st_unit &u : best) tl.n_cut_units += u.dummy ? 0 : (u.rlo >= 0 ? 2 : 1);
     tl.n_flip = n_flip;
     tl.cut_seg = cut_seg; tl.cut_seg2 = cut_seg2; tl.cut_split = cut_split; tl.cut_twin = cut_twin;
     tl.cut_rows = 0;
@@ -2002,12 +2320,13 @@ int ocean_launch_stream(dmg_ocean *o, int lo, int hi, int part, int zone_lo, int
 #ifdef ST_EXPERIMENTS
     static const char *stepprof_path = getenv("DMG_ST_STEPPROF");
     static int stepprof_count = 0;
-    const bool stepprof_now = stepprof_path && !variant && tl->n > 1024 && ++stepprof_count == 40;    // the 40th full-size launch
-    if (stepprof_now && (hipMalloc((void **)&a.stepprof, (size_t)tl->n * 64 * 8) != hipSuccess || hipMemset(a.stepprof, 0, (size_t)tl->n * 64 * 8) != hipSuccess)) a.stepprof = nullptr;
+    const bool stepprof_now = stepprof_path && !variant && tl->n_units > 1024 && ++stepprof_count == 40;    // the 40th full-size launch
+    if (stepprof_now && (hipMalloc((void **)&a.stepprof, tl->n_units * 64 * 8) != hipSuccess || hipMemset(a.stepprof, 0, tl->n_units * 64 * 8) != hipSuccess)) a.stepprof = nullptr;
 #endif
     static const char *prof_path = getenv("DMG_ST_PROF");  // experiments: the first full-size launch writes one line per unit to this file
     static bool prof_done = false;
-    const bool prof_now = prof_path && !prof_done && !variant && tl->n_units > 1024;
+    static int prof_skip = [] { const char *e = getenv("DMG_ST_PROF_SKIP"); return e ? atoi(e) : 0; }();      // ... the (n+1)-th such launch: a warm one
+    const bool prof_now = prof_path && !prof_done && !variant && tl->n_units > 1024 && prof_skip-- <= 0;
     if (prof_now && hipMalloc((void **)&a.prof, tl->n_units * 24) != hipSuccess) a.prof = nullptr;
     static const int extra_lds = [] { const char *e = getenv("DMG_ST_EXTRA_LDS"); return e ? atoi(e) : 0; }();   // experiments: caps the waves per CU
     if (variant == 2) {
@@ -2060,12 +2379,12 @@ int ocean_launch_stream(dmg_ocean *o, int lo, int hi, int part, int zone_lo, int
     DMG_HIP(hipGetLastError());
 #ifdef ST_EXPERIMENTS
     if (a.stepprof) {
-        std::vector<unsigned long long> tt((size_t)tl->n * 64);
+        std::vector<unsigned long long> tt(tl->n_units * 64);
         DMG_HIP(hipStreamSynchronize(st));
         DMG_HIP(hipMemcpy(tt.data(), a.stepprof, tt.size() * 8, hipMemcpyDeviceToHost));
         (void)hipFree(a.stepprof);
         if (FILE *f = fopen(stepprof_path, "w")) {
-            for (int i = 0; i < tl->n; i++) { for (int k = 0; k < 64; k++) fprintf(f, "%llu%c", tt[(size_t)i * 64 + k], k == 63 ? '\n' : ','); }
+            for (int i = 0; i < (int)tl->n_units; i++) { for (int k = 0; k < 64; k++) fprintf(f, "%llu%c", tt[(size_t)i * 64 + k], k == 63 ? '\n' : ','); }
             fclose(f);
         }
     }
@@ -2080,13 +2399,21 @@ int ocean_launch_stream(dmg_ocean *o, int lo, int hi, int part, int zone_lo, int
         DMG_HIP(hipMemcpy(uu.data(), tl->d, uu.size() * 4, hipMemcpyDeviceToHost));
         (void)hipFree(a.prof);
         if (FILE *f = fopen(prof_path, "w")) {
-            fprintf(f, "tx,r0,r1,open,mixed,land,t0,t1,hwid,xcc\n");
+            // (r0, r1: the unit's rows in the band's own numbering; open / mixed / land: the classes of its window's rows; then what its
+            // steps are made of, st_unit_features)
+            fprintf(f, "tx,r0,r1,open,mixed,land,t0,t1,hwid,xcc,flip,twin,fast,coast,tested,t_open,t_mixed,t_land,f_open,f_mixed,f_land\n");
             for (int i = 0; i < n_units; i++) {
                 int cnt[3] = { 0, 0, 0 };
                 const unsigned char *cls = o->rowclass_host.empty() ? nullptr : o->rowclass_host.data() + (size_t)uu[4 * i] * o->L;
-                for (int r = uu[4 * i + 1] - TB_T; r < uu[4 * i + 2] + TB_T; r++) cnt[(cls && r >= 0 && r < o->L) ? cls[r] : 2]++;
-                fprintf(f, "%d,%d,%d,%d,%d,%d,%llu,%llu,%llu,%llu\n", uu[4 * i], uu[4 * i + 1], uu[4 * i + 2], cnt[0], cnt[2], cnt[1], tt[3 * i], tt[3 * i + 1],
-                        tt[3 * i + 2] & 0xFFFFFFFFull, tt[3 * i + 2] >> 32);
+                const bool flip = (uu[4 * i + 3] & 2) != 0, twin = (uu[4 * i + 3] & 4) != 0;
+                const int v0 = uu[4 * i + 1], v1 = uu[4 * i + 2];                   // the unit's rows in its view
+                const int b0 = flip ? o->L - v1 : v0, b1 = flip ? o->L - v0 : v1;
+                const int w0 = (twin && !flip) ? b0 : b0 - TB_T, w1 = (twin && flip) ? b1 : b1 + TB_T;
+                for (int r = w0; r < w1; r++) cnt[(cls && r >= 0 && r < o->L) ? cls[r] : 2]++;
+                const st_features ft = st_unit_features(cls, o->L, o->y0 - o->gs, o->grid.H, v0, v1, flip, twin);
+                fprintf(f, "%d,%d,%d,%d,%d,%d,%llu,%llu,%llu,%llu,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d\n", uu[4 * i], b0, b1, cnt[0], cnt[2], cnt[1], tt[3 * i], tt[3 * i + 1],
+                        tt[3 * i + 2] & 0xFFFFFFFFull, tt[3 * i + 2] >> 32, (int)flip, (int)twin, ft.fast, ft.coast, ft.tested, ft.t_open, ft.t_mixed, ft.t_land,
+                        ft.f_open, ft.f_mixed, ft.f_land);
             }
             fclose(f);
         }

@@ -3,7 +3,7 @@ usage: python tools/unit_times.py <file>"""
 import sys
 import numpy as np
 import csv
-rows = list(csv.DictReader(open(sys.argv[1])))
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if int(r["t1"]) > 0]      # (place holders of a twin list record nothing)
 t0 = np.array([int(r["t0"]) for r in rows]) / 100.0
 t1 = np.array([int(r["t1"]) for r in rows]) / 100.0
 h = np.array([int(r["r1"]) - int(r["r0"]) for r in rows])
