@@ -35,6 +35,7 @@
 #include "ocean_internal.h"
 #include "ocean_tb.h"
 #include <algorithm>
+#include <chrono>
 
 // The DMG_ST_DBG experiments (st_args::dbg) are compiled in with -DST_EXPERIMENTS only: one scalar test and branch per level
 // visit costs the kernel 3 % (measured), so the shipped kernels carry none of them
@@ -823,7 +824,7 @@ __global__ __launch_bounds__(64, 2) void k_jacobi_stream(st_args a_up, st_args a
 // plain view), wave 1 the unit below it (the mirrored view); a_up.units holds two entries per workgroup.  The window of a twin
 // unit starts ON its first row (no halo towards the seam); ST_TWIN_MAXROWS keeps the two waves' tables and the 4 KB they
 // trade rows through within a quarter of a CU's LDS: four workgroups, eight waves, two per SIMD as before.
-#define ST_TWIN_MAXROWS 104
+#define ST_TWIN_MAXROWS 152
 template <int DV>
 __global__ __launch_bounds__(128, 2) void k_jacobi_stream_twin(st_args a_up, st_args a_dn)
 {
@@ -2077,24 +2078,35 @@ static const dmg_ocean::tile_list *st_units(dmg_ocean *o, int variant, int lo, i
             }
         // ... and into twin units (pairs that start on a common seam and need no halo between them: k_jacobi_stream_twin), one round's worth
         static const int twin_env = [] { const char *e = getenv("DMG_ST_TWIN"); return e ? atoi(e) : ST_TWIN_DEFAULT; }();
-        // (up to the band of a 4-way split: at 16384 x 2048 one round of twin units takes 80.0 us against 82.0 on the survey terrain and 96.6
-        // against 116.9 without land; from 4096 rows on a round's units would be taller than ST_TWIN_MAXROWS and the simulation prefers the plain cut)
-        static const int twin_rows = [] { const char *e = getenv("DMG_ST_TWIN_ROWS"); return e ? atoi(e) : 2400; }();
+        // (up to the band of a 2-way split.  16384 x 2048: one round of twin units 73.1 us against 81.6 on the survey terrain, 93.9 against
+        // 114.2 without land; 16384 x 4096: 144.2-145.6 against 149.9 / 187.3 against 188.5; at 16384 x 8192 a round's units would be
+        // taller than ST_TWIN_MAXROWS allows, and two or three rounds of shorter twin units LOSE to 1.3 rounds of 200-row plain
+        // ones: 292-296 against 273.9 us, 395 against 362.6 without land -- profiles/r04_twin_units.txt)
+        static const int twin_rows = [] { const char *e = getenv("DMG_ST_TWIN_ROWS"); return e ? atoi(e) : 4400; }();
         if (twin_env && bal_env && variant == 0 && !o->rowclass_host.empty() && hi - lo <= twin_rows) {
-            st_cut_balanced(o, lo, hi, slots, part, zone_lo, zone_hi, units, 0, true);
-            if (!units.empty()) {
+            // (the twin units' costs are st_exact_cost's: the cut they are compared with is priced the same way)
+            std::vector<st_unit> ref = best;
+            for (st_unit &u : ref) u.cost = 16.0f * st_exact_cost(o, u.tx, u.r0, u.r1, u.flip != 0, false);
+            const float ref_span = ref.empty() ? 1e30f : st_makespan(ref, slots, true);
+            float twin_span = 1e30f;
+            std::vector<st_unit> twin_best;
+            int twin_want = 0;
+            // one round's worth of units (DMG_ST_TWIN_ROUNDS=3: also one and a half, two and three rounds' worth -- measured, never better)
+            static const int twin_rounds = [] { const char *e = getenv("DMG_ST_TWIN_ROUNDS"); return e ? atoi(e) : 1; }();
+            for (int eighths = 8; eighths <= 8 * twin_rounds; eighths += (eighths < 16 ? 4 : 8)) {
+                const int want = slots * eighths / 8;
+                const auto t_cut0 = std::chrono::steady_clock::now();
+                st_cut_balanced(o, lo, hi, want, part, zone_lo, zone_hi, units, 0, true);
+                const double cut_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_cut0).count();
+                if (units.empty()) continue;
                 const float span = st_makespan(units, slots / 2);          // (a pair holds two of the slots)
-                // (the twin units' costs are st_exact_cost's: the cut they are compared with is priced the same way)
-                std::vector<st_unit> ref = best;
-                for (st_unit &u : ref) u.cost = 16.0f * st_exact_cost(o, u.tx, u.r0, u.r1, u.flip != 0, false);
-                const float ref_span = ref.empty() ? 1e30f : st_makespan(ref, slots, true);
-                static const bool dbgc = getenv("DMG_ST_DEBUG") != nullptr;
+                static const int dbgc = [] { const char *e = getenv("DMG_ST_DEBUG"); return e ? atoi(e) : 0; }();
                 if (dbgc) {
                     double sum = 0; float lo_c = 1e30f;
                     for (const st_unit &u : units) { sum += u.cost; lo_c = std::min(lo_c, u.cost); }
-                    fprintf(stderr, "[stream]   balanced cut into %zu pairs of twin units: predicted span %.0f (dearest pair %.0f, mean %.0f, cheapest %.0f); the best plain cut priced alike: %.0f\n",
-                            units.size(), span, units.front().cost, sum / units.size(), lo_c, ref_span);
-                    for (size_t i = 0; i < units.size() && i < 12; i++) {
+                    fprintf(stderr, "[stream]   balanced cut into %zu pairs of twin units (%d asked for, %.0f ms on the host): predicted span %.0f (dearest pair %.0f, mean %.0f, cheapest %.0f); the best plain cut priced alike: %.0f\n",
+                            units.size(), want / 2, cut_ms, span, units.front().cost, sum / units.size(), lo_c, ref_span);
+                    for (size_t i = 0; i < units.size() && i < 12 && dbgc > 1; i++) {
                         const st_unit &u = units[i];
                         const unsigned char *cls = o->rowclass_host.data() + (size_t)u.tx * o->L;
                         const st_features fn = st_unit_features(cls, o->L, o->y0 - o->gs, o->grid.H, u.r0, u.r1, false, true);
@@ -2105,8 +2117,9 @@ static const dmg_ocean::tile_list *st_units(dmg_ocean *o, int variant, int lo, i
                                 st_exact_cost(o, u.tx, u.rlo, u.r0, true, true));
                     }
                 }
-                if (span < ref_span || twin_env > 1) { best_span = span; best.swap(units); best_seg = -slots; best_seg2 = 0; best_split = hi; cut_twin = 1; }
+                if (span < twin_span) { twin_span = span; twin_best.swap(units); twin_want = want; }
             }
+            if (!twin_best.empty() && (twin_span < ref_span || twin_env > 1)) { best_span = twin_span; best.swap(twin_best); best_seg = -twin_want; best_seg2 = 0; best_split = hi; cut_twin = 1; }
         }
         (void)st_makespan(best, cut_twin ? slots / 2 : slots);      // (longest first)
         cut_seg = best_seg; cut_seg2 = best_seg2; cut_split = best_split;
