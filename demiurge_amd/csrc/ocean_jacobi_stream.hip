@@ -461,12 +461,12 @@ __device__ __forceinline__ unsigned st_class_p(const st_args &a, const st_state 
 // start on the two sides of a seam row at the same moment need no halo between them: the northward wave's level s needs, of
 // the other side, only level s-1 of the ONE row below the seam, which is the southward wave's first row of that level (and
 // the other way round), made in the same or the previous step.  So the two hand each other their first row of every level
-// through 2 KB of LDS while their pipelines fill -- the pipeline of such a unit is full after FOUR steps instead of eight
+// through LDS while their pipelines fill -- the pipeline of such a unit is full after FOUR steps instead of eight
 // (level s has its first row at step s/2: there is no shrinking edge to wait for), it streams n + 8 rows, and after step 3 the
 // two waves never meet again.  At step t (0..3): level 2t makes the unit's rows (0, 1); its row 0 goes to the partner, a
 // barrier, and the partner's is this wave's row -1 of level 2t, which level 2t + 1 needs for row 0 in this same step; that row
-// 0 goes over likewise, and the partner's becomes row -1 of level 2t + 1 for level 2t + 2 in the next step.  Eight barriers
-// per unit, all in its first four steps.  The southward wave is the same program on the mirrored view (above).
+// 0 goes over likewise, and the partner's becomes row -1 of level 2t + 1 for level 2t + 2 in the next step.  Nine barriers
+// per unit, all in its first five steps (the ninth: k_jacobi_stream_twin, the ring slots the rows travel through).  The southward wave is the same program on the mirrored view (above).
 // Same operations on the same values as a unit with a halo: bit-identical (tests/stream_worker.py `twin`).
 template <int S, int K>
 __device__ __forceinline__ void st_twin_hand_over(st_state &z, v4f (*xme)[64], const v4f (*xpeer)[64], int lane, bool second)
@@ -513,6 +513,8 @@ __device__ __forceinline__ void st_step(const st_args &a, st_state &z, v4f (*bri
         a.stepprof[(size_t)(TW ? 2 * blockIdx.x + (threadIdx.x >> 6) : blockIdx.x) * 64 + 22 + t / 2] = __builtin_amdgcn_s_memrealtime();
     }
 #endif
+    // (twin units: the partner has read the last row handed over -- ring slots 10 and 11 are the unit's own from here on)
+    if (TW && K == 0 && t == TB_T / 2) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     st_arrive<K>(a, z, bring, cring, lane, 0, e_t, clsA, z.slot, landA, mixA);
     st_arrive<K>(a, z, bring, cring, lane, 1, e_t + 1, clsB, slotB, landB, mixB);
     if (TW && K == 0 && t == 0) st_twin_hand_over<0, K>(z, xme, xpeer, lane, false);      // "level 0": the partner's first row is this unit's row -1
@@ -822,16 +824,18 @@ __global__ __launch_bounds__(64, 2) void k_jacobi_stream(st_args a_up, st_args a
 
 // Twin units (st_step's TW form, described there): a workgroup of two waves per pair -- wave 0 the unit above the seam (the
 // plain view), wave 1 the unit below it (the mirrored view); a_up.units holds two entries per workgroup.  The window of a twin
-// unit starts ON its first row (no halo towards the seam); ST_TWIN_MAXROWS keeps the two waves' tables and the 4 KB they
-// trade rows through within a quarter of a CU's LDS: four workgroups, eight waves, two per SIMD as before.
-#define ST_TWIN_MAXROWS 152
+// unit starts ON its first row (no halo towards the seam); ST_TWIN_MAXROWS keeps the two waves' tables within a quarter of a
+// CU's LDS: four workgroups, eight waves, two per SIMD as before.
+#define ST_TWIN_MAXROWS 232
 template <int DV>
 __global__ __launch_bounds__(128, 2) void k_jacobi_stream_twin(st_args a_up, st_args a_dn)
 {
     __shared__ v4f bring2[2][ST_RING][64];
     __shared__ unsigned cring2[2][ST_RING][64];
     __shared__ v4f ktab2[2][ST_TWIN_MAXROWS + TB_T + 8];
-    __shared__ v4f xch[2][2][64];                     // [wave][first row of an even / an odd level][lane]
+    // the rows the two waves hand each other travel through ring slots 10 and 11 of the SENDER's right-hand-side ring: a unit's own
+    // rows reach those slots with the arrivals of step 5, the last hand-over is read after step 3, and one more barrier at the top of
+    // step 4 (st_step) keeps the two apart whatever the waves' pace -- no LDS of their own, which is what lets the tables hold 232 rows
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
     v4f (*bring)[64] = bring2[wave];
@@ -889,16 +893,16 @@ __global__ __launch_bounds__(128, 2) void k_jacobi_stream_twin(st_args a_up, st_
     z.fc[0][0] = st_class4(cls_lo, 0); z.fc[0][1] = st_class4(cls_lo, 1); z.fc[1][0] = st_class4(cls_lo, 2); z.fc[1][1] = st_class4(cls_lo, 3);
     {
         const int n = 2 * nsteps + 2;
-        v4f kt[2];
+        v4f kt[4];
 #pragma unroll
-        for (int q = 0; q < 2; q++) kt[q] = st_kswap(*reinterpret_cast<const v4f *>(a.jcoef + (size_t)st_map_row(a, e0 + min(lane + 64 * q, n - 1)).l * 8));
+        for (int q = 0; q < 4; q++) kt[q] = st_kswap(*reinterpret_cast<const v4f *>(a.jcoef + (size_t)st_map_row(a, e0 + min(lane + 64 * q, n - 1)).l * 8));
 #pragma unroll
-        for (int q = 0; q < 2; q++) if (lane + 64 * q < n) ktab[lane + 64 * q] = kt[q];
+        for (int q = 0; q < 4; q++) if (lane + 64 * q < n) ktab[lane + 64 * q] = kt[q];
         const st_kptr cf = (st_kptr)(unsigned long long)a.jcoef;
         z.cy = cf[4]; z.ry = cf[5];
     }
-    v4f (*xme)[64] = xch[wave];
-    const v4f (*xpeer)[64] = xch[wave ^ 1];
+    v4f (*xme)[64] = &bring2[wave][ST_RING - 2];
+    const v4f (*xpeer)[64] = &bring2[wave ^ 1][ST_RING - 2];
     for (int t = 0; t < nsteps; t += 2) {
 #ifdef ST_EXPERIMENTS
         if (a.stepprof && lane == 0 && t < 44) a.stepprof[(size_t)(2 * blockIdx.x + wave) * 64 + t / 2] = __builtin_amdgcn_s_memrealtime();
@@ -2079,9 +2083,10 @@ static const dmg_ocean::tile_list *st_units(dmg_ocean *o, int variant, int lo, i
         // ... and into twin units (pairs that start on a common seam and need no halo between them: k_jacobi_stream_twin), one round's worth
         static const int twin_env = [] { const char *e = getenv("DMG_ST_TWIN"); return e ? atoi(e) : ST_TWIN_DEFAULT; }();
         // (up to the band of a 2-way split.  16384 x 2048: one round of twin units 73.1 us against 81.6 on the survey terrain, 93.9 against
-        // 114.2 without land; 16384 x 4096: 144.2-145.6 against 149.9 / 187.3 against 188.5; at 16384 x 8192 a round's units would be
-        // taller than ST_TWIN_MAXROWS allows, and two or three rounds of shorter twin units LOSE to 1.3 rounds of 200-row plain
-        // ones: 292-296 against 273.9 us, 395 against 362.6 without land -- profiles/r04_twin_units.txt)
+        // 114.2 without land; 16384 x 4096: 144.2-145.6 against 149.9 / 187.3 against 188.5.  At 16384 x 8192 they LOSE to 1.3 rounds of
+        // 200-row plain units, as two or three rounds of short pairs (292-296 against 273.9 us, 395 against 362.6 without land) and as
+        // one round of pairs of up to 232 rows (300.2 against 279.9 us): a launch of one round lasts as long as its slowest SIMD, 1.2
+        // medians, where the plain cut's short units fill the slots its tall ones leave -- profiles/r04_twin_units.txt)
         static const int twin_rows = [] { const char *e = getenv("DMG_ST_TWIN_ROWS"); return e ? atoi(e) : 4400; }();
         if (twin_env && bal_env && variant == 0 && !o->rowclass_host.empty() && hi - lo <= twin_rows) {
             // (the twin units' costs are st_exact_cost's: the cut they are compared with is priced the same way)
