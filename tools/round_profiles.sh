@@ -3,10 +3,18 @@
 set -o pipefail
 R=${R:-r04}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-# PART=tests: the GPU test suite alone (a gpurun call is at most 1200 s); PART=profiles (default): everything else
+# PART=tests: the GPU test suite alone (a gpurun call is at most 1200 s); PART=twin: the twin units' A/B; PART=profiles (default): everything else
 if [ "${PART:-profiles}" = tests ]; then
 timeout -k 10 1100 python -u -m pytest tests -m gpu -q > gpurun_out/${R}_pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/${R}_pytest_gpu.log; tail -3 gpurun_out/${R}_pytest_gpu.log
 grep -q "GPU core dump\|Memory access fault" gpurun_out/${R}_pytest_gpu.log && exit 9
+exit 0
+fi
+if [ "${PART:-profiles}" = twin ]; then
+# the twin units' A/B (DMG_ST_TWIN=0/1 and the cut's parts), and the band kernel under the profiler
+bash tools/twin_ab.sh > /dev/null 2>&1; cp gpurun_out/r04_twin_units.txt gpurun_out/${R}_twin_units.txt 2>/dev/null; head -30 gpurun_out/${R}_twin_units.txt
+rm -rf gpurun_out/${R}_stats
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${R}_stats -o x -- python3 bench.py --steps 2 --warmup 1 --height 1024 --no-cpu-baseline --no-extra-legs > gpurun_out/${R}_twin_bench_profiled.json.log 2>&1
+cp gpurun_out/${R}_stats/x_kernel_stats.csv gpurun_out/${R}_twin_kernel_stats.csv 2>/dev/null; rm -rf gpurun_out/${R}_stats
 exit 0
 fi
 python bench.py > gpurun_out/${R}_bench_default.json.log 2> gpurun_out/${R}_bench_default.err; tail -c 600 gpurun_out/${R}_bench_default.json.log

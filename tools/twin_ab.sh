@@ -24,6 +24,24 @@ for n in 8 4; do
   done
 done
 done
+for rep in 1 2; do
+  for tw in 0 1; do
+    echo "bands 2 DMG_ST_TWIN=$tw" >> $L; DMG_ST_TWIN=$tw python tools/band_probe.py 2 32 2>&1 | grep "whole\|split" >> $L
+  done
+done
+echo "# taller launches: 16384 x 4096 (twin units by default), 16384 x 8192 (plain units by default; forced: one round of pairs of up to 232 rows, and the best of 1 / 1.5 / 2 / 3 rounds' worth)" >> $L
+for rep in 1 2; do
+  for terr in survey ocean; do
+    for tw in 0 1; do
+      echo "height 4096 $terr DMG_ST_TWIN=$tw" >> $L
+      DMG_ST_TWIN=$tw timeout -k 10 300 python bench.py --steps 2 --warmup 1 --height 4096 --terrain $terr --no-extra-legs --no-cpu-baseline 2>/dev/null | line >> $L 2>&1
+    done
+    for cfg in "DMG_ST_TWIN=1" "DMG_ST_TWIN=2 DMG_ST_TWIN_ROWS=9000" "DMG_ST_TWIN=2 DMG_ST_TWIN_ROWS=9000 DMG_ST_TWIN_ROUNDS=3"; do
+      echo "height 8192 $terr $cfg" >> $L
+      env $cfg timeout -k 10 400 python bench.py --steps 2 --warmup 1 --terrain $terr --no-extra-legs --no-cpu-baseline 2>/dev/null | line >> $L 2>&1
+    done
+  done
+done
 echo "# what the cut's parts are worth on the 8-way band: without the packing under a common limit (DMG_ST_PACK=0: units dealt out by row weights), without the placement (DMG_ST_PLACE=0: longest first)" >> $L
 for rep in 1 2; do
 for env in "DMG_ST_PACK=1 DMG_ST_PLACE=1" "DMG_ST_PACK=0 DMG_ST_PLACE=1" "DMG_ST_PACK=1 DMG_ST_PLACE=0" "DMG_ST_PACK=0 DMG_ST_PLACE=0"; do
