@@ -1607,7 +1607,8 @@ static void st_cut_balanced(const dmg_ocean *o, int lo, int hi, int want, int pa
     auto per_unit = [&](const stretch &x) { return x.cost * 8.0 / x.k + fixed; };
     int have = 0;
     for (const stretch &x : st) have += x.k;
-    want -= n_all;                                           // (the send zones' units are part of the round)
+    if (!twin) want -= n_all;                                // (the send zones' units are part of the round; the twin units of a split launch's
+                                                             // interior are a launch of their own, behind the zones' plain units: a round to themselves)
     {
         auto worse = [&](int a, int b) { return per_unit(st[a]) < per_unit(st[b]); };
         std::vector<int> heap(st.size());
@@ -1716,7 +1717,7 @@ static void st_cut_balanced(const dmg_ocean *o, int lo, int hi, int want, int pa
             while (r < x.r1) {
                 int n = std::min(4, x.r1 - r);
                 while (r + n < x.r1 && n + 4 <= ST_TWIN_MAXROWS && cost_rows(x, r, std::min(r + n + 4, x.r1), u) <= T) n = std::min(n + 4, x.r1 - r);
-                if (x.r1 - (r + n) < 3) n = x.r1 - r;                     // (no sliver at the end)
+                if (x.r1 - (r + n) < 3 && x.r1 - r <= ST_TWIN_MAXROWS) n = x.r1 - r;     // (no sliver at the end)
                 r += n; u++;
                 if (c) c->push_back(r);
             }
@@ -1973,8 +1974,10 @@ static void st_place_twins(std::vector<st_unit> &units, int num_cu, int tiles_x)
 // (7/n), but the last round must be full -- and the units are issued longest first.
 // part 1 / 2: only the units that do / do not produce rows of [lo, zone_lo) or [zone_hi, hi) (the two halves of a launch
 // split around a halo exchange).
+static thread_local bool st_units_failed = false;         // the last st_units call of this thread failed with a message of its own
 static const dmg_ocean::tile_list *st_units(dmg_ocean *o, int variant, int lo, int hi, int part, int zone_lo, int zone_hi, int seg)
 {
+    st_units_failed = false;
     auto key = std::make_tuple(lo, hi, (variant == 2 ? -5000 : (variant ? -3000 : -1000)) - seg, part, zone_lo, zone_hi);    // "rows per wave" <= -1000 = stream units (seg 0 = auto)
     auto it = o->tb_lists.find(key);
     if (it != o->tb_lists.end()) return &it->second;
@@ -2023,7 +2026,7 @@ static const dmg_ocean::tile_list *st_units(dmg_ocean *o, int variant, int lo, i
             for (const st_unit &u : all) rows_all += u.r1 - u.first();
             for (const st_unit &u : best) rows_parts += u.r1 - u.first();
             if (other->second.n_cut_units + units_of(best) != units_of(all) || other->second.cut_rows + rows_parts != rows_all) {
-                dmg_fail(DMG_ESTATE, "split launch over rows [%d, %d): %zu + %zu units in the two parts, %zu in the cut they are halves of", lo, hi,
+                st_units_failed = true; dmg_fail(DMG_ESTATE, "split launch over rows [%d, %d): %zu + %zu units in the two parts, %zu in the cut they are halves of", lo, hi,
                          other->second.n_cut_units, units_of(best), units_of(all));
                 return nullptr;
             }
@@ -2205,11 +2208,11 @@ static const dmg_ocean::tile_list *st_units(dmg_ocean *o, int variant, int lo, i
     const std::vector<unsigned char> &ctab = o->rowclass_host;
     int n_open = 0, n_flip = 0, n_twin = 0;
     for (const st_unit &u : best) n_twin += u.rlo >= 0;
-    if (n_twin && n_twin != (int)best.size()) { dmg_fail(DMG_ESTATE, "a unit list mixes twin units with plain ones"); return nullptr; }
+    if (n_twin && n_twin != (int)best.size()) { st_units_failed = true; dmg_fail(DMG_ESTATE, "a unit list mixes twin units with plain ones"); return nullptr; }
     for (const st_unit &u : best) {
         int flag = 0;
         if (u.rlo >= 0) {                                  // the unit above the seam and the one below it in the mirrored view's rows
-            if (u.r1 - u.r0 > ST_TWIN_MAXROWS || u.r0 - u.rlo > ST_TWIN_MAXROWS) { dmg_fail(DMG_ESTATE, "a twin unit of more than %d rows", ST_TWIN_MAXROWS); return nullptr; }
+            if (u.r1 - u.r0 > ST_TWIN_MAXROWS || u.r0 - u.rlo > ST_TWIN_MAXROWS) { st_units_failed = true; dmg_fail(DMG_ESTATE, "a twin unit of more than %d rows", ST_TWIN_MAXROWS); return nullptr; }
             const int north[4] = { u.tx, u.r0, u.r1, u.dummy ? 4 | 8 : 4 }, south[4] = { u.tx, o->L - u.r0, o->L - u.rlo, u.dummy ? 4 | 2 | 8 : 4 | 2 };
             flat.insert(flat.end(), u.south_first ? south : north, (u.south_first ? south : north) + 4);
             flat.insert(flat.end(), u.south_first ? north : south, (u.south_first ? north : south) + 4);
@@ -2308,7 +2311,10 @@ int ocean_launch_stream(dmg_ocean *o, int lo, int hi, int part, int zone_lo, int
     if (variant == 2 && (part != 0 || !o->rowclass32 || o->L + STP_BIAS >= (1 << STP_FIELD) || (o->grid.W + TB_OW - 1) / TB_OW >= 4096)) variant = 0;   // the halves of a split launch keep their unit lists
     if (variant != 2 && seg > (variant == 1 ? STN_MAXROWS : ST_MAXROWS)) seg = variant == 1 ? STN_MAXROWS : ST_MAXROWS;
     const dmg_ocean::tile_list *tl = st_units(o, variant, lo, hi, part, zone_lo, zone_hi, seg);
-    if (!tl) return dmg_fail(DMG_ENOMEM, "unit list allocation failed");
+    if (!tl) {
+        if (getenv("DMG_ST_DEBUG")) fprintf(stderr, "[stream] no unit list for rows [%d,%d) part %d: %s\n", lo, hi, part, st_units_failed ? dmg_last_error() : "allocation failed");
+        return st_units_failed ? DMG_ESTATE : dmg_fail(DMG_ENOMEM, "unit list allocation failed");     // (st_units has said what failed)
+    }
     if (tl->n == 0) return DMG_OK;
     st_args a;
     a.pin = o->p[from];

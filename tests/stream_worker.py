@@ -154,7 +154,9 @@ def case_split(capi, ctx, oracle, names):
     from demiurge_amd import synth
     rng = np.random.default_rng(13)
     ok = True
-    for W, H, bands, ghost, iters in ((512, 256, 2, 8, 40), (1024, 768, 3, 16, 64), (16384, 2048, 2, 32, 96), (16384, 2048, 2, 8, 24)):
+    # (ghost 128 at 16384 wide: the send zones alone hold more short units than the chip has wave slots -- the interior's twin
+    # units are a round of their own; round 4's first cut of them was not, and failed on exactly this geometry)
+    for W, H, bands, ghost, iters in ((512, 256, 2, 8, 40), (1024, 768, 3, 16, 64), (16384, 2048, 2, 32, 96), (16384, 2048, 2, 8, 24), (16384, 2048, 2, 128, 256)):
         grid = capi.make_grid(W, H)
         if W < 16384:
             img = np.where(rng.random((H, W)) < 0.2, 1.0, -1.0).astype(f32)
