@@ -2084,7 +2084,9 @@ static const dmg_ocean::tile_list *st_units(dmg_ocean *o, int variant, int lo, i
                 if (span < best_span) { best_span = span; best.swap(units); best_seg = -want; best_seg2 = 0; best_split = hi; }
             }
         // ... and into twin units (pairs that start on a common seam and need no halo between them: k_jacobi_stream_twin), one round's worth
-        static const int twin_env = [] { const char *e = getenv("DMG_ST_TWIN"); return e ? atoi(e) : ST_TWIN_DEFAULT; }();
+        // (read whenever a list is built, not once per process: bench.py switches the twin units off and tries again if every leg
+        // of a first multi-GPU run fails with them)
+        const int twin_env = [] { const char *e = getenv("DMG_ST_TWIN"); return e ? atoi(e) : ST_TWIN_DEFAULT; }();
         // (up to the band of a 2-way split.  16384 x 2048: one round of twin units 73.1 us against 81.6 on the survey terrain, 93.9 against
         // 114.2 without land; 16384 x 4096: 144.2-145.6 against 149.9 / 187.3 against 188.5.  At 16384 x 8192 they LOSE to 1.3 rounds of
         // 200-row plain units, as two or three rounds of short pairs (292-296 against 273.9 us, 395 against 362.6 without land) and as
@@ -2208,6 +2210,10 @@ static const dmg_ocean::tile_list *st_units(dmg_ocean *o, int variant, int lo, i
     const std::vector<unsigned char> &ctab = o->rowclass_host;
     int n_open = 0, n_flip = 0, n_twin = 0;
     for (const st_unit &u : best) n_twin += u.rlo >= 0;
+    if (n_twin && getenv("DMG_ST_TWIN_FAIL")) {            // tests: a launch that would run twin units fails instead (bench.py's fall-back to plain units)
+        st_units_failed = true; dmg_fail(DMG_ESTATE, "twin units: injected failure (DMG_ST_TWIN_FAIL)");
+        return nullptr;
+    }
     if (n_twin && n_twin != (int)best.size()) { st_units_failed = true; dmg_fail(DMG_ESTATE, "a unit list mixes twin units with plain ones"); return nullptr; }
     for (const st_unit &u : best) {
         int flag = 0;

@@ -131,12 +131,28 @@ def test_bench_prints_its_line_when_the_overlapped_legs_fail(tmp_path):
 
 
 @pytest.mark.gpu
+def test_bench_falls_back_to_plain_units_when_every_twin_leg_fails(tmp_path):
+    """Round 4: bands run the streaming kernel's twin units, which no run between two devices has seen.  DMG_ST_TWIN_FAIL makes
+    every launch that would run them fail: all four legs of the first pass fail on every rank, bench.py switches the twin
+    units off (DMG_ST_TWIN=0, read by the library whenever it cuts a launch) and runs its plan once more on fresh handles:
+    the line carries the second pass's numbers and says so."""
+    r, lines, d = _bench_rehearsal({"DMG_ST_TWIN_FAIL": "1", "DMG_TB_SHAPE": "stream"})
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2000:]
+    assert len(lines) == 1, r.stdout
+    assert d["value"] > 0 and "plain units" in d.get("note", ""), d
+    assert len(d["legs"]) == 4 and all(l.get("units") == "plain (fall-back)" and l.get("value", 0) > 0 for l in d["legs"]), d["legs"]
+    assert "every leg failed" in r.stderr and "injected failure" in r.stderr
+
+
+@pytest.mark.gpu
 def test_bench_prints_a_line_even_when_every_leg_fails(tmp_path):
-    """... and when nothing works the line still appears (value null, the reasons spelled out) with a non-zero exit status"""
+    """... and when nothing works -- not with plain units either, which the bench tries once every leg has failed -- the line
+    still appears (value null, the reasons spelled out) with a non-zero exit status"""
     r, lines, d = _bench_rehearsal({"DMG_MULTI_FAIL": "1:2", "DMG_MULTI_TIMEOUT_MS": "3000"}, ("--transport", "rccl"))
     assert r.returncode != 0
     assert len(lines) == 1, r.stdout + r.stderr[-1500:]
-    assert d["value"] is None and "no leg completed" in d["error"] and len(d["legs"]) == 2
+    assert d["value"] is None and "no leg completed" in d["error"]
+    assert [l.get("units") for l in d["legs"]] == ["twin", "twin", "plain (fall-back)", "plain (fall-back)"], d["legs"]
 
 
 @pytest.mark.gpu
