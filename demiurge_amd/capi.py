@@ -180,6 +180,8 @@ def lib():
         "dmg_noise_params_default": (None, [ctypes.POINTER(NoiseParams)]),
         "dmg_noise_seed_offset": (c_int, [c_int, ctypes.POINTER(c_float)]),
         "dmg_div2_split": (c_int, [vp, c_float, ctypes.POINTER(c_float), ctypes.POINTER(c_float)]),
+        "dmg_stream_units_probe": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, vp, c_int, c_int, c_int, c_int, c_int, c_int, vp, sz,
+                                           ctypes.POINTER(sz), ctypes.POINTER(c_int)]),
         "dmg_gradient_noise": (c_int, [vp, PG, vp, vp, ctypes.POINTER(NoiseParams)]),
         "dmg_ocean_generate_terrain": (c_int, [vp, ctypes.POINTER(NoiseParams)]),
         "dmg_tectonics_create": (c_int, [vp, PG, vp, ctypes.POINTER(vp)]),
@@ -517,6 +519,21 @@ class Erosion:
         if self.h:
             lib().dmg_erosion_destroy(self.h)
             self.h = None
+
+
+def stream_units_probe(W, H, rowclass, lo, hi, y0=0, y1=None, gs=0, gn=0, part=0, zone_lo=0, zone_hi=0, num_cu=256):
+    """Test hook (no GPU): the streaming kernel's unit list for local rows [lo, hi) of a band, from a row-class table
+    rowclass[strip, local row] (uint8: 0 open water, 1 land everywhere, 2 mixed).  -> (int32 array [n, 4], twin flag)"""
+    y1 = H if y1 is None else y1
+    rc = np.ascontiguousarray(rowclass, dtype=np.uint8)
+    L = gs + (y1 - y0) + gn
+    assert rc.shape == ((W + 239) // 240, L), (rc.shape, L)
+    n, twin = ctypes.c_size_t(0), ctypes.c_int(0)
+    cap = 65536
+    out = np.zeros((cap, 4), np.int32)
+    check(lib().dmg_stream_units_probe(W, H, y0, y1, gs, gn, rc.ctypes.data_as(ctypes.c_void_p), num_cu, lo, hi, part, zone_lo, zone_hi,
+                                       out.ctypes.data_as(ctypes.c_void_p), cap, ctypes.byref(n), ctypes.byref(twin)))
+    return out[:n.value].copy(), twin.value
 
 
 def default_ocean_params():

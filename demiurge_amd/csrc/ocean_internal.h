@@ -44,6 +44,7 @@ struct dmg_ocean {
     std::vector<unsigned char> rowclass_n_host;
     struct tile_list {
         int *d = nullptr; int n = 0;
+        std::vector<int> host;                           // the list as the kernel reads it (kept only for dmg_stream_units_probe)
         // persistent streaming kernel: segment table templates and the launch's live copies (ocean_jacobi_stream.hip)
         unsigned long long *seg_word0 = nullptr, *seg_word = nullptr;
         unsigned *seg_cur0 = nullptr, *seg_cur = nullptr;
@@ -60,6 +61,7 @@ struct dmg_ocean {
     // (out_lo, out_hi, rows per wave, part, zone_lo, zone_hi) of a launch -> tiles that are not land everywhere; part 0 = all
     // tile rows, 1 = tile rows touching the send zones [out_lo, zone_lo) / [zone_hi, out_hi), 2 = the tile rows in between
     std::map<std::tuple<int, int, int, int, int, int>, tile_list> tb_lists;
+    bool lists_on_host = false;    // dmg_stream_units_probe: unit lists are kept in tile_list::host and never copied to a device
     // per launch geometry: which of the three candidate shapes is fastest.  A trial is timed with an event pair that is
     // read back when the geometry is launched the next time, so that trial launches run back to back with their
     // neighbours like every other launch (timing them in isolation, with a host synchronisation after each, favoured

@@ -2251,6 +2251,7 @@ static const dmg_ocean::tile_list *st_units(dmg_ocean *o, int variant, int lo, i
     tl.cut_seg = cut_seg; tl.cut_seg2 = cut_seg2; tl.cut_split = cut_split; tl.cut_twin = cut_twin;
     tl.cut_rows = 0;
     for (const st_unit &u : best) tl.cut_rows += u.r1 - u.first();
+    if (o->lists_on_host) { tl.host = flat; return &(o->tb_lists[key] = tl); }       // (dmg_stream_units_probe: no device)
     if (tl.n && hipMalloc((void **)&tl.d, flat.size() * sizeof(int)) != hipSuccess) return nullptr;
     if (tl.n && hipMemcpy(tl.d, flat.data(), flat.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
     if (variant == 2 && tl.n) {
@@ -2448,5 +2449,33 @@ int ocean_launch_stream(dmg_ocean *o, int lo, int hi, int part, int zone_lo, int
             fclose(f);
         }
     }
+    return DMG_OK;
+}
+
+// Test hook (include/demiurge_hip.h): the unit list the streaming kernel would be launched with, from a row-class table, on
+// the host alone -- the cut, the halves of a split launch and the placement are plain host code, and the multi-GPU paths that
+// depend on them cannot run on a one-GPU box.
+extern "C" int dmg_stream_units_probe(int W, int H, int y0, int y1, int gs, int gn, const unsigned char *rowclass, int num_cu,
+                                      int lo, int hi, int part, int zone_lo, int zone_hi, int *out, size_t cap, size_t *n_entries, int *twin)
+{
+    if (W < TB_EW || H < 1 || y0 < 0 || y1 <= y0 || y1 > H || gs < 0 || gn < 0 || !rowclass || num_cu < 1 || !n_entries)
+        return dmg_fail(DMG_EINVAL, "dmg_stream_units_probe: bad arguments");
+    dmg_ctx ctx;
+    ctx.num_cu = num_cu;
+    dmg_ocean o;
+    o.ctx = &ctx;
+    o.grid.W = W; o.grid.H = H;
+    o.y0 = y0; o.y1 = y1; o.gs = gs; o.gn = gn;
+    o.L = gs + (y1 - y0) + gn;
+    o.lists_on_host = true;
+    if (lo < 0 || hi > o.L || lo >= hi) return dmg_fail(DMG_EINVAL, "dmg_stream_units_probe: rows [%d, %d) outside the band's %d", lo, hi, o.L);
+    const int tiles_x = (W + TB_OW - 1) / TB_OW;
+    o.rowclass_host.assign(rowclass, rowclass + (size_t)tiles_x * o.L);
+    const dmg_ocean::tile_list *tl = st_units(&o, 0, lo, hi, part, zone_lo, zone_hi, 0);
+    if (!tl) return st_units_failed ? DMG_ESTATE : dmg_fail(DMG_ENOMEM, "unit list allocation failed");
+    *n_entries = tl->host.size() / 4;
+    if (twin) *twin = tl->twin;
+    if (out && tl->host.size() <= cap * 4) memcpy(out, tl->host.data(), tl->host.size() * sizeof(int));
+    else if (out) return dmg_fail(DMG_EINVAL, "dmg_stream_units_probe: %zu entries, room for %zu", tl->host.size() / 4, cap);
     return DMG_OK;
 }
