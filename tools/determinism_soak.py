@@ -1,6 +1,7 @@
 """Run the hot paths repeatedly on the same inputs and compare the bits of every repetition with the first (GPU box).
 usage: python tools/determinism_soak.py [repetitions]"""
-import hashlib, sys, time
+import hashlib, os, sys, time
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # (the overlapped order: the library no longer sets it itself)
 import numpy as np
 sys.path.insert(0, ".")
 from demiurge_amd import capi, synth
@@ -25,7 +26,7 @@ print("jacobi 16384x8192 x1000 sweeps, %d solves: %s (%s), %.1f s" % (n, "identi
 o.close()
 
 for order, name in ((capi.MULTI_EXCHANGE_THEN_SWEEP, "exchange-then-sweep"), (capi.MULTI_OVERLAP_LAST_LAUNCH, "overlap")):
-    for transport, tname in ((capi.MULTI_RCCL_LOOPBACK, "loopback"), (capi.MULTI_PEER, "peer")):
+    for transport, tname in ((capi.MULTI_RCCL_LOOPBACK, "loopback"), (capi.MULTI_PEER, "peer"), (capi.MULTI_STORE, "store")):
         Wb, Hb = 16384, 4096
         m = capi.Multi(capi.make_grid(Wb, Hb), devices=[0] * 4, ghost=32, flags=transport | order)
         m.set_terrain(synth.terrain(Wb, Hb)); m.set_divw(synth.divw(Wb, Hb))
@@ -39,6 +40,21 @@ for order, name in ((capi.MULTI_EXCHANGE_THEN_SWEEP, "exchange-then-sweep"), (ca
         ok &= good
         print("4 bands x 1024 rows, %s, %s, 640 sweeps x %d: %s (%s), %.1f s" % (tname, name, max(n // 2, 3), "identical" if good else "DIFFER", r2, time.perf_counter() - t0), flush=True)
         m.close()
+
+# the band of an 8-way split as it would run on eight GPUs (twin units, whole launches), eight of them on this one
+Wb, Hb = 16384, 8192
+m = capi.Multi(capi.make_grid(Wb, Hb), devices=[0] * 8, ghost=32, flags=capi.MULTI_PEER | capi.MULTI_EXCHANGE_THEN_SWEEP)
+m.set_terrain(synth.terrain(Wb, Hb)); m.set_divw(synth.divw(Wb, Hb))
+r2, good = None, True
+t0 = time.perf_counter()
+for i in range(max(n // 2, 3)):
+    m.jacobi(640, zero_first=True)
+    h = sha(m.get(want=("pressure",))["pressure"])
+    r2 = r2 or h
+    good &= h == r2
+ok &= good
+print("8 bands x 1024 rows, peer, exchange-then-sweep, 640 sweeps x %d: %s (%s), %.1f s" % (max(n // 2, 3), "identical" if good else "DIFFER", r2, time.perf_counter() - t0), flush=True)
+m.close()
 
 W, H = 4096, 2048
 g = capi.make_grid(W, H)
