@@ -1535,10 +1535,24 @@ static void st_cut_balanced(const dmg_ocean *o, int lo, int hi, int want, int pa
         u.rlo = rlo; u.cost_n = cn; u.cost_s = cs;
         units.push_back(u);
     };
-    // the send zones: short units of their own, as in st_cut
+    // the send zones: short units of their own, as in st_cut -- in a twin cut as pairs of such units around a seam (a unit of four
+    // rows then runs six steps instead of ten: the edge half of a split launch is what the exchange waits for).  DMG_ST_TWIN_EDGES=0:
+    // plain short units in a twin cut's zones as well
+    const bool twin_edges = [] { const char *e = getenv("DMG_ST_TWIN_EDGES"); return !e || atoi(e) != 0; }();
     if (zones)
         for (int tx = 0; tx < tiles_x; tx++) {
             const unsigned char *cls = classes ? table.data() + (size_t)tx * L : nullptr;
+            if (twin && twin_edges) {
+                auto zone_pairs = [&](int z0, int z1) {
+                    for (int s0 = z0; s0 < z1; s0 += 2 * edge_seg) {
+                        const int s2 = std::min(s0 + 2 * edge_seg, z1), seam = std::min(s0 + edge_seg, s2);
+                        emit_twin(tx, cls, s0, seam, s2);
+                    }
+                };
+                zone_pairs(lo, mid_lo);
+                zone_pairs(mid_hi, hi);
+                continue;
+            }
             int k = 0;
             for (int s0 = lo; s0 < mid_lo; s0 += edge_seg, k++) emit(tx, cls, s0, std::min(s0 + edge_seg, mid_lo), flipping && (k & 1));
             for (int s0 = mid_hi; s0 < hi; s0 += edge_seg, k++) emit(tx, cls, s0, std::min(s0 + edge_seg, hi), flipping && (k & 1));
