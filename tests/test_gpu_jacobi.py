@@ -452,6 +452,20 @@ def test_streaming_southward_units_vs_oracle(flip):
 
 
 @pytest.mark.gpu
+def test_twin_units_equal_plain_units_at_size():
+    """Twin units against plain units where the oracle is too slow to referee: whole grids of 16384 columns and 777 to 4400 rows
+    (survey, no land, salt-and-pepper, striped land), and the 16384x8192 solve in 2, 4 and 8 latitude bands on this GPU (peer
+    copies, direct stores, RCCL loopback; both exchange orders, ghost 16 to 128) -- each run once with twin units forced and
+    once with plain units, in child processes: the same SHA-256 every time, and one and the same field for one, two, four
+    and eight bands (tools/twin_vs_plain.py)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "twin_vs_plain.py")], cwd=root, capture_output=True, text=True, timeout=1100)
+    assert r.returncode == 0 and "ALL IDENTICAL" in r.stdout and "one field" in r.stdout, r.stdout[-3000:] + r.stderr[-1500:]
+    assert r.stdout.count("k_jacobi_stream_twin") >= 12, r.stdout[-3000:]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("form", ["stream", "auto"])
 def test_streaming_split_launches_vs_oracle(form):
     """the two halves of a split launch (_begin / exchange / _end) are halves of one cut.  Band splits
