@@ -26,8 +26,10 @@
 // two rows of 256 cells; everything else was taken out piece by piece -- rows are held as cell pairs (c0,c3),(c1,c2) so
 // that pW + pE needs no register shuffling; coast rows go through counts of land neighbours (one packed fma per pair
 // instead of eight selects); steps without land or coast, and steps with coast but no all-land row, run their eight
-// levels without a test or a branch; one ring read per row and level.  Three forms share the code: units (the default),
-// narrow units (2 cells per lane, five waves per SIMD) and persistent waves with work stealing.
+// levels without a test or a branch; one ring read per row and level.  Four forms share the code: units (the default for
+// the full grid), twin units (round 4, the default for launches of up to 4400 rows -- the bands of a split grid: two waves
+// that start on the two sides of a seam and need no halo between them, k_jacobi_stream_twin), narrow units (2 cells per
+// lane, five waves per SIMD) and persistent waves with work stealing.
 //
 // Canvas topology exactly as in ocean_jacobi_tb.hip: columns wrap, rows beyond a pole are the same rows mirrored and
 // shifted by W/2 (offset(), src/Shader.h:86-95), rows beyond a non-pole edge are plain mirrors with the clamp bit
