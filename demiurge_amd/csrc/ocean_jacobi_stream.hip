@@ -56,6 +56,9 @@
 #ifndef ST_TWIN_DEFAULT
 #define ST_TWIN_DEFAULT 1         // launches of about one round are cut into twin units (DMG_ST_TWIN=0/1 overrides; 2: whatever the simulation says)
 #endif
+#ifndef ST_TWIN_FAIR
+#define ST_TWIN_FAIR 1            // k_jacobi_stream_twin: the SIMD's two waves take turns at priority, every iteration (1; 2, 3: every 2, 4; 4: every step; 0: off)
+#endif
 #ifndef ST_OPEN_UNITS
 #define ST_OPEN_UNITS 1           // units whose whole window is plain open water run st_open_unit (0: every unit generic, round 3's kernel)
 #endif
@@ -811,6 +814,9 @@ __global__ __launch_bounds__(64, 2) void k_jacobi_stream(st_args a_up, st_args a
         const st_kptr cf = (st_kptr)(unsigned long long)a.jcoef;
         z.cy = cf[4]; z.ry = cf[5];
     }
+    // (the two waves of a SIMD taking turns at priority, as in k_jacobi_stream_twin: measured here, 16384 x 8192, and dropped -- 277.5
+    // against 272.4 us, 364.7 against 359.3 without land: in a launch of several rounds the older wave ending early is what
+    // staggers the rounds)
     for (int t = 0; t < nsteps; t += 2) {
 #ifdef ST_EXPERIMENTS
         if (a.stepprof && lane == 0 && t < 44) a.stepprof[(size_t)blockIdx.x * 64 + t / 2] = __builtin_amdgcn_s_memrealtime();
@@ -905,11 +911,26 @@ __global__ __launch_bounds__(128, 2) void k_jacobi_stream_twin(st_args a_up, st_
     }
     v4f (*xme)[64] = &bring2[wave][ST_RING - 2];
     const v4f (*xpeer)[64] = &bring2[wave ^ 1][ST_RING - 2];
+#if ST_TWIN_FAIR
+    // The SIMD's arbiter serves the older of its two waves first: of two equal units the older ends after 37 us, the younger after
+    // 44, and runs its last stretch alone at two thirds of the SIMD's throughput.  Here the two take turns at a raised priority
+    // (s_setprio), iteration by iteration, so that they end together: the 8-way band 48.2 -> 47.7 us per launch, the 4-way band
+    // 80.5 -> 78.3 (same-box A/B of two builds; turns every step: the same; every other iteration: nothing)
+    const int wslot = __builtin_amdgcn_readfirstlane((int)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (3 << 11))) & 1;
+#endif
     for (int t = 0; t < nsteps; t += 2) {
+#if ST_TWIN_FAIR == 4
+        if (wslot) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
+#elif ST_TWIN_FAIR
+        if (((t >> ST_TWIN_FAIR) ^ wslot) & 1) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
+#endif
 #ifdef ST_EXPERIMENTS
         if (a.stepprof && lane == 0 && t < 44) a.stepprof[(size_t)(2 * blockIdx.x + wave) * 64 + t / 2] = __builtin_amdgcn_s_memrealtime();
 #endif
         st_step<0, false, DV, 1>(a, z, bring, cring, ktab, lane, t, e0, nsteps, r1, cls_lo, cls_hi, col, colp, lane_ok, xcol, 0, xme, xpeer);
+#if ST_TWIN_FAIR == 4
+        if (wslot) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(2);
+#endif
         st_step<1, false, DV, 1>(a, z, bring, cring, ktab, lane, t + 1, e0, nsteps, r1, cls_lo, cls_hi, col, colp, lane_ok, xcol, 0, xme, xpeer);
     }
     if (a.prof && lane == 0) a.prof[3 * (2 * blockIdx.x + wave) + 1] = __builtin_amdgcn_s_memrealtime();
