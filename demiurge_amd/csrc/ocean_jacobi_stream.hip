@@ -922,7 +922,8 @@ __global__ __launch_bounds__(128, 2) void k_jacobi_stream_twin(st_args a_up, st_
 #if ST_TWIN_FAIR == 4
         if (wslot) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
 #elif ST_TWIN_FAIR
-        if (((t >> ST_TWIN_FAIR) ^ wslot) & 1) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
+        if (uflags & 16) __builtin_amdgcn_s_setprio(3);          // an edge unit: ahead of whatever shares its SIMD, all the way
+        else if (((t >> ST_TWIN_FAIR) ^ wslot) & 1) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
 #endif
 #ifdef ST_EXPERIMENTS
         if (a.stepprof && lane == 0 && t < 44) a.stepprof[(size_t)(2 * blockIdx.x + wave) * 64 + t / 2] = __builtin_amdgcn_s_memrealtime();
@@ -2256,7 +2257,9 @@ static const dmg_ocean::tile_list *st_units(dmg_ocean *o, int variant, int lo, i
         int flag = 0;
         if (u.rlo >= 0) {                                  // the unit above the seam and the one below it in the mirrored view's rows
             if (u.r1 - u.r0 > ST_TWIN_MAXROWS || u.r0 - u.rlo > ST_TWIN_MAXROWS) { st_units_failed = true; dmg_fail(DMG_ESTATE, "a twin unit of more than %d rows", ST_TWIN_MAXROWS); return nullptr; }
-            const int north[4] = { u.tx, u.r0, u.r1, u.dummy ? 4 | 8 : 4 }, south[4] = { u.tx, o->L - u.r0, o->L - u.rlo, u.dummy ? 4 | 2 | 8 : 4 | 2 };
+            // (bit 4: the units of a split launch's edge half -- the exchange waits for them: they keep a raised priority)
+            const int urgent = part == 1 ? 16 : 0;
+            const int north[4] = { u.tx, u.r0, u.r1, (u.dummy ? 4 | 8 : 4) | urgent }, south[4] = { u.tx, o->L - u.r0, o->L - u.rlo, (u.dummy ? 4 | 2 | 8 : 4 | 2) | urgent };
             flat.insert(flat.end(), u.south_first ? south : north, (u.south_first ? south : north) + 4);
             flat.insert(flat.end(), u.south_first ? north : south, (u.south_first ? north : south) + 4);
             n_flip++;
