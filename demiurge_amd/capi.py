@@ -250,6 +250,7 @@ def lib():
         "dmg_multi_climate_set_terrain": (c_int, [vp, vp]),
         "dmg_multi_climate_get": (c_int, [vp, vp]),
         "dmg_multi_climate_sync": (c_int, [vp]),
+        "dmg_multi_comm_ranks": (c_int, [vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
         "dmg_multi_timer_start": (c_int, [vp]),
         "dmg_multi_timer_stop": (c_int, [vp, ctypes.POINTER(c_float)]),
     }
@@ -934,6 +935,12 @@ class Multi:
         s = MultiStats()
         check(lib().dmg_multi_get_stats(self.h, ctypes.byref(s)))
         return {k: getattr(s, k) for k, _ in MultiStats._fields_}
+
+    def comm_ranks(self):
+        """(ranks RCCL reports for the data communicator, distinct devices among this process's bands)"""
+        r, d = ctypes.c_int(), ctypes.c_int()
+        check(lib().dmg_multi_comm_ranks(self.h, ctypes.byref(r), ctypes.byref(d)))
+        return r.value, d.value
 
     def timer_start(self):
         check(lib().dmg_multi_timer_start(self.h))

@@ -406,17 +406,29 @@ __global__ __launch_bounds__(256) void k_store_land(store_jobs jobs)
     }
     __syncthreads();
     if (!ok) return;
-    __atomic_thread_fence(__ATOMIC_ACQUIRE);                 // (system scope: what the neighbour stored, not what a cache remembers)
+    // Who wrote these bytes: another GPU (or this one, in a rehearsal), with plain stores into THIS device's memory over
+    // xGMI, released at system scope before the flag.  Who reads them: every wave of this launch, which may have been
+    // resident -- and this XCD's L2 may hold lines of the same slot from two exchanges ago -- since before they arrived.
+    // So (1) the slot is fine-grained memory (store_alloc): its lines are never kept across a system-scope acquire; (2) every
+    // wave performs that acquire itself behind the flag (it invalidates this CU's L1 and the L2's non-coherent lines:
+    // buffer_inv sc0 sc1); (3) the loads themselves are system-scope loads (sc0 sc1), which no cache level answers from a
+    // line it filled before the acquire.  Any one of the three is what the memory model asks for; the slab is 2 MB.
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
     const unsigned char *__restrict__ src = j.src;
     unsigned char *__restrict__ dst = j.dst;
     const size_t n = j.n;
     const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (size_t)gridDim.x * blockDim.x;
     if ((((size_t)src | (size_t)dst | n) & 15) == 0) {
-        const uint4 *s4 = (const uint4 *)src; uint4 *d4 = (uint4 *)dst;
-        for (size_t k = tid; k < n / 16; k += nthr) d4[k] = s4[k];
+        const unsigned long long *s8 = (const unsigned long long *)src; ulonglong2 *d16 = (ulonglong2 *)dst;
+        for (size_t k = tid; k < n / 16; k += nthr) {
+            ulonglong2 v;
+            v.x = __hip_atomic_load(s8 + 2 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            v.y = __hip_atomic_load(s8 + 2 * k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            d16[k] = v;
+        }
     } else {
-        const unsigned *s1 = (const unsigned *)src; unsigned *d1 = (unsigned *)dst;
-        for (size_t k = tid; k < n / 4; k += nthr) d1[k] = s1[k];
+        const unsigned *s1 = (const unsigned *)src; unsigned *d1 = (unsigned *)dst;      // (rows are whole floats)
+        for (size_t k = tid; k < n / 4; k += nthr) d1[k] = __hip_atomic_load(s1 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -442,9 +454,19 @@ static int store_alloc(dmg_multi *m, int i)
 {
     store_band &sb = m->store[i];
     DMG_HIP(hipSetDevice(m->ctx_of(i)->device));
-    if (hipMalloc((void **)&sb.land_base, 4 * m->slot_bytes) != hipSuccess)
-        return dmg_fail(DMG_ENOMEM, "store transport: hipMalloc of the landing slots (%zu bytes) failed", 4 * m->slot_bytes);
-    // the flag words are written by another GPU while a kernel of this one polls them: fine-grained, uncached device memory
+    // The landing slots are written by ANOTHER GPU while a kernel of this one is resident and about to read them: that is
+    // what fine-grained device memory is for (coarse-grained memory is only coherent at kernel boundaries); uncached device
+    // memory is the fall-back, and there is no coarse-grained one
+    if (hipExtMallocWithFlags((void **)&sb.land_base, 4 * m->slot_bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+        (void)hipGetLastError();
+        sb.land_base = nullptr;
+        if (hipExtMallocWithFlags((void **)&sb.land_base, 4 * m->slot_bytes, hipDeviceMallocUncached) != hipSuccess) {
+            (void)hipGetLastError();
+            sb.land_base = nullptr;
+            return dmg_fail(DMG_ENOMEM, "store transport: no fine-grained or uncached device memory for the landing slots (%zu bytes)", 4 * m->slot_bytes);
+        }
+    }
+    // the flag words likewise: written by another GPU while a kernel of this one polls them
     if (hipExtMallocWithFlags((void **)&sb.flag_base, 4096, hipDeviceMallocUncached) != hipSuccess) {
         (void)hipGetLastError();
         if (hipExtMallocWithFlags((void **)&sb.flag_base, 4096, hipDeviceMallocFinegrained) != hipSuccess)
@@ -1404,6 +1426,22 @@ int dmg_multi_get_stats(dmg_multi *m, dmg_multi_stats *s)
     long long l = 0, sw = 0;
     if (!m->oc.empty()) (void)dmg_ocean_counters(m->oc[0], &l, &sw);
     s->jacobi_launches = l; s->jacobi_sweeps = sw;
+    return DMG_OK;
+}
+
+int dmg_multi_comm_ranks(dmg_multi *m, int *ranks, int *devices)
+{
+    DMG_CHECK_ARG(m != nullptr && ranks != nullptr);
+    // what RCCL itself says of the communicator the slabs travel on (ncclCommCount), not what the handle was asked for
+    int n = m->world, distinct = 0;
+    if (!m->comm.empty() && m->comm[0] && m->transport != DMG_MULTI_RCCL_LOOPBACK) DMG_NCCL(ncclCommCount(m->comm[0], &n));
+    for (int i = 0; i < m->n; i++) {
+        bool seen = false;
+        for (int k = 0; k < i; k++) seen = seen || m->ctx_of(k)->device == m->ctx_of(i)->device;
+        distinct += seen ? 0 : 1;
+    }
+    *ranks = n;
+    if (devices) *devices = distinct;
     return DMG_OK;
 }
 

