@@ -42,10 +42,22 @@ class OceanParams(ctypes.Structure):
                 ("wind", ctypes.c_float), ("quirks", ctypes.c_int), ("jacobi_kernel", ctypes.c_int)]
 
 
+class ClimateParams(ctypes.Structure):
+    """dmg_climate_params: every literal of Temperature.cpp as a field"""
+    _fields_ = [("steps_per_year", ctypes.c_int), ("year_seconds", ctypes.c_float), ("diffusivity", ctypes.c_float), ("albedo", ctypes.c_float),
+                ("olr_coeff", ctypes.c_float), ("olr_ref_kelvin", ctypes.c_float), ("emissivity", ctypes.c_float), ("celsius_offset", ctypes.c_float),
+                ("heat_capacity_land", ctypes.c_float), ("heat_capacity_ocean", ctypes.c_float), ("eccentricity", ctypes.c_float),
+                ("obliquity_deg", ctypes.c_float), ("perihelion_deg", ctypes.c_float), ("solar_constant", ctypes.c_float),
+                ("initial_temperature", ctypes.c_float), ("quirks", ctypes.c_int)]
+
+
+CLIMATE_QUIRK_ACOS_NAN = 1
+
+
 class WorldParams(ctypes.Structure):
     _fields_ = [("tectonics_steps", ctypes.c_int), ("erosion_rounds", ctypes.c_int), ("climate_steps", ctypes.c_int),
                 ("erosion_N", ctypes.c_int), ("exponent", ctypes.c_float), ("slope_exponent", ctypes.c_float), ("factor", ctypes.c_float),
-                ("lakes", ctypes.c_int)]
+                ("lakes", ctypes.c_int), ("climate", ClimateParams)]
 
 
 class MultiStats(ctypes.Structure):
@@ -159,7 +171,10 @@ def lib():
         "dmg_ocean_checkpoint": (c_int, [vp, ctypes.c_char_p]),
         "dmg_ocean_restore": (c_int, [vp, ctypes.c_char_p]),
         "dmg_blur": (c_int, [vp, PG, vp, c_float]),
-        "dmg_temperature_steps": (c_int, [vp, PG, vp, vp, c_int, c_int]),
+        "dmg_temperature_steps": (c_int, [vp, PG, vp, vp, ctypes.POINTER(ClimateParams), c_int, c_int]),
+        "dmg_climate_params_default": (None, [ctypes.POINTER(ClimateParams)]),
+        "dmg_climate_set_params": (c_int, [vp, ctypes.POINTER(ClimateParams)]),
+        "dmg_multi_climate_set_params": (c_int, [vp, ctypes.POINTER(ClimateParams)]),
         "dmg_erosion_pass": (c_int, [vp, PG, vp, vp, vp, c_float, c_float]),
         "dmg_flow_accumulate": (c_int, [vp, PG, vp, vp, c_float, c_float, c_int, vp]),
         "dmg_erosion_run": (c_int, [vp, PG, vp, c_int, c_int, c_float, c_float, c_float]),
@@ -346,10 +361,11 @@ class Context:
         check(lib().dmg_blur(self.h, ctypes.byref(grid), _p(f), radius))
         return f
 
-    def temperature_steps(self, grid, T, terrain, first_step, n_steps):
+    def temperature_steps(self, grid, T, terrain, first_step, n_steps, params=None):
         T = _f32(T).copy()
         terrain = _f32(terrain)
-        check(lib().dmg_temperature_steps(self.h, ctypes.byref(grid), _p(T), _p(terrain), first_step, n_steps))
+        check(lib().dmg_temperature_steps(self.h, ctypes.byref(grid), _p(T), _p(terrain), ctypes.byref(params) if params is not None else None,
+                                          first_step, n_steps))
         return T
 
     def erosion_pass(self, grid, h, flow, updrift, factor=1.0, slope_exponent=1.0):
@@ -422,15 +438,33 @@ Context.erosion_run = _ctx_erosion_run
 Context.flow_passes = _ctx_flow_passes
 
 
-class Climate:
-    """dmg_climate: the climate field (Temperature.cpp) resident on the device between step calls"""
+def climate_params(**kw):
+    """the reference's values (Temperature.cpp), with the given fields replaced"""
+    p = ClimateParams()
+    lib().dmg_climate_params_default(ctypes.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
 
-    def __init__(self, ctx, grid, T, terrain, band_rank=0, band_count=1, ghost=0):
-        T, terrain = _f32(T), _f32(terrain)
-        self.ctx, self.shape = ctx, T.shape
+
+class Climate:
+    """dmg_climate: the climate field (Temperature.cpp) resident on the device between step calls.  T None: the field starts
+    at params.initial_temperature (the reference clears the layer)."""
+
+    def __init__(self, ctx, grid, T, terrain, band_rank=0, band_count=1, ghost=0, params=None):
+        terrain = _f32(terrain)
+        T = _f32(T) if T is not None else None
+        self.ctx, self.shape = ctx, terrain.shape
         h = ctypes.c_void_p()
         check(lib().dmg_climate_create_band(ctx.h, ctypes.byref(grid), _p(T), _p(terrain), band_rank, band_count, ghost, ctypes.byref(h)))
         self.h = h
+        if params is not None:
+            self.set_params(params)
+
+    def set_params(self, params):
+        check(lib().dmg_climate_set_params(self.h, ctypes.byref(params)))
 
     def steps(self, first_step, n_steps):
         check(lib().dmg_climate_steps(self.h, first_step, n_steps))
@@ -458,7 +492,7 @@ class MultiClimate:
     """dmg_multi_climate: the climate year cycle over latitude bands driven by the library (threads, streams and
     transports of dmg_multi).  devices=[...]: one process drives the bands; rank/world/unique_id: one process per GPU."""
 
-    def __init__(self, grid, T, terrain, devices=None, ghost=8, flags=MULTI_AUTO, rank=None, world=None, unique_id=None, device=0):
+    def __init__(self, grid, T, terrain, devices=None, ghost=8, flags=MULTI_AUTO, rank=None, world=None, unique_id=None, device=0, params=None):
         T, terrain = _f32(T), _f32(terrain)
         self.shape = T.shape
         h = ctypes.c_void_p()
@@ -469,6 +503,11 @@ class MultiClimate:
             buf = ctypes.create_string_buffer(unique_id, 128) if unique_id is not None else None
             check(lib().dmg_multi_climate_create_rank(rank, world, buf, device, ctypes.byref(grid), _p(T), _p(terrain), ghost, flags, ctypes.byref(h)))
         self.h = h
+        if params is not None:
+            self.set_params(params)
+
+    def set_params(self, params):
+        check(lib().dmg_multi_climate_set_params(self.h, ctypes.byref(params)))
 
     def steps(self, first_step, n_steps):
         check(lib().dmg_multi_climate_steps(self.h, first_step, n_steps))

@@ -103,7 +103,8 @@ struct dev_buf {
     void *p = nullptr;
     dmg_ctx *owner = nullptr;
     size_t bytes = 0;
-    ~dev_buf() { if (p) dmg_scratch_free(owner, p, bytes); }
+    ~dev_buf() { reset(); }
+    void reset() { if (p) dmg_scratch_free(owner, p, bytes); p = nullptr; bytes = 0; }     // (before a second upload into the same buffer)
     // grid-sized fields (and everything else whose size does not change from call to call): the size asked for
     hipError_t alloc(dmg_ctx *ctx, size_t n)
     {

@@ -215,27 +215,33 @@ __device__ __forceinline__ float d_sign(float x) { return x > 0.0f ? 1.0f : (x <
 // (one launch for a batch of steps: blockIdx.y = the step within the batch; M = (float)(M_PI*2/15000*i), the host's
 // expression in the host's double arithmetic, :146)
 #define TEMP_ROWS_BATCH 64
-__global__ void k_temperature_rows(canvas c, const float *__restrict__ lat, int first_step, float sin_gamma, float *__restrict__ asr_batch)
+// the orbit and the surface: every literal of the shader's preamble (Temperature.cpp:56-95) and of :102, as the host hands them over
+struct temp_orbit { float eccentricity, sin_gamma, omega2, S0, one_minus_albedo; int steps_per_year, clamp_acos; };
+__global__ void k_temperature_rows(canvas c, const float *__restrict__ lat, int first_step, temp_orbit ob, float *__restrict__ asr_batch)
 {
     int y = blockIdx.x * blockDim.x + threadIdx.x;
     if (y >= c.H) return;
-    const float M = (float)(M_PI * 2 / 15000 * (first_step + (int)blockIdx.y));
+    const float M = (float)(M_PI * 2 / ob.steps_per_year * (first_step + (int)blockIdx.y));
     float *asr = asr_batch + (size_t)blockIdx.y * c.H;
     float phi = lat[y];
-    const float eccentricity = 0.017f;
-    const float omega = 0.0f, omega2 = 77.05f / 180.0f * DMG_PI;
-    const float S0 = 1365.0f;
+    const float eccentricity = ob.eccentricity;
+    const float omega = 0.0f, omega2 = ob.omega2;
+    const float S0 = ob.S0;
     float e3 = eccentricity * eccentricity * eccentricity;
     float A = M + (2.0f * eccentricity - e3 / 4.0f * glsl::sin(M) + 5.0f / 4.0f * (eccentricity * eccentricity) * glsl::sin(2.0f * M)
                    + 13.0f / 12.0f * e3 * glsl::sin(3.0f * M));
     float Ls = A - omega2;
-    float delt = glsl::asin(sin_gamma * glsl::sin(Ls));
+    float delt = glsl::asin(ob.sin_gamma * glsl::sin(Ls));
     float h = d_sign(phi) == d_sign(delt) ? DMG_PI : 0.0f;
-    if (fabsf(phi) <= DMG_PI / 2.0f - fabsf(delt)) h = glsl::acos(-glsl::tan(phi) * glsl::tan(delt));
+    if (fabsf(phi) <= DMG_PI / 2.0f - fabsf(delt)) {
+        float arg = -glsl::tan(phi) * glsl::tan(delt);
+        if (ob.clamp_acos) arg = fminf(fmaxf(arg, -1.0f), 1.0f);     // DMG_CLIMATE_QUIRK_ACOS_NAN cleared: 1 + 2^-23 is 1
+        h = glsl::acos(arg);
+    }
     float S = S0 * (1.0f + 2.0f * eccentricity * glsl::cos(A - omega));
     float X = h * glsl::sin(phi) * glsl::sin(delt) + glsl::cos(phi) * glsl::cos(delt) * glsl::sin(h);
     // (1-alpha) * (S/M_PI * X): Mesa moves the constant factor next to the other one, ((S/pi) * 0.7) * X (probe shader)
-    asr[y] = ((S / DMG_PI) * (1.0f - 0.30f)) * X;
+    asr[y] = ((S / DMG_PI) * ob.one_minus_albedo) * X;
 }
 
 // The nine taps of get_texture_laplacian (Shader.h:304-312): offset(st, -vec2(i/factor, j)) fetched with GL_NEAREST.
@@ -282,46 +288,58 @@ __global__ __launch_bounds__(256) void k_temperature_taps(canvas c, const float 
     if (!ok) atomicOr(&literal_row[y], 1);
 }
 
-struct temp_consts { float ref_t4, r_t4, r_15000, r_c_land, r_c_ocean; };
+// A divisor that is the same for every cell (or for every cell of a row): its correctly rounded reciprocal for the Markstein form
+// (3 operations), and -- where the device has verified one for it (div2.hip) -- the pair (h, l) with x / c == fma(x, h, x * l)
+struct temp_div { float c, r, h, l; };
+// every literal of the cell update (Temperature.cpp:97-133), as dmg_climate_params hands them over
+struct temp_consts {
+    float celsius, olr_coeff, emissivity, diffusivity, year_s;
+    temp_div t4, steps, land, ocean;
+    int two;                                          // bit 0: t4 has a pair, 1: steps, 2: land AND ocean
+    // The window in which division through the constant IS the IEEE quotient, for every divisor of the step at once: numerators
+    // that are zero, or win_lo <= |x| <= 2^100.  dmg_div_rc needs 2^-100 .. 2^100; a pair needs its products x * h and x * l to
+    // be normal numbers, so win_lo = max(2^-64, 2^-125 / |l|) over the pairs in use (climate_set_params; a pair that would push it
+    // above 2^-40 is not used), and win_emin is win_lo's exponent as v_frexp_exp counts it.
+    float win_lo; int win_emin;
+};
+#define TEMP_WIN_HI 0x1p100f
 
-// one cell of the step (Temperature.cpp:97-133) from its own value, the terrain height and the nine Laplacian taps
-__device__ __forceinline__ float temperature_update(float Tc, bool land, const float s[9], float asr, float den, float rden,
+__device__ __forceinline__ float temp_div_exact(float x, const temp_div &d, bool two)
+{
+    return two ? __fmaf_rn(x, d.h, __fmul_rn(x, d.l)) : dmg_div_rc(x, d.c, d.r);
+}
+__device__ __forceinline__ bool temp_in_window(float x, float win_lo)
+{
+    float a = fabsf(x);
+    return x == 0.0f || (a >= win_lo && a <= TEMP_WIN_HI);
+}
+
+// one cell of the step (Temperature.cpp:97-133) from its own value, the terrain height and the nine Laplacian taps: the generic
+// form, every division by itself -- through the constant where the numerator is in the window, the IEEE sequence where it is not
+// (0 < |n| < win_lo, |n| > 2^100, inf, NaN: the reference's explicit scheme does blow up at fine resolutions, so non-finite fields
+// are real inputs here)
+__device__ __forceinline__ float temperature_update(float Tc, bool land, const float s[9], float asr, const temp_div &den, bool den_two,
                                                     const temp_consts &k)
 {
     float A_ = s[0], B_ = s[1], C_ = s[2], D_ = s[3], E_ = s[4], F_ = s[5], G_ = s[6], H_ = s[7], I_ = s[8];
     // (a - 2*b + c + 2*d - 4*e + 2*f + g - 2*h + i) and (a + 2*b + c - 2*d - 4*e - 2*f + g + 2*h + i), left to right
     float nx = __fadd_rn(__fsub_rn(__fadd_rn(__fadd_rn(__fsub_rn(__fadd_rn(__fadd_rn(__fsub_rn(A_, __fmul_rn(2.0f, B_)), C_), __fmul_rn(2.0f, D_)), __fmul_rn(4.0f, E_)), __fmul_rn(2.0f, F_)), G_), __fmul_rn(2.0f, H_)), I_);
     float ny = __fadd_rn(__fadd_rn(__fadd_rn(__fsub_rn(__fsub_rn(__fsub_rn(__fadd_rn(__fadd_rn(A_, __fmul_rn(2.0f, B_)), C_), __fmul_rn(2.0f, D_)), __fmul_rn(4.0f, E_)), __fmul_rn(2.0f, F_)), G_), __fmul_rn(2.0f, H_)), I_);
-    // The five divisions of the step are by row or literal constants: Markstein form through the constant's correctly
-    // rounded reciprocal (3 ops instead of the ~14 issue slots of the IEEE sequence), with the IEEE sequence kept for the
-    // numerators that form is not exact for -- 0 < |n| < 2^-100, |n| > 2^100, inf, NaN (the reference's explicit scheme
-    // does blow up at fine resolutions, so non-finite fields are real inputs here).
-    float t = __fadd_rn(Tc, 273.15f);
+    float t = __fadd_rn(Tc, k.celsius);
     float t2 = __fmul_rn(t, t);                                                   // pow(x,4) -> (x*x)*(x*x); pow(273.4,4): host constant
-    float olr_n = __fmul_rn(t2, __fmul_rn(t2, 210.0f));                           // :125, associated as Mesa does: x2*(x2*210)
-    float delta_x, delta_y, olr_q;
-    {
-        const float thr = 0x1p-100f, big = 0x1p100f;
-        float lo = fminf(fminf(fabsf(nx), fabsf(ny)), fabsf(olr_n));
-        bool fast = lo >= thr && fabsf(nx) <= big && fabsf(ny) <= big && fabsf(olr_n) <= big;          // NaN fails
-        if (!fast) fast = dmg_div_rc_exact_for(nx) && dmg_div_rc_exact_for(ny) && dmg_div_rc_exact_for(olr_n);   // zeros are fine
-        if (fast) {
-            delta_x = dmg_div_rc(nx, den, rden); delta_y = dmg_div_rc(ny, den, rden);
-            olr_q = dmg_div_rc(olr_n, k.ref_t4, k.r_t4);
-        } else {
-            delta_x = __fdiv_rn(nx, den); delta_y = __fdiv_rn(ny, den);
-            olr_q = __fdiv_rn(olr_n, k.ref_t4);
-        }
-    }
+    float olr_n = __fmul_rn(t2, __fmul_rn(t2, k.olr_coeff));                      // :125, associated as Mesa does: x2*(x2*210)
+    float delta_x = temp_in_window(nx, k.win_lo) ? temp_div_exact(nx, den, den_two) : __fdiv_rn(nx, den.c);
+    float delta_y = temp_in_window(ny, k.win_lo) ? temp_div_exact(ny, den, den_two) : __fdiv_rn(ny, den.c);
+    float olr_q = temp_in_window(olr_n, k.win_lo) ? temp_div_exact(olr_n, k.t4, (k.two & 1) != 0) : __fdiv_rn(olr_n, k.t4.c);
     if (isnan(delta_x)) delta_x = 0.0f;
     if (isnan(delta_y)) delta_y = 0.0f;
-    float OLR = __fmul_rn(olr_q, 0.93f);
-    float change = __fadd_rn(__fsub_rn(asr, OLR), __fmul_rn(__fmul_rn(0.55f, 1e6f), __fadd_rn(delta_x, delta_y)));   // :128
-    const float Cc = land ? 1.5e7f : 7e7f;          // atmosphere + (terrain>0 ? atmosphere*0.5 : 4*1.5*atmosphere), atmosphere = 1e7 (:131-132)
-    const float rCc = land ? k.r_c_land : k.r_c_ocean;
-    float n1 = __fmul_rn(change, __fmul_rn(3.154f, 1e7f));                        // :133, the two factors merged
-    float q1 = dmg_div_rc_exact_for(n1) ? dmg_div_rc(n1, 15000.0f, k.r_15000) : __fdiv_rn(n1, 15000.0f);
-    float q2 = dmg_div_rc_exact_for(q1) ? dmg_div_rc(q1, Cc, rCc) : __fdiv_rn(q1, Cc);
+    float OLR = __fmul_rn(olr_q, k.emissivity);
+    float change = __fadd_rn(__fsub_rn(asr, OLR), __fmul_rn(k.diffusivity, __fadd_rn(delta_x, delta_y)));   // :128
+    // C = atmosphere + (terrain>0 ? atmosphere*0.5 : 4*1.5*atmosphere), atmosphere = 1e7 (:131-132)
+    const temp_div &Cc = land ? k.land : k.ocean;
+    float n1 = __fmul_rn(change, k.year_s);                                       // :133, the two factors merged
+    float q1 = temp_in_window(n1, k.win_lo) ? temp_div_exact(n1, k.steps, (k.two & 2) != 0) : __fdiv_rn(n1, k.steps.c);
+    float q2 = temp_in_window(q1, k.win_lo) ? temp_div_exact(q1, Cc, (k.two & 4) != 0) : __fdiv_rn(q1, Cc.c);
     return __fadd_rn(Tc, q2);
 }
 
@@ -329,8 +347,8 @@ __device__ __forceinline__ float temperature_update(float Tc, bool land, const f
 // grid whose width is not a multiple of 4 (only_literal == 0, rows == null).
 __global__ __launch_bounds__(256) void k_temperature(canvas c, const float *__restrict__ T, float *__restrict__ out,
                                                      const float *__restrict__ terrain, const float *__restrict__ asr,
-                                                     const float *__restrict__ cosphi, const float *__restrict__ dyrow,
-                                                     const float *__restrict__ rdenrow, temp_consts k,
+                                                     const float *__restrict__ cosphi, const float4 *__restrict__ denrow,
+                                                     const int *__restrict__ dentwo, temp_consts k,
                                                      const int *__restrict__ shift, const int *__restrict__ srow,
                                                      const int *__restrict__ literal_row, const int *__restrict__ rows)
 {
@@ -338,8 +356,8 @@ __global__ __launch_bounds__(256) void k_temperature(canvas c, const float *__re
     const int x = blockIdx.x * 256 + threadIdx.x;
     if (x >= c.W) return;
     float factor = cosphi[y];                        // get_texture_laplacian: cos(geo.y) (Shader.h:301-302)
-    float dy = dyrow[y];
-    float den = __fmul_rn(4.0f, __fmul_rn(dy, dy));  // 4*pow(pixelwidth.y,2)
+    const float4 dr = denrow[y];                     // den = 4*pow(pixelwidth.y,2), its reciprocal and its pair
+    const temp_div den = { dr.x, dr.y, dr.z, dr.w };
     float s[9];
     if (!literal_row[y]) {                           // row-uniform: the verified per-row displacements
 #pragma unroll
@@ -353,7 +371,7 @@ __global__ __launch_bounds__(256) void k_temperature(canvas c, const float *__re
         }
     }
     size_t p = (size_t)y * c.W + x;
-    out[p] = temperature_update(T[p], terrain[p] > 0.0f, s, asr[y], den, rdenrow[y], k);
+    out[p] = temperature_update(T[p], terrain[p] > 0.0f, s, asr[y], den, dentwo[y] != 0, k);
 }
 
 // land4[i]: bit j = cell 4 i + j lies above sea level.  The step reads the terrain only for that sign (Temperature.cpp:131-132):
@@ -368,16 +386,70 @@ __global__ void k_land_mask4(const float *__restrict__ terrain, unsigned char *_
 
 // Four consecutive cells per thread for the rows whose tap displacements were verified (W % 4 == 0): every tap is one
 // 16-byte load at (tap row, x + displacement) -- unaligned in general, which the global load unit takes -- unless the
-// four cells straddle the seam or the clamped edge, and the index arithmetic is paid once per four cells.  A tap that is
-// the cell itself (the middle one, on every row seen so far) is not loaded again.
-// (Measured and dropped, round 3: the three tap rows of a 1024-cell block staged in LDS -- aligned 16-byte loads, a tile
-// de-interleaved by column mod 4, taps as conflict-free ds_read_b32 -- bit-identical, and slower: 0.77 ms against 0.51 on
-// the same box; without its halo columns 0.56, without the tap reads 0.60, with neither 0.39.  The unaligned tap loads
-// mostly hit the L1 / L2 of a CU that has just streamed the neighbouring rows; a barrier per block, half-rate 4-byte LDS
-// reads and a halo fetched by one wave cost more than they save.)
-__global__ __launch_bounds__(256) void k_temperature_v4(canvas c, const float *__restrict__ T, float *__restrict__ out,
+// four cells straddle the seam or the clamped edge.  A tap that is the cell itself (the middle one, on every row seen so
+// far) is not loaded again.
+//
+// Round 5.  profiles/r04_kernel_counters.txt: the round-4 kernel (k_temperature_v4) was bound by its vector instructions -- 135
+// per cell at 0.91 vector-ALU busy, of which about 22 decided, per cell and per division, whether the numerator lies in the
+// window in which division through the constant is exact, 15 were the divisions and most of the rest selects and branches
+// around them.  This one asks that question ONCE PER WAVE:
+//   * the four cells of a thread are computed as two packed pairs (v_pk_add / v_pk_mul / v_pk_fma: the same IEEE operations
+//     on two cells per issue slot), every division as its two-operation pair (three where a constant has none);
+//   * the admission test is one sum of magnitudes per thread (any NaN, infinity or value above 2^64 among the numerators
+//     makes it fail), the exponents of the two Laplacian numerators (zero is at home there: a field that is smooth along a
+//     row has nx == 0 exactly) and one minimum of the others;
+//   * a wave in which every lane passes -- every wave of a finite field -- stores the packed results; any other wave
+//     recomputes its cells through temperature_update, the generic form with the IEEE sequences.
+// Both paths produce the IEEE quotients, so which one a wave takes changes no bit (tests/test_gpu_filters.py runs fields that
+// force either).  (Measured and dropped, round 3: the three tap rows staged in LDS -- slower; see profiles/NOTEBOOK.md.)
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 f2_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 temp_div2(f2 x, const temp_div &d, bool two)
+{
+    if (two) return f2_fma(x, f2{ d.h, d.h }, x * f2{ d.l, d.l });
+    f2 q = x * f2{ d.r, d.r };
+    return f2_fma(f2_fma(f2{ -d.c, -d.c }, q, x), f2{ d.r, d.r }, q);
+}
+
+// the generic form of four cells: every tap checked against the seam / the clamped edge, every cell through temperature_update
+__device__ __forceinline__ void temperature_cells_generic(const canvas &c, const float *__restrict__ T, float *__restrict__ out, unsigned lm,
+                                                          float a, const temp_div &den, bool den_two, const temp_consts &k,
+                                                          const int *__restrict__ shift, const int *__restrict__ srow, int y, int x0)
+{
+    const int W = c.W;
+    const size_t p = (size_t)y * W + x0;
+    const float4 Tc = *reinterpret_cast<const float4 *>(T + p);
+    float s[4][9];
+#pragma unroll
+    for (int t = 0; t < 9; t++) {
+        const int shf = shift[y * 9 + t], sr = srow[y * 9 + t];
+        if (shf == 0 && sr == y) { s[0][t] = Tc.x; s[1][t] = Tc.y; s[2][t] = Tc.z; s[3][t] = Tc.w; continue; }   // (row-uniform)
+        const float *row = T + (size_t)sr * W;
+        int i = x0 + shf;
+        if (c.lonwrap && i >= W) i -= W;             // shf is a forward distance in [0, W) on a full-longitude grid, signed otherwise
+        if (i >= 0 && i + 3 < W) {
+            float4 v;
+            __builtin_memcpy(&v, row + i, 16);
+            s[0][t] = v.x; s[1][t] = v.y; s[2][t] = v.z; s[3][t] = v.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) s[j][t] = row[temperature_shifted(c, x0 + j, shf)];
+        }
+    }
+    float4 o;
+    o.x = temperature_update(Tc.x, (lm & 1u) != 0, s[0], a, den, den_two, k);
+    o.y = temperature_update(Tc.y, (lm & 2u) != 0, s[1], a, den, den_two, k);
+    o.z = temperature_update(Tc.z, (lm & 4u) != 0, s[2], a, den, den_two, k);
+    o.w = temperature_update(Tc.w, (lm & 8u) != 0, s[3], a, den, den_two, k);
+    *reinterpret_cast<float4 *>(out + p) = o;
+}
+
+// ALL2: every divisor of the step has its two-operation pair (the host knows: all but about one set of values in a hundred) --
+// the hot path is then one basic block; otherwise each division asks its (wave-uniform) flag
+template <bool ALL2>
+__global__ __launch_bounds__(256) void k_temperature_v5(canvas c, const float *__restrict__ T, float *__restrict__ out,
                                                         const unsigned char *__restrict__ land4, const float *__restrict__ asr,
-                                                        const float *__restrict__ dyrow, const float *__restrict__ rdenrow, temp_consts k,
+                                                        const float4 *__restrict__ denrow, const int *__restrict__ dentwo, temp_consts k,
                                                         const int *__restrict__ shift, const int *__restrict__ srow,
                                                         const int *__restrict__ literal_row)
 {
@@ -385,17 +457,16 @@ __global__ __launch_bounds__(256) void k_temperature_v4(canvas c, const float *_
     const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4;
     if (x0 >= c.W || literal_row[y]) return;
     const int W = c.W;
-    float dy = dyrow[y];
-    float den = __fmul_rn(4.0f, __fmul_rn(dy, dy));
-    float s[4][9];
+    const float4 dr = denrow[y];
+    const temp_div den = { dr.x, dr.y, dr.z, dr.w };
+    const bool den_two = ALL2 || dentwo[y] != 0;
+    const int ktwo = ALL2 ? 7 : k.two;
     const size_t p = (size_t)y * W + x0;
-    const float4 Tc = *reinterpret_cast<const float4 *>(T + p);
     const unsigned lm = land4[p >> 2];
-    // Round 4 (profiles/r04_kernel_counters.txt: the step is bound by its vector instructions, 146 per cell, 61 of them the
-    // taps' index arithmetic -- wrap, bounds and a 64-bit address per tap and thread).  The nine displacements and source rows
-    // are the same for the whole row (scalars); a thread whose four cells stay clear of the seam for the row's widest
-    // displacement -- all but the first and last few of a row -- takes every tap as ONE 16-byte load at a scalar row base plus
-    // a lane offset: one vector add per tap.  The others keep the checked form.  Same loads, same values.
+    const float a = asr[y];
+    // The nine displacements and source rows are the same for the whole row (scalars).  A wave whose cells all stay clear of the
+    // seam for the row's widest displacement -- all but the first and the last of a row -- takes every tap as ONE 16-byte load
+    // at a scalar row base plus a lane offset and goes on in packed arithmetic; the others take the generic form.
     int sh[9], sr[9], smin = 0, smax = 0;
 #pragma unroll
     for (int t = 0; t < 9; t++) {
@@ -405,39 +476,72 @@ __global__ __launch_bounds__(256) void k_temperature_v4(canvas c, const float *_
         sh[t] = d;
         smin = min(smin, d); smax = max(smax, d);
     }
-    if (x0 + smin >= 0 && x0 + smax + 3 < W) {
+    const bool interior = x0 + smin >= 0 && x0 + smax + 3 < W;
+    const bool middle_is_self = sh[4] == 0 && sr[4] == y;   // (row-uniform; true on every row seen so far: offset(st, -vec2(0, 0)))
+    bool done = false;
+    if (middle_is_self && __builtin_amdgcn_ballot_w64(!interior) == 0) {
+        float4 v[9];                                 // nine loads in flight at once, no branch between them; v[4] is the cell itself
 #pragma unroll
-        for (int t = 0; t < 9; t++) {
-            if (sh[t] == 0 && sr[t] == y) { s[0][t] = Tc.x; s[1][t] = Tc.y; s[2][t] = Tc.z; s[3][t] = Tc.w; continue; }   // (row-uniform)
-            float4 v;
-            __builtin_memcpy(&v, reinterpret_cast<const char *>(T + (size_t)sr[t] * W + sh[t]) + (unsigned)x0 * 4u, 16);
-            s[0][t] = v.x; s[1][t] = v.y; s[2][t] = v.z; s[3][t] = v.w;
-        }
-    } else {
+        for (int t = 0; t < 9; t++)
+            __builtin_memcpy(&v[t], reinterpret_cast<const char *>(T + (size_t)sr[t] * W + sh[t]) + (unsigned)x0 * 4u, 16);
+        const float4 Tc = v[4];
+        // ---- the packed form: pair 0 = cells 0, 1; pair 1 = cells 2, 3 ----
+        f2 res[2], nx[2], ny[2], olr_n[2], n1[2], q1[2];
+        const f2 Tcp[2] = { f2{ Tc.x, Tc.y }, f2{ Tc.z, Tc.w } };
 #pragma unroll
-        for (int t = 0; t < 9; t++) {
-            const int shf = shift[y * 9 + t];
-            if (shf == 0 && sr[t] == y) { s[0][t] = Tc.x; s[1][t] = Tc.y; s[2][t] = Tc.z; s[3][t] = Tc.w; continue; }
-            const float *row = T + (size_t)sr[t] * W;
-            int i = x0 + shf;
-            if (c.lonwrap && i >= W) i -= W;         // shf is a forward distance in [0, W)
-            if (i >= 0 && i + 3 < W) {
-                float4 v;
-                __builtin_memcpy(&v, row + i, 16);
-                s[0][t] = v.x; s[1][t] = v.y; s[2][t] = v.z; s[3][t] = v.w;
+        for (int h = 0; h < 2; h++) {
+#define TAP(t) (h == 0 ? f2{ v[t].x, v[t].y } : f2{ v[t].z, v[t].w })
+            const f2 A_ = TAP(0), B_ = TAP(1), C_ = TAP(2), D_ = TAP(3), E_ = TAP(4), F_ = TAP(5), G_ = TAP(6), H_ = TAP(7), I_ = TAP(8);
+#undef TAP
+            const f2 two = f2{ 2.0f, 2.0f }, four = f2{ 4.0f, 4.0f };
+            const f2 B2 = two * B_, D2 = two * D_, E4 = four * E_, F2 = two * F_, H2 = two * H_;
+            nx[h] = (((((((A_ - B2) + C_) + D2) - E4) + F2) + G_) - H2) + I_;      // left to right, as the shader
+            ny[h] = (((((((A_ + B2) + C_) - D2) - E4) - F2) + G_) + H2) + I_;
+            const f2 t = Tcp[h] + f2{ k.celsius, k.celsius };
+            const f2 t2 = t * t;
+            olr_n[h] = t2 * (t2 * f2{ k.olr_coeff, k.olr_coeff });
+            const f2 delta_x = temp_div2(nx[h], den, den_two), delta_y = temp_div2(ny[h], den, den_two);    // (finite in the window: no NaN to clear)
+            const f2 olr_q = temp_div2(olr_n[h], k.t4, (ktwo & 1) != 0);
+            const f2 OLR = olr_q * f2{ k.emissivity, k.emissivity };
+            const f2 change = (f2{ a, a } - OLR) + f2{ k.diffusivity, k.diffusivity } * (delta_x + delta_y);
+            n1[h] = change * f2{ k.year_s, k.year_s };
+            q1[h] = temp_div2(n1[h], k.steps, (ktwo & 2) != 0);
+            // the heat capacity is the cell's own: land or ocean, bits 2 h and 2 h + 1 of the mask
+            const int m0 = __builtin_amdgcn_sbfe((int)lm, 2 * h, 1), m1 = __builtin_amdgcn_sbfe((int)lm, 2 * h + 1, 1);     // 0 or -1
+            auto pick = [](int m, float land, float ocean) { return __int_as_float((m & __float_as_int(land)) | (~m & __float_as_int(ocean))); };
+            f2 q2;
+            if (ktwo & 4) {
+                const f2 hh = f2{ pick(m0, k.land.h, k.ocean.h), pick(m1, k.land.h, k.ocean.h) }, ll = f2{ pick(m0, k.land.l, k.ocean.l), pick(m1, k.land.l, k.ocean.l) };
+                q2 = f2_fma(q1[h], hh, q1[h] * ll);
             } else {
-#pragma unroll
-                for (int j = 0; j < 4; j++) s[j][t] = row[temperature_shifted(c, x0 + j, shf)];
+                const f2 cc = f2{ pick(m0, k.land.c, k.ocean.c), pick(m1, k.land.c, k.ocean.c) }, rr = f2{ pick(m0, k.land.r, k.ocean.r), pick(m1, k.land.r, k.ocean.r) };
+                const f2 q = q1[h] * rr;
+                q2 = f2_fma(f2_fma(-cc, q, q1[h]), rr, q);
             }
+            res[h] = Tcp[h] + q2;
+        }
+        // ---- admission: every numerator of every division of the four cells in {0} u [win_lo, 2^100] ----
+        // (1) nothing above the window, no infinity, no NaN: one sum of magnitudes (|q1| <= |n1|: steps_per_year >= 1)
+        float sum = fabsf(nx[0].x) + fabsf(nx[0].y);
+        sum += fabsf(nx[1].x); sum += fabsf(nx[1].y);
+        sum += fabsf(ny[0].x); sum += fabsf(ny[0].y); sum += fabsf(ny[1].x); sum += fabsf(ny[1].y);
+        sum += fabsf(olr_n[0].x); sum += fabsf(olr_n[0].y); sum += fabsf(olr_n[1].x); sum += fabsf(olr_n[1].y);
+        sum += fabsf(n1[0].x); sum += fabsf(n1[0].y); sum += fabsf(n1[1].x); sum += fabsf(n1[1].y);
+        // (2) the Laplacian numerators: zero or at least win_lo -- v_frexp_exp gives 0 for zero and e + 1 for 2^e <= |x| < 2^(e+1)
+        int emin = min(min(__builtin_amdgcn_frexp_expf(nx[0].x), __builtin_amdgcn_frexp_expf(nx[0].y)), min(__builtin_amdgcn_frexp_expf(nx[1].x), __builtin_amdgcn_frexp_expf(nx[1].y)));
+        emin = min(emin, min(min(__builtin_amdgcn_frexp_expf(ny[0].x), __builtin_amdgcn_frexp_expf(ny[0].y)), min(__builtin_amdgcn_frexp_expf(ny[1].x), __builtin_amdgcn_frexp_expf(ny[1].y))));
+        // (3) the others (a zero among them is rare: the generic form takes it): at least win_lo (|q1| <= |n1| again)
+        float lo = fminf(fminf(fminf(fabsf(olr_n[0].x), fabsf(olr_n[0].y)), fminf(fabsf(olr_n[1].x), fabsf(olr_n[1].y))),
+                         fminf(fminf(fabsf(q1[0].x), fabsf(q1[0].y)), fminf(fabsf(q1[1].x), fabsf(q1[1].y))));
+        const bool ok = sum <= TEMP_WIN_HI && emin >= k.win_emin && lo >= k.win_lo;
+        if (__builtin_amdgcn_ballot_w64(!ok) == 0) {
+            float4 o;
+            o.x = res[0].x; o.y = res[0].y; o.z = res[1].x; o.w = res[1].y;
+            *reinterpret_cast<float4 *>(out + p) = o;
+            done = true;
         }
     }
-    const float a = asr[y], rden = rdenrow[y];
-    float4 o;
-    o.x = temperature_update(Tc.x, (lm & 1u) != 0, s[0], a, den, rden, k);
-    o.y = temperature_update(Tc.y, (lm & 2u) != 0, s[1], a, den, rden, k);
-    o.z = temperature_update(Tc.z, (lm & 4u) != 0, s[2], a, den, rden, k);
-    o.w = temperature_update(Tc.w, (lm & 8u) != 0, s[3], a, den, rden, k);
-    *reinterpret_cast<float4 *>(out + p) = o;
+    if (!done) temperature_cells_generic(c, T, out, lm, a, den, den_two, k, shift, srow, y, x0);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -619,8 +723,13 @@ struct dmg_climate {
     dmg_ctx *ctx = nullptr;
     dmg_grid grid{};
     dmg_topology topo{};
-    dev_buf a, b, terr, land4, dlat, dcos, ddy, drden, dasr, dshift, dsrow, dlit;
+    dev_buf a, b, terr, land4, dlat, dcos, dden, ddentwo, dasr, dshift, dsrow, dlit;
     dev_buf dlitrows;
+    dmg_climate_params prm{};
+    temp_consts tc{};                                // the cell update's constants and divisors for prm
+    temp_orbit orbit{};                              // the rows kernel's
+    bool all_two = false;                            // every divisor has its two-operation pair
+    bool from_initial = false, stepped = false;      // created without a field: it holds prm.initial_temperature until the first step
     int n_literal = 0;                               // rows that keep the literal taps (their indices in dlitrows)
     std::vector<int> lit_rows;                       // the same list on the host (ascending), to launch the rows of a range
     float *cur = nullptr, *nxt = nullptr;
@@ -631,6 +740,102 @@ struct dmg_climate {
     size_t voff() const { return (size_t)(y0 - gs) * grid.W; }
 };
 
+void dmg_climate_params_default(dmg_climate_params *p)
+{
+    if (!p) return;
+    p->steps_per_year = 15000;
+    p->year_seconds = 3.154f * 1e7f;                 // the shader's 3.154*1e7, folded in fp32
+    p->diffusivity = 0.55f * 1e6f;                   // 0.55*1e6
+    p->albedo = 0.30f;
+    p->olr_coeff = 210.0f; p->olr_ref_kelvin = 273.4f; p->emissivity = 0.93f; p->celsius_offset = 273.15f;
+    p->heat_capacity_land = 1.5e7f; p->heat_capacity_ocean = 7e7f;
+    p->eccentricity = 0.017f; p->obliquity_deg = 23.44f; p->perihelion_deg = 77.05f; p->solar_constant = 1365.0f;
+    p->initial_temperature = 0.0f;
+    p->quirks = DMG_CLIMATE_QUIRK_ACOS_NAN;
+}
+
+// A pair handed out by div2.hip is exact for every x whose products x * h and x * l are normal numbers.  Upper end of the step's
+// window (2^100): |h| <= 2^27.  Lower end: |x| >= 2^-125 / |l| (l == 0 -- c a power of two -- asks for nothing); the step uses one
+// lower end for all its divisors, so a pair that would push it above 2^-40 is left unused (Markstein's three operations instead)
+static float temp_pair_needs(float h, float l)
+{
+    if (!(fabsf(h) <= 0x1p27f)) return INFINITY;
+    return l == 0.0f ? 0.0f : 0x1p-125f / fabsf(l);
+}
+
+int dmg_climate_set_params(dmg_climate *k, const dmg_climate_params *params)
+{
+    DMG_CHECK_ARG(k != nullptr && params != nullptr);
+    const dmg_climate_params &p = *params;
+    auto positive = [](float v) { return v > 0.0f && v <= 0x1p100f; };
+    if (p.steps_per_year < 1 || !positive(p.heat_capacity_land) || !positive(p.heat_capacity_ocean) || !positive(p.olr_ref_kelvin) ||
+        !std::isfinite(p.year_seconds) || !std::isfinite(p.diffusivity) || !std::isfinite(p.albedo) || !std::isfinite(p.olr_coeff) ||
+        !std::isfinite(p.emissivity) || !std::isfinite(p.celsius_offset) || !std::isfinite(p.eccentricity) || !std::isfinite(p.obliquity_deg) ||
+        !std::isfinite(p.perihelion_deg) || !std::isfinite(p.solar_constant) || !std::isfinite(p.initial_temperature))
+        return dmg_fail(DMG_EINVAL, "dmg_climate_params: steps_per_year >= 1, positive finite heat capacities and olr_ref_kelvin, finite values");
+    dmg_ctx *ctx = k->ctx;
+    DMG_HIP(hipSetDevice(ctx->device));
+    const int H = k->grid.H;
+    // the divisors: den = 4*pow(pixelwidth.y,2) per row (one value on an equirectangular canvas, but a table costs nothing),
+    // pow(273.4,4) (:125: a constant expression, folded by Mesa with libm's powf -- not 273.4^2 squared, one ulp apart),
+    // the steps per year and the two heat capacities; reciprocals by host IEEE division (correctly rounded)
+    std::vector<float> cs((size_t)H + 4), hh(cs.size()), ll(cs.size());
+    std::vector<unsigned char> ok(cs.size());
+    for (int y = 0; y < H; y++) {
+        float dx, dy;
+        dmg_row_pixelsize(k->grid, y, &dx, &dy);
+        cs[y] = 4.0f * (dy * dy);
+    }
+    cs[H] = powf(p.olr_ref_kelvin, 4.0f); cs[H + 1] = (float)p.steps_per_year; cs[H + 2] = p.heat_capacity_land; cs[H + 3] = p.heat_capacity_ocean;
+    int rc = dmg_div2_splits(ctx, cs.data(), (int)cs.size(), hh.data(), ll.data(), ok.data());
+    if (rc) return rc;
+    for (float cv : cs)
+        if (!(cv >= 0x1p-20f && cv <= 0x1p60f))
+            return dmg_fail(DMG_EINVAL, "dmg_climate_params / canvas: a divisor of the step (%g) is outside 2^-20 .. 2^60", (double)cv);
+    auto mk = [&](size_t i) { return temp_div{ cs[i], 1.0f / cs[i], hh[i], ll[i] }; };
+    auto two = [&](size_t i) { return ok[i] && temp_pair_needs(hh[i], ll[i]) <= 0x1p-40f; };
+    float win_lo = 0x1p-64f;
+    for (size_t i = 0; i < cs.size(); i++)
+        if (two(i)) win_lo = std::max(win_lo, temp_pair_needs(hh[i], ll[i]));
+    {                                                // a power of two, so that its exponent says the same as the comparison
+        int e;
+        const float m = frexpf(win_lo, &e);          // win_lo = m * 2^e, 0.5 <= m < 1
+        if (m != 0.5f) win_lo = ldexpf(1.0f, e);
+    }
+    std::vector<float> denrow((size_t)H * 4);
+    std::vector<int> dentwo(H);
+    for (int y = 0; y < H; y++) {
+        const temp_div d = mk(y);
+        denrow[4 * y] = d.c; denrow[4 * y + 1] = d.r; denrow[4 * y + 2] = d.h; denrow[4 * y + 3] = d.l;
+        dentwo[y] = two(y) ? 1 : 0;
+    }
+    k->dden.reset(); k->ddentwo.reset();             // (steps already queued read the old tables: the pool hands a block on in stream order)
+    if ((rc = upload_rows(ctx, k->dden, denrow)) || (rc = upload_vec(ctx, k->ddentwo, dentwo))) return rc;
+    temp_consts tc{};
+    tc.celsius = p.celsius_offset; tc.olr_coeff = p.olr_coeff; tc.emissivity = p.emissivity; tc.diffusivity = p.diffusivity; tc.year_s = p.year_seconds;
+    tc.t4 = mk(H); tc.steps = mk(H + 1); tc.land = mk(H + 2); tc.ocean = mk(H + 3);
+    tc.two = (two(H) ? 1 : 0) | (two(H + 1) ? 2 : 0) | (two(H + 2) && two(H + 3) ? 4 : 0);
+    tc.win_lo = win_lo;
+    { int e; (void)frexpf(win_lo, &e); tc.win_emin = e; }      // v_frexp_exp: 2^(e-1) <= |x| < 2^e  ->  e
+    k->tc = tc;
+    k->all_two = tc.two == 7 && std::all_of(dentwo.begin(), dentwo.end(), [](int v) { return v != 0; }) && !getenv("DMG_CLIMATE_NO_PAIRS");
+    if (getenv("DMG_TEMPERATURE_REPORT"))            // experiments
+        fprintf(stderr, "dmg_climate_set_params: pairs t4 %d steps %d land %d ocean %d den %d/%d rows, window from 2^%d, all_two %d\n", (int)two(H),
+                (int)two(H + 1), (int)two(H + 2), (int)two(H + 3), (int)std::count(dentwo.begin(), dentwo.end(), 1), H, tc.win_emin - 1, (int)k->all_two);
+    // sin(gamma), omega2, 1 - alpha: expressions of constants, folded by Mesa on the host in fp32
+    k->orbit = temp_orbit{ p.eccentricity, sinf(p.obliquity_deg / 180.0f * DMG_PI), p.perihelion_deg / 180.0f * DMG_PI, p.solar_constant,
+                           1.0f - p.albedo, p.steps_per_year, (p.quirks & DMG_CLIMATE_QUIRK_ACOS_NAN) ? 0 : 1 };
+    if (k->from_initial && !k->stepped && (p.initial_temperature != k->prm.initial_temperature || !k->a.p)) {
+        const size_t n = (size_t)k->grid.W * k->L;
+        std::vector<float> fill(n, p.initial_temperature);
+        DMG_HIP(hipMemcpyAsync(k->a.p, fill.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
+        DMG_HIP(hipMemcpyAsync(k->b.p, fill.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
+        DMG_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    k->prm = p;
+    return DMG_OK;
+}
+
 int dmg_climate_create(dmg_ctx *ctx, const dmg_grid *grid, const float *T, const float *terrain, dmg_climate **out)
 {
     return dmg_climate_create_band(ctx, grid, T, terrain, 0, 1, 0, out);
@@ -639,7 +844,7 @@ int dmg_climate_create(dmg_ctx *ctx, const dmg_grid *grid, const float *T, const
 int dmg_climate_create_band(dmg_ctx *ctx, const dmg_grid *grid, const float *T, const float *terrain, int band_rank, int band_count,
                             int ghost, dmg_climate **out)
 {
-    DMG_CHECK_ARG(ctx != nullptr && T != nullptr && terrain != nullptr && out != nullptr);
+    DMG_CHECK_ARG(ctx != nullptr && terrain != nullptr && out != nullptr);
     *out = nullptr;
     dmg_topology topo;
     int rc = dmg_check_grid(grid, &topo);
@@ -652,14 +857,10 @@ int dmg_climate_create_band(dmg_ctx *ctx, const dmg_grid *grid, const float *T, 
     const int bgs = band_rank > 0 ? ghost : 0, bgn = band_rank < band_count - 1 ? ghost : 0, bL = bgs + (by1 - by0) + bgn;
     const size_t n = (size_t)grid->W * bL;
     const size_t src_off = (size_t)(by0 - bgs) * grid->W;
-    std::vector<float> lat(H), cosphi(H), dyr(H), rden(H);
+    std::vector<float> lat(H), cosphi(H);
     for (int y = 0; y < H; y++) {
-        float dx, dy;
-        dmg_row_pixelsize(*grid, y, &dx, &dy);
         lat[y] = dmg_row_lat(*grid, y);
         cosphi[y] = glsl::cos(lat[y]);
-        dyr[y] = dy;
-        rden[y] = 1.0f / (4.0f * (dy * dy));         // correctly rounded reciprocal of the kernel's den = 4*pow(pixelwidth.y,2)
     }
     std::unique_ptr<dmg_climate> k(new (std::nothrow) dmg_climate);
     if (!k) return dmg_fail(DMG_ENOMEM, "out of host memory");
@@ -667,10 +868,18 @@ int dmg_climate_create_band(dmg_ctx *ctx, const dmg_grid *grid, const float *T, 
     k->rank = band_rank; k->count = band_count; k->ghost = ghost; k->y0 = by0; k->y1 = by1; k->gs = bgs; k->gn = bgn; k->L = bL;
     DMG_ALLOC(k->a, n * 4); DMG_ALLOC(k->b, n * 4); DMG_ALLOC(k->terr, n * 4); DMG_ALLOC(k->dasr, (size_t)H * 4 * TEMP_ROWS_BATCH);
     DMG_ALLOC(k->dshift, (size_t)H * 9 * sizeof(int)); DMG_ALLOC(k->dsrow, (size_t)H * 9 * sizeof(int)); DMG_ALLOC(k->dlit, (size_t)H * sizeof(int));
-    if ((rc = upload_rows(ctx, k->dlat, lat)) || (rc = upload_rows(ctx, k->dcos, cosphi)) || (rc = upload_rows(ctx, k->ddy, dyr)) ||
-        (rc = upload_rows(ctx, k->drden, rden))) return rc;
-    DMG_HIP(hipMemcpyAsync(k->a.p, T + src_off, n * 4, hipMemcpyHostToDevice, ctx->stream));
-    DMG_HIP(hipMemcpyAsync(k->b.p, T + src_off, n * 4, hipMemcpyHostToDevice, ctx->stream));      // (rows a band step does not write keep a defined value)
+    if ((rc = upload_rows(ctx, k->dlat, lat)) || (rc = upload_rows(ctx, k->dcos, cosphi))) return rc;
+    dmg_climate_params def;
+    dmg_climate_params_default(&def);
+    k->prm = def;
+    std::vector<float> fill;
+    if (!T) {                                        // Temperature::Temperature clears the layer (:26-44)
+        k->from_initial = true;
+        fill.assign(n, def.initial_temperature);
+    }
+    const float *src = T ? T + src_off : fill.data();
+    DMG_HIP(hipMemcpyAsync(k->a.p, src, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    DMG_HIP(hipMemcpyAsync(k->b.p, src, n * 4, hipMemcpyHostToDevice, ctx->stream));      // (rows a band step does not write keep a defined value)
     DMG_HIP(hipMemcpyAsync(k->terr.p, terrain + src_off, n * 4, hipMemcpyHostToDevice, ctx->stream));
     if (grid->W % 4 == 0) {
         DMG_ALLOC(k->land4, n / 4);
@@ -679,6 +888,7 @@ int dmg_climate_create_band(dmg_ctx *ctx, const dmg_grid *grid, const float *T, 
     }
     DMG_HIP(hipStreamSynchronize(ctx->stream));      // the caller's buffers may go away
     k->cur = k->a.f(); k->nxt = k->b.f();
+    if ((rc = dmg_climate_set_params(k.get(), &def))) return rc;
     dmg_ctx_retain(ctx);
     *out = k.release();
     return DMG_OK;
@@ -704,9 +914,8 @@ int dmg_climate_steps(dmg_climate *k, int first_step, int n_steps)
     const int first_row = k->y0 - k->gs;             // stored rows
     c.row0 = first_row;
     dim3 g((W + 255) / 256, k->L);
-    const float sin_gamma = sinf(23.44f / 180.0f * DMG_PI);   // sin(gamma): an expression of constants, folded by Mesa on the host
-    const float ref_t4 = powf(273.4f, 4.0f);                  // pow(273.4,4) (:125), likewise (not 273.4^2 squared: one ulp apart)
-    const temp_consts tc = { ref_t4, 1.0f / ref_t4, 1.0f / 15000.0f, 1.0f / 1.5e7f, 1.0f / 7e7f };   // host IEEE divisions: correctly rounded reciprocals
+    const temp_consts tc = k->tc;
+    if (n_steps > 0) k->stepped = true;
     if (!k->taps_ready && n_steps > 0) {
         // per-row tap displacements, verified cell by cell against the literal offset() arithmetic (once per field)
         static const bool literal_only = getenv("DMG_TEMPERATURE_LITERAL") != nullptr;      // experiments: every row literal
@@ -740,21 +949,22 @@ int dmg_climate_steps(dmg_climate *k, int first_step, int n_steps)
         const int in_batch = (i - first_step) % TEMP_ROWS_BATCH;
         if (in_batch == 0)
             hipLaunchKernelGGL(k_temperature_rows, dim3((H + 255) / 256, std::min(TEMP_ROWS_BATCH, first_step + n_steps - i)), dim3(256), 0, ctx->stream,
-                               c, k->dlat.f(), i, sin_gamma, k->dasr.f());
+                               c, k->dlat.f(), i, k->orbit, k->dasr.f());
         const float *asr_i = k->dasr.f() + (size_t)in_batch * H;
         if (W % 4 == 0) {                            // tabled rows four cells per thread, the few literal rows one cell per thread
-            hipLaunchKernelGGL(k_temperature_v4, dim3((W / 4 + 255) / 256, nrows), dim3(256), 0, ctx->stream, c, cur_v, nxt_v, land4_v,
-                               asr_i, k->ddy.f(), k->drden.f(), tc, (const int *)k->dshift.p, (const int *)k->dsrow.p, (const int *)k->dlit.p);
+            hipLaunchKernelGGL(k->all_two ? k_temperature_v5<true> : k_temperature_v5<false>, dim3((W / 4 + 255) / 256, nrows), dim3(256), 0,
+                               ctx->stream, c, cur_v, nxt_v, land4_v, asr_i, (const float4 *)k->dden.p, (const int *)k->ddentwo.p, tc,
+                               (const int *)k->dshift.p, (const int *)k->dsrow.p, (const int *)k->dlit.p);
             const int l0 = (int)(std::lower_bound(k->lit_rows.begin(), k->lit_rows.end(), lo) - k->lit_rows.begin());
             const int l1 = (int)(std::lower_bound(k->lit_rows.begin(), k->lit_rows.end(), hi) - k->lit_rows.begin());
             if (l1 > l0)
                 hipLaunchKernelGGL(k_temperature, dim3((W + 255) / 256, l1 - l0), dim3(256), 0, ctx->stream, c, cur_v, nxt_v, terr_v,
-                                   asr_i, k->dcos.f(), k->ddy.f(), k->drden.f(), tc, (const int *)k->dshift.p, (const int *)k->dsrow.p,
-                                   (const int *)k->dlit.p, (const int *)k->dlitrows.p + l0);
+                                   asr_i, k->dcos.f(), (const float4 *)k->dden.p, (const int *)k->ddentwo.p, tc, (const int *)k->dshift.p,
+                                   (const int *)k->dsrow.p, (const int *)k->dlit.p, (const int *)k->dlitrows.p + l0);
         } else {
             hipLaunchKernelGGL(k_temperature, dim3((W + 255) / 256, nrows), dim3(256), 0, ctx->stream, c, cur_v, nxt_v, terr_v, asr_i,
-                               k->dcos.f(), k->ddy.f(), k->drden.f(), tc, (const int *)k->dshift.p, (const int *)k->dsrow.p, (const int *)k->dlit.p,
-                               (const int *)nullptr);
+                               k->dcos.f(), (const float4 *)k->dden.p, (const int *)k->ddentwo.p, tc, (const int *)k->dshift.p,
+                               (const int *)k->dsrow.p, (const int *)k->dlit.p, (const int *)nullptr);
         }
         DMG_HIP(hipGetLastError());
         std::swap(k->cur, k->nxt);                   // terrain.swap(scratch2) (:148)
@@ -833,13 +1043,15 @@ int dmg_climate_halo(dmg_climate *k, int side, int rows, void **send, void **rec
     return DMG_OK;
 }
 
-int dmg_temperature_steps(dmg_ctx *ctx, const dmg_grid *grid, float *T, const float *terrain, int first_step, int n_steps)
+int dmg_temperature_steps(dmg_ctx *ctx, const dmg_grid *grid, float *T, const float *terrain, const dmg_climate_params *params,
+                          int first_step, int n_steps)
 {
     DMG_CHECK_ARG(ctx != nullptr && T != nullptr && terrain != nullptr && n_steps >= 0);
     dmg_climate *k = nullptr;
     int rc = dmg_climate_create(ctx, grid, T, terrain, &k);
     if (rc) return rc;
-    rc = dmg_climate_steps(k, first_step, n_steps);
+    if (params) rc = dmg_climate_set_params(k, params);
+    if (!rc) rc = dmg_climate_steps(k, first_step, n_steps);
     if (!rc) rc = dmg_climate_get(k, T);
     dmg_climate_destroy(k);
     return rc;

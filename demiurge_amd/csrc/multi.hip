@@ -1142,6 +1142,13 @@ int dmg_multi_climate_set_terrain(dmg_multi_climate *h, const float *terrain)
 }
 
 // owned rows of this process's bands into the FULL-grid array; synchronises
+int dmg_multi_climate_set_params(dmg_multi_climate *h, const dmg_climate_params *params)
+{
+    dmg_multi *m = reinterpret_cast<dmg_multi *>(h);
+    DMG_CHECK_ARG(m != nullptr && params != nullptr && !m->cl.empty());
+    return m->team.run([&](int i) { return dmg_climate_set_params(m->cl[i], params); });
+}
+
 int dmg_multi_climate_get(dmg_multi_climate *h, float *T)
 {
     dmg_multi *m = reinterpret_cast<dmg_multi *>(h);
@@ -1177,6 +1184,8 @@ struct dmg_multi_world {
     hipEvent_t ev_ready = nullptr;                   // the eroded terrain of this iteration is complete (ctx0's stream)
     std::vector<hipEvent_t> ev_taken;                // band i has copied its rows (its stream): the next iteration may overwrite them
     long long climate_step = 0, iterations = 0;
+    dmg_climate_params clim_prm{};                   // what the climate bands hold
+    bool clim_prm_set = false;
 };
 
 static void multi_world_free(dmg_multi_world *w)
@@ -1287,6 +1296,11 @@ int dmg_multi_world_step(dmg_multi_world *w, const dmg_world_params *params)
     DMG_HIP(hipEventRecord(w->ev_ready, st));
     // the climate's bands: each pulls its rows of the eroded terrain (behind the event), then steps; asynchronous
     if (p.climate_steps > 0) {
+        if (!w->clim_prm_set) { dmg_climate_params_default(&w->clim_prm); w->clim_prm_set = true; }
+        if (memcmp(&p.climate, &w->clim_prm, sizeof p.climate) != 0) {      // other literals than the bands hold: hand them on, once
+            if ((rc = dmg_multi_climate_set_params(reinterpret_cast<dmg_multi_climate *>(m), &p.climate))) return rc;
+            w->clim_prm = p.climate;
+        }
         const int first = (int)w->climate_step, n_steps = p.climate_steps;
         rc = m->team.run([&](int i) -> int {
             dmg_climate *k = m->cl[i];

@@ -13,6 +13,7 @@
 // at 16384x8192).  Tectonics renders into its own device buffer, the erosion handle is created from that buffer with a
 // device copy, the climate takes the eroded heights with a device copy; the reference keeps all of it in textures
 // (cpufilter.cpp:106-216).  dmg_world_get downloads what the host asks for.
+#include <cstring>
 #include "dmg_internal.h"
 #include <memory>
 
@@ -23,6 +24,7 @@ struct dmg_world {
     dmg_climate *clim = nullptr;
     float *d_terrain = nullptr, *d_eroded = nullptr; // what the tectonics render pass left; after the erosion rounds (scaled by 1/N like the reference)
     long long climate_step = 0, iterations = 0;
+    dmg_climate_params clim_prm{};                   // what the climate handle holds (handed on only when a step brings other values)
 };
 
 extern "C" {
@@ -36,6 +38,7 @@ void dmg_world_params_default(dmg_world_params *p)
     p->erosion_N = 50;                               // cpufilter.cpp:42
     p->exponent = 0.5f; p->slope_exponent = 1.0f; p->factor = 1.0f;      // the menu's defaults, cpufilter.h:18-21
     p->lakes = 0;
+    dmg_climate_params_default(&p->climate);
 }
 
 int dmg_world_create(dmg_ctx *ctx, const dmg_grid *grid, const float *terrain, const float *T0, dmg_world **out)
@@ -62,6 +65,7 @@ int dmg_world_create(dmg_ctx *ctx, const dmg_grid *grid, const float *terrain, c
         (void)hipFree(w->d_terrain); (void)hipFree(w->d_eroded);
         return rc;
     }
+    dmg_climate_params_default(&w->clim_prm);
     dmg_ctx_retain(ctx);
     *out = w.release();
     return DMG_OK;
@@ -104,6 +108,10 @@ int dmg_world_step(dmg_world *w, const dmg_world_params *params)
         if (rc) return rc;
     } else DMG_HIP(hipMemcpyAsync(w->d_eroded, w->d_terrain, bytes, hipMemcpyDeviceToDevice, st));
     if (p.climate_steps > 0) {
+        if (memcmp(&p.climate, &w->clim_prm, sizeof p.climate) != 0) {
+            if ((rc = dmg_climate_set_params(w->clim, &p.climate))) return rc;
+            w->clim_prm = p.climate;
+        }
         if ((rc = climate_set_terrain_device(w->clim, w->d_eroded))) return rc;
         if ((rc = dmg_climate_steps(w->clim, (int)w->climate_step, p.climate_steps))) return rc;
         w->climate_step += p.climate_steps;

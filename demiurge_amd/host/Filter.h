@@ -8,6 +8,7 @@
 // Project here is only what the simulation filters read and write: canvas geometry and the host copies of the
 // `img` terrain layer and the scratch1/scratch2 textures (what Texture::downloadDataRAW / uploadData move).
 #pragma once
+#include <atomic>
 #include <condition_variable>
 #include <functional>
 #include <mutex>
@@ -32,7 +33,18 @@ public:
 
 class AsyncSubFilter : public SubFilter {
 public:
-    ~AsyncSubFilter() override { if (worker.joinable()) worker.join(); }
+    // The reference's Cancel (src/filter/Filter.cpp:105-108) restores the backup but lets the worker run on -- 10000 outer ocean
+    // steps, half an hour at 16384x8192 -- and ~AsyncSubFilter would join it.  Here cancel() raises a flag the adapters' run()
+    // loops read once per outer step / round / frame (cancelled()), a worker parked in dispatchGPU is released without its closure
+    // being run, and the destructor cancels before it joins.
+    ~AsyncSubFilter() override { cancel(); if (worker.joinable()) worker.join(); }
+    void cancel()
+    {
+        cancel_requested.store(true);
+        std::lock_guard<std::mutex> lk(gpu_mtx);
+        cv.notify_all();
+    }
+    bool cancelled() const { return cancel_requested.load(); }
 
     std::pair<bool, float> step(Project *p) override
     {
@@ -67,13 +79,15 @@ protected:
         std::lock_guard<std::mutex> lk(progress_mtx);
         progress = p;
     }
-    // blocks the worker until a step() call has executed f
+    // blocks the worker until a step() call has executed f (or the filter has been cancelled: f is then dropped)
     void dispatchGPU(std::function<void(Project *)> f)
     {
         std::unique_lock<std::mutex> lk(gpu_mtx);
+        if (cancel_requested.load()) return;
         closure = std::move(f);
         pending = true;
-        cv.wait(lk, [this] { return !pending; });
+        cv.wait(lk, [this] { return !pending || cancel_requested.load(); });
+        pending = false;
     }
 
 private:
@@ -83,6 +97,7 @@ private:
     std::condition_variable cv;
     std::function<void(Project *)> closure;
     bool pending = false;
+    std::atomic<bool> cancel_requested{false};
     std::thread worker;
 };
 

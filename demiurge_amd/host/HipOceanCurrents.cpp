@@ -32,7 +32,7 @@ void HipOceanCurrents::run()
     if (dmg_multi_set_terrain(oc, img.data())) return fail("dmg_multi_set_terrain");
 
     std::vector<float> vx((size_t)g.W * g.H), vy((size_t)g.W * g.H);
-    for (int j = 0; j < n_outer_; j++) {                // :155
+    for (int j = 0; j < n_outer_ && !cancelled(); j++) {   // :155; Cancel (Filter.cpp:105-108) ends the solve at the next outer step
         if (dmg_multi_step(oc, 1)) return fail("dmg_multi_step");                         // advect .. subDiv (:156-168)
         if (dmg_multi_get(oc, vx.data(), vy.data(), nullptr, nullptr)) return fail("dmg_multi_get");
         dispatchGPU([&](Project *p) {                   // :175-205  scratch1 := v.x, scratch2 := v.y

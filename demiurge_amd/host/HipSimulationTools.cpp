@@ -29,7 +29,7 @@ void HipErosion::run()
     if (!layer_matches(h, g.W, g.H)) { error_ = "terrain layer does not hold width*height texels"; setProgress({ true, 1.0f }); return; }
     if (dmg_create(0, nullptr, DMG_PRIVATE_STREAM, &ctx)) return fail("dmg_create");
     if (dmg_erosion_create(ctx, &g, h.data(), N_, exponent_, slope_exponent_, factor_, dolakes_ > 0 ? 1 : 0, &e)) return fail("dmg_erosion_create");
-    for (int i = 0; i < rounds_; i++) {                                                  // :93
+    for (int i = 0; i < rounds_ && !cancelled(); i++) {                                  // :93
         if (dmg_erosion_rounds(e, 1)) return fail("dmg_erosion_rounds");
         if (dmg_erosion_get(e, h.data())) return fail("dmg_erosion_get");
         dispatchGPU([&](Project *p) { p->terrain = h; });                                // :213 heightdata = terrain->downloadDataRAW()
@@ -58,8 +58,9 @@ void HipTemperature::run()
     if (!layer_matches(T, g.W, g.H) || heights.size() != T.size()) { error_ = "terrain / scratch1 layers do not hold width*height texels"; setProgress({ true, 1.0f }); return; }
     if (dmg_create(0, nullptr, DMG_PRIVATE_STREAM, &ctx)) return fail("dmg_create");
     if (dmg_climate_create(ctx, &g, T.data(), heights.data(), &k)) return fail("dmg_climate_create");
+    if (dmg_climate_set_params(k, &params_)) return fail("dmg_climate_set_params");
     int i = 0;
-    for (int f = 0; f < frames_; f++) {                                                  // :48 (the index advances 10 per frame plus the loop's ++, :151 and :48)
+    for (int f = 0; f < frames_ && !cancelled(); f++) {                                  // :48 (the index advances 10 per frame plus the loop's ++, :151 and :48)
         if (dmg_climate_steps(k, i, per_frame_)) return fail("dmg_climate_steps");
         i += per_frame_;
         if (dmg_climate_get(k, T.data())) return fail("dmg_climate_get");

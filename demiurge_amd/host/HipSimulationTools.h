@@ -37,12 +37,16 @@ public:
     {
         std::swap(p->terrain, p->scratch1);
         p->terrain.assign((size_t)p->getWidth() * p->getHeight(), 50.0f);
+        dmg_climate_params_default(&params_);
     }
+    // the shader's literals (Temperature.cpp:56-134) as the menu's fields: set before the first step()
+    dmg_climate_params &params() { return params_; }
     const std::string &error() const { return error_; }
 protected:
     void run() override;
 private:
     int frames_, per_frame_;
+    dmg_climate_params params_;
     std::string error_;
 };
 

@@ -25,7 +25,7 @@ void HipTectonics::run()
     if (dmg_create(0, nullptr, DMG_PRIVATE_STREAM, &ctx)) return fail("dmg_create");
     if (dmg_tectonics_create(ctx, &g, img.data(), &t)) return fail("dmg_tectonics_create");     // Tectonics::Tectonics :15-154
     std::vector<float> terrain((size_t)g.W * g.H);
-    for (int i = 0; i < n_steps_; i++) {                                                        // :157
+    for (int i = 0; i < n_steps_ && !cancelled(); i++) {                                                        // :157
         if (dmg_tectonics_step(t, 1)) return fail("dmg_tectonics_step");
         if (dmg_tectonics_get_terrain(t, terrain.data())) return fail("dmg_tectonics_get_terrain");
         dispatchGPU([&](Project *p) { p->terrain = terrain; });                                  // the render pass' target, :210

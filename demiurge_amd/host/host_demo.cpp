@@ -116,9 +116,42 @@ static int lifetime_check()
     return 0;
 }
 
+// Cancel (reference src/filter/Filter.cpp:105-108 sets `aborting` and restores the backup; its worker runs on): here the
+// adapter's loop reads the flag once per outer step.  host_demo cancel W H terrain.f32: the reference's 10000 outer steps are
+// asked for, Cancel arrives once the first has been shown, and the filter finishes within a step or two.
+static int cancel_check(int argc, char **argv)
+{
+    if (argc != 5) { fprintf(stderr, "usage: host_demo cancel W H terrain.f32\n"); return 2; }
+    Project p;
+    p.width = atoi(argv[2]); p.height = atoi(argv[3]);
+    p.terrain.resize((size_t)p.width * p.height);
+    if (!read_f32(argv[4], p.terrain)) { fprintf(stderr, "cannot read %s\n", argv[4]); return 2; }
+    auto filter = std::make_unique<HipOceanCurrents>(&p, 100.0f, 10000, 200, 10);
+    int frames = 0, frames_at_cancel = -1;
+    float progress_at_cancel = 0.0f, last = 0.0f;
+    for (;;) {
+        auto [finished, progress] = filter->step(&p);
+        frames++;
+        if (finished) break;
+        last = progress;
+        if (frames_at_cancel < 0 && progress > 0.0f) { filter->cancel(); frames_at_cancel = frames; progress_at_cancel = progress; }
+        std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    }
+    if (!filter->error().empty()) { fprintf(stderr, "filter failed: %s\n", filter->error().c_str()); return 1; }
+    printf("cancelled at outer step %d of 10000 (frame %d); finished at outer step %d (frame %d)\n", (int)(progress_at_cancel * 10000 + 0.5f),
+           frames_at_cancel, (int)(last * 10000 + 0.5f), frames);
+    // a filter destroyed in mid-run (the editor closing the modal): the destructor cancels, then joins
+    auto second = std::make_unique<HipOceanCurrents>(&p, 100.0f, 10000, 200, 10);
+    for (int i = 0; i < 50; i++) { second->step(&p); std::this_thread::sleep_for(std::chrono::milliseconds(1)); }
+    second.reset();
+    printf("destroyed in mid-run\n");
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     if (argc == 2 && std::string(argv[1]) == "lifetime") return lifetime_check();
+    if (argc >= 2 && std::string(argv[1]) == "cancel") return cancel_check(argc, argv);
     if (argc >= 2 && !(argv[1][0] >= '0' && argv[1][0] <= '9')) return other_tools(argc, argv);
     if (argc != 8 && argc != 9) { fprintf(stderr, "usage: host_demo W H terrain.f32 n_outer jacobi_iters diffusion_iters out_prefix [n_bands on GPU 0]\n"); return 2; }
     Project p;

@@ -335,6 +335,7 @@ int dmg_multi_comm_ranks(dmg_multi *m, int *ranks, int *devices);
  * the ghost rows are refreshed every `ghost` steps.  T and terrain are FULL-grid arrays; results are bit-identical to
  * dmg_climate_steps on one band. */
 typedef struct dmg_multi_climate dmg_multi_climate;
+struct dmg_climate_params;                       /* below, with dmg_temperature_steps */
 int dmg_multi_climate_create(int n_bands, const int *device_ids, const dmg_grid *grid, const float *T, const float *terrain, int ghost, int flags,
                              dmg_multi_climate **out);
 int dmg_multi_climate_create_rank(int rank, int n_ranks, const void *id128, int device_id, const dmg_grid *grid, const float *T,
@@ -342,6 +343,7 @@ int dmg_multi_climate_create_rank(int rank, int n_ranks, const void *id128, int 
 void dmg_multi_climate_destroy(dmg_multi_climate *h);
 int dmg_multi_climate_steps(dmg_multi_climate *h, int first_step, int n_steps);   /* asynchronous on the bands' streams */
 int dmg_multi_climate_set_terrain(dmg_multi_climate *h, const float *terrain);    /* Temperature.cpp:131-132: only the sign matters */
+int dmg_multi_climate_set_params(dmg_multi_climate *h, const struct dmg_climate_params *params);   /* dmg_climate_set_params on every local band */
 int dmg_multi_climate_get(dmg_multi_climate *h, float *T);                        /* owned rows of this process's bands; synchronises */
 int dmg_multi_climate_sync(dmg_multi_climate *h);
 int dmg_multi_climate_store_blob(dmg_multi_climate *h, void *blob);                          /* as dmg_multi_store_blob / _connect */
@@ -352,15 +354,51 @@ int dmg_multi_timer_stop(dmg_multi *m, float *elapsed_ms);
 /* ---- generic stencil filters on a whole grid ---------------------------- */
 /* Blur::Blur + Blur::step until finished (src/filter/BlurMenu.cpp:24-117), in place on host data */
 int dmg_blur(dmg_ctx *ctx, const dmg_grid *grid, float *field_inout, float radius);
-/* Temperature::run inner pass (src/filter/Temperature.cpp:140-150) n_steps times from step index first_step */
+/* Every literal the reference hard-codes in Temperature.cpp, as a field.  The defaults reproduce the
+ * shader bit for bit; the arithmetic keeps the shader's form whatever the values.  Why a host wants them: with the reference's
+ * values the explicit scheme is unstable on fine grids -- the diffusion number diffusivity * (year_seconds / steps_per_year) /
+ * (heat_capacity * dy^2) must stay below 1/4, and at 16384x8192 (dy = 2.56 km) it is 11.8 over land: fp32 overflows within 38
+ * steps.  More steps per year, or a smaller diffusivity, give BASELINE config 5 a year it can finish. */
+typedef struct dmg_climate_params {
+    int steps_per_year;            /* 15000    :133 (the time step, 3.154e7/15000 s) and :146 (the orbital phase, M = 2 pi i / 15000) */
+    float year_seconds;            /* 3.154e7  :133 (written 3.154*1e7) */
+    float diffusivity;             /* 0.55e6   :128 (written 0.55*1e6) */
+    float albedo;                  /* 0.30     :102 (the terrain-dependent 0.15 / 0.06 of :101 is overwritten there) */
+    float olr_coeff;               /* 210      :125  OLR = olr_coeff * ((T + celsius_offset) / olr_ref_kelvin)^4 * emissivity */
+    float olr_ref_kelvin;          /* 273.4    :125 */
+    float emissivity;              /* 0.93     :125 */
+    float celsius_offset;          /* 273.15   :125 */
+    float heat_capacity_land;      /* 1.5e7    :131-132  atmosphere + atmosphere*0.5, atmosphere = 1e7 */
+    float heat_capacity_ocean;     /* 7e7      :131-132  atmosphere + 4*1.5*atmosphere */
+    float eccentricity;            /* 0.017    :59 */
+    float obliquity_deg;           /* 23.44    :60 (gamma) */
+    float perihelion_deg;          /* 77.05    :62 (omega2) */
+    float solar_constant;          /* 1365     :65 (S0) */
+    float initial_temperature;     /* 0        Temperature::Temperature clears the layer (:26-44): the field a handle starts from when it is
+                                               created with T == NULL */
+    int quirks;                    /* DMG_CLIMATE_QUIRK_* bit set; default = reference behaviour */
+} dmg_climate_params;
+/* h0 (:85-89) takes acos(-tan(phi)*tan(delta)) whenever |phi| <= pi/2 - |delta|; on the row where the two sides are within an ulp
+ * the product rounds to 1 + 2^-23, GLSL's acos is undefined there and llvmpipe returns NaN: once or twice a year a whole row of the
+ * field turns NaN and stays NaN (the Laplacian's isnan guard keeps it from spreading; its neighbours lose their diffusion term
+ * instead).  Set: the same (default).  Cleared: the argument is clamped to [-1, 1] first and the field stays finite. */
+#define DMG_CLIMATE_QUIRK_ACOS_NAN 1
+void dmg_climate_params_default(dmg_climate_params *p);
+/* Temperature::run inner pass (src/filter/Temperature.cpp:140-150) n_steps times from step index first_step;
+ * params NULL = the reference's values */
 int dmg_temperature_steps(dmg_ctx *ctx, const dmg_grid *grid, float *T_inout, const float *terrain,
-                          int first_step, int n_steps);
+                          const dmg_climate_params *params, int first_step, int n_steps);
 /* The same with the field resident on the device between calls: Temperature::run (:47-162) steps the field ten times
  * per UI frame (:140) for as long as the tool runs, so a frame costs its kernels, not two PCIe crossings.
  * T and terrain are copied at creation. */
 typedef struct dmg_climate dmg_climate;
 int dmg_climate_create(dmg_ctx *ctx, const dmg_grid *grid, const float *T, const float *terrain, dmg_climate **out);
 void dmg_climate_destroy(dmg_climate *k);
+/* New values for the steps that follow (a handle starts with the reference's).  The divisors among them get their exact
+ * two-operation pairs here (one short device check per new constant); DMG_EINVAL for values the scheme cannot use (steps_per_year
+ * < 1, a heat capacity or olr_ref_kelvin that is not a positive finite number).  T == NULL at creation is allowed since this
+ * exists: the field then starts at the default initial_temperature (0), or at the one set here before the first step. */
+int dmg_climate_set_params(dmg_climate *k, const dmg_climate_params *params);
 int dmg_climate_steps(dmg_climate *k, int first_step, int n_steps);   /* asynchronous on the context's stream */
 int dmg_climate_get(dmg_climate *k, float *T_out);                    /* synchronises */
 /* The same field as one latitude band of a multi-GPU run (the laplacian reads 1 row): rows of band
@@ -510,6 +548,7 @@ typedef struct {
     int erosion_N;                                           /* cpufilter's N = 50 (:42) */
     float exponent, slope_exponent, factor;                  /* the erosion menu's 0.5, 1, 1 (cpufilter.h:18-21) */
     int lakes;
+    dmg_climate_params climate;                              /* the climate stage's literals (defaults: the reference's) */
 } dmg_world_params;
 void dmg_world_params_default(dmg_world_params *p);
 int dmg_world_create(dmg_ctx *ctx, const dmg_grid *grid, const float *terrain, const float *T0, dmg_world **out);

@@ -786,13 +786,26 @@ void orc_blur(const orc_grid *g, float *field, float *scratch, float radius)
 /* ====================================================================== */
 /* Climate (src/filter/Temperature.cpp:56-134)                             */
 /* ====================================================================== */
-/* returns ASR = (1-0.30)*QDay(phi,M) in the association Mesa gives it; parts[5] is QDay itself */
-static float qday_parts(float phi, float M, float *parts)
+/* Every literal of Temperature.cpp as a field (include/demiurge_hip.h dmg_climate_params has the same list, with the
+ * lines); orc_climate_params_default() = the reference.  The arithmetic keeps the shader's form whatever the values, so a
+ * parity test can move them (a stable year on a fine grid needs other values than the reference's). */
+void orc_climate_params_default(orc_climate_params *p)
 {
-    const float eccentricity = 0.017f;
-    const float gamma = 23.44f / 180.0f * MPI;
-    const float omega = 0.0f, omega2 = 77.05f / 180.0f * MPI;
-    const float S0 = 1365.0f;
+    p->steps_per_year = 15000; p->year_seconds = 3.154f * 1e7f; p->diffusivity = 0.55f * 1e6f; p->albedo = 0.30f;
+    p->olr_coeff = 210.0f; p->olr_ref_kelvin = 273.4f; p->emissivity = 0.93f; p->celsius_offset = 273.15f;
+    p->heat_capacity_land = 1e7f + 1e7f * 0.5f; p->heat_capacity_ocean = 1e7f + 4.0f * 1.5f * 1e7f;
+    p->eccentricity = 0.017f; p->obliquity_deg = 23.44f; p->perihelion_deg = 77.05f; p->solar_constant = 1365.0f;
+    p->initial_temperature = 0.0f;
+    p->quirks = 1;
+}
+
+/* returns ASR = (1-0.30)*QDay(phi,M) in the association Mesa gives it; parts[5] is QDay itself */
+static float qday_parts_p(const orc_climate_params *cp, float phi, float M, float *parts)
+{
+    const float eccentricity = cp->eccentricity;
+    const float gamma = cp->obliquity_deg / 180.0f * MPI;
+    const float omega = 0.0f, omega2 = cp->perihelion_deg / 180.0f * MPI;
+    const float S0 = cp->solar_constant;
     /* A(M) :73-75 */
     float e3 = eccentricity * eccentricity * eccentricity;   /* pow(e,3) */
     float A = M + (2.0f * eccentricity - e3 / 4.0f * gsin(M) + 5.0f / 4.0f * (eccentricity * eccentricity) * gsin(2.0f * M)
@@ -801,32 +814,41 @@ static float qday_parts(float phi, float M, float *parts)
     float delt = gasin(sinf(gamma) * gsin(Ls));          /* sin(gamma) is a constant expression: folded on the host */
     /* h0 :85-89 */
     float h = glsl_sign(phi) == glsl_sign(delt) ? MPI : 0.0f;
-    if (fabsf(phi) <= MPI / 2.0f - fabsf(delt)) h = gacos(-gtan(phi) * gtan(delt));
+    if (fabsf(phi) <= MPI / 2.0f - fabsf(delt)) {
+        float arg = -gtan(phi) * gtan(delt);
+        if (!(cp->quirks & 1)) arg = fminf(fmaxf(arg, -1.0f), 1.0f);
+        h = gacos(arg);
+    }
     float S = S0 * (1.0f + 2.0f * eccentricity * gcos(A - omega));
     float X = h * gsin(phi) * gsin(delt) + gcos(phi) * gcos(delt) * gsin(h);
     float Q = S / MPI * X;
-    if (parts) { parts[0] = A; parts[1] = delt; parts[2] = h; parts[3] = S; parts[4] = X; parts[5] = Q; parts[6] = ((S / MPI) * (1.0f - 0.30f)) * X; }
+    if (parts) { parts[0] = A; parts[1] = delt; parts[2] = h; parts[3] = S; parts[4] = X; parts[5] = Q; parts[6] = ((S / MPI) * (1.0f - cp->albedo)) * X; }
     /* :122 (1-alpha)*QDay: Mesa moves the constant next to the division, ((S/pi)*0.7)*X (tools/climate_probe.py) */
-    return ((S / MPI) * (1.0f - 0.30f)) * X;
+    return ((S / MPI) * (1.0f - cp->albedo)) * X;
 }
-static float asr_row(float phi, float M) { return qday_parts(phi, M, 0); }
 /* debugging aid for probe shaders (tools/climate_probe.py): the intermediates of QDay for one latitude and M */
-void orc_qday_parts(float phi, float M, float *parts7) { qday_parts(phi, M, parts7); }
+void orc_qday_parts(float phi, float M, float *parts7)
+{
+    orc_climate_params cp;
+    orc_climate_params_default(&cp);
+    qday_parts_p(&cp, phi, M, parts7);
+}
 
-void orc_temperature(const orc_grid *g, float *T, float *scratch, const float *terrain, int first_step, int n_steps)
+void orc_temperature_p(const orc_grid *g, float *T, float *scratch, const float *terrain, const orc_climate_params *cp, int first_step, int n_steps)
 {
     const int W = g->W, H = g->H;
     const float rx = (float)W, ry = (float)H;
     float *a = T, *b = scratch;
-    const float ref_t4 = powf(273.4f, 4.0f);       /* pow(273.4,4): a constant expression, folded by Mesa with libm */
+    const float ref_t4 = powf(cp->olr_ref_kelvin, 4.0f);       /* pow(273.4,4): a constant expression, folded by Mesa with libm */
+    const float steps_f = (float)cp->steps_per_year;
     for (int i = first_step; i < first_step + n_steps; i++) {
-        float M = (float)(M_PI * 2 / 15000 * i);          /* :146 glUniform1f(id, M_PI*2/15000*i) */
+        float M = (float)(M_PI * 2 / cp->steps_per_year * i);          /* :146 glUniform1f(id, M_PI*2/15000*i) */
 #pragma omp parallel for schedule(static) num_threads(nthreads_rows(H, 0))
         for (int y = 0; y < H; y++) {
             float sy = sty(g, y);
             float lon, phi;
             orc_tex_to_spheric(g, 0.0f, sy, &lon, &phi);
-            float ASR = asr_row(phi, M);                    /* :102,:122 (1-0.30)*QDay(phi,M) */
+            float ASR = qday_parts_p(cp, phi, M, 0);        /* :102,:122 (1-0.30)*QDay(phi,M) */
             float factor = gcos(phi);                      /* get_texture_laplacian, Shader.h:301-302 */
             float dx, dy;
             orc_pixelsize(g, sy, &dx, &dy);
@@ -836,7 +858,7 @@ void orc_temperature(const orc_grid *g, float *T, float *scratch, const float *t
                 if (g_raster_st) {                       /* per fragment, as the shader has it */
                     st_raster(g, x, y, &sx, &sy);
                     orc_tex_to_spheric(g, 0.0f, sy, &lon, &phi);
-                    ASR = asr_row(phi, M);
+                    ASR = qday_parts_p(cp, phi, M, 0);
                     factor = gcos(phi);
                     orc_pixelsize(g, sy, &dx, &dy);
                     den = 4.0f * (dy * dy);
@@ -858,18 +880,25 @@ void orc_temperature(const orc_grid *g, float *T, float *scratch, const float *t
                 float delta_y = (A_ + 2 * B_ + C_ - 2 * D_ - 4 * E_ - 2 * F_ + G_ + 2 * H_ + I_) / den;
                 if (isnan(delta_x)) delta_x = 0;
                 if (isnan(delta_y)) delta_y = 0;
-                float t = Tc + 273.15f;
+                float t = Tc + cp->celsius_offset;
                 float t2 = t * t;                                             /* pow(x,4) -> (x*x)*(x*x) */
-                float OLR = t2 * (t2 * 210.0f) / ref_t4 * 0.93f;               /* :125, in Mesa's association (tools/climate_probe.py) */
-                float change = ASR - OLR + 0.55f * 1e6f * (delta_x + delta_y);   /* :128 */
-                float atmosphere = 1e7f;
-                float C = atmosphere + (terr > 0 ? atmosphere * 0.5f : 4.0f * 1.5f * atmosphere);
-                b[(size_t)y * W + x] = Tc + change * (3.154f * 1e7f) / 15000.0f / C;   /* :133, the two constant factors merged */
+                float OLR = t2 * (t2 * cp->olr_coeff) / ref_t4 * cp->emissivity;   /* :125, in Mesa's association (tools/climate_probe.py) */
+                float change = ASR - OLR + cp->diffusivity * (delta_x + delta_y);   /* :128 */
+                /* C = atmosphere + (terrain>0 ? atmosphere*0.5 : 4*1.5*atmosphere), atmosphere = 1e7 (:131-132) */
+                float C = terr > 0 ? cp->heat_capacity_land : cp->heat_capacity_ocean;
+                b[(size_t)y * W + x] = Tc + change * cp->year_seconds / steps_f / C;   /* :133, the two constant factors merged */
             }
         }
         float *t = a; a = b; b = t;
     }
     if (a != T) memcpy(T, a, sizeof(float) * (size_t)W * H);
+}
+
+void orc_temperature(const orc_grid *g, float *T, float *scratch, const float *terrain, int first_step, int n_steps)
+{
+    orc_climate_params cp;
+    orc_climate_params_default(&cp);
+    orc_temperature_p(g, T, scratch, terrain, &cp, first_step, n_steps);
 }
 
 /* ====================================================================== */

@@ -53,6 +53,8 @@ def lib():
         L.orc_blur13_pass.argtypes = [G, P, ctypes.c_float, ctypes.c_float, P]
         L.orc_blur.argtypes = [G, P, P, ctypes.c_float]
         L.orc_temperature.argtypes = [G, P, P, P, ctypes.c_int, ctypes.c_int]
+        L.orc_temperature_p.argtypes = [G, P, P, P, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        L.orc_climate_params_default.argtypes = [ctypes.c_void_p]
         L.orc_erosion_pass.argtypes = [G, P, P, P, ctypes.c_float, ctypes.c_float, P]
         L.orc_thermal_erosion.argtypes = [G, P, P, P]
         L.orc_morph_rlist.argtypes = [ctypes.c_float, P, ctypes.c_int]
@@ -178,10 +180,31 @@ def blur(g, field, radius):
     return f
 
 
-def temperature(g, T, terrain, first_step, n_steps):
+class ClimateParams(ctypes.Structure):
+    """orc_climate_params (= the layout of the product's dmg_climate_params)"""
+    _fields_ = [("steps_per_year", ctypes.c_int)] + [(n, ctypes.c_float) for n in (
+        "year_seconds", "diffusivity", "albedo", "olr_coeff", "olr_ref_kelvin", "emissivity", "celsius_offset", "heat_capacity_land",
+        "heat_capacity_ocean", "eccentricity", "obliquity_deg", "perihelion_deg", "solar_constant", "initial_temperature")] + [("quirks", ctypes.c_int)]
+
+
+def climate_params(**kw):
+    p = ClimateParams()
+    lib().orc_climate_params_default(ctypes.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+def temperature(g, T, terrain, first_step, n_steps, params=None):
     T, terrain = _f32(T).copy(), _f32(terrain)
     s = np.empty_like(T)
-    lib().orc_temperature(ctypes.byref(g), _ptr(T), _ptr(s), _ptr(terrain), first_step, n_steps)
+    if params is None:
+        lib().orc_temperature(ctypes.byref(g), _ptr(T), _ptr(s), _ptr(terrain), first_step, n_steps)
+    else:
+        cp = climate_params(**{n: getattr(params, n) for n, _ in ClimateParams._fields_})      # (a product-side struct is accepted: same fields)
+        lib().orc_temperature_p(ctypes.byref(g), _ptr(T), _ptr(s), _ptr(terrain), ctypes.byref(cp), first_step, n_steps)
     return T
 
 

@@ -24,10 +24,19 @@ FILES = {
     # cpufilter.cpp:42  `int N = 50;` is spliced into the GLSL via std::to_string(N) (:52,:72)
     "src/filter/cpufilter.cpp": "int N = 50;",
     "src/filter/FlowFilter.cpp": "",
-    # ThermalErosion.cpp:30 includes p->canvas->projection_shader(): display-projection helper functions that the
-    # erosion shader never calls; an empty Shader stands in for that include (the canvas classes need imgui/glm)
-    "src/filter/ThermalErosion.cpp": "struct _Cv { Shader* projection_shader() { return Shader::builder().create(\"\",\"\"); } }; "
-                                     "struct _Pj { _Cv* canvas; }; static _Cv _cv; static _Pj _pj{&_cv}; _Pj* p = &_pj;",
+    # ThermalErosion.cpp:30 includes p->canvas->projection_shader(): the display-projection helpers of the project's canvas
+    # (AbstractCanvas::projection_shader, src/projections/Canvas.cpp:188-277, with the canvas's inverseShader() -- the project's
+    # canvas is an Equiretangular, src/Project.cpp:109,185; src/projections/Equiretangular.cpp:16-23).  The canvas CLASSES need
+    # imgui/glm; their two shader expressions are lifted as text like every other one and handed out by a two-method struct
+    # that stands where `p->canvas` stands (thermal_prelude below).
+    "src/filter/ThermalErosion.cpp": ("thermal",),
+    # ... and the two variants that show what that include does to the tool (tests/test_golden_provenance.py):
+    #   #noproj  an empty shader in the include's place: the erosion passes by themselves -- the committed goldens
+    #   #inita   the real include with its one uninitialised variable given the value a zero-initialising driver gives it
+    #            (`bool a;` read by `if(a) discard;`, Canvas.cpp:271-273): equals #noproj
+    "src/filter/ThermalErosion.cpp#noproj": "struct _Cv { Shader* projection_shader() { return Shader::builder().create(\"\",\"\"); } }; "
+                                            "struct _Pj { _Cv* canvas; }; static _Cv _cv; static _Pj _pj{&_cv}; _Pj* p = &_pj;",
+    "src/filter/ThermalErosion.cpp#inita": ("thermal", "inita"),
     # Morphological.cpp:57 splices the GLSL builtin name: "min" (Erode) or "max" (Dilate) (:25)
     "src/filter/Morphological.cpp#min": "std::string operation = \"min\";",
     "src/filter/Morphological.cpp#max": "std::string operation = \"max\";",
@@ -52,6 +61,41 @@ def gradient_noise_prelude(ref, mode, blend):
     fsrc = (ref / "src/filter/Filter.cpp").read_text()
     bl = {name: expr for _, name, expr in extract(fsrc)}[blend]
     return "std::string code = %s; Shader* blendmode = %s;" % (code, bl)
+
+
+def extract_returned(src, signature):
+    """the `Shader::builder()...` expression a function of the reference returns: `signature` is the text of its head up to the
+    opening parenthesis, e.g. "AbstractCanvas::projection_shader("; raw strings and comments are skipped over like in extract()"""
+    at = src.index(signature)
+    spans = scan(src)
+    skip = [False] * (len(src) + 1)
+    for _, a, b in spans:
+        for k in range(a, b):
+            skip[k] = True
+    m = re.compile(r"return\s+(Shader::builder\(\))").search(src, at)
+    a = m.start(1)
+    depth, j = 0, m.end(1)
+    while True:
+        if not skip[j]:
+            ch = src[j]
+            if ch == "(":
+                depth += 1
+            elif ch == ")":
+                depth -= 1
+            elif ch == ";" and depth == 0:
+                break
+        j += 1
+    return src[a:j]
+
+
+def thermal_prelude(ref, init_a=False):
+    proj = extract_returned((ref / "src/projections/Canvas.cpp").read_text(), "AbstractCanvas::projection_shader(")
+    if init_a:
+        assert proj.count("bool a;") == 1
+        proj = proj.replace("bool a;", "bool a = false;")
+    inv = extract_returned((ref / "src/projections/Equiretangular.cpp").read_text(), "Equiretangular::inverseShader(")
+    return ("struct _Cv { Shader* inverseShader() { return %s; } Shader* projection_shader() { return %s; } }; "
+            "struct _Pj { _Cv* canvas; }; static _Cv _cv; static _Pj _pj{&_cv}; _Pj* p = &_pj;" % (inv, proj))
 
 
 def scan(src):
@@ -140,7 +184,7 @@ def main():
         if not p.exists():
             continue
         if isinstance(prelude, tuple):
-            prelude = gradient_noise_prelude(ref, prelude[1], prelude[2])
+            prelude = thermal_prelude(ref, len(prelude) > 1) if prelude[0] == "thermal" else gradient_noise_prelude(ref, prelude[1], prelude[2])
         src = p.read_text()
         items = extract(src)
         tag = re.sub(r"\W", "_", p.name + ("_" + variant if variant else ""))

@@ -393,16 +393,21 @@ def lake_adjacency(lake_id_bits, coords=FULL_GLOBE, circ=42000.0):
     return out
 
 
-def thermal_erosion(img, coords=FULL_GLOBE, circ=42000.0):
+def thermal_erosion(img, coords=FULL_GLOBE, circ=42000.0, include="#noproj"):
     """ThermalErosion::step (ThermalErosion.cpp:25-142): 10 x { talus loss -> scratch1 ; gain pass -> scratch2 ;
-    scratch2.swap(terrain) }.  All textures NEAREST."""
+    scratch2.swap(terrain) }.  All textures NEAREST.
+    include: what stands at `.include(p->canvas->projection_shader())` (:30) -- "" the canvas's real shader text (Canvas.cpp:188-277
+    + Equiretangular.cpp:16-23), "#inita" the same with its uninitialised `bool a` set false, "#noproj" (default) nothing.  Under
+    llvmpipe the real text discards EVERY fragment: `bool a; projection(st, a); if(a) discard;` reads a variable nothing has
+    written (and filter programs never get the view uniforms, Project.cpp:456-461), so the tool would do nothing; "#inita" and
+    "#noproj" agree bit for bit, and are what the committed goldens hold."""
     g = RefGL.get()
     g.set_canvas(coords, circ)
     H, W = img.shape
     t_img = g.tex(W, H, 1, False, img)
     t_s1 = g.tex(W, H, 1, False)
     t_s2 = g.tex(W, H, 1, False)
-    p1, p2 = g.program("ThermalErosion.cpp:27"), g.program("ThermalErosion.cpp:84")
+    p1, p2 = g.program("ThermalErosion.cpp:27" + include), g.program("ThermalErosion.cpp:84" + include)
     for _ in range(10):
         g.apply(p1, t_s1, {"img": t_img})
         g.apply(p2, t_s2, {"img": t_img, "scratch1": t_s1})

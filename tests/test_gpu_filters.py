@@ -114,6 +114,123 @@ def test_climate_handle_equals_one_shot(dev):
     assert np.array_equal(got, ctx.temperature_steps(g, G["T0"], G["terrain"], 7000, 5))
 
 
+def _extreme_field(W, H, seed):
+    """a climate field that makes waves of the packed kernel take BOTH paths: ordinary temperatures, and patches of values whose
+    Laplacian numerators leave the window in which division through the constant is exact -- tiny (2^-90 .. 2^-70), denormal,
+    huge (2^70 .. 2^120), infinite, NaN, exactly zero, and -273.15 (OLR numerator zero)"""
+    rng = np.random.default_rng(seed)
+    T = (rng.standard_normal((H, W)) * 20).astype(np.float32)
+    yy, xx = np.mgrid[0:H, 0:W]
+    kinds = [lambda n: (2.0 ** rng.uniform(-90, -70, n) * rng.choice([-1, 1], n)), lambda n: np.full(n, 1e-42), lambda n: 2.0 ** rng.uniform(70, 120, n),
+             lambda n: np.full(n, np.inf), lambda n: np.full(n, np.nan), lambda n: np.zeros(n), lambda n: np.full(n, -273.15), lambda n: np.full(n, -np.inf)]
+    for i, kind in enumerate(kinds):
+        cy, cx = int(rng.integers(4, H - 4)), int(rng.integers(0, W))
+        m = (np.abs(yy - cy) <= 2) & (np.abs((xx - cx + W // 2) % W - W // 2) <= 5 + i)
+        T[m] = kind(int(m.sum())).astype(np.float32)
+    T[H // 2 - 3:H // 2 + 3, :] = 1.5                        # a band that is smooth along the rows: nx == 0 exactly (the fast path's zero)
+    return T
+
+
+@pytest.mark.parametrize("W,H,seed", [(512, 96, 1), (1024, 64, 2), (260, 48, 3)])
+def test_temperature_window_edges_take_either_path_to_the_same_bits(dev, oracle, W, H, seed):
+    """k_temperature_v5 asks once per wave whether every division of its 256 cells may go through the constant; waves that hold
+    a value outside the window recompute their cells with the IEEE sequences.  Fields with such patches, against the oracle's
+    plain divisions, NaNs and all (W = 260: the one-cell-per-thread kernel's rows of a width that is no multiple of 4 ... 260 is:
+    its seam threads then)"""
+    capi, ctx = dev
+    T = _extreme_field(W, H, seed)
+    terr = (np.random.default_rng(seed + 10).standard_normal((H, W)) > 0.3).astype(np.float32) - 0.5
+    g, og = capi.make_grid(W, H), oracle.grid(W, H)
+    with np.errstate(all="ignore"):
+        for first, n in ((0, 1), (5000, 3)):
+            got = ctx.temperature_steps(g, T, terr, first, n)
+            want = oracle.temperature(og, T, terr, first, n)
+            # (bit for bit where the value is a number; a NaN is a NaN -- x86 and the GPU give the default NaN different signs)
+            num = ~np.isnan(want)
+            assert np.array_equal(np.isnan(got), ~num) and np.array_equal(got.view(np.uint32)[num], want.view(np.uint32)[num]), \
+                (first, n, int((got.view(np.uint32)[num] != want.view(np.uint32)[num]).sum()), int((np.isnan(got) != ~num).sum()))
+            assert np.isnan(want).any() and np.isinf(want).any()
+
+
+@pytest.mark.parametrize("kw", [
+    dict(steps_per_year=730, diffusivity=1.0e4),                                        # a stable coarse year
+    dict(steps_per_year=1500000, year_seconds=3.0e7, albedo=0.25, olr_coeff=200.0, olr_ref_kelvin=280.0, emissivity=0.9),
+    dict(heat_capacity_land=2.0e7, heat_capacity_ocean=8.0e7, celsius_offset=273.0, eccentricity=0.05, obliquity_deg=10.0, perihelion_deg=120.0,
+         solar_constant=1400.0),
+    dict(steps_per_year=4096, heat_capacity_land=float(2 ** 24), heat_capacity_ocean=1.0e7 / 3),    # a power-of-two divisor (l == 0), an awkward one
+])
+def test_temperature_params_follow_the_oracle(dev, oracle, kw):
+    """dmg_climate_params: every literal of Temperature.cpp moved, the arithmetic's form kept -- against the oracle's restatement
+    with the same values (the defaults are pinned by the llvmpipe goldens above)"""
+    capi, ctx = dev
+    G = load_golden("temperature_128x64_rough")
+    g, og = grids(capi, oracle, G, G["T0"].shape)
+    prm = capi.climate_params(**kw)
+    out = ctx.temperature_steps(g, G["T0"], G["terrain"], 100, 12, params=prm)
+    want = oracle.temperature(og, G["T0"], G["terrain"], 100, 12, params=prm)
+    assert np.array_equal(out.view(np.uint32), want.view(np.uint32)), int((out != want).sum())
+    assert not np.array_equal(out, ctx.temperature_steps(g, G["T0"], G["terrain"], 100, 12))     # (the values did change something)
+    # the same through a resident handle whose parameters change between two step calls
+    k = capi.Climate(ctx, g, G["T0"], G["terrain"])
+    k.steps(100, 5)
+    k.set_params(prm)
+    k.steps(105, 7)
+    mixed = k.get()
+    k.close()
+    half = oracle.temperature(og, G["T0"], G["terrain"], 100, 5)
+    assert np.array_equal(mixed, oracle.temperature(og, half, G["terrain"], 105, 7, params=prm))
+
+
+def test_climate_acos_quirk(dev, oracle):
+    """h0's acos(-tan(phi)*tan(delta)) (Temperature.cpp:85-89) meets an argument of 1 + 2^-23 on the row where |phi| is within an
+    ulp of pi/2 - |delta|: NaN under llvmpipe, and a row of the field is NaN from then on -- at 2048x1024 row 122 between steps 320
+    and 328.  Reproduced by default (the oracle has the same NaNs); with DMG_CLIMATE_QUIRK_ACOS_NAN cleared the argument is
+    clamped and the field stays finite."""
+    from demiurge_amd import synth
+    capi, ctx = dev
+    W, H = 2048, 1024
+    g, og = capi.make_grid(W, H), oracle.grid(W, H)
+    terrain = (synth.terrain(W, H) * 100).astype(np.float32)
+    T0 = (15 - 40 * np.abs(np.linspace(-1, 1, H, dtype=np.float32))[:, None] + np.zeros((1, W), np.float32)).astype(np.float32)
+    stable = dict(diffusivity=0.55e4)
+    quirky = ctx.temperature_steps(g, T0, terrain, 318, 12, params=capi.climate_params(**stable))
+    rows = np.unique(np.argwhere(np.isnan(quirky))[:, 0])
+    assert len(rows) >= 1 and np.isnan(quirky[rows]).all()
+    want = oracle.temperature(og, T0, terrain, 318, 12, params=capi.climate_params(**stable))
+    assert np.array_equal(quirky, want, equal_nan=True)
+    clean_prm = capi.climate_params(quirks=0, **stable)
+    clean = ctx.temperature_steps(g, T0, terrain, 318, 12, params=clean_prm)
+    assert np.isfinite(clean).all() and np.array_equal(clean, oracle.temperature(og, T0, terrain, 318, 12, params=clean_prm))
+    # (rows next to a NaN row lose their Laplacian to the isnan guard -- a step further out per step: beyond that reach nothing changes)
+    far = np.ones(H, bool)
+    for r in rows:
+        far[max(0, r - 13):r + 14] = False
+    assert far.sum() > H - 200 and np.array_equal(clean[far], quirky[far])
+
+
+def test_climate_without_a_field_starts_from_the_initial_temperature(dev, oracle):
+    """Temperature::Temperature clears the layer (Temperature.cpp:26-44): a handle created with T == NULL starts at
+    params.initial_temperature; bad parameter values are refused"""
+    capi, ctx = dev
+    G = load_golden("temperature_128x64_full")
+    g, og = grids(capi, oracle, G, G["T0"].shape)
+    k = capi.Climate(ctx, g, None, G["terrain"])
+    k.steps(0, 4)
+    assert np.array_equal(k.get(), oracle.temperature(og, np.zeros_like(G["T0"]), G["terrain"], 0, 4))
+    k.close()
+    prm = capi.climate_params(initial_temperature=12.5, steps_per_year=20000)
+    k = capi.Climate(ctx, g, None, G["terrain"], params=prm)
+    k.steps(0, 4)
+    assert np.array_equal(k.get(), oracle.temperature(og, np.full_like(G["T0"], 12.5), G["terrain"], 0, 4, params=prm))
+    for bad in (dict(steps_per_year=0), dict(heat_capacity_land=0.0), dict(heat_capacity_ocean=float("nan")), dict(olr_ref_kelvin=-1.0),
+                dict(diffusivity=float("inf"))):
+        with pytest.raises(capi.DmgError):
+            k.set_params(capi.climate_params(**bad))
+    k.steps(4, 1)                                            # a refused set_params leaves the handle as it was
+    assert np.array_equal(k.get(), oracle.temperature(og, np.full_like(G["T0"], 12.5), G["terrain"], 0, 5, params=prm))
+    k.close()
+
+
 def test_temperature_tap_table(oracle, tmp_path):
     """the per-row tap displacements (verified against the literal offset() arithmetic at set-up, rows that disagree
     stay literal) give the fields of the all-literal path and of the oracle: the reference's own 1000x500 size,

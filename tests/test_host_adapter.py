@@ -37,6 +37,32 @@ def test_adapter_reports_missing_device(tmp_path):
     assert r.returncode == 1 and "no HIP device" in r.stderr
 
 
+def test_async_filter_cancel_semantics(tmp_path):
+    """Filter.h's cooperative cancel (the reference's Cancel leaves the worker running, Filter.cpp:105-108) on the CPU: g++ builds
+    tests/host_cancel_check.cpp against the mirror header alone"""
+    exe = tmp_path / "cancel_check"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-pthread", "-I", str(HOST), str(ROOT / "tests" / "host_cancel_check.cpp"), "-o", str(exe)])
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "ok" in r.stdout and "destroyed while parked" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_adapter_cancel_ends_the_solve_at_the_next_outer_step(tmp_path):
+    """HipOceanCurrents asked for the reference's 10000 outer steps (OceanCurrents.cpp:155) and cancelled once the first has been
+    shown: it finishes a step or two later; one destroyed in mid-run joins at once"""
+    import re
+    from demiurge_amd import synth
+    build()
+    W, H = 512, 256
+    t = tmp_path / "t.f32"
+    synth.terrain(W, H).tofile(t)
+    r = subprocess.run([str(HOST / "host_demo"), "cancel", str(W), str(H), str(t)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    m = re.search(r"cancelled at outer step (\d+) of 10000 .* finished at outer step (\d+)", r.stdout)
+    assert m and 1 <= int(m.group(1)) <= int(m.group(2)) <= int(m.group(1)) + 3, r.stdout
+    assert "destroyed in mid-run" in r.stdout
+
+
 @pytest.mark.gpu
 def test_adapter_matches_golden_and_oracle(oracle, tmp_path):
     """drive HipOceanCurrents like the editor (one step() per frame) and compare scratch1/scratch2 = v.x/v.y"""

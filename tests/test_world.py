@@ -131,3 +131,40 @@ def test_config5_at_size(dev):
     assert (a["eroded"][land] <= a["terrain"][land] / np.float32(50) + 3 * np.tan(np.pi / 6) * np.hypot(42000 / W, 21000 / H) + 1e-3).all()
     assert not np.array_equal(a["T"], T0)                        # the climate moved ...
     assert np.abs(a["T"] - T0).max() < 50                        # ... by a few steps' worth, nowhere near blowing up
+
+
+def test_config5_a_whole_stable_year_in_eight_bands(dev):
+    """BASELINE config 5's "year-cycle climate" at its own size.  With the reference's literals the explicit
+    scheme cannot run a year at 16384x8192 (diffusion number 11.8 over land where the limit is 1/4: fp32 overflows within 40
+    steps); dmg_climate_params makes them fields, and with a diffusivity a hundredth of the reference's the same 15000 steps are
+    a stable year (and DMG_CLIMATE_QUIRK_ACOS_NAN cleared: with it the reference turns a row of the field into NaNs once or twice
+    a year, identically here): through dmg_multi_world in 8 latitude bands (store transport, ghost 8: 1875 halo exchanges per band) and
+    through the one-GPU dmg_world -- bit-identical, finite, and a climate (warm equator, cold poles, the seasons' asymmetry gone
+    after a whole orbit)"""
+    capi, ctx = dev
+    W, H = 16384, 8192
+    grid = capi.make_grid(W, H)
+    terrain, T0 = inputs(W, H)
+    p = capi.World.default_params()
+    p.tectonics_steps, p.erosion_rounds, p.climate_steps = 0, 0, 15000          # Temperature.cpp:146: one orbit = 15000 steps
+    p.climate.diffusivity = 0.55e4
+    p.climate.quirks &= ~capi.CLIMATE_QUIRK_ACOS_NAN
+    assert p.climate.steps_per_year == 15000
+    w = capi.World(ctx, grid, terrain, T0)
+    w.step(p)
+    a = w.get()["T"]
+    w.close()
+    ctx.trim()
+    m = capi.MultiWorld(grid, terrain, T0, devices=[0] * 8, ghost=8, flags=capi.MULTI_STORE)
+    m.step(p)
+    b = m.get()["T"]
+    m.close()
+    assert np.array_equal(a, b)
+    assert np.isfinite(a).all() and -120 < a.min() and a.max() < 60
+    zonal = a.mean(axis=1)
+    assert zonal[H // 2 - 200:H // 2 + 200].mean() > zonal[:400].mean() + 20 and zonal[H // 2 - 200:H // 2 + 200].mean() > zonal[-400:].mean() + 20
+    # the same year with the reference's own values does not survive (what the parameter struct is for)
+    k = capi.Climate(ctx, grid, T0, terrain)
+    k.steps(0, 60)
+    assert not np.isfinite(k.get()).all()
+    k.close()
