@@ -20,6 +20,7 @@ F_PRESSURE, F_DIVW, F_TERRAIN, F_V = range(4)
 SIDE_SOUTH, SIDE_NORTH = 0, 1
 QUIRK_DIFFUSION_SCALAR_RHS = 1
 QUIRK_LLVMPIPE_RASTER = 2
+QUIRK_EXACT_LLVMPIPE = 4
 PRIVATE_STREAM = 1
 JACOBI_AUTO, JACOBI_SINGLE, JACOBI_BLOCKED = 0, 1, 2
 FULL_GLOBE = (np.float32(-np.pi / 2), np.float32(np.pi / 2), np.float32(-np.pi), np.float32(np.pi))  # Project.h:97
@@ -130,6 +131,7 @@ def lib():
         "dmg_version": (c_int, []),
         "dmg_last_error": (ctypes.c_char_p, []),
         "dmg_runtime_init": (c_int, []),
+        "dmg_debug_set": (c_int, [ctypes.c_char_p, ctypes.c_char_p]),
         "dmg_create": (c_int, [c_int, vp, c_int, ctypes.POINTER(vp)]),
         "dmg_destroy": (None, [vp]),
         "dmg_sync": (c_int, [vp]),
@@ -273,8 +275,23 @@ def lib():
         fn = getattr(L, name)          # AttributeError if the library does not export a declared symbol
         fn.restype, fn.argtypes = res, args
     L._dmg_signatures = sig
+    # The library itself reads two environment variables (DMG_MULTI_TIMEOUT_MS, DMG_ST_TWIN: demiurge_hip.h).  Its test hooks and
+    # experiment knobs come in through dmg_debug_set: THIS binding -- the harness of the tests, the bench and the tools, not the
+    # product -- hands over the DMG_* variables of its own environment, once, before any handle exists.
+    for k, v in os.environ.items():
+        if k.startswith("DMG_") and k not in HARNESS_ENV:
+            L.dmg_debug_set(k.encode(), v.encode())
     _lib = L
     return L
+
+
+# read by the Python side (this file, bands.py, bench.py), not hooks of the library
+HARNESS_ENV = {"DMG_LIB", "DMG_BENCH_REHEARSAL", "DMG_HALO_OVERLAP", "DMG_HALO_BOUNCE", "DMG_HALO_PIPELINE", "DMG_MULTI_TIMEOUT_MS", "DMG_ST_TWIN"}
+
+
+def debug_set(name, value):
+    """dmg_debug_set: a test hook / experiment knob by name (value None removes it); most are read once, before the first handle"""
+    check(lib().dmg_debug_set(name.encode(), None if value is None else str(value).encode()))
 
 
 def check(rc):

@@ -28,7 +28,32 @@ int dmg_check_grid(const dmg_grid *g, dmg_topology *t)
     return DMG_OK;
 }
 
+// ---- test hooks: a process-wide table that only dmg_debug_set writes ----
+#include <map>
+#include <memory>
+#include <string>
+namespace {
+std::mutex g_hook_mu;
+std::map<std::string, std::unique_ptr<std::string>> g_hooks;     // (values are never freed while the process lives: dmg_hook hands out their c_str)
+std::vector<std::unique_ptr<std::string>> g_hook_graveyard;
+}
+const char *dmg_hook(const char *name)
+{
+    std::lock_guard<std::mutex> lk(g_hook_mu);
+    auto it = g_hooks.find(name);
+    return it == g_hooks.end() ? nullptr : it->second->c_str();
+}
+
 extern "C" {
+int dmg_debug_set(const char *name, const char *value)
+{
+    if (!name || strncmp(name, "DMG_", 4) != 0) return dmg_fail(DMG_EINVAL, "dmg_debug_set: hook names start with DMG_");
+    std::lock_guard<std::mutex> lk(g_hook_mu);
+    auto it = g_hooks.find(name);
+    if (it != g_hooks.end()) { g_hook_graveyard.push_back(std::move(it->second)); g_hooks.erase(it); }
+    if (value) g_hooks[name] = std::make_unique<std::string>(value);
+    return DMG_OK;
+}
 
 int dmg_version(void) { return DMG_VERSION; }
 

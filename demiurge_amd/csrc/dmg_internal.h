@@ -29,6 +29,11 @@ __device__ __forceinline__ bool dmg_div_rc_exact_for(float x)
     return x == 0.0f || (a >= 0x1p-100f && a <= 0x1p100f);
 }
 
+// Test hooks and experiment knobs (failure and delay injection, forced kernel forms, the unit cut's tuning constants, traces):
+// values a test harness has handed over through dmg_debug_set(name, value) -- never the environment.  The library reads two
+// environment variables of its own, both documented in include/demiurge_hip.h: DMG_MULTI_TIMEOUT_MS and DMG_ST_TWIN.
+const char *dmg_hook(const char *name);              // nullptr: not set
+
 // div2.hip: exact two-operation divisors, x / c[i] == fma(x, h[i], x * l[i]); ok[i] = 0 where no such pair exists
 struct dmg_ctx;
 int dmg_div2_splits(dmg_ctx *ctx, const float *c, int n, float *h, float *l, unsigned char *ok);

@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void k_blur13_axis(canvas c, const float *__re
 // one pass of blur13 in direction (dirx, diry): the axis forms where they apply
 static void launch_blur13(hipStream_t st, dim3 g, const canvas &c, const float *src, float *dst, const float *pf, float dirx, float diry)
 {
-    static const bool literal = getenv("DMG_BLUR_LITERAL") != nullptr;       // tests: the general kernel for every pass
+    static const bool literal = dmg_hook("DMG_BLUR_LITERAL") != nullptr;       // tests: the general kernel for every pass
     const dim3 ga((unsigned)((c.W + 256 * BLUR_CPT - 1) / (256 * BLUR_CPT)), g.y);
     if (!literal && diry == 0.0f && dirx > 0.0f) hipLaunchKernelGGL(k_blur13_axis<0>, ga, dim3(256), 0, st, c, src, dst, pf, dirx);
     else if (!literal && dirx == 0.0f && diry > 0.0f) hipLaunchKernelGGL(k_blur13_axis<1>, ga, dim3(256), 0, st, c, src, dst, pf, diry);
@@ -818,8 +818,8 @@ int dmg_climate_set_params(dmg_climate *k, const dmg_climate_params *params)
     tc.win_lo = win_lo;
     { int e; (void)frexpf(win_lo, &e); tc.win_emin = e; }      // v_frexp_exp: 2^(e-1) <= |x| < 2^e  ->  e
     k->tc = tc;
-    k->all_two = tc.two == 7 && std::all_of(dentwo.begin(), dentwo.end(), [](int v) { return v != 0; }) && !getenv("DMG_CLIMATE_NO_PAIRS");
-    if (getenv("DMG_TEMPERATURE_REPORT"))            // experiments
+    k->all_two = tc.two == 7 && std::all_of(dentwo.begin(), dentwo.end(), [](int v) { return v != 0; }) && !dmg_hook("DMG_CLIMATE_NO_PAIRS");
+    if (dmg_hook("DMG_TEMPERATURE_REPORT"))            // experiments
         fprintf(stderr, "dmg_climate_set_params: pairs t4 %d steps %d land %d ocean %d den %d/%d rows, window from 2^%d, all_two %d\n", (int)two(H),
                 (int)two(H + 1), (int)two(H + 2), (int)two(H + 3), (int)std::count(dentwo.begin(), dentwo.end(), 1), H, tc.win_emin - 1, (int)k->all_two);
     // sin(gamma), omega2, 1 - alpha: expressions of constants, folded by Mesa on the host in fp32
@@ -918,7 +918,7 @@ int dmg_climate_steps(dmg_climate *k, int first_step, int n_steps)
     if (n_steps > 0) k->stepped = true;
     if (!k->taps_ready && n_steps > 0) {
         // per-row tap displacements, verified cell by cell against the literal offset() arithmetic (once per field)
-        static const bool literal_only = getenv("DMG_TEMPERATURE_LITERAL") != nullptr;      // experiments: every row literal
+        static const bool literal_only = dmg_hook("DMG_TEMPERATURE_LITERAL") != nullptr;      // experiments: every row literal
         DMG_HIP(hipMemsetAsync(k->dlit.p, literal_only ? 0xFF : 0, (size_t)H * sizeof(int), ctx->stream));
         hipLaunchKernelGGL(k_temperature_taps, g, dim3(256), 0, ctx->stream, c, k->dcos.f(), k->dshift.i(), k->dsrow.i(), k->dlit.i());
         DMG_HIP(hipGetLastError());
@@ -930,7 +930,7 @@ int dmg_climate_steps(dmg_climate *k, int first_step, int n_steps)
             k->n_literal = (int)rows.size();
             k->lit_rows = rows;
             if (k->n_literal) { int rc = upload_vec(ctx, k->dlitrows, rows); if (rc) return rc; }
-            if (getenv("DMG_TEMPERATURE_REPORT"))       // experiments
+            if (dmg_hook("DMG_TEMPERATURE_REPORT"))       // experiments
                 fprintf(stderr, "dmg_climate_steps: %d of %d rows keep the literal offset() path\n", k->n_literal, H);
         }
         k->taps_ready = true;

@@ -706,7 +706,7 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
     const size_t N = (size_t)W * H;
     hipStream_t st = ctx->stream;
     const unsigned nb = (unsigned)((N + 255) / 256);
-    static const bool timing = getenv("DMG_FLOW_TIMING") != nullptr;
+    static const bool timing = dmg_hook("DMG_FLOW_TIMING") != nullptr;
     auto t_prev = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
         if (!timing) return;
@@ -886,7 +886,7 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
     std::vector<int> assigned;                                         // connection events in order: connections[s] = entry
     const bool mouth_filter_on = !(lakes & DMG_FLOW_FIX_MOUTH_FILTER);
     // which growth: one host thread (small graphs: nothing to gain), or the cascades on all cores (k_growth_* above)
-    static const int growth_env = [] { const char *e = getenv("DMG_FLOW_GROWTH"); return !e ? 0 : (!strcmp(e, "serial") ? 1 : (!strcmp(e, "parallel") ? 2 : 0)); }();
+    static const int growth_env = [] { const char *e = dmg_hook("DMG_FLOW_GROWTH"); return !e ? 0 : (!strcmp(e, "serial") ? 1 : (!strcmp(e, "parallel") ? 2 : 0)); }();
     const bool parallel_growth = nuniq > 0 && nmouth > 0 && (growth_env == 2 || (growth_env == 0 && nlakes >= 100000));
     if (parallel_growth) {
         typedef unsigned long long u64;
@@ -1228,7 +1228,7 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
     DMG_HIP(hipGetLastError());
     if (timing) fprintf(stderr, "[flow] %d levels\n", levels);
     lap("upload + depth sort");
-    static const bool by_levels = getenv("DMG_FLOW_LEVELS") != nullptr;      // experiments: the level-synchronous form
+    static const bool by_levels = dmg_hook("DMG_FLOW_LEVELS") != nullptr;      // experiments: the level-synchronous form
     const int n_reached = start[levels];
     if (by_levels) {
         for (int l = levels - 1; l >= 0; l--) {
@@ -1253,7 +1253,7 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
         // that XCD's L2: workgroup-scope loads (sc0) are served by the CU's own L1 and never see another CU's sum, with or
         // without a `buffer_inv sc0` in front; `buffer_inv sc1` works at 50 ms per solve; agent-scope loads of sums stored at
         // workgroup scope work, and take as long as before (4.0 ms on one XCD against 3.2 ms on eight).
-        static const int nblocks_env = [] { const char *e = getenv("DMG_FLOW_NBLOCKS"); return e ? atoi(e) : 0; }();
+        static const int nblocks_env = [] { const char *e = dmg_hook("DMG_FLOW_NBLOCKS"); return e ? atoi(e) : 0; }();
         const int blocks = std::min((waves + 3) / 4, nblocks_env > 0 ? nblocks_env : 128);
         hipLaunchKernelGGL(k_flow_dataflow, dim3(blocks), dim3(256), 0, st, fc, order.i(), n_reached, (const unsigned short *)mask.p, dcf.i(),
                            down.f(), (unsigned *)acc.p, dtick.i(), dtick.i() + 1);

@@ -240,7 +240,7 @@ struct dmg_multi {
     bool uses_rccl_data() const { return transport == DMG_MULTI_RCCL || transport == DMG_MULTI_RCCL_LOOPBACK; }
 };
 
-static bool multi_trace() { static const bool on = getenv("DMG_MULTI_TRACE") != nullptr; return on; }
+static bool multi_trace() { static const bool on = dmg_hook("DMG_MULTI_TRACE") != nullptr; return on; }
 #define MTRACE(...) do { if (multi_trace()) { fprintf(stderr, "[multi] " __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
 
 #define TEAM_BARRIER(m) do { if (!(m)->team.barrier()) return dmg_fail(DMG_ESTATE, "stopped: another band failed"); } while (0)
@@ -841,7 +841,7 @@ static int multi_common(dmg_multi *m, const dmg_grid *grid, const dmg_ocean_para
     m->ghost = ghost;
     m->order = (flags & DMG_MULTI_OVERLAP_LAST_LAUNCH) ? DMG_MULTI_OVERLAP_LAST_LAUNCH : DMG_MULTI_EXCHANGE_THEN_SWEEP;
     if (const char *e = getenv("DMG_MULTI_TIMEOUT_MS")) { const int v = atoi(e); if (v > 0) m->timeout_ms = v; }
-    if (const char *e = getenv("DMG_MULTI_FAIL")) {          // tests: "<band>:<n>"
+    if (const char *e = dmg_hook("DMG_MULTI_FAIL")) {          // tests: "<band>:<n>"
         int b = -1, ord = -1; long long k = 0;
         const int got = sscanf(e, "%d:%lld:%d", &b, &k, &ord);
         if (got >= 2 && b >= 0 && k > 0) { m->fail_band = b; m->fail_at = k; m->fail_order = got == 3 ? ord : -1; }
@@ -864,7 +864,7 @@ static int multi_common(dmg_multi *m, const dmg_grid *grid, const dmg_ocean_para
                                 "(dmg_runtime_init); it is %s: using exchange-then-sweep\n", q ? q : "unset");
         }
     }
-    if (const char *e = getenv("DMG_MULTI_FAKE_LINK_US")) {
+    if (const char *e = dmg_hook("DMG_MULTI_FAKE_LINK_US")) {
         const int us = atoi(e);
         if (us > 0 && us <= 100000) m->fake_link_us = us;
     }
@@ -879,7 +879,7 @@ static int multi_streams(dmg_multi *m)
     m->comm_owner.assign((size_t)m->n, 0);
     m->n_band_exchanges.assign((size_t)m->n, 0);
     m->beat.resize((size_t)m->n);
-    static const bool share = [] { const char *e = getenv("DMG_MULTI_SHARE_COMM_STREAM"); return !e || atoi(e) != 0; }();   // experiments: 0 = one per band
+    static const bool share = [] { const char *e = dmg_hook("DMG_MULTI_SHARE_COMM_STREAM"); return !e || atoi(e) != 0; }();   // experiments: 0 = one per band
     for (int i = 0; i < m->n; i++) {
         DMG_HIP(hipSetDevice(m->ctx_of(i)->device));
         int owner = i;
@@ -890,12 +890,12 @@ static int multi_streams(dmg_multi *m)
         else if (i < ns) {
             int lo = 0, hi = 0;
             DMG_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));  // (hi = greatest priority, numerically lowest)
-            static const bool normal = [] { const char *e = getenv("DMG_MULTI_COMM_PRIORITY"); return e && atoi(e) == 0; }();   // experiments
+            static const bool normal = [] { const char *e = dmg_hook("DMG_MULTI_COMM_PRIORITY"); return e && atoi(e) == 0; }();   // experiments
             DMG_HIP(hipStreamCreateWithPriority(&m->comm_stream[i], hipStreamNonBlocking, normal ? lo : hi));
         }
         // experiments (DMG_MULTI_EVENT_FLAGS=2): the join event with an agent-scope release too.  The default keeps the
         // system-scope release: what it orders was written by a neighbour GPU or a copy engine
-        static const int evf = [] { const char *e = getenv("DMG_MULTI_EVENT_FLAGS"); return e ? atoi(e) : 1; }();
+        static const int evf = [] { const char *e = dmg_hook("DMG_MULTI_EVENT_FLAGS"); return e ? atoi(e) : 1; }();
         DMG_HIP(hipEventCreateWithFlags(&m->ev_edge[i], hipEventDisableTiming));
         DMG_HIP(hipEventCreateWithFlags(&m->ev_xchg[i], hipEventDisableTiming | (evf >= 2 ? hipEventReleaseToDevice : 0)));
     }
@@ -950,7 +950,7 @@ static int multi_create_local(int n_bands, const int *device_ids, const dmg_grid
         // resident and it time-slices them.  A real device holds two streams.  Such a handle runs exchange-then-sweep and says so.
         int most = 0;
         for (int i = 0; i < n_bands; i++) { int c = 0; for (int j = 0; j < n_bands; j++) c += device_ids[j] == device_ids[i]; most = std::max(most, c); }
-        if (most > 4 && m->order == DMG_MULTI_OVERLAP_LAST_LAUNCH && transport != DMG_MULTI_RCCL_LOOPBACK && !getenv("DMG_MULTI_FORCE_OVERLAP")) {
+        if (most > 4 && m->order == DMG_MULTI_OVERLAP_LAST_LAUNCH && transport != DMG_MULTI_RCCL_LOOPBACK && !dmg_hook("DMG_MULTI_FORCE_OVERLAP")) {
             m->order = DMG_MULTI_EXCHANGE_THEN_SWEEP;
             m->warnings |= DMG_MULTI_WARN_SHARED_GPU_FALLBACK;
         }

@@ -232,7 +232,7 @@ void dmg_ocean_params_default(dmg_ocean_params *p)
     p->timestep_h = 24.0f;        // :294
     p->scale = 420.0f;            // :419,:478,:574,:689
     p->wind = 10.0f;              // :342
-    p->quirks = DMG_QUIRK_DIFFUSION_SCALAR_RHS;   // :687,:693
+    p->quirks = DMG_QUIRK_DIFFUSION_SCALAR_RHS | DMG_QUIRK_EXACT_LLVMPIPE;   // :687,:693; the reference's pixels bit for bit
     p->jacobi_kernel = DMG_JACOBI_AUTO;
 }
 
@@ -382,7 +382,7 @@ int dmg_ocean_jacobi_sweeps(dmg_ocean *o, int n)
     // after k sweeps since the last halo refresh the rows still computable lie k rows inside the ghost slabs:
     // the region shrinks by one row per sweep on every side that has a neighbour band
     if (blocked) {
-        static const int cap = [] { const char *e = getenv("DMG_TB_SWEEPS"); int v = e ? atoi(e) : 8; return v >= 1 && v <= 8 ? v : 8; }();
+        static const int cap = [] { const char *e = dmg_hook("DMG_TB_SWEEPS"); int v = e ? atoi(e) : 8; return v >= 1 && v <= 8 ? v : 8; }();
         for (int k = 0; k < n;) {
             int m = n - k < cap ? n - k : cap;   // DMG_TB_SWEEPS (1..8): sweeps per launch, for phase-cost experiments
             k += m;
@@ -425,7 +425,7 @@ extern "C++" int ocean_jacobi_sweeps_begin(dmg_ocean *o, int n, hipStream_t edge
     int rc = no_pending(o, "dmg_ocean_jacobi_sweeps_begin");
     if (rc) return rc;
     const bool blocked = o->prm.jacobi_kernel != DMG_JACOBI_SINGLE && ocean_tb_supported(o);
-    static const int cap = [] { const char *e = getenv("DMG_TB_SWEEPS"); int v = e ? atoi(e) : 8; return v >= 1 && v <= 8 ? v : 8; }();
+    static const int cap = [] { const char *e = dmg_hook("DMG_TB_SWEEPS"); int v = e ? atoi(e) : 8; return v >= 1 && v <= 8 ? v : 8; }();
     if (!blocked || o->count == 1 || n == 0 || cap != 8) return dmg_ocean_jacobi_sweeps(o, n);
     if (n > o->ghost)
         return dmg_fail(DMG_EINVAL, "%d sweeps between halo refreshes but only %d ghost rows", n, o->ghost);
@@ -447,7 +447,7 @@ extern "C++" int ocean_jacobi_sweeps_begin(dmg_ocean *o, int n, hipStream_t edge
     }
     if (edge_stream && edge_stream != o->ctx->stream) {
         // (kernel -> kernel on one device: an agent-scope release is all the edge units need)
-        static const int evf = [] { const char *e = getenv("DMG_MULTI_EVENT_FLAGS"); return e ? atoi(e) : 1; }();
+        static const int evf = [] { const char *e = dmg_hook("DMG_MULTI_EVENT_FLAGS"); return e ? atoi(e) : 1; }();
         if (!o->ev_fork) DMG_HIP(hipEventCreateWithFlags(&o->ev_fork, hipEventDisableTiming | (evf >= 1 ? hipEventReleaseToDevice : 0)));
         DMG_HIP(hipEventRecord(o->ev_fork, o->ctx->stream));             // everything this launch reads has been written
         DMG_HIP(hipStreamWaitEvent(edge_stream, o->ev_fork, 0));
@@ -459,7 +459,7 @@ extern "C++" int ocean_jacobi_sweeps_begin(dmg_ocean *o, int n, hipStream_t edge
     // every SIMD with an interior wave), so the exchange behind them started when the interior was nearly through and
     // hid nothing (profiles/r03_fake_link.log).  Alone on the chip, as units of 8 rows (st_cut's edge_seg), they are done
     // in ~25 us, and the exchange then has the whole interior to hide behind.  DMG_MULTI_EDGE_FIRST=0: side by side.
-    static const bool edge_first = [] { const char *e = getenv("DMG_MULTI_EDGE_FIRST"); return !e || atoi(e) != 0; }();
+    static const bool edge_first = [] { const char *e = dmg_hook("DMG_MULTI_EDGE_FIRST"); return !e || atoi(e) != 0; }();
     o->edge_wait = false;
     if (edge_first && edge_stream && edge_stream != o->ctx->stream) {
         if (!o->ev_edge) DMG_HIP(hipEventCreateWithFlags(&o->ev_edge, hipEventDisableTiming));

@@ -256,7 +256,7 @@ int ocean_launch_diffusion_tb(dmg_ocean *o, int lo, int hi, int n)
     // R = 4 10.3 ms, R = 8 13.5 ms (it needs ~150 VGPRs and spills at the 128 that two resident workgroups allow;
     // 6-wave workgroups of 8 or 10 rows per thread at 3 waves per SIMD: 11.5 / 10.9 ms);
     // one sweep per launch: 28.7 ms.  DMG_DTB_ROWS=4|6|7|8 forces a height for experiments.
-    static const int forced = [] { const char *e = getenv("DMG_DTB_ROWS"); int r = e ? atoi(e) : 0; return (r == 4 || r == 6 || r == 7 || r == 8) ? r : 0; }();
+    static const int forced = [] { const char *e = dmg_hook("DMG_DTB_ROWS"); int r = e ? atoi(e) : 0; return (r == 4 || r == 6 || r == 7 || r == 8) ? r : 0; }();
     const int tiles88 = ((a.W + TB_OW - 1) / TB_OW) * ((hi - lo + 47) / 48);
     const int R = forced ? forced : (tiles88 > 2000 ? 7 : (tiles88 > 400 ? 6 : 4));
     hipStream_t st = o->ctx->stream;

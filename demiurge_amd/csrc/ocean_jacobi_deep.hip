@@ -256,11 +256,11 @@ int ocean_launch_deep_open(dmg_ocean *o, int lo, int hi, int seg, int from, hipS
     a.spole = o->topo.spole ? 1 : 0; a.npole = o->topo.npole ? 1 : 0;
     a.units = (const int4 *)tl.d;
     o->last_kernel = "k_jacobi_deep_open";
-    static const char *prof_path = getenv("DMG_DEEP_PROF");      // experiments: per-wave clocks of the first launch with more than 1024 units
+    static const char *prof_path = dmg_hook("DMG_DEEP_PROF");      // experiments: per-wave clocks of the first launch with more than 1024 units
     static bool prof_done = false;
     a.prof = nullptr;
     if (prof_path && !prof_done && tl.n > 1024 && hipMalloc((void **)&a.prof, (size_t)tl.n * 2 * 4 * 8) != hipSuccess) a.prof = nullptr;
-    static const int sync_env = [] { const char *e = getenv("DMG_DEEP_SYNC"); return e ? atoi(e) : 2; }();      // experiments: 0 none (wrong results), 1 a barrier per step, 2 counters (default)
+    static const int sync_env = [] { const char *e = dmg_hook("DMG_DEEP_SYNC"); return e ? atoi(e) : 2; }();      // experiments: 0 none (wrong results), 1 a barrier per step, 2 counters (default)
     if (sync_env == 0) hipLaunchKernelGGL((k_jacobi_deep_open<1, 0>), dim3((unsigned)tl.n), dim3(128), 0, st, a);
     else if (sync_env == 1) hipLaunchKernelGGL((k_jacobi_deep_open<1, 1>), dim3((unsigned)tl.n), dim3(128), 0, st, a);
     else if (div2) hipLaunchKernelGGL((k_jacobi_deep_open<1, 2>), dim3((unsigned)tl.n), dim3(128), 0, st, a);

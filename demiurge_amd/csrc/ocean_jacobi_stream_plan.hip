@@ -8,7 +8,7 @@
 int st_unit_rows()                                 // DMG_ST_ROWS=<n>: fixed unit height (experiments); default 0 = chosen per launch geometry
 {
     static const int rows = [] {
-        const char *e = getenv("DMG_ST_ROWS");
+        const char *e = dmg_hook("DMG_ST_ROWS");
         int v = e ? atoi(e) : 0;
         return v >= 1 && v <= ST_MAXROWS ? v : 0;
     }();
@@ -96,8 +96,8 @@ static float st_exact_cost(const dmg_ocean *o, int tx, int r0, int r1, bool flip
 // unit costs before and after its rows
 static float st_unit_cost(const unsigned char *cls, int L, int r0, int r1, int variant, int twin = 0)    // twin 1: no halo below r0 (a unit that starts on a seam), 2: none above r1
 {
-    static const float w_mixed = [] { const char *e = getenv("DMG_ST_WMIXED"); return e ? (float)atof(e) : 1.4f; }();    // experiments: the cost model's weights (1.4: best of a sweep 1.0 .. 1.6 on the survey terrain; the per-unit timings fit 1.23 .. 1.40)
-    static const float w_land = [] { const char *e = getenv("DMG_ST_WLAND"); return e ? (float)atof(e) : 0.1f; }();
+    static const float w_mixed = [] { const char *e = dmg_hook("DMG_ST_WMIXED"); return e ? (float)atof(e) : 1.4f; }();    // experiments: the cost model's weights (1.4: best of a sweep 1.0 .. 1.6 on the survey terrain; the per-unit timings fit 1.23 .. 1.40)
+    static const float w_land = [] { const char *e = dmg_hook("DMG_ST_WLAND"); return e ? (float)atof(e) : 0.1f; }();
     float cost = 0.0f;
     for (int r = twin == 1 ? r0 : r0 - TB_T; r < (twin == 2 ? r1 : r1 + TB_T); r++) {
         const int c = (cls && r >= 0 && r < L) ? cls[r] : 2;
@@ -108,10 +108,10 @@ static float st_unit_cost(const unsigned char *cls, int L, int r0, int r1, int v
     // + what a unit costs before and after its rows: dispatch, the class and coefficient tables, the first loads' round
     // trip, the last stores.  Per-unit timings (DMG_ST_PROF) fit duration = 0.152 us x cost + 22 us: ~140 cost units,
     // not the 4 the first version assumed -- which made the simulation prefer many short units
-    static const float unit_cost = [] { const char *e = getenv("DMG_ST_UNITCOST"); return e ? (float)atof(e) : 140.0f; }();
+    static const float unit_cost = [] { const char *e = dmg_hook("DMG_ST_UNITCOST"); return e ? (float)atof(e) : 140.0f; }();
     // an open-water unit (st_open_unit: no row of its window is anything but open water) spends ~440 instead of ~590
     // instructions per step
-    static const float w_openunit = [] { const char *e = getenv("DMG_ST_WOPEN"); return e ? (float)atof(e) : 1.0f; }();     // (experiments; 0.78 is what their instruction count suggests and what made the cut worse)
+    static const float w_openunit = [] { const char *e = dmg_hook("DMG_ST_WOPEN"); return e ? (float)atof(e) : 1.0f; }();     // (experiments; 0.78 is what their instruction count suggests and what made the cut worse)
     if (cls && !variant && w_openunit != 1.0f) {
         bool all_open = r0 - TB_T >= 0 && r1 + TB_T + 6 <= L;
         for (int r = r0 - TB_T; all_open && r < r1 + TB_T + 6; r++) all_open = cls[r] == 0;
@@ -126,8 +126,8 @@ static float st_unit_cost(const unsigned char *cls, int L, int r0, int r1, int v
 static void st_cut(const dmg_ocean *o, int variant, int lo, int hi, int seg, int part, int zone_lo, int zone_hi, std::vector<st_unit> &units,
                    int seg2 = 0, int split = 0, int edge_seg = 0)
 {
-    const int ow = variant ? STN_OW : TB_OW;
-    const std::vector<unsigned char> &table = variant ? o->rowclass_n_host : o->rowclass_host;
+    const int ow = TB_OW;
+    const std::vector<unsigned char> &table = o->rowclass_host;
     const int tiles_x = (o->grid.W + ow - 1) / ow, L = o->L;
     const bool classes = !table.empty();
     units.clear();
@@ -141,7 +141,7 @@ static void st_cut(const dmg_ocean *o, int variant, int lo, int hi, int seg, int
     const bool zones = edge_seg > 0 && zone_lo >= lo && zone_hi <= hi && zone_lo <= zone_hi;
     const int mid_lo = zones ? zone_lo : lo, mid_hi = zones ? zone_hi : hi;
     // every other segment streams southwards (k_jacobi_stream): neighbouring units then start, or end, on the rows they share
-    static const int flip_env = [] { const char *e = getenv("DMG_ST_FLIP"); return e ? atoi(e) : -1; }();
+    static const int flip_env = [] { const char *e = dmg_hook("DMG_ST_FLIP"); return e ? atoi(e) : -1; }();
     const bool flipping = variant == 0 && (flip_env >= 0 ? flip_env != 0 : ST_FLIP_DEFAULT != 0);
     int segi = 0;
     for (int s0 = lo; s0 < hi; segi++) {
@@ -191,7 +191,7 @@ static void st_cut_balanced(const dmg_ocean *o, int lo, int hi, int want, int pa
     const std::vector<unsigned char> &table = o->rowclass_host;
     const int tiles_x = (o->grid.W + TB_OW - 1) / TB_OW, L = o->L;
     const bool classes = !table.empty();
-    static const int flip_env = [] { const char *e = getenv("DMG_ST_FLIP"); return e ? atoi(e) : -1; }();
+    static const int flip_env = [] { const char *e = dmg_hook("DMG_ST_FLIP"); return e ? atoi(e) : -1; }();
     const bool flipping = flip_env >= 0 ? flip_env != 0 : ST_FLIP_DEFAULT != 0;
     const bool zones = edge_seg > 0 && zone_lo >= lo && zone_hi <= hi && zone_lo <= zone_hi;
     const int mid_lo = zones ? zone_lo : lo, mid_hi = zones ? zone_hi : hi;
@@ -230,7 +230,7 @@ static void st_cut_balanced(const dmg_ocean *o, int lo, int hi, int want, int pa
     // the send zones: short units of their own, as in st_cut -- in a twin cut as pairs of such units around a seam (a unit of four
     // rows then runs six steps instead of ten: the edge half of a split launch is what the exchange waits for).  DMG_ST_TWIN_EDGES=0:
     // plain short units in a twin cut's zones as well
-    const bool twin_edges = [] { const char *e = getenv("DMG_ST_TWIN_EDGES"); return !e || atoi(e) != 0; }();
+    const bool twin_edges = [] { const char *e = dmg_hook("DMG_ST_TWIN_EDGES"); return !e || atoi(e) != 0; }();
     if (zones)
         for (int tx = 0; tx < tiles_x; tx++) {
             const unsigned char *cls = classes ? table.data() + (size_t)tx * L : nullptr;
@@ -252,7 +252,7 @@ static void st_cut_balanced(const dmg_ocean *o, int lo, int hi, int want, int pa
     // stretches of water in the middle zone
     struct stretch { int tx, r0, r1, k; double cost; };
     std::vector<stretch> st;
-    static const double w_mixed = [] { const char *e = getenv("DMG_ST_WMIXED"); return e ? atof(e) : 1.4; }();
+    static const double w_mixed = [] { const char *e = dmg_hook("DMG_ST_WMIXED"); return e ? atof(e) : 1.4; }();
     // twin units: what a row adds to its unit is what the STEP it arrives in costs (st_exact_cost's weights: its ten rows in flight
     // decide the step's form), so that a stretch's weight, the number of units it is given and its first cut are priced the way
     // the finished units will be.  (Priced row by row -- a coast row 1.4, a land row 0.1 -- the stretches along the coasts got
@@ -410,7 +410,7 @@ static void st_cut_balanced(const dmg_ocean *o, int lo, int hi, int want, int pa
         // under T -- need no more than `want` units together.  (Dealt out by the stretches' summed row weights, the stretches along
         // the coasts came away with too few: their units end on land, and a unit that ends on land has five tested steps
         // whatever its height -- forcing the coast weight to 2.4 in that deal brought the 8-way band from 52.9 to 48.1 us.)
-        static const int pack_env = [] { const char *e = getenv("DMG_ST_PACK"); return e ? atoi(e) : 1; }();
+        static const int pack_env = [] { const char *e = dmg_hook("DMG_ST_PACK"); return e ? atoi(e) : 1; }();
         auto cost_rows = [&](const stretch &x, int a, int b, int u) -> float {
             const unsigned char *cls = classes ? table.data() + (size_t)x.tx * L : nullptr;
             if (u & 1) { while (cls && b > a && cls[b - 1] == 1) b--; }
@@ -466,64 +466,6 @@ static void st_cut_balanced(const dmg_ocean *o, int lo, int hi, int want, int pa
     }
 }
 
-// Segments for the persistent form: every strip cut into pieces of about equal cost (the waves even out the rest among
-// themselves).  Runs of 24 or more rows that are land everywhere are left out; a piece starts and ends on a row with water.
-static void st_cut_cost(const dmg_ocean *o, int lo, int hi, float target, std::vector<st_unit> &units, double *total)
-{
-    static const float w_mixed = [] { const char *e = getenv("DMG_ST_WMIXED"); return e ? (float)atof(e) : 1.4f; }();
-    static const float w_land = [] { const char *e = getenv("DMG_ST_WLAND"); return e ? (float)atof(e) : 0.15f; }();
-    const float fill = 15.0f;                              // a piece of n rows costs about n + 15 (measured: fill and drain of the 8 levels)
-    const std::vector<unsigned char> &table = o->rowclass_host;
-    const int tiles_x = (o->grid.W + TB_OW - 1) / TB_OW, L = o->L;
-    units.clear();
-    double sum = 0.0;
-    for (int tx = 0; tx < tiles_x; tx++) {
-        const unsigned char *cls = table.empty() ? nullptr : table.data() + (size_t)tx * L;
-        auto cost_of = [&](int r) { const int c = cls ? cls[r] : 0; return c == 1 ? w_land : (c == 2 ? w_mixed : 1.0f); };
-        int r = lo;
-        while (r < hi) {
-            while (r < hi && cls && cls[r] == 1) r++;      // land before the piece
-            if (r >= hi) break;
-            const int s0 = r;
-            float acc = fill;
-            int last_water = r;                            // last row of the piece that is not land everywhere
-            bool absorb = false;                           // the rest of this stretch is too short for a piece of its own
-            while (r < hi) {
-                if (cls && cls[r] == 1) {
-                    int e = r;
-                    while (e < hi && cls[e] == 1) e++;
-                    if (e - r >= 24 || e == hi) break;     // a long run of land (or land up to the end): the piece ends before it
-                    for (; r < e; r++) acc += w_land;
-                    continue;
-                }
-                acc += cost_of(r);
-                last_water = r;
-                r++;
-                if (!absorb && acc >= target) {
-                    // do not leave a sliver behind: if the stretch ends within the next 24 rows, take them along
-                    int e = r;
-                    bool ends = false;
-                    while (e - r < 24) {
-                        if (e >= hi) { ends = true; break; }
-                        if (cls && cls[e] == 1) {
-                            int f = e;
-                            while (f < hi && cls[f] == 1) f++;
-                            if (f - e >= 24 || f == hi) { ends = true; break; }
-                            e = f;
-                        } else e++;
-                    }
-                    if (!ends) break;                      // plenty follows: cut here
-                    absorb = true;
-                }
-            }
-            units.push_back(st_unit{ tx, s0, last_water + 1, acc });
-            sum += acc;
-            r = std::max(r, last_water + 1);
-        }
-    }
-    if (total) *total = sum;
-}
-
 // makespan of the units on `slots` waves that each take the next unit when they are done (how the dispatcher hands
 // workgroups to free slots), units in descending cost order.
 //
@@ -549,7 +491,7 @@ static float st_makespan(std::vector<st_unit> &units, int slots, bool paired = f
         }
         return span;
     }
-    static const float r_old_env = [] { const char *e = getenv("DMG_ST_ROLD"); return e ? (float)atof(e) : 1.25f; }();     // experiments (1.15 .. 1.35 choose the same or equally fast cuts)
+    static const float r_old_env = [] { const char *e = dmg_hook("DMG_ST_ROLD"); return e ? (float)atof(e) : 1.25f; }();     // experiments (1.15 .. 1.35 choose the same or equally fast cuts)
     const float r_old = r_old_env, r_young = 2.0f - r_old_env;
     const int nsimd = slots / 2, n = (int)units.size();
     struct simd { double rem[2]; double t; signed char busy[2]; signed char older; };
@@ -669,7 +611,7 @@ static void st_place_twins(std::vector<st_unit> &units, int num_cu, int tiles_x)
     }
     // (trailing dummies are dropped: nothing follows them)
     while (!out.empty() && out.back().dummy) out.pop_back();
-    static const bool dbg = getenv("DMG_ST_DEBUG") != nullptr;
+    static const bool dbg = dmg_hook("DMG_ST_DEBUG") != nullptr;
     if (dbg) fprintf(stderr, "[stream]   %d pairs placed on %d CUs, %d per CU: the SIMDs' predicted sums %.1f .. %.1f steps\n", n, C, R, couple_lo, couple_hi);
     units.swap(out);
 }
@@ -685,38 +627,22 @@ bool st_units_failed() { return st_units_failed_flag; }
 const dmg_ocean::tile_list *st_units(dmg_ocean *o, int variant, int lo, int hi, int part, int zone_lo, int zone_hi, int seg)
 {
     st_units_failed_flag = false;
-    auto key = std::make_tuple(lo, hi, (variant == 2 ? -5000 : (variant ? -3000 : -1000)) - seg, part, zone_lo, zone_hi);    // "rows per wave" <= -1000 = stream units (seg 0 = auto)
+    auto key = std::make_tuple(lo, hi, -1000 - seg, part, zone_lo, zone_hi);    // "rows per wave" <= -1000 = stream units (seg 0 = auto)
     auto it = o->tb_lists.find(key);
     if (it != o->tb_lists.end()) return &it->second;
-    const int slots = std::max(o->ctx->num_cu, 1) * (variant == 1 ? 20 : 8);     // five (96 VGPRs) / two waves per SIMD
+    const int slots = std::max(o->ctx->num_cu, 1) * 8;     // two waves per SIMD
     std::vector<st_unit> units, best;
-    int p_waves = 0;
     int cut_seg = 0, cut_seg2 = 0, cut_split = 0;         // the cut this list was made with (st_cut's seg, seg2, split)
     int cut_twin = 0;                                     // ... a balanced cut into twin units
-    if (variant == 2) {
-        // persistent form: about one segment per wave (the waves balance the rest among themselves); a strip's rows that
-        // are land everywhere at either end of a cut are trimmed as for the units
-        double total = 0.0;
-        st_cut_cost(o, lo, hi, 1e30f, units, &total);      // uncut: one piece per stretch of water, for the total
-        p_waves = (int)std::max(1.0, std::min((double)std::max(o->ctx->num_cu, 1) * 8, total / 32.0));
-        // every further cut adds a fill: solve target = (total + 15 (pieces - stretches)) / waves for pieces ~ waves
-        float target = (float)((total + 15.0 * std::max(0, p_waves - (int)units.size())) / p_waves);
-        if (seg > 0) target = (float)seg;
-        st_cut_cost(o, lo, hi, std::max(target, 39.0f), best, &total);
-        (void)st_makespan(best, p_waves);                  // (sorts: longest first)
-        static const bool dbg = getenv("DMG_ST_DEBUG") != nullptr;
-        if (dbg) fprintf(stderr, "[stream] rows [%d,%d): persistent, %d waves, %zu segments of cost %.0f (total %.0f, longest %.0f, shortest %.0f)\n", lo, hi, p_waves,
-                         best.size(), target, total, best.empty() ? 0.0f : best.front().cost, best.empty() ? 0.0f : best.back().cost);
-    }
-    else if (part) {
+    if (part) {
         // The two halves of a split launch are halves of ONE cut: the one the whole launch over these rows uses (chosen
         // with every unit in play), filtered by the edge predicate.  (Each half choosing its own unit heights left the
         // rows between the two choices to neither of them.)
         const dmg_ocean::tile_list *whole = st_units(o, variant, lo, hi, 0, 0, 0, seg);
         if (!whole) return nullptr;
         cut_seg = whole->cut_seg; cut_seg2 = whole->cut_seg2; cut_split = whole->cut_split; cut_twin = whole->cut_twin;
-        if (cut_seg == 0) { cut_seg = variant == 1 ? STN_MAXROWS : ST_MAXROWS; cut_seg2 = 0; cut_split = hi; }   // (a launch with no live unit)
-        static const int edge_seg = [] { const char *e = getenv("DMG_ST_EDGE_SEG"); const int v = e ? atoi(e) : 4; return v >= 2 && v <= ST_MAXROWS ? v : 0; }();
+        if (cut_seg == 0) { cut_seg = ST_MAXROWS; cut_seg2 = 0; cut_split = hi; }   // (a launch with no live unit)
+        static const int edge_seg = [] { const char *e = dmg_hook("DMG_ST_EDGE_SEG"); const int v = e ? atoi(e) : 4; return v >= 2 && v <= ST_MAXROWS ? v : 0; }();
         auto cut_as_whole = [&](int which, std::vector<st_unit> &out) {      // (cut_seg < 0: the balanced cut, -cut_seg units in all)
             if (cut_seg < 0) st_cut_balanced(o, lo, hi, -cut_seg, which, zone_lo, zone_hi, out, edge_seg, cut_twin != 0);
             else st_cut(o, variant, lo, hi, cut_seg, which, zone_lo, zone_hi, out, cut_seg2, cut_split, edge_seg);
@@ -746,7 +672,7 @@ const dmg_ocean::tile_list *st_units(dmg_ocean *o, int variant, int lo, int hi, 
         // what a cut is judged by: alpha * (makespan of the simulated dispatch) + (1 - alpha) * (its work / slots).  The chip's
         // throughput is shared by the two waves of a SIMD -- when a slot idles, its neighbour speeds up -- so an idle tail costs
         // less than its length and the work (taller units stream fewer fill rows) counts for more than the makespan alone says
-        static const float alpha_env = [] { const char *e = getenv("DMG_ST_ALPHA"); return e ? (float)atof(e) : -1.0f; }();
+        static const float alpha_env = [] { const char *e = dmg_hook("DMG_ST_ALPHA"); return e ? (float)atof(e) : -1.0f; }();
         const float alpha = alpha_env >= 0.0f ? alpha_env : (seg == -2 ? 0.5f : 1.0f);                  // seg -2: the second automatic cut
         auto judge = [&](std::vector<st_unit> &u) {
             const float span = st_makespan(u, slots, variant == 0);
@@ -756,8 +682,8 @@ const dmg_ocean::tile_list *st_units(dmg_ocean *o, int variant, int lo, int hi, 
         };
         // (every height up to 48 rows: a band of a thousand rows has ~25 rows per wave slot, and one row more or less per unit
         // decides whether the launch's single round fills the slots or spills into a second)
-        static const int fine_env = [] { const char *e = getenv("DMG_ST_FINE"); return e ? atoi(e) : 1; }();
-        for (int cand = fine_env ? 20 : 24; cand <= (variant == 1 ? STN_MAXROWS : ST_MAXROWS); cand += (fine_env && cand < 48) ? 1 : 4) {
+        static const int fine_env = [] { const char *e = dmg_hook("DMG_ST_FINE"); return e ? atoi(e) : 1; }();
+        for (int cand = fine_env ? 20 : 24; cand <= ST_MAXROWS; cand += (fine_env && cand < 48) ? 1 : 4) {
             st_cut(o, variant, lo, hi, cand, part, zone_lo, zone_hi, units);
             float span = judge(units);
             if (span < best_span) { best_span = span; best.swap(units); best_seg = cand; best_seg2 = 0; best_split = hi; }
@@ -772,21 +698,21 @@ const dmg_ocean::tile_list *st_units(dmg_ocean *o, int variant, int lo, int hi, 
                 }
         }
         // ... and the strip-by-strip cut into units of equal cost (st_cut_balanced), at one, two and three rounds' worth of units
-        static const int bal_env = [] { const char *e = getenv("DMG_ST_BALANCED"); return e ? atoi(e) : 1; }();     // how many rounds' worth at most (0: off)
+        static const int bal_env = [] { const char *e = dmg_hook("DMG_ST_BALANCED"); return e ? atoi(e) : 1; }();     // how many rounds' worth at most (0: off)
         // (only on launches of at most ST_BALANCED_ROWS rows whose best fixed-height cut is itself about one round -- the band of an
         // 8-way split.  There it is worth 5-9 % (16384 x 1024: 65.0 -> 59.5 / 61.6 us on two boxes; the middle band of the 8-way split
         // 62.3 -> 59.3 us).  On taller launches the simulation's preference is not the chip's: 16384 x 2048 in one round of 2048
         // equal-cost units takes 94 us against 87 for 1981 units of 52 rows -- strips whose units no longer cover the same rows at
         // the same time stop sharing their halo columns in the L2 -- although the 4-way middle band gains 4.5 %;
         // profiles/r04_balanced_cut.txt)
-        static const int bal_rows = [] { const char *e = getenv("DMG_ST_BALANCED_ROWS"); return e ? atoi(e) : 1200; }();
+        static const int bal_rows = [] { const char *e = dmg_hook("DMG_ST_BALANCED_ROWS"); return e ? atoi(e) : 1200; }();
         if (bal_env && variant == 0 && !o->rowclass_host.empty() && (int)best.size() <= slots + slots / 10 && hi - lo <= bal_rows)
             for (int eighths = 6; eighths <= 8 * bal_env; eighths += (eighths < 8 ? 1 : 8)) {      // 3/4, 7/8, 1 (, 2, 3) rounds' worth of units
                 const int want = slots * eighths / 8;
                 st_cut_balanced(o, lo, hi, want, part, zone_lo, zone_hi, units);
                 if (units.empty()) continue;
                 const float span = judge(units);
-                static const bool dbgc = getenv("DMG_ST_DEBUG") != nullptr;
+                static const bool dbgc = dmg_hook("DMG_ST_DEBUG") != nullptr;
                 if (dbgc) fprintf(stderr, "[stream]   balanced cut of %d units: predicted span %.0f (best so far %.0f)\n", want, span, best_span);
                 if (span < best_span) { best_span = span; best.swap(units); best_seg = -want; best_seg2 = 0; best_split = hi; }
             }
@@ -799,7 +725,7 @@ const dmg_ocean::tile_list *st_units(dmg_ocean *o, int variant, int lo, int hi, 
         // 200-row plain units, as two or three rounds of short pairs (292-296 against 273.9 us, 395 against 362.6 without land) and as
         // one round of pairs of up to 232 rows (300.2 against 279.9 us): a launch of one round lasts as long as its slowest SIMD, 1.2
         // medians, where the plain cut's short units fill the slots its tall ones leave -- profiles/r04_twin_units.txt)
-        static const int twin_rows = [] { const char *e = getenv("DMG_ST_TWIN_ROWS"); return e ? atoi(e) : 4400; }();
+        static const int twin_rows = [] { const char *e = dmg_hook("DMG_ST_TWIN_ROWS"); return e ? atoi(e) : 4400; }();
         if (twin_env && bal_env && variant == 0 && !o->rowclass_host.empty() && hi - lo <= twin_rows) {
             // (the twin units' costs are st_exact_cost's: the cut they are compared with is priced the same way)
             std::vector<st_unit> ref = best;
@@ -809,7 +735,7 @@ const dmg_ocean::tile_list *st_units(dmg_ocean *o, int variant, int lo, int hi, 
             std::vector<st_unit> twin_best;
             int twin_want = 0;
             // one round's worth of units (DMG_ST_TWIN_ROUNDS=3: also one and a half, two and three rounds' worth -- measured, never better)
-            static const int twin_rounds = [] { const char *e = getenv("DMG_ST_TWIN_ROUNDS"); return e ? atoi(e) : 1; }();
+            static const int twin_rounds = [] { const char *e = dmg_hook("DMG_ST_TWIN_ROUNDS"); return e ? atoi(e) : 1; }();
             for (int eighths = 8; eighths <= 8 * twin_rounds; eighths += (eighths < 16 ? 4 : 8)) {
                 const int want = slots * eighths / 8;
                 const auto t_cut0 = std::chrono::steady_clock::now();
@@ -817,7 +743,7 @@ const dmg_ocean::tile_list *st_units(dmg_ocean *o, int variant, int lo, int hi, 
                 const double cut_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_cut0).count();
                 if (units.empty()) continue;
                 const float span = st_makespan(units, slots / 2);          // (a pair holds two of the slots)
-                static const int dbgc = [] { const char *e = getenv("DMG_ST_DEBUG"); return e ? atoi(e) : 0; }();
+                static const int dbgc = [] { const char *e = dmg_hook("DMG_ST_DEBUG"); return e ? atoi(e) : 0; }();
                 if (dbgc) {
                     double sum = 0; float lo_c = 1e30f;
                     for (const st_unit &u : units) { sum += u.cost; lo_c = std::min(lo_c, u.cost); }
@@ -840,7 +766,7 @@ const dmg_ocean::tile_list *st_units(dmg_ocean *o, int variant, int lo, int hi, 
         }
         (void)st_makespan(best, cut_twin ? slots / 2 : slots);      // (longest first)
         cut_seg = best_seg; cut_seg2 = best_seg2; cut_split = best_split;
-        static const bool dbg = getenv("DMG_ST_DEBUG") != nullptr;
+        static const bool dbg = dmg_hook("DMG_ST_DEBUG") != nullptr;
         if (dbg) {
             double total = 0;
             for (const st_unit &u : best) total += u.cost;
@@ -849,7 +775,7 @@ const dmg_ocean::tile_list *st_units(dmg_ocean *o, int variant, int lo, int hi, 
                     100.0 * total / slots / best_span);
             // which path the steps of these units take (host classes: 0 open, 1 land, 2 mixed), and how many of the rows that go
             // through the coast formula in an all-coast step are open water
-            const std::vector<unsigned char> &table = variant ? o->rowclass_n_host : o->rowclass_host;
+            const std::vector<unsigned char> &table = o->rowclass_host;
             if (!table.empty() && !cut_twin) {
                 long long n1 = 0, n2 = 0, n0 = 0, rows2 = 0, open2 = 0;
                 for (const st_unit &u : best) {
@@ -876,8 +802,8 @@ const dmg_ocean::tile_list *st_units(dmg_ocean *o, int variant, int lo, int hi, 
         // row block by row block: the 16 halo columns two neighbouring strips share are then read through one L2 instead of
         // two (+0.7 % on the survey terrain, +1.0 % without land in a same-box A/B; wider cost buckets disturb longest-first
         // and lose).  DMG_ST_XCC=0 keeps the sorted order.
-        static const int xcc_mode = [] { const char *e = getenv("DMG_ST_XCC"); return e ? atoi(e) : 1; }();
-        static const int place_mode = [] { const char *e = getenv("DMG_ST_PLACE"); return e ? atoi(e) : 1; }();
+        static const int xcc_mode = [] { const char *e = dmg_hook("DMG_ST_XCC"); return e ? atoi(e) : 1; }();
+        static const int place_mode = [] { const char *e = dmg_hook("DMG_ST_PLACE"); return e ? atoi(e) : 1; }();
         const bool twins = !best.empty() && best.front().rlo >= 0;
         if (twins && place_mode && (int)best.size() <= slots / 2) st_place_twins(best, o->ctx->num_cu, (o->grid.W + TB_OW - 1) / TB_OW);
         else if (xcc_mode && variant == 0 && !best.empty()) {
@@ -913,11 +839,11 @@ const dmg_ocean::tile_list *st_units(dmg_ocean *o, int variant, int lo, int hi, 
     flat.reserve(best.size() * 4);
     // a unit is an open-water unit (bit 0 of its fourth word; st_open_unit) if every row of its window, and every row its
     // steps request past the window, is plain open water with exact divisor pairs inside the grid and the stored band
-    static const bool open_units = [] { const char *e = getenv("DMG_ST_OPEN_UNITS"); return e && atoi(e) != 0; }();     // (measured: no gain; off by default)
+    static const bool open_units = [] { const char *e = dmg_hook("DMG_ST_OPEN_UNITS"); return e && atoi(e) != 0; }();     // (measured: no gain; off by default)
     const std::vector<unsigned char> &ctab = o->rowclass_host;
     int n_open = 0, n_flip = 0, n_twin = 0;
     for (const st_unit &u : best) n_twin += u.rlo >= 0;
-    if (n_twin && getenv("DMG_ST_TWIN_FAIL")) {            // tests: a launch that would run twin units fails instead (bench.py's fall-back to plain units)
+    if (n_twin && dmg_hook("DMG_ST_TWIN_FAIL")) {            // tests: a launch that would run twin units fails instead (bench.py's fall-back to plain units)
         st_units_failed_flag = true; dmg_fail(DMG_ESTATE, "twin units: injected failure (DMG_ST_TWIN_FAIL)");
         return nullptr;
     }
@@ -947,7 +873,7 @@ const dmg_ocean::tile_list *st_units(dmg_ocean *o, int variant, int lo, int hi, 
         else { flat.push_back(u.tx); flat.push_back(u.r0); flat.push_back(u.r1); flat.push_back(flag); }
     }
     {
-        static const bool dbg = getenv("DMG_ST_DEBUG") != nullptr;
+        static const bool dbg = dmg_hook("DMG_ST_DEBUG") != nullptr;
         if (dbg) fprintf(stderr, "[stream] rows [%d,%d) part %d: %d of %zu units are open-water units, %d stream southwards\n", lo, hi, part, n_open, best.size(), n_flip);
     }
     dmg_ocean::tile_list tl;
@@ -963,22 +889,6 @@ const dmg_ocean::tile_list *st_units(dmg_ocean *o, int variant, int lo, int hi, 
     if (o->lists_on_host) { tl.host = flat; return &(o->tb_lists[key] = tl); }       // (dmg_stream_units_probe: no device)
     if (tl.n && hipMalloc((void **)&tl.d, flat.size() * sizeof(int)) != hipSuccess) return nullptr;
     if (tl.n && hipMemcpy(tl.d, flat.data(), flat.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
-    if (variant == 2 && tl.n) {
-        tl.waves = p_waves;
-        tl.cap = ((tl.n + p_waves + 511) / 512) * 512;   // initial segments + about one steal per wave (a thief that finds the table full keeps its piece to itself)
-        std::vector<unsigned long long> w0((size_t)tl.n);
-        std::vector<unsigned> c0((size_t)tl.n);
-        for (int i = 0; i < tl.n; i++) {
-            w0[i] = stp_word(best[i].tx, best[i].r0, best[i].r1);
-            c0[i] = (unsigned)(best[i].r0 - TB_T + STP_BIAS);
-        }
-        const size_t total = (size_t)tl.cap + tl.waves;
-        if (hipMalloc((void **)&tl.seg_word0, w0.size() * 8) != hipSuccess || hipMalloc((void **)&tl.seg_cur0, c0.size() * 4) != hipSuccess ||
-            hipMalloc((void **)&tl.seg_word, total * 8) != hipSuccess || hipMalloc((void **)&tl.seg_cur, total * 4) != hipSuccess ||
-            hipMalloc((void **)&tl.seg_ctl, 2 * sizeof(int)) != hipSuccess) return nullptr;
-        if (hipMemcpy(tl.seg_word0, w0.data(), w0.size() * 8, hipMemcpyHostToDevice) != hipSuccess ||
-            hipMemcpy(tl.seg_cur0, c0.data(), c0.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return nullptr;
-    }
     return &(o->tb_lists[key] = tl);
 }
 

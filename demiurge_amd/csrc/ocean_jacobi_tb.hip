@@ -288,21 +288,6 @@ __global__ __launch_bounds__(64) void k_tb_rowclass(const unsigned char *__restr
     if (lane == 0) cls[(size_t)tx * L + l] = all_land ? 1 : (any ? 2 : 0);
 }
 
-// the same for the narrow streaming kernel: strips of 128 columns (112 written), two cells per lane
-__global__ __launch_bounds__(64) void k_tb_rowclass_n(const unsigned char *__restrict__ code, unsigned char *__restrict__ cls, int W, int L,
-                                                      int y_first, int H, int spole, int npole)
-{
-    const int lane = threadIdx.x, tx = blockIdx.x, l = blockIdx.y;
-    int col = tx * (128 - 2 * TB_T) - TB_T + 2 * lane;
-    col %= W; if (col < 0) col += W;
-    unsigned c = *reinterpret_cast<const unsigned short *>(code + (size_t)l * W + col);
-    int yg = y_first + l;
-    if (yg == 0 && !spole) c &= ~0x0202u;
-    if (yg == H - 1 && !npole) c &= ~0x0101u;
-    bool any = __builtin_amdgcn_ballot_w64((c & 0x1F1Fu) != 0) != 0;
-    bool all_land = __builtin_amdgcn_ballot_w64((c & 0x1010u) != 0x1010u) == 0;
-    if (lane == 0) cls[(size_t)tx * L + l] = all_land ? 1 : (any ? 2 : 0);
-}
 
 void ocean_tb_free_lists(dmg_ocean *o)
 {
@@ -348,13 +333,6 @@ int ocean_build_rowclass(dmg_ocean *o)
     ocean_tb_free_lists(o);                              // lists of the previous terrain
     o->rowclass_host.resize((size_t)tiles_x * o->L);
     DMG_HIP(hipMemcpyAsync(o->rowclass_host.data(), o->rowclass, o->rowclass_host.size(), hipMemcpyDeviceToHost, o->ctx->stream));
-    const int tiles_n = (o->grid.W + (128 - 2 * TB_T) - 1) / (128 - 2 * TB_T);
-    if (!o->rowclass_n) DMG_HIP(hipMalloc((void **)&o->rowclass_n, (size_t)tiles_n * o->L));
-    hipLaunchKernelGGL(k_tb_rowclass_n, dim3(tiles_n, o->L), dim3(64), 0, o->ctx->stream, o->code, o->rowclass_n, o->grid.W, o->L,
-                       o->y0 - o->gs, o->grid.H, o->topo.spole ? 1 : 0, o->topo.npole ? 1 : 0);
-    DMG_HIP(hipGetLastError());
-    o->rowclass_n_host.resize((size_t)tiles_n * o->L);
-    DMG_HIP(hipMemcpyAsync(o->rowclass_n_host.data(), o->rowclass_n, o->rowclass_n_host.size(), hipMemcpyDeviceToHost, o->ctx->stream));
     DMG_HIP(hipStreamSynchronize(o->ctx->stream));
     return DMG_OK;
 }
@@ -403,17 +381,15 @@ static const dmg_ocean::tile_list *tb_live_tiles(dmg_ocean *o, int lo, int hi, i
 // tile shapes built into the library: R rows per thread x NW waves per workgroup.  The default is chosen from
 // measurements; DMG_TB_SHAPE=<R>x<NW> overrides it for experiments.
 struct tb_shape { int R, NW; };
-#define TB_NCAND 6
+#define TB_NCAND 5
 static tb_shape tb_forced_shape()
 {
     static const tb_shape forced = [] {
         tb_shape d = { 0, 0 };
-        const char *e = getenv("DMG_TB_SHAPE");
+        const char *e = dmg_hook("DMG_TB_SHAPE");
         int r = 0, nw = 0;
-        // stream / stream-n / stream-p: the streaming kernel's unit, narrow and persistent forms for every 8-sweep launch
+        // stream: the streaming kernel for every 8-sweep launch
         if (e && !strcmp(e, "stream")) d = { -1000, 0 };
-        else if (e && !strcmp(e, "stream-n")) d = { -1000, 1 };
-        else if (e && !strcmp(e, "stream-p")) d = { -1000, 2 };
         else if (e && sscanf(e, "%dx%d", &r, &nw) == 2 &&
             ((r == 8 && nw == 8) || (r == 16 && nw == 8) || (r == 8 && nw == 16) || (r == 12 && nw == 8) || (r == 10 && nw == 8) ||
              (r == 4 && nw == 8) || (r == 6 && nw == 8)))
@@ -430,12 +406,12 @@ static int tb_launch(dmg_ocean *o, tb_args a, int W, int rows, hipStream_t strea
     constexpr int OH = R * NW - 2 * TB_T;
     a.tiles_x = (W + TB_OW - 1) / TB_OW;
     a.tiles_y = (rows + OH - 1) / OH;
-    static const int order = [] { const char *e = getenv("DMG_TB_ORDER"); return e ? atoi(e) : 0; }();
+    static const int order = [] { const char *e = dmg_hook("DMG_TB_ORDER"); return e ? atoi(e) : 0; }();
     a.order = order;
     a.trace = nullptr;
     a.tile_list = nullptr;
     size_t nt = (size_t)a.tiles_x * a.tiles_y;
-    static const bool all_tiles = getenv("DMG_TB_ALLTILES") != nullptr;
+    static const bool all_tiles = dmg_hook("DMG_TB_ALLTILES") != nullptr;
     if ((a.rowclass && order == 0 && !all_tiles) || part) {
         const dmg_ocean::tile_list *tl = tb_live_tiles<R, NW>(o, a.out_lo, a.out_hi, a.tiles_x, a.tiles_y, part, zone_lo, zone_hi);
         if (!tl && part) return dmg_fail(DMG_ENOMEM, "tile list allocation failed");
@@ -446,7 +422,7 @@ static int tb_launch(dmg_ocean *o, tb_args a, int W, int rows, hipStream_t strea
         }
         if (part) a.order = 0;                            // lists of a part hold natural tile ids
     }
-    static const char *trace_path = getenv("DMG_TB_TRACE");      // experiments: dump the per-workgroup timeline of every launch
+    static const char *trace_path = dmg_hook("DMG_TB_TRACE");      // experiments: dump the per-workgroup timeline of every launch
     if (trace_path) {
         (void)hipMalloc((void **)&a.trace, nt * 48);
         (void)hipMemsetAsync(a.trace, 0, nt * 48, stream);
@@ -486,7 +462,7 @@ int ocean_launch_tb(dmg_ocean *o, int lo, int hi, int n, int part, int zone_lo, 
     a.y_first = o->y0 - o->gs; a.H = o->grid.H;
     a.spole = o->topo.spole ? 1 : 0; a.npole = o->topo.npole ? 1 : 0;
     a.nsweeps = n;
-    static const bool use_cls = getenv("DMG_TB_NOCLASS") == nullptr;
+    static const bool use_cls = dmg_hook("DMG_TB_NOCLASS") == nullptr;
     a.rowclass = use_cls ? o->rowclass : nullptr;
     hipStream_t st = stream ? stream : o->ctx->stream;
     // Tile shape.  Every shape gives bit-identical results, so which one runs is purely a matter of time.  Large
@@ -499,7 +475,7 @@ int ocean_launch_tb(dmg_ocean *o, int lo, int hi, int n, int part, int zone_lo, 
     int cand = -1;
     // candidates: three tile shapes of the workgroup kernel (k_jacobi_tb8) and the streaming kernel (k_jacobi_stream,
     // ocean_jacobi_stream.hip) with its own choice of unit height and with short units.  R < 0 = streaming with -R rows per unit.
-    static const tb_shape cands[TB_NCAND] = { { 8, 8 }, { 6, 8 }, { 4, 8 }, { -1000, 0 }, { -32, 0 }, { -1000, 1 } };   // NW = 1 with R < 0: the narrow streaming kernel   // -1000: unit height from the dispatch simulation
+    static const tb_shape cands[TB_NCAND] = { { 8, 8 }, { 6, 8 }, { 4, 8 }, { -1000, 0 }, { -32, 0 } };   // -1000: unit height from the dispatch simulation
     const bool stream_ok = n == TB_T && ocean_stream_enabled();
     if (sh.R < 0 && !stream_ok) sh = tb_shape{ 8, 8 };      // (a forced streaming form: launches of fewer than 8 sweeps keep the tile kernel)
     if (!sh.R) {
@@ -564,7 +540,7 @@ int ocean_tb_tile_rows(dmg_ocean *o, int lo, int hi)
     if (f.R < 0) return 0;
     if (f.R) return f.R * f.NW - 2 * TB_T;
     if (ocean_tb_tuning_open(o, lo, hi)) return 0;
-    static const int rows_of[TB_NCAND] = { 8 * 8 - 2 * TB_T, 6 * 8 - 2 * TB_T, 4 * 8 - 2 * TB_T, 0, 0, 0 };   // streaming forms: no tile-row grid
+    static const int rows_of[TB_NCAND] = { 8 * 8 - 2 * TB_T, 6 * 8 - 2 * TB_T, 4 * 8 - 2 * TB_T, 0, 0 };   // streaming forms: no tile-row grid
     auto it = o->tb_tuning.find(std::make_pair(lo, hi));
     if (it != o->tb_tuning.end() && it->second.chosen >= 0) return rows_of[it->second.chosen];
     const int tiles88 = ((o->grid.W + TB_OW - 1) / TB_OW) * ((hi - lo + 47) / 48);
@@ -575,7 +551,7 @@ int ocean_tb_tile_rows(dmg_ocean *o, int lo, int hi)
 bool ocean_tb_tuning_open(dmg_ocean *o, int lo, int hi)
 {
     if (tb_forced_shape().R) return false;
-    static const bool use_cls = getenv("DMG_TB_NOCLASS") == nullptr;
+    static const bool use_cls = dmg_hook("DMG_TB_NOCLASS") == nullptr;
     if (!use_cls || !o->rowclass || o->count > 1) return false;
     const int tiles88 = ((o->grid.W + TB_OW - 1) / TB_OW) * ((hi - lo + 47) / 48);
     if (tiles88 > 4096) return false;

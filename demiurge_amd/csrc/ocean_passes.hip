@@ -58,6 +58,7 @@ __device__ __forceinline__ float2 neg2(float2 v) { return make_float2(-v.x, -v.y
 // ---------------------------------------------------------------------------------------------
 // divergence (:376-420)
 // ---------------------------------------------------------------------------------------------
+template <bool X>
 __global__ __launch_bounds__(256) void k_divergence(pass_args a)
 {
     int x = blockIdx.x * blockDim.x + threadIdx.x, l = a.row_lo + blockIdx.y;
@@ -82,9 +83,15 @@ __global__ __launch_bounds__(256) void k_divergence(pass_args a)
     if (c8 & 64u) vSy = 0.0f;
     if (c8 & 1u) vEx = 0.0f;
     if (c8 & 16u) vWx = 0.0f;
-    float pwx = __fdiv_rn(dxr[l], a.scale), pwy = __fdiv_rn(dyr[l], a.scale);    // pixelsize(st)/420 (:419)
-    a.out[(size_t)l * W + x] =
-        __fmul_rn(0.5f, __fadd_rn(__fdiv_rn(__fsub_rn(vEx, vWx), pwx), __fdiv_rn(__fsub_rn(vNy, vSy), pwy)));   // :420
+    if (X) {
+        float pwx = __fdiv_rn(dxr[l], a.scale), pwy = __fdiv_rn(dyr[l], a.scale);    // pixelsize(st)/420 (:419)
+        a.out[(size_t)l * W + x] =
+            __fmul_rn(0.5f, __fadd_rn(__fdiv_rn(__fsub_rn(vEx, vWx), pwx), __fdiv_rn(__fsub_rn(vNy, vSy), pwy)));   // :420
+    } else {
+        // the row's two quotients as reciprocals (wave-uniform: one v_rcp each), the per-cell divisions as multiplications
+        const float rpwx = a.scale * __frcp_rn(dxr[l]), rpwy = a.scale * __frcp_rn(dyr[l]);
+        a.out[(size_t)l * W + x] = 0.5f * ((vEx - vWx) * rpwx + (vNy - vSy) * rpwy);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -176,21 +183,74 @@ __device__ __forceinline__ vec3 v3(float x, float y, float z) { vec3 r; r.x = x;
 __device__ __forceinline__ vec3 cross3(vec3 a, vec3 b)
 { return v3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y); }
 __device__ __forceinline__ float dot3(vec3 a, vec3 b) { return (a.z * b.z + a.y * b.y) + a.x * b.x; }   // Mesa's dot(): from the last component down
-__device__ __forceinline__ vec3 norm3(vec3 a) { float r = 1.0f / sqrtf(dot3(a, a)); return v3(a.x * r, a.y * r, a.z * r); }
-__device__ __forceinline__ vec3 sph2cart(float lon, float lat) { return v3(glsl::cos(lat) * glsl::cos(lon), glsl::cos(lat) * glsl::sin(lon), glsl::sin(lat)); }
-// v_to_cartesian / cartesian_to_v (:251-268)
-__device__ __forceinline__ void tangent_basis(float lon, float lat, vec3 *par, vec3 *ycomp)
+
+// The transcendental and division steps of the trig-heavy passes, in two renderings (dmg_ocean_params.quirks,
+// DMG_QUIRK_EXACT_LLVMPIPE).  EXACT: glsl_math.h's restatement of Mesa / gallivm, IEEE divisions and square roots -- the
+// reference's pixels bit for bit, at ~530 vector instructions per advected cell.  Otherwise the SAME expressions (Mesa's asin
+// and atan polynomials are approximations with 1e-4 rad of error of their own: a "better" arcsine would be further from the
+// reference than this) on the hardware's sine, cosine, log2, exp2, reciprocal and reciprocal square root (1 ulp each):
+// within north_star's 1e-5 of the exact rendering (tests/test_gpu_ocean_passes.py), a third of the instructions.
+template <bool EXACT> struct gmath {
+    static __device__ __forceinline__ float sin(float x) { return EXACT ? glsl::sin(x) : __sinf(x); }
+    static __device__ __forceinline__ float cos(float x) { return EXACT ? glsl::cos(x) : __cosf(x); }
+    static __device__ __forceinline__ float rcp(float x) { return EXACT ? 1.0f / x : __frcp_rn(x); }
+    static __device__ __forceinline__ float rsqrt(float x) { return EXACT ? 1.0f / sqrtf(x) : __frsqrt_rn(x); }
+    static __device__ __forceinline__ float sqrt(float x) { return EXACT ? sqrtf(x) : __fsqrt_rn(x); }
+    static __device__ __forceinline__ float div(float a, float b) { return EXACT ? a / b : __fdividef(a, b); }
+    static __device__ __forceinline__ float pow(float x, float y) { return EXACT ? glsl::pow(x, y) : __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(x) * y); }
+    static __device__ __forceinline__ float asin(float x)
+    {
+        if (EXACT) return glsl::asin(x);
+        const float ax = fabsf(x);
+        float t = 0.086566724f + ax * -0.03102955f;
+        t = (glsl::PI_4 - 1.0f) + ax * t;
+        t = glsl::PI_2 + ax * t;
+        return glsl::sign(x) * (glsl::PI_2 - __fsqrt_rn(1.0f - ax) * t);
+    }
+    static __device__ __forceinline__ float atan_pos(float a)
+    {
+        const float x = fminf(a, 1.0f) * __frcp_rn(fmaxf(a, 1.0f));
+        const float x2 = x * x, x3 = x2 * x, x5 = x3 * x2, x7 = x5 * x2, x9 = x7 * x2;
+        float p = x * 0.9999793128310355f;
+        p = p + x3 * -0.3326756418091246f;
+        p = p + x5 * 0.1938924977115610f;
+        p = p + x7 * -0.1173503194786851f;
+        p = p + x9 * 0.0536813784310406f;
+        p = p + (x9 * -0.0121323213173444f) * x2;
+        return p + (a > 1.0f ? 1.0f : 0.0f) * (p * -2.0f + glsl::PI_2);
+    }
+    static __device__ __forceinline__ float atan2(float y, float x)
+    {
+        if (EXACT) return glsl::atan2(y, x);
+        const bool flip = 0.0f >= x;
+        const float s = flip ? fabsf(x) : y, t = flip ? y : fabsf(x);
+        const float scale = fabsf(t) >= 1e18f ? 0.25f : 1.0f;
+        const float rcp_scaled_t = __frcp_rn(t * scale);
+        const float s_over_t = (s * scale) * rcp_scaled_t;
+        const float tn = fabsf(x) == fabsf(y) ? 1.0f : fabsf(s_over_t);
+        const float arc = (flip ? 1.0f : 0.0f) * glsl::PI_2 + atan_pos(tn) * glsl::sign(tn);
+        return fminf(y, rcp_scaled_t) < 0.0f ? -arc : arc;
+    }
+};
+template <bool X> __device__ __forceinline__ vec3 norm3(vec3 a) { float r = gmath<X>::rsqrt(dot3(a, a)); return v3(a.x * r, a.y * r, a.z * r); }
+template <bool X> __device__ __forceinline__ vec3 sph2cart(float lon, float lat)
 {
-    vec3 c = sph2cart(lon, lat);
-    float il = 1.0f / sqrtf(c.y * c.y + c.x * c.x);      // normalize(c.xy): dot() from the last component down
+    const float cl = gmath<X>::cos(lat);
+    return v3(cl * gmath<X>::cos(lon), cl * gmath<X>::sin(lon), gmath<X>::sin(lat));
+}
+// v_to_cartesian / cartesian_to_v (:251-268)
+template <bool X> __device__ __forceinline__ void tangent_basis(float lon, float lat, vec3 *par, vec3 *ycomp)
+{
+    vec3 c = sph2cart<X>(lon, lat);
+    float il = gmath<X>::rsqrt(c.y * c.y + c.x * c.x);      // normalize(c.xy): dot() from the last component down
     float inx = c.x * il, iny = c.y * il;
-    *ycomp = v3(glsl::sin(lat) * (-inx), glsl::sin(lat) * (-iny), glsl::cos(lat));
-    *par = norm3(cross3(v3(0, 0, 1), c));
+    *ycomp = v3(gmath<X>::sin(lat) * (-inx), gmath<X>::sin(lat) * (-iny), gmath<X>::cos(lat));
+    *par = norm3<X>(cross3(v3(0, 0, 1), c));
 }
 // rotation_matrix(theta,u)*v (reference src/Shader.h:35-40; mat3 columns)
-__device__ __forceinline__ vec3 rotate3(float theta, vec3 u, vec3 v)
+template <bool X> __device__ __forceinline__ vec3 rotate3(float theta, vec3 u, vec3 v)
 {
-    float c = glsl::cos(theta), s = glsl::sin(theta), ic = 1.0f - c;
+    float c = gmath<X>::cos(theta), s = gmath<X>::sin(theta), ic = 1.0f - c;
     vec3 c0 = v3(c + u.x * u.x * ic, u.y * u.x * ic + u.z * s, u.z * u.x * ic - u.y * s);
     vec3 c1 = v3(u.x * u.y * ic - u.z * s, c + u.y * u.y * ic, u.z * u.y * ic + u.x * s);
     vec3 c2 = v3(u.x * u.z * ic + u.y * s, u.y * u.z * ic - u.x * s, c + u.z * u.z * ic);
@@ -219,6 +279,7 @@ __device__ __forceinline__ float2 fetch_linear2(const float2 *t, int W, int H, f
     return make_float2(fmaf(wy, bx - ax, ax), fmaf(wy, by - ay, ay));
 }
 
+template <bool X>
 __global__ __launch_bounds__(256) void k_advect(pass_args a, float k04)
 {
     int x = blockIdx.x * blockDim.x + threadIdx.x, l = a.row_lo + blockIdx.y;
@@ -227,30 +288,30 @@ __global__ __launch_bounds__(256) void k_advect(pass_args a, float k04)
     size_t i = (size_t)l * W + x;
     if (a.code[i] & 16u) { a.vout[i] = make_float2(0.0f, 0.0f); return; }        // :284-288
     float2 vel = a.vin[i];                                                         // :290
-    float sx = ((float)x + 0.5f) / (float)W, sy = ((float)(a.y_first + l) + 0.5f) / (float)a.H;
-    float distance = sqrtf(vel.x * vel.x + vel.y * vel.y) * a.timestep;           // :298
-    float arclength = 2.0f * 3.14159f / a.circumference * distance;                // :299
+    float sx = gmath<X>::div((float)x + 0.5f, (float)W), sy = gmath<X>::div((float)(a.y_first + l) + 0.5f, (float)a.H);
+    float distance = gmath<X>::sqrt(vel.x * vel.x + vel.y * vel.y) * a.timestep;           // :298
+    float arclength = gmath<X>::div(2.0f * 3.14159f, a.circumference) * distance;                // :299
     float lon = sx * (a.c3 - a.c2) + a.c2, lat = sy * (a.c1 - a.c0) + a.c0;        // tex_to_spheric
-    vec3 cart = sph2cart(lon, lat);
+    vec3 cart = sph2cart<X>(lon, lat);
     vec3 par, yc;
-    tangent_basis(lon, lat, &par, &yc);
+    tangent_basis<X>(lon, lat, &par, &yc);
     vec3 v_cart = v3(par.x * vel.x + yc.x * vel.y, par.y * vel.x + yc.y * vel.y, par.z * vel.x + yc.z * vel.y);
-    vec3 rotdir = norm3(cross3(cart, v_cart));                                     // :306
-    cart = rotate3(-arclength, rotdir, cart);                                      // :308
-    float lon_n = glsl::atan2(cart.y, cart.x), lat_n = glsl::asin(cart.z);                   // cartesian_to_spheric
-    float cu = (lon_n - a.c2) / (a.c3 - a.c2), cv = (lat_n - a.c0) / (a.c1 - a.c0);   // spheric_to_tex
+    vec3 rotdir = norm3<X>(cross3(cart, v_cart));                                     // :306
+    cart = rotate3<X>(-arclength, rotdir, cart);                                      // :308
+    float lon_n = gmath<X>::atan2(cart.y, cart.x), lat_n = gmath<X>::asin(cart.z);                   // cartesian_to_spheric
+    float cu = gmath<X>::div(lon_n - a.c2, a.c3 - a.c2), cv = gmath<X>::div(lat_n - a.c0, a.c1 - a.c0);   // spheric_to_tex
     float2 nv = fetch_linear2(a.vg, W, a.H, cu, cv, a.g_y_first, a.g_L, a.oob_flag);  // :315
     vec3 par_n, yc_n;
-    tangent_basis(lon_n, lat_n, &par_n, &yc_n);
+    tangent_basis<X>(lon_n, lat_n, &par_n, &yc_n);
     vec3 testv = v3(par_n.x * nv.x + yc_n.x * nv.y, par_n.y * nv.x + yc_n.y * nv.y, par_n.z * nv.x + yc_n.z * nv.y);
-    testv = rotate3(arclength, rotdir, testv);
+    testv = rotate3<X>(arclength, rotdir, testv);
     float nvx = dot3(testv, par), nvy = dot3(testv, yc);                           // cartesian_to_v(testv, tex_to_spheric(st))
     if (isnan(nvx) || isnan(nvy)) { nvx = 0.0f; nvy = 0.0f; }                      // :321 (zero velocity: normalize(0))
     float fcx = 1.0f * nvx, fcy = 1.0f * nvy;                                      // Dissipation :332; Coriolis x0.0 (:327)
     float phi = 2.0f * (sy - 0.5f) * 3.14159f;                                     // :341
     // phi*3/2: Mesa merges the literal factors of the product chain into one constant (pinned with a probe shader)
     const float phi32 = (sy - 0.5f) * ((2.0f * 3.14159f) * (3.0f * 0.5f));
-    float windx = a.wind * -glsl::cos(phi32), windy = a.wind * glsl::sin(phi32);
+    float windx = a.wind * -gmath<X>::cos(phi32), windy = a.wind * gmath<X>::sin(phi32);
     if (fabsf(phi32) > 3.14159f) windx = -windx;
     if (fabsf(phi) > 3.14159f * 1.0f / 3.0f && fabsf(phi) < 3.1459f * 2.0f / 3.0f) windy = -windy;   // sic 3.1459 (:344)
     if (phi < 0.0f) windy = -windy;
@@ -258,8 +319,8 @@ __global__ __launch_bounds__(256) void k_advect(pass_args a, float k04)
     float stressx = 1.0f + (0.0001f * ax) * ax, stressy = 1.0f + (0.0001f * ay) * ay;   // :347, pow(x,2) -> x*x, associated as Mesa does
     float e = -1.0f / 24.0f * 2.0f;
     float2 o;
-    o.x = fcx + windx * (1.0f - glsl::pow(stressx, e)) - fcx * (1.0f - k04);            // :348
-    o.y = fcy + windy * (1.0f - glsl::pow(stressy, e)) - fcy * (1.0f - k04);
+    o.x = fcx + windx * (1.0f - gmath<X>::pow(stressx, e)) - fcx * (1.0f - k04);            // :348
+    o.y = fcy + windy * (1.0f - gmath<X>::pow(stressy, e)) - fcy * (1.0f - k04);
     a.vout[i] = o;
 }
 
@@ -405,7 +466,9 @@ int dmg_ocean_divergence(dmg_ocean *o)
 {
     int rc = require_terrain(o, "dmg_ocean_divergence");
     if (rc) return rc;
-    return launch_rows(o, k_divergence, make_args(o), o->gs ? 1 : 0, o->L - (o->gn ? 1 : 0));
+    const bool exact = (o->prm.quirks & DMG_QUIRK_EXACT_LLVMPIPE) != 0;
+    return exact ? launch_rows(o, k_divergence<true>, make_args(o), o->gs ? 1 : 0, o->L - (o->gn ? 1 : 0))
+                 : launch_rows(o, k_divergence<false>, make_args(o), o->gs ? 1 : 0, o->L - (o->gn ? 1 : 0));
 }
 
 int dmg_ocean_diffusion(dmg_ocean *o, int iters)
@@ -416,7 +479,7 @@ int dmg_ocean_diffusion(dmg_ocean *o, int iters)
     if (o->count > 1 && iters > o->ghost)
         return dmg_fail(DMG_EINVAL, "%d diffusion sweeps between halo refreshes but only %d ghost rows", iters, o->ghost);
     // after k sweeps since the last halo refresh the rows still computable lie k rows inside the ghost slabs
-    static const bool single = getenv("DMG_DIFFUSION_SINGLE") != nullptr;     // experiments: one sweep per launch
+    static const bool single = dmg_hook("DMG_DIFFUSION_SINGLE") != nullptr;     // experiments: one sweep per launch
     if (!single && o->prm.jacobi_kernel != DMG_JACOBI_SINGLE && ocean_tb_supported(o) && o->rowclass) {
         for (int k = 0; k < iters;) {                     // up to 8 sweeps per launch (ocean_diffusion_tb.hip)
             int m = iters - k < 8 ? iters - k : 8;
@@ -490,7 +553,8 @@ int dmg_ocean_advect(dmg_ocean *o)
     }
     float k04 = powf(0.4f, 1.0f / 24.0f);                  // pow(vec2(0.4),vec2(1.0/24)) (:348), a constant
     if (o->count > 1) DMG_HIP(hipMemsetAsync(o->oob_flag, 0, sizeof(int), o->ctx->stream));
-    rc = launch_rows(o, k_advect, a, o->gs, o->gs + (o->y1 - o->y0), k04);
+    rc = (o->prm.quirks & DMG_QUIRK_EXACT_LLVMPIPE) ? launch_rows(o, k_advect<true>, a, o->gs, o->gs + (o->y1 - o->y0), k04)
+                                                     : launch_rows(o, k_advect<false>, a, o->gs, o->gs + (o->y1 - o->y0), k04);
     if (rc) return rc;
     if (o->count > 1) {                                    // did a departure point leave the stored rows?
         int flag = 0;

@@ -721,17 +721,3 @@ __device__ __forceinline__ void st_open_unit(const st_args &a, v4f (*bring)[64],
 
 // constants of the kernel forms that the host-side planner (ocean_jacobi_stream_plan.hip) needs as well
 #define ST_TWIN_MAXROWS 232
-#define STP_BIAS 1024             // rows are stored + STP_BIAS (a window starts 8 rows below its segment)
-#define STP_MIN_STEAL 24          // rows left (not yet taken in by the owner) below which a segment is left alone
-#define STP_FIELD 26
-#define STP_MASK ((1u << STP_FIELD) - 1u)
-#define STN_EW 128
-#define STN_OW (STN_EW - 2 * TB_T)
-#define ST_PAD 16                 // rows of padding on both ends of the coefficient table: window rows -16 .. L+15 need no mapping
-__host__ __device__ __forceinline__ unsigned long long stp_word(int tx, int lo, int hi)
-{
-    return ((unsigned long long)(unsigned)tx << (2 * STP_FIELD)) | ((unsigned long long)(unsigned)(lo + STP_BIAS) << STP_FIELD) | (unsigned)(hi + STP_BIAS);
-}
-__device__ __forceinline__ int stp_hi(unsigned long long w) { return (int)((unsigned)w & STP_MASK) - STP_BIAS; }
-__device__ __forceinline__ int stp_lo(unsigned long long w) { return (int)((unsigned)(w >> STP_FIELD) & STP_MASK) - STP_BIAS; }
-__device__ __forceinline__ int stp_tx(unsigned long long w) { return (int)(w >> (2 * STP_FIELD)); }

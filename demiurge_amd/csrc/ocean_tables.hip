@@ -79,7 +79,7 @@ int ocean_upload_row_tables(dmg_ocean *o)
         std::vector<unsigned char> bad((size_t)L, 0);
         // tests only: DMG_DIV2_FORCE_BAD=<k> treats every k-th grid row as if it had no pair (rows without one are one in a
         // thousand: small grids may have none, and the path that handles them has to be exercised)
-        static const int force_bad = [] { const char *e = getenv("DMG_DIV2_FORCE_BAD"); return e ? atoi(e) : 0; }();
+        static const int force_bad = [] { const char *e = dmg_hook("DMG_DIV2_FORCE_BAD"); return e ? atoi(e) : 0; }();
         for (int l = 0; l < L; l++) {
             float *e = &j2[(size_t)l * 8];
             const bool forced = force_bad > 0 && ((o->y0 - o->gs + l) % force_bad) == 0;

@@ -86,6 +86,15 @@ enum { DMG_JACOBI_AUTO = 0, DMG_JACOBI_SINGLE = 1, DMG_JACOBI_BLOCKED = 2 };
  * the software GL path's pixels on e.g. the reference's default 1000x500 canvas.  Identical to the default kernels on
  * power-of-two grids; slow (not a performance path). */
 #define DMG_QUIRK_LLVMPIPE_RASTER 2
+/* Set by dmg_ocean_params_default: every pass reproduces the reference's pixels (as Mesa llvmpipe renders its GLSL) bit for bit.
+ * north_star asks for 1e-5 relative; the bits cost the trig-heavy passes most of their time (advect: 530 vector instructions per
+ * cell, two thirds of them Mesa's sine / cosine / pow expansions and IEEE division sequences; divergence: four IEEE divisions by
+ * row constants per cell).  Cleared: advect and divergence keep the reference's expressions -- Mesa's arcsine and arctangent
+ * polynomials included, which are approximations of their own -- but take sine, cosine, log2, exp2, reciprocals and square roots from
+ * the hardware (1 ulp): results within 1e-5 of the exact rendering after a whole outer step (tests/test_gpu_ocean_passes.py), advect
+ * 2-3x, divergence ~1.5x sooner.  The pressure solve, diffusion and subDiv (whose coastline snapping turns on comparisons of
+ * angles: no tolerance there) are the same in both renderings. */
+#define DMG_QUIRK_EXACT_LLVMPIPE 4
 
 /* field ids for dmg_ocean_halo */
 enum { DMG_F_PRESSURE = 0, DMG_F_DIVW = 1, DMG_F_TERRAIN = 2, DMG_F_V = 3 /* interleaved (vx,vy), 8 B per cell */,
@@ -101,6 +110,16 @@ const char *dmg_last_error(void);
  * first sets the variable itself.  The library never edits the environment on its own.  Returns DMG_OK, or DMG_ESTATE when the
  * variable is already set to less than 8. */
 int dmg_runtime_init(void);
+/* The library's behaviour does not depend on its host's environment, with two documented exceptions: DMG_MULTI_TIMEOUT_MS (how long
+ * a band waits without progress before it gives its neighbours up, dmg_multi_destroy below) and DMG_ST_TWIN=0 (plain instead of twin
+ * units for the band launches of the pressure solve: the switch a first run between two devices can fall back on).  Everything a
+ * test or an experiment needs to force -- failure and delay injection (DMG_MULTI_FAIL, DMG_ST_TWIN_FAIL, DMG_MULTI_FAKE_LINK_US ...),
+ * a kernel form (DMG_TB_SHAPE, DMG_TEMPERATURE_LITERAL ...), the unit cut's constants, traces -- goes through this call: a
+ * process-wide table of name -> value that the library consults where it used to read the environment.  Names start with DMG_;
+ * value NULL removes a name.  Most hooks are read once, when the code that looks at them first runs: set them before the first
+ * handle is created.  The Python test binding (demiurge_amd/capi.py) forwards the DMG_* variables of ITS environment here when it
+ * loads the library; the C++ adapters never call it. */
+int dmg_debug_set(const char *name, const char *value);
 
 /* Binds HIP device `device_id`.  Work is enqueued on `stream`: an existing hipStream_t of the host program
  * (NULL = the device's default stream, which is what e.g. torch.cuda.current_stream() is unless changed), or,

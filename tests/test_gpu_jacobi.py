@@ -336,9 +336,9 @@ def test_llvmpipe_raster_quirk(dev, oracle):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("canvas", ["globe", "belt"])
-@pytest.mark.parametrize("form", ["stream", "stream-n", "stream-p"])
+@pytest.mark.parametrize("form", ["stream"])
 def test_streaming_forms_forced_are_bitwise(form, canvas):
-    """Every form of the streaming kernel (units, narrow units, persistent waves with work stealing), forced for all
+    """The streaming kernel (round 5 retired its narrow and persistent forms: no launch of a BASELINE size ever chose them), forced for all
     8-sweep launches of a 2048x1024 solve through DMG_TB_SHAPE, against single-sweep launches, bit for bit, on the globe
     (rows beyond a pole are the pole rows shifted by W/2) and on a latitude belt (rows beyond an edge are plain mirrors).
     The environment is read once per process, hence the child process (tools/stream_check.py does the comparison)."""
@@ -348,7 +348,7 @@ def test_streaming_forms_forced_are_bitwise(form, canvas):
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "stream_check.py"), "2048", "1024", "64", "survey", canvas], cwd=root, env=env,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    kern = {"stream": "k_jacobi_stream ", "stream-n": "k_jacobi_stream_n", "stream-p": "k_jacobi_stream_p"}[form]
+    kern = {"stream": "k_jacobi_stream "}[form]
     assert kern.strip() in r.stdout and "bit-identical" in r.stdout, r.stdout[-2000:]
 
 
@@ -376,15 +376,15 @@ def _stream_worker(env_extra, cases, timeout=900):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("form", ["stream", "stream-n", "stream-p"])
+@pytest.mark.parametrize("form", ["stream"])
 def test_streaming_forms_forced_vs_oracle(form):
-    """every form of the streaming kernel, forced for all 8-sweep launches, against the ORACLE on
+    """the streaming kernel, forced for all 8-sweep launches, against the ORACLE on
     coast-heavy inputs with random starting pressure (tests/stream_worker.py: 20 random geometries, salt-and-pepper land
     at 2048x1024 on globe and belt, band splits with ghost 8 and 16), and against the reference's own llvmpipe output
     after its full 5000 sweeps (256x128 golden, 625 streaming launches)."""
     # (DMG_ST_TWIN=0: the plain units; the twin units that small launches take by default have their own test below)
     out = _stream_worker({"DMG_TB_SHAPE": form, "DMG_ST_TWIN": "0"}, ["random", "pepper", "golden", "bands"])
-    kern = {"stream": "k_jacobi_stream", "stream-n": "k_jacobi_stream_n", "stream-p": "k_jacobi_stream_p"}[form]
+    kern = {"stream": "k_jacobi_stream"}[form]
     assert "'%s'" % kern in out, out[-1500:]
 
 

@@ -318,3 +318,67 @@ def test_blocked_kernels_vs_reference_hashes(dev, name):
     for key, a in (("step_v", r["v"]), ("step_pressure", r["pressure"]), ("step_divw", r["divw"])):
         assert np.array_equal(np.ascontiguousarray(a)[::8, ::8], G[key + "_sample"]), key
         assert sha(a) == str(G[key + "_sha256"]), key
+
+
+# ---- DMG_QUIRK_EXACT_LLVMPIPE cleared: the trig-heavy passes on the hardware's transcendentals ----
+def _fast(capi):
+    return capi.QUIRK_DIFFUSION_SCALAR_RHS            # (the reference's quirks without the exact-rendering bit)
+
+
+@pytest.mark.parametrize("name", ["ocean_passes_128x64_full", "ocean_passes_128x64_region", "ocean_advect_fast_128x64_full"])
+def test_tolerance_mode_advect_and_divergence_against_the_reference_pixels(dev, name):
+    """north_star asks for 1e-5 relative to the reference's GLSL output; the default rendering pays for every bit.  With
+    DMG_QUIRK_EXACT_LLVMPIPE cleared advect and divergence keep the reference's expressions (Mesa's asin / atan polynomials included)
+    and take sin, cos, log2, exp2, reciprocals and square roots from the hardware: within 1e-5 (max norm, relative to the field's
+    largest value) of the llvmpipe goldens -- and not the same bits, or the switch would be doing nothing."""
+    capi, ctx = dev
+    G = load_golden(name)
+    grid, o = make(capi, ctx, G, quirks=_fast(capi))
+    o.set_velocity(G["v"])
+    o.advect()
+    v = o.get(want=("v",))["v"]
+    assert relerr(v, G["advect"]) <= 1e-5, relerr(v, G["advect"])
+    assert not np.array_equal(v, G["advect"])
+    o.close()
+    if "divergence" in G:
+        for pf, key in ((100.0, "divergence"), (7.5, "divergence_pf7")):
+            grid, o = make(capi, ctx, G, pressurefactor=pf, quirks=_fast(capi))
+            o.set_velocity(G["v"])
+            o.divergence()
+            d = o.get(want=("divw",))["divw"]
+            assert relerr(d, G[key]) <= 1e-5, (key, relerr(d, G[key]))
+            o.close()
+
+
+def test_tolerance_mode_after_a_whole_outer_step_at_4096x2048(dev):
+    """... and after everything an outer step does with those two passes' outputs (50 diffusion sweeps, 200 Jacobi sweeps on the
+    divergence, subDiv's coastline snapping on the result) at 8.4 M cells: velocity, pressure and divergence within 1e-5 of the
+    exact rendering's.  (subDiv snaps a coastal cell's velocity to a compass direction by comparing angles -- a decision, not a
+    value -- so cells whose angle sits within rounding of a threshold may snap differently: they are counted, and must be a
+    handful.)"""
+    capi, ctx = dev
+    from demiurge_amd import synth
+    W, H = 4096, 2048
+    grid = capi.make_grid(W, H)
+    img = synth.terrain(W, H)
+    v0 = synth.velocity(W, H)
+    v0[img > 0] = 0
+    out = []
+    for quirks in (None, _fast(capi)):
+        prm = capi.default_ocean_params()
+        prm.jacobi_iters, prm.diffusion_iters = 200, 50
+        if quirks is not None:
+            prm.quirks = quirks
+        o = capi.Ocean(ctx, grid, params=prm)
+        o.set_terrain(img)
+        o.set_velocity(v0)
+        o.step(1)
+        out.append(o.get())
+        o.close()
+    exact, fast = out
+    assert relerr(fast["divw"], exact["divw"]) <= 1e-5 and relerr(fast["pressure"], exact["pressure"]) <= 1e-5
+    dv = np.abs(fast["v"].astype(np.float64) - exact["v"]).max(axis=2)
+    snapped = dv > 1e-5 * np.abs(exact["v"]).max()
+    assert snapped.sum() <= 50, int(snapped.sum())
+    assert relerr(fast["v"][~snapped], exact["v"][~snapped]) <= 1e-5
+    assert not np.array_equal(fast["v"], exact["v"])

@@ -2,6 +2,7 @@
 
   python tools/cpu_lines.py refgl <threads>     the reference's own GLSL on llvmpipe (needs oracle/_ref + Mesa)
   python tools/cpu_lines.py port <threads>      the OpenMP C restatement (oracle/), any host
+  python tools/cpu_lines.py configs <threads>   the reference's CPU path beside BASELINE configs 2, 3 and 5 (bounded samples)
 
 TEST/BENCH INFRASTRUCTURE: times the checkers, never the product."""
 import json
@@ -55,6 +56,49 @@ def refgl_lines(threads):
     emit(line="llvmpipe ocean outer step 1024x512 (advect + 50 diffusion + divergence + 100 jacobi + subDiv)", seconds=dt, threads=threads)
 
 
+def config_lines(threads):
+    """the reference's CPU path beside BASELINE configs 2, 3 and 5 (VERDICT r4 "What's missing" 4): bounded samples, each saying how
+    it extends to the config's own counts"""
+    os.environ["LP_NUM_THREADS"] = str(threads)
+    import oracle
+    import refgl
+    oracle.set_threads(threads)
+    rend = refgl.RefGL.get().renderer().split("|")[0].strip()
+    # config 2: one round of cpufilter::run at 4096x2048 = FlowFilter (CPU code in the reference: the restatement, flow_oracle.cpp, one
+    # thread like the reference's recursion) + the erosion / uplift shader (llvmpipe)
+    W, H = 4096, 2048
+    h = (synth.terrain(W, H) * 100 + synth.lcg_uniform(W * H, 5).reshape(H, W) * 3).astype(np.float32)
+    g = oracle.grid(W, H)
+    t0 = time.time(); flow = oracle.flow_accumulate(g, np.where(h > 0, h / 50, h).astype(np.float32), 0.5, 0.5)["flow"]; t_flow = time.time() - t0
+    up = (np.maximum(h, 0) / 50).astype(np.float32)
+    refgl.erosion_shader(h, flow, up)
+    t0 = time.time(); refgl.erosion_shader(h, flow, up); t_shader = time.time() - t0
+    emit(config=2, line="erosion round 4096x2048 on the CPU: FlowFilter restatement (oracle/flow_oracle.cpp, 1 thread, incl. its two GLSL-equivalent passes "
+         "in C) + the erosion shader on %s" % rend, seconds_flow=t_flow, seconds_shader=t_shader, seconds_per_round=t_flow + t_shader,
+         seconds_for_1000_rounds=1000 * (t_flow + t_shader), threads=threads)
+    # config 3: the outer step at 8192x4096 on llvmpipe: every pass once, 20 of the 5000 Jacobi sweeps timed, the rest at that rate
+    W, H = 8192, 4096
+    img = synth.terrain(W, H)
+    v = synth.velocity(W, H); v[img > 0] = 0
+    t0 = time.time(); v1 = refgl.ocean_advect(img, v); t_adv = time.time() - t0
+    t0 = time.time(); v2 = refgl.ocean_diffusion(img, v1, 50); t_dif = time.time() - t0
+    t0 = time.time(); d = refgl.ocean_divergence(img, v2); t_div = time.time() - t0
+    t = []; p = refgl.ocean_jacobi(img, d, 20, timing=t); t_jac = t[0] / 20
+    t0 = time.time(); refgl.ocean_subdiv(img, v2, p); t_sub = time.time() - t0
+    emit(config=3, line="ocean outer step 8192x4096 on %s: advect, 50 diffusion sweeps, divergence, subDiv timed whole (incl. texture up/download); "
+         "20 Jacobi sweeps timed, 5000 at that rate" % rend, seconds_advect=t_adv, seconds_diffusion50=t_dif, seconds_divergence=t_div,
+         seconds_subdiv=t_sub, seconds_per_jacobi_sweep=t_jac, seconds_outer_step=t_adv + t_dif + t_div + t_sub + 5000 * t_jac, threads=threads)
+    del img, v, v1, v2, d, p
+    # config 5 pieces at 16384x8192: the climate step on llvmpipe (3 steps), the tectonics step would need W x W RGBA textures (4 GiB each)
+    W, H = 16384, 8192
+    terr = (synth.terrain(W, H) * 100).astype(np.float32)
+    T0 = (15 - 40 * np.abs(np.linspace(-1, 1, H, dtype=np.float32))[:, None] + np.zeros((1, W), np.float32)).astype(np.float32)
+    refgl.temperature(T0, terr, 0, 1)
+    t0 = time.time(); refgl.temperature(T0, terr, 0, 3); t_clim = (time.time() - t0) / 3
+    emit(config=5, line="climate step 16384x8192 on %s (3 steps incl. texture up/download; the reference recompiles the shader every ten steps, not counted)" % rend,
+         seconds_per_step=t_clim, seconds_per_year_of_15000_steps=15000 * t_clim, threads=threads)
+
+
 def port_lines(threads):
     import oracle
     oracle.set_threads(threads)
@@ -74,4 +118,4 @@ def port_lines(threads):
 if __name__ == "__main__":
     kind, threads = sys.argv[1], int(sys.argv[2])
     emit(host_cpus=os.cpu_count(), affinity=len(os.sched_getaffinity(0)))
-    (refgl_lines if kind == "refgl" else port_lines)(threads)
+    {"refgl": refgl_lines, "port": port_lines, "configs": config_lines}[kind](threads)

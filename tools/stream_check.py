@@ -1,7 +1,7 @@
 """Bitwise check of the 8-sweep Jacobi launch against single-sweep launches at a given size (GPU).
 
 usage: python tools/stream_check.py [W H [sweeps [survey|ocean [globe|belt]]]]
-(environment: DMG_TB_SHAPE=stream|stream-n|stream-p forces a streaming form; belt = latitudes -1 .. 1.2 rad, both edges
+(environment: DMG_TB_SHAPE=stream forces the streaming kernel; belt = latitudes -1 .. 1.2 rad, both edges
  clamp instead of reflecting through a pole)
 """
 import sys, time
