@@ -9,14 +9,17 @@
 // instead of 12, read by both.  Each row of pressure and right-hand side crosses HBM once per SIXTEEN sweeps; the price is a strip
 // of 224 output columns instead of 240 (the halo in x is 16) and a window of n + 32 rows instead of n + 16.
 //
-// What it measured (all-ocean 16384x8192, units of 200 rows, same box, per 16 sweeps): two plain launches 733-787 us; this form
-// bit-identical to them and NOT faster -- 801 us with one s_barrier per step, 806 us with the two LDS counters below instead
-// (hand-over slots 2), 885 us with four slots (the larger ring costs a workgroup per CU).  Per-wave clocks (DMG_DEEP_PROF): a
-// unit takes 261 us, each wave spends 15-19 % of it waiting for its partner whatever the slack, and its ACTIVE steps take 1.8 us
-// where the same two programs run at 1.4 us when nothing couples them (a timing experiment with no synchronisation at all,
-// wrong results: 516-526 us per 16 sweeps, 4.1 M).  So the bytes ARE what the plain kernel waits for -- halving them is worth
-// a third of the launch -- but two waves that must meet every step do not keep the pace of two that need not; the prototype
-// covers open water only and was not widened.  DESIGN.md 4.1b has the account.
+// What it measured (all-ocean 16384x8192, units of 200 rows, same box, per 16 sweeps): two plain launches 733-788 us; this form,
+// bit-identical to them, 801 us with one s_barrier per step, 806 us with the two LDS counters below instead (two hand-over slots),
+// 885 us with four slots (the larger ring costs a workgroup per CU), 792 us with four pairs per workgroup so that the two waves of a
+// pair share a SIMD (DP_WG=4) -- and 783-797 us with every synchronisation instruction switched off at run time (DMG_DEEP_NOSPIN:
+// wrong results): the pair does not lose its time waiting.  It is as long as the plain kernel because it issues as many
+// instructions per sweep (one arrival instead of two per sixteen levels, against 224 instead of 240 useful columns and a window of
+// n + 32 rows) -- HALF THE HBM BYTES AND THE SAME TIME.  The streaming kernel is bound by instruction issue (4.6 clocks of SIMD time per
+// vector instruction at two waves per SIMD, where independent packed instructions measure 4.4-5.2), not by its bytes: round 4's
+// reading is revised.  (A build with the synchronisation compiled OUT ran 516-526 us and looked like proof of the
+// opposite for an hour: without it the front wave's hand-over stores are dead stores, and the compiler removes the sweeps behind them.)
+// The prototype covers open water only and was not widened.
 #ifdef DMG_EXPERIMENTS
 #ifndef DP_D
 #define DP_D 2                        // hand-over slots (pairs of rows); the shared ring of right-hand sides needs 2 * DP_D + 20 rows
@@ -41,10 +44,13 @@
 // results are then wrong, the grid drains, and the launch's error word says so).
 #define DP_SPIN_MAX (1 << 22)
 struct dp_sync { int prod, cons, err, pad; };
+__constant__ int dp_nospin = 0;
 __device__ __forceinline__ void dp_wait_at_least(const int *word, int want, int *err, unsigned long long *acc = nullptr)
 {
     const unsigned long long t0 = acc ? __builtin_amdgcn_s_memrealtime() : 0ull;
     int spins = 0;
+    if (dp_nospin & 4) return;                       // experiments (wrong results): not even a look
+    if (dp_nospin) { if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < want) *err = 2; return; }   // ... look once, never wait
     while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < want) {
         __builtin_amdgcn_s_sleep(1);
         if (++spins > DP_SPIN_MAX) { *err = 1; break; }
@@ -53,7 +59,8 @@ __device__ __forceinline__ void dp_wait_at_least(const int *word, int want, int 
 }
 __device__ __forceinline__ void dp_publish(int *word, int value, int lane)
 {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's LDS writes (reads) of the pair are done; the global loads stay in flight
+    if (!(dp_nospin & 2)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's LDS writes (reads) of the pair are done; the global loads stay in flight
+    if (dp_nospin & 8) return;                       // experiments: no flag store either
     if (lane == 0) __hip_atomic_store(word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
@@ -128,17 +135,34 @@ __device__ __forceinline__ void dp_back_step(const st_args &a, st_state &z, v4f 
     DP_BARRIER();
 }
 
+// DP_WG pairs per workgroup.  1: a workgroup is one pair (its two waves land on different SIMDs, each beside a wave of another
+// pair).  4: a workgroup is a whole CU's worth, waves w and w + 4 are a pair -- the CU deals a workgroup's waves round its four
+// SIMDs, so the two waves of a pair SHARE a SIMD and whichever of them waits leaves the SIMD to the other.
+#ifndef DP_WG
+#define DP_WG 1
+#endif
 template <int DV, int SYNC>
-__global__ __launch_bounds__(128, 2) void k_jacobi_deep_open(st_args a)
+__global__ __launch_bounds__(128 * DP_WG, DP_WG == 1 ? 2 : 1) void k_jacobi_deep_open(st_args a)
 {
-    __shared__ v4f bring[ST_RING][64];
-    __shared__ v4f xring[DP_D][2][64];               // [pair mod DP_D][row of the pair][lane]
-    __shared__ v4f ktab[ST_MAXROWS + 2 * DP_T + 8];   // the FRONT wave's window; the back wave's starts eight entries in
-    __shared__ dp_sync sync;
-    if (threadIdx.x == 0) { sync.prod = 0; sync.cons = 0; sync.err = 0; }
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    __shared__ v4f bring_[DP_WG][ST_RING][64];
+    __shared__ v4f xring_[DP_WG][DP_D][2][64];        // [pair mod DP_D][row of the pair][lane]
+    __shared__ v4f ktab_[DP_WG][ST_MAXROWS + 2 * DP_T + 8];   // the FRONT wave's window; the back wave's starts eight entries in
+    __shared__ dp_sync sync_[DP_WG];
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int pr = DP_WG == 1 ? 0 : (wv & (DP_WG - 1));
+    const int wave = DP_WG == 1 ? wv : (wv / DP_WG);   // 0: front, 1: back
+    v4f (*bring)[64] = bring_[pr];
+    v4f (*xring)[2][64] = xring_[pr];
+    v4f *ktab = ktab_[pr];
+    dp_sync &sync = sync_[pr];
     const int lane = threadIdx.x & 63;
-    const int4 u = a.units[blockIdx.x];
+    if (wave == 0 && lane == 0) { sync.prod = 0; sync.cons = 0; sync.err = 0; }
+    const int ui = (int)blockIdx.x * DP_WG + pr;
+    if (DP_WG > 1 && ui >= a.nseg0) {                 // a pair without a unit (the list's last workgroup): the one barrier, then out
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        return;
+    }
+    const int4 u = a.units[ui];
     const int tx = __builtin_amdgcn_readfirstlane(u.x), r0 = __builtin_amdgcn_readfirstlane(u.y), r1 = __builtin_amdgcn_readfirstlane(u.z);
     const int W = a.W;
     const int nsb = (((r1 - r0) + 2 * TB_T + 3) / 4) * 2;        // the back wave's steps: its window is rows [r0 - 8, r1 + 8)
@@ -214,7 +238,7 @@ __global__ __launch_bounds__(128, 2) void k_jacobi_deep_open(st_args a)
         }
     }
     if (a.prof && lane == 0) {                       // experiments: {start, end, clocks spent waiting for the partner, hardware id} per wave
-        unsigned long long *q = a.prof + 4 * (2 * (size_t)blockIdx.x + wave);
+        unsigned long long *q = a.prof + 4 * (2 * (size_t)ui + wave);
         q[0] = t_begin; q[1] = __builtin_amdgcn_s_memrealtime(); q[2] = waited;
         q[3] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) | (unsigned)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
     }
@@ -261,10 +285,14 @@ int ocean_launch_deep_open(dmg_ocean *o, int lo, int hi, int seg, int from, hipS
     a.prof = nullptr;
     if (prof_path && !prof_done && tl.n > 1024 && hipMalloc((void **)&a.prof, (size_t)tl.n * 2 * 4 * 8) != hipSuccess) a.prof = nullptr;
     static const int sync_env = [] { const char *e = dmg_hook("DMG_DEEP_SYNC"); return e ? atoi(e) : 2; }();      // experiments: 0 none (wrong results), 1 a barrier per step, 2 counters (default)
-    if (sync_env == 0) hipLaunchKernelGGL((k_jacobi_deep_open<1, 0>), dim3((unsigned)tl.n), dim3(128), 0, st, a);
-    else if (sync_env == 1) hipLaunchKernelGGL((k_jacobi_deep_open<1, 1>), dim3((unsigned)tl.n), dim3(128), 0, st, a);
-    else if (div2) hipLaunchKernelGGL((k_jacobi_deep_open<1, 2>), dim3((unsigned)tl.n), dim3(128), 0, st, a);
-    else hipLaunchKernelGGL((k_jacobi_deep_open<0, 2>), dim3((unsigned)tl.n), dim3(128), 0, st, a);
+    a.nseg0 = tl.n;
+    static const int nospin = [] { const char *e = dmg_hook("DMG_DEEP_NOSPIN"); return e ? atoi(e) : 0; }();
+    if (nospin) { static bool set = false; if (!set) { DMG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(dp_nospin), &nospin, sizeof nospin)); set = true; } }
+    const dim3 grid((unsigned)((tl.n + DP_WG - 1) / DP_WG)), block(128 * DP_WG);
+    if (sync_env == 0) hipLaunchKernelGGL((k_jacobi_deep_open<1, 0>), grid, block, 0, st, a);
+    else if (sync_env == 1 && DP_WG == 1) hipLaunchKernelGGL((k_jacobi_deep_open<1, 1>), grid, block, 0, st, a);
+    else if (div2) hipLaunchKernelGGL((k_jacobi_deep_open<1, 2>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((k_jacobi_deep_open<0, 2>), grid, block, 0, st, a);
     DMG_HIP(hipGetLastError());
     if (a.prof) {
         prof_done = true;

@@ -90,9 +90,9 @@ enum { DMG_JACOBI_AUTO = 0, DMG_JACOBI_SINGLE = 1, DMG_JACOBI_BLOCKED = 2 };
  * north_star asks for 1e-5 relative; the bits cost the trig-heavy passes most of their time (advect: 530 vector instructions per
  * cell, two thirds of them Mesa's sine / cosine / pow expansions and IEEE division sequences; divergence: four IEEE divisions by
  * row constants per cell).  Cleared: advect and divergence keep the reference's expressions -- Mesa's arcsine and arctangent
- * polynomials included, which are approximations of their own -- but take sine, cosine, log2, exp2, reciprocals and square roots from
- * the hardware (1 ulp): results within 1e-5 of the exact rendering after a whole outer step (tests/test_gpu_ocean_passes.py), advect
- * 2-3x, divergence ~1.5x sooner.  The pressure solve, diffusion and subDiv (whose coastline snapping turns on comparisons of
+ * polynomials included, which are approximations of their own, and gallivm's sine / cosine (the hardware's are good to 1e-6 absolute:
+ * 2.6e-3 cells of longitude at 16384 wide) -- but take log2, exp2, reciprocals and square roots from the hardware (1 ulp): results
+ * within 1e-5 of the exact rendering after a whole outer step (tests/test_gpu_ocean_passes.py).  The pressure solve, diffusion and subDiv (whose coastline snapping turns on comparisons of
  * angles: no tolerance there) are the same in both renderings. */
 #define DMG_QUIRK_EXACT_LLVMPIPE 4
 
