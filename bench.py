@@ -764,13 +764,13 @@ def worker(args):
             roof["shape_ceiling"] = HBM_ROWS_GBS
             roof["frac_of_shape_ceiling"] = roof["achieved"] / HBM_ROWS_GBS
             roof["note"] = ("8 sweeps per launch on chip: `achieved` is the HBM traffic the launch really moves (PMC) over its "
-                            "duration.  Round 4 measured what binds it: a program with a third fewer instructions per step finishes "
-                            "its waves 16 % sooner and the launch no sooner -- it waits for its bytes, fetched as 1-KB pieces of rows "
-                            "64 KB apart, for which this part reaches 5.5-5.6 TB/s (`shape_ceiling`), not the 8 TB/s of `peak`.  "
-                            "Fewer bytes per launch therefore LOWER `frac` while the solve gets faster (round 3: 1.475 -> 1.364 GB, "
-                            "round 4: -> 1.33 GB).  The SURVEY 8d model (16 B per cell-sweep) stops bounding a kernel that does "
-                            "8 sweeps per HBM pass: `algorithmic_x_peak`; the HBM-bound form the 60 % target is stated for is "
-                            "`roofline_single`")
+                            "duration; compare it with `copy_ceiling`, a device copy timed in this run -- the launch moves its bytes at "
+                            "about the rate this box copies at.  Round 5 built a form with HALF the bytes per sweep (16 sweeps per trip, "
+                            "two waves per unit through LDS, bit-identical): it takes the same time, because the kernel's instruction "
+                            "issue (4.6 clocks of SIMD time per instruction at two waves per SIMD) is a second wall at the same place "
+                            "(DESIGN.md 4.1b, profiles/r05_deep_form.txt).  The SURVEY 8d model (16 B per cell-sweep) stops bounding a "
+                            "kernel that does 8 sweeps per HBM pass: `algorithmic_x_peak`; the HBM-bound form the 60 % target is stated "
+                            "for is `roofline_single`")
         else:
             roof["achieved"], roof["frac"] = None, None
             roof["note"] = "no PMC traffic for this configuration (%s); see algorithmic_x_peak and fp32" % tsrc

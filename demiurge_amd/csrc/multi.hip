@@ -457,7 +457,9 @@ static int store_alloc(dmg_multi *m, int i)
     // The landing slots are written by ANOTHER GPU while a kernel of this one is resident and about to read them: that is
     // what fine-grained device memory is for (coarse-grained memory is only coherent at kernel boundaries); uncached device
     // memory is the fall-back, and there is no coarse-grained one
-    if (hipExtMallocWithFlags((void **)&sb.land_base, 4 * m->slot_bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+    static const bool coarse_ab = dmg_hook("DMG_STORE_COARSE") != nullptr;      // A/B measurements only: round 4's coarse-grained slots
+    if (coarse_ab) { if (hipMalloc((void **)&sb.land_base, 4 * m->slot_bytes) != hipSuccess) return dmg_fail(DMG_ENOMEM, "store transport: hipMalloc failed"); }
+    else if (hipExtMallocWithFlags((void **)&sb.land_base, 4 * m->slot_bytes, hipDeviceMallocFinegrained) != hipSuccess) {
         (void)hipGetLastError();
         sb.land_base = nullptr;
         if (hipExtMallocWithFlags((void **)&sb.land_base, 4 * m->slot_bytes, hipDeviceMallocUncached) != hipSuccess) {

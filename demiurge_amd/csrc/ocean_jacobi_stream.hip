@@ -249,8 +249,13 @@ bool ocean_stream_enabled()
 static int ocean_stream_flipped_tables(dmg_ocean *o)
 {
     if (o->jcoef_f) return DMG_OK;
+    // all four tables into locals first: they are published together or not at all (a half-built set would hand null mirrored
+    // tables to every later twin or southward launch)
     const int L = o->L;
     const size_t nj = (size_t)L * 8;
+    float *jf_d = nullptr, *j2f_d = nullptr;
+    unsigned char *bad_d = nullptr, *cls_d = nullptr;
+    auto drop = [&](int rc) { for (void *q : { (void *)jf_d, (void *)j2f_d, (void *)bad_d, (void *)cls_d }) if (q) (void)hipFree(q); return rc; };
     std::vector<float> j(nj), jf(nj);
     auto flip_j = [&](const float *src, float **dst) -> int {
         DMG_HIP(hipMemcpy(j.data(), src, nj * sizeof(float), hipMemcpyDeviceToHost));
@@ -261,22 +266,24 @@ static int ocean_stream_flipped_tables(dmg_ocean *o)
     };
     DMG_HIP(hipStreamSynchronize(o->ctx->stream));
     int rc;
-    if ((rc = flip_j(o->jcoef, &o->jcoef_f)) || (rc = flip_j(o->jcoef2, &o->jcoef2_f))) return rc;
+    if ((rc = flip_j(o->jcoef, &jf_d)) || (rc = flip_j(o->jcoef2, &j2f_d))) return drop(rc);
     {
         std::vector<unsigned char> b((size_t)L, 0), bf((size_t)L);
-        DMG_HIP(hipMemcpy(b.data(), o->rowbad, (size_t)L, hipMemcpyDeviceToHost));
+        if (hipMemcpy(b.data(), o->rowbad, (size_t)L, hipMemcpyDeviceToHost) != hipSuccess) return drop(dmg_fail(DMG_EHIP, "mirrored row tables: download failed"));
         for (int l = 0; l < L; l++) bf[l] = b[L - 1 - l];
-        DMG_HIP(hipMalloc((void **)&o->rowbad_f, (size_t)L));
-        DMG_HIP(hipMemcpy(o->rowbad_f, bf.data(), (size_t)L, hipMemcpyHostToDevice));
+        if (hipMalloc((void **)&bad_d, (size_t)L) != hipSuccess || hipMemcpy(bad_d, bf.data(), (size_t)L, hipMemcpyHostToDevice) != hipSuccess)
+            return drop(dmg_fail(DMG_ENOMEM, "mirrored row tables: allocation failed"));
     }
     if (!o->rowclass_host.empty()) {
         const size_t n = o->rowclass_host.size(), tiles_x = n / (size_t)L;
         std::vector<unsigned char> cf(n);
         for (size_t tx = 0; tx < tiles_x; tx++)
             for (int l = 0; l < L; l++) cf[tx * L + l] = o->rowclass_host[tx * L + (L - 1 - l)];
-        DMG_HIP(hipMalloc((void **)&o->rowclass_f, n));
-        DMG_HIP(hipMemcpy(o->rowclass_f, cf.data(), n, hipMemcpyHostToDevice));
+        if (hipMalloc((void **)&cls_d, n) != hipSuccess || hipMemcpy(cls_d, cf.data(), n, hipMemcpyHostToDevice) != hipSuccess)
+            return drop(dmg_fail(DMG_ENOMEM, "mirrored row tables: allocation failed"));
     }
+    o->jcoef2_f = j2f_d; o->rowbad_f = bad_d; o->rowclass_f = cls_d;
+    o->jcoef_f = jf_d;                                   // (the guard above reads this one: last)
     return DMG_OK;
 }
 

@@ -297,7 +297,8 @@ typedef struct dmg_multi dmg_multi;
                                                   of one device that wait on each other are time-sliced by its scheduler */
 /* One process, n_bands bands; device_ids[i] = HIP device of band i (ids may repeat with DMG_MULTI_PEER / _LOOPBACK).
  * ghost = halo rows per band side: the Jacobi solve exchanges every `ghost` sweeps (rounded down to whole 8-sweep
- * launches), and advect may reach at most `ghost` rows (dmg_multi_step checks this on all bands before it moves). */
+ * launches).  An advect that reaches beyond `ghost` rows gathers from a deeper copy of v that dmg_multi_step exchanges for that
+ * step (dmg_ocean_advect_prepare). */
 int dmg_multi_create(int n_bands, const int *device_ids, const dmg_grid *grid, const dmg_ocean_params *params, int ghost, int flags,
                      dmg_multi **out);
 /* One process per GPU: rank 0 calls dmg_multi_unique_id, the host hands the 128 bytes to every rank (torch.distributed,
@@ -327,7 +328,11 @@ int dmg_multi_set_velocity(dmg_multi *m, const float *vx, const float *vy);
 int dmg_multi_get(dmg_multi *m, float *vx, float *vy, float *pressure, float *divw);
 int dmg_multi_sync(dmg_multi *m);
 /* OceanCurrents::jacobi (:437-509) over the bands: pressure := 0 when zero_first, then `iters` sweeps, ghost rows refreshed
- * every block.  Asynchronous on the bands' streams (dmg_multi_sync / dmg_multi_get wait). */
+ * every block.  Asynchronous on the bands' streams (dmg_multi_sync / dmg_multi_get wait) -- up to a point: a band's host thread
+ * runs at most 128 halo exchanges ahead of its GPU (the progress ring the failure detection reads), so a call that queues more
+ * than that -- this one from ~4000 sweeps at ghost 32, dmg_multi_climate_steps from 128 x ghost steps, dmg_multi_step always --
+ * returns when all but its last 128 exchanges have completed.  A host that overlaps other work with these calls gives them
+ * a thread. */
 int dmg_multi_jacobi(dmg_multi *m, int iters, int zero_first);
 /* OceanCurrents::run body (:155-209) n_outer times over the bands.  Before each advect the bands all-reduce the longest
  * back-trace (|v| * timestep, :298-299): if it exceeds `ghost` every rank returns DMG_EINVAL with its state untouched. */

@@ -1,7 +1,7 @@
 # the evidence set of a round: run on the GPU box (gpurun -- 'bash tools/round_profiles.sh'), then copy what is to be judged
 # from gpurun_out/ into profiles/.  R = round tag.
 set -o pipefail
-R=${R:-r04}
+R=${R:-r05}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 # PART=tests: the GPU test suite alone (a gpurun call is at most 1200 s); PART=twin: the twin units' A/B; PART=profiles (default): everything else
 if [ "${PART:-profiles}" = tests ]; then
