@@ -228,8 +228,41 @@ def case_twin(capi, ctx, oracle, names):
     return ok
 
 
+class _OracleMemo:
+    """The oracle's Jacobi solve, remembered on disk for the length of a test session: half a dozen tests run these same cases under
+    different kernel switches, each in a child process of its own, and the CPU solve (seconds to tens of seconds per case on the
+    box's 16 cores) is most of their time.  The key is a hash of everything the solve reads."""
+
+    def __init__(self, oracle):
+        import hashlib, tempfile
+        self.o, self.hashlib = oracle, hashlib
+        self.dir = Path(tempfile.gettempdir()) / "dmg_oracle_memo"
+        self.dir.mkdir(exist_ok=True)
+
+    def __getattr__(self, name):
+        return getattr(self.o, name)
+
+    def ocean_jacobi(self, g, img, divw, iters, p0=None, rows=False, nthreads=0):
+        h = self.hashlib.sha1()
+        h.update(repr((g.W, g.H, tuple(g.coords), g.circumference, iters, bool(rows))).encode())
+        for a in (img, divw, p0):
+            h.update(b"-" if a is None else np.ascontiguousarray(a, dtype=np.float32).tobytes())
+        f = self.dir / (h.hexdigest() + ".npy")
+        if f.exists():
+            try:
+                return np.load(f)
+            except Exception:
+                pass
+        out = self.o.ocean_jacobi(g, img, divw, iters, p0=p0, rows=rows, nthreads=nthreads)
+        tmp = self.dir / ("%s.%d.tmp.npy" % (h.hexdigest(), os.getpid()))
+        np.save(tmp, out)
+        os.replace(tmp, f)
+        return out
+
+
 def main():
     import oracle
+    oracle = _OracleMemo(oracle)
     from demiurge_amd import capi
     ctx = capi.Context(0)
     names = set()
