@@ -764,11 +764,11 @@ def worker(args):
             roof["shape_ceiling"] = HBM_ROWS_GBS
             roof["frac_of_shape_ceiling"] = roof["achieved"] / HBM_ROWS_GBS
             roof["note"] = ("8 sweeps per launch on chip: `achieved` is the HBM traffic the launch really moves (PMC) over its "
-                            "duration; compare it with `copy_ceiling`, a device copy timed in this run -- the launch moves its bytes at "
-                            "about the rate this box copies at.  Round 5 built a form with HALF the bytes per sweep (16 sweeps per trip, "
-                            "two waves per unit through LDS, bit-identical): it takes the same time, because the kernel's instruction "
-                            "issue (4.6 clocks of SIMD time per instruction at two waves per SIMD) is a second wall at the same place "
-                            "(DESIGN.md 4.1b, profiles/r05_deep_form.txt).  The SURVEY 8d model (16 B per cell-sweep) stops bounding a "
+                            "duration.  It is not what the launch waits for: the one-sweep kernel moves more bytes per second in this "
+                            "same run (`demonstrated_GBps`), and round 5 built a form with HALF the bytes per sweep (16 sweeps per "
+                            "trip, two waves per unit through LDS, bit-identical) that takes the same time -- the kernel is bound by "
+                            "instruction issue and the stalls of two waves per SIMD (4.6 clocks of SIMD time per instruction; "
+                            "DESIGN.md 4.1b, profiles/r05_deep_form.txt).  The SURVEY 8d model (16 B per cell-sweep) stops bounding a "
                             "kernel that does 8 sweeps per HBM pass: `algorithmic_x_peak`; the HBM-bound form the 60 % target is stated "
                             "for is `roofline_single`")
         else:
@@ -810,6 +810,12 @@ def worker(args):
         out["roofline_single"] = {"bound": "hbm", "kernel": k1, "achieved": a1, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a1 / HBM_PEAK_GBS,
                                   "traffic": t1, "traffic_source": t1src, "launch_us": ls1 * 1e6, "sweeps_per_launch": sw1 / l1,
                                   "value": float(W) * H * n1 / dt1 / 1e6, "sample": "1 solve of %d sweeps, one per launch, after 1 warm-up" % n1}
+        if t1:
+            # what this box's HBM demonstrably delivers to a streaming kernel in this very run: the one-sweep kernel's real traffic rate
+            # (a torch device copy -- copy_ceiling -- reads lower than that on these boxes)
+            roof["demonstrated_GBps"] = {"value": t1 / ls1 / 1e9, "what": "%s: PMC traffic / launch time, this run" % k1}
+            if roof.get("achieved"):
+                roof["frac_of_demonstrated"] = roof["achieved"] / (t1 / ls1 / 1e9)
         # ---- untimed check: 64 sweeps of the default kernel == 64 single-sweep launches, bit for bit ----
         md = make("auto", args.terrain)
         md.jacobi(64, zero_first=True)

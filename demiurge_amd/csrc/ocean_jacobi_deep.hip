@@ -15,9 +15,9 @@
 // pair share a SIMD (DP_WG=4) -- and 783-797 us with every synchronisation instruction switched off at run time (DMG_DEEP_NOSPIN:
 // wrong results): the pair does not lose its time waiting.  It is as long as the plain kernel because it issues as many
 // instructions per sweep (one arrival instead of two per sixteen levels, against 224 instead of 240 useful columns and a window of
-// n + 32 rows) -- HALF THE HBM BYTES AND THE SAME TIME.  The plain kernel moves its bytes at 0.98 of the box's copy rate AND issues
-// its instructions at 4.6 clocks of SIMD time each (independent packed instructions measure 4.4-5.2 at two waves per SIMD): both
-// walls stand at the same place, and taking one away buys nothing.  (A build with the synchronisation compiled OUT ran 516-526 us and looked like proof of the
+// n + 32 rows) -- HALF THE HBM BYTES AND THE SAME TIME.  The streaming kernel is not waiting for HBM (the one-sweep kernel moves a
+// fifth more bytes per second in the same run): it is bound by instruction issue and the stalls of two in-order waves per SIMD
+// (vector ALU busy 50–57 %); round 4's reading is revised.  (A build with the synchronisation compiled OUT ran 516-526 us and looked like proof of the
 // opposite for an hour: without it the front wave's hand-over stores are dead stores, and the compiler removes the sweeps behind them.)
 // The prototype covers open water only and was not widened.
 #ifdef DMG_EXPERIMENTS
