@@ -1226,7 +1226,16 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
     DMG_HIP(hipStreamSynchronize(st));
     hipLaunchKernelGGL(k_fill_f, dim3(nb), dim3(256), 0, st, d_flow, -1.0f, N);        // unreached cells keep -1 (:598-604)
     DMG_HIP(hipGetLastError());
-    if (timing) fprintf(stderr, "[flow] %d levels\n", levels);
+    if (timing) {
+        fprintf(stderr, "[flow] %d levels\n", levels);
+        // level populations: how much of the dependency chain is sparse (counted from the deepest level down)
+        const int lim[4] = { 64, 1024, 4096, 16384 };
+        int nlev[4] = { 0, 0, 0, 0 }; long long ncell[4] = { 0, 0, 0, 0 };
+        for (int q = 0; q < 4; q++)
+            for (int l = levels - 1; l >= 0; l--) { const int c = start[l + 1] - start[l]; if (c < lim[q]) { nlev[q]++; ncell[q] += c; } }
+        fprintf(stderr, "[flow] levels with < 64 / 1024 / 4096 / 16384 cells: %d / %d / %d / %d (%lld / %lld / %lld / %lld cells of %d reached)\n", nlev[0], nlev[1], nlev[2],
+                nlev[3], ncell[0], ncell[1], ncell[2], ncell[3], start[levels]);
+    }
     lap("upload + depth sort");
     static const bool by_levels = dmg_hook("DMG_FLOW_LEVELS") != nullptr;      // experiments: the level-synchronous form
     const int n_reached = start[levels];
@@ -1243,6 +1252,13 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
         DMG_HIP(hipMemsetAsync(dtick.p, 0, 8, st));
         DMG_HIP(hipMemsetAsync(acc.p, 0xFF, N * 4, st));                  // FLOW_NOT_READY everywhere
         const int waves = (n_reached + 63) / 64;
+        // (Round 5 measured where this kernel's 2.9 ms per config-2 iteration go.  Of ~1830 levels the deepest ~1400 hold fewer than 1024
+        // cells each -- the upper reaches of the longest rivers, 0.3 M of 3.1 M cells -- and looked like 1400 x 1.6 us of latency.  They
+        // are not: with those levels taken over by ONE workgroup (a thread per cell, the level's sums in LDS, a __syncthreads per level,
+        // the additions pre-decoded into 16 bytes per cell: bit-identical, 0.75 ms) this kernel still took 2.28 ms for the rest, and with
+        // levels of up to 4096 cells taken over (1790 levels, 1.05 M cells: 2.18 ms on one CU) 1.52 ms for the last 190 levels.  It
+        // spends ~0.4 us on a sparse level and is bound by THROUGHPUT, ~1.1 G cells/s, on the dense levels near the mouths, where the
+        // cells are: a dozen scattered loads per cell from 512 waves.  The single-workgroup form was dropped.)
         // The persistent grid is SMALL: 128 blocks = 512 waves.  Every wave that holds a ticket polls, and the polls of waves far
         // from the front compete with the loads that matter: with what the chip holds at once (8 192 waves) the sums of a
         // 16384x8192 round took 45 ms, with 512 waves 30 ms (4096x2048: 4.5 -> 3.4 ms; 128 waves are too few: 36 ms).
