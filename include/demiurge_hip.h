@@ -601,7 +601,7 @@ int dmg_multi_world_get(dmg_multi_world *w, float *terrain, float *eroded, float
  * (rowclass[strip][local row]: 0 open water, 1 land everywhere, 2 mixed; strips of 240 columns) for a device of num_cu compute
  * units.  part 0: the whole launch; 1 / 2: the edge / interior half of a split launch with send zones [lo, zone_lo) and
  * [zone_hi, hi).  out: 4 ints per entry {strip, first row, end row, flags} as the kernel reads them (flags: 1 open-water unit,
- * 2 rows are the mirrored view's, 4 twin unit, 8 place holder); *twin: two entries per workgroup.  No device is touched: the
+ * 2 rows are the mirrored view's, 4 twin unit, 8 place holder, 16 an edge unit of a split launch: it keeps a raised priority); *twin: two entries per workgroup.  No device is touched: the
  * cut, the halves of a split launch and the placement are host code, covered by tests/test_stream_cut.py on the CPU. */
 int dmg_stream_units_probe(int W, int H, int y0, int y1, int gs, int gn, const unsigned char *rowclass, int num_cu,
                            int lo, int hi, int part, int zone_lo, int zone_hi, int *out, size_t cap, size_t *n_entries, int *twin);
