@@ -345,21 +345,12 @@ __device__ __forceinline__ float temperature_update(float Tc, bool land, const f
 
 // One cell per thread: rows whose taps stay literal (only_literal != 0: the rows listed in `rows`), or every row of a
 // grid whose width is not a multiple of 4 (only_literal == 0, rows == null).
-__global__ __launch_bounds__(256) void k_temperature(canvas c, const float *__restrict__ T, float *__restrict__ out,
-                                                     const float *__restrict__ terrain, const float *__restrict__ asr,
-                                                     const float *__restrict__ cosphi, const float4 *__restrict__ denrow,
-                                                     const int *__restrict__ dentwo, temp_consts k,
-                                                     const int *__restrict__ shift, const int *__restrict__ srow,
-                                                     const int *__restrict__ literal_row, const int *__restrict__ rows)
+__device__ __forceinline__ float temperature_cell(const canvas &c, const float *__restrict__ T, bool land, float a, float factor, const temp_div &den,
+                                                  bool den_two, const temp_consts &k, const int *__restrict__ shift, const int *__restrict__ srow,
+                                                  bool literal, int y, int x)
 {
-    const int y = rows ? rows[blockIdx.y] : c.row0 + (int)blockIdx.y;
-    const int x = blockIdx.x * 256 + threadIdx.x;
-    if (x >= c.W) return;
-    float factor = cosphi[y];                        // get_texture_laplacian: cos(geo.y) (Shader.h:301-302)
-    const float4 dr = denrow[y];                     // den = 4*pow(pixelwidth.y,2), its reciprocal and its pair
-    const temp_div den = { dr.x, dr.y, dr.z, dr.w };
     float s[9];
-    if (!literal_row[y]) {                           // row-uniform: the verified per-row displacements
+    if (!literal) {                                  // row-uniform: the verified per-row displacements
 #pragma unroll
         for (int t = 0; t < 9; t++) s[t] = T[(size_t)srow[y * 9 + t] * c.W + temperature_shifted(c, x, shift[y * 9 + t])];
     } else {
@@ -370,8 +361,23 @@ __global__ __launch_bounds__(256) void k_temperature(canvas c, const float *__re
             s[t] = T[(size_t)j * c.W + i];
         }
     }
-    size_t p = (size_t)y * c.W + x;
-    out[p] = temperature_update(T[p], terrain[p] > 0.0f, s, asr[y], den, dentwo[y] != 0, k);
+    return temperature_update(T[(size_t)y * c.W + x], land, s, a, den, den_two, k);
+}
+__global__ __launch_bounds__(256) void k_temperature(canvas c, const float *__restrict__ T, float *__restrict__ out,
+                                                     const float *__restrict__ terrain, const float *__restrict__ asr,
+                                                     const float *__restrict__ cosphi, const float4 *__restrict__ denrow,
+                                                     const int *__restrict__ dentwo, temp_consts k,
+                                                     const int *__restrict__ shift, const int *__restrict__ srow,
+                                                     const int *__restrict__ literal_row, const int *__restrict__ rows)
+{
+    const int y = rows ? rows[blockIdx.y] : c.row0 + (int)blockIdx.y;
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= c.W) return;
+    const float4 dr = denrow[y];                     // den = 4*pow(pixelwidth.y,2), its reciprocal and its pair
+    const temp_div den = { dr.x, dr.y, dr.z, dr.w };
+    const size_t p = (size_t)y * c.W + x;
+    // get_texture_laplacian: cos(geo.y) (Shader.h:301-302)
+    out[p] = temperature_cell(c, T, terrain[p] > 0.0f, asr[y], cosphi[y], den, dentwo[y] != 0, k, shift, srow, literal_row[y] != 0, y, x);
 }
 
 // land4[i]: bit j = cell 4 i + j lies above sea level.  The step reads the terrain only for that sign (Temperature.cpp:131-132):
@@ -444,104 +450,301 @@ __device__ __forceinline__ void temperature_cells_generic(const canvas &c, const
     *reinterpret_cast<float4 *>(out + p) = o;
 }
 
+// The packed form of four cells from their nine taps (A .. I as get_texture_laplacian names them, E the cells themselves): pair 0 =
+// cells 0, 1; pair 1 = cells 2, 3.  Returns whether every numerator of every division of the four cells lies in {0} u [win_lo, 2^100]
+// -- only then are the values in *o the IEEE quotients' results.
 // ALL2: every divisor of the step has its two-operation pair (the host knows: all but about one set of values in a hundred) --
 // the hot path is then one basic block; otherwise each division asks its (wave-uniform) flag
 template <bool ALL2>
-__global__ __launch_bounds__(256) void k_temperature_v5(canvas c, const float *__restrict__ T, float *__restrict__ out,
-                                                        const unsigned char *__restrict__ land4, const float *__restrict__ asr,
-                                                        const float4 *__restrict__ denrow, const int *__restrict__ dentwo, temp_consts k,
-                                                        const int *__restrict__ shift, const int *__restrict__ srow,
-                                                        const int *__restrict__ literal_row)
+__device__ __forceinline__ bool temperature_packed4(const float4 &vA, const float4 &vB, const float4 &vC, const float4 &vD, const float4 &vE,
+                                                    const float4 &vF, const float4 &vG, const float4 &vH, const float4 &vI, unsigned lm, float a,
+                                                    const temp_div &den, bool den_two, const temp_consts &k, float4 *o)
 {
-    const int y = c.row0 + (int)blockIdx.y;
-    const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4;
-    if (x0 >= c.W || literal_row[y]) return;
-    const int W = c.W;
-    const float4 dr = denrow[y];
-    const temp_div den = { dr.x, dr.y, dr.z, dr.w };
-    const bool den_two = ALL2 || dentwo[y] != 0;
     const int ktwo = ALL2 ? 7 : k.two;
+    f2 res[2], nx[2], ny[2], olr_n[2], n1[2], q1[2];
+    const f2 Tcp[2] = { f2{ vE.x, vE.y }, f2{ vE.z, vE.w } };
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+#define TAP(v) (h == 0 ? f2{ v.x, v.y } : f2{ v.z, v.w })
+        const f2 A_ = TAP(vA), B_ = TAP(vB), C_ = TAP(vC), D_ = TAP(vD), E_ = TAP(vE), F_ = TAP(vF), G_ = TAP(vG), H_ = TAP(vH), I_ = TAP(vI);
+#undef TAP
+        const f2 two = f2{ 2.0f, 2.0f }, four = f2{ 4.0f, 4.0f };
+        const f2 B2 = two * B_, D2 = two * D_, E4 = four * E_, F2 = two * F_, H2 = two * H_;
+        nx[h] = (((((((A_ - B2) + C_) + D2) - E4) + F2) + G_) - H2) + I_;      // left to right, as the shader
+        ny[h] = (((((((A_ + B2) + C_) - D2) - E4) - F2) + G_) + H2) + I_;
+        const f2 t = Tcp[h] + f2{ k.celsius, k.celsius };
+        const f2 t2 = t * t;
+        olr_n[h] = t2 * (t2 * f2{ k.olr_coeff, k.olr_coeff });
+        const f2 delta_x = temp_div2(nx[h], den, den_two), delta_y = temp_div2(ny[h], den, den_two);    // (finite in the window: no NaN to clear)
+        const f2 olr_q = temp_div2(olr_n[h], k.t4, (ktwo & 1) != 0);
+        const f2 OLR = olr_q * f2{ k.emissivity, k.emissivity };
+        const f2 change = (f2{ a, a } - OLR) + f2{ k.diffusivity, k.diffusivity } * (delta_x + delta_y);
+        n1[h] = change * f2{ k.year_s, k.year_s };
+        q1[h] = temp_div2(n1[h], k.steps, (ktwo & 2) != 0);
+        // the heat capacity is the cell's own: land or ocean, bits 2 h and 2 h + 1 of the mask
+        const int m0 = __builtin_amdgcn_sbfe((int)lm, 2 * h, 1), m1 = __builtin_amdgcn_sbfe((int)lm, 2 * h + 1, 1);     // 0 or -1
+        auto pick = [](int m, float land, float ocean) { return __int_as_float((m & __float_as_int(land)) | (~m & __float_as_int(ocean))); };
+        f2 q2;
+        if (ktwo & 4) {
+            const f2 hh = f2{ pick(m0, k.land.h, k.ocean.h), pick(m1, k.land.h, k.ocean.h) }, ll = f2{ pick(m0, k.land.l, k.ocean.l), pick(m1, k.land.l, k.ocean.l) };
+            q2 = f2_fma(q1[h], hh, q1[h] * ll);
+        } else {
+            const f2 cc = f2{ pick(m0, k.land.c, k.ocean.c), pick(m1, k.land.c, k.ocean.c) }, rr = f2{ pick(m0, k.land.r, k.ocean.r), pick(m1, k.land.r, k.ocean.r) };
+            const f2 q = q1[h] * rr;
+            q2 = f2_fma(f2_fma(-cc, q, q1[h]), rr, q);
+        }
+        res[h] = Tcp[h] + q2;
+    }
+    // ---- admission: every numerator of every division of the four cells in {0} u [win_lo, 2^100] ----
+    // (1) nothing above the window, no infinity, no NaN: one sum of magnitudes (|q1| <= |n1|: steps_per_year >= 1)
+    float sum = fabsf(nx[0].x) + fabsf(nx[0].y);
+    sum += fabsf(nx[1].x); sum += fabsf(nx[1].y);
+    sum += fabsf(ny[0].x); sum += fabsf(ny[0].y); sum += fabsf(ny[1].x); sum += fabsf(ny[1].y);
+    sum += fabsf(olr_n[0].x); sum += fabsf(olr_n[0].y); sum += fabsf(olr_n[1].x); sum += fabsf(olr_n[1].y);
+    sum += fabsf(n1[0].x); sum += fabsf(n1[0].y); sum += fabsf(n1[1].x); sum += fabsf(n1[1].y);
+    // (2) the Laplacian numerators: zero or at least win_lo -- v_frexp_exp gives 0 for zero and e + 1 for 2^e <= |x| < 2^(e+1)
+    int emin = min(min(__builtin_amdgcn_frexp_expf(nx[0].x), __builtin_amdgcn_frexp_expf(nx[0].y)), min(__builtin_amdgcn_frexp_expf(nx[1].x), __builtin_amdgcn_frexp_expf(nx[1].y)));
+    emin = min(emin, min(min(__builtin_amdgcn_frexp_expf(ny[0].x), __builtin_amdgcn_frexp_expf(ny[0].y)), min(__builtin_amdgcn_frexp_expf(ny[1].x), __builtin_amdgcn_frexp_expf(ny[1].y))));
+    // (3) the others (a zero among them is rare: the generic form takes it): at least win_lo (|q1| <= |n1| again)
+    float lo = fminf(fminf(fminf(fabsf(olr_n[0].x), fabsf(olr_n[0].y)), fminf(fabsf(olr_n[1].x), fabsf(olr_n[1].y))),
+                     fminf(fminf(fabsf(q1[0].x), fabsf(q1[0].y)), fminf(fabsf(q1[1].x), fabsf(q1[1].y))));
+    o->x = res[0].x; o->y = res[0].y; o->z = res[1].x; o->w = res[1].y;
+    return sum <= TEMP_WIN_HI && emin >= k.win_emin && lo >= k.win_lo;
+}
+
+// What a wave needs to know about its row, as ONE 64-byte scalar load (k_temperature_rowrec builds it from the verified tap table
+// and the divisor table): the nine taps as byte offsets from the field's first cell ((source row * W + displacement) * 4, modulo
+// 2^32: a lane adds its own 4 * x0, and for the lanes of an interior wave the sum is a true offset below 4 GB), the range of x0
+// for which every tap of four cells stays clear of the seam / the clamped edge, flags, and the row's divisor den = 4 * pow(pixelwidth.y, 2)
+// with its reciprocal and its pair.  Round 5 (profiles/r05_climate_shape.txt): the kernel used to derive the offsets per wave from
+// the shift / srow tables -- two hundred scalar instructions, as many as its vector instructions -- behind a chain of five
+// dependent scalar loads; a wave's lifetime, not its bytes or its arithmetic, is what bounds a kernel of half a million short waves.
+#define TEMP_REC_FAST 1                               // tabled row, the middle tap is the cell itself, the field is below 4 GB
+#define TEMP_REC_LITERAL 2                            // the row keeps the literal offset() path (k_temperature)
+#define TEMP_REC_REGULAR 4                            // taps 0-2 / 3-5 / 6-8 on rows y-1 / y / y+1 at displacements (L, 0, R)
+#define TEMP_REC_DEN_TWO 8                            // the row's divisor has its two-operation pair
+#define TEMP_REC_AS_ABOVE 16                          // regular, and so is the row above, with the same (L, R)
+struct temp_rowrec_tail { unsigned off8; int xlo, xhi, flags; float den_c, den_r, den_h, den_l; };   // the record's second half by itself
+struct temp_rowrec { unsigned off[9]; int xlo, xhi, flags; float den_c, den_r, den_h, den_l; };
+static_assert(sizeof(temp_rowrec) == 64 && sizeof(temp_rowrec_tail) == 32, "one s_load_dwordx16 / one s_load_dwordx8");
+#define TEMP_ROWS_MAX 4
+__global__ void k_temperature_rowrec(canvas c, const int *__restrict__ shift, const int *__restrict__ srow, const int *__restrict__ literal_row,
+                                     const float4 *__restrict__ denrow, const int *__restrict__ dentwo, temp_rowrec *__restrict__ rec, int n)
+{
+    const int y = blockIdx.x * blockDim.x + threadIdx.x;
+    if (y >= n) return;
+    temp_rowrec r = {};
+    if (y < c.H) {
+        const float4 d = denrow[y];
+        r.den_c = d.x; r.den_r = d.y; r.den_h = d.z; r.den_l = d.w;
+        r.flags = dentwo[y] ? TEMP_REC_DEN_TWO : 0;
+    }
+    if (y < c.H && literal_row[y]) r.flags |= TEMP_REC_LITERAL;
+    else if (y < c.H) {
+        int sh[9], sr[9], smin = 0, smax = 0;
+        for (int t = 0; t < 9; t++) {
+            sr[t] = srow[y * 9 + t];
+            int d = shift[y * 9 + t];                 // a forward distance in [0, W) on a full-longitude grid, signed otherwise
+            if (c.lonwrap && d > c.W / 2) d -= c.W;
+            sh[t] = d;
+            smin = min(smin, d); smax = max(smax, d);
+            r.off[t] = (unsigned)(((long long)sr[t] * c.W + d) * 4);
+        }
+        r.xlo = -smin; r.xhi = c.W - smax - 3;
+        bool regular = y >= 1 && y + 1 < c.H;
+        for (int g = 0; g < 3; g++) {
+            regular = regular && sh[3 * g] == sh[0] && sh[3 * g + 1] == 0 && sh[3 * g + 2] == sh[2];
+            for (int t = 0; t < 3; t++) regular = regular && sr[3 * g + t] == y - 1 + g;
+        }
+        const bool fast = sh[4] == 0 && sr[4] == y && (long long)c.W * c.H * 4 < (1ll << 32);
+        r.flags |= (fast ? TEMP_REC_FAST : 0) | (fast && regular ? TEMP_REC_REGULAR : 0);
+        if (fast && regular && y >= 2 && !literal_row[y - 1]) {       // the row above: regular as well (its own test), the same displacements
+            bool same = true;
+            for (int t = 0; t < 9; t++) {
+                int d = shift[(y - 1) * 9 + t];
+                if (c.lonwrap && d > c.W / 2) d -= c.W;
+                same = same && d == sh[t] && srow[(y - 1) * 9 + t] == sr[t] - 1;
+            }
+            if (same) r.flags |= TEMP_REC_AS_ABOVE;
+        }
+    }
+    rec[y] = r;
+}
+
+// Which rows' seam cells k_temperature_edges computes after the main kernel: the row's displacements leave every wave but the
+// first and the last (wl: the one with the row's last four cells) clear of the seam
+__device__ __host__ __forceinline__ bool temperature_seams_apart(int flags, int xlo, int xhi, int W)
+{
+    const int wl = (W / 4 - 1) / 64;
+    return (flags & TEMP_REC_REGULAR) != 0 && wl >= 1 && xlo <= 256 && xhi > 256 * wl - 4;
+}
+
+// four cells of ONE row: nine 16-byte loads at the record's offsets, the packed form; the generic form where either does not apply.
+// seam_ok: the row's seam cells are computed again by k_temperature_edges and its 16-byte loads stay in bounds across the seam (two
+// more rows stored on either side): the first and the last wave of the row then run like any other -- what the few lanes
+// whose taps cross the seam store is overwritten.  (Through the generic form these two waves in 64 cost the step a fifth of its
+// time: profiles/r05_climate_shape.txt.)
+template <bool ALL2>
+__device__ __forceinline__ void temperature_row4(const canvas &c, const float *__restrict__ T, float *__restrict__ out,
+                                                 const unsigned char *__restrict__ land4, float a, const temp_consts &k,
+                                                 const int *__restrict__ shift, const int *__restrict__ srow, const temp_rowrec &rc, int y, int x0,
+                                                 bool seam_ok)
+{
+    const int W = c.W;
+    const temp_div den = { rc.den_c, rc.den_r, rc.den_h, rc.den_l };
+    const bool den_two = ALL2 || (rc.flags & TEMP_REC_DEN_TWO) != 0;
     const size_t p = (size_t)y * W + x0;
     const unsigned lm = land4[p >> 2];
-    const float a = asr[y];
-    // The nine displacements and source rows are the same for the whole row (scalars).  A wave whose cells all stay clear of the
-    // seam for the row's widest displacement -- all but the first and the last of a row -- takes every tap as ONE 16-byte load
-    // at a scalar row base plus a lane offset and goes on in packed arithmetic; the others take the generic form.
-    int sh[9], sr[9], smin = 0, smax = 0;
-#pragma unroll
-    for (int t = 0; t < 9; t++) {
-        sr[t] = srow[y * 9 + t];
-        int d = shift[y * 9 + t];                    // a forward distance in [0, W) on a full-longitude grid, signed otherwise
-        if (c.lonwrap && d > W / 2) d -= W;
-        sh[t] = d;
-        smin = min(smin, d); smax = max(smax, d);
-    }
-    const bool interior = x0 + smin >= 0 && x0 + smax + 3 < W;
-    const bool middle_is_self = sh[4] == 0 && sr[4] == y;   // (row-uniform; true on every row seen so far: offset(st, -vec2(0, 0)))
+    // A wave whose cells all stay clear of the seam for the row's widest displacement -- all but the first and the last of a row --
+    // takes every tap as ONE 16-byte load at the field's base plus a 32-bit lane offset and goes on in packed arithmetic
+    const bool interior = x0 >= rc.xlo && x0 < rc.xhi;
     bool done = false;
-    if (middle_is_self && __builtin_amdgcn_ballot_w64(!interior) == 0) {
+    if ((rc.flags & TEMP_REC_FAST) && (seam_ok || __builtin_amdgcn_ballot_w64(!interior) == 0)) {
         float4 v[9];                                 // nine loads in flight at once, no branch between them; v[4] is the cell itself
+        const char *Tb = reinterpret_cast<const char *>(T);
+        const unsigned lane = (unsigned)x0 * 4u;
 #pragma unroll
-        for (int t = 0; t < 9; t++)
-            __builtin_memcpy(&v[t], reinterpret_cast<const char *>(T + (size_t)sr[t] * W + sh[t]) + (unsigned)x0 * 4u, 16);
-        const float4 Tc = v[4];
-        // ---- the packed form: pair 0 = cells 0, 1; pair 1 = cells 2, 3 ----
-        f2 res[2], nx[2], ny[2], olr_n[2], n1[2], q1[2];
-        const f2 Tcp[2] = { f2{ Tc.x, Tc.y }, f2{ Tc.z, Tc.w } };
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-#define TAP(t) (h == 0 ? f2{ v[t].x, v[t].y } : f2{ v[t].z, v[t].w })
-            const f2 A_ = TAP(0), B_ = TAP(1), C_ = TAP(2), D_ = TAP(3), E_ = TAP(4), F_ = TAP(5), G_ = TAP(6), H_ = TAP(7), I_ = TAP(8);
-#undef TAP
-            const f2 two = f2{ 2.0f, 2.0f }, four = f2{ 4.0f, 4.0f };
-            const f2 B2 = two * B_, D2 = two * D_, E4 = four * E_, F2 = two * F_, H2 = two * H_;
-            nx[h] = (((((((A_ - B2) + C_) + D2) - E4) + F2) + G_) - H2) + I_;      // left to right, as the shader
-            ny[h] = (((((((A_ + B2) + C_) - D2) - E4) - F2) + G_) + H2) + I_;
-            const f2 t = Tcp[h] + f2{ k.celsius, k.celsius };
-            const f2 t2 = t * t;
-            olr_n[h] = t2 * (t2 * f2{ k.olr_coeff, k.olr_coeff });
-            const f2 delta_x = temp_div2(nx[h], den, den_two), delta_y = temp_div2(ny[h], den, den_two);    // (finite in the window: no NaN to clear)
-            const f2 olr_q = temp_div2(olr_n[h], k.t4, (ktwo & 1) != 0);
-            const f2 OLR = olr_q * f2{ k.emissivity, k.emissivity };
-            const f2 change = (f2{ a, a } - OLR) + f2{ k.diffusivity, k.diffusivity } * (delta_x + delta_y);
-            n1[h] = change * f2{ k.year_s, k.year_s };
-            q1[h] = temp_div2(n1[h], k.steps, (ktwo & 2) != 0);
-            // the heat capacity is the cell's own: land or ocean, bits 2 h and 2 h + 1 of the mask
-            const int m0 = __builtin_amdgcn_sbfe((int)lm, 2 * h, 1), m1 = __builtin_amdgcn_sbfe((int)lm, 2 * h + 1, 1);     // 0 or -1
-            auto pick = [](int m, float land, float ocean) { return __int_as_float((m & __float_as_int(land)) | (~m & __float_as_int(ocean))); };
-            f2 q2;
-            if (ktwo & 4) {
-                const f2 hh = f2{ pick(m0, k.land.h, k.ocean.h), pick(m1, k.land.h, k.ocean.h) }, ll = f2{ pick(m0, k.land.l, k.ocean.l), pick(m1, k.land.l, k.ocean.l) };
-                q2 = f2_fma(q1[h], hh, q1[h] * ll);
-            } else {
-                const f2 cc = f2{ pick(m0, k.land.c, k.ocean.c), pick(m1, k.land.c, k.ocean.c) }, rr = f2{ pick(m0, k.land.r, k.ocean.r), pick(m1, k.land.r, k.ocean.r) };
-                const f2 q = q1[h] * rr;
-                q2 = f2_fma(f2_fma(-cc, q, q1[h]), rr, q);
-            }
-            res[h] = Tcp[h] + q2;
-        }
-        // ---- admission: every numerator of every division of the four cells in {0} u [win_lo, 2^100] ----
-        // (1) nothing above the window, no infinity, no NaN: one sum of magnitudes (|q1| <= |n1|: steps_per_year >= 1)
-        float sum = fabsf(nx[0].x) + fabsf(nx[0].y);
-        sum += fabsf(nx[1].x); sum += fabsf(nx[1].y);
-        sum += fabsf(ny[0].x); sum += fabsf(ny[0].y); sum += fabsf(ny[1].x); sum += fabsf(ny[1].y);
-        sum += fabsf(olr_n[0].x); sum += fabsf(olr_n[0].y); sum += fabsf(olr_n[1].x); sum += fabsf(olr_n[1].y);
-        sum += fabsf(n1[0].x); sum += fabsf(n1[0].y); sum += fabsf(n1[1].x); sum += fabsf(n1[1].y);
-        // (2) the Laplacian numerators: zero or at least win_lo -- v_frexp_exp gives 0 for zero and e + 1 for 2^e <= |x| < 2^(e+1)
-        int emin = min(min(__builtin_amdgcn_frexp_expf(nx[0].x), __builtin_amdgcn_frexp_expf(nx[0].y)), min(__builtin_amdgcn_frexp_expf(nx[1].x), __builtin_amdgcn_frexp_expf(nx[1].y)));
-        emin = min(emin, min(min(__builtin_amdgcn_frexp_expf(ny[0].x), __builtin_amdgcn_frexp_expf(ny[0].y)), min(__builtin_amdgcn_frexp_expf(ny[1].x), __builtin_amdgcn_frexp_expf(ny[1].y))));
-        // (3) the others (a zero among them is rare: the generic form takes it): at least win_lo (|q1| <= |n1| again)
-        float lo = fminf(fminf(fminf(fabsf(olr_n[0].x), fabsf(olr_n[0].y)), fminf(fabsf(olr_n[1].x), fabsf(olr_n[1].y))),
-                         fminf(fminf(fabsf(q1[0].x), fabsf(q1[0].y)), fminf(fabsf(q1[1].x), fabsf(q1[1].y))));
-        const bool ok = sum <= TEMP_WIN_HI && emin >= k.win_emin && lo >= k.win_lo;
+        for (int t = 0; t < 9; t++) __builtin_memcpy(&v[t], Tb + (size_t)(lane + rc.off[t]), 16);
+        float4 o;
+        const bool ok = temperature_packed4<ALL2>(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], lm, a, den, den_two, k, &o);
         if (__builtin_amdgcn_ballot_w64(!ok) == 0) {
-            float4 o;
-            o.x = res[0].x; o.y = res[0].y; o.z = res[1].x; o.w = res[1].y;
             *reinterpret_cast<float4 *>(out + p) = o;
             done = true;
         }
     }
     if (!done) temperature_cells_generic(c, T, out, lm, a, den, den_two, k, shift, srow, y, x0);
+}
+
+// After the main kernel: (a) the groups of four cells whose taps cross the seam, on the rows where the main kernel's first and last
+// wave ran like the others -- a thread each, from the host's list: the taps cell by cell at the wrapped / clamped columns, the
+// packed form, the generic one where it does not apply; (b) the rows that keep the literal offset() arithmetic, a cell per thread.
+struct temp_item { int y, x0; };
+template <bool ALL2>
+__global__ __launch_bounds__(256) void k_temperature_edges(canvas c, const float *__restrict__ T, float *__restrict__ out,
+                                                           const unsigned char *__restrict__ land4, const float *__restrict__ asr,
+                                                           const float *__restrict__ cosphi, temp_consts k, const int *__restrict__ shift,
+                                                           const int *__restrict__ srow, const temp_rowrec *__restrict__ rec,
+                                                           const temp_item *__restrict__ items, int n_items, int item_blocks,
+                                                           const int *__restrict__ lit_rows, int lo, int hi, int safe_lo, int safe_hi)
+{
+    const int W = c.W;
+    if ((int)blockIdx.x < item_blocks) {
+        const int i = (int)blockIdx.x * 256 + (int)threadIdx.x;
+        if (i >= n_items) return;
+        const temp_item it = items[i];
+        const int y = it.y, x0 = it.x0;
+        if (y < lo || y >= hi || y < safe_lo || y >= safe_hi) return;      // (as the main kernel decides: seam_ok)
+        const temp_rowrec_tail rt = *reinterpret_cast<const temp_rowrec_tail *>(&rec[y].off[8]);
+        const temp_div den = { rt.den_c, rt.den_r, rt.den_h, rt.den_l };
+        const bool den_two = ALL2 || (rt.flags & TEMP_REC_DEN_TWO) != 0;
+        const size_t p = (size_t)y * W + x0;
+        const unsigned lm = land4[p >> 2];
+        const float a = asr[y];
+        float4 v[9];
+#pragma unroll
+        for (int t = 0; t < 9; t++) {
+            const int shf = shift[y * 9 + t];
+            const float *row = T + (size_t)srow[y * 9 + t] * W;
+            v[t].x = row[temperature_shifted(c, x0, shf)];
+            v[t].y = row[temperature_shifted(c, x0 + 1, shf)];
+            v[t].z = row[temperature_shifted(c, x0 + 2, shf)];
+            v[t].w = row[temperature_shifted(c, x0 + 3, shf)];
+        }
+        float4 o;
+        if (!temperature_packed4<ALL2>(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], lm, a, den, den_two, k, &o)) {
+            float *e = reinterpret_cast<float *>(&o);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                float s9[9];
+#pragma unroll
+                for (int t = 0; t < 9; t++) s9[t] = reinterpret_cast<const float *>(&v[t])[j];
+                e[j] = temperature_update(s9[4], (lm >> j & 1u) != 0, s9, a, den, den_two, k);
+            }
+        }
+        *reinterpret_cast<float4 *>(out + p) = o;
+        return;
+    }
+    const int b = (int)blockIdx.x - item_blocks, per_row = (W + 255) / 256;
+    const int y = lit_rows[b / per_row], x = (b % per_row) * 256 + (int)threadIdx.x;
+    if (x >= W) return;
+    const temp_rowrec_tail rt = *reinterpret_cast<const temp_rowrec_tail *>(&rec[y].off[8]);
+    const temp_div den = { rt.den_c, rt.den_r, rt.den_h, rt.den_l };
+    const size_t p = (size_t)y * W + x;
+    out[p] = temperature_cell(c, T, (land4[p >> 2] >> (x & 3) & 1) != 0, asr[y], cosphi[y], den, (rt.flags & TEMP_REC_DEN_TWO) != 0, k, shift, srow, true, y, x);
+}
+
+// A wave takes 256 columns of ROWS consecutive rows.  Where those rows have the regular tap pattern -- taps 0-2 on the row above
+// at displacements (L, 0, R), 3-5 on the row itself, 6-8 on the row below at the same (L, 0, R) -- with the same (L, R) on all of
+// them (every row but the grid's first and last has the pattern; L = -R = round(1 / cos(lat)) changes 434 times over 8192 rows),
+// the ROWS + 2 rows the group reads are fetched ONCE at the three displacements: 3 (ROWS + 2) loads for ROWS rows instead of
+// 9 ROWS, all in flight together behind ONE round of scalar loads (the rows' records and their absorbed radiation).  The values,
+// the packed form and the admission test per row of four cells are the same; rows of a group without the common pattern, and the
+// first and last wave of a row (the seam), go through temperature_row4 one by one.  ROWS = 1 is the round-5 kernel.
+// Why (tools/shape_probe.hip, profiles/r05_climate_shape.txt): one 16-byte load per lane costs the CU's texture path 16 clocks
+// a wave whether it hits or not; nine of them per row of four cells add 0.08 ms to a 0.18 ms copy of the field.
+template <bool ALL2, int ROWS>
+__global__ __launch_bounds__(256) void k_temperature_v6(canvas c, const float *__restrict__ T, float *__restrict__ out,
+                                                        const unsigned char *__restrict__ land4, const float *__restrict__ asr, temp_consts k,
+                                                        const int *__restrict__ shift, const int *__restrict__ srow,
+                                                        const temp_rowrec *__restrict__ rec, int row_end, int safe_lo, int safe_hi)
+{
+    const int W = c.W;
+    const int y0 = c.row0 + (int)blockIdx.y * ROWS;
+    const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    // (rec and asr have TEMP_ROWS_MAX entries behind the grid's last row: the scalar loads need no bound)
+    const temp_rowrec rc0 = rec[y0];
+    temp_rowrec_tail rt[ROWS];                        // (rt[0] is rc0's: not loaded)
+    float a[ROWS];
+    a[0] = asr[y0];
+#pragma unroll
+    for (int r = 1; r < ROWS; r++) { rt[r] = *reinterpret_cast<const temp_rowrec_tail *>(&rec[y0 + r].off[8]); a[r] = asr[y0 + r]; }
+    if (x0 >= W) return;
+    bool fused = ROWS > 1 && y0 + ROWS <= row_end && (rc0.flags & TEMP_REC_REGULAR) != 0;
+#pragma unroll
+    for (int r = 1; r < ROWS; r++) fused = fused && (rt[r].flags & TEMP_REC_AS_ABOVE) != 0;
+    const bool interior = x0 >= rc0.xlo && x0 < rc0.xhi;
+    const bool all_interior = __builtin_amdgcn_ballot_w64(!interior) == 0;
+    // the first / last wave of rows whose seam cells k_temperature_edges computes again: like any other wave, where its 16-byte
+    // loads stay in bounds across the seam (safe_lo <= y < safe_hi: two more rows stored on either side)
+    const bool apart = temperature_seams_apart(rc0.flags, rc0.xlo, rc0.xhi, W);
+    unsigned done = 0;                                // bit r: row r of the group is stored
+    if (fused && (all_interior || (apart && y0 >= safe_lo && y0 + ROWS <= safe_hi))) {
+        float4 v[ROWS + 2][3];
+        const char *Tb = reinterpret_cast<const char *>(T);
+        const unsigned lane = (unsigned)x0 * 4u, pitch = (unsigned)W * 4u;
+#pragma unroll
+        for (int j = 0; j < ROWS + 2; j++)
+#pragma unroll
+            for (int t = 0; t < 3; t++) __builtin_memcpy(&v[j][t], Tb + (size_t)(lane + rc0.off[t] + (unsigned)j * pitch), 16);
+        unsigned lm[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) lm[r] = land4[((size_t)(y0 + r) * W + x0) >> 2];
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) {
+            const temp_div den = r == 0 ? temp_div{ rc0.den_c, rc0.den_r, rc0.den_h, rc0.den_l } : temp_div{ rt[r].den_c, rt[r].den_r, rt[r].den_h, rt[r].den_l };
+            const bool den_two = ALL2 || ((r == 0 ? rc0.flags : rt[r].flags) & TEMP_REC_DEN_TWO) != 0;
+            float4 o;
+            const bool ok = temperature_packed4<ALL2>(v[r][0], v[r][1], v[r][2], v[r + 1][0], v[r + 1][1], v[r + 1][2], v[r + 2][0], v[r + 2][1],
+                                                      v[r + 2][2], lm[r], a[r], den, den_two, k, &o);
+            if (__builtin_amdgcn_ballot_w64(!ok) == 0) {
+                *reinterpret_cast<float4 *>(out + (size_t)(y0 + r) * W + x0) = o;
+                done |= 1u << r;
+            }
+        }
+    }
+    if (done == (1u << ROWS) - 1u) return;
+    // what is left: rows of a group without the common pattern, rows the packed form did not admit
+#pragma unroll
+    for (int r = 0; r < ROWS; r++) {
+        const int fl = r == 0 ? rc0.flags : rt[r].flags, y = y0 + r;
+        if (y >= row_end || (done >> r & 1u) || (fl & TEMP_REC_LITERAL)) continue;
+        if (r == 0) temperature_row4<ALL2>(c, T, out, land4, a[r], k, shift, srow, rc0, y, x0, apart && y >= safe_lo && y < safe_hi);
+        else {
+            const temp_rowrec rcr = rec[y];
+            temperature_row4<ALL2>(c, T, out, land4, a[r], k, shift, srow, rcr, y, x0,
+                                   temperature_seams_apart(rcr.flags, rcr.xlo, rcr.xhi, W) && y >= safe_lo && y < safe_hi);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -724,7 +927,10 @@ struct dmg_climate {
     dmg_grid grid{};
     dmg_topology topo{};
     dev_buf a, b, terr, land4, dlat, dcos, dden, ddentwo, dasr, dshift, dsrow, dlit;
-    dev_buf dlitrows;
+    dev_buf dlitrows, drec;                         // drec: temp_rowrec per row (+ TEMP_ROWS_MAX of zeros)
+    bool rec_ready = false;                         // (the records carry the row's divisor: rebuilt after dmg_climate_set_params)
+    dev_buf ditems;                                 // temp_item: the groups of four cells whose taps cross the seam (k_temperature_edges), ascending rows
+    std::vector<int> item_rows;                     // their rows on the host
     dmg_climate_params prm{};
     temp_consts tc{};                                // the cell update's constants and divisors for prm
     temp_orbit orbit{};                              // the rows kernel's
@@ -810,6 +1016,7 @@ int dmg_climate_set_params(dmg_climate *k, const dmg_climate_params *params)
         dentwo[y] = two(y) ? 1 : 0;
     }
     k->dden.reset(); k->ddentwo.reset();             // (steps already queued read the old tables: the pool hands a block on in stream order)
+    k->rec_ready = false;
     if ((rc = upload_rows(ctx, k->dden, denrow)) || (rc = upload_vec(ctx, k->ddentwo, dentwo))) return rc;
     temp_consts tc{};
     tc.celsius = p.celsius_offset; tc.olr_coeff = p.olr_coeff; tc.emissivity = p.emissivity; tc.diffusivity = p.diffusivity; tc.year_s = p.year_seconds;
@@ -866,8 +1073,9 @@ int dmg_climate_create_band(dmg_ctx *ctx, const dmg_grid *grid, const float *T, 
     if (!k) return dmg_fail(DMG_ENOMEM, "out of host memory");
     k->ctx = ctx; k->grid = *grid; k->topo = topo;
     k->rank = band_rank; k->count = band_count; k->ghost = ghost; k->y0 = by0; k->y1 = by1; k->gs = bgs; k->gn = bgn; k->L = bL;
-    DMG_ALLOC(k->a, n * 4); DMG_ALLOC(k->b, n * 4); DMG_ALLOC(k->terr, n * 4); DMG_ALLOC(k->dasr, (size_t)H * 4 * TEMP_ROWS_BATCH);
+    DMG_ALLOC(k->a, n * 4); DMG_ALLOC(k->b, n * 4); DMG_ALLOC(k->terr, n * 4); DMG_ALLOC(k->dasr, ((size_t)H * TEMP_ROWS_BATCH + TEMP_ROWS_MAX) * 4);
     DMG_ALLOC(k->dshift, (size_t)H * 9 * sizeof(int)); DMG_ALLOC(k->dsrow, (size_t)H * 9 * sizeof(int)); DMG_ALLOC(k->dlit, (size_t)H * sizeof(int));
+    DMG_ALLOC(k->drec, ((size_t)H + TEMP_ROWS_MAX) * sizeof(temp_rowrec));
     if ((rc = upload_rows(ctx, k->dlat, lat)) || (rc = upload_rows(ctx, k->dcos, cosphi))) return rc;
     dmg_climate_params def;
     dmg_climate_params_default(&def);
@@ -935,6 +1143,32 @@ int dmg_climate_steps(dmg_climate *k, int first_step, int n_steps)
         }
         k->taps_ready = true;
     }
+    if (!k->rec_ready && n_steps > 0) {              // the rows' records: the tap table and the divisors (dmg_climate_set_params) in one place
+        hipLaunchKernelGGL(k_temperature_rowrec, dim3((H + TEMP_ROWS_MAX + 255) / 256), dim3(256), 0, ctx->stream, c, k->dshift.i(), k->dsrow.i(), k->dlit.i(),
+                           (const float4 *)k->dden.p, (const int *)k->ddentwo.p, (temp_rowrec *)k->drec.p, H + TEMP_ROWS_MAX);
+        DMG_HIP(hipGetLastError());
+        if (!k->ditems.p && W % 4 == 0) {            // (the taps do not change with the parameters)
+            std::vector<temp_rowrec> rec(H);
+            DMG_HIP(hipMemcpyAsync(rec.data(), k->drec.p, (size_t)H * sizeof(temp_rowrec), hipMemcpyDeviceToHost, ctx->stream));
+            DMG_HIP(hipStreamSynchronize(ctx->stream));
+            std::vector<temp_item> items;
+            k->item_rows.clear();
+            for (int y = first_row; y < first_row + k->L; y++) {
+                if ((rec[y].flags & TEMP_REC_LITERAL) || !temperature_seams_apart(rec[y].flags, rec[y].xlo, rec[y].xhi, W)) continue;
+                auto add = [&](int x0) { items.push_back(temp_item{ y, x0 }); k->item_rows.push_back(y); };
+                int x0 = 0;
+                for (; x0 < W && x0 < rec[y].xlo; x0 += 4) add(x0);                       // (interior: xlo <= x0 < xhi)
+                for (x0 = std::max(x0, (std::max(rec[y].xhi, 0) + 3) / 4 * 4); x0 < W; x0 += 4) add(x0);
+            }
+            items.push_back(temp_item{ 1 << 30, 0 });  // (never an empty allocation)
+            DMG_ALLOC(k->ditems, items.size() * sizeof(temp_item));
+            DMG_HIP(hipMemcpyAsync(k->ditems.p, items.data(), items.size() * sizeof(temp_item), hipMemcpyHostToDevice, ctx->stream));
+            DMG_HIP(hipStreamSynchronize(ctx->stream));
+            if (dmg_hook("DMG_TEMPERATURE_REPORT"))       // experiments
+                fprintf(stderr, "dmg_climate_steps: %zu groups of four cells at the seam on %d stored rows\n", k->item_rows.size(), k->L);
+        }
+        k->rec_ready = true;
+    }
     const float *terr_v = k->terr.f() - k->voff();
     const unsigned char *land4_v = k->land4.p ? (const unsigned char *)k->land4.p - k->voff() / 4 : nullptr;
     for (int i = first_step, s = 1; i < first_step + n_steps; i++, s++) {
@@ -952,15 +1186,31 @@ int dmg_climate_steps(dmg_climate *k, int first_step, int n_steps)
                                c, k->dlat.f(), i, k->orbit, k->dasr.f());
         const float *asr_i = k->dasr.f() + (size_t)in_batch * H;
         if (W % 4 == 0) {                            // tabled rows four cells per thread, the few literal rows one cell per thread
-            hipLaunchKernelGGL(k->all_two ? k_temperature_v5<true> : k_temperature_v5<false>, dim3((W / 4 + 255) / 256, nrows), dim3(256), 0,
-                               ctx->stream, c, cur_v, nxt_v, land4_v, asr_i, (const float4 *)k->dden.p, (const int *)k->ddentwo.p, tc,
-                               (const int *)k->dshift.p, (const int *)k->dsrow.p, (const int *)k->dlit.p);
+            // (DMG_CLIMATE_ROWS: experiments; 1 = one row per wave, the round-5 geometry)
+            static const int rows_per_wave = [] { const char *e = dmg_hook("DMG_CLIMATE_ROWS"); return e ? atoi(e) : 3; }();
+#define TEMP_V6(R)                                                                                                                        \
+    hipLaunchKernelGGL((k->all_two ? k_temperature_v6<true, R> : k_temperature_v6<false, R>), dim3((W / 4 + 255) / 256, (nrows + R - 1) / R), dim3(256), \
+                       0, ctx->stream, c, cur_v, nxt_v, land4_v, asr_i, tc, (const int *)k->dshift.p, (const int *)k->dsrow.p,              \
+                       (const temp_rowrec *)k->drec.p, hi, safe_lo, safe_hi)
+            // (DMG_CLIMATE_NO_SEAMS: experiments -- the first and last wave of every row through the generic form, as before round 5)
+            static const bool seams = !dmg_hook("DMG_CLIMATE_NO_SEAMS");
+            const int safe_lo = seams ? first_row + 2 : 1 << 30, safe_hi = seams ? first_row + k->L - 2 : 0;
+            if (rows_per_wave == 1) TEMP_V6(1);
+            else if (rows_per_wave == 2) TEMP_V6(2);
+            else if (rows_per_wave == 4) TEMP_V6(4);
+            else TEMP_V6(3);
+#undef TEMP_V6
+            // the seam cells of the rows [lo, hi) and the literal rows among them
+            const int i0 = (int)(std::lower_bound(k->item_rows.begin(), k->item_rows.end(), lo) - k->item_rows.begin());
+            const int i1 = (int)(std::lower_bound(k->item_rows.begin(), k->item_rows.end(), hi) - k->item_rows.begin());
             const int l0 = (int)(std::lower_bound(k->lit_rows.begin(), k->lit_rows.end(), lo) - k->lit_rows.begin());
             const int l1 = (int)(std::lower_bound(k->lit_rows.begin(), k->lit_rows.end(), hi) - k->lit_rows.begin());
-            if (l1 > l0)
-                hipLaunchKernelGGL(k_temperature, dim3((W + 255) / 256, l1 - l0), dim3(256), 0, ctx->stream, c, cur_v, nxt_v, terr_v,
-                                   asr_i, k->dcos.f(), (const float4 *)k->dden.p, (const int *)k->ddentwo.p, tc, (const int *)k->dshift.p,
-                                   (const int *)k->dsrow.p, (const int *)k->dlit.p, (const int *)k->dlitrows.p + l0);
+            const int n_items = seams ? i1 - i0 : 0, item_blocks = (n_items + 255) / 256, lit_blocks = (l1 - l0) * ((W + 255) / 256);
+            if (item_blocks + lit_blocks > 0)
+                hipLaunchKernelGGL(k->all_two ? k_temperature_edges<true> : k_temperature_edges<false>, dim3(item_blocks + lit_blocks), dim3(256), 0, ctx->stream,
+                                   c, cur_v, nxt_v, land4_v, asr_i, k->dcos.f(), tc, (const int *)k->dshift.p, (const int *)k->dsrow.p,
+                                   (const temp_rowrec *)k->drec.p, (const temp_item *)k->ditems.p + i0, n_items, item_blocks,
+                                   l1 > l0 ? (const int *)k->dlitrows.p + l0 : nullptr, lo, hi, safe_lo, safe_hi);
         } else {
             hipLaunchKernelGGL(k_temperature, dim3((W + 255) / 256, nrows), dim3(256), 0, ctx->stream, c, cur_v, nxt_v, terr_v, asr_i,
                                k->dcos.f(), (const float4 *)k->dden.p, (const int *)k->ddentwo.p, tc, (const int *)k->dshift.p,

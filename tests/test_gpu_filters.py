@@ -152,6 +152,38 @@ def test_temperature_window_edges_take_either_path_to_the_same_bits(dev, oracle,
             assert np.isnan(want).any() and np.isinf(want).any()
 
 
+def test_climate_kernel_forms_agree(dev, oracle):
+    """Round 5's climate kernel gives a wave three rows (the rows it reads fetched once), lets a row's first and last wave run like the
+    others and computes the cells whose taps cross the seam again in k_temperature_edges.  Every form -- 1, 2, 3 (default), 4 rows per
+    wave, with and without the seam cells apart -- must produce the same bits (tests/climate_worker.py: globe and belt canvases, odd
+    widths, finite and blown-up fields, three bands), and the default form the oracle's."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    from climate_worker import field
+    capi, ctx = dev
+    root = Path(__file__).resolve().parents[1]
+    forms = [{}, {"DMG_CLIMATE_ROWS": "1", "DMG_CLIMATE_NO_SEAMS": "1"}, {"DMG_CLIMATE_ROWS": "2"}, {"DMG_CLIMATE_ROWS": "4"}, {"DMG_CLIMATE_ROWS": "1"}]
+    procs = [subprocess.Popen([sys.executable, str(root / "tests" / "climate_worker.py")], env=dict(os.environ, **f), stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for f in forms]
+    outs = []
+    for f, p in zip(forms, procs):
+        o, e = p.communicate(timeout=300)
+        assert p.returncode == 0, (f, e[-2000:])
+        outs.append(o.strip().splitlines())
+    assert len(outs[0]) == 9, outs[0]
+    for f, o in zip(forms[1:], outs[1:]):
+        assert o == outs[0], (f, [(a, b) for a, b in zip(outs[0], o) if a != b])
+    # the default form against the oracle where the new paths are all in play (2048 wide: 8 waves a row, seams apart)
+    W, H = 2048, 1024
+    T, h = field(W, H, W)
+    prm = capi.climate_params(diffusivity=0.55e2)
+    got = ctx.temperature_steps(capi.make_grid(W, H), T, h, 0, 3, params=prm)
+    want = oracle.temperature(oracle.grid(W, H), T, h, 0, 3, params=prm)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), int((got != want).sum())
+
+
 @pytest.mark.parametrize("kw", [
     dict(steps_per_year=730, diffusivity=1.0e4),                                        # a stable coarse year
     dict(steps_per_year=1500000, year_seconds=3.0e7, albedo=0.25, olr_coeff=200.0, olr_ref_kelvin=280.0, emissivity=0.9),

@@ -6,6 +6,7 @@
 import os
 import sys
 import time
+import zlib
 from pathlib import Path
 
 import numpy as np
@@ -39,6 +40,6 @@ for name, prm, n in (("reference values, smooth field, %d steps" % nsteps, None,
         best = min(best, ctx.timer_stop() / n)
         out = k.get()
         k.close()
-    print("%dx%d climate step, %s: %.3f ms (%.0f GB/s at 8.25 B per cell)  literal=%s  field finite: %s, |T| <= %.3g"
-          % (W, H, name, best, W * H * 8.25 / best / 1e6, os.environ.get("DMG_TEMPERATURE_LITERAL", "0"), bool(np.isfinite(out).all()),
-             float(np.nanmax(np.abs(out)))))
+    print("%dx%d climate step, %s: %.3f ms (%.0f GB/s at 8.25 B per cell)  literal=%s  rows per wave=%s  field finite: %s, |T| <= %.3g, crc %08x"
+          % (W, H, name, best, W * H * 8.25 / best / 1e6, os.environ.get("DMG_TEMPERATURE_LITERAL", "0"), os.environ.get("DMG_CLIMATE_ROWS", "default"),
+             bool(np.isfinite(out).all()), float(np.nanmax(np.abs(out))), zlib.crc32(out.tobytes())))
