@@ -13,7 +13,9 @@ kernels = [  # substring, what, unavoidable bytes per cell and launch
     ("k_diffusion_tb", "diffusion 7-8 sweeps/launch", 17),
     ("k_advect", "advect", 16),
     ("k_subdiv", "subDiv", 22),
-    ("k_temperature_v5", "climate step", 8.25),
+    ("k_temperature_v6", "climate step", 8.25),
+    ("k_temperature_edges", "climate step: seam cells", 0.01),
+    ("k_temperature_v5", "climate step (round 5, first form)", 8.25),
     ("k_temperature_v4", "climate step (round 4)", 8.25),
     ("k_erosion(", "erosion pass", 16),
     ("k_blur13_axis<0>", "blur13 x", 8),
