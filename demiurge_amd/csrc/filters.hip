@@ -571,6 +571,25 @@ __global__ void k_temperature_rowrec(canvas c, const int *__restrict__ shift, co
     rec[y] = r;
 }
 
+// four cells from taps already in registers through the generic update (every division by itself): what a wave does whose packed
+// form was not admitted -- a value outside the window somewhere among its 256 cells
+__device__ __forceinline__ float4 temperature_cells_from_taps(const float4 &vA, const float4 &vB, const float4 &vC, const float4 &vD, const float4 &vE,
+                                                              const float4 &vF, const float4 &vG, const float4 &vH, const float4 &vI, unsigned lm, float a,
+                                                              const temp_div &den, bool den_two, const temp_consts &k)
+{
+    const float4 *v[9] = { &vA, &vB, &vC, &vD, &vE, &vF, &vG, &vH, &vI };
+    float4 o;
+    float *e = reinterpret_cast<float *>(&o);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        float s9[9];
+#pragma unroll
+        for (int t = 0; t < 9; t++) s9[t] = reinterpret_cast<const float *>(v[t])[j];
+        e[j] = temperature_update(s9[4], (lm >> j & 1u) != 0, s9, a, den, den_two, k);
+    }
+    return o;
+}
+
 // Which rows' seam cells k_temperature_edges computes after the main kernel: the row's displacements leave every wave but the
 // first and the last (wl: the one with the row's last four cells) clear of the seam
 __device__ __host__ __forceinline__ bool temperature_seams_apart(int flags, int xlo, int xhi, int W)
@@ -607,10 +626,9 @@ __device__ __forceinline__ void temperature_row4(const canvas &c, const float *_
         for (int t = 0; t < 9; t++) __builtin_memcpy(&v[t], Tb + (size_t)(lane + rc.off[t]), 16);
         float4 o;
         const bool ok = temperature_packed4<ALL2>(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], lm, a, den, den_two, k, &o);
-        if (__builtin_amdgcn_ballot_w64(!ok) == 0) {
-            *reinterpret_cast<float4 *>(out + p) = o;
-            done = true;
-        }
+        if (__builtin_amdgcn_ballot_w64(!ok) != 0) o = temperature_cells_from_taps(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], lm, a, den, den_two, k);
+        *reinterpret_cast<float4 *>(out + p) = o;
+        done = true;
     }
     if (!done) temperature_cells_generic(c, T, out, lm, a, den, den_two, k, shift, srow, y, x0);
 }
@@ -651,16 +669,8 @@ __global__ __launch_bounds__(256) void k_temperature_edges(canvas c, const float
             v[t].w = row[temperature_shifted(c, x0 + 3, shf)];
         }
         float4 o;
-        if (!temperature_packed4<ALL2>(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], lm, a, den, den_two, k, &o)) {
-            float *e = reinterpret_cast<float *>(&o);
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                float s9[9];
-#pragma unroll
-                for (int t = 0; t < 9; t++) s9[t] = reinterpret_cast<const float *>(&v[t])[j];
-                e[j] = temperature_update(s9[4], (lm >> j & 1u) != 0, s9, a, den, den_two, k);
-            }
-        }
+        if (!temperature_packed4<ALL2>(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], lm, a, den, den_two, k, &o))
+            o = temperature_cells_from_taps(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], lm, a, den, den_two, k);
         *reinterpret_cast<float4 *>(out + p) = o;
         return;
     }
@@ -707,7 +717,6 @@ __global__ __launch_bounds__(256) void k_temperature_v6(canvas c, const float *_
     // the first / last wave of rows whose seam cells k_temperature_edges computes again: like any other wave, where its 16-byte
     // loads stay in bounds across the seam (safe_lo <= y < safe_hi: two more rows stored on either side)
     const bool apart = temperature_seams_apart(rc0.flags, rc0.xlo, rc0.xhi, W);
-    unsigned done = 0;                                // bit r: row r of the group is stored
     if (fused && (all_interior || (apart && y0 >= safe_lo && y0 + ROWS <= safe_hi))) {
         float4 v[ROWS + 2][3];
         const char *Tb = reinterpret_cast<const char *>(T);
@@ -726,18 +735,18 @@ __global__ __launch_bounds__(256) void k_temperature_v6(canvas c, const float *_
             float4 o;
             const bool ok = temperature_packed4<ALL2>(v[r][0], v[r][1], v[r][2], v[r + 1][0], v[r + 1][1], v[r + 1][2], v[r + 2][0], v[r + 2][1],
                                                       v[r + 2][2], lm[r], a[r], den, den_two, k, &o);
-            if (__builtin_amdgcn_ballot_w64(!ok) == 0) {
-                *reinterpret_cast<float4 *>(out + (size_t)(y0 + r) * W + x0) = o;
-                done |= 1u << r;
-            }
+            if (__builtin_amdgcn_ballot_w64(!ok) != 0)
+                o = temperature_cells_from_taps(v[r][0], v[r][1], v[r][2], v[r + 1][0], v[r + 1][1], v[r + 1][2], v[r + 2][0], v[r + 2][1], v[r + 2][2], lm[r], a[r],
+                                                den, den_two, k);
+            *reinterpret_cast<float4 *>(out + (size_t)(y0 + r) * W + x0) = o;
         }
+        return;
     }
-    if (done == (1u << ROWS) - 1u) return;
-    // what is left: rows of a group without the common pattern, rows the packed form did not admit
+    // what is left: the rows of a group without the common pattern, one by one
 #pragma unroll
     for (int r = 0; r < ROWS; r++) {
         const int fl = r == 0 ? rc0.flags : rt[r].flags, y = y0 + r;
-        if (y >= row_end || (done >> r & 1u) || (fl & TEMP_REC_LITERAL)) continue;
+        if (y >= row_end || (fl & TEMP_REC_LITERAL)) continue;
         if (r == 0) temperature_row4<ALL2>(c, T, out, land4, a[r], k, shift, srow, rc0, y, x0, apart && y >= safe_lo && y < safe_hi);
         else {
             const temp_rowrec rcr = rec[y];
