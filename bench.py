@@ -300,6 +300,75 @@ def pmc_child(args):
     ctx.close()
 
 
+POWER_HELPER = r"""
+import re, subprocess, sys, time
+gpu = int(sys.argv[1])
+pat_c = re.compile(r"GPU\[%d\]\s*: sclk clock level: \S+ \((\d+)Mhz\)" % gpu)
+pat_p = re.compile(r"GPU\[%d\]\s*: Current Socket Graphics Package Power \(W\): ([\d.]+)" % gpu)
+while True:
+    t = time.time()
+    out = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True, timeout=20).stdout
+    c, w = pat_c.search(out), pat_p.search(out)
+    if c and w:
+        print("%.3f %.3f %s %s" % (t, time.time(), c.group(1), w.group(1)), flush=True)
+    time.sleep(0.1)
+"""
+
+
+class PowerWatch:
+    """The shader clock and the package power the timed launches really run at: a small helper process (started before the
+    warm-ups, so that nothing of it lies in the timed region; it touches no GPU runtime) loops over `rocm-smi --showclocks
+    --showpower`, and the samples that fall between begin() and end() are kept.  The 8-sweep kernel holds an MI355X at its package
+    power limit, and the clock it is given there, not the 2.4 GHz of the data sheet, is what its instruction rates have to be read
+    against (profiles/r05_clock_power.txt).  Never raises; `stop()` returns None when the tool is not there or no sample fell
+    into the window."""
+
+    def __init__(self, gpu_index=0):
+        self.gpu, self.p, self.t0, self.t1 = int(gpu_index), None, None, None
+
+    def start(self):
+        try:
+            self.p = subprocess.Popen([sys.executable, "-c", POWER_HELPER, str(self.gpu)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True,
+                                      env=child_env())
+        except Exception:
+            self.p = None
+        return self
+
+    def begin(self):
+        self.t0 = time.time()
+
+    def end(self):
+        self.t1 = time.time()
+
+    def stop(self):
+        if self.p is None:
+            return None
+        try:
+            self.p.terminate()
+            out, _ = self.p.communicate(timeout=20)
+        except Exception:
+            try:
+                self.p.kill()
+            except Exception:
+                pass
+            return None
+        if self.t0 is None or self.t1 is None:
+            return None
+        body = []
+        for line in out.splitlines():
+            try:
+                a, b, c, w = line.split()
+                if float(a) >= self.t0 and float(b) <= self.t1:      # (the whole query inside the timed region)
+                    body.append((int(c), float(w)))
+            except ValueError:
+                pass
+        if not body:
+            return None
+        clk, pw = sorted(c for c, _ in body), sorted(w for _, w in body)
+        return {"sclk_MHz": clk[len(clk) // 2], "package_W": pw[len(pw) // 2], "samples": len(body), "spec_sclk_MHz": 2400,
+                "source": "rocm-smi --showclocks --showpower looped by a helper process, the queries that lie inside the timed steps, medians (GPU[%d])" % self.gpu}
+
+
 def measure_traffic(args, kernels, bands=1, ghost=32):
     """-> {kernel name: dict(hbm_bytes_per_launch, fetch_kb_raw, write_kb_raw, launches)} or {} with a reason"""
     exe = shutil.which("rocprofv3")
@@ -529,6 +598,7 @@ def worker(args):
             return "%s: %s" % (type(e).__name__, str(e)[:300])
 
         rccl_id = ctl.fresh_id(capi) if not rehearsal else None   # (collective: every rank, before anything can fail locally)
+        watch = PowerWatch(dev_index).start() if rank == 0 and not args.no_extra_legs else None
         try:
             m = make(args.kernel, args.terrain, order_name, transport, rccl_id)
         except Exception as e:
@@ -547,12 +617,16 @@ def worker(args):
             try:
                 torch.cuda.synchronize(device)
                 s0 = m.stats()
+                if watch is not None:
+                    watch.begin()
                 t0 = time.perf_counter()
                 m.timer_start()
                 for _ in range(args.steps):
                     m.jacobi(sweeps, zero_first=True)
                 ev_ms = m.timer_stop()
                 m.sync(); torch.cuda.synchronize(device)
+                if watch is not None:
+                    watch.end()
             except Exception as e:
                 err, ev_ms = note(e), 0.0
             bad, _ = agree(err)                                       # the barrier behind it
@@ -583,6 +657,8 @@ def worker(args):
                 m.close()
         except Exception as e:
             err = err or "close: %s" % e
+        if watch is not None:
+            res["clock"] = watch.stop()
         bad, sums = agree(err, sums)
         if bad:
             res = {"transport": transport, "order": order_name, "error": err or "another rank failed in this leg"}
@@ -752,6 +828,13 @@ def worker(args):
                      "issuable_peak": FP32_ISSUABLE_TFLOPS, "frac_of_issuable": tflops / FP32_ISSUABLE_TFLOPS,
                      "issuable_note": "packed FMAs measured at two waves per SIMD (this kernel's occupancy) issue 106 TFLOP/s, 121 at four "
                                       "(tools/pk_probe.hip, profiles/r03_valu_issue_probe.log): no instruction stream reaches the spec peak"}}
+    clock = best.get("clock")
+    if clock:
+        # what the launches really ran at: the package power limit holds the shader clock below the data sheet's 2.4 GHz
+        roof["clock"] = clock
+        at = FP32_PEAK_TFLOPS * clock["sclk_MHz"] / clock["spec_sclk_MHz"]
+        roof["fp32"].update(peak_at_clock=at, frac_at_clock=tflops / at, issuable_at_clock=FP32_ISSUABLE_TFLOPS * clock["sclk_MHz"] / clock["spec_sclk_MHz"],
+                            frac_of_issuable_at_clock=tflops / (FP32_ISSUABLE_TFLOPS * clock["sclk_MHz"] / clock["spec_sclk_MHz"]))
     if nb > 1:
         roof["band"] = ("band 0 of %d (rank 0): %d owned + %d ghost rows; launch_us = band 0's stream time per launch%s"
                         % (nb, row0[1] - row0[0], ghost, ", halo exchanges taken out" if best["order"] == "exchange-then-sweep" else
@@ -766,9 +849,11 @@ def worker(args):
             roof["note"] = ("8 sweeps per launch on chip: `achieved` is the HBM traffic the launch really moves (PMC) over its "
                             "duration.  It is not what the launch waits for: the one-sweep kernel moves more bytes per second in this "
                             "same run (`demonstrated_GBps`), and round 5 built a form with HALF the bytes per sweep (16 sweeps per "
-                            "trip, two waves per unit through LDS, bit-identical) that takes the same time -- the kernel is bound by "
-                            "instruction issue and the stalls of two waves per SIMD (4.6 clocks of SIMD time per instruction; "
-                            "DESIGN.md 4.1b, profiles/r05_deep_form.txt).  The SURVEY 8d model (16 B per cell-sweep) stops bounding a "
+                            "trip, two waves per unit through LDS, bit-identical) that takes the same time.  What it runs into is the "
+                            "package power limit: these launches hold the chip at ~1390 W and the shader clock at ~2.1 GHz (`clock`, sampled "
+                            "beside the timed steps; a device copy runs at 2.4 GHz and 850 W, the one-sweep kernel at 2.4 GHz and 1270 W), "
+                            "with the vector pipe ~80 % occupied by the formula's own instructions at that clock (DESIGN.md 4.1b, "
+                            "profiles/r05_clock_power.txt, profiles/r05_deep_form.txt).  The SURVEY 8d model (16 B per cell-sweep) stops bounding a "
                             "kernel that does 8 sweeps per HBM pass: `algorithmic_x_peak`; the HBM-bound form the 60 % target is stated "
                             "for is `roofline_single`")
         else:
