@@ -89,3 +89,44 @@ def test_run_child_ends_the_process_group_it_started():
     assert rc is None and out.startswith("x")
     rc, out = bench.run_child([sys.executable, "-c", "print('{\"metric\": 1}')"], 30, dict(os.environ))
     assert rc == 0 and "metric" in out
+
+
+def test_power_watch_reads_a_looping_rocm_smi(tmp_path):
+    """bench.PowerWatch: a helper process loops over `rocm-smi --showclocks --showpower`; the queries that lie between begin() and end()
+    give the medians the bench line carries as roofline.clock.  Here against a stand-in for the tool (this container has no GPU);
+    without the tool stop() answers None and nothing is raised."""
+    import importlib.util
+    import os
+    import stat
+    import time
+    spec = importlib.util.spec_from_file_location("bench_under_test", str(ROOT / "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    fake = tmp_path / "rocm-smi"
+    fake.write_text("#!/bin/sh\n"
+                    "echo '============ ROCm System Management Interface ============'\n"
+                    "echo 'GPU[0]\t\t: sclk clock level: 1: (2051Mhz)'\n"
+                    "echo 'GPU[1]\t\t: sclk clock level: 1: (111Mhz)'\n"
+                    "echo 'GPU[0]\t\t: Current Socket Graphics Package Power (W): 1388.0'\n"
+                    "echo 'GPU[1]\t\t: Current Socket Graphics Package Power (W): 90.0'\n")
+    fake.chmod(fake.stat().st_mode | stat.S_IEXEC)
+    old = os.environ["PATH"]
+    os.environ["PATH"] = str(tmp_path) + os.pathsep + old
+    try:
+        w = bench.PowerWatch(0).start()
+        time.sleep(0.5)
+        w.begin()
+        time.sleep(1.5)
+        w.end()
+        got = w.stop()
+    finally:
+        os.environ["PATH"] = old
+    assert got and got["sclk_MHz"] == 2051 and got["package_W"] == 1388.0 and got["samples"] >= 2, got
+    # no tool at all: nothing to report, nothing raised
+    os.environ["PATH"] = str(tmp_path / "nowhere")
+    try:
+        w = bench.PowerWatch(0).start()
+        w.begin(); time.sleep(0.3); w.end()
+        assert w.stop() is None
+    finally:
+        os.environ["PATH"] = old

@@ -133,7 +133,7 @@ def _extreme_field(W, H, seed):
 
 @pytest.mark.parametrize("W,H,seed", [(512, 96, 1), (1024, 64, 2), (260, 48, 3)])
 def test_temperature_window_edges_take_either_path_to_the_same_bits(dev, oracle, W, H, seed):
-    """k_temperature_v5 asks once per wave whether every division of its 256 cells may go through the constant; waves that hold
+    """The climate kernel asks once per wave and row whether every division of its 256 cells may go through the constant; waves that hold
     a value outside the window recompute their cells with the IEEE sequences.  Fields with such patches, against the oracle's
     plain divisions, NaNs and all (W = 260: the one-cell-per-thread kernel's rows of a width that is no multiple of 4 ... 260 is:
     its seam threads then)"""
