@@ -174,12 +174,123 @@ __global__ __launch_bounds__(256) void k_blur13_axis(canvas c, const float *__re
     }
 }
 
+// Round 5: the same two passes with what is the same for a whole row kept in scalar registers.  profiles/r04_kernel_counters.txt
+// had the axis forms bound by their vector instructions (236 / 409 per cell): most of them computed, in every lane, values that
+// are the row's -- the tap rows, their weights and the pole crossings of the (0, r) pass, the two rows and the weight of the
+// (r, 0) pass -- and 64-bit addresses for 28 loads per cell.  Here six threads compute the row's part once (the same operations
+// on the same values), every lane reads it back through LDS and v_readfirstlane, and a tap's four loads are two scalar row bases
+// plus the cell's two column offsets.  What stays per cell is what depends on x: the column pair and its weight (once for the
+// (0, r) pass, per tap for the (r, 0) pass) and the three lerps per tap.  Bit-identical to k_blur13_axis and k_blur13
+// (tests/test_gpu_filters.py holds the three against each other and against the goldens).
+struct blur_row { int j0, j1, crossed; float wy; };
+__device__ __forceinline__ blur_row blur_row_uniform(const blur_row &r)
+{
+    blur_row u;
+    u.j0 = __builtin_amdgcn_readfirstlane(r.j0); u.j1 = __builtin_amdgcn_readfirstlane(r.j1);
+    u.crossed = __builtin_amdgcn_readfirstlane(r.crossed);
+    u.wy = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(r.wy)));
+    return u;
+}
+__device__ __forceinline__ float blur_tap_rows(const float *__restrict__ r0, const float *__restrict__ r1, const blur_x &bx, float wy)
+{
+    const unsigned o0 = (unsigned)bx.i0 * 4u, o1 = (unsigned)bx.i1 * 4u;
+    const char *b0 = reinterpret_cast<const char *>(r0), *b1 = reinterpret_cast<const char *>(r1);
+    const float t00 = *reinterpret_cast<const float *>(b0 + o0), t10 = *reinterpret_cast<const float *>(b0 + o1);
+    const float t01 = *reinterpret_cast<const float *>(b1 + o0), t11 = *reinterpret_cast<const float *>(b1 + o1);
+    const float a = fmaf(bx.wx, __fsub_rn(t10, t00), t00);       // (d_fetch_linear)
+    const float b = fmaf(bx.wx, __fsub_rn(t11, t01), t01);
+    return fmaf(wy, __fsub_rn(b, a), a);
+}
+template <int DIR>
+__global__ __launch_bounds__(256) void k_blur13_axis2(canvas c, const float *__restrict__ src, float *__restrict__ dst,
+                                                      const float *__restrict__ phifactor, float r)
+{
+    __shared__ float s_off[3];
+    __shared__ blur_row s_row[7];                       // [0..5]: the taps' rows (DIR 1); [6]: the cell's own rows
+    const int y = c.row0 + (int)blockIdx.y, W = c.W;
+    const float sy = d_sty(c, y);
+    if (threadIdx.x < 3) {
+        const float k = threadIdx.x == 0 ? 1.411764705882353f : (threadIdx.x == 1 ? 3.2941176470588234f : 5.176470588235294f);
+        float o = __fmul_rn(k, r);
+        if (DIR == 0) o = __fdiv_rn(o, phifactor[y]);
+        o = __fdiv_rn(o, DIR == 0 ? (float)c.W : (float)c.H);
+        s_off[threadIdx.x] = o;
+        if (DIR == 1) {
+#pragma unroll
+            for (int sgn = 0; sgn < 2; sgn++) {
+                float py = __fadd_rn(sy, sgn ? -o : o);
+                int cr = 0;
+                if (c.spole && py < 0.0f) { py = -py; cr++; }
+                if (c.npole && py > 1.0f) { py = __fsub_rn(2.0f, py); cr++; }
+                const blur_y by = blur_ypart(py, c.H);
+                s_row[2 * threadIdx.x + sgn] = blur_row{ by.j0, by.j1, cr, by.wy };
+            }
+        }
+    } else if (threadIdx.x == 3) {
+        const blur_y by = blur_ypart(sy, c.H);
+        s_row[6] = blur_row{ by.j0, by.j1, 0, by.wy };
+    }
+    __syncthreads();
+    const float w0 = 0.1964825501511404f, w[3] = { 0.2969069646728344f, 0.09447039785044732f, 0.010381362401148057f };
+    const blur_row own = blur_row_uniform(s_row[6]);
+    const float *own0 = src + (size_t)own.j0 * W, *own1 = src + (size_t)own.j1 * W;
+    const int x = min((int)(blockIdx.x * 256 + threadIdx.x), W - 1);        // (a column past the edge repeats the last: not stored)
+    const float sx = d_stx(c, x);
+    // the cell's own tap: d_fetch_linear(src, sx, sy)
+    float color = __fadd_rn(0.0f, __fmul_rn(blur_tap_rows(own0, own1, blur_xpart(sx, W), own.wy), w0));
+    if (DIR == 0) {
+        float off[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) off[k] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(s_off[k])));
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+#pragma unroll
+            for (int sgn = 0; sgn < 2; sgn++) {
+                float px = __fadd_rn(sx, sgn ? -off[k] : off[k]);
+                if (c.lonwrap) { px = d_mod(__fadd_rn(px, 1.0f), 1.0f); px = d_mod(__fadd_rn(px, 1.0f), 1.0f); }
+                color = __fadd_rn(color, __fmul_rn(blur_tap_rows(own0, own1, blur_xpart(px, W), own.wy), w[k]));
+            }
+    } else {
+        blur_row by[6];
+        int any_crossed = 0;
+#pragma unroll
+        for (int t = 0; t < 6; t++) { by[t] = blur_row_uniform(s_row[t]); any_crossed |= by[t].crossed; }
+        float px1 = sx;
+        if (c.lonwrap) px1 = d_mod(__fadd_rn(px1, 1.0f), 1.0f);
+        const blur_x plain = blur_xpart(c.lonwrap ? d_mod(__fadd_rn(px1, 1.0f), 1.0f) : px1, W);
+        blur_x mirrored = plain;
+        if (any_crossed) {                                   // (the same for every cell of the row: no divergence)
+            float px = d_pole_lon(__fadd_rn(__fmul_rn(px1, __fsub_rn(c.c3, c.c2)), c.c2));
+            px = __fdiv_rn(__fsub_rn(px, c.c2), __fsub_rn(c.c3, c.c2));
+            if (c.lonwrap) px = d_mod(__fadd_rn(px, 1.0f), 1.0f);
+            mirrored = blur_xpart(px, W);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+#pragma unroll
+            for (int sgn = 0; sgn < 2; sgn++) {
+                const int t = 2 * k + sgn;
+                float v;
+                if (by[t].crossed == 2) {
+                    const float kk = k == 0 ? 1.411764705882353f : (k == 1 ? 3.2941176470588234f : 5.176470588235294f);
+                    v = blur_tap_literal(c, src, sx, sy, sgn ? -0.0f : 0.0f, sgn ? -__fmul_rn(kk, r) : __fmul_rn(kk, r));
+                } else
+                    v = blur_tap_rows(src + (size_t)by[t].j0 * W, src + (size_t)by[t].j1 * W, by[t].crossed ? mirrored : plain, by[t].wy);
+                color = __fadd_rn(color, __fmul_rn(v, w[k]));
+            }
+    }
+    if ((int)(blockIdx.x * 256 + threadIdx.x) < W) dst[(size_t)y * W + x] = color;
+}
+
 // one pass of blur13 in direction (dirx, diry): the axis forms where they apply
 static void launch_blur13(hipStream_t st, dim3 g, const canvas &c, const float *src, float *dst, const float *pf, float dirx, float diry)
 {
     static const bool literal = dmg_hook("DMG_BLUR_LITERAL") != nullptr;       // tests: the general kernel for every pass
     const dim3 ga((unsigned)((c.W + 256 * BLUR_CPT - 1) / (256 * BLUR_CPT)), g.y);
-    if (!literal && diry == 0.0f && dirx > 0.0f) hipLaunchKernelGGL(k_blur13_axis<0>, ga, dim3(256), 0, st, c, src, dst, pf, dirx);
+    static const bool axis_v1 = dmg_hook("DMG_BLUR_AXIS_V1") != nullptr;       // tests, A/B: the round-3 axis kernels
+    if (!literal && !axis_v1 && diry == 0.0f && dirx > 0.0f) hipLaunchKernelGGL(k_blur13_axis2<0>, ga, dim3(256), 0, st, c, src, dst, pf, dirx);
+    else if (!literal && !axis_v1 && dirx == 0.0f && diry > 0.0f) hipLaunchKernelGGL(k_blur13_axis2<1>, ga, dim3(256), 0, st, c, src, dst, pf, diry);
+    else if (!literal && diry == 0.0f && dirx > 0.0f) hipLaunchKernelGGL(k_blur13_axis<0>, ga, dim3(256), 0, st, c, src, dst, pf, dirx);
     else if (!literal && dirx == 0.0f && diry > 0.0f) hipLaunchKernelGGL(k_blur13_axis<1>, ga, dim3(256), 0, st, c, src, dst, pf, diry);
     else hipLaunchKernelGGL(k_blur13, g, dim3(256), 0, st, c, src, dst, pf, dirx, diry);
 }

@@ -370,14 +370,16 @@ __global__ void k_flow_mark(const int *__restrict__ idx, unsigned char *__restri
 // the root, i.e. pointer doubling: ~log2(lakes) sweeps over flat arrays instead of a host walk that misses the cache at
 // every lake (0.3 s for 2.6 M lakes).
 __global__ void k_lake_jump(const int *__restrict__ pin, const int *__restrict__ oin, const float *__restrict__ lin,
-                            int *__restrict__ pout, int *__restrict__ oout, float *__restrict__ lout, int n)
+                            int *__restrict__ pout, int *__restrict__ oout, float *__restrict__ lout, int n, int *__restrict__ changed)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const int p = pin[i];
+    const int p = pin[i], pp = pin[p];
     oout[i] = oin[i] + oin[p];                          // (a root carries 0 and points at itself)
     lout[i] = fmaxf(lin[i], lin[p]);
-    pout[i] = pin[p];
+    pout[i] = pp;
+    // a sweep in which no pointer moves changes nothing (0 is added, the maximum is taken with itself): the forest is flat
+    if (changed && pp != p && *changed == 0) *changed = 1;
 }
 // per lake: into the per-cell tables at its sink cell, if its root is a river mouth
 __global__ void k_lake_scatter(const int *__restrict__ root, const int *__restrict__ off, const float *__restrict__ lvl,
@@ -1191,8 +1193,22 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
         while ((1ll << rounds) < nlakes) rounds++;           // paths are at most nlakes long
         int b = 0;
         const unsigned lb = (unsigned)((nlakes + 255) / 256);
-        for (int it = 0; it <= rounds; it++, b ^= 1)
-            hipLaunchKernelGGL(k_lake_jump, dim3(lb), dim3(256), 0, st, dp[b], dof[b], dlv[b], dp[b ^ 1], dof[b ^ 1], dlv[b ^ 1], nlakes);
+        // The forest is far shallower than it is large (2.6 M lakes at 16384x8192 hang a few hundred deep): where a sweep costs more
+        // than a read-back -- a quarter of a million lakes and more -- every other sweep from the fifth on reports whether a
+        // pointer still moved, and the loop ends with the first that says none did.  (Same tables: further sweeps are the identity.)
+        const bool ask = nlakes >= (1 << 18);
+        for (int it = 0; it <= rounds; it++, b ^= 1) {
+            const bool check = ask && it >= 4 && (it & 1) == 0;
+            if (check) DMG_HIP(hipMemsetAsync(changed.p, 0, 4, st));
+            hipLaunchKernelGGL(k_lake_jump, dim3(lb), dim3(256), 0, st, dp[b], dof[b], dlv[b], dp[b ^ 1], dof[b ^ 1], dlv[b ^ 1], nlakes,
+                               check ? changed.i() : (int *)nullptr);
+            if (check) {
+                int ch = 0;
+                DMG_HIP(hipMemcpyAsync(&ch, changed.p, 4, hipMemcpyDeviceToHost, st));
+                DMG_HIP(hipStreamSynchronize(st));
+                if (!ch) { b ^= 1; break; }
+            }
+        }
         hipLaunchKernelGGL(k_lake_scatter, dim3(lb), dim3(256), 0, st, dp[b], dof[b], dlv[b], (const unsigned char *)dmo.p, sinkc.i(),
                            dlo.i(), draw_lakes ? dlevel.f() : nullptr, dmax.i() + 1, nlakes);
         DMG_HIP(hipGetLastError());

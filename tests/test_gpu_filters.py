@@ -56,8 +56,9 @@ def _blur_cases(capi):
 
 
 def test_blur_axis_kernels_equal_the_literal_kernel_and_the_oracle(dev, oracle):
-    """Blur::step's two directions go through the axis forms of blur13 (k_blur13_axis); DMG_BLUR_LITERAL=1 (read once per
-    process: a child) sends every pass through the general kernel.  Same bits, and the oracle's, on random fields."""
+    """Blur::step's two directions go through the axis forms of blur13 (k_blur13_axis2: what is the same for a row in scalar
+    registers); DMG_BLUR_LITERAL=1 (read once per process: a child) sends every pass through the general kernel, DMG_BLUR_AXIS_V1=1
+    through the axis kernels of round 3.  Same bits, and the oracle's, on random fields."""
     import hashlib
     import os
     import subprocess
@@ -73,9 +74,10 @@ def test_blur_axis_kernels_equal_the_literal_kernel_and_the_oracle(dev, oracle):
             "import test_gpu_filters as t\nctx = capi.Context(0)\n"
             "for W, H, coords, r, f in t._blur_cases(capi):\n    print(hashlib.sha256(ctx.blur(capi.make_grid(W, H, coords), f, r).tobytes()).hexdigest())\n"
             % (str(Path(__file__).resolve().parents[1]), str(Path(__file__).resolve().parent)))
-    res = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DMG_BLUR_LITERAL="1"), capture_output=True, text=True, timeout=600)
-    assert res.returncode == 0, res.stderr[-2000:]
-    assert res.stdout.split() == mine
+    for hook in ("DMG_BLUR_LITERAL", "DMG_BLUR_AXIS_V1"):       # the general kernel; the axis kernels before round 5's row-uniform form
+        res = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **{hook: "1"}), capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-2000:]
+        assert res.stdout.split() == mine, hook
 
 
 def test_temperature(dev, oracle):
