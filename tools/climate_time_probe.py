@@ -26,6 +26,8 @@ h = (synth.terrain(W, H) * 100).astype(np.float32)
 # means something.  DMG_CLIMATE_PROBE_STEPS=120 times that regime.
 lat = np.linspace(-1, 1, H, dtype=np.float32)[:, None]
 T0 = (15 - 40 * np.abs(lat) + 3 * np.sin(np.linspace(0, 12 * np.pi, W, dtype=np.float32))[None, :]).astype(np.float32)
+if os.environ.get("DMG_CLIMATE_PROBE_T0") == "const":      # Temperature::Temperature's start: 50 everywhere
+    T0 = np.full((H, W), 50, np.float32)
 nsteps = int(os.environ.get("DMG_CLIMATE_PROBE_STEPS", "12"))
 # ... and with values the scheme is stable with at this resolution (dmg_climate_params: the diffusivity a hundredth of the
 # reference's: diffusion number 0.12 over land), where any number of steps stays a climate: 60 steps
