@@ -1285,6 +1285,8 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
         // that XCD's L2: workgroup-scope loads (sc0) are served by the CU's own L1 and never see another CU's sum, with or
         // without a `buffer_inv sc0` in front; `buffer_inv sc1` works at 50 ms per solve; agent-scope loads of sums stored at
         // workgroup scope work, and take as long as before (4.0 ms on one XCD against 3.2 ms on eight).
+        // (Longer sleeps for waves that have polled in vain for a while -- far from the front -- cost a third at 4096x2048 and
+        // gain nothing at 16384x8192, with 128, 256 or 512 blocks: round 5.)
         static const int nblocks_env = [] { const char *e = dmg_hook("DMG_FLOW_NBLOCKS"); return e ? atoi(e) : 0; }();
         const int blocks = std::min((waves + 3) / 4, nblocks_env > 0 ? nblocks_env : 128);
         hipLaunchKernelGGL(k_flow_dataflow, dim3(blocks), dim3(256), 0, st, fc, order.i(), n_reached, (const unsigned short *)mask.p, dcf.i(),
