@@ -852,7 +852,7 @@ def worker(args):
                             "trip, two waves per unit through LDS, bit-identical) that takes the same time.  What it runs into is the "
                             "package power limit: these launches hold the chip at ~1390 W and the shader clock at ~2.1 GHz (`clock`, sampled "
                             "beside the timed steps; a device copy runs at 2.4 GHz and 850 W, the one-sweep kernel at 2.4 GHz and 1270 W), "
-                            "with the vector pipe ~80 % occupied by the formula's own instructions at that clock (DESIGN.md 4.1b, "
+                            "with the vector pipe ~70 % occupied at that clock, nine tenths of it by the formula's own instructions (DESIGN.md 4.1b, "
                             "profiles/r05_clock_power.txt, profiles/r05_deep_form.txt).  The SURVEY 8d model (16 B per cell-sweep) stops bounding a "
                             "kernel that does 8 sweeps per HBM pass: `algorithmic_x_peak`; the HBM-bound form the 60 % target is stated "
                             "for is `roofline_single`")
