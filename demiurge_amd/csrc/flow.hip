@@ -164,12 +164,17 @@ __global__ void k_flow_parent(flow_canvas fc, const unsigned char *__restrict__ 
     dist[i] = d;
 }
 
-__global__ void k_flow_jump(const int *__restrict__ pin, const int *__restrict__ din, int *__restrict__ pout, int *__restrict__ dout,
-                            size_t n, int *__restrict__ changed)
+// One round of pointer doubling, from one pair of tables into the other.  A cell whose parent is a root is done: it adds the root's 0
+// and keeps its pointer -- and from the second round after that on, the table it would write already holds the same pair (each
+// table is consistent by itself: a pointer and the distance to it; a pointer to a root comes with the final distance), so
+// nothing is written.  After a few rounds that is nine cells in ten: 12 bytes a cell instead of 24 (round 5).  first: the
+// table written has nothing in it yet.
+__global__ void k_flow_jump(const int *__restrict__ pin, const int *__restrict__ din, int *pout, int *dout, size_t n, int *__restrict__ changed, int first)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int p = pin[i], pp = pin[p];
+    if (pp == p && !first && pout[i] == p) return;
     dout[i] = din[i] + din[p];
     pout[i] = pp;
     if (pp != p) *changed = 1;
@@ -757,7 +762,7 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
     int cur = 0;
     for (int it = 0; it < 40; it++) {
         DMG_HIP(hipMemsetAsync(changed.p, 0, 4, st));
-        hipLaunchKernelGGL(k_flow_jump, dim3(nb), dim3(256), 0, st, par[cur].i(), dst[cur].i(), par[cur ^ 1].i(), dst[cur ^ 1].i(), N, changed.i());
+        hipLaunchKernelGGL(k_flow_jump, dim3(nb), dim3(256), 0, st, par[cur].i(), dst[cur].i(), par[cur ^ 1].i(), dst[cur ^ 1].i(), N, changed.i(), it == 0 ? 1 : 0);
         DMG_HIP(hipGetLastError());
         cur ^= 1;
         // (a round past the last one changes nothing: rivers of 2^8 cells and more are the rule, so the first rounds run
