@@ -746,7 +746,7 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
     if ((rc = upload_vec(ctx, ddx, dxr)) || (rc = upload_vec(ctx, ddy, dyr)) || (rc = upload_vec(ctx, down, own))) return rc;
     DMG_ALLOC(hb, N * 4); DMG_ALLOC(tmp, N * 4); DMG_ALLOC(code, N); DMG_ALLOC(mask, N * 2);
     DMG_ALLOC(par[0], N * 4); DMG_ALLOC(par[1], N * 4); DMG_ALLOC(dst[0], N * 4); DMG_ALLOC(dst[1], N * 4);
-    DMG_ALLOC(label, N * 4); DMG_ALLOC(changed, 4); DMG_ALLOC(count, 4);
+    DMG_ALLOC(label, N * 4); DMG_ALLOC(changed, 128 * 4); DMG_ALLOC(count, 4);      // changed: a word per round (cleared once, not once per round)
 
     // findMagicNumbers: pre-blur (:90-103) then the two passes on the blurred terrain
     DMG_HIP(hipMemcpyAsync(hb.p, d_h, N * 4, hipMemcpyDeviceToDevice, st));
@@ -760,16 +760,16 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
     // catchment labels + depth by pointer jumping (log2 of the longest river iterations)
     hipLaunchKernelGGL(k_flow_parent, dim3(nb), dim3(256), 0, st, fc, (const unsigned char *)code.p, par[0].i(), dst[0].i());
     int cur = 0;
+    DMG_HIP(hipMemsetAsync(changed.p, 0, 128 * 4, st));
     for (int it = 0; it < 40; it++) {
-        DMG_HIP(hipMemsetAsync(changed.p, 0, 4, st));
-        hipLaunchKernelGGL(k_flow_jump, dim3(nb), dim3(256), 0, st, par[cur].i(), dst[cur].i(), par[cur ^ 1].i(), dst[cur ^ 1].i(), N, changed.i(), it == 0 ? 1 : 0);
+        hipLaunchKernelGGL(k_flow_jump, dim3(nb), dim3(256), 0, st, par[cur].i(), dst[cur].i(), par[cur ^ 1].i(), dst[cur ^ 1].i(), N, changed.i() + it, it == 0 ? 1 : 0);
         DMG_HIP(hipGetLastError());
         cur ^= 1;
         // (a round past the last one changes nothing: rivers of 2^8 cells and more are the rule, so the first rounds run
         // without asking; a readback costs more than the round)
         if (it < 7 && N >= ((size_t)1 << 20)) continue;
         int ch = 0;
-        DMG_HIP(hipMemcpyAsync(&ch, changed.p, 4, hipMemcpyDeviceToHost, st));
+        DMG_HIP(hipMemcpyAsync(&ch, changed.i() + it, 4, hipMemcpyDeviceToHost, st));
         DMG_HIP(hipStreamSynchronize(st));
         if (!ch) break;
     }
@@ -1203,13 +1203,13 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
         // pointer still moved, and the loop ends with the first that says none did.  (Same tables: further sweeps are the identity.)
         const bool ask = nlakes >= (1 << 18);
         for (int it = 0; it <= rounds; it++, b ^= 1) {
-            const bool check = ask && it >= 4 && (it & 1) == 0;
-            if (check) DMG_HIP(hipMemsetAsync(changed.p, 0, 4, st));
+            const bool check = ask && it >= 4 && (it & 1) == 0 && it < 64;
+            int *flag = changed.i() + 64 + it;           // (words 64.. of the table cleared in front of the cells' pointer doubling)
             hipLaunchKernelGGL(k_lake_jump, dim3(lb), dim3(256), 0, st, dp[b], dof[b], dlv[b], dp[b ^ 1], dof[b ^ 1], dlv[b ^ 1], nlakes,
-                               check ? changed.i() : (int *)nullptr);
+                               check ? flag : (int *)nullptr);
             if (check) {
                 int ch = 0;
-                DMG_HIP(hipMemcpyAsync(&ch, changed.p, 4, hipMemcpyDeviceToHost, st));
+                DMG_HIP(hipMemcpyAsync(&ch, flag, 4, hipMemcpyDeviceToHost, st));
                 DMG_HIP(hipStreamSynchronize(st));
                 if (!ch) { b ^= 1; break; }
             }
