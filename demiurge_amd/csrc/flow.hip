@@ -479,11 +479,40 @@ __global__ void k_flow_level(flow_canvas fc, const int *__restrict__ order, int 
 // river times one L2 round trip.  Values cross CUs through sc1 (L2) loads and stores.  A poll budget turns a protocol
 // error into a failed call instead of a hung GPU.
 #define FLOW_NOT_READY 0xFFFFFFFFu
-__global__ __launch_bounds__(256) void k_flow_dataflow(flow_canvas fc, const int *__restrict__ order, int n_reached,
-                                                       const unsigned short *__restrict__ mask, const int *__restrict__ conn_from,
-                                                       const float *__restrict__ own_row, unsigned *acc, int *ticket, int *error)
+// what a cell adds, in the order it adds it: the upstream neighbours in FlowFilter::neighbours order (:614-616), then the lake
+// connected to it (:617-619)
+__device__ __forceinline__ int flow_sources(const flow_canvas &fc, int p, const unsigned short *__restrict__ mask, const int *__restrict__ conn_from, int src[9])
 {
     const int W = fc.c.W, H = fc.c.H;
+    const int x0 = p % W, y0 = p / W;
+    const unsigned m = mask[p];
+    int n = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        if (!(m & (unsigned)c_nbit[k])) continue;
+        int x = x0 + c_ndx[k], y = y0 + c_ndy[k];
+        if (fc.wrap) x = (x + W) % W; else if (x < 0 || x >= W) continue;
+        if (y < 0 || y >= H) continue;
+        src[n++] = y * W + x;
+    }
+    const int from = conn_from[p];
+    if (from >= 0) src[n++] = from;
+    return n;
+}
+
+// Round 5, look-through: the kernel is bound by the chain of hops along the longest river -- a coherent store and a poll, ~1.1 us,
+// for each of ~3000 cells (finishing the four cells in five near the sources beforehand took nothing off its time).  A cell
+// that waits for exactly ONE sum need not wait for it to be PUBLISHED: while it waits it fetches what that upstream cell u itself
+// adds, and as soon as all of THAT is there it forms u's sum in a register -- the same additions in the same order, so the same
+// bits; u's own lane publishes it, this lane never does -- and goes on to its own.  The chain then advances two cells per hop.
+// (Measured and dropped with it: a wave that takes four tickets at a time and fetches the next ticket's cells while it polls for the
+// current one's -- the cells it holds without working on them are cells the front waits for: 3.2 -> 12.7 ms.  Nor does it help to
+// finish the four cells in five that sit within three hops of a source in full-width passes beforehand: 3.43 -> 3.30 ms.)
+__global__ __launch_bounds__(256) void k_flow_dataflow(flow_canvas fc, const int *__restrict__ order, int n_reached,
+                                                       const unsigned short *__restrict__ mask, const int *__restrict__ conn_from,
+                                                       const float *__restrict__ own_row, unsigned *acc, int *ticket, int *error, int look_through)
+{
+    const int W = fc.c.W;
     const int lane = threadIdx.x & 63;
     for (;;) {
         int base = 0;
@@ -497,32 +526,47 @@ __global__ __launch_bounds__(256) void k_flow_dataflow(flow_canvas fc, const int
         float own = 0.0f;
         if (pending) {
             p = order[idx];
-            const int x0 = p % W, y0 = p / W;
-            own = own_row[y0];                               // pixelwidthy*pixelwidthx*cos(geoy)*1e-5 (:608-613)
-            const unsigned m = mask[p];
-#pragma unroll
-            for (int k = 0; k < 8; k++) {                    // FlowFilter::neighbours order (:614-616)
-                if (!(m & (unsigned)c_nbit[k])) continue;
-                int x = x0 + c_ndx[k], y = y0 + c_ndy[k];
-                if (fc.wrap) x = (x + W) % W; else if (x < 0 || x >= W) continue;
-                if (y < 0 || y >= H) continue;
-                src[nsrc++] = y * W + x;
-            }
-            const int from = conn_from[p];
-            if (from >= 0) src[nsrc++] = from;               // sum += rec(connections[p].from) (:617-619)
+            own = own_row[p / W];                            // pixelwidthy*pixelwidthx*cos(geoy)*1e-5 (:608-613)
+            nsrc = flow_sources(fc, p, mask, conn_from, src);
         }
+        int u = -1, unsrc = 0, usrc[9];                      // the upstream cell looked through, and what IT adds
+        float uown = 0.0f;
         int polls = 0;
         while (__builtin_amdgcn_ballot_w64(pending)) {
             if (pending) {
                 unsigned v[9];
-                bool ready = true;
+                int missing = 0, which = 0;
 #pragma unroll
                 for (int k = 0; k < 9; k++)
                     if (k < nsrc) {
                         v[k] = __hip_atomic_load(acc + src[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        ready = ready && v[k] != FLOW_NOT_READY;
+                        if (v[k] == FLOW_NOT_READY) { missing++; which = k; }
                     }
-                if (ready) {
+                if (missing == 1 && look_through) {
+                    int cell = 0;
+#pragma unroll
+                    for (int k = 0; k < 9; k++) if (k == which) cell = src[k];
+                    if (cell != u) {                         // (once per cell looked through)
+                        u = cell;
+                        uown = own_row[u / W];
+                        unsrc = flow_sources(fc, u, mask, conn_from, usrc);
+                    }
+                    bool uready = true;
+                    float usum = uown;
+#pragma unroll
+                    for (int k = 0; k < 9; k++)
+                        if (k < unsrc) {
+                            const unsigned uv = __hip_atomic_load(acc + usrc[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            uready = uready && uv != FLOW_NOT_READY;
+                            usum = __fadd_rn(usum, __uint_as_float(uv));
+                        }
+                    if (uready) {
+#pragma unroll
+                        for (int k = 0; k < 9; k++) if (k == which) v[k] = __float_as_uint(usum);
+                        missing = 0;
+                    }
+                }
+                if (missing == 0) {
                     float sum = own;
 #pragma unroll
                     for (int k = 0; k < 9; k++)
@@ -1292,10 +1336,13 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
         // workgroup scope work, and take as long as before (4.0 ms on one XCD against 3.2 ms on eight).
         // (Longer sleeps for waves that have polled in vain for a while -- far from the front -- cost a third at 4096x2048 and
         // gain nothing at 16384x8192, with 128, 256 or 512 blocks: round 5.)
+        static const int look_env = [] { const char *e = dmg_hook("DMG_FLOW_LOOK_THROUGH"); return e ? atoi(e) : -1; }();      // experiments: 0 = every cell waits for its sums to be published
+        // (3.40 -> 3.15 ms at 4096x2048; at 16384x8192, where a level holds ten times the cells, its extra loads cost 5 %)
+        const int look_through = look_env >= 0 ? look_env : (N <= ((size_t)1 << 25) ? 1 : 0);
         static const int nblocks_env = [] { const char *e = dmg_hook("DMG_FLOW_NBLOCKS"); return e ? atoi(e) : 0; }();
         const int blocks = std::min((waves + 3) / 4, nblocks_env > 0 ? nblocks_env : 128);
         hipLaunchKernelGGL(k_flow_dataflow, dim3(blocks), dim3(256), 0, st, fc, order.i(), n_reached, (const unsigned short *)mask.p, dcf.i(),
-                           down.f(), (unsigned *)acc.p, dtick.i(), dtick.i() + 1);
+                           down.f(), (unsigned *)acc.p, dtick.i(), dtick.i() + 1, look_through);
         DMG_HIP(hipGetLastError());
         int flow_err = 0;
         DMG_HIP(hipMemcpyAsync(&flow_err, dtick.i() + 1, 4, hipMemcpyDeviceToHost, st));
