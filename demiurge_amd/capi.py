@@ -20,7 +20,10 @@ F_PRESSURE, F_DIVW, F_TERRAIN, F_V = range(4)
 SIDE_SOUTH, SIDE_NORTH = 0, 1
 QUIRK_DIFFUSION_SCALAR_RHS = 1
 QUIRK_LLVMPIPE_RASTER = 2
-QUIRK_EXACT_LLVMPIPE = 4
+QUIRK_EXACT_LLVMPIPE = 4            # round 5's bit: accepted and ignored
+QUIRK_FAST_TRANSCENDENTALS = 8
+QUIRK_JACOBI_TOLERANCE = 16
+QUIRK_TOLERANCE = QUIRK_FAST_TRANSCENDENTALS | QUIRK_JACOBI_TOLERANCE
 PRIVATE_STREAM = 1
 JACOBI_AUTO, JACOBI_SINGLE, JACOBI_BLOCKED = 0, 1, 2
 FULL_GLOBE = (np.float32(-np.pi / 2), np.float32(np.pi / 2), np.float32(-np.pi), np.float32(np.pi))  # Project.h:97

@@ -232,7 +232,7 @@ void dmg_ocean_params_default(dmg_ocean_params *p)
     p->timestep_h = 24.0f;        // :294
     p->scale = 420.0f;            // :419,:478,:574,:689
     p->wind = 10.0f;              // :342
-    p->quirks = DMG_QUIRK_DIFFUSION_SCALAR_RHS | DMG_QUIRK_EXACT_LLVMPIPE;   // :687,:693; the reference's pixels bit for bit
+    p->quirks = DMG_QUIRK_DIFFUSION_SCALAR_RHS;   // :687,:693; the reference's pixels bit for bit (no tolerance bit set)
     p->jacobi_kernel = DMG_JACOBI_AUTO;
 }
 
@@ -273,6 +273,7 @@ int dmg_ocean_create(dmg_ctx *ctx, const dmg_grid *grid, const dmg_ocean_params 
     alloc((void **)&o->jcoef, sizeof(float) * 8 * o->L);
     alloc((void **)&o->jcoefp, sizeof(float) * 4 * (o->L + 32));
     alloc((void **)&o->jcoef2, sizeof(float) * 8 * o->L);
+    alloc((void **)&o->jcoef3, sizeof(float) * 8 * o->L);
     alloc((void **)&o->rowbad, (size_t)o->L);
     alloc((void **)&o->oob_flag, sizeof(int));
     if (e != hipSuccess) {
@@ -299,7 +300,7 @@ void dmg_ocean_destroy(dmg_ocean *o)
     (void)hipSetDevice(o->ctx->device);
     (void)hipStreamSynchronize(o->ctx->stream);
     for (void *p : { (void *)o->p[0], (void *)o->p[1], (void *)o->divw, (void *)o->img, (void *)o->code, (void *)o->code8,
-                     (void *)o->v[0], (void *)o->v[1], (void *)o->rowtab, (void *)o->jcoef, (void *)o->jcoefp, (void *)o->jcoef2, (void *)o->rowbad, (void *)o->oob_flag, (void *)o->rowclass, (void *)o->rowclass_n, (void *)o->rowclass32, (void *)o->vadv })
+                     (void *)o->v[0], (void *)o->v[1], (void *)o->rowtab, (void *)o->jcoef, (void *)o->jcoefp, (void *)o->jcoef2, (void *)o->jcoef3, (void *)o->rowbad, (void *)o->oob_flag, (void *)o->rowclass, (void *)o->rowclass_n, (void *)o->rowclass32, (void *)o->vadv })
         if (p) (void)hipFree(p);
     ocean_tb_free_lists(o);
     if (o->ev_fork) (void)hipEventDestroy(o->ev_fork);

@@ -88,8 +88,9 @@ struct dmg_ocean {
     float *jcoefp = nullptr;       // [L + 32][4] = cx, 1/cx, Beta, 1/Beta of local rows -16 .. L+15, rows beyond the grid mirrored (scalar loads, no mapping)
     float *jcoef = nullptr;        // [L][8] = cx, 1/cx, Beta, 1/Beta, cy, 1/cy, -, -: a row's Jacobi coefficients in one 16-byte load (ocean_jacobi_stream.hip)
     float *jcoef2 = nullptr;       // [L][8] = the same rows as exact two-operation divisors: (h, l) of cx, of Beta, of cy with x / c == fma(x, h, x * l) (div2.hip)
+    float *jcoef3 = nullptr;       // [L][8] = ah, bh, c, e: the tolerance rendering's fused coefficients (ocean_tables.hip; DMG_QUIRK_JACOBI_TOLERANCE)
     // the streaming kernel's mirrored view of the band (units that stream southwards): the row tables reversed, built on first use
-    float *jcoef_f = nullptr, *jcoef2_f = nullptr;
+    float *jcoef_f = nullptr, *jcoef2_f = nullptr, *jcoef3_f = nullptr;
     unsigned char *rowbad_f = nullptr, *rowclass_f = nullptr;
     std::vector<unsigned char> rowbad_host;   // the same flags on the host (empty: no row is flagged), for the unit lists
     unsigned char *rowbad = nullptr; // [L] 1 = no exact pair for the row's cx or Beta: jcoef2 holds (c, 1/c) there and the kernel takes the three-operation form for that row

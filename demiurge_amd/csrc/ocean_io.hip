@@ -74,6 +74,20 @@ static int write_npy(const std::string &path, const float *data, int rows, int W
 }
 
 // what a restore must agree with: the canvas, the band split and the solver parameters
+// (quirks without round 5's DMG_QUIRK_EXACT_LLVMPIPE: that bit was set by default then and means nothing now -- a sidecar written
+// by a round-5 default handle, "quirks 5", describes the same run as today's default "quirks 1"; meta_normalised does the same to
+// the text read back)
+static std::string meta_normalised(const std::string &got)
+{
+    const size_t k = got.find(" quirks ");
+    if (k == std::string::npos) return got;
+    const size_t v0 = k + 8, v1 = got.find('\n', v0);
+    if (v1 == std::string::npos) return got;
+    char *end = nullptr;
+    const long q = strtol(got.c_str() + v0, &end, 10);
+    if (end != got.c_str() + v1) return got;
+    return got.substr(0, v0) + std::to_string((int)q & ~DMG_QUIRK_EXACT_LLVMPIPE) + got.substr(v1);
+}
 static std::string meta_text(const dmg_ocean *o, bool counters)
 {
     char b[1024];
@@ -83,7 +97,7 @@ static std::string meta_text(const dmg_ocean *o, bool counters)
                      "demiurge_hip ocean checkpoint v2\nW %d H %d\ncoords %a %a %a %a\ncircumference %a\n"
                      "band %d of %d rows %d %d\nparams pressurefactor %a jacobi_iters %d diffusion_iters %d timestep_h %a scale %a wind %a quirks %d\n",
                      g.W, g.H, g.coords[0], g.coords[1], g.coords[2], g.coords[3], g.circumference, o->rank, o->count, o->y0, o->y1,
-                     q.pressurefactor, q.jacobi_iters, q.diffusion_iters, q.timestep_h, q.scale, q.wind, q.quirks);
+                     q.pressurefactor, q.jacobi_iters, q.diffusion_iters, q.timestep_h, q.scale, q.wind, q.quirks & ~DMG_QUIRK_EXACT_LLVMPIPE);
     std::string s(b, (size_t)n);
     if (counters) {
         snprintf(b, sizeof b, "counters jacobi_launches %lld jacobi_sweeps %lld outer_steps %lld\n", o->n_launches, o->n_sweeps, o->n_outer);
@@ -173,6 +187,7 @@ int dmg_ocean_restore(dmg_ocean *o, const char *prefix)
     long long outer = o->n_outer;
     {                                                      // the sidecar must describe this canvas, band and parameter set
         const std::string want = meta_text(o, false);
+        got = meta_normalised(got);
         if (got.compare(0, want.size(), want) != 0)
             return dmg_fail(DMG_EINVAL, "%s.meta describes another run:\n%swanted:\n%s", prefix, got.c_str(), want.c_str());
         long long a = 0, b = 0, c = 0;

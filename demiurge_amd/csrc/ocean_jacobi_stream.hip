@@ -35,7 +35,9 @@ __global__ __launch_bounds__(64, 2) void k_jacobi_stream(st_args a_up, st_args a
     const int tx = __builtin_amdgcn_readfirstlane(u.x), r0 = __builtin_amdgcn_readfirstlane(u.y), r1 = __builtin_amdgcn_readfirstlane(u.z);
     const st_args &a = (__builtin_amdgcn_readfirstlane(u.w) & 2) ? a_dn : a_up;                // bit 1: a unit that streams southwards (its rows are the mirrored view's)
     const int W = a.W;
-    if (ST_OPEN_UNITS && !ST_DBG(a, 1) && (__builtin_amdgcn_readfirstlane(u.w) & 1)) {       // an open-water unit (st_units flags it)
+    // (DV = 3: with the open-unit program inlined this kernel crashes the register allocator of ROCm 7.2's clang under the
+    // iterative-ILP scheduling strategy (VirtRegAuxInfo::isRematerializable); its open units run the generic program)
+    if (ST_OPEN_UNITS && DV != 3 && !ST_DBG(a, 1) && (__builtin_amdgcn_readfirstlane(u.w) & 1)) {       // an open-water unit (st_units flags it)
         if (a.prof && lane == 0) {
             a.prof[3 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
             a.prof[3 * blockIdx.x + 2] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) | (unsigned)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(64, 2) void k_jacobi_stream(st_args a_up, st_args a
             if (yg >= 0 && yg < a.H && lu >= 0 && lu < a.L) cls_lo = (cls_lo & ~(0xFFu << (8 * q))) | ((unsigned)a.rowclass[(size_t)tx * a.L + lu] << (8 * q));
         }
     }
-    if (DV && a.rowbad) {                                    // (mirrored and clamped rows have their image's divisors)
+    if (DV == 1 && a.rowbad) {                                    // (mirrored and clamped rows have their image's divisors)
 #pragma unroll
         for (int q = 0; q < 4; q++) cls_lo |= ((unsigned)a.rowbad[st_map_row(a, e0 + lane + 64 * q).l] & 1u) << (8 * q + 2);
     }
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(128, 2) void k_jacobi_stream_twin(st_args a_up, st_
             if (yg >= 0 && yg < a.H && lu >= 0 && lu < a.L) cls_lo = (cls_lo & ~(0xFFu << (8 * q))) | ((unsigned)a.rowclass[(size_t)tx * a.L + lu] << (8 * q));
         }
     }
-    if (DV && a.rowbad) {
+    if (DV == 1 && a.rowbad) {
 #pragma unroll
         for (int q = 0; q < 4; q++) cls_lo |= ((unsigned)a.rowbad[st_map_row(a, e0 + lane + 64 * q).l] & 1u) << (8 * q + 2);
     }
@@ -253,9 +255,9 @@ static int ocean_stream_flipped_tables(dmg_ocean *o)
     // tables to every later twin or southward launch)
     const int L = o->L;
     const size_t nj = (size_t)L * 8;
-    float *jf_d = nullptr, *j2f_d = nullptr;
+    float *jf_d = nullptr, *j2f_d = nullptr, *j3f_d = nullptr;
     unsigned char *bad_d = nullptr, *cls_d = nullptr;
-    auto drop = [&](int rc) { for (void *q : { (void *)jf_d, (void *)j2f_d, (void *)bad_d, (void *)cls_d }) if (q) (void)hipFree(q); return rc; };
+    auto drop = [&](int rc) { for (void *q : { (void *)jf_d, (void *)j2f_d, (void *)j3f_d, (void *)bad_d, (void *)cls_d }) if (q) (void)hipFree(q); return rc; };
     std::vector<float> j(nj), jf(nj);
     auto flip_j = [&](const float *src, float **dst) -> int {
         DMG_HIP(hipMemcpy(j.data(), src, nj * sizeof(float), hipMemcpyDeviceToHost));
@@ -266,7 +268,7 @@ static int ocean_stream_flipped_tables(dmg_ocean *o)
     };
     DMG_HIP(hipStreamSynchronize(o->ctx->stream));
     int rc;
-    if ((rc = flip_j(o->jcoef, &jf_d)) || (rc = flip_j(o->jcoef2, &j2f_d))) return drop(rc);
+    if ((rc = flip_j(o->jcoef, &jf_d)) || (rc = flip_j(o->jcoef2, &j2f_d)) || (rc = flip_j(o->jcoef3, &j3f_d))) return drop(rc);
     {
         std::vector<unsigned char> b((size_t)L, 0), bf((size_t)L);
         if (hipMemcpy(b.data(), o->rowbad, (size_t)L, hipMemcpyDeviceToHost) != hipSuccess) return drop(dmg_fail(DMG_EHIP, "mirrored row tables: download failed"));
@@ -282,7 +284,7 @@ static int ocean_stream_flipped_tables(dmg_ocean *o)
         if (hipMalloc((void **)&cls_d, n) != hipSuccess || hipMemcpy(cls_d, cf.data(), n, hipMemcpyHostToDevice) != hipSuccess)
             return drop(dmg_fail(DMG_ENOMEM, "mirrored row tables: allocation failed"));
     }
-    o->jcoef2_f = j2f_d; o->rowbad_f = bad_d; o->rowclass_f = cls_d;
+    o->jcoef2_f = j2f_d; o->jcoef3_f = j3f_d; o->rowbad_f = bad_d; o->rowclass_f = cls_d;
     o->jcoef_f = jf_d;                                   // (the guard above reads this one: last)
     return DMG_OK;
 }
@@ -306,8 +308,10 @@ int ocean_launch_stream(dmg_ocean *o, int lo, int hi, int part, int zone_lo, int
     a.code = o->code;
     // the division form: two operations per quotient where every row constant of this band has an exact pair (div2.hip)
     static const bool div2_env = [] { const char *e = dmg_hook("DMG_JACOBI_DIV2"); return !e || atoi(e) != 0; }();
-    const bool div2 = div2_env && o->div2_ok && o->jcoef2;
-    a.jcoef = div2 ? o->jcoef2 : o->jcoef;
+    // the tolerance rendering (DMG_QUIRK_JACOBI_TOLERANCE): fused row coefficients, within 1e-5 of the exact form (st_value2s<3>)
+    const bool tol = (o->prm.quirks & DMG_QUIRK_JACOBI_TOLERANCE) != 0;
+    const bool div2 = !tol && div2_env && o->div2_ok && o->jcoef2;
+    a.jcoef = tol ? o->jcoef3 : div2 ? o->jcoef2 : o->jcoef;
     a.rowbad = div2 && o->div2_nbad ? o->rowbad : nullptr;
     a.jcoef_cy = o->jcoef + 4;                           // row 0's {cy, 1/cy}: the same for every row
     a.W = o->grid.W; a.L = o->L;
@@ -346,7 +350,7 @@ int ocean_launch_stream(dmg_ocean *o, int lo, int hi, int part, int zone_lo, int
             const long last = (long)(o->L - 1) * o->grid.W;
             ad.pin = a.pin + last; ad.pout = a.pout + last; ad.b = a.b + last; ad.code = a.code + last;
             ad.rs = -(long)o->grid.W; ad.flipped = 1;
-            ad.jcoef = div2 ? o->jcoef2_f : o->jcoef_f;
+            ad.jcoef = tol ? o->jcoef3_f : div2 ? o->jcoef2_f : o->jcoef_f;
             ad.rowbad = a.rowbad ? o->rowbad_f : nullptr;
             ad.rowclass = a.rowclass ? o->rowclass_f : nullptr;
             ad.y_first = o->grid.H - a.y_first - o->L;
@@ -354,9 +358,11 @@ int ocean_launch_stream(dmg_ocean *o, int lo, int hi, int part, int zone_lo, int
         }
         if (tl->twin) {
             o->last_kernel = "k_jacobi_stream_twin";
-            if (div2) hipLaunchKernelGGL(k_jacobi_stream_twin<1>, dim3((unsigned)tl->n), dim3(128), 0, st, a, ad);
+            if (tol) hipLaunchKernelGGL(k_jacobi_stream_twin<3>, dim3((unsigned)tl->n), dim3(128), 0, st, a, ad);
+            else if (div2) hipLaunchKernelGGL(k_jacobi_stream_twin<1>, dim3((unsigned)tl->n), dim3(128), 0, st, a, ad);
             else hipLaunchKernelGGL(k_jacobi_stream_twin<0>, dim3((unsigned)tl->n), dim3(128), 0, st, a, ad);
         }
+        else if (tol) hipLaunchKernelGGL(k_jacobi_stream<3>, dim3((unsigned)tl->n), dim3(64), (size_t)extra_lds, st, a, ad);
         else if (div2) hipLaunchKernelGGL(k_jacobi_stream<1>, dim3((unsigned)tl->n), dim3(64), (size_t)extra_lds, st, a, ad);
         else hipLaunchKernelGGL(k_jacobi_stream<0>, dim3((unsigned)tl->n), dim3(64), (size_t)extra_lds, st, a, ad);
     }

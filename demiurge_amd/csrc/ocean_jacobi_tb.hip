@@ -296,8 +296,8 @@ void ocean_tb_free_lists(dmg_ocean *o)
             if (q) (void)hipFree(q);
     o->tb_lists.clear();
     // (the streaming kernel's mirrored row tables: the classes change with the terrain, the lists go with it)
-    for (void *q : { (void *)o->jcoef_f, (void *)o->jcoef2_f, (void *)o->rowbad_f, (void *)o->rowclass_f }) if (q) (void)hipFree(q);
-    o->jcoef_f = o->jcoef2_f = nullptr; o->rowbad_f = o->rowclass_f = nullptr;
+    for (void *q : { (void *)o->jcoef_f, (void *)o->jcoef2_f, (void *)o->jcoef3_f, (void *)o->rowbad_f, (void *)o->rowclass_f }) if (q) (void)hipFree(q);
+    o->jcoef_f = o->jcoef2_f = o->jcoef3_f = nullptr; o->rowbad_f = o->rowclass_f = nullptr;
     for (auto &kv : o->tb_tuning) {
         if (kv.second.ev0) (void)hipEventDestroy(kv.second.ev0);
         if (kv.second.ev1) (void)hipEventDestroy(kv.second.ev1);
@@ -485,7 +485,8 @@ int ocean_launch_tb(dmg_ocean *o, int lo, int hi, int n, int part, int zone_lo, 
         // (a band of a split grid does not time candidates: its launches share the GPU with its second stream's edge units
         // and exchanges -- and on a one-GPU rehearsal with the other bands -- so the timings mean nothing; and the tile shapes
         // only win on grids too small to be worth splitting)
-        if (tiles88 <= 4096 && n == TB_T && a.rowclass && o->count == 1) {
+        // (the tolerance rendering is the streaming kernel's: every 8-sweep launch takes it, whatever the grid's size)
+        if (tiles88 <= 4096 && n == TB_T && a.rowclass && o->count == 1 && !(stream_ok && (o->prm.quirks & DMG_QUIRK_JACOBI_TOLERANCE))) {
             tune = &o->tb_tuning[std::make_pair(lo, hi)];
             if (tune->chosen < 0 && !part) {
                 if (!tune->ev0 && (hipEventCreate(&tune->ev0) != hipSuccess || hipEventCreate(&tune->ev1) != hipSuccess))
@@ -553,6 +554,7 @@ bool ocean_tb_tuning_open(dmg_ocean *o, int lo, int hi)
     if (tb_forced_shape().R) return false;
     static const bool use_cls = dmg_hook("DMG_TB_NOCLASS") == nullptr;
     if (!use_cls || !o->rowclass || o->count > 1) return false;
+    if ((o->prm.quirks & DMG_QUIRK_JACOBI_TOLERANCE) && ocean_stream_enabled()) return false;
     const int tiles88 = ((o->grid.W + TB_OW - 1) / TB_OW) * ((hi - lo + 47) / 48);
     if (tiles88 > 4096) return false;
     auto it = o->tb_tuning.find(std::make_pair(lo, hi));

@@ -185,7 +185,7 @@ __device__ __forceinline__ vec3 cross3(vec3 a, vec3 b)
 __device__ __forceinline__ float dot3(vec3 a, vec3 b) { return (a.z * b.z + a.y * b.y) + a.x * b.x; }   // Mesa's dot(): from the last component down
 
 // The transcendental and division steps of the trig-heavy passes, in two renderings (dmg_ocean_params.quirks,
-// DMG_QUIRK_EXACT_LLVMPIPE).  EXACT: glsl_math.h's restatement of Mesa / gallivm, IEEE divisions and square roots -- the
+// DMG_QUIRK_FAST_TRANSCENDENTALS set: the second).  EXACT: glsl_math.h's restatement of Mesa / gallivm, IEEE divisions and square roots -- the
 // reference's pixels bit for bit, at ~530 vector instructions per advected cell.  Otherwise the SAME expressions (Mesa's asin
 // and atan polynomials are approximations with 1e-4 rad of error of their own: a "better" arcsine would be further from the
 // reference than this) on the hardware's sine, cosine, log2, exp2, reciprocal and reciprocal square root (1 ulp each):
@@ -470,7 +470,7 @@ int dmg_ocean_divergence(dmg_ocean *o)
 {
     int rc = require_terrain(o, "dmg_ocean_divergence");
     if (rc) return rc;
-    const bool exact = (o->prm.quirks & DMG_QUIRK_EXACT_LLVMPIPE) != 0;
+    const bool exact = (o->prm.quirks & DMG_QUIRK_FAST_TRANSCENDENTALS) == 0;
     return exact ? launch_rows(o, k_divergence<true>, make_args(o), o->gs ? 1 : 0, o->L - (o->gn ? 1 : 0))
                  : launch_rows(o, k_divergence<false>, make_args(o), o->gs ? 1 : 0, o->L - (o->gn ? 1 : 0));
 }
@@ -557,7 +557,7 @@ int dmg_ocean_advect(dmg_ocean *o)
     }
     float k04 = powf(0.4f, 1.0f / 24.0f);                  // pow(vec2(0.4),vec2(1.0/24)) (:348), a constant
     if (o->count > 1) DMG_HIP(hipMemsetAsync(o->oob_flag, 0, sizeof(int), o->ctx->stream));
-    rc = (o->prm.quirks & DMG_QUIRK_EXACT_LLVMPIPE) ? launch_rows(o, k_advect<true>, a, o->gs, o->gs + (o->y1 - o->y0), k04)
+    rc = !(o->prm.quirks & DMG_QUIRK_FAST_TRANSCENDENTALS) ? launch_rows(o, k_advect<true>, a, o->gs, o->gs + (o->y1 - o->y0), k04)
                                                      : launch_rows(o, k_advect<false>, a, o->gs, o->gs + (o->y1 - o->y0), k04);
     if (rc) return rc;
     if (o->count > 1) {                                    // did a departure point leave the stored rows?

@@ -139,9 +139,15 @@ __device__ __forceinline__ v2f st_value2(v2f pN, v2f pS, v2f pE, v2f pW, v2f b, 
     return st_div2(t - b, k.beta, k.rb);
 }
 // the same from the two neighbour sums
+// DV = 3, the tolerance rendering (DMG_QUIRK_JACOBI_TOLERANCE; oracle/dmg_oracle.c form 3): the statement is linear in its operands,
+// fc = a (pW + pE) + b (pS + pN) - c bC with a = 1/(pw2.x Beta), b = 1/(pw2.y Beta), c = 1/Beta taken from the reference's own fp32
+// row constants in fp64.  a = ah + al, b = bh + bl with ah + bh = 0.5 exactly and e = RN(al + bl): no systematic error in the gain
+// of a smooth field, which 5000 sweeps would raise to the 5000th power.  Three fused multiply-adds on the two sums; -c bC sits in
+// the ring (st_arrive).  k.cx = ah, k.rx = bh, k.rb = e, k.beta = c.
 template <int DV = 0>
 __device__ __forceinline__ v2f st_value2s(v2f we, v2f sn, v2f b, const jacobi_row &k)
 {
+    if (DV == 3) return __builtin_elementwise_fma((v2f)k.cx, we, __builtin_elementwise_fma((v2f)k.rx, sn, __builtin_elementwise_fma((v2f)k.rb, sn, b)));
     const v2f t = st_div2<DV>(we, k.cx, k.rx) + st_div2<(DV != 0)>(sn, k.cy, k.ry);
     return st_div2<DV>(t - b, k.beta, k.rb);
 }
@@ -245,6 +251,13 @@ __device__ __forceinline__ v4f st_row_any(const v4f N, const v4f C, const v4f S,
         asm("v_pk_add_f32 %0, %1, %2 clamp" : "=v"(L1) : "v"(ksn1), "s"(one));
         const v2f we0 = __builtin_elementwise_fma(kwe0, C.xy, we.outer), we1 = __builtin_elementwise_fma(kwe1, C.zw, we.inner);
         const v2f sn0 = __builtin_elementwise_fma(ksn0, C.xy, S.xy + N.xy), sn1 = __builtin_elementwise_fma(ksn1, C.zw, S.zw + N.zw);
+        if (DV == 3) {
+            // (the ring holds -c bC, +0.0 on land: L * w + 0 is +0.0 on a land centre whatever the sign of w, and w on water)
+            const v2f w0 = st_value2s<3>(we0, sn0, bb.xy, k), w1 = st_value2s<3>(we1, sn1, bb.zw, k);
+            asm("v_pk_fma_f32 %0, %1, %2, 0" : "=v"(o0) : "v"(L0), "v"(w0));
+            asm("v_pk_fma_f32 %0, %1, %2, 0" : "=v"(o1) : "v"(L1), "v"(w1));
+            return v4f{ o0.x, o0.y, o1.x, o1.y };
+        }
         const v2f t0 = st_div2<DV>(we0, k.cx, k.rx) + st_div2<(DV != 0)>(sn0, k.cy, k.ry), t1 = st_div2<DV>(we1, k.cx, k.rx) + st_div2<(DV != 0)>(sn1, k.cy, k.ry);
         o0 = st_div2<DV>(__builtin_elementwise_fma(L0, t0, -bb.xy), k.beta, k.rb);
         o1 = st_div2<DV>(__builtin_elementwise_fma(L1, t1, -bb.zw), k.beta, k.rb);
@@ -293,7 +306,7 @@ __device__ __forceinline__ void st_level(const st_args &a, st_state &z, v4f (*br
         const int sa = st_wrap(z.slot - S), sb = sa + 1 == ST_RING ? 0 : sa + 1;
         oA = st_row_any<DV>(N0, C0, S0, bA, kA, z.cy, z.ry, true, cring[sa], lane);
         oB = st_row_any<DV>(N1, N0, C0, bB, kB, z.cy, z.ry, true, cring[sb], lane);
-    } else if (MODE == 1 || MODE == 3 || MODE == 4 || !(((z.landbits | z.mixbits | (DV ? z.badbits : 0u)) >> S) & 3u)) {   // (one two-bit field of the step's combined mask: the common case costs one scalar test)
+    } else if (MODE == 1 || MODE == 3 || MODE == 4 || !(((z.landbits | z.mixbits | (DV == 1 ? z.badbits : 0u)) >> S) & 3u)) {   // (one two-bit field of the step's combined mask: the common case costs one scalar test)
         // both rows open ocean (wave-uniform): one block of 8 independent division chains
         const jacobi_row ka = { kA.x, z.cy, kA.w, kA.y, z.ry, kA.z }, kb = { kB.x, z.cy, kB.w, kB.y, z.ry, kB.z };
         const st_we weA = st_we_sums(C0), weB = st_we_sums(N0);
@@ -305,7 +318,7 @@ __device__ __forceinline__ void st_level(const st_args &a, st_state &z, v4f (*br
         landA = (z.landbits >> (S + 1)) & 1u; landB = (z.landbits >> S) & 1u;
         const unsigned mixA = (z.mixbits >> (S + 1)) & 1u, mixB = (z.mixbits >> S) & 1u;
         const int sa = st_wrap(z.slot - S), sb = sa + 1 == ST_RING ? 0 : sa + 1;
-        if (DV && ((z.badbits >> S) & 3u)) {
+        if (DV == 1 && ((z.badbits >> S) & 3u)) {
             // a row whose divisors have no exact pair (one in a thousand): Markstein form for that row
             const unsigned badA = (z.badbits >> (S + 1)) & 1u, badB = (z.badbits >> S) & 1u;
             oA = landA ? (v4f)(0.0f) : (badA ? st_row_any<2>(N0, C0, S0, bA, kA, z.cy, z.ry, mixA != 0, cring[sa], lane)
@@ -391,9 +404,10 @@ typedef const float __attribute__((address_space(4))) *st_kptr;
 
 // the row that has arrived in staging slot [K][j]: classify it, take its pressure into level 0, park its right-hand side
 // and codes in the rings
-template <int K>
+// DV = 3 (tolerance rendering): the right-hand side is parked as -c bC, c = the row's 1 / Beta (negc = -c), +0.0 on land
+template <int K, int DV = 0>
 __device__ __forceinline__ void st_arrive(const st_args &a, st_state &z, v4f (*bring)[64], unsigned (*cring)[64], int lane,
-                                          int j, int e, unsigned cls, int slot, unsigned &land, unsigned &mix)
+                                          int j, int e, unsigned cls, int slot, unsigned &land, unsigned &mix, float negc = 0.0f)
 {
     cls &= 3u;                                               // (bit 2: the row's divisors have no exact pair, st_step)
     // (the flags as integer arithmetic on scalars: written as comparisons they come out as lane masks, turned into 0 / 1 in a
@@ -439,17 +453,20 @@ __device__ __forceinline__ void st_arrive(const st_args &a, st_state &z, v4f (*b
             cring[slot][lane] = __builtin_amdgcn_perm(sn, we, 0x05040100u) | (__builtin_amdgcn_perm(sn, we, 0x06070203u) << 4);
             // the right-hand side of a land cell becomes -0.0: x = 0 * t - (-0.0) is then +0.0 whatever the sign of t
             v4f bq = z.bs[K][j];
-            asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(bq.x) : "v"(code_mask<4>(c, 0)), "v"(0x80000000u), "v"(bq.x));
-            asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(bq.y) : "v"(code_mask<12>(c, 0)), "v"(0x80000000u), "v"(bq.y));
-            asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(bq.z) : "v"(code_mask<20>(c, 0)), "v"(0x80000000u), "v"(bq.z));
-            asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(bq.w) : "v"(code_mask<28>(c, 0)), "v"(0x80000000u), "v"(bq.w));
+            if (DV == 3) { bq.xy = bq.xy * negc; bq.zw = bq.zw * negc; }
+            const unsigned landb = DV == 3 ? 0u : 0x80000000u;
+            asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(bq.x) : "v"(code_mask<4>(c, 0)), "v"(landb), "v"(bq.x));
+            asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(bq.y) : "v"(code_mask<12>(c, 0)), "v"(landb), "v"(bq.y));
+            asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(bq.z) : "v"(code_mask<20>(c, 0)), "v"(landb), "v"(bq.z));
+            asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(bq.w) : "v"(code_mask<28>(c, 0)), "v"(landb), "v"(bq.w));
             st_park_pairs(&bring[slot][lane], bq);
             return;
         }
     }
     // (an open row among coast rows goes through the coast formula with the rest of its step: counts of zero)
     cring[slot][lane] = 0u;                                   // (a land row's entry is never read: no test)
-    st_park_pairs(&bring[slot][lane], z.bs[K][j]);
+    if (DV == 3) { v4f bq = z.bs[K][j]; bq.xy = bq.xy * negc; bq.zw = bq.zw * negc; st_park_pairs(&bring[slot][lane], bq); }
+    else st_park_pairs(&bring[slot][lane], z.bs[K][j]);
 }
 
 // class of the row in staging slot [K][j] (persistent form): rows beyond the grid or the stored band count as mixed
@@ -527,13 +544,16 @@ __device__ __forceinline__ void st_step(const st_args &a, st_state &z, v4f (*bri
 #endif
     // (twin units: the partner has read the last row handed over -- ring slots 10 and 11 are the unit's own from here on)
     if (TW && K == 0 && t == TB_T / 2) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    st_arrive<K>(a, z, bring, cring, lane, 0, e_t, clsA, z.slot, landA, mixA);
-    st_arrive<K>(a, z, bring, cring, lane, 1, e_t + 1, clsB, slotB, landB, mixB);
+    // (tolerance rendering: the two rows' -1 / Beta from the table, window rows 2t and 2t + 1; every lane reads the same word)
+    const float ncA = DV == 3 ? -reinterpret_cast<const float *>(&ktab[st_kt<P>(2 * t)])[3] : 0.0f;
+    const float ncB = DV == 3 ? -reinterpret_cast<const float *>(&ktab[st_kt<P>(2 * t + 1)])[3] : 0.0f;
+    st_arrive<K, DV>(a, z, bring, cring, lane, 0, e_t, clsA, z.slot, landA, mixA, ncA);
+    st_arrive<K, DV>(a, z, bring, cring, lane, 1, e_t + 1, clsB, slotB, landB, mixB, ncB);
     if (TW && K == 0 && t == 0) st_twin_hand_over<0, K>(z, xme, xpeer, lane, false);      // "level 0": the partner's first row is this unit's row -1
     z.landbits = (z.landbits << 2) | (landA << 1) | landB;
     z.mixbits = (z.mixbits << 2) | (mixA << 1) | mixB;
-    if (DV) z.badbits = (z.badbits << 2) | ((clsA >> 1) & 2u) | ((clsB >> 2) & 1u);
-    const unsigned special = DV ? z.badbits : 0u;           // rows that need the tested path like an all-land row does
+    if (DV == 1) z.badbits = (z.badbits << 2) | ((clsA >> 1) & 2u) | ((clsB >> 2) & 1u);
+    const unsigned special = DV == 1 ? z.badbits : 0u;           // rows that need the tested path like an all-land row does
     // the staging set is free again: the pair of step t + 2 (past the window's end the rows are clamped and unused)
     if (!P) { z.fc[K][0] = st_class4(cls_lo, 2 * t + 4); z.fc[K][1] = st_class4(cls_lo, 2 * t + 5); }
     st_fetch<P>(a, z, K, 0, e_t + 4, col, colp, tx, P ? 2u : z.fc[K][0]);
@@ -630,7 +650,13 @@ __device__ __forceinline__ void st_open_step(const st_args &a, st_state &z, v4f 
         asm volatile("v_pk_mov_b32 %0, %1, %2 op_sel:[0,1]" : "=v"(lo) : "v"(z.ps[K][j].xy), "v"(z.ps[K][j].zw) : "memory");
         asm volatile("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=v"(hi) : "v"(z.ps[K][j].xy), "v"(z.ps[K][j].zw) : "memory");
         z.w[0][K][j] = v4f{ lo.x, lo.y, hi.x, hi.y };
-        st_park_pairs(&bring[z.slot + j][lane], z.bs[K][j]);
+        if (DV == 3) {
+            const v4f kc = ktab[2 * t + j];
+            const float negc = -kc.w;
+            v4f bq = z.bs[K][j]; bq.xy = bq.xy * negc; bq.zw = bq.zw * negc;
+            st_park_pairs(&bring[z.slot + j][lane], bq);
+        }
+        else st_park_pairs(&bring[z.slot + j][lane], z.bs[K][j]);
     }
     // the pair of step t + 2
     const unsigned voA = rowb + col4, voB = voA + (unsigned)a.W * 4u;

@@ -92,5 +92,21 @@ int ocean_upload_row_tables(dmg_ocean *o)
         DMG_HIP(hipMemcpyAsync(o->rowbad, bad.data(), bad.size(), hipMemcpyHostToDevice, o->ctx->stream));
         DMG_HIP(hipStreamSynchronize(o->ctx->stream));
     }
+    {   // the tolerance rendering's coefficients (DMG_QUIRK_JACOBI_TOLERANCE; ocean_stream_dev.h, st_value2s<3>): the statement
+        // ((pW + pE)/pw2.x + (pS + pN)/pw2.y - bC)/Beta is a (pW + pE) + b (pS + pN) - c bC with a = 1/(pw2.x Beta), b = 1/(pw2.y Beta),
+        // c = 1/Beta, from the fp32 row constants above (the reference's own) in fp64.  [L][8] = ah, bh, c, e: ah + bh = 0.5 exactly
+        // (the larger of a, b rounded, the other 0.5 minus it: exact), e = RN((a - ah) + (b - bh))
+        std::vector<float> j3((size_t)L * 8, 0.0f);
+        for (int l = 0; l < L; l++) {
+            const double cx = jc[(size_t)l * 8 + 0], be = jc[(size_t)l * 8 + 2], cy = jc[(size_t)l * 8 + 4];
+            const double a = 1.0 / (cx * be), b = 1.0 / (cy * be);
+            float ah, bh;
+            if (a >= b) { ah = (float)a; bh = 0.5f - ah; } else { bh = (float)b; ah = 0.5f - bh; }
+            float *e = &j3[(size_t)l * 8];
+            e[0] = ah; e[1] = bh; e[2] = (float)(1.0 / be); e[3] = (float)((a - (double)ah) + (b - (double)bh));
+        }
+        DMG_HIP(hipMemcpyAsync(o->jcoef3, j3.data(), j3.size() * sizeof(float), hipMemcpyHostToDevice, o->ctx->stream));
+        DMG_HIP(hipStreamSynchronize(o->ctx->stream));
+    }
     return DMG_OK;
 }

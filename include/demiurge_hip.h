@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define DMG_VERSION 100            /* 0.1.0 */
+#define DMG_VERSION 101            /* 0.1.1: round 6 -- quirks: set bits mean tolerance (DMG_QUIRK_EXACT_LLVMPIPE ignored) */
 
 enum {
     DMG_OK = 0,
@@ -86,15 +86,27 @@ enum { DMG_JACOBI_AUTO = 0, DMG_JACOBI_SINGLE = 1, DMG_JACOBI_BLOCKED = 2 };
  * the software GL path's pixels on e.g. the reference's default 1000x500 canvas.  Identical to the default kernels on
  * power-of-two grids; slow (not a performance path). */
 #define DMG_QUIRK_LLVMPIPE_RASTER 2
-/* Set by dmg_ocean_params_default: every pass reproduces the reference's pixels (as Mesa llvmpipe renders its GLSL) bit for bit.
- * north_star asks for 1e-5 relative; the bits cost the trig-heavy passes most of their time (advect: 530 vector instructions per
- * cell, two thirds of them Mesa's sine / cosine / pow expansions and IEEE division sequences; divergence: four IEEE divisions by
- * row constants per cell).  Cleared: advect and divergence keep the reference's expressions -- Mesa's arcsine and arctangent
- * polynomials included, which are approximations of their own, and gallivm's sine / cosine (the hardware's are good to 1e-6 absolute:
- * 2.6e-3 cells of longitude at 16384 wide) -- but take log2, exp2, reciprocals and square roots from the hardware (1 ulp): results
- * within 1e-5 of the exact rendering after a whole outer step (tests/test_gpu_ocean_passes.py).  The pressure solve, diffusion and subDiv (whose coastline snapping turns on comparisons of
- * angles: no tolerance there) are the same in both renderings. */
+/* The default (no tolerance bit set) reproduces the reference's pixels -- as Mesa llvmpipe renders its GLSL -- bit for bit in every
+ * pass.  north_star asks for 1e-5 relative; the bits cost the trig-heavy passes and the pressure solve most of their time.  The
+ * tolerance renderings are opt-in, one bit each (round 6, ADVICE r5: SET means tolerance, so every quirks value an older caller
+ * holds keeps its meaning):
+ * DMG_QUIRK_FAST_TRANSCENDENTALS: advect and divergence keep the reference's expressions -- Mesa's arcsine and arctangent
+ *   polynomials included, which are approximations of their own, and gallivm's sine / cosine (the hardware's are good to 1e-6
+ *   absolute: 2.6e-3 cells of longitude at 16384 wide) -- but take log2, exp2, reciprocals and square roots from the hardware
+ *   (1 ulp): within 1e-5 of the exact rendering after a whole outer step (tests/test_gpu_ocean_passes.py).  Diffusion and subDiv
+ *   (whose coastline snapping turns on comparisons of angles: no tolerance there) are the same in both renderings.
+ * DMG_QUIRK_JACOBI_TOLERANCE: the pressure sweep ((pW + pE)/pw2.x + (pS + pN)/pw2.y - bC)/Beta (OceanCurrents.cpp:480) as
+ *   a (pW + pE) + b (pS + pN) - c bC with a = 1/(pw2.x Beta), b = 1/(pw2.y Beta), c = 1/Beta formed in fp64 from the reference's own
+ *   fp32 row constants; a = ah + al, b = bh + bl with ah + bh = 0.5 exactly and the residues folded into one term, so that the gain
+ *   of a smooth field carries no systematic error through the 5000 sweeps: three fused multiply-adds per cell instead of three
+ *   divisions.  2.5e-6 of the field's maximum from the exact rendering after 5000 sweeps (1.8e-6 from the llvmpipe golden at
+ *   256x128; tools/jacobi_tolerance_eval.py), bit-equal to the oracle's form 3.  Applies to the launches of 8 sweeps (the
+ *   streaming kernel); the last 1..7 sweeps of a count that is no multiple of 8 run in the exact arithmetic.
+ * DMG_QUIRK_EXACT_LLVMPIPE (4) was round 5's "exact" bit, set by default then; it is accepted and ignored. */
 #define DMG_QUIRK_EXACT_LLVMPIPE 4
+#define DMG_QUIRK_FAST_TRANSCENDENTALS 8
+#define DMG_QUIRK_JACOBI_TOLERANCE 16
+#define DMG_QUIRK_TOLERANCE (DMG_QUIRK_FAST_TRANSCENDENTALS | DMG_QUIRK_JACOBI_TOLERANCE)
 
 /* field ids for dmg_ocean_halo */
 enum { DMG_F_PRESSURE = 0, DMG_F_DIVW = 1, DMG_F_TERRAIN = 2, DMG_F_V = 3 /* interleaved (vx,vy), 8 B per cell */,

@@ -448,6 +448,95 @@ void orc_ocean_jacobi_rows(const orc_grid *g, const float *img, const float *div
     free(cx); free(cy); free(be); free(pc);
 }
 
+/* ---- tolerance renderings of the sweep (north_star allows 1e-5 relative) ---------------------------
+ * fc = ((pW + pE)/pw2.x + (pS + pN)/pw2.y - bC)/Beta (OceanCurrents.cpp:480) is linear in its operands with three row
+ * constants: fc = a (pW + pE) + b (pS + pN) - c bC,  a = 1/(pw2.x Beta), b = 1/(pw2.y Beta), c = 1/Beta -- taken from the
+ * reference's OWN fp32 row constants (its Beta is RN(2 (RN(1/pw2.x) + RN(1/pw2.y))), so 2a + 2b is 1 + delta, |delta| <~ 1e-7:
+ * the gain of a constant field per sweep, which 5000 sweeps raise to the 5000th power) and evaluated in fp64 before rounding.
+ *   form 1: a, b, c rounded to fp32; t = RN(c bC); fc = fma(a, we, fma(b, sn, -t))                       (2 adds, 1 mul, 2 fma)
+ *   form 2: a = ah + al, b = bh + bl with ah + bh = 0.5 EXACTLY (the larger of the two rounded, the other 0.5 minus it:
+ *           exact by Sterbenz) and the residues al, bl rounded: fc = fma(ah, we, fma(bh, sn, fma(bl, sn, fma(al, we, -t))))
+ *           -- no systematic error in the gain of smooth fields                                            (2 adds, 1 mul, 4 fma)
+ *   form 3: as 2 with the residues folded on the N/S sum: e = RN(al + bl): fma(ah, we, fma(bh, sn, fma(e, sn, -t)))
+ *           (exact for a constant field; the E/W and N/S sums of a smooth field differ by its curvature)   (2 adds, 1 mul, 3 fma)
+ *   form 4: the reference's three divisions as plain multiplications by rounded reciprocals (DESIGN.md 4's rejected form)
+ * Land handling as in the exact form (a land neighbour reads the centre, a land centre is 0).
+ * Test infrastructure: evaluated by tools/jacobi_tolerance_eval.py against the llvmpipe golden and the exact form. */
+void orc_jacobi_fused_tables(const orc_grid *g, int form, float *tab /* [H][8]: ah, bh, al, bl, c, e, -, - */)
+{
+    const int H = g->H;
+    float *cx = malloc(sizeof(float) * H), *cy = malloc(sizeof(float) * H), *be = malloc(sizeof(float) * H);
+    orc_jacobi_row_tables(g, cx, cy, be);
+    for (int y = 0; y < H; y++) {
+        const double a = 1.0 / ((double)cx[y] * (double)be[y]), b = 1.0 / ((double)cy[y] * (double)be[y]);
+        float *t = tab + (size_t)y * 8;
+        memset(t, 0, 8 * sizeof(float));
+        t[4] = (float)(1.0 / (double)be[y]);
+        if (form == 1) { t[0] = (float)a; t[1] = (float)b; continue; }
+        float ah, bh;
+        if (a >= b) { ah = (float)a; bh = 0.5f - ah; } else { bh = (float)b; ah = 0.5f - bh; }
+        t[0] = ah; t[1] = bh;
+        t[2] = (float)(a - (double)ah); t[3] = (float)(b - (double)bh);
+        t[5] = (float)((a - (double)ah) + (b - (double)bh));
+    }
+    free(cx); free(cy); free(be);
+}
+
+void orc_ocean_jacobi_rows_form(const orc_grid *g, const float *img, const float *divw, float *p, float *scratch,
+                                int iters, int nth, int form)
+{
+    if (form == 0) { orc_ocean_jacobi_rows(g, img, divw, p, scratch, iters, nth); return; }
+    const int W = g->W, H = g->H;
+    float *cx = malloc(sizeof(float) * H), *cy = malloc(sizeof(float) * H), *be = malloc(sizeof(float) * H);
+    float *tab = malloc(sizeof(float) * 8 * H);
+    int *pc = malloc(sizeof(int) * W);
+    orc_jacobi_row_tables(g, cx, cy, be);
+    orc_jacobi_fused_tables(g, form == 4 ? 1 : form, tab);
+    orc_pole_columns(g, pc);
+    orc_topo t = topo_of(g);
+    nth = nthreads_rows(H, nth);
+    float *a = p, *b = scratch;
+    for (int it = 0; it < iters; it++) {
+#pragma omp parallel for schedule(static) num_threads(nth)
+        for (int y = 0; y < H; y++) {
+            const float *k = tab + (size_t)y * 8;
+            const float ah = k[0], bh = k[1], al = k[2], bl = k[3], c = k[4], e = k[5];
+            const float rcx = 1.0f / cx[y], rcy = 1.0f / cy[y], rbe = 1.0f / be[y];
+            const float *rowC = a + (size_t)y * W, *imgC = img + (size_t)y * W;
+            int yn = y + 1, ys = y - 1, nflip = 0, sflip = 0;
+            if (yn >= H) { yn = H - 1; nflip = t.npole; }
+            if (ys < 0) { ys = 0; sflip = t.spole; }
+            const float *rowN = a + (size_t)yn * W, *imgN = img + (size_t)yn * W;
+            const float *rowS = a + (size_t)ys * W, *imgS = img + (size_t)ys * W;
+            for (int x = 0; x < W; x++) {
+                int xe = x + 1, xw = x - 1;
+                if (t.lonwrap) { if (xe >= W) xe = 0; if (xw < 0) xw = W - 1; }
+                else { if (xe >= W) xe = W - 1; if (xw < 0) xw = 0; }
+                int xn = nflip ? pc[x] : x, xs = sflip ? pc[x] : x;
+                float pC = rowC[x];
+                float pN = imgN[xn] > 0 ? pC : rowN[xn];
+                float pS = imgS[xs] > 0 ? pC : rowS[xs];
+                float pE = imgC[xe] > 0 ? pC : rowC[xe];
+                float pW = imgC[xw] > 0 ? pC : rowC[xw];
+                const float we = pW + pE, sn = pS + pN, bC = divw[(size_t)y * W + x];
+                float fc;
+                if (form == 4) fc = ((we * rcx + sn * rcy) - bC) * rbe;
+                else {
+                    const float tt = c * bC;
+                    if (form == 1) fc = fmaf(ah, we, fmaf(bh, sn, -tt));
+                    else if (form == 2) fc = fmaf(ah, we, fmaf(bh, sn, fmaf(bl, sn, fmaf(al, we, -tt))));
+                    else fc = fmaf(ah, we, fmaf(bh, sn, fmaf(e, sn, -tt)));
+                }
+                if (imgC[x] > 0) fc = 0;
+                b[(size_t)y * W + x] = fc;
+            }
+        }
+        float *s = a; a = b; b = s;
+    }
+    if (a != p) memcpy(p, a, sizeof(float) * (size_t)W * H);
+    free(cx); free(cy); free(be); free(tab); free(pc);
+}
+
 /* get_velocity(st,o) of divergence/diffusion shaders (OceanCurrents.cpp:376-393, :647-661).
  * Returns v (sign-flipped across a pole) and the neighbour coordinate. */
 static inline void get_velocity(const orc_grid *g, const float *v, float sx, float sy, float ox, float oy,

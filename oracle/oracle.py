@@ -42,6 +42,8 @@ def lib():
         L.orc_set_glsl_math.argtypes = [ctypes.c_int]
         L.orc_ocean_jacobi.argtypes = [G, P, P, P, P, ctypes.c_int]
         L.orc_ocean_jacobi_rows.argtypes = [G, P, P, P, P, ctypes.c_int, ctypes.c_int]
+        L.orc_ocean_jacobi_rows_form.argtypes = [G, P, P, P, P, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        L.orc_jacobi_fused_tables.argtypes = [G, ctypes.c_int, P]
         L.orc_ocean_divergence.argtypes = [G, P, P, ctypes.c_float, P]
         L.orc_ocean_diffusion.argtypes = [G, P, P, P, ctypes.c_int, ctypes.c_int]
         L.orc_ocean_advect.argtypes = [G, P, P, P]
@@ -106,6 +108,21 @@ def ocean_jacobi(g, img, divw, iters, p0=None, rows=False, nthreads=0):
     else:
         lib().orc_ocean_jacobi(ctypes.byref(g), _ptr(img), _ptr(divw), _ptr(p), _ptr(s), iters)
     return p
+
+
+def ocean_jacobi_form(g, img, divw, iters, form, p0=None, nthreads=0):
+    """a tolerance rendering of the sweep (dmg_oracle.c: orc_ocean_jacobi_rows_form); form 0 is the exact row-table form"""
+    img, divw = _f32(img), _f32(divw)
+    p = np.zeros((g.H, g.W), np.float32) if p0 is None else _f32(p0).copy()
+    s = np.empty_like(p)
+    lib().orc_ocean_jacobi_rows_form(ctypes.byref(g), _ptr(img), _ptr(divw), _ptr(p), _ptr(s), iters, nthreads, form)
+    return p
+
+
+def jacobi_fused_tables(g, form):
+    tab = np.zeros((g.H, 8), np.float32)
+    lib().orc_jacobi_fused_tables(ctypes.byref(g), form, _ptr(tab))
+    return tab
 
 
 def ocean_divergence(g, img, v, pressurefactor=100.0):

@@ -17,6 +17,9 @@ sys.path.insert(0, str(ROOT / "oracle"))
 sys.path.insert(0, str(ROOT / "tests"))
 
 f32 = np.float32
+# STREAM_WORKER_FORM=3 (round 6): every case in the tolerance rendering (DMG_QUIRK_JACOBI_TOLERANCE) against the oracle's form 3 --
+# bit for bit, like the exact cases: launches of 8 sweeps in the fused form, the last 1..7 sweeps of a count in the exact form
+FORM = int(os.environ.get("STREAM_WORKER_FORM", "0"))
 BELT = (f32(-1.0), f32(1.2), f32(-np.pi), f32(np.pi))
 
 
@@ -30,6 +33,8 @@ def solve(capi, ctx, grid, img, b, iters, p0=None, bands=1, ghost=1, block=8, sp
     from test_gpu_jacobi import exchange
     prm = capi.default_ocean_params()
     prm.jacobi_kernel = capi.JACOBI_BLOCKED
+    if FORM == 3:
+        prm.quirks |= capi.QUIRK_JACOBI_TOLERANCE
     oc = [capi.Ocean(ctx, grid, params=prm, band_rank=r, band_count=bands, ghost=ghost) for r in range(bands)]
     for o in oc:
         o.set_terrain(img)
@@ -66,6 +71,15 @@ def solve(capi, ctx, grid, img, b, iters, p0=None, bands=1, ghost=1, block=8, sp
     return out["pressure"]
 
 
+def ref_solve(oracle, g, img, b, iters, p0=None, rows=True, nthreads=0):
+    """the oracle's solve in the form under test"""
+    if FORM != 3:
+        return oracle.ocean_jacobi(g, img, b, iters, p0=p0, rows=rows, nthreads=nthreads)
+    n8 = iters // 8 * 8
+    p = oracle.ocean_jacobi_form(g, img, b, n8, 3, p0=p0, nthreads=nthreads) if n8 else p0
+    return oracle.ocean_jacobi(g, img, b, iters - n8, p0=p, rows=True, nthreads=nthreads) if iters > n8 else p
+
+
 def same(tag, got, ref):
     bad = got.view(np.uint32) != ref.view(np.uint32)
     if bad.any():
@@ -94,7 +108,7 @@ def case_random(capi, ctx, oracle, names):
             img = np.repeat(np.repeat(np.where(rng.random((H // 2 + 1, W // 64 + 1)) < land, 1.0, -1.0), 2, 0), 64, 1)[:H, :W].astype(f32)
         b = rng.standard_normal((H, W)).astype(f32)
         p0 = rng.standard_normal((H, W)).astype(f32)
-        ref = oracle.ocean_jacobi(ogrid(oracle, grid), img, b, iters, p0=p0, rows=True)
+        ref = ref_solve(oracle, ogrid(oracle, grid), img, b, iters, p0=p0, rows=True)
         ok &= same("random %d: %dx%d x%d %s land %.2f" % (case, W, H, iters, "belt" if coords is BELT else "globe", land),
                    solve(capi, ctx, grid, img, b, iters, p0=p0, names=names), ref)
     return ok
@@ -114,7 +128,7 @@ def case_pepper(capi, ctx, oracle, names):
         img[rng.random((H, W)) < 0.05] = -1.0            # ... and lakes inside the continents
         b = rng.standard_normal((H, W)).astype(f32)
         p0 = (rng.standard_normal((H, W)) * 3).astype(f32)
-        ref = oracle.ocean_jacobi(ogrid(oracle, grid), img, b, 24, p0=p0, rows=True)
+        ref = ref_solve(oracle, ogrid(oracle, grid), img, b, 24, p0=p0, rows=True)
         ok &= same("pepper 2048x1024 " + tag, solve(capi, ctx, grid, img, b, 24, p0=p0, names=names), ref)
     return ok
 
@@ -127,9 +141,14 @@ def case_golden(capi, ctx, oracle, names):
     ok = True
     for iters, key in ((8, None), (104, None), (5000, "p5000")):
         got = solve(capi, ctx, grid, G["img"], G["divw"], iters, names=names)
-        if key:
+        if key and FORM == 3:
+            # (VERDICT r5 item 2's bound: half of north_star's 1e-5 against the reference's own pixels -- and not the same bits)
+            err = float(np.max(np.abs(got.astype(np.float64) - G[key])) / np.max(np.abs(G[key])))
+            print("tolerance rendering vs llvmpipe golden x%d: %.3g" % (iters, err), flush=True)
+            ok &= err <= 5e-6 and not np.array_equal(got, G[key])
+        elif key:
             ok &= same("golden 256x128 x%d vs llvmpipe" % iters, got, G[key])
-        ok &= same("golden 256x128 x%d vs oracle" % iters, got, oracle.ocean_jacobi(ogrid(oracle, grid), G["img"], G["divw"], iters, rows=True))
+        ok &= same("golden 256x128 x%d vs oracle" % iters, got, ref_solve(oracle, ogrid(oracle, grid), G["img"], G["divw"], iters, rows=True))
     return ok
 
 
@@ -142,7 +161,7 @@ def case_bands(capi, ctx, oracle, names):
         img = np.where(rng.random((H, W)) < 0.2, 1.0, -1.0).astype(f32)
         b = rng.standard_normal((H, W)).astype(f32)
         p0 = rng.standard_normal((H, W)).astype(f32)
-        ref = oracle.ocean_jacobi(ogrid(oracle, grid), img, b, iters, p0=p0, rows=True)
+        ref = ref_solve(oracle, ogrid(oracle, grid), img, b, iters, p0=p0, rows=True)
         ok &= same("bands %dx%d %d bands ghost %d" % (W, H, bands, ghost),
                    solve(capi, ctx, grid, img, b, iters, p0=p0, bands=bands, ghost=ghost, block=ghost, names=names), ref)
     return ok
@@ -164,7 +183,7 @@ def case_split(capi, ctx, oracle, names):
             img = synth.terrain(W, H)
         b = rng.standard_normal((H, W)).astype(f32)
         p0 = rng.standard_normal((H, W)).astype(f32)
-        ref = oracle.ocean_jacobi(ogrid(oracle, grid), img, b, iters, p0=p0, rows=True, nthreads=16)
+        ref = ref_solve(oracle, ogrid(oracle, grid), img, b, iters, p0=p0, rows=True, nthreads=16)
         ok &= same("split %dx%d %d bands ghost %d" % (W, H, bands, ghost),
                    solve(capi, ctx, grid, img, b, iters, p0=p0, bands=bands, ghost=ghost, block=ghost, split=True, names=names), ref)
     return ok
@@ -184,7 +203,7 @@ def case_open(capi, ctx, oracle, names):
         img = synth.terrain(W, H) if terrain == "survey" else -np.ones((H, W), f32)
         b = rng.standard_normal((H, W)).astype(f32)
         p0 = rng.standard_normal((H, W)).astype(f32)
-        ref = oracle.ocean_jacobi(ogrid(oracle, grid), img, b, iters, p0=p0, rows=True, nthreads=16)
+        ref = ref_solve(oracle, ogrid(oracle, grid), img, b, iters, p0=p0, rows=True, nthreads=16)
         ok &= same("open units %dx%d x%d %s %s" % (W, H, iters, terrain, "belt" if coords is BELT else "globe"),
                    solve(capi, ctx, grid, img, b, iters, p0=p0, names=names), ref)
     return ok
@@ -222,7 +241,7 @@ def case_twin(capi, ctx, oracle, names):
             img = -np.ones((H, W), f32)
         b = rng.standard_normal((H, W)).astype(f32)
         p0 = rng.standard_normal((H, W)).astype(f32)
-        ref = oracle.ocean_jacobi(ogrid(oracle, grid), img, b, iters, p0=p0, rows=True, nthreads=16)
+        ref = ref_solve(oracle, ogrid(oracle, grid), img, b, iters, p0=p0, rows=True, nthreads=16)
         ok &= same("twin units %dx%d x%d %s %s" % (W, H, iters, terrain, "belt" if coords is BELT else "globe"),
                    solve(capi, ctx, grid, img, b, iters, p0=p0, names=names), ref)
     return ok

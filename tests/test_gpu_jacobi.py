@@ -18,11 +18,12 @@ def dev():
     ctx.close()
 
 
-def run_jacobi(capi, ctx, grid, img, divw, iters, p0=None, bands=1, ghost=1, block=1, kernel=0):
+def run_jacobi(capi, ctx, grid, img, divw, iters, p0=None, bands=1, ghost=1, block=1, kernel=0, quirks=0):
     """Single GPU.  bands > 1 emulates the latitude-band split on one device: one dmg_ocean per band, halo
     slabs moved with dmg_copy_device between sweep blocks of `block` (<= ghost) sweeps."""
     prm = capi.default_ocean_params()
     prm.jacobi_kernel = kernel
+    prm.quirks |= quirks
     oc = [capi.Ocean(ctx, grid, params=prm, band_rank=r, band_count=bands, ghost=ghost) for r in range(bands)]
     for o in oc:
         o.set_terrain(img)
@@ -269,6 +270,27 @@ def test_blocked_full_size_bitwise(dev, oracle):
     assert np.array_equal(blocked, ref)
 
 
+def test_tolerance_rendering_full_size(dev):
+    """the pressure solve's tolerance rendering (DMG_QUIRK_JACOBI_TOLERANCE: fused row coefficients, three
+    fused multiply-adds per cell instead of three divisions) against the exact rendering at the headline size, 16384x8192, after
+    the reference's full 5000 sweeps from zero pressure: within north_star's 1e-5 of the field's maximum -- and not the same
+    bits, or the switch would be doing nothing.  (The oracle's form 3 says 2.5e-6 at 2048x1024 and 3.6e-6 at 4096x2048.)"""
+    capi, ctx = dev
+    from demiurge_amd import synth
+    W, H = 16384, 8192
+    grid = capi.make_grid(W, H)
+    img, b = synth.terrain(W, H), synth.divw(W, H)
+    exact = run_jacobi(capi, ctx, grid, img, b, 5000, block=5000, kernel=capi.JACOBI_BLOCKED)
+    tol = run_jacobi(capi, ctx, grid, img, b, 5000, block=5000, kernel=capi.JACOBI_BLOCKED, quirks=capi.QUIRK_JACOBI_TOLERANCE)
+    m = float(np.max(np.abs(exact)))
+    err = 0.0
+    for y in range(0, H, 1024):                              # (in slices: a float64 copy of the grid is 1 GiB)
+        err = max(err, float(np.max(np.abs(tol[y:y + 1024].astype(np.float64) - exact[y:y + 1024]))))
+    print("tolerance rendering vs exact, 16384x8192 x5000: max|d| / max|ref| = %.3g" % (err / m))
+    assert 0 < err / m <= 1e-5, err / m
+    assert np.array_equal(tol[img > 0], exact[img > 0])      # land: exactly +0.0 in both
+
+
 def test_blocked_randomised_geometries(dev, oracle):
     """many small random cases: widths that are multiples of 8 from 256 up, heights down to 2 tile rows or less, land
     fractions from none to nearly all, sweep counts that are not multiples of 8, pole and belt canvases, band splits"""
@@ -406,6 +428,20 @@ def test_streaming_twin_units_vs_oracle(env):
              ["twin", "bands", "split"] if "DMG_ST_TWIN" in env else ["twin", "random", "golden"])
     out = _stream_worker(e, cases, timeout=1500)
     assert "'k_jacobi_stream_twin'" in out, out[-1500:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("twin", ["0", "2"], ids=["plain-units", "twin-units"])
+def test_streaming_tolerance_rendering_vs_oracle_form3(twin):
+    """Round 6: DMG_QUIRK_JACOBI_TOLERANCE -- the sweep with fused row coefficients, a = ah + al, b = bh + bl,
+    ah + bh = 0.5 exactly -- is the oracle's form 3 (oracle/dmg_oracle.c, orc_ocean_jacobi_rows_form) BIT FOR BIT on the cases of
+    the exact kernel: 20 random geometries, salt-and-pepper coasts, band splits with whole and split launches, open water,
+    twin units; sweep counts that are no multiple of 8 end in the exact arithmetic on both sides.  Against the reference's own
+    pixels (llvmpipe golden, 256x128, 5000 sweeps) it is within 5e-6 of the field's maximum."""
+    cases = ["random", "pepper", "golden", "bands", "open"] + (["twin", "split"] if twin == "2" else [])
+    out = _stream_worker({"DMG_TB_SHAPE": "stream", "DMG_ST_TWIN": twin, "STREAM_WORKER_FORM": "3"}, cases, timeout=1500)
+    assert "tolerance rendering vs llvmpipe golden x5000" in out, out[-1500:]
+    assert ("'k_jacobi_stream_twin'" if twin == "2" else "'k_jacobi_stream'") in out, out[-1500:]
 
 
 @pytest.mark.gpu

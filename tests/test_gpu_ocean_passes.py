@@ -207,6 +207,56 @@ def test_band_passes_fake_cluster(dev):
         o.close()
 
 
+def test_restore_accepts_a_round5_sidecar(dev, tmp_path):
+    """round 5 set DMG_QUIRK_EXACT_LLVMPIPE (4) by default and wrote `quirks 5` into the sidecar; round 6 turned
+    the bit's sense round (set bits mean tolerance; 4 is ignored) and writes `quirks 1` for the same run.  A stored round-5 sidecar
+    restores into today's default handle, one that really describes other parameters is still refused, and a handle created with
+    the old default value behaves like the default one."""
+    capi, ctx = dev
+    from demiurge_amd import synth
+    W, H = 256, 128
+    grid = capi.make_grid(W, H)
+    img = synth.terrain(W, H)
+    prm = capi.default_ocean_params()
+    assert prm.quirks == capi.QUIRK_DIFFUSION_SCALAR_RHS
+    prm.jacobi_iters, prm.diffusion_iters = 16, 8
+    a = capi.Ocean(ctx, grid, params=prm)
+    a.set_terrain(img)
+    a.step(1)
+    a.checkpoint(tmp_path / "ck")
+    a.step(1)
+    ref = a.get()
+    a.close()
+    meta = (tmp_path / "ck.meta").read_text()
+    assert " quirks 1\n" in meta
+    (tmp_path / "ck.meta").write_text(meta.replace(" quirks 1\n", " quirks 5\n"))        # as round 5's default handle wrote it
+    b = capi.Ocean(ctx, grid, params=prm)
+    b.set_terrain(img)
+    b.restore(tmp_path / "ck")
+    b.step(1)
+    got = b.get()
+    b.close()
+    for k in ("vx", "vy", "pressure", "divw"):
+        assert np.array_equal(got[k], ref[k]), k
+    old = capi.default_ocean_params()
+    old.jacobi_iters, old.diffusion_iters = 16, 8
+    old.quirks = capi.QUIRK_DIFFUSION_SCALAR_RHS | capi.QUIRK_EXACT_LLVMPIPE          # a caller that still passes round 5's default
+    c = capi.Ocean(ctx, grid, params=old)
+    c.set_terrain(img)
+    c.restore(tmp_path / "ck")
+    c.step(1)
+    got = c.get()
+    c.close()
+    for k in ("vx", "vy", "pressure", "divw"):
+        assert np.array_equal(got[k], ref[k]), k
+    (tmp_path / "ck.meta").write_text(meta.replace(" quirks 1\n", " quirks 9\n"))        # another rendering: refused
+    d = capi.Ocean(ctx, grid, params=prm)
+    d.set_terrain(img)
+    with pytest.raises(capi.DmgError):
+        d.restore(tmp_path / "ck")
+    d.close()
+
+
 def test_checkpoint_resume(dev, tmp_path):
     """run 2 outer steps in one go == run 1, checkpoint to .npy, restore into a fresh ocean, run 1 more"""
     capi, ctx = dev
@@ -320,15 +370,16 @@ def test_blocked_kernels_vs_reference_hashes(dev, name):
         assert sha(a) == str(G[key + "_sha256"]), key
 
 
-# ---- DMG_QUIRK_EXACT_LLVMPIPE cleared: the trig-heavy passes on the hardware's transcendentals ----
+# ---- DMG_QUIRK_FAST_TRANSCENDENTALS: the trig-heavy passes on the hardware's transcendentals (the bit's sense
+# inverted in round 6, ADVICE r5: set = tolerance) ----
 def _fast(capi):
-    return capi.QUIRK_DIFFUSION_SCALAR_RHS            # (the reference's quirks without the exact-rendering bit)
+    return capi.QUIRK_DIFFUSION_SCALAR_RHS | capi.QUIRK_FAST_TRANSCENDENTALS
 
 
 @pytest.mark.parametrize("name", ["ocean_passes_128x64_full", "ocean_passes_128x64_region", "ocean_advect_fast_128x64_full"])
 def test_tolerance_mode_advect_and_divergence_against_the_reference_pixels(dev, name):
     """north_star asks for 1e-5 relative to the reference's GLSL output; the default rendering pays for every bit.  With
-    DMG_QUIRK_EXACT_LLVMPIPE cleared advect and divergence keep the reference's expressions (Mesa's asin / atan polynomials included)
+    DMG_QUIRK_FAST_TRANSCENDENTALS set advect and divergence keep the reference's expressions (Mesa's asin / atan polynomials included)
     and take sin, cos, log2, exp2, reciprocals and square roots from the hardware: within 1e-5 (max norm, relative to the field's
     largest value) of the llvmpipe goldens -- and not the same bits, or the switch would be doing nothing."""
     capi, ctx = dev

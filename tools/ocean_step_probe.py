@@ -11,7 +11,7 @@ for (W, H), fast in itertools.product(((8192, 4096), (16384, 8192)), (False, Tru
     ctx = capi.Context(0)
     prm = capi.default_ocean_params()
     if fast:
-        prm.quirks &= ~capi.QUIRK_EXACT_LLVMPIPE      # advect and divergence on the hardware's transcendentals (within 1e-5)
+        prm.quirks |= capi.QUIRK_FAST_TRANSCENDENTALS     # advect and divergence on the hardware's transcendentals (within 1e-5)
     o = capi.Ocean(ctx, capi.make_grid(W, H), params=prm)
     img = synth.terrain(W, H)
     o.set_terrain(img)
