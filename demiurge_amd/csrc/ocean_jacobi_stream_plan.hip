@@ -47,7 +47,13 @@ static void st_parallel_for(size_t n, F &&f)
 // row through the coast formula; every other step -- the pipeline's fill, a land row in flight -- takes the tested path, level by
 // level and row by row.  cls: the strip's row classes (null: all mixed), rows outside [0, L) and outside the grid count as mixed
 // as in the kernel; flip: the unit runs on the mirrored view (rows r0, r1 are that view's); twin: its window starts on r0.
-st_features st_unit_features(const unsigned char *cls, int L, int y_first, int H, int r0, int r1, bool flip, bool twin)
+// Round 6: a row whose divisors have no exact two-operation pair (div2.hip: 8 of the 8192 rows of the headline grid) puts the five
+// steps it is in flight for on the tested path like a land row does (st_step's `special`) -- at twice an open-water step each.  On
+// the full grid that is nothing; in a one-round launch the unit that holds such a row was the one every other unit waited for
+// (profiles/r06_band_units.txt: the 36-row units around local row 512 of bands 1 and 6 of the 8-way split took 55 us, the rest 45).
+// Priced at three open-water steps (DMG_ST_WBAD; per-unit timings fit 2.0, a same-box sweep of the weight was flat from 3 up:
+// profiles/r06_band_probe.log) the unit that holds such a row is cut shorter: the slowest band of the 8-way split 58.1 -> 47.8 us.
+st_features st_unit_features(const unsigned char *cls, int L, int y_first, int H, int r0, int r1, bool flip, bool twin, const unsigned char *bad)
 {
     st_features f;
     const int e0 = twin ? r0 : r0 - TB_T, nsteps = (((r1 - r0) + (twin ? TB_T : 2 * TB_T) + 3) / 4) * 2;
@@ -58,13 +64,15 @@ st_features st_unit_features(const unsigned char *cls, int L, int y_first, int H
         if (!cls || lu < 0 || lu >= L || yg < 0 || yg >= H) return 2;
         return cls[flip ? L - 1 - lu : lu];
     };
+    auto bd = [&](int lu) -> bool { return bad && lu >= e0 && lu >= 0 && lu < L && bad[flip ? L - 1 - lu : lu]; };
     for (int t = 0; t < nsteps; t++) {
         const int newest = e0 + 2 * t + 1;
-        bool land = false, mix = false;
-        for (int k = 0; k < 10; k++) { const int c = cl(newest - k); land |= c == 1; mix |= c == 2; }
+        bool land = false, mix = false, special = false;
+        for (int k = 0; k < 10; k++) { const int c = cl(newest - k); land |= c == 1; mix |= c == 2; special |= bd(newest - k); }
         const bool filled = t >= (twin ? TB_T / 2 : TB_T);
-        if (filled && !land && !mix) f.fast++;
-        else if (filled && !land) f.coast++;
+        if (filled && !land && !mix && !special) f.fast++;
+        else if (filled && !land && !special) f.coast++;
+        else if (filled && !land) f.bad++;
         else {
             if (filled) f.tested++;
             for (int S = 1; S <= 8; S++) {
@@ -89,12 +97,12 @@ st_features st_unit_features(const unsigned char *cls, int L, int y_first, int H
 // (step clocks: 1.0 + 0.12 us per level-row against 2.7 us for a full step).  r0, r1 in the band's own numbering; flip: the
 // unit streams southwards; twin: its window starts on its first row (no halo there).
 struct st_weights {
-    float coast, t_open, t_mixed, t_land;
+    float coast, t_open, t_mixed, t_land, bad;
     static const st_weights &get()
     {
         static const st_weights w = [] {
             auto env = [](const char *name, float dflt) { const char *e = dmg_hook(name); return e ? (float)atof(e) : dflt; };
-            return st_weights{ env("DMG_ST_WCOAST", 1.7f), env("DMG_ST_WTOPEN", 0.05f), env("DMG_ST_WTMIXED", 0.14f), env("DMG_ST_WTLAND", 0.11f) };
+            return st_weights{ env("DMG_ST_WCOAST", 1.7f), env("DMG_ST_WTOPEN", 0.05f), env("DMG_ST_WTMIXED", 0.14f), env("DMG_ST_WTLAND", 0.11f), env("DMG_ST_WBAD", 3.0f) };
         }();
         return w;
     }
@@ -103,9 +111,10 @@ static float st_exact_cost(const dmg_ocean *o, int tx, int r0, int r1, bool flip
 {
     const st_weights &w = st_weights::get();
     const unsigned char *cls = o->rowclass_host.empty() ? nullptr : o->rowclass_host.data() + (size_t)tx * o->L;
-    const st_features f = st_unit_features(cls, o->L, o->y0 - o->gs, o->grid.H, flip ? o->L - r1 : r0, flip ? o->L - r0 : r1, flip, twin);
+    const st_features f = st_unit_features(cls, o->L, o->y0 - o->gs, o->grid.H, flip ? o->L - r1 : r0, flip ? o->L - r0 : r1, flip, twin,
+                                           o->rowbad_host.empty() ? nullptr : o->rowbad_host.data());
     const float fill_steps = twin ? 4.0f : 8.0f;
-    return 0.7f + (float)f.fast + w.coast * (float)f.coast + 0.37f * fill_steps + w.t_open * (float)(f.t_open + f.f_open) + w.t_mixed * (float)(f.t_mixed + f.f_mixed) +
+    return 0.7f + (float)f.fast + w.coast * (float)f.coast + w.bad * (float)f.bad + 0.37f * fill_steps + w.t_open * (float)(f.t_open + f.f_open) + w.t_mixed * (float)(f.t_mixed + f.f_mixed) +
            w.t_land * (float)(f.t_land + f.f_land);
 }
 
@@ -282,15 +291,16 @@ static void st_cut_balanced(const dmg_ocean *o, int lo, int hi, int want, int pa
         for (int tx = 0; tx < tiles_x; tx++) {
             const unsigned char *cls = table.data() + (size_t)tx * L;
             auto cl = [&](int r) { return r >= 0 && r < L ? (int)cls[r] : 2; };
+            const unsigned char *bad = o->rowbad_host.empty() ? nullptr : o->rowbad_host.data();
             for (int r = std::max(lo - 1, 0); r < std::min(hi + 1, L); r++) {
-                bool land = false, mix = false;
-                for (int k = 0; k < 10; k++) { const int c = cl(r - k); land |= c == 1; mix |= c == 2; }
+                bool land = false, mix = false, special = false;
+                for (int k = 0; k < 10; k++) { const int c = cl(r - k); land |= c == 1; mix |= c == 2; special |= bad && r - k >= 0 && bad[r - k]; }
                 float v;
                 if (land) {
                     v = 0.0f;
                     for (int S = 1; S <= 8; S++)
                         for (int k = S; k <= S + 1; k++) { const int c = cl(r - k); v += c == 0 ? w.t_open : (c == 2 ? w.t_mixed : w.t_land); }
-                } else v = mix ? w.coast : 1.0f;
+                } else v = special ? w.bad : (mix ? w.coast : 1.0f);
                 step_w[(size_t)tx * L + r] = v;
             }
         }

@@ -87,7 +87,8 @@ int ocean_upload_row_tables(dmg_ocean *o)
             else { for (int k = 0; k < 4; k++) e[k] = jc[(size_t)l * 8 + k]; bad[l] = 1; o->div2_nbad++; }
             e[4] = h[(size_t)2 * L]; e[5] = lo[(size_t)2 * L];
         }
-        if (o->div2_nbad) o->rowbad_host = bad; else o->rowbad_host.clear();
+        // (the planner prices the rows without a pair: ocean_jacobi_stream_plan.hip; the tolerance rendering has no divisions, so none)
+        if (o->div2_nbad && !(o->prm.quirks & DMG_QUIRK_JACOBI_TOLERANCE)) o->rowbad_host = bad; else o->rowbad_host.clear();
         DMG_HIP(hipMemcpyAsync(o->jcoef2, j2.data(), j2.size() * sizeof(float), hipMemcpyHostToDevice, o->ctx->stream));
         DMG_HIP(hipMemcpyAsync(o->rowbad, bad.data(), bad.size(), hipMemcpyHostToDevice, o->ctx->stream));
         DMG_HIP(hipStreamSynchronize(o->ctx->stream));
