@@ -24,6 +24,40 @@
 // 3.959 / 3.970 M (+0.8 %), all-ocean 2.933 / 2.943 -> 2.997 / 2.998 M (+2.0 %), 16384x2048 +0.5 / +1.5 %, a 16384x1024 band
 // +0.2 % / within its noise (the middle band of an 8-way split with its ghost rows: 59.8 -> 59.3 us per launch).  Small, never a
 // loss: the default.  What it says about the small band: its 36 % of re-read halo rows are not what it waits for.
+// A unit's tables: the classes of its window rows (four per lane: st_class4), the flags of rows without an exact divisor pair, the
+// coefficient table in LDS.  Round 6: every load unconditional (addresses clamped, the choice made afterwards) and all twelve in
+// flight together behind ONE wait.  Written as `if (inside) cls = table[...]` the class loads came out as four conditional loads
+// with an s_waitcnt vmcnt(0) after each -- four memory round trips in a row, the first of them behind the unit's first row
+// requests, then a fifth for the flags and a sixth for the coefficients: 5.5 us of a 45-us unit of a one-round launch
+// (profiles/r06_band_units.txt, per-step clocks).
+template <int DV>
+__device__ __forceinline__ void st_unit_tables(const st_args &a, int lane, int tx, int e0, int n, unsigned &cls_lo, v4f *ktab)
+{
+    unsigned cb[4], bd[4];
+    v4f kt[4];
+    bool inside[4];
+    const unsigned char *rc = a.rowclass ? a.rowclass + (size_t)tx * a.L : a.code;      // (no class table: any readable byte, not used)
+    const unsigned char *rb = a.rowbad ? a.rowbad : a.code;                             // (likewise)
+    const unsigned badmask = (DV == 1 && a.rowbad) ? 1u : 0u;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int lu = e0 + lane + 64 * q, yg = a.y_first + lu;
+        inside[q] = yg >= 0 && yg < a.H && lu >= 0 && lu < a.L;
+        cb[q] = rc[inside[q] ? lu : 0];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) bd[q] = DV == 1 ? (unsigned)rb[st_map_row(a, e0 + lane + 64 * q).l] : 0u;     // (mirrored and clamped rows have their image's divisors)
+    // one 16-byte table entry per window row (two spare: the next level's prefetch)
+#pragma unroll
+    for (int q = 0; q < 4; q++) kt[q] = st_kswap(*reinterpret_cast<const v4f *>(a.jcoef + (size_t)st_map_row(a, e0 + min(lane + 64 * q, n - 1)).l * 8));
+    // classes of the window rows: rows beyond the grid or the stored band count as mixed (their codes decide)
+    cls_lo = 0u;
+#pragma unroll
+    for (int q = 0; q < 4; q++) cls_lo |= (((a.rowclass && inside[q]) ? cb[q] : 2u) | ((bd[q] & badmask) << 2)) << (8 * q);
+#pragma unroll
+    for (int q = 0; q < 4; q++) if (lane + 64 * q < n) ktab[lane + 64 * q] = kt[q];
+}
+
 template <int DV>
 __global__ __launch_bounds__(64, 2) void k_jacobi_stream(st_args a_up, st_args a_dn)
 {
@@ -42,10 +76,19 @@ __global__ __launch_bounds__(64, 2) void k_jacobi_stream(st_args a_up, st_args a
             a.prof[3 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
             a.prof[3 * blockIdx.x + 2] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) | (unsigned)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
         }
+#ifdef ST_EXPERIMENTS
+        if (a.clk && lane == 0) a.clk[2 * blockIdx.x] = __builtin_amdgcn_s_memtime();
+#endif
         st_open_unit<DV>(a, bring, ktab, lane, tx, r0, r1);
         if (a.prof && lane == 0) a.prof[3 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+#ifdef ST_EXPERIMENTS
+        if (a.clk && lane == 0) a.clk[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memtime();
+#endif
         return;
     }
+#ifdef ST_EXPERIMENTS
+    if (a.clk && lane == 0) a.clk[2 * blockIdx.x] = __builtin_amdgcn_s_memtime();
+#endif
     if (a.prof && lane == 0) {
         a.prof[3 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
         // where the unit ran: HW_ID (wave slot, SIMD, CU, SH, SE) and XCC_ID
@@ -77,19 +120,8 @@ __global__ __launch_bounds__(64, 2) void k_jacobi_stream(st_args a_up, st_args a
     st_fetch<false>(a, z, 1, 0, e0 + 2, col, colp);          // (rows past the window are clamped into the band: harmless)
     st_fetch<false>(a, z, 1, 1, e0 + 3, col, colp);
 
-    // classes of the window rows: rows beyond the grid or the stored band count as mixed (their codes decide)
-    unsigned cls_lo = 0x02020202u, cls_hi = 0u;              // (cls_lo: four classes per lane, st_class4)
-    if (a.rowclass) {
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int lu = e0 + lane + 64 * q, yg = a.y_first + lu;
-            if (yg >= 0 && yg < a.H && lu >= 0 && lu < a.L) cls_lo = (cls_lo & ~(0xFFu << (8 * q))) | ((unsigned)a.rowclass[(size_t)tx * a.L + lu] << (8 * q));
-        }
-    }
-    if (DV == 1 && a.rowbad) {                                    // (mirrored and clamped rows have their image's divisors)
-#pragma unroll
-        for (int q = 0; q < 4; q++) cls_lo |= ((unsigned)a.rowbad[st_map_row(a, e0 + lane + 64 * q).l] & 1u) << (8 * q + 2);
-    }
+    unsigned cls_lo, cls_hi = 0u;                            // (cls_lo: four classes per lane, st_class4)
+    st_unit_tables<DV>(a, lane, tx, e0, 2 * nsteps + 2, cls_lo, ktab);
 
 #pragma unroll
     for (int s = 0; s < 8; s++)
@@ -99,14 +131,6 @@ __global__ __launch_bounds__(64, 2) void k_jacobi_stream(st_args a_up, st_args a
     z.mixbits = 0; z.slot = 0; z.badbits = 0;
     z.fc[0][0] = st_class4(cls_lo, 0); z.fc[0][1] = st_class4(cls_lo, 1); z.fc[1][0] = st_class4(cls_lo, 2); z.fc[1][1] = st_class4(cls_lo, 3);
     {
-        // one 16-byte table entry per window row (two spare: the next level's prefetch): all of a lane's (up to four) loads in
-        // flight together -- a loop of load, wait, store costs a unit a memory round trip per 64 rows
-        const int n = 2 * nsteps + 2;
-        v4f kt[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) kt[q] = st_kswap(*reinterpret_cast<const v4f *>(a.jcoef + (size_t)st_map_row(a, e0 + min(lane + 64 * q, n - 1)).l * 8));
-#pragma unroll
-        for (int q = 0; q < 4; q++) if (lane + 64 * q < n) ktab[lane + 64 * q] = kt[q];
         const st_kptr cf = (st_kptr)(unsigned long long)a.jcoef;
         z.cy = cf[4]; z.ry = cf[5];
     }
@@ -122,6 +146,7 @@ __global__ __launch_bounds__(64, 2) void k_jacobi_stream(st_args a_up, st_args a
     }
     if (a.prof && lane == 0) a.prof[3 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
 #ifdef ST_EXPERIMENTS
+    if (a.clk && lane == 0) a.clk[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memtime();
     if (a.stepprof && lane == 0) a.stepprof[(size_t)blockIdx.x * 64 + 63] = __builtin_amdgcn_s_memrealtime();
 #endif
 }
@@ -153,6 +178,9 @@ __global__ __launch_bounds__(128, 2) void k_jacobi_stream_twin(st_args a_up, st_
     if (uflags & 8) return;                            // a workgroup that only holds its place in the list (st_place_twins): both its entries say so
     const st_args &a = (uflags & 2) ? a_dn : a_up;     // (either unit of a pair can be the workgroup's first wave)
     const int W = a.W;
+#ifdef ST_EXPERIMENTS
+    if (a.clk && lane == 0) a.clk[2 * (2 * blockIdx.x + wave)] = __builtin_amdgcn_s_memtime();
+#endif
     if (a.prof && lane == 0) {
         a.prof[3 * (2 * blockIdx.x + wave)] = __builtin_amdgcn_s_memrealtime();
         a.prof[3 * (2 * blockIdx.x + wave) + 2] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) | (unsigned)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
@@ -175,18 +203,8 @@ __global__ __launch_bounds__(128, 2) void k_jacobi_stream_twin(st_args a_up, st_
     st_fetch<false>(a, z, 0, 1, e0 + 1, col, colp);
     st_fetch<false>(a, z, 1, 0, e0 + 2, col, colp);
     st_fetch<false>(a, z, 1, 1, e0 + 3, col, colp);
-    unsigned cls_lo = 0x02020202u, cls_hi = 0u;
-    if (a.rowclass) {
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int lu = e0 + lane + 64 * q, yg = a.y_first + lu;
-            if (yg >= 0 && yg < a.H && lu >= 0 && lu < a.L) cls_lo = (cls_lo & ~(0xFFu << (8 * q))) | ((unsigned)a.rowclass[(size_t)tx * a.L + lu] << (8 * q));
-        }
-    }
-    if (DV == 1 && a.rowbad) {
-#pragma unroll
-        for (int q = 0; q < 4; q++) cls_lo |= ((unsigned)a.rowbad[st_map_row(a, e0 + lane + 64 * q).l] & 1u) << (8 * q + 2);
-    }
+    unsigned cls_lo, cls_hi = 0u;
+    st_unit_tables<DV>(a, lane, tx, e0, 2 * nsteps + 2, cls_lo, ktab);
 #pragma unroll
     for (int s = 0; s < 8; s++)
 #pragma unroll
@@ -195,12 +213,6 @@ __global__ __launch_bounds__(128, 2) void k_jacobi_stream_twin(st_args a_up, st_
     z.mixbits = 0; z.slot = 0; z.badbits = 0;
     z.fc[0][0] = st_class4(cls_lo, 0); z.fc[0][1] = st_class4(cls_lo, 1); z.fc[1][0] = st_class4(cls_lo, 2); z.fc[1][1] = st_class4(cls_lo, 3);
     {
-        const int n = 2 * nsteps + 2;
-        v4f kt[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) kt[q] = st_kswap(*reinterpret_cast<const v4f *>(a.jcoef + (size_t)st_map_row(a, e0 + min(lane + 64 * q, n - 1)).l * 8));
-#pragma unroll
-        for (int q = 0; q < 4; q++) if (lane + 64 * q < n) ktab[lane + 64 * q] = kt[q];
         const st_kptr cf = (st_kptr)(unsigned long long)a.jcoef;
         z.cy = cf[4]; z.ry = cf[5];
     }
@@ -231,6 +243,7 @@ __global__ __launch_bounds__(128, 2) void k_jacobi_stream_twin(st_args a_up, st_
     }
     if (a.prof && lane == 0) a.prof[3 * (2 * blockIdx.x + wave) + 1] = __builtin_amdgcn_s_memrealtime();
 #ifdef ST_EXPERIMENTS
+    if (a.clk && lane == 0) a.clk[2 * (2 * blockIdx.x + wave) + 1] = __builtin_amdgcn_s_memtime();
     if (a.stepprof && lane == 0) { a.stepprof[(size_t)(2 * blockIdx.x + wave) * 64 + 63] = __builtin_amdgcn_s_memrealtime(); a.stepprof[(size_t)(2 * blockIdx.x + wave) * 64 + 62] = t_entry; }
 #endif
 }
@@ -327,6 +340,7 @@ int ocean_launch_stream(dmg_ocean *o, int lo, int hi, int part, int zone_lo, int
     static const int dbg = [] { const char *e = dmg_hook("DMG_ST_DBG"); return e ? atoi(e) : 0; }();
     a.dbg = dbg;
     a.prof = nullptr;
+    a.clk = nullptr;
     a.stepprof = nullptr;
 #ifdef ST_EXPERIMENTS
     static const char *stepprof_path = dmg_hook("DMG_ST_STEPPROF");
@@ -339,6 +353,9 @@ int ocean_launch_stream(dmg_ocean *o, int lo, int hi, int part, int zone_lo, int
     static int prof_skip = [] { const char *e = dmg_hook("DMG_ST_PROF_SKIP"); return e ? atoi(e) : 0; }();      // ... the (n+1)-th such launch: a warm one
     const bool prof_now = prof_path && !prof_done && !variant && tl->n_units > 1024 && prof_skip-- <= 0;
     if (prof_now && hipMalloc((void **)&a.prof, tl->n_units * 24) != hipSuccess) a.prof = nullptr;
+#ifdef ST_EXPERIMENTS
+    if (prof_now && a.prof && (hipMalloc((void **)&a.clk, tl->n_units * 16) != hipSuccess || hipMemset(a.clk, 0, tl->n_units * 16) != hipSuccess)) a.clk = nullptr;
+#endif
     static const int extra_lds = [] { const char *e = dmg_hook("DMG_ST_EXTRA_LDS"); return e ? atoi(e) : 0; }();   // experiments: caps the waves per CU
     {
         // the mirrored view of the band for the units that stream southwards: pointers to the last stored row, a negative row
@@ -382,16 +399,17 @@ int ocean_launch_stream(dmg_ocean *o, int lo, int hi, int part, int zone_lo, int
     if (prof_now && a.prof) {
         prof_done = true;
         const int n_units = (int)tl->n_units;
-        std::vector<unsigned long long> tt((size_t)n_units * 3);
+        std::vector<unsigned long long> tt((size_t)n_units * 3), cc((size_t)n_units * 2, 0ull);
         std::vector<int> uu((size_t)n_units * 4);
         DMG_HIP(hipStreamSynchronize(st));
         DMG_HIP(hipMemcpy(tt.data(), a.prof, tt.size() * 8, hipMemcpyDeviceToHost));
+        if (a.clk) { DMG_HIP(hipMemcpy(cc.data(), a.clk, cc.size() * 8, hipMemcpyDeviceToHost)); (void)hipFree(a.clk); }
         DMG_HIP(hipMemcpy(uu.data(), tl->d, uu.size() * 4, hipMemcpyDeviceToHost));
         (void)hipFree(a.prof);
         if (FILE *f = fopen(prof_path, "w")) {
             // (r0, r1: the unit's rows in the band's own numbering; open / mixed / land: the classes of its window's rows; then what its
             // steps are made of, st_unit_features)
-            fprintf(f, "tx,r0,r1,open,mixed,land,t0,t1,hwid,xcc,flip,twin,fast,coast,tested,t_open,t_mixed,t_land,f_open,f_mixed,f_land\n");
+            fprintf(f, "tx,r0,r1,open,mixed,land,t0,t1,hwid,xcc,flip,twin,fast,coast,tested,t_open,t_mixed,t_land,f_open,f_mixed,f_land,bad,c0,c1\n");
             for (int i = 0; i < n_units; i++) {
                 int cnt[3] = { 0, 0, 0 };
                 const unsigned char *cls = o->rowclass_host.empty() ? nullptr : o->rowclass_host.data() + (size_t)uu[4 * i] * o->L;
@@ -400,10 +418,10 @@ int ocean_launch_stream(dmg_ocean *o, int lo, int hi, int part, int zone_lo, int
                 const int b0 = flip ? o->L - v1 : v0, b1 = flip ? o->L - v0 : v1;
                 const int w0 = (twin && !flip) ? b0 : b0 - TB_T, w1 = (twin && flip) ? b1 : b1 + TB_T;
                 for (int r = w0; r < w1; r++) cnt[(cls && r >= 0 && r < o->L) ? cls[r] : 2]++;
-                const st_features ft = st_unit_features(cls, o->L, o->y0 - o->gs, o->grid.H, v0, v1, flip, twin);
-                fprintf(f, "%d,%d,%d,%d,%d,%d,%llu,%llu,%llu,%llu,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d\n", uu[4 * i], b0, b1, cnt[0], cnt[2], cnt[1], tt[3 * i], tt[3 * i + 1],
+                const st_features ft = st_unit_features(cls, o->L, o->y0 - o->gs, o->grid.H, v0, v1, flip, twin, o->rowbad_host.empty() ? nullptr : o->rowbad_host.data());
+                fprintf(f, "%d,%d,%d,%d,%d,%d,%llu,%llu,%llu,%llu,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%llu,%llu\n", uu[4 * i], b0, b1, cnt[0], cnt[2], cnt[1], tt[3 * i], tt[3 * i + 1],
                         tt[3 * i + 2] & 0xFFFFFFFFull, tt[3 * i + 2] >> 32, (int)flip, (int)twin, ft.fast, ft.coast, ft.tested, ft.t_open, ft.t_mixed, ft.t_land,
-                        ft.f_open, ft.f_mixed, ft.f_land);
+                        ft.f_open, ft.f_mixed, ft.f_land, ft.bad, cc[2 * i], cc[2 * i + 1]);
             }
             fclose(f);
         }

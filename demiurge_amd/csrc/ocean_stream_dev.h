@@ -88,6 +88,7 @@ struct st_args {
     int nseg0, cap;
     const unsigned *rowclass32;     // rowclass, one 32-bit word per entry
     unsigned long long *prof;       // experiments only (DMG_ST_PROF): {start, end} of every unit on the 100 MHz s_memrealtime clock, or null
+    unsigned long long *clk;        // experiments only (-DST_EXPERIMENTS, with DMG_ST_PROF): s_memtime (the shader clock's counter) at every unit's start and end, beside prof's s_memrealtime
     unsigned long long *stepprof;   // experiments only (-DST_EXPERIMENTS, DMG_ST_STEPPROF): s_memrealtime at the top of the first 64 steps of every unit
     int dbg;                        // experiments only (DMG_ST_DBG bits): 1 = every unit re-reads 64 rows (cache hits), 2 = no stores, 4 = plain instead of nontemporal stores;
                                     // persistent form: 8 = owners do not re-read their end row, 16 = no stealing, 32 = owners do not publish progress,
