@@ -75,7 +75,13 @@ __device__ __forceinline__ void dp_front_step(const st_args &a, st_state &z, v4f
         asm volatile("v_pk_mov_b32 %0, %1, %2 op_sel:[0,1]" : "=v"(lo) : "v"(z.ps[K][j].xy), "v"(z.ps[K][j].zw) : "memory");
         asm volatile("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=v"(hi) : "v"(z.ps[K][j].xy), "v"(z.ps[K][j].zw) : "memory");
         z.w[0][K][j] = v4f{ lo.x, lo.y, hi.x, hi.y };
-        st_park_pairs(&bring[z.slot + j][lane], z.bs[K][j]);
+        if (DV == 3) {                               // (tolerance rendering: -c bC in the ring, st_arrive)
+            const v4f kc = ktab[2 * t + j];
+            const float negc = -kc.w;
+            v4f bq = z.bs[K][j]; bq.xy = bq.xy * negc; bq.zw = bq.zw * negc;
+            st_park_pairs(&bring[z.slot + j][lane], bq);
+        }
+        else st_park_pairs(&bring[z.slot + j][lane], z.bs[K][j]);
     }
     const unsigned voA = rowb + col4, voB = voA + (unsigned)a.W * 4u;
     z.ps[K][0] = *reinterpret_cast<const v4f *>(pb + voA); z.bs[K][0] = *reinterpret_cast<const v4f *>(bb + voA);
@@ -254,7 +260,8 @@ int ocean_launch_deep_open(dmg_ocean *o, int lo, int hi, int seg, int from, hipS
     const int y_first = o->y0 - o->gs;
     if (lo - DP_T < 0 || hi + DP_T + 8 > o->L || y_first + lo - DP_T < 0 || y_first + hi + DP_T + 8 > o->grid.H || W < TB_EW || W % 4)
         return dmg_fail(DMG_EINVAL, "deep form (prototype): rows [%d, %d) need 16 rows below and 24 above inside the band and the grid", lo, hi);
-    const bool div2 = o->div2_ok && o->jcoef2 && !o->div2_nbad;
+    const bool tol = (o->prm.quirks & DMG_QUIRK_JACOBI_TOLERANCE) != 0;
+    const bool div2 = !tol && o->div2_ok && o->jcoef2 && !o->div2_nbad;
     auto key = std::make_tuple(lo, hi, -7000 - seg, 0, 0, 0);
     auto it = o->tb_lists.find(key);
     if (it == o->tb_lists.end()) {
@@ -273,7 +280,7 @@ int ocean_launch_deep_open(dmg_ocean *o, int lo, int hi, int seg, int from, hipS
     const dmg_ocean::tile_list &tl = it->second;
     st_args a{};
     a.pin = o->p[from]; a.pout = o->p[from ^ 1]; a.b = o->divw; a.code = o->code;
-    a.jcoef = div2 ? o->jcoef2 : o->jcoef;
+    a.jcoef = tol ? o->jcoef3 : div2 ? o->jcoef2 : o->jcoef;
     a.jcoef_cy = o->jcoef + 4;
     a.W = W; a.L = o->L; a.rs = W; a.flipped = 0;
     a.y_first = y_first; a.H = o->grid.H;
@@ -291,6 +298,7 @@ int ocean_launch_deep_open(dmg_ocean *o, int lo, int hi, int seg, int from, hipS
     const dim3 grid((unsigned)((tl.n + DP_WG - 1) / DP_WG)), block(128 * DP_WG);
     if (sync_env == 0) hipLaunchKernelGGL((k_jacobi_deep_open<1, 0>), grid, block, 0, st, a);
     else if (sync_env == 1 && DP_WG == 1) hipLaunchKernelGGL((k_jacobi_deep_open<1, 1>), grid, block, 0, st, a);
+    else if (tol) hipLaunchKernelGGL((k_jacobi_deep_open<3, 2>), grid, block, 0, st, a);
     else if (div2) hipLaunchKernelGGL((k_jacobi_deep_open<1, 2>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((k_jacobi_deep_open<0, 2>), grid, block, 0, st, a);
     DMG_HIP(hipGetLastError());

@@ -1,10 +1,12 @@
 #include "HipOceanCurrents.h"
+#include "HipAbi.h"
 #include <memory>
 
 // OceanCurrents::run (reference src/filter/OceanCurrents.cpp:151-223) with the GL passes replaced by the C ABI.
 // Only data hand-over needs the thread that owns the textures; compute runs on this worker thread.
 void HipOceanCurrents::run()
 {
+    if (!hip_abi_matches(&error_)) { setProgress({ true, 1.0f }); return; }
     std::vector<float> img;
     dmg_grid g{};
     dispatchGPU([&](Project *p) {                       // Texture::downloadDataRAW of the terrain layer

@@ -8,6 +8,7 @@
 
 class HipOceanCurrents : public AsyncSubFilter {
 public:
+    ~HipOceanCurrents() override { stop(); }           // the worker is inside run(), reading the members below: joined before they go
     // pressure = OceanCurrentsMenu::pressure (reference OceanCurrents.h:21); n_outer replaces the reference's
     // hard-coded 10000 / while(true) (OceanCurrents.cpp:155,212); the iteration counts are its literals (:50,:701)
     // devices: the GPUs the solve is split over, one latitude band each ({0} = one GPU; {0,0} = two bands on GPU 0, a

@@ -1,4 +1,5 @@
 #include "HipSimulationTools.h"
+#include "HipAbi.h"
 
 static dmg_grid grid_of(const Project *p)
 {
@@ -15,6 +16,7 @@ static dmg_grid grid_of(const Project *p)
 // the terrain layer is refreshed once per round (what the user sees, :104-108,:214).
 void HipErosion::run()
 {
+    if (!hip_abi_matches(&error_)) { setProgress({ true, 1.0f }); return; }
     std::vector<float> h;
     dmg_grid g{};
     dispatchGPU([&](Project *p) { h = p->terrain; g = grid_of(p); });                    // :47-91 heightdata / updrift set-up
@@ -44,6 +46,7 @@ void HipErosion::run()
 // on the field kept in the terrain layer, heights in scratch1
 void HipTemperature::run()
 {
+    if (!hip_abi_matches(&error_)) { setProgress({ true, 1.0f }); return; }
     std::vector<float> T, heights;
     dmg_grid g{};
     dispatchGPU([&](Project *p) { T = p->terrain; heights = p->scratch1; g = grid_of(p); });
@@ -76,6 +79,7 @@ void HipTemperature::run()
 // FlowFilter::run (reference src/filter/FlowFilter.cpp:719-786): terrain := pow(upstream area, exponent)
 void HipFlow::run()
 {
+    if (!hip_abi_matches(&error_)) { setProgress({ true, 1.0f }); return; }
     std::vector<float> h;
     dmg_grid g{};
     dispatchGPU([&](Project *p) { h = p->terrain; g = grid_of(p); });

@@ -15,6 +15,7 @@
 
 class HipErosion : public AsyncSubFilter {
 public:
+    ~HipErosion() override { stop(); }           // the worker is inside run(), reading the members below: joined before they go
     // cpufilter(Project*, exponent, slope_exponent, factor, dolakes); N = 50 and 3*N rounds are the reference's (:42,:93)
     HipErosion(Project *p, float exponent, float slope_exponent, float factor, int dolakes, int N = 50, int rounds = 150)
         : exponent_(exponent), slope_exponent_(slope_exponent), factor_(factor), dolakes_(dolakes), N_(N), rounds_(rounds) { (void)p; }
@@ -29,6 +30,7 @@ private:
 
 class HipTemperature : public AsyncSubFilter {
 public:
+    ~HipTemperature() override { stop(); }           // the worker is inside run(), reading the members below: joined before they go
     // Temperature(Project*) (Temperature.cpp:26-44): the heights move to scratch1 (terrain.swap(scratch1)) and the terrain
     // layer becomes the temperature field, 50 everywhere.  The reference then runs 500000 frames of 10 steps (:48,:140)
     // -- `frames` bounds it here.  (Its closing terrain.swap(scratch2), :158-161, is never reached in practice and is
@@ -52,6 +54,7 @@ private:
 
 class HipFlow : public AsyncSubFilter {
 public:
+    ~HipFlow() override { stop(); }           // the worker is inside run(), reading the members below: joined before they go
     HipFlow(float preblur, float exponent, bool lakeflag = false) : preblur_(preblur), exponent_(exponent), lakeflag_(lakeflag) {}   // FlowFilter.cpp:29-33
     const std::string &error() const { return error_; }
 protected:

@@ -1,10 +1,12 @@
 #include "HipTectonics.h"
+#include "HipAbi.h"
 
 // Tectonics::run (reference src/filter/tectonics/Tectonics.cpp:156-275): the reference dispatches one closure per
 // step onto the GL thread (all of its ~40 draws) and shows the terrain it rendered; here the steps run on the worker
 // thread through the C ABI and only the terrain hand-over needs the thread that owns the textures.
 void HipTectonics::run()
 {
+    if (!hip_abi_matches(&error_)) { setProgress({ true, 1.0f }); return; }
     std::vector<float> img;
     dmg_grid g{};
     dispatchGPU([&](Project *p) {

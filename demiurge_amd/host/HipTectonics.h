@@ -8,6 +8,7 @@
 
 class HipTectonics : public AsyncSubFilter {
 public:
+    ~HipTectonics() override { stop(); }           // the worker is inside run(), reading the members below: joined before they go
     explicit HipTectonics(Project *p, int n_steps = 70) : n_steps_(n_steps) { (void)p; }   // 70: Tectonics.cpp:157
     const std::string &error() const { return error_; }
 

@@ -148,8 +148,56 @@ static int cancel_check(int argc, char **argv)
     return 0;
 }
 
+// ProgressFilter / BackupFilter (reference src/filter/Filter.cpp:12-23,70-115): the tool as the editor runs it -- a backup of the target
+// layer when the filter is made, one step per frame, and Cancel: `aborting` -> the backup is restored, the filter finalized.  HipErosion
+// writes the terrain layer every round (cpufilter.cpp:200-216), so a cancel in mid-run finds a changed terrain to put back.
+// host_demo progress W H terrain.f32
+static int progress_check(int argc, char **argv)
+{
+    if (argc != 5) { fprintf(stderr, "usage: host_demo progress W H terrain.f32\n"); return 2; }
+    Project p;
+    p.width = atoi(argv[2]); p.height = atoi(argv[3]);
+    p.terrain.resize((size_t)p.width * p.height);
+    if (!read_f32(argv[4], p.terrain)) { fprintf(stderr, "cannot read %s\n", argv[4]); return 2; }
+    const std::vector<float> before = p.terrain;
+    auto target = [](Project *q) { return &q->terrain; };
+    {   // cancelled in mid-run
+        ProgressFilter f(&p, target, std::make_unique<HipErosion>(&p, 0.5f, 1.0f, 1.0f, 0, 50, 150));
+        int frames = 0, changed_at = -1;
+        while (!f.isFinished() && frames < 200000) {
+            f.run(&p);
+            frames++;
+            if (changed_at < 0 && p.terrain != before) { changed_at = frames; f.abort(); }     // the first round's result has arrived: Cancel
+            std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        }
+        if (!f.isFinished() || !f.wasAborted() || changed_at < 0) { fprintf(stderr, "FAIL: finished %d aborted %d changed_at %d\n", (int)f.isFinished(), (int)f.wasAborted(), changed_at); return 1; }
+        if (p.terrain != before) { fprintf(stderr, "FAIL: the terrain is not the backup after Cancel\n"); return 1; }
+        if (p.finalized != 1) { fprintf(stderr, "FAIL: finalizeFilter called %d times\n", p.finalized); return 1; }
+        printf("cancelled at frame %d (progress %.3f): the terrain equals the backup, the filter is finalized\n", changed_at, f.getProgress());
+    }   // (~ProgressFilter -> ~HipErosion: stop() joins the worker before the adapter's members go)
+    {   // run to the end with half the canvas selected: the other half keeps the backup (restoreUnselected)
+        p.selection.assign(p.terrain.size(), 0.0f);
+        for (int y = 0; y < p.height; y++) for (int x = 0; x < p.width / 2; x++) p.selection[(size_t)y * p.width + x] = 1.0f;
+        ProgressFilter f(&p, target, std::make_unique<HipErosion>(&p, 0.5f, 1.0f, 1.0f, 0, 50, 3));
+        int frames = 0;
+        while (!f.isFinished() && frames++ < 200000) { f.run(&p); std::this_thread::sleep_for(std::chrono::milliseconds(1)); }
+        if (!f.isFinished() || f.wasAborted()) { fprintf(stderr, "FAIL: the second filter did not finish\n"); return 1; }
+        f.restoreUnselected();
+        size_t kept = 0, moved = 0;
+        for (int y = 0; y < p.height; y++)
+            for (int x = 0; x < p.width; x++) {
+                const size_t i = (size_t)y * p.width + x;
+                if (x >= p.width / 2) kept += p.terrain[i] == before[i]; else moved += p.terrain[i] != before[i];
+            }
+        if (kept != (size_t)p.height * (p.width - p.width / 2) || moved == 0 || p.finalized != 2) { fprintf(stderr, "FAIL: kept %zu moved %zu finalized %d\n", kept, moved, p.finalized); return 1; }
+        printf("finished: %zu selected texels changed, the %zu unselected ones hold the backup\n", moved, kept);
+    }
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
+    if (argc >= 2 && std::string(argv[1]) == "progress") return progress_check(argc, argv);
     if (argc == 2 && std::string(argv[1]) == "lifetime") return lifetime_check();
     if (argc >= 2 && std::string(argv[1]) == "cancel") return cancel_check(argc, argv);
     if (argc >= 2 && !(argv[1][0] >= '0' && argv[1][0] <= '9')) return other_tools(argc, argv);

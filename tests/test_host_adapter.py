@@ -44,6 +44,8 @@ def test_async_filter_cancel_semantics(tmp_path):
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-pthread", "-I", str(HOST), str(ROOT / "tests" / "host_cancel_check.cpp"), "-o", str(exe)])
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
     assert r.returncode == 0 and "ok" in r.stdout and "destroyed while parked" in r.stdout, r.stdout + r.stderr
+    # the ProgressFilter / BackupFilter mirror (reference Filter.cpp:12-23,70-115) -- Cancel restores the backup
+    assert "progress filter: cancelled" in r.stdout and "terrain restored" in r.stdout, r.stdout
 
 
 @pytest.mark.gpu
@@ -61,6 +63,21 @@ def test_adapter_cancel_ends_the_solve_at_the_next_outer_step(tmp_path):
     m = re.search(r"cancelled at outer step (\d+) of 10000 .* finished at outer step (\d+)", r.stdout)
     assert m and 1 <= int(m.group(1)) <= int(m.group(2)) <= int(m.group(1)) + 3, r.stdout
     assert "destroyed in mid-run" in r.stdout
+
+
+@pytest.mark.gpu
+def test_progress_filter_cancel_restores_the_backup(tmp_path):
+    """VERDICT r5 item 7: HipErosion inside the ProgressFilter / BackupFilter mirror, as cpufilterMenu::makeFilter builds it
+    (cpufilter.cpp:30-31): cancelled once its first round's terrain has arrived, the terrain equals the backup taken when the filter
+    was made and the filter is finalized; run to the end with half the canvas selected, restoreUnselected keeps the other half"""
+    from demiurge_amd import synth
+    build()
+    W, H = 256, 128
+    t = tmp_path / "t.f32"
+    (synth.terrain(W, H) * 1000.0).astype(np.float32).tofile(t)
+    r = subprocess.run([str(HOST / "host_demo"), "progress", str(W), str(H), str(t)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "the terrain equals the backup" in r.stdout and "unselected ones hold the backup" in r.stdout, r.stdout
 
 
 @pytest.mark.gpu

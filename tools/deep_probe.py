@@ -10,13 +10,17 @@ from demiurge_amd import capi, synth
 W = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 H = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
 import ctypes
-_probe = ctypes.CDLL(str(Path(__file__).resolve().parents[1] / "demiurge_amd" / "libdemiurge_hip.so")).dmg_ocean_jacobi_deep_probe
+import os
+_probe = ctypes.CDLL(os.environ.get("DMG_LIB") or str(Path(__file__).resolve().parents[1] / "demiurge_amd" / "libdemiurge_hip.so")).dmg_ocean_jacobi_deep_probe
 _probe.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
 def deep(o, lo, hi, seg, src):
     capi.check(_probe(o.h, lo, hi, seg, src))
 ctx = capi.Context(0)
 g = capi.make_grid(W, H)
-o = capi.Ocean(ctx, g)
+prm = capi.default_ocean_params()
+if os.environ.get("DEEP_TOL") == "1":                 # round 6: the deep form in the tolerance rendering (DMG_QUIRK_JACOBI_TOLERANCE)
+    prm.quirks |= capi.QUIRK_JACOBI_TOLERANCE
+o = capi.Ocean(ctx, g, params=prm)
 o.set_terrain(-np.ones((H, W), np.float32)); o.set_divw(synth.divw(W, H))
 o.zero_pressure(); o.jacobi_sweeps(8)
 p8 = o.get(want=("pressure",))["pressure"]
