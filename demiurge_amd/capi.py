@@ -5,6 +5,7 @@ loudly when the library is missing or no MI355X is visible -- there is no CPU fa
 """
 import ctypes
 import os
+import sys
 import weakref
 from pathlib import Path
 
@@ -281,15 +282,39 @@ def lib():
     # The library itself reads two environment variables (DMG_MULTI_TIMEOUT_MS, DMG_ST_TWIN: demiurge_hip.h).  Its test hooks and
     # experiment knobs come in through dmg_debug_set: THIS binding -- the harness of the tests, the bench and the tools, not the
     # product -- hands over the DMG_* variables of its own environment, once, before any handle exists.
-    for k, v in os.environ.items():
-        if k.startswith("DMG_") and k not in HARNESS_ENV:
-            L.dmg_debug_set(k.encode(), v.encode())
     _lib = L
+    if L.dmg_version() != VERSION:
+        raise RuntimeError("%s is version %d, this binding was written for %d" % (LIB_PATH, L.dmg_version(), VERSION))
+    if _is_harness():
+        load_hooks_from_env()
     return L
 
 
+VERSION = 101          # DMG_VERSION of include/demiurge_hip.h (tests/test_abi.py holds the two together)
+
+
+def _is_harness():
+    """the hooks reach the library only from the harness -- the tests, bench.py, the tools, __graft_entry__ (or any
+    process started with DMG_TEST_HOOKS=1) -- not from whatever else imports this binding with DMG_* variables in its environment"""
+    if os.environ.get("DMG_TEST_HOOKS") == "1" or "pytest" in sys.modules:
+        return True
+    main = getattr(sys.modules.get("__main__"), "__file__", None)
+    if not main:
+        return False
+    p = Path(main).resolve()
+    root = Path(__file__).resolve().parents[1]
+    return root in p.parents and (p.parent.name in ("tools", "tests") or p.name in ("bench.py", "__graft_entry__.py"))
+
+
+def load_hooks_from_env():
+    """hand the DMG_* variables of this process's environment to dmg_debug_set (before the first handle: most hooks are read once)"""
+    for k, v in os.environ.items():
+        if k.startswith("DMG_") and k not in HARNESS_ENV:
+            lib().dmg_debug_set(k.encode(), v.encode())
+
+
 # read by the Python side (this file, bands.py, bench.py), not hooks of the library
-HARNESS_ENV = {"DMG_LIB", "DMG_BENCH_REHEARSAL", "DMG_HALO_OVERLAP", "DMG_HALO_BOUNCE", "DMG_HALO_PIPELINE", "DMG_MULTI_TIMEOUT_MS", "DMG_ST_TWIN"}
+HARNESS_ENV = {"DMG_TEST_HOOKS", "DMG_LIB", "DMG_BENCH_REHEARSAL", "DMG_HALO_OVERLAP", "DMG_HALO_BOUNCE", "DMG_HALO_PIPELINE", "DMG_MULTI_TIMEOUT_MS", "DMG_ST_TWIN"}
 
 
 def debug_set(name, value):

@@ -36,10 +36,12 @@ namespace {
 std::mutex g_hook_mu;
 std::map<std::string, std::unique_ptr<std::string>> g_hooks;     // (values are never freed while the process lives: dmg_hook hands out their c_str)
 std::vector<std::unique_ptr<std::string>> g_hook_graveyard;
+std::map<std::string, int> g_hook_reads;                          // names the library has looked up so far (most look-ups happen once: `static const`)
 }
 const char *dmg_hook(const char *name)
 {
     std::lock_guard<std::mutex> lk(g_hook_mu);
+    g_hook_reads[name]++;
     auto it = g_hooks.find(name);
     return it == g_hooks.end() ? nullptr : it->second->c_str();
 }
@@ -49,6 +51,13 @@ int dmg_debug_set(const char *name, const char *value)
 {
     if (!name || strncmp(name, "DMG_", 4) != 0) return dmg_fail(DMG_EINVAL, "dmg_debug_set: hook names start with DMG_");
     std::lock_guard<std::mutex> lk(g_hook_mu);
+    // (most hooks are read once, into a `static const`, the first time the code that owns them runs -- a value set after
+    // that is accepted and does nothing.  The call says so, once per name, instead of succeeding silently.)
+    auto rd = g_hook_reads.find(name);
+    if (rd != g_hook_reads.end() && rd->second > 0) {
+        fprintf(stderr, "dmg_debug_set: %s has been read %d time(s) already; if its reader keeps the first value (most do), this one has no effect\n", name, rd->second);
+        rd->second = -1000000000;                                   // (said once)
+    }
     auto it = g_hooks.find(name);
     if (it != g_hooks.end()) { g_hook_graveyard.push_back(std::move(it->second)); g_hooks.erase(it); }
     if (value) g_hooks[name] = std::make_unique<std::string>(value);

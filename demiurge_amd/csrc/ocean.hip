@@ -300,7 +300,7 @@ void dmg_ocean_destroy(dmg_ocean *o)
     (void)hipSetDevice(o->ctx->device);
     (void)hipStreamSynchronize(o->ctx->stream);
     for (void *p : { (void *)o->p[0], (void *)o->p[1], (void *)o->divw, (void *)o->img, (void *)o->code, (void *)o->code8,
-                     (void *)o->v[0], (void *)o->v[1], (void *)o->rowtab, (void *)o->jcoef, (void *)o->jcoefp, (void *)o->jcoef2, (void *)o->jcoef3, (void *)o->rowbad, (void *)o->oob_flag, (void *)o->rowclass, (void *)o->rowclass_n, (void *)o->rowclass32, (void *)o->vadv })
+                     (void *)o->v[0], (void *)o->v[1], (void *)o->rowtab, (void *)o->jcoef, (void *)o->jcoefp, (void *)o->jcoef2, (void *)o->jcoef3, (void *)o->rowbad, (void *)o->oob_flag, (void *)o->rowclass, (void *)o->vadv })
         if (p) (void)hipFree(p);
     ocean_tb_free_lists(o);
     if (o->ev_fork) (void)hipEventDestroy(o->ev_fork);

@@ -150,7 +150,9 @@ __global__ __launch_bounds__(NW * 64, (R <= 8 ? 4 : 2)) void k_diffusion_tb(dtb_
         // the outermost waves read a slot of their own: those rows are halo, their values never reach the output
         const int ws = wave > 0 ? wave - 1 : 0, wn = wave < NW - 1 ? wave + 1 : NW - 1;
         float4 prevx = halo[par][ws][1][0][lane], prevy = halo[par][ws][1][1][lane];      // row below r = 0
-        const float4 northx = halo[par][wn][0][0][lane], northy = halo[par][wn][0][1][lane];   // row above r = R-1
+        // (the row above r = R-1 is read where it is used, at the loop's last row: held from here on its eight registers were what
+        // pushed the default shape, R = 7, over its 128 -- 16 bytes of scratch per lane through round 5.  The slot is not written
+        // again before the barrier of the sweep after next.)
 
         // rows closer than s+1 to the top/bottom edge of the extended tile are stale after this sweep whatever we do
         unsigned skip = 0;
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(NW * 64, (R <= 8 ? 4 : 2)) void k_diffusion_tb(dtb_
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const float4 Cx = vx[r], Cy = vy[r];
-            const float4 Nx = (r < R - 1) ? vx[r + 1] : northx, Ny = (r < R - 1) ? vy[r + 1] : northy;
+            const float4 Nx = (r < R - 1) ? vx[r + 1] : halo[par][wn][0][0][lane], Ny = (r < R - 1) ? vy[r + 1] : halo[par][wn][0][1][lane];
             const float4 Sx = prevx, Sy = prevy;
             prevx = Cx; prevy = Cy;
             if (skip & (1u << r)) continue;

@@ -39,17 +39,9 @@ struct dmg_ocean {
     unsigned char *code8 = nullptr;   // 8-neighbour solid bits (divergence, subDiv)
     unsigned char *rowclass = nullptr; // blocked Jacobi: class of every (tile column, row) wave-row (ocean_jacobi_tb.hip)
     std::vector<unsigned char> rowclass_host;   // the same table on the host, for the live-tile lists
-    unsigned char *rowclass_n = nullptr;        // the same for the narrow streaming kernel's 112-column strips
-    unsigned *rowclass32 = nullptr;             // rowclass widened to 32 bits per entry (the persistent streaming kernel loads it per row)
-    std::vector<unsigned char> rowclass_n_host;
     struct tile_list {
         int *d = nullptr; int n = 0;
         std::vector<int> host;                           // the list as the kernel reads it (kept only for dmg_stream_units_probe)
-        // persistent streaming kernel: segment table templates and the launch's live copies (ocean_jacobi_stream.hip)
-        unsigned long long *seg_word0 = nullptr, *seg_word = nullptr;
-        unsigned *seg_cur0 = nullptr, *seg_cur = nullptr;
-        int *seg_ctl = nullptr;
-        int cap = 0, waves = 0;
         int twin = 0;                                    // streaming kernel: the list holds pairs of twin units (two entries per workgroup, k_jacobi_stream_twin)
         size_t n_units = 0;                              // entries in the list (2 n for twin units)
         size_t n_cut_units = 0;                          // ... that are units of the cut (not place holders)
@@ -123,7 +115,7 @@ int ocean_launch_tb(dmg_ocean *o, int lo, int hi, int n, int part = 0, int zone_
                     hipStream_t stream = nullptr);   // src >= 0: from p[src] into p[src ^ 1] instead of the current pair; stream: instead of the context's
 int ocean_tb_tile_rows(dmg_ocean *o, int lo, int hi);    // output rows per tile row of the shape an 8-sweep launch over [lo, hi) uses; 0 while its tuner is open
 // ocean_jacobi_stream.hip: 8 sweeps over local rows [lo, hi) by the streaming kernel; seg = rows per unit (0 = default)
-// variant 0: 4 columns per lane, two waves per SIMD; 1: 2 columns per lane, four waves per SIMD
+// (variant: unused since round 5 retired the narrow and the persistent form)
 int ocean_launch_stream(dmg_ocean *o, int lo, int hi, int part, int zone_lo, int zone_hi, int from, hipStream_t st, int seg = 0, int variant = -1);
 bool ocean_stream_enabled();
 int ocean_launch_diffusion_tb(dmg_ocean *o, int lo, int hi, int n);   // ocean_diffusion_tb.hip: n (1..8) sweeps over local rows [lo, hi)

@@ -94,17 +94,17 @@ __device__ __forceinline__ void dp_front_step(const st_args &a, st_state &z, v4f
     bq[1] = bring[s1][lane]; bq[0] = bring[z.slot][lane];
     kq[1] = ktab[max(2 * t - 1, 0)]; kq[0] = ktab[max(2 * t - 1, 0) + 1];
     unsigned (*nocring)[64] = nullptr;
-    if (PHASE != 0 || 1 <= t) st_level<1, K, false, 1, DV>(a, z, bring, nocring, ktab, lane, t, e_t - 1, 0, 0, false, 0, bq, kq, kb);
-    if (PHASE != 0 || 2 <= t) st_level<2, K, false, 1, DV>(a, z, bring, nocring, ktab, lane, t, e_t - 2, 0, 0, false, 0, bq, kq, kb);
-    if (PHASE != 0 || 3 <= t) st_level<3, K, false, 1, DV>(a, z, bring, nocring, ktab, lane, t, e_t - 3, 0, 0, false, 0, bq, kq, kb);
-    if (PHASE != 0 || 4 <= t) st_level<4, K, false, 1, DV>(a, z, bring, nocring, ktab, lane, t, e_t - 4, 0, 0, false, 0, bq, kq, kb);
-    if (PHASE != 0 || 5 <= t) st_level<5, K, false, 1, DV>(a, z, bring, nocring, ktab, lane, t, e_t - 5, 0, 0, false, 0, bq, kq, kb);
-    if (PHASE != 0 || 6 <= t) st_level<6, K, false, 1, DV>(a, z, bring, nocring, ktab, lane, t, e_t - 6, 0, 0, false, 0, bq, kq, kb);
-    if (PHASE != 0 || 7 <= t) st_level<7, K, false, 1, DV>(a, z, bring, nocring, ktab, lane, t, e_t - 7, 0, 0, false, 0, bq, kq, kb);
+    if (PHASE != 0 || 1 <= t) st_level<1, K, 1, DV>(a, z, bring, nocring, ktab, lane, t, e_t - 1, 0, 0, false, 0, bq, kq, kb);
+    if (PHASE != 0 || 2 <= t) st_level<2, K, 1, DV>(a, z, bring, nocring, ktab, lane, t, e_t - 2, 0, 0, false, 0, bq, kq, kb);
+    if (PHASE != 0 || 3 <= t) st_level<3, K, 1, DV>(a, z, bring, nocring, ktab, lane, t, e_t - 3, 0, 0, false, 0, bq, kq, kb);
+    if (PHASE != 0 || 4 <= t) st_level<4, K, 1, DV>(a, z, bring, nocring, ktab, lane, t, e_t - 4, 0, 0, false, 0, bq, kq, kb);
+    if (PHASE != 0 || 5 <= t) st_level<5, K, 1, DV>(a, z, bring, nocring, ktab, lane, t, e_t - 5, 0, 0, false, 0, bq, kq, kb);
+    if (PHASE != 0 || 6 <= t) st_level<6, K, 1, DV>(a, z, bring, nocring, ktab, lane, t, e_t - 6, 0, 0, false, 0, bq, kq, kb);
+    if (PHASE != 0 || 7 <= t) st_level<7, K, 1, DV>(a, z, bring, nocring, ktab, lane, t, e_t - 7, 0, 0, false, 0, bq, kq, kb);
     if (PHASE != 0) {
         const int p = t - TB_T;                      // the pair this step hands over
         if (SYNC == 2) dp_wait_at_least(&sy->cons, p - (DP_D - 1), &sy->err, wacc);
-        st_level<8, K, false, 4, DV>(a, z, bring, nocring, ktab, lane, t, e_t - 8, 0, 0, false, 0, bq, kq, kb, nullptr, 0, 0, xout);
+        st_level<8, K, 4, DV>(a, z, bring, nocring, ktab, lane, t, e_t - 8, 0, 0, false, 0, bq, kq, kb, nullptr, 0, 0, xout);
         if (SYNC == 2) dp_publish(&sy->prod, p + 1, lane);
     }
     z.slot = z.slot + 2 == ST_RING ? 0 : z.slot + 2;
@@ -128,15 +128,15 @@ __device__ __forceinline__ void dp_back_step(const st_args &a, st_state &z, v4f 
     kq[1] = ktab[max(2 * t - 1, 0)]; kq[0] = ktab[max(2 * t - 1, 0) + 1];
     unsigned (*nocring)[64] = nullptr;
     constexpr int M = PHASE == 1 ? 3 : 1;
-    if (PHASE != 0 || 1 <= t) st_level<1, K, false, M, DV>(a, z, bring, nocring, ktab, lane, t, e_t - 1, r0, r1, lane_ok, xcol, bq, kq, kb);
-    if (PHASE != 0 || 2 <= t) st_level<2, K, false, M, DV>(a, z, bring, nocring, ktab, lane, t, e_t - 2, r0, r1, lane_ok, xcol, bq, kq, kb);
-    if (PHASE != 0 || 3 <= t) st_level<3, K, false, M, DV>(a, z, bring, nocring, ktab, lane, t, e_t - 3, r0, r1, lane_ok, xcol, bq, kq, kb);
-    if (PHASE != 0 || 4 <= t) st_level<4, K, false, M, DV>(a, z, bring, nocring, ktab, lane, t, e_t - 4, r0, r1, lane_ok, xcol, bq, kq, kb);
-    if (PHASE != 0 || 5 <= t) st_level<5, K, false, M, DV>(a, z, bring, nocring, ktab, lane, t, e_t - 5, r0, r1, lane_ok, xcol, bq, kq, kb);
-    if (PHASE != 0 || 6 <= t) st_level<6, K, false, M, DV>(a, z, bring, nocring, ktab, lane, t, e_t - 6, r0, r1, lane_ok, xcol, bq, kq, kb);
-    if (PHASE != 0 || 7 <= t) st_level<7, K, false, M, DV>(a, z, bring, nocring, ktab, lane, t, e_t - 7, r0, r1, lane_ok, xcol, bq, kq, kb);
+    if (PHASE != 0 || 1 <= t) st_level<1, K, M, DV>(a, z, bring, nocring, ktab, lane, t, e_t - 1, r0, r1, lane_ok, xcol, bq, kq, kb);
+    if (PHASE != 0 || 2 <= t) st_level<2, K, M, DV>(a, z, bring, nocring, ktab, lane, t, e_t - 2, r0, r1, lane_ok, xcol, bq, kq, kb);
+    if (PHASE != 0 || 3 <= t) st_level<3, K, M, DV>(a, z, bring, nocring, ktab, lane, t, e_t - 3, r0, r1, lane_ok, xcol, bq, kq, kb);
+    if (PHASE != 0 || 4 <= t) st_level<4, K, M, DV>(a, z, bring, nocring, ktab, lane, t, e_t - 4, r0, r1, lane_ok, xcol, bq, kq, kb);
+    if (PHASE != 0 || 5 <= t) st_level<5, K, M, DV>(a, z, bring, nocring, ktab, lane, t, e_t - 5, r0, r1, lane_ok, xcol, bq, kq, kb);
+    if (PHASE != 0 || 6 <= t) st_level<6, K, M, DV>(a, z, bring, nocring, ktab, lane, t, e_t - 6, r0, r1, lane_ok, xcol, bq, kq, kb);
+    if (PHASE != 0 || 7 <= t) st_level<7, K, M, DV>(a, z, bring, nocring, ktab, lane, t, e_t - 7, r0, r1, lane_ok, xcol, bq, kq, kb);
     // (voA, voB address rows e_t + 4, e_t + 5; this wave's level 8 makes rows e_t - 8, e_t - 7: sb = pout - 12 rows)
-    if (PHASE != 0) st_level<8, K, false, M, DV>(a, z, bring, nocring, ktab, lane, t, e_t - 8, r0, r1, lane_ok, xcol, bq, kq, kb, sb, voA, voB);
+    if (PHASE != 0) st_level<8, K, M, DV>(a, z, bring, nocring, ktab, lane, t, e_t - 8, r0, r1, lane_ok, xcol, bq, kq, kb, sb, voA, voB);
     z.slot = z.slot + 2 == ST_RING ? 0 : z.slot + 2;
     DP_BARRIER();
 }

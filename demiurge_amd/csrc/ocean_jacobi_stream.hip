@@ -115,10 +115,10 @@ __global__ __launch_bounds__(64, 2) void k_jacobi_stream(st_args a_up, st_args a
         z.plain = e0 >= 0 && e_last < a.L && a.y_first + e0 >= 0 && a.y_first + e_last < a.H;
         z.nx_p = a.pin + (long)e0 * a.rs; z.nx_b = a.b + (long)e0 * a.rs; z.nx_c = a.code + (long)e0 * a.rs;
     }
-    st_fetch<false>(a, z, 0, 0, e0, col, colp);
-    st_fetch<false>(a, z, 0, 1, e0 + 1, col, colp);
-    st_fetch<false>(a, z, 1, 0, e0 + 2, col, colp);          // (rows past the window are clamped into the band: harmless)
-    st_fetch<false>(a, z, 1, 1, e0 + 3, col, colp);
+    st_fetch(a, z, 0, 0, e0, col, colp);
+    st_fetch(a, z, 0, 1, e0 + 1, col, colp);
+    st_fetch(a, z, 1, 0, e0 + 2, col, colp);          // (rows past the window are clamped into the band: harmless)
+    st_fetch(a, z, 1, 1, e0 + 3, col, colp);
 
     unsigned cls_lo, cls_hi = 0u;                            // (cls_lo: four classes per lane, st_class4)
     st_unit_tables<DV>(a, lane, tx, e0, 2 * nsteps + 2, cls_lo, ktab);
@@ -141,8 +141,8 @@ __global__ __launch_bounds__(64, 2) void k_jacobi_stream(st_args a_up, st_args a
 #ifdef ST_EXPERIMENTS
         if (a.stepprof && lane == 0 && t < 44) a.stepprof[(size_t)blockIdx.x * 64 + t / 2] = __builtin_amdgcn_s_memrealtime();
 #endif
-        st_step<0, false, DV>(a, z, bring, cring, ktab, lane, t, e0, nsteps, r1, cls_lo, cls_hi, col, colp, lane_ok, xcol);
-        st_step<1, false, DV>(a, z, bring, cring, ktab, lane, t + 1, e0, nsteps, r1, cls_lo, cls_hi, col, colp, lane_ok, xcol);
+        st_step<0, DV>(a, z, bring, cring, ktab, lane, t, e0, nsteps, r1, cls_lo, cls_hi, col, colp, lane_ok, xcol);
+        st_step<1, DV>(a, z, bring, cring, ktab, lane, t + 1, e0, nsteps, r1, cls_lo, cls_hi, col, colp, lane_ok, xcol);
     }
     if (a.prof && lane == 0) a.prof[3 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
 #ifdef ST_EXPERIMENTS
@@ -199,10 +199,10 @@ __global__ __launch_bounds__(128, 2) void k_jacobi_stream_twin(st_args a_up, st_
         z.plain = e0 >= 0 && e_last < a.L && a.y_first + e0 >= 0 && a.y_first + e_last < a.H;
         z.nx_p = a.pin + (long)e0 * a.rs; z.nx_b = a.b + (long)e0 * a.rs; z.nx_c = a.code + (long)e0 * a.rs;
     }
-    st_fetch<false>(a, z, 0, 0, e0, col, colp);
-    st_fetch<false>(a, z, 0, 1, e0 + 1, col, colp);
-    st_fetch<false>(a, z, 1, 0, e0 + 2, col, colp);
-    st_fetch<false>(a, z, 1, 1, e0 + 3, col, colp);
+    st_fetch(a, z, 0, 0, e0, col, colp);
+    st_fetch(a, z, 0, 1, e0 + 1, col, colp);
+    st_fetch(a, z, 1, 0, e0 + 2, col, colp);
+    st_fetch(a, z, 1, 1, e0 + 3, col, colp);
     unsigned cls_lo, cls_hi = 0u;
     st_unit_tables<DV>(a, lane, tx, e0, 2 * nsteps + 2, cls_lo, ktab);
 #pragma unroll
@@ -235,11 +235,11 @@ __global__ __launch_bounds__(128, 2) void k_jacobi_stream_twin(st_args a_up, st_
 #ifdef ST_EXPERIMENTS
         if (a.stepprof && lane == 0 && t < 44) a.stepprof[(size_t)(2 * blockIdx.x + wave) * 64 + t / 2] = __builtin_amdgcn_s_memrealtime();
 #endif
-        st_step<0, false, DV, 1>(a, z, bring, cring, ktab, lane, t, e0, nsteps, r1, cls_lo, cls_hi, col, colp, lane_ok, xcol, 0, xme, xpeer);
+        st_step<0, DV, 1>(a, z, bring, cring, ktab, lane, t, e0, nsteps, r1, cls_lo, cls_hi, col, colp, lane_ok, xcol, 0, xme, xpeer);
 #if ST_TWIN_FAIR == 4
         if (wslot) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(2);
 #endif
-        st_step<1, false, DV, 1>(a, z, bring, cring, ktab, lane, t + 1, e0, nsteps, r1, cls_lo, cls_hi, col, colp, lane_ok, xcol, 0, xme, xpeer);
+        st_step<1, DV, 1>(a, z, bring, cring, ktab, lane, t + 1, e0, nsteps, r1, cls_lo, cls_hi, col, colp, lane_ok, xcol, 0, xme, xpeer);
     }
     if (a.prof && lane == 0) a.prof[3 * (2 * blockIdx.x + wave) + 1] = __builtin_amdgcn_s_memrealtime();
 #ifdef ST_EXPERIMENTS
@@ -334,8 +334,7 @@ int ocean_launch_stream(dmg_ocean *o, int lo, int hi, int part, int zone_lo, int
     static const bool use_cls = dmg_hook("DMG_TB_NOCLASS") == nullptr;
     a.rowclass = use_cls ? o->rowclass : nullptr;
     a.units = (const int4 *)tl->d;
-    a.rowclass32 = o->rowclass32;
-    a.seg_word = nullptr; a.seg_cur = nullptr; a.seg_ctl = nullptr; a.nseg0 = 0; a.cap = 0;
+    a.nseg0 = 0;
     o->last_kernel = "k_jacobi_stream";
     static const int dbg = [] { const char *e = dmg_hook("DMG_ST_DBG"); return e ? atoi(e) : 0; }();
     a.dbg = dbg;

@@ -292,8 +292,7 @@ __global__ __launch_bounds__(64) void k_tb_rowclass(const unsigned char *__restr
 void ocean_tb_free_lists(dmg_ocean *o)
 {
     for (auto &kv : o->tb_lists)
-        for (void *q : { (void *)kv.second.d, (void *)kv.second.seg_word0, (void *)kv.second.seg_word, (void *)kv.second.seg_cur0, (void *)kv.second.seg_cur, (void *)kv.second.seg_ctl })
-            if (q) (void)hipFree(q);
+        if (kv.second.d) (void)hipFree(kv.second.d);
     o->tb_lists.clear();
     // (the streaming kernel's mirrored row tables: the classes change with the terrain, the lists go with it)
     for (void *q : { (void *)o->jcoef_f, (void *)o->jcoef2_f, (void *)o->jcoef3_f, (void *)o->rowbad_f, (void *)o->rowclass_f }) if (q) (void)hipFree(q);
@@ -310,12 +309,6 @@ void ocean_tb_free_lists(dmg_ocean *o)
     o->st_tuning.clear();
 }
 
-__global__ void k_tb_widen(const unsigned char *__restrict__ in, unsigned *__restrict__ out, size_t n)
-{
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = in[i];
-}
-
 int ocean_build_rowclass(dmg_ocean *o)
 {
     if (!ocean_tb_supported(o)) return DMG_OK;
@@ -324,12 +317,6 @@ int ocean_build_rowclass(dmg_ocean *o)
     hipLaunchKernelGGL(k_tb_rowclass, dim3(tiles_x, o->L), dim3(64), 0, o->ctx->stream, o->code, o->rowclass, o->grid.W, o->L,
                        o->y0 - o->gs, o->grid.H, o->topo.spole ? 1 : 0, o->topo.npole ? 1 : 0);
     DMG_HIP(hipGetLastError());
-    {
-        const size_t n = (size_t)tiles_x * o->L;
-        if (!o->rowclass32) DMG_HIP(hipMalloc((void **)&o->rowclass32, n * sizeof(unsigned)));
-        hipLaunchKernelGGL(k_tb_widen, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, o->ctx->stream, o->rowclass, o->rowclass32, n);
-        DMG_HIP(hipGetLastError());
-    }
     ocean_tb_free_lists(o);                              // lists of the previous terrain
     o->rowclass_host.resize((size_t)tiles_x * o->L);
     DMG_HIP(hipMemcpyAsync(o->rowclass_host.data(), o->rowclass, o->rowclass_host.size(), hipMemcpyDeviceToHost, o->ctx->stream));

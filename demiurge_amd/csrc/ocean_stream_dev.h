@@ -26,10 +26,11 @@
 // two rows of 256 cells; everything else was taken out piece by piece -- rows are held as cell pairs (c0,c3),(c1,c2) so
 // that pW + pE needs no register shuffling; coast rows go through counts of land neighbours (one packed fma per pair
 // instead of eight selects); steps without land or coast, and steps with coast but no all-land row, run their eight
-// levels without a test or a branch; one ring read per row and level.  Four forms share the code: units (the default for
-// the full grid), twin units (round 4, the default for launches of up to 4400 rows -- the bands of a split grid: two waves
-// that start on the two sides of a seam and need no halo between them, k_jacobi_stream_twin), narrow units (2 cells per
-// lane, five waves per SIMD) and persistent waves with work stealing.
+// levels without a test or a branch; one ring read per row and level.  Two forms share the code: units (the default for
+// the full grid) and twin units (round 4, the default for launches of up to 4400 rows -- the bands of a split grid: two waves
+// that start on the two sides of a seam and need no halo between them, k_jacobi_stream_twin); each in three arithmetics
+// (DV: Markstein divisions, exact two-operation divisions -- the default -- and round 6's tolerance rendering with fused row
+// coefficients).  (Narrow units and persistent waves with work stealing were retired in round 5: profiles/NOTEBOOK.md.)
 //
 // Canvas topology exactly as in ocean_jacobi_tb.hip: columns wrap, rows beyond a pole are the same rows mirrored and
 // shifted by W/2 (offset(), src/Shader.h:86-95), rows beyond a non-pole edge are plain mirrors with the clamp bit
@@ -49,7 +50,6 @@
 #endif
 #define ST_MAXROWS 232            // output rows per unit of the wide form: 248 window rows' classes fit one register (four bytes per
                                   // lane), and the coefficient table of 232 + 22 rows leaves its LDS at 19424 bytes: 8 waves share 160 KB
-#define STN_MAXROWS 104           // narrow form: two class registers
 #ifndef ST_RING
 #define ST_RING 12                // ring slots (rows): 10 rows are in flight between level 0 and level 8, two arrive
 #endif
@@ -81,18 +81,11 @@ struct st_args {
     const int4 *units;              // {tile column, first output row, end output row, -}
     const unsigned char *rowbad;    // DV = 1: [L] 1 = the row's divisors have no exact two-operation pair (its table entry holds (c, r)); or null
     const float *jcoef_cy;          // {cy, 1/cy}: the same for every row
-    // persistent form (k_jacobi_stream_p): segment table and queue, see there
-    unsigned long long *seg_word;   // [cap + waves]: stp_word(strip, first row, end row); the end row only ever moves down (compare-and-swap by a thief)
-    unsigned *seg_cur;              // [cap + waves]: next window row its owner will take + STP_BIAS (owner's progress, plain stores; advisory)
-    int *seg_ctl;                   // [0] next queued segment, [1] next free table slot
-    int nseg0, cap;
-    const unsigned *rowclass32;     // rowclass, one 32-bit word per entry
+    int nseg0;                      // the deep form (ocean_jacobi_deep.hip, experiments): units in the list
     unsigned long long *prof;       // experiments only (DMG_ST_PROF): {start, end} of every unit on the 100 MHz s_memrealtime clock, or null
     unsigned long long *clk;        // experiments only (-DST_EXPERIMENTS, with DMG_ST_PROF): s_memtime (the shader clock's counter) at every unit's start and end, beside prof's s_memrealtime
     unsigned long long *stepprof;   // experiments only (-DST_EXPERIMENTS, DMG_ST_STEPPROF): s_memrealtime at the top of the first 64 steps of every unit
     int dbg;                        // experiments only (DMG_ST_DBG bits): 1 = every unit re-reads 64 rows (cache hits), 2 = no stores, 4 = plain instead of nontemporal stores;
-                                    // persistent form: 8 = owners do not re-read their end row, 16 = no stealing, 32 = owners do not publish progress,
-                                    // 64 = row classes from the table instead of from the codes, 128 = no coefficient refills (timing only: wrong results)
 };
 
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -200,8 +193,7 @@ struct st_state {
     // ~4-6 us of the wave's arithmetic, to come back: one step was not enough, the waves sat in s_waitcnt a third of the time)
     v4f ps[2][2], bs[2][2];
     unsigned cs[2][2];
-    unsigned ks[2][2];              // persistent form: the row's class travels with its loads
-    unsigned fc[2][2];              // unit form: the class byte of the row in flight (looked up when its loads are issued: scalar)
+    unsigned fc[2][2];              // the class byte of the row in flight (looked up when its loads are issued: scalar)
     unsigned landbits, mixbits;     // bit j: row (newest - j) is land everywhere / has coast; newest = second row of this step's pair
     // units whose whole window (and the rows requested past it) lies inside the grid and the stored band fetch their rows
     // through three row pointers that advance by one row per fetch (scalar adds) instead of mapping every row index
@@ -212,8 +204,6 @@ struct st_state {
     int slot;                       // ring slot of the first row of this step's pair (row offset mod ST_RING)
     float cy, ry;                   // the same for every row (pixelsize().y, src/Shader.h:71-74): two SGPRs
 };
-#define STP_KT 128                // persistent form: the coefficient table is a ring over the window rows
-template <bool P> __device__ __forceinline__ int st_kt(int window_row) { return P ? (window_row & (STP_KT - 1)) : window_row; }
 
 // LDS coefficient entries: {cx, 1/cx, 1/Beta, Beta} -- with 1/Beta in the low half of its register pair the packed multiply
 // takes it as it is (from the high half the compiler first copies it into a pair of its own: two moves per level visit)
@@ -273,7 +263,7 @@ __device__ __forceinline__ v4f st_row_any(const v4f N, const v4f C, const v4f S,
 // MODE 0: the pair's rows as their classes say (tests and branches); 1: both open water; 2: both through the coast formula;
 // 3: both open water and known to be rows the unit writes (st_open_unit): level 8 stores them through a scalar base and the
 // lane's byte offsets sA, sB, without a range test
-template <int S, int K, bool P, int MODE = 0, int DV = 0>
+template <int S, int K, int MODE = 0, int DV = 0>
 __device__ __forceinline__ void st_level(const st_args &a, st_state &z, v4f (*bring)[64], unsigned (*cring)[64], const v4f *ktab,
                                          int lane, int t, int yA, int r0, int r1, bool lane_ok, int xcol,
                                          v4f (&bq)[9], v4f (&kq)[9], int kb = 0, const char *sbase = nullptr, unsigned sA = 0, unsigned sB = 0,
@@ -287,8 +277,7 @@ __device__ __forceinline__ void st_level(const st_args &a, st_state &z, v4f (*br
         // coefficients of row k = S + 1, window row 2t - (S + 1); every lane reads the same 16 bytes: one broadcast.
         // Unit form: kb = byte offset of window row 2t - 8 in a VGPR, set once per step -- the level adds a constant (in the
         // first four steps of a unit the offset is negative: the read lands in the ring in front of the table and is not used)
-        if (P) kq[S + 1] = ktab[st_kt<P>(max(2 * t - (S + 1), 0))];
-        else kq[S + 1] = *reinterpret_cast<const v4f *>(reinterpret_cast<const char *>(ktab) + kb + (8 - (S + 1)) * 16);
+        kq[S + 1] = *reinterpret_cast<const v4f *>(reinterpret_cast<const char *>(ktab) + kb + (8 - (S + 1)) * 16);
     }
     // right-hand sides: the ring slot of row k = S + 1 is odd for even S (slots advance by two per step), so the slot below it
     // exists without a wrap: an even level reads rows S + 1 and S + 2 off one address, the odd levels after the first none
@@ -372,7 +361,6 @@ __device__ __forceinline__ unsigned st_class(unsigned cls_lo, unsigned cls_hi, i
 // (Round 2 measured pointing the loads a row does not need -- everything of a land row, the codes of an open-ocean row -- at an
 // already cached row as a loss, 2.58 -> 2.49 M: address arithmetic in VGPR pairs.  With scalar row bases the codes of an open
 // row ARE redirected now, below; a land row's loads are not: such rows are few inside a live unit.)
-template <bool P>
 __device__ __forceinline__ void st_fetch(const st_args &a, st_state &z, int set, int j, int e, int col, int colp, int tx = 0, unsigned cls = 2u)
 {
     // Three scalar row bases and one 32-bit byte offset per lane: the loads take the SGPR-base + VGPR-offset form, whichever
@@ -382,24 +370,22 @@ __device__ __forceinline__ void st_fetch(const st_args &a, st_state &z, int set,
     // written as two branches that each load, the compiler merges them and builds every address in a VGPR pair.
     const char *bp, *bb, *bc;
     bool shift = false;
-    int ml = 0;
-    if (!P && z.plain && !ST_DBG(a, 1)) {
+    if (z.plain && !ST_DBG(a, 1)) {
         bp = reinterpret_cast<const char *>(z.nx_p); bb = reinterpret_cast<const char *>(z.nx_b); bc = reinterpret_cast<const char *>(z.nx_c);
         z.nx_p += a.rs; z.nx_b += a.rs; z.nx_c += a.rs;
     } else {
         const st_row m = st_map_row(a, ST_DBG(a, 1) ? (e & 63) : e);
         const long rowoff = (long)m.l * a.rs;
         bp = reinterpret_cast<const char *>(a.pin + rowoff); bb = reinterpret_cast<const char *>(a.b + rowoff); bc = reinterpret_cast<const char *>(a.code + rowoff);
-        shift = m.shift; ml = m.l;
+        shift = m.shift;
     }
     // an open-water row's codes are never looked at (st_arrive): its load goes to the band's first row, which every wave
     // keeps in the L2 -- the same instruction, a ninth of the row's bytes less from HBM
-    if (!P && (cls & 3u) == 0u) bc = reinterpret_cast<const char *>(a.code);
+    if ((cls & 3u) == 0u) bc = reinterpret_cast<const char *>(a.code);
     const unsigned cc = (unsigned)(shift ? colp : col);
     z.ps[set][j] = *reinterpret_cast<const v4f *>(bp + cc * 4u);
     z.bs[set][j] = *reinterpret_cast<const v4f *>(bb + cc * 4u);
     z.cs[set][j] = *reinterpret_cast<const unsigned *>(bc + cc);
-    if (P && ST_DBG(a, 64)) z.ks[set][j] = a.rowclass32[(size_t)tx * a.L + ml];          // every lane the same word
 }
 typedef const float __attribute__((address_space(4))) *st_kptr;
 
@@ -470,20 +456,6 @@ __device__ __forceinline__ void st_arrive(const st_args &a, st_state &z, v4f (*b
     else st_park_pairs(&bring[slot][lane], z.bs[K][j]);
 }
 
-// class of the row in staging slot [K][j] (persistent form): rows beyond the grid or the stored band count as mixed
-template <int K>
-__device__ __forceinline__ unsigned st_class_p(const st_args &a, const st_state &z, int j, int e)
-{
-    const int yg = a.y_first + e;
-    if (!ST_DBG(a, 64)) return 2u;                            // the codes decide (st_arrive)
-    const bool inside = yg >= 0 && yg < a.H && e >= 0 && e < a.L;
-    // (volatile: left to the scheduler, this read -- and with it the wait for the staging set's loads -- moves a whole step
-    // up, to where the set before it has only just been taken)
-    unsigned c;
-    asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(c) : "v"(z.ks[K][j]) : "memory");
-    return inside ? c : 2u;
-}
-
 // ---- twin units (round 4): two units of a strip that START on the same seam and stream away from it ------------------------
 // A unit of n rows streams n + 16: eight rows beyond each end, on which its levels shrink back to the rows it writes -- a
 // 28-row unit (the band of an 8-way split has ~28 rows per wave slot) runs 22 steps for 14 steps' worth of rows.  The halo
@@ -518,7 +490,7 @@ __device__ __forceinline__ void st_twin_level(const st_args &a, st_state &z, v4f
                                               v4f (*xme)[64], const v4f (*xpeer)[64])
 {
     if (S <= 2 * t + 1) {
-        st_level<S, K, false, 0, DV>(a, z, bring, cring, ktab, lane, t, e_t - S, r0, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<S, K, 0, DV>(a, z, bring, cring, ktab, lane, t, e_t - S, r0, r1, lane_ok, xcol, bq, kq, kb);
         if (S < 8) {
             if (S == 2 * t) st_twin_hand_over<S & 7, K>(z, xme, xpeer, lane, false);
             else if (S == 2 * t + 1) st_twin_hand_over<S & 7, K>(z, xme, xpeer, lane, true);
@@ -526,7 +498,7 @@ __device__ __forceinline__ void st_twin_level(const st_args &a, st_state &z, v4f
     }
 }
 
-template <int K, bool P = false, int DV = 0, int TW = 0>
+template <int K, int DV = 0, int TW = 0>
 __device__ __forceinline__ void st_step(const st_args &a, st_state &z, v4f (*bring)[64], unsigned (*cring)[64], const v4f *ktab, int lane, int t,
                                         int e0, int nsteps, int r1, unsigned cls_lo, unsigned cls_hi, int col, int colp, bool lane_ok, int xcol, int tx = 0,
                                         v4f (*xme)[64] = nullptr, const v4f (*xpeer)[64] = nullptr)
@@ -534,11 +506,11 @@ __device__ __forceinline__ void st_step(const st_args &a, st_state &z, v4f (*bri
     const int e_t = e0 + 2 * t;                              // first row of the pair that has just arrived
     const int slotB = z.slot + 1;                            // (ST_RING is even: a pair never wraps)
     unsigned landA, mixA, landB, mixB;
-    const unsigned clsA = P ? st_class_p<K>(a, z, 0, e_t) : z.fc[K][0], clsB = P ? st_class_p<K>(a, z, 1, e_t + 1) : z.fc[K][1];
+    const unsigned clsA = z.fc[K][0], clsB = z.fc[K][1];
 #ifdef ST_EXPERIMENTS
     // DMG_ST_STEPPROF: slots 22..42 = the clock when the even step's rows have arrived (its wait for the staged loads is over),
     // slots 43..62 = when the even step's levels are done, of a unit's first 20 iterations (slots 0..21: top of the iteration)
-    if (!P && K == 0 && a.stepprof && lane == 0 && t < 40) {
+    if (K == 0 && a.stepprof && lane == 0 && t < 40) {
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");          // (the even step's six loads are the oldest of the twelve in flight)
         a.stepprof[(size_t)(TW ? 2 * blockIdx.x + (threadIdx.x >> 6) : blockIdx.x) * 64 + 22 + t / 2] = __builtin_amdgcn_s_memrealtime();
     }
@@ -546,8 +518,8 @@ __device__ __forceinline__ void st_step(const st_args &a, st_state &z, v4f (*bri
     // (twin units: the partner has read the last row handed over -- ring slots 10 and 11 are the unit's own from here on)
     if (TW && K == 0 && t == TB_T / 2) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     // (tolerance rendering: the two rows' -1 / Beta from the table, window rows 2t and 2t + 1; every lane reads the same word)
-    const float ncA = DV == 3 ? -reinterpret_cast<const float *>(&ktab[st_kt<P>(2 * t)])[3] : 0.0f;
-    const float ncB = DV == 3 ? -reinterpret_cast<const float *>(&ktab[st_kt<P>(2 * t + 1)])[3] : 0.0f;
+    const float ncA = DV == 3 ? -reinterpret_cast<const float *>(&ktab[2 * t])[3] : 0.0f;
+    const float ncB = DV == 3 ? -reinterpret_cast<const float *>(&ktab[2 * t + 1])[3] : 0.0f;
     st_arrive<K, DV>(a, z, bring, cring, lane, 0, e_t, clsA, z.slot, landA, mixA, ncA);
     st_arrive<K, DV>(a, z, bring, cring, lane, 1, e_t + 1, clsB, slotB, landB, mixB, ncB);
     if (TW && K == 0 && t == 0) st_twin_hand_over<0, K>(z, xme, xpeer, lane, false);      // "level 0": the partner's first row is this unit's row -1
@@ -556,45 +528,45 @@ __device__ __forceinline__ void st_step(const st_args &a, st_state &z, v4f (*bri
     if (DV == 1) z.badbits = (z.badbits << 2) | ((clsA >> 1) & 2u) | ((clsB >> 2) & 1u);
     const unsigned special = DV == 1 ? z.badbits : 0u;           // rows that need the tested path like an all-land row does
     // the staging set is free again: the pair of step t + 2 (past the window's end the rows are clamped and unused)
-    if (!P) { z.fc[K][0] = st_class4(cls_lo, 2 * t + 4); z.fc[K][1] = st_class4(cls_lo, 2 * t + 5); }
-    st_fetch<P>(a, z, K, 0, e_t + 4, col, colp, tx, P ? 2u : z.fc[K][0]);
-    st_fetch<P>(a, z, K, 1, e_t + 5, col, colp, tx, P ? 2u : z.fc[K][1]);
+    z.fc[K][0] = st_class4(cls_lo, 2 * t + 4); z.fc[K][1] = st_class4(cls_lo, 2 * t + 5);
+    st_fetch(a, z, K, 0, e_t + 4, col, colp, tx, z.fc[K][0]);
+    st_fetch(a, z, K, 1, e_t + 5, col, colp, tx, z.fc[K][1]);
     // level 1: rows e_t - 1 (in the ring since the last step) and e_t (just written)
     // (a twin unit's level 1 computes window row 0 in step 0: its table index is not clamped -- row -1's entry is the 16 bytes in
     // front of the table, read and not used)
     const int s1 = st_wrap(z.slot - 1), r1w = TW ? 2 * t - 1 : max(2 * t - 1, 0);
     v4f bq[9], kq[9];
-    bq[1] = bring[s1][lane]; bq[0] = bring[z.slot][lane]; kq[1] = ktab[st_kt<P>(r1w)]; kq[0] = ktab[st_kt<P>(r1w + 1)];
+    bq[1] = bring[s1][lane]; bq[0] = bring[z.slot][lane]; kq[1] = ktab[r1w]; kq[0] = ktab[r1w + 1];
     int kb = 0;
-    if (!P) asm volatile("v_mov_b32 %0, %1" : "=v"(kb) : "s"((2 * t - 8) * 16));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(kb) : "s"((2 * t - 8) * 16));
     // no land and no coast in any of the ten rows in flight (every step of a strip in open water): the eight levels without
     // a test or a branch between them -- one block for the scheduler; a branch per level visit costs the kernel ~3 %
     // A unit's first eight steps fill the pipeline: level S has its first rows to compute at step S.  Those steps take the
     // tested path whatever their rows are, and there a level that has nothing to do yet is skipped outright (round 3: per-step
     // clocks showed a skipped level visit costing 0.25 us through the all-land path -- as much as a real one -- and a unit's
     // eight fill steps 2.1 us each; with the skip a unit is ~7 us shorter)
-    const bool filled = P || t >= (TW ? TB_T / 2 : TB_T);
+    const bool filled = t >= (TW ? TB_T / 2 : TB_T);
     const int r0 = TW ? e0 : e0 + TB_T;                      // the unit's first output row
     if (filled && !((z.landbits | z.mixbits | special) & 0x3FFu)) {
-        st_level<1, K, P, 1, DV>(a, z, bring, cring, ktab, lane, t, e_t - 1, r0, r1, lane_ok, xcol, bq, kq, kb);
-        st_level<2, K, P, 1, DV>(a, z, bring, cring, ktab, lane, t, e_t - 2, r0, r1, lane_ok, xcol, bq, kq, kb);
-        st_level<3, K, P, 1, DV>(a, z, bring, cring, ktab, lane, t, e_t - 3, r0, r1, lane_ok, xcol, bq, kq, kb);
-        st_level<4, K, P, 1, DV>(a, z, bring, cring, ktab, lane, t, e_t - 4, r0, r1, lane_ok, xcol, bq, kq, kb);
-        st_level<5, K, P, 1, DV>(a, z, bring, cring, ktab, lane, t, e_t - 5, r0, r1, lane_ok, xcol, bq, kq, kb);
-        st_level<6, K, P, 1, DV>(a, z, bring, cring, ktab, lane, t, e_t - 6, r0, r1, lane_ok, xcol, bq, kq, kb);
-        st_level<7, K, P, 1, DV>(a, z, bring, cring, ktab, lane, t, e_t - 7, r0, r1, lane_ok, xcol, bq, kq, kb);
-        st_level<8, K, P, 1, DV>(a, z, bring, cring, ktab, lane, t, e_t - 8, r0, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<1, K, 1, DV>(a, z, bring, cring, ktab, lane, t, e_t - 1, r0, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<2, K, 1, DV>(a, z, bring, cring, ktab, lane, t, e_t - 2, r0, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<3, K, 1, DV>(a, z, bring, cring, ktab, lane, t, e_t - 3, r0, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<4, K, 1, DV>(a, z, bring, cring, ktab, lane, t, e_t - 4, r0, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<5, K, 1, DV>(a, z, bring, cring, ktab, lane, t, e_t - 5, r0, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<6, K, 1, DV>(a, z, bring, cring, ktab, lane, t, e_t - 6, r0, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<7, K, 1, DV>(a, z, bring, cring, ktab, lane, t, e_t - 7, r0, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<8, K, 1, DV>(a, z, bring, cring, ktab, lane, t, e_t - 8, r0, r1, lane_ok, xcol, bq, kq, kb);
     } else if (filled && !((z.landbits | special) & 0x3FFu)) {
         // coast among the ten rows, but no row that is land everywhere (coast rows come in long runs: 18 % of the survey
         // terrain's steps): every row through the coast formula, open rows with counts of zero -- again no test, no branch
-        st_level<1, K, P, 2, DV>(a, z, bring, cring, ktab, lane, t, e_t - 1, r0, r1, lane_ok, xcol, bq, kq, kb);
-        st_level<2, K, P, 2, DV>(a, z, bring, cring, ktab, lane, t, e_t - 2, r0, r1, lane_ok, xcol, bq, kq, kb);
-        st_level<3, K, P, 2, DV>(a, z, bring, cring, ktab, lane, t, e_t - 3, r0, r1, lane_ok, xcol, bq, kq, kb);
-        st_level<4, K, P, 2, DV>(a, z, bring, cring, ktab, lane, t, e_t - 4, r0, r1, lane_ok, xcol, bq, kq, kb);
-        st_level<5, K, P, 2, DV>(a, z, bring, cring, ktab, lane, t, e_t - 5, r0, r1, lane_ok, xcol, bq, kq, kb);
-        st_level<6, K, P, 2, DV>(a, z, bring, cring, ktab, lane, t, e_t - 6, r0, r1, lane_ok, xcol, bq, kq, kb);
-        st_level<7, K, P, 2, DV>(a, z, bring, cring, ktab, lane, t, e_t - 7, r0, r1, lane_ok, xcol, bq, kq, kb);
-        st_level<8, K, P, 2, DV>(a, z, bring, cring, ktab, lane, t, e_t - 8, r0, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<1, K, 2, DV>(a, z, bring, cring, ktab, lane, t, e_t - 1, r0, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<2, K, 2, DV>(a, z, bring, cring, ktab, lane, t, e_t - 2, r0, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<3, K, 2, DV>(a, z, bring, cring, ktab, lane, t, e_t - 3, r0, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<4, K, 2, DV>(a, z, bring, cring, ktab, lane, t, e_t - 4, r0, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<5, K, 2, DV>(a, z, bring, cring, ktab, lane, t, e_t - 5, r0, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<6, K, 2, DV>(a, z, bring, cring, ktab, lane, t, e_t - 6, r0, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<7, K, 2, DV>(a, z, bring, cring, ktab, lane, t, e_t - 7, r0, r1, lane_ok, xcol, bq, kq, kb);
+        st_level<8, K, 2, DV>(a, z, bring, cring, ktab, lane, t, e_t - 8, r0, r1, lane_ok, xcol, bq, kq, kb);
     } else if (TW) {
         st_twin_level<1, K, DV>(a, z, bring, cring, ktab, lane, t, e_t, r0, r1, lane_ok, xcol, bq, kq, kb, xme, xpeer);
         st_twin_level<2, K, DV>(a, z, bring, cring, ktab, lane, t, e_t, r0, r1, lane_ok, xcol, bq, kq, kb, xme, xpeer);
@@ -605,18 +577,18 @@ __device__ __forceinline__ void st_step(const st_args &a, st_state &z, v4f (*bri
         st_twin_level<7, K, DV>(a, z, bring, cring, ktab, lane, t, e_t, r0, r1, lane_ok, xcol, bq, kq, kb, xme, xpeer);
         st_twin_level<8, K, DV>(a, z, bring, cring, ktab, lane, t, e_t, r0, r1, lane_ok, xcol, bq, kq, kb, xme, xpeer);
     } else {
-        if (P || 1 <= t) st_level<1, K, P, 0, DV>(a, z, bring, cring, ktab, lane, t, e_t - 1, r0, r1, lane_ok, xcol, bq, kq, kb);
-        if (P || 2 <= t) st_level<2, K, P, 0, DV>(a, z, bring, cring, ktab, lane, t, e_t - 2, r0, r1, lane_ok, xcol, bq, kq, kb);
-        if (P || 3 <= t) st_level<3, K, P, 0, DV>(a, z, bring, cring, ktab, lane, t, e_t - 3, r0, r1, lane_ok, xcol, bq, kq, kb);
-        if (P || 4 <= t) st_level<4, K, P, 0, DV>(a, z, bring, cring, ktab, lane, t, e_t - 4, r0, r1, lane_ok, xcol, bq, kq, kb);
-        if (P || 5 <= t) st_level<5, K, P, 0, DV>(a, z, bring, cring, ktab, lane, t, e_t - 5, r0, r1, lane_ok, xcol, bq, kq, kb);
-        if (P || 6 <= t) st_level<6, K, P, 0, DV>(a, z, bring, cring, ktab, lane, t, e_t - 6, r0, r1, lane_ok, xcol, bq, kq, kb);
-        if (P || 7 <= t) st_level<7, K, P, 0, DV>(a, z, bring, cring, ktab, lane, t, e_t - 7, r0, r1, lane_ok, xcol, bq, kq, kb);
-        if (P || 8 <= t) st_level<8, K, P, 0, DV>(a, z, bring, cring, ktab, lane, t, e_t - 8, r0, r1, lane_ok, xcol, bq, kq, kb);
+        if (1 <= t) st_level<1, K, 0, DV>(a, z, bring, cring, ktab, lane, t, e_t - 1, r0, r1, lane_ok, xcol, bq, kq, kb);
+        if (2 <= t) st_level<2, K, 0, DV>(a, z, bring, cring, ktab, lane, t, e_t - 2, r0, r1, lane_ok, xcol, bq, kq, kb);
+        if (3 <= t) st_level<3, K, 0, DV>(a, z, bring, cring, ktab, lane, t, e_t - 3, r0, r1, lane_ok, xcol, bq, kq, kb);
+        if (4 <= t) st_level<4, K, 0, DV>(a, z, bring, cring, ktab, lane, t, e_t - 4, r0, r1, lane_ok, xcol, bq, kq, kb);
+        if (5 <= t) st_level<5, K, 0, DV>(a, z, bring, cring, ktab, lane, t, e_t - 5, r0, r1, lane_ok, xcol, bq, kq, kb);
+        if (6 <= t) st_level<6, K, 0, DV>(a, z, bring, cring, ktab, lane, t, e_t - 6, r0, r1, lane_ok, xcol, bq, kq, kb);
+        if (7 <= t) st_level<7, K, 0, DV>(a, z, bring, cring, ktab, lane, t, e_t - 7, r0, r1, lane_ok, xcol, bq, kq, kb);
+        if (8 <= t) st_level<8, K, 0, DV>(a, z, bring, cring, ktab, lane, t, e_t - 8, r0, r1, lane_ok, xcol, bq, kq, kb);
     }
     z.slot = z.slot + 2 == ST_RING ? 0 : z.slot + 2;
 #ifdef ST_EXPERIMENTS
-    if (!P && K == 0 && a.stepprof && lane == 0 && t < 40) a.stepprof[(size_t)(TW ? 2 * blockIdx.x + (threadIdx.x >> 6) : blockIdx.x) * 64 + 43 + t / 2] = __builtin_amdgcn_s_memrealtime();
+    if (K == 0 && a.stepprof && lane == 0 && t < 40) a.stepprof[(size_t)(TW ? 2 * blockIdx.x + (threadIdx.x >> 6) : blockIdx.x) * 64 + 43 + t / 2] = __builtin_amdgcn_s_memrealtime();
 #endif
 }
 
@@ -672,15 +644,15 @@ __device__ __forceinline__ void st_open_step(const st_args &a, st_state &z, v4f 
     kq[1] = ktab[max(2 * t - 1, 0)]; kq[0] = ktab[max(2 * t - 1, 0) + 1];
     unsigned (*nocring)[64] = nullptr;
     constexpr int M = PHASE == 1 ? 3 : 1;
-    if (PHASE != 0 || 1 <= t) st_level<1, K, false, M, DV>(a, z, bring, nocring, ktab, lane, t, e_t - 1, r0, r1, lane_ok, xcol, bq, kq, kb);
-    if (PHASE != 0 || 2 <= t) st_level<2, K, false, M, DV>(a, z, bring, nocring, ktab, lane, t, e_t - 2, r0, r1, lane_ok, xcol, bq, kq, kb);
-    if (PHASE != 0 || 3 <= t) st_level<3, K, false, M, DV>(a, z, bring, nocring, ktab, lane, t, e_t - 3, r0, r1, lane_ok, xcol, bq, kq, kb);
-    if (PHASE != 0 || 4 <= t) st_level<4, K, false, M, DV>(a, z, bring, nocring, ktab, lane, t, e_t - 4, r0, r1, lane_ok, xcol, bq, kq, kb);
-    if (PHASE != 0 || 5 <= t) st_level<5, K, false, M, DV>(a, z, bring, nocring, ktab, lane, t, e_t - 5, r0, r1, lane_ok, xcol, bq, kq, kb);
-    if (PHASE != 0 || 6 <= t) st_level<6, K, false, M, DV>(a, z, bring, nocring, ktab, lane, t, e_t - 6, r0, r1, lane_ok, xcol, bq, kq, kb);
-    if (PHASE != 0 || 7 <= t) st_level<7, K, false, M, DV>(a, z, bring, nocring, ktab, lane, t, e_t - 7, r0, r1, lane_ok, xcol, bq, kq, kb);
+    if (PHASE != 0 || 1 <= t) st_level<1, K, M, DV>(a, z, bring, nocring, ktab, lane, t, e_t - 1, r0, r1, lane_ok, xcol, bq, kq, kb);
+    if (PHASE != 0 || 2 <= t) st_level<2, K, M, DV>(a, z, bring, nocring, ktab, lane, t, e_t - 2, r0, r1, lane_ok, xcol, bq, kq, kb);
+    if (PHASE != 0 || 3 <= t) st_level<3, K, M, DV>(a, z, bring, nocring, ktab, lane, t, e_t - 3, r0, r1, lane_ok, xcol, bq, kq, kb);
+    if (PHASE != 0 || 4 <= t) st_level<4, K, M, DV>(a, z, bring, nocring, ktab, lane, t, e_t - 4, r0, r1, lane_ok, xcol, bq, kq, kb);
+    if (PHASE != 0 || 5 <= t) st_level<5, K, M, DV>(a, z, bring, nocring, ktab, lane, t, e_t - 5, r0, r1, lane_ok, xcol, bq, kq, kb);
+    if (PHASE != 0 || 6 <= t) st_level<6, K, M, DV>(a, z, bring, nocring, ktab, lane, t, e_t - 6, r0, r1, lane_ok, xcol, bq, kq, kb);
+    if (PHASE != 0 || 7 <= t) st_level<7, K, M, DV>(a, z, bring, nocring, ktab, lane, t, e_t - 7, r0, r1, lane_ok, xcol, bq, kq, kb);
     // (voA, voB address rows e_t + 4, e_t + 5; level 8's rows are e_t - 8, e_t - 7: sb = pout - 12 rows)
-    if (PHASE != 0) st_level<8, K, false, M, DV>(a, z, bring, nocring, ktab, lane, t, e_t - 8, r0, r1, lane_ok, xcol, bq, kq, kb, sb, voA, voB);
+    if (PHASE != 0) st_level<8, K, M, DV>(a, z, bring, nocring, ktab, lane, t, e_t - 8, r0, r1, lane_ok, xcol, bq, kq, kb, sb, voA, voB);
     z.slot = z.slot + 2 == ST_RING ? 0 : z.slot + 2;
 }
 

@@ -39,7 +39,7 @@ def test_library_exports_every_declared_symbol(built_lib):
 def test_ctypes_binding_covers_header(built_lib):
     from demiurge_amd import capi
     L = capi.lib()
-    assert L.dmg_version() == 101
+    assert L.dmg_version() == 101 == capi.VERSION
     bound = set(L._dmg_signatures)
     assert set(declared_symbols()) <= bound, set(declared_symbols()) - bound
 
