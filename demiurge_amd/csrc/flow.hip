@@ -229,31 +229,53 @@ __device__ __forceinline__ int block_append_base(int c, int *count)
 // One candidate per boundary cell s: the lowest neighbour that belongs to another catchment (:470-492).
 //   key = (dense id of the lake of s) << 32 | (dense id of the neighbouring lake)     val = (pass height bits) << 32 | s
 // heights are > 0, so their fp32 bit patterns order like the values; dense ids order like the sink cell indices.
+// Round 6: a block takes a TILE of 256 columns x FLOW_ITEMS rows, a thread one column of it, top to bottom, with the labels of its three
+// columns in the three rows around the cell in registers -- three label loads per cell, the left and right ones out of the L1, instead
+// of nine from wherever the neighbouring rows' blocks had left them; and no integer division: the first version turned every cell's
+// index back into (x, y) with a 64-bit `%` and `/` and wrapped each of its eight neighbours with a 32-bit `%` -- ~400 instructions of
+// division per cell for a kernel that reads 12 bytes of it (5.7 ms at 16384 x 8192, profiles/r05_world_kernels.txt).
 __global__ __launch_bounds__(256) void k_flow_passes(flow_canvas fc, const float *__restrict__ h, const int *__restrict__ label, const int *__restrict__ dense,
                                                      const unsigned short *__restrict__ mask, unsigned long long *__restrict__ key,
                                                      unsigned long long *__restrict__ val, int *__restrict__ count, int cap)
 {
     const int W = fc.c.W, H = fc.c.H;
-    const size_t N = (size_t)W * H;
     int found[FLOW_ITEMS];                              // the neighbour cell the pass leads to, or -1
     float pass[FLOW_ITEMS];
     int c = 0;
+    const int x0 = (int)blockIdx.x * 256 + (int)threadIdx.x, yb = (int)blockIdx.y * FLOW_ITEMS;
+    const bool col_ok = x0 < W;
+    // the three columns: the cell's own, its western and its eastern neighbour's (wrapped, or absent: -1)
+    int xw = x0 - 1, xe = x0 + 1;
+    if (fc.wrap) { if (xw < 0) xw += W; if (xe >= W) xe -= W; }
+    else { if (xe >= W) xe = -1; }
+    auto row3 = [&](int y, int &lw, int &lc, int &le) {   // labels of row y at the three columns; -1 outside the canvas
+        lw = lc = le = -1;
+        if (col_ok && y >= 0 && y < H) {
+            const int *r = label + (size_t)y * W;
+            lc = r[x0];
+            if (xw >= 0) lw = r[xw];
+            if (xe >= 0) le = r[xe];
+        }
+    };
+    int aw, ac, ae, bw, bc, be, nw, nc, ne;              // rows y - 1, y, y + 1
+    row3(yb - 1, aw, ac, ae);
+    row3(yb, bw, bc, be);
 #pragma unroll
     for (int t = 0; t < FLOW_ITEMS; t++) {
-        const size_t i = ((size_t)blockIdx.x * FLOW_ITEMS + t) * 256 + threadIdx.x;
-        const int lake = i < N ? label[i] : -1;
+        const int y0 = yb + t;
+        row3(y0 + 1, nw, nc, ne);
+        const int lake = bc;                            // (-1: not a cell of the canvas, or no lake)
         float minpass = INFINITY;
         int nlake = -1;
         if (lake >= 0) {
-            const int x0 = (int)(i % W), y0 = (int)(i / W);
+            // FlowFilter::neighbours order (keypad 1,2,3,4,6,7,8,9 = (dx,dy): row y-1 west..east, row y west, east, row y+1 west..east);
+            // strict '<' keeps the first
+            const int ln[8] = { aw, ac, ae, bw, be, nw, nc, ne };
+            const int nx[8] = { xw, x0, xe, xw, xe, xw, x0, xe };
 #pragma unroll
-            for (int k = 0; k < 8; k++) {               // FlowFilter::neighbours order, strict '<' keeps the first
-                int x = x0 + c_ndx[k], y = y0 + c_ndy[k];
-                if (fc.wrap) x = (x + W) % W; else if (x < 0 || x >= W) continue;
-                if (y < 0 || y >= H) continue;
-                const int n = y * W + x;
-                const int ln = label[n];
-                if (ln < 0 || ln == lake) continue;     // the adjacency pass: another lake's id (:417-439)
+            for (int k = 0; k < 8; k++) {
+                if (ln[k] < 0 || ln[k] == lake) continue;   // the adjacency pass: another lake's id (:417-439)
+                const int n = (y0 + c_ndy[k]) * W + nx[k];
                 const float bd = h[n];
                 if (bd > 0.0f && bd < minpass) { minpass = bd; nlake = n; }     // :476-481
             }
@@ -261,12 +283,13 @@ __global__ __launch_bounds__(256) void k_flow_passes(flow_canvas fc, const float
         if (nlake >= 0 && (mask[label[nlake]] & 512u)) nlake = -1;             // never towards a river-mouth lake (:484)
         found[t] = nlake; pass[t] = minpass;
         c += nlake >= 0;
+        aw = bw; ac = bc; ae = be; bw = nw; bc = nc; be = ne;
     }
     int slot = block_append_base(c, count);             // (the order of the candidates does not matter: they are sorted next)
 #pragma unroll
     for (int t = 0; t < FLOW_ITEMS; t++) {
         if (found[t] < 0) continue;
-        const size_t i = ((size_t)blockIdx.x * FLOW_ITEMS + t) * 256 + threadIdx.x;
+        const size_t i = (size_t)(yb + t) * W + x0;
         if (slot < cap) {
             key[slot] = ((unsigned long long)(unsigned)dense[label[i]] << 32) | (unsigned)dense[label[found[t]]];
             val[slot] = ((unsigned long long)__float_as_uint(fmaxf(pass[t], h[i])) << 32) | (unsigned)i;
@@ -853,8 +876,9 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
     DMG_ALLOC_VAR(k0, (size_t)cap * 8); DMG_ALLOC_VAR(v0, (size_t)cap * 8); DMG_ALLOC_VAR(k1, (size_t)cap * 8); DMG_ALLOC_VAR(v1, (size_t)cap * 8);
     DMG_ALLOC(nsel, 8);
     DMG_HIP(hipMemsetAsync(count.p, 0, 4, st));
-    const unsigned nbi = (unsigned)((N + (size_t)256 * FLOW_ITEMS - 1) / ((size_t)256 * FLOW_ITEMS));     // blocks of FLOW_ITEMS x 256 cells
-    hipLaunchKernelGGL(k_flow_passes, dim3(nbi), dim3(256), 0, st, fc, d_h, label.i(), dense.i(), (const unsigned short *)mask.p,
+    const unsigned nbi = (unsigned)((N + (size_t)256 * FLOW_ITEMS - 1) / ((size_t)256 * FLOW_ITEMS));     // blocks of FLOW_ITEMS x 256 cells (k_flow_mouths, k_flow_gdepth)
+    hipLaunchKernelGGL(k_flow_passes, dim3((unsigned)((W + 255) / 256), (unsigned)((H + FLOW_ITEMS - 1) / FLOW_ITEMS)), dim3(256), 0, st, fc, d_h,    // tiles of 256 x FLOW_ITEMS cells
+                       label.i(), dense.i(), (const unsigned short *)mask.p,
                        (unsigned long long *)k0.p, (unsigned long long *)v0.p, count.i(), cap);
     DMG_HIP(hipGetLastError());
     int ncand = 0;

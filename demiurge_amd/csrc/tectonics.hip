@@ -102,6 +102,18 @@ __device__ __forceinline__ void t_rotate_st(const canvas &c, const mat3 &R, floa
     *v = (lat2 - c.c0) / (c.c1 - c.c0);
 }
 
+// the same from the sines and cosines of lat and lon (the per-row / per-column tables below)
+__device__ __forceinline__ void t_rotate_cs(const canvas &c, const mat3 &R, float sl, float cl, float so, float co, float *u, float *v)
+{
+    float cx = cl * co, cy = cl * so, cz = sl;
+    float rx = R.m[0] * cx + R.m[3] * cy + R.m[6] * cz;
+    float ry = R.m[1] * cx + R.m[4] * cy + R.m[7] * cz;
+    float rz = R.m[2] * cx + R.m[5] * cy + R.m[8] * cz;
+    float lon2 = t_atan2(ry, rx), lat2 = t_asin(rz);
+    *u = (lon2 - c.c2) / (c.c3 - c.c2);
+    *v = (lat2 - c.c0) / (c.c1 - c.c0);
+}
+
 // geodistance(p1, p2, size) (Shader.h:349-354); pow(x,2) is x*x
 __device__ __forceinline__ float t_geodistance(const canvas &c, float p1x, float p1y, float p2x, float p2y, float sizex)
 {
@@ -133,18 +145,42 @@ struct fold_args {
     mat3 rot[TECT_MAX_PLATES];
 };
 
+// The rotated gathers of fold and unfold are done by TILES of TT_W x TT_H texels per workgroup (round 6).  A workgroup of 256
+// texels of ONE row reads a one-texel-wide curve through the other frame: every 16-byte texel it fetches pulls in a cache line of which
+// its row has no further use -- 9.8 GB moved for 2.15 GB of unavoidable traffic at 16384 x 8192 (profiles/r04_kernel_counters.txt: 4.6 x).
+// A tile's image under a rotation is a compact patch: the lines it pulls in are used by its other rows.
+#ifndef TT_W
+#define TT_W 32
+#define TT_H 8
+#endif
+static_assert(TT_W * TT_H == 256, "a tile is one workgroup of 256 threads");
+
+// Round 6: fold and unfold are bound by their vector instructions (~380 per map texel: two sine / cosine pairs, then per plate a
+// rotation, an arctangent, an arcsine, two IEEE divisions), not by their gathers -- tiling them took nothing off fold's 3.0 ms at
+// 16384 x 8192.  The sine and cosine of a texel's longitude depend on its column alone and those of its latitude on its row:
+// k_tect_trig evaluates them once per column and per row -- the same statements on the same operands, so the same bits -- and the
+// kernels read two 8-byte entries instead of running ~120 instructions.  which 0: (sin, cos) of tex_to_spheric's lon for
+// st.x = (i + 0.5) / n; 1: of its lat for st.y = (i + 0.5) / n.
+__global__ void k_tect_trig(canvas c, int n, int which, float2 *out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float s = ((float)i + 0.5f) / (float)n;
+    float lon, lat, sn, cs;
+    t_spheric(c, s, s, &lon, &lat);
+    t_sincos(which ? lat : lon, &sn, &cs);
+    out[i] = make_float2(sn, cs);
+}
+
 // Tectonics::fold (:278-293) = setzero (:99-106) then the fold shader (:112-149) once per plate, in registers
 __global__ void __launch_bounds__(256) k_tect_fold(canvas c, fold_args A, float4 *map, int S, int zero_z,
-                                                   unsigned *count, unsigned *active)
+                                                   unsigned *count, unsigned *active, const float2 *__restrict__ trig_lon,
+                                                   const float2 *__restrict__ trig_lat)
 {
-    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= S) return;
-    float sx = ((float)x + 0.5f) / (float)S, sy = ((float)y + 0.5f) / (float)S;
-    float lon, lat;
-    t_spheric(c, sx, sy, &lon, &lat);
-    float sl, cl, so, co;
-    t_sincos(lat, &sl, &cl);
-    t_sincos(lon, &so, &co);
+    int x = blockIdx.x * TT_W + (int)(threadIdx.x % TT_W), y = blockIdx.y * TT_H + (int)(threadIdx.x / TT_W);
+    if (x >= S || y >= S) return;
+    const float2 tl = trig_lat[y], to = trig_lon[x];
+    const float sl = tl.x, cl = tl.y, so = to.x, co = to.y;
     float cx = cl * co, cy = cl * so, cz = sl;
     float4 fc = make_float4(0.0f, -1.0f, -1.0f, -1.1e6f);          // plate id, height, age, collision
     for (int k = 0; k < A.n; k++) {
@@ -228,14 +264,18 @@ __global__ void k_tect_ring_scatter(float4 *__restrict__ map, const unsigned *__
 
 // back to plates (:216-251)
 __global__ void __launch_bounds__(256) k_tect_unfold(canvas c, const float4 *__restrict__ map, int S, ctex4 old, mat3 inv,
-                                                     float index, float4 *__restrict__ out, int w, int h)
+                                                     float index, float4 *__restrict__ out, int w, int h,
+                                                     const float2 *__restrict__ trig_lon, const float2 *__restrict__ trig_lat)
 {
-    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= w) return;
+    int x = blockIdx.x * TT_W + (int)(threadIdx.x % TT_W), y = blockIdx.y * TT_H + (int)(threadIdx.x / TT_W);
+    if (x >= w || y >= h) return;
     float sx = ((float)x + 0.5f) / (float)w, sy = ((float)y + 0.5f) / (float)h;
     float lon, phi, u, v;
     t_spheric(c, sx, sy, &lon, &phi);
-    t_rotate_st(c, inv, lon, phi, &u, &v);
+    {
+        const float2 tl = trig_lat[y], to = trig_lon[x];        // (sin, cos) of phi and lon: the row's and the column's
+        t_rotate_cs(c, inv, tl.x, tl.y, to.x, to.y, &u, &v);
+    }
     float4 a = t_fetch(map, S, S, u, v);
     float4 fc = t_fetch(old.p, old.w, old.h, sx, sy);
     if (fc.y >= 0.0f) fc.y += 0.01f;                               // increment age
@@ -311,6 +351,10 @@ struct dmg_tectonics {
     unsigned *count = nullptr;
     bool z_is_age = false;                       // map[cur] still carries the plate age in z (fold called on its own)
     long steps_done = 0;
+    // (sin, cos) per column of a texture S wide, per row of one S high and of one H high (k_tect_trig): the storage shuffle
+    // (c <-> plate) only ever makes textures of S x S and S x H
+    float2 *trig_lon = nullptr, *trig_lat_S = nullptr, *trig_lat_H = nullptr;
+    const float2 *trig_lat(int h) const { return h == S ? trig_lat_S : trig_lat_H; }
 };
 
 static mat3 plate_mat3(const dmg_tectonics *t, int k, bool transpose)
@@ -323,6 +367,7 @@ static mat3 plate_mat3(const dmg_tectonics *t, int k, bool transpose)
 }
 
 static dim3 grid_for(int w, int h) { return dim3((unsigned)((w + 255) / 256), (unsigned)h); }
+static dim3 grid_tiles(int w, int h) { return dim3((unsigned)((w + TT_W - 1) / TT_W), (unsigned)((h + TT_H - 1) / TT_H)); }
 
 extern "C" {
 
@@ -349,6 +394,9 @@ int dmg_tectonics_create(dmg_ctx *ctx, const dmg_grid *grid, const float *terrai
     if (e == hipSuccess) e = hipMalloc((void **)&t->terrain, (size_t)grid->W * grid->H * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void **)&t->ring, sizeof(ring_table));
     if (e == hipSuccess) e = hipMalloc((void **)&t->active, (size_t)t->S * t->S * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMalloc((void **)&t->trig_lon, (size_t)t->S * sizeof(float2));
+    if (e == hipSuccess) e = hipMalloc((void **)&t->trig_lat_S, (size_t)t->S * sizeof(float2));
+    if (e == hipSuccess) e = hipMalloc((void **)&t->trig_lat_H, (size_t)grid->H * sizeof(float2));
     if (e == hipSuccess) e = hipMalloc((void **)&t->count, sizeof(unsigned));
     if (e != hipSuccess) {
         dmg_tectonics_destroy(t);
@@ -367,6 +415,9 @@ int dmg_tectonics_create(dmg_ctx *ctx, const dmg_grid *grid, const float *terrai
         hipLaunchKernelGGL(k_tect_init, grid_for(grid->W, grid->H), dim3(256), 0, ctx->stream, t->cv, t->terrain,
                            t->plate[0], t->plate[1]);
         hipLaunchKernelGGL(k_tect_ring_table, dim3(1), dim3(64), 0, ctx->stream, t->ring);
+        hipLaunchKernelGGL(k_tect_trig, dim3((unsigned)((t->S + 255) / 256)), dim3(256), 0, ctx->stream, t->cv, t->S, 0, t->trig_lon);
+        hipLaunchKernelGGL(k_tect_trig, dim3((unsigned)((t->S + 255) / 256)), dim3(256), 0, ctx->stream, t->cv, t->S, 1, t->trig_lat_S);
+        hipLaunchKernelGGL(k_tect_trig, dim3((unsigned)((grid->H + 255) / 256)), dim3(256), 0, ctx->stream, t->cv, grid->H, 1, t->trig_lat_H);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);                   // `terrain` is the caller's buffer
@@ -390,6 +441,7 @@ void dmg_tectonics_destroy(dmg_tectonics *t)
     if (t->ring) (void)hipFree(t->ring);
     if (t->active) (void)hipFree(t->active);
     if (t->count) (void)hipFree(t->count);
+    for (void *q : { (void *)t->trig_lon, (void *)t->trig_lat_S, (void *)t->trig_lat_H }) if (q) (void)hipFree(q);
     dmg_ctx *ctx = t->ctx;
     delete t;
     dmg_ctx_release(ctx);
@@ -416,8 +468,8 @@ static int tect_fold(dmg_tectonics *t, bool zero_z)
         A.rot[k] = plate_mat3(t, k, false);
     }
     DMG_HIP(hipMemsetAsync(t->count, 0, sizeof(unsigned), t->ctx->stream));
-    hipLaunchKernelGGL(k_tect_fold, grid_for(t->S, t->S), dim3(256), 0, t->ctx->stream, t->cv, A, t->map[t->cur], t->S,
-                       zero_z ? 1 : 0, t->count, t->active);
+    hipLaunchKernelGGL(k_tect_fold, grid_tiles(t->S, t->S), dim3(256), 0, t->ctx->stream, t->cv, A, t->map[t->cur], t->S,
+                       zero_z ? 1 : 0, t->count, t->active, t->trig_lon, t->trig_lat_S);
     DMG_HIP(hipGetLastError());
     t->z_is_age = !zero_z;
     return DMG_OK;
@@ -459,9 +511,9 @@ int dmg_tectonics_unfold(dmg_tectonics *t)
         std::swap(t->cbuf, t->plate[k]);                                         // c->swap(plate->getTexture()), :260
         std::swap(t->c_w, t->pw[k]);
         std::swap(t->c_h, t->ph[k]);
-        hipLaunchKernelGGL(k_tect_unfold, grid_for(t->pw[k], t->ph[k]), dim3(256), 0, t->ctx->stream, t->cv,
+        hipLaunchKernelGGL(k_tect_unfold, grid_tiles(t->pw[k], t->ph[k]), dim3(256), 0, t->ctx->stream, t->cv,
                            t->map[t->cur], t->S, ctex4{ t->cbuf, t->c_w, t->c_h }, plate_mat3(t, k, true), (float)(k + 1),
-                           t->plate[k], t->pw[k], t->ph[k]);
+                           t->plate[k], t->pw[k], t->ph[k], t->trig_lon, t->trig_lat(t->ph[k]));
     }
     DMG_HIP(hipGetLastError());
     t->steps_done++;
