@@ -822,6 +822,35 @@ int orc_blur_rlist(float radius, float *rlist, int cap)
     return n;
 }
 
+/* what a "per-row weights" rendering of the blur would differ by.  The literal shader reaches a tap through
+ * offset() in fp32 texture coordinates: st.x + off.x / W carries ~W * 2^-24 texels of rounding noise, so a tap meant to sit ON a
+ * texel centre across the pass's axis blends in ~1e-3 (W = 16384) of the neighbouring column, and the weights along the axis move
+ * by as much from cell to cell.  orc_set_blur_clean(1) evaluates every tap at the position the arithmetic MEANS -- the fractional
+ * part of the offset itself (one pair of weights per row and tap), exactly on the centre across the axis -- by moving the literal
+ * coordinate to the nearest such position; tools/blur_tolerance_eval.py measures the difference. */
+static int g_blur_clean = 0;
+void orc_set_blur_clean(int on) { g_blur_clean = on; }
+static inline float blur_clean_coord(float u, int n, float off_texels)
+{
+    const double fu = (double)u * n - 0.5, f = fabs((double)off_texels) - floor(fabs((double)off_texels));
+    const double base = floor(fu);
+    double best = fu, bd = 1e9;
+    for (int k = -1; k <= 1; k++)
+        for (int s = 0; s < 2; s++) {
+            const double c = base + k + (s ? 1.0 - f : f);
+            if (fabs(c - fu) < bd) { bd = fabs(c - fu); best = c; }
+        }
+    return (float)((best + 0.5) / n);
+}
+static inline float blur_tap(const orc_grid *g, const float *src, float sx, float sy, float ox, float oy)
+{
+    const int W = g->W, H = g->H;
+    float px, py;
+    orc_offset(g, sx, sy, ox, oy, (float)W, (float)H, &px, &py);
+    if (g_blur_clean) { px = blur_clean_coord(px, W, ox); py = blur_clean_coord(py, H, oy); }
+    return fetch_linear(src, W, H, 1, 0, px, py);
+}
+
 /* blur13 :41-62; image is GL_LINEAR (:29-30): genuine bilinear taps at fractional offsets */
 void orc_blur13_pass(const orc_grid *g, const float *src, float dirx, float diry, float *dst)
 {
@@ -845,14 +874,15 @@ void orc_blur13_pass(const orc_grid *g, const float *src, float dirx, float diry
                 phifactor = gcos(fabsf(lat));
                 o1x = k1 * dirx / phifactor; o2x = k2 * dirx / phifactor; o3x = k3 * dirx / phifactor;
             }
-            float color = 0.0f, px, py;
+            float color = 0.0f;
+            (void)rx; (void)ry;
             color += fetch_linear(src, W, H, 1, 0, sx, sy) * w0;
-            orc_offset(g, sx, sy, o1x, o1y, rx, ry, &px, &py);   color += fetch_linear(src, W, H, 1, 0, px, py) * w1;
-            orc_offset(g, sx, sy, -o1x, -o1y, rx, ry, &px, &py); color += fetch_linear(src, W, H, 1, 0, px, py) * w1;
-            orc_offset(g, sx, sy, o2x, o2y, rx, ry, &px, &py);   color += fetch_linear(src, W, H, 1, 0, px, py) * w2;
-            orc_offset(g, sx, sy, -o2x, -o2y, rx, ry, &px, &py); color += fetch_linear(src, W, H, 1, 0, px, py) * w2;
-            orc_offset(g, sx, sy, o3x, o3y, rx, ry, &px, &py);   color += fetch_linear(src, W, H, 1, 0, px, py) * w3;
-            orc_offset(g, sx, sy, -o3x, -o3y, rx, ry, &px, &py); color += fetch_linear(src, W, H, 1, 0, px, py) * w3;
+            color += blur_tap(g, src, sx, sy, o1x, o1y) * w1;
+            color += blur_tap(g, src, sx, sy, -o1x, -o1y) * w1;
+            color += blur_tap(g, src, sx, sy, o2x, o2y) * w2;
+            color += blur_tap(g, src, sx, sy, -o2x, -o2y) * w2;
+            color += blur_tap(g, src, sx, sy, o3x, o3y) * w3;
+            color += blur_tap(g, src, sx, sy, -o3x, -o3y) * w3;
             dst[(size_t)y * W + x] = color;
         }
     }
