@@ -225,6 +225,8 @@ __global__ __launch_bounds__(128, 2) void k_jacobi_stream_twin(st_args a_up, st_
     // 80.5 -> 78.3 (same-box A/B of two builds; turns every step: the same; every other iteration: nothing)
     const int wslot = __builtin_amdgcn_readfirstlane((int)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (3 << 11))) & 1;
 #endif
+    // (Round 6, measured and dropped: starting the wave in a SIMD's second slot 1000 .. 6400 clocks late, so that the two are out of
+    // phase -- one takes its rows in while the other runs its levels: the 8-way bands 51.5 -> 51.8 / 53.3 / 54.1 us; the delay is just lost.)
     for (int t = 0; t < nsteps; t += 2) {
 #if ST_TWIN_FAIR == 4
         if (wslot) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);

@@ -10,6 +10,9 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import numpy as np
 import pytest
 
+# the tests are the harness: their child processes (workers, `python -c` probes) hand DMG_* hooks to the library too (capi._is_harness)
+os.environ.setdefault("DMG_TEST_HOOKS", "1")
+
 # torch bundles its own libamdhip64; it must be loaded BEFORE libdemiurge_hip.so so that both resolve to ONE HIP
 # runtime in this process (loading /opt/rocm's first leaves torch unable to see the GPU: "No HIP GPUs are available")
 try:

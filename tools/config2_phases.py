@@ -14,7 +14,7 @@ h = (synth.terrain(W, H) * 100 + synth.lcg_uniform(W * H, 5).reshape(H, W) * 3).
 ctx.erosion_run(g, h, 50, 1, 0.5, 1.0, 1.0)
 t0 = time.perf_counter(); ctx.erosion_run(g, h, 50, %d, 0.5, 1.0, 1.0); print('TOTAL %%.3f' %% (time.perf_counter() - t0))
 """ % n
-env = dict(os.environ, DMG_FLOW_TIMING="1")
+env = dict(os.environ, DMG_FLOW_TIMING="1", DMG_TEST_HOOKS="1")
 r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
 out = r.stdout + r.stderr
 tot = collections.OrderedDict()
