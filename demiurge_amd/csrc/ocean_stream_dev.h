@@ -258,7 +258,7 @@ __device__ __forceinline__ v4f st_row_any(const v4f N, const v4f C, const v4f S,
 
 // one level: sweep S of rows yA = e0 + 2t - S and yB = yA + 1 from level S-1's rows yA-1 .. yB+1 (the pair made one step ago
 // and the pair made in this step); K = t mod 2
-// MODE 4, 5 (the deep form's front wave, ocean_jacobi_deep.hip): as 1 / 0, but level 8's rows go, in pair order and whatever they
+// MODE 4, 5, 6 (the deep form's front wave, ocean_jacobi_deep.hip): as 1 / 0 / 2, but level 8's rows go, in pair order and whatever they
 // are, into the LDS slots `xout` for the back wave instead of to memory
 // MODE 0: the pair's rows as their classes say (tests and branches); 1: both open water; 2: both through the coast formula;
 // 3: both open water and known to be rows the unit writes (st_open_unit): level 8 stores them through a scalar base and the
@@ -292,7 +292,7 @@ __device__ __forceinline__ void st_level(const st_args &a, st_state &z, v4f (*br
     const v4f S0 = z.w[S - 1][K ^ 1][0], C0 = z.w[S - 1][K ^ 1][1], N0 = z.w[S - 1][K][0], N1 = z.w[S - 1][K][1];
     v4f oA, oB;
     unsigned landA = 0, landB = 0;
-    if (MODE == 2) {
+    if (MODE == 2 || MODE == 6) {
         const int sa = st_wrap(z.slot - S), sb = sa + 1 == ST_RING ? 0 : sa + 1;
         oA = st_row_any<DV>(N0, C0, S0, bA, kA, z.cy, z.ry, true, cring[sa], lane);
         oB = st_row_any<DV>(N1, N0, C0, bB, kB, z.cy, z.ry, true, cring[sb], lane);
@@ -321,7 +321,7 @@ __device__ __forceinline__ void st_level(const st_args &a, st_state &z, v4f (*br
         }
     }
     if (S < 8) { z.w[S & 7][K][0] = oA; z.w[S & 7][K][1] = oB; }
-    else if (MODE == 4 || MODE == 5) { xout[0][lane] = oA; xout[1][lane] = oB; }
+    else if (MODE == 4 || MODE == 5 || MODE == 6) { xout[0][lane] = oA; xout[1][lane] = oB; }
     else if (MODE == 3) {
         // (a use outside the branch: left alone, the compiler sinks all of level 8 into the `lane_ok` region, where its
         // neighbour-lane adds no longer fuse with their DPP moves)

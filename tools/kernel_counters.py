@@ -22,8 +22,15 @@ kernels = [  # substring, what, unavoidable bytes per cell and launch
     ("k_blur13_axis<1>", "blur13 y", 8),
     ("k_flow_direction", "flow direction", 5),
     ("k_flow_jump", "pointer jumping", 16),
-    ("k_tect_fold", "tectonics fold", 16),
-    ("k_tect_unfold", "tectonics unfold", 32),
+    ("k_blur13_axis2<0>", "blur13 x", 8),
+    ("k_blur13_axis2<1>", "blur13 y", 8),
+    ("k_flow_passes", "flow: pass candidates", 12),
+    # (round 6: the map is W x W texels of 16 B -- two per cell of the W x H canvas: written once = 32 B per cell -- and each of the
+    # two plates' 16-byte texels is gathered about once = 32 B; round 4's 16 B per cell made the fold look 4.6 x over its bytes)
+    ("k_tect_fold", "tectonics fold", 64),
+    # per plate: the old plate read, the new one written, one gather of the map per texel (a plate is W x H, or W x W in one launch of three)
+    ("k_tect_unfold", "tectonics unfold", 48),
+    ("k_tect_ring_gather", "ocean spreading, one ring pass", 0.5),
 ]
 def pmc(sub):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))

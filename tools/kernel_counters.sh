@@ -3,7 +3,7 @@
 # (separate passes: --pmc never next to --stats; the program directly after --)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=/root/repo
-TAG=${TAG:-r05}
+TAG=${TAG:-r06}
 D=$R/gpurun_out/${TAG}_kc
 rm -rf $D; mkdir -p $D
 cd $R

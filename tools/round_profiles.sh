@@ -1,7 +1,7 @@
 # the evidence set of a round: run on the GPU box (gpurun -- 'bash tools/round_profiles.sh'), then copy what is to be judged
 # from gpurun_out/ into profiles/.  R = round tag.
 set -o pipefail
-R=${R:-r05}
+R=${R:-r06}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 # PART=tests: the GPU test suite alone (a gpurun call is at most 1200 s); PART=twin: the twin units' A/B; PART=profiles (default): everything else
 if [ "${PART:-profiles}" = tests ]; then
@@ -32,7 +32,7 @@ for h in 8192 4096 2048 1024; do python bench.py --height $h --steps 2 --warmup 
 python tools/config_lines.py > gpurun_out/${R}_config_lines.jsonl 2> gpurun_out/${R}_config_lines.err; tail -4 gpurun_out/${R}_config_lines.jsonl | cut -c1-200
 DMG_FLOW_TIMING=1 python tools/flow_timing.py > gpurun_out/${R}_flow_timing.log 2>&1; tail -13 gpurun_out/${R}_flow_timing.log
 python tools/config2_phases.py 1000 > gpurun_out/${R}_config2_phases.log 2>&1; cat gpurun_out/${R}_config2_phases.log
-for n in 8 4 2; do python tools/band_probe.py $n 32 2>&1 | grep bands; done > gpurun_out/${R}_band_probe.log; cat gpurun_out/${R}_band_probe.log
+python tools/band_probe.py 8 4 2 --split 2>&1 | grep bands > gpurun_out/${R}_band_probe.log; cat gpurun_out/${R}_band_probe.log
 timeout -k 10 300 python tools/bands_one_gpu.py 1600 loopback > gpurun_out/${R}_bands_one_gpu_loopback.log 2>&1; grep bands gpurun_out/${R}_bands_one_gpu_loopback.log
 timeout -k 10 300 python tools/bands_one_gpu.py 1600 store > gpurun_out/${R}_bands_one_gpu_store.log 2>&1; grep bands gpurun_out/${R}_bands_one_gpu_store.log
 timeout -k 10 300 python tools/bands_one_gpu.py 1600 peer > gpurun_out/${R}_bands_one_gpu_peer.log 2>&1; grep bands gpurun_out/${R}_bands_one_gpu_peer.log
