@@ -300,7 +300,7 @@ void dmg_ocean_destroy(dmg_ocean *o)
     (void)hipSetDevice(o->ctx->device);
     (void)hipStreamSynchronize(o->ctx->stream);
     for (void *p : { (void *)o->p[0], (void *)o->p[1], (void *)o->divw, (void *)o->img, (void *)o->code, (void *)o->code8,
-                     (void *)o->v[0], (void *)o->v[1], (void *)o->rowtab, (void *)o->jcoef, (void *)o->jcoefp, (void *)o->jcoef2, (void *)o->jcoef3, (void *)o->rowbad, (void *)o->oob_flag, (void *)o->rowclass, (void *)o->vadv })
+                     (void *)o->v[0], (void *)o->v[1], (void *)o->rowtab, (void *)o->jcoef, (void *)o->jcoefp, (void *)o->jcoef2, (void *)o->jcoef3, (void *)o->rowbad, (void *)o->oob_flag, (void *)o->rowclass, (void *)o->vadv, (void *)o->deep_err })
         if (p) (void)hipFree(p);
     ocean_tb_free_lists(o);
     if (o->ev_fork) (void)hipEventDestroy(o->ev_fork);
@@ -384,7 +384,18 @@ int dmg_ocean_jacobi_sweeps(dmg_ocean *o, int n)
     // the region shrinks by one row per sweep on every side that has a neighbour band
     if (blocked) {
         static const int cap = [] { const char *e = dmg_hook("DMG_TB_SWEEPS"); int v = e ? atoi(e) : 8; return v >= 1 && v <= 8 ? v : 8; }();
+        // the deep form (16 sweeps per trip through HBM) where it pays: the tolerance rendering (ocean_jacobi_deep.hip)
+        const bool deep = cap == 8 && ocean_deep_enabled(o);
         for (int k = 0; k < n;) {
+            if (deep && n - k >= 16) {
+                k += 16;
+                int lo = o->gs ? k : 0, hi = o->L - (o->gn ? k : 0);
+                int rc = ocean_launch_deep(o, lo, hi, o->cur, o->ctx->stream);
+                if (rc) return rc;
+                o->cur ^= 1;
+                o->n_launches++; o->n_sweeps += 16;
+                continue;
+            }
             int m = n - k < cap ? n - k : cap;   // DMG_TB_SWEEPS (1..8): sweeps per launch, for phase-cost experiments
             k += m;
             int lo = o->gs ? k : 0, hi = o->L - (o->gn ? k : 0);
@@ -393,7 +404,7 @@ int dmg_ocean_jacobi_sweeps(dmg_ocean *o, int n)
             o->cur ^= 1;
             o->n_launches++; o->n_sweeps += m;
         }
-        return DMG_OK;
+        return DMG_OK;                                   // (the deep form's error word is looked at where results leave the device: dmg_ocean_get)
     }
     for (int k = 1; k <= n; k++) {
         int lo = o->gs ? k : 0, hi = o->L - (o->gn ? k : 0);
@@ -626,6 +637,7 @@ int dmg_ocean_get(dmg_ocean *o, float *vx, float *vy, float *pressure, float *di
     int rc;
     if (pressure && (rc = no_pending(o, "dmg_ocean_get(pressure)"))) return rc;
     if (pressure && (rc = ocean_download_rows(o, pressure, o->p[o->cur], 1))) return rc;
+    if ((rc = ocean_deep_check(o, o->ctx->stream))) return rc;         // (no deep launch so far: nothing to look at)
     if (divw && (rc = ocean_download_rows(o, divw, o->divw, 1))) return rc;
     if (vx || vy) {
         size_t own = (size_t)(o->y1 - o->y0) * o->grid.W;

@@ -80,6 +80,9 @@ struct dmg_ocean {
     float *jcoefp = nullptr;       // [L + 32][4] = cx, 1/cx, Beta, 1/Beta of local rows -16 .. L+15, rows beyond the grid mirrored (scalar loads, no mapping)
     float *jcoef = nullptr;        // [L][8] = cx, 1/cx, Beta, 1/Beta, cy, 1/cy, -, -: a row's Jacobi coefficients in one 16-byte load (ocean_jacobi_stream.hip)
     float *jcoef2 = nullptr;       // [L][8] = the same rows as exact two-operation divisors: (h, l) of cx, of Beta, of cy with x / c == fma(x, h, x * l) (div2.hip)
+    unsigned char *rowclass_d = nullptr;       // the deep form's strips (224 columns written, 16 of halo): their class table, per terrain (ocean_jacobi_deep.hip)
+    std::vector<unsigned char> rowclass_d_host;
+    unsigned *deep_err = nullptr;              // the deep form's error word (a wave gave up waiting for its partner)
     float *jcoef3 = nullptr;       // [L][8] = ah, bh, c, e: the tolerance rendering's fused coefficients (ocean_tables.hip; DMG_QUIRK_JACOBI_TOLERANCE)
     // the streaming kernel's mirrored view of the band (units that stream southwards): the row tables reversed, built on first use
     float *jcoef_f = nullptr, *jcoef2_f = nullptr, *jcoef3_f = nullptr;
@@ -118,6 +121,10 @@ int ocean_tb_tile_rows(dmg_ocean *o, int lo, int hi);    // output rows per tile
 // (variant: unused since round 5 retired the narrow and the persistent form)
 int ocean_launch_stream(dmg_ocean *o, int lo, int hi, int part, int zone_lo, int zone_hi, int from, hipStream_t st, int seg = 0, int variant = -1);
 bool ocean_stream_enabled();
+// ocean_jacobi_deep.hip: 16 sweeps over local rows [lo, hi) by the deep form (two waves per unit, half the HBM bytes per sweep)
+bool ocean_deep_enabled(const dmg_ocean *o);
+int ocean_launch_deep(dmg_ocean *o, int lo, int hi, int from, hipStream_t st);
+int ocean_deep_check(dmg_ocean *o, hipStream_t st);
 int ocean_launch_diffusion_tb(dmg_ocean *o, int lo, int hi, int n);   // ocean_diffusion_tb.hip: n (1..8) sweeps over local rows [lo, hi)
 int ocean_launch_literal(dmg_ocean *o);          // ocean_jacobi_literal.hip: one per-fragment sweep as llvmpipe evaluates the shader
 bool ocean_tb_supported(const dmg_ocean *o);

@@ -24,40 +24,6 @@
 // 3.959 / 3.970 M (+0.8 %), all-ocean 2.933 / 2.943 -> 2.997 / 2.998 M (+2.0 %), 16384x2048 +0.5 / +1.5 %, a 16384x1024 band
 // +0.2 % / within its noise (the middle band of an 8-way split with its ghost rows: 59.8 -> 59.3 us per launch).  Small, never a
 // loss: the default.  What it says about the small band: its 36 % of re-read halo rows are not what it waits for.
-// A unit's tables: the classes of its window rows (four per lane: st_class4), the flags of rows without an exact divisor pair, the
-// coefficient table in LDS.  Round 6: every load unconditional (addresses clamped, the choice made afterwards) and all twelve in
-// flight together behind ONE wait.  Written as `if (inside) cls = table[...]` the class loads came out as four conditional loads
-// with an s_waitcnt vmcnt(0) after each -- four memory round trips in a row, the first of them behind the unit's first row
-// requests, then a fifth for the flags and a sixth for the coefficients: 5.5 us of a 45-us unit of a one-round launch
-// (profiles/r06_band_units.txt, per-step clocks).
-template <int DV>
-__device__ __forceinline__ void st_unit_tables(const st_args &a, int lane, int tx, int e0, int n, unsigned &cls_lo, v4f *ktab)
-{
-    unsigned cb[4], bd[4];
-    v4f kt[4];
-    bool inside[4];
-    const unsigned char *rc = a.rowclass ? a.rowclass + (size_t)tx * a.L : a.code;      // (no class table: any readable byte, not used)
-    const unsigned char *rb = a.rowbad ? a.rowbad : a.code;                             // (likewise)
-    const unsigned badmask = (DV == 1 && a.rowbad) ? 1u : 0u;
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int lu = e0 + lane + 64 * q, yg = a.y_first + lu;
-        inside[q] = yg >= 0 && yg < a.H && lu >= 0 && lu < a.L;
-        cb[q] = rc[inside[q] ? lu : 0];
-    }
-#pragma unroll
-    for (int q = 0; q < 4; q++) bd[q] = DV == 1 ? (unsigned)rb[st_map_row(a, e0 + lane + 64 * q).l] : 0u;     // (mirrored and clamped rows have their image's divisors)
-    // one 16-byte table entry per window row (two spare: the next level's prefetch)
-#pragma unroll
-    for (int q = 0; q < 4; q++) kt[q] = st_kswap(*reinterpret_cast<const v4f *>(a.jcoef + (size_t)st_map_row(a, e0 + min(lane + 64 * q, n - 1)).l * 8));
-    // classes of the window rows: rows beyond the grid or the stored band count as mixed (their codes decide)
-    cls_lo = 0u;
-#pragma unroll
-    for (int q = 0; q < 4; q++) cls_lo |= (((a.rowclass && inside[q]) ? cb[q] : 2u) | ((bd[q] & badmask) << 2)) << (8 * q);
-#pragma unroll
-    for (int q = 0; q < 4; q++) if (lane + 64 * q < n) ktab[lane + 64 * q] = kt[q];
-}
-
 template <int DV>
 __global__ __launch_bounds__(64, 2) void k_jacobi_stream(st_args a_up, st_args a_dn)
 {

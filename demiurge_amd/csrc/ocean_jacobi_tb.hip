@@ -297,6 +297,7 @@ void ocean_tb_free_lists(dmg_ocean *o)
     // (the streaming kernel's mirrored row tables: the classes change with the terrain, the lists go with it)
     for (void *q : { (void *)o->jcoef_f, (void *)o->jcoef2_f, (void *)o->jcoef3_f, (void *)o->rowbad_f, (void *)o->rowclass_f }) if (q) (void)hipFree(q);
     o->jcoef_f = o->jcoef2_f = o->jcoef3_f = nullptr; o->rowbad_f = o->rowclass_f = nullptr;
+    if (o->rowclass_d) { (void)hipFree(o->rowclass_d); o->rowclass_d = nullptr; o->rowclass_d_host.clear(); }
     for (auto &kv : o->tb_tuning) {
         if (kv.second.ev0) (void)hipEventDestroy(kv.second.ev0);
         if (kv.second.ev1) (void)hipEventDestroy(kv.second.ev1);

@@ -81,7 +81,8 @@ struct st_args {
     const int4 *units;              // {tile column, first output row, end output row, -}
     const unsigned char *rowbad;    // DV = 1: [L] 1 = the row's divisors have no exact two-operation pair (its table entry holds (c, r)); or null
     const float *jcoef_cy;          // {cy, 1/cy}: the same for every row
-    int nseg0;                      // the deep form (ocean_jacobi_deep.hip, experiments): units in the list
+    int nseg0;                      // the deep form's prototype (ocean_jacobi_deep.hip, experiments): units in the list
+    unsigned *deep_err;             // the deep form: a word the launch ORs 1 into when a wave gave up waiting for its partner (never, unless the protocol is broken)
     unsigned long long *prof;       // experiments only (DMG_ST_PROF): {start, end} of every unit on the 100 MHz s_memrealtime clock, or null
     unsigned long long *clk;        // experiments only (-DST_EXPERIMENTS, with DMG_ST_PROF): s_memtime (the shader clock's counter) at every unit's start and end, beside prof's s_memrealtime
     unsigned long long *stepprof;   // experiments only (-DST_EXPERIMENTS, DMG_ST_STEPPROF): s_memrealtime at the top of the first 64 steps of every unit
@@ -716,6 +717,40 @@ __device__ __forceinline__ void st_open_unit(const st_args &a, v4f (*bring)[64],
         st_open_step<0, DV, 2>(a, z, bring, ktab, lane, t, e0 + 2 * t, r0, r1, lane_ok, xcol, col4, rowb, pb, bb, sb);
         st_open_step<1, DV, 2>(a, z, bring, ktab, lane, t + 1, e0 + 2 * t + 2, r0, r1, lane_ok, xcol, col4, rowb, pb, bb, sb);
     }
+}
+
+// A unit's tables: the classes of its window rows (four per lane: st_class4), the flags of rows without an exact divisor pair, the
+// coefficient table in LDS.  Round 6: every load unconditional (addresses clamped, the choice made afterwards) and all twelve in
+// flight together behind ONE wait.  Written as `if (inside) cls = table[...]` the class loads came out as four conditional loads
+// with an s_waitcnt vmcnt(0) after each -- four memory round trips in a row, the first of them behind the unit's first row
+// requests, then a fifth for the flags and a sixth for the coefficients: 5.5 us of a 45-us unit of a one-round launch
+// (profiles/r06_band_units.txt, per-step clocks).
+template <int DV>
+__device__ __forceinline__ void st_unit_tables(const st_args &a, int lane, int tx, int e0, int n, unsigned &cls_lo, v4f *ktab)
+{
+    unsigned cb[4], bd[4];
+    v4f kt[4];
+    bool inside[4];
+    const unsigned char *rc = a.rowclass ? a.rowclass + (size_t)tx * a.L : a.code;      // (no class table: any readable byte, not used)
+    const unsigned char *rb = a.rowbad ? a.rowbad : a.code;                             // (likewise)
+    const unsigned badmask = (DV == 1 && a.rowbad) ? 1u : 0u;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int lu = e0 + lane + 64 * q, yg = a.y_first + lu;
+        inside[q] = yg >= 0 && yg < a.H && lu >= 0 && lu < a.L;
+        cb[q] = rc[inside[q] ? lu : 0];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) bd[q] = DV == 1 ? (unsigned)rb[st_map_row(a, e0 + lane + 64 * q).l] : 0u;     // (mirrored and clamped rows have their image's divisors)
+    // one 16-byte table entry per window row (two spare: the next level's prefetch)
+#pragma unroll
+    for (int q = 0; q < 4; q++) kt[q] = st_kswap(*reinterpret_cast<const v4f *>(a.jcoef + (size_t)st_map_row(a, e0 + min(lane + 64 * q, n - 1)).l * 8));
+    // classes of the window rows: rows beyond the grid or the stored band count as mixed (their codes decide)
+    cls_lo = 0u;
+#pragma unroll
+    for (int q = 0; q < 4; q++) cls_lo |= (((a.rowclass && inside[q]) ? cb[q] : 2u) | ((bd[q] & badmask) << 2)) << (8 * q);
+#pragma unroll
+    for (int q = 0; q < 4; q++) if (lane + 64 * q < n) ktab[lane + 64 * q] = kt[q];
 }
 
 // constants of the kernel forms that the host-side planner (ocean_jacobi_stream_plan.hip) needs as well

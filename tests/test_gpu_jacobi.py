@@ -431,6 +431,22 @@ def test_streaming_twin_units_vs_oracle(env):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("rendering", ["exact", "tolerance"])
+def test_deep_form_vs_oracle(rendering):
+    """Round 6: the deep form of the streaming kernel (k_jacobi_deep: two waves per unit, the front wave's level 8 handed to the
+    back wave's level 0 through LDS, SIXTEEN sweeps per trip through HBM) widened from round 5's open-water prototype to
+    everything a unit handles -- land, coast, poles, band edges.  It is the default for the 16-sweep launches of the tolerance
+    rendering (where half the bytes per sweep pay) and can be forced in the exact one (DMG_JACOBI_DEEP=1): 20 random geometries,
+    salt-and-pepper coasts, band splits (ghost 16: the bands' launches are deep ones), open water, the 5000-sweep golden -- bit for
+    bit against the oracle (the exact form, and form 3) and, in the exact rendering, against the reference's own llvmpipe pixels."""
+    env = {"DMG_TB_SHAPE": "stream", "DMG_ST_TWIN": "0", "DMG_JACOBI_DEEP": "1"}
+    if rendering == "tolerance":
+        env["STREAM_WORKER_FORM"] = "3"
+    out = _stream_worker(env, ["random", "pepper", "golden", "bands", "open", "split"], timeout=1500)
+    assert "'k_jacobi_deep'" in out, out[-1500:]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("twin", ["0", "2"], ids=["plain-units", "twin-units"])
 def test_streaming_tolerance_rendering_vs_oracle_form3(twin):
     """Round 6: DMG_QUIRK_JACOBI_TOLERANCE -- the sweep with fused row coefficients, a = ah + al, b = bh + bl,
@@ -439,7 +455,8 @@ def test_streaming_tolerance_rendering_vs_oracle_form3(twin):
     twin units; sweep counts that are no multiple of 8 end in the exact arithmetic on both sides.  Against the reference's own
     pixels (llvmpipe golden, 256x128, 5000 sweeps) it is within 5e-6 of the field's maximum."""
     cases = ["random", "pepper", "golden", "bands", "open"] + (["twin", "split"] if twin == "2" else [])
-    out = _stream_worker({"DMG_TB_SHAPE": "stream", "DMG_ST_TWIN": twin, "STREAM_WORKER_FORM": "3"}, cases, timeout=1500)
+    # (DMG_JACOBI_DEEP=0: the 8-sweep kernel's fused arithmetic alone; the deep form that takes the 16-sweep launches by default: test_deep_form_vs_oracle)
+    out = _stream_worker({"DMG_TB_SHAPE": "stream", "DMG_ST_TWIN": twin, "STREAM_WORKER_FORM": "3", "DMG_JACOBI_DEEP": "0"}, cases, timeout=1500)
     assert "tolerance rendering vs llvmpipe golden x5000" in out, out[-1500:]
     assert ("'k_jacobi_stream_twin'" if twin == "2" else "'k_jacobi_stream'") in out, out[-1500:]
 
