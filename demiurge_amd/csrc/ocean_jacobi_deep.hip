@@ -455,6 +455,9 @@ bool ocean_deep_enabled(const dmg_ocean *o)
     if (env == 0) return false;
     const bool tol = (o->prm.quirks & DMG_QUIRK_JACOBI_TOLERANCE) != 0;
     if (env < 0 && !tol) return false;
+    // (a unit of the deep form streams its rows + 32: the bands of a split grid, a round of ~36-row units, lose with it -- the
+    // middle band of a 2- / 4- / 8-way split in the tolerance rendering 124.5 / 76.2 / 48.1 us per 8 sweeps against 124.0 / 63.5 / 37.3)
+    if (env < 0 && o->L < 6000) return false;
     // (the exact rendering's rows without a two-operation divisor pair would need the per-row division forms in both waves: not built)
     if (!tol && o->div2_nbad) return false;
     return ocean_tb_supported(o) && ocean_stream_enabled() && o->grid.W % 4 == 0;
