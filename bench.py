@@ -932,7 +932,9 @@ def worker(args):
             pmax = float(np.abs(pe).max())
             dmax = max(float(np.abs(pt[y:y + 512].astype(np.float64) - pe[y:y + 512]).max()) for y in range(0, H, 512))
             out["tolerance"] = {"value": float(W) * H * sweeps / dtt / 1e6, "unit": "Mcell-steps/s", "ms_per_step": dtt * 1e3,
-                                "launch_us": evt / lt_ * 1e3, "kernel": mt.band(0).kernel_name() + "<3>", "max_rel": dmax / max(pmax, 1e-30),
+                                "launch_us": evt / lt_ * 1e3, "sweeps_per_launch": swt / lt_,
+                                "kernel": ("k_jacobi_deep<3> (16 sweeps per trip through HBM, two waves per unit) + k_jacobi_stream<3> for the last 8"
+                                           if swt / lt_ > 8.5 else mt.band(0).kernel_name() + "<3>"), "max_rel": dmax / max(pmax, 1e-30),
                                 "max_rel_what": "max|p_tol - p_exact| / max|p_exact| after %d sweeps from zero pressure, this run" % sweeps,
                                 "bound": 1e-5, "sample": "1 solve after 1 warm-up",
                                 "what": "DMG_QUIRK_JACOBI_TOLERANCE: a(pW+pE) + b(pS+pN) - c bC with split row coefficients (three fused "
