@@ -555,6 +555,7 @@ __global__ __launch_bounds__(256) void k_flow_dataflow(flow_canvas fc, const int
         int u = -1, unsrc = 0, usrc[9];                      // the upstream cell looked through, and what IT adds
         float uown = 0.0f;
         int polls = 0;
+        const unsigned long long t_wait0 = __builtin_amdgcn_s_memrealtime();        // (100 MHz: the budget below is wall time, whatever a poll costs)
         unsigned v[9];                                       // (a sum that has arrived is not asked for again)
 #pragma unroll
         for (int k = 0; k < 9; k++) v[k] = FLOW_NOT_READY;
@@ -598,8 +599,8 @@ __global__ __launch_bounds__(256) void k_flow_dataflow(flow_canvas fc, const int
                         if (k < nsrc) sum = __fadd_rn(sum, __uint_as_float(v[k]));
                     __hip_atomic_store(acc + p, __float_as_uint(sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     pending = false;
-                } else if (++polls > (1 << 20) ||            // ~a second: something upstream was never published
-                           ((polls & 1023) == 0 && __hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                } else if ((++polls & 1023) == 0 &&          // two seconds without the sums: something upstream was never published
+                           (__builtin_amdgcn_s_memrealtime() - t_wait0 > 200000000ull || __hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
                     atomicOr(error, 1);                      // (the whole grid then drains within a millisecond)
                     pending = false;
                 } else __builtin_amdgcn_s_sleep(2);
@@ -1364,10 +1365,14 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
         // gain nothing at 16384x8192, with 128, 256 or 512 blocks: round 5.)
         static const int look_env = [] { const char *e = dmg_hook("DMG_FLOW_LOOK_THROUGH"); return e ? atoi(e) : -1; }();      // experiments: 0 = every cell waits for its sums to be published
         // (3.40 -> 3.15 ms at 4096x2048; at 16384x8192, where a level holds ten times the cells, its extra loads cost 5 %)
-        const int look_through = look_env >= 0 ? look_env : (N <= ((size_t)1 << 25) ? 1 : 0);
+        // (chosen by what was measured to decide it -- how many cells a level holds -- not by the grid's size: 1 700 cells per
+        // level at 4096x2048 (3.1 M reached cells, 1 830 levels), 14 700 at 16384x8192 (50 M, 3 400); the line between them at 5 000)
+        const int level_pop = (int)(n_reached / std::max(levels, 1));
+        const bool sparse_levels = level_pop <= 5000;
+        const int look_through = look_env >= 0 ? look_env : (sparse_levels ? 1 : 0);
         static const int nblocks_env = [] { const char *e = dmg_hook("DMG_FLOW_NBLOCKS"); return e ? atoi(e) : 0; }();
         // (with a sum asked for only until it has arrived, 4096x2048 takes 256 blocks better than 128: 3.13 -> 2.86 ms; 16384x8192 does not: 32.7 -> 37.0)
-        const int blocks = std::min((waves + 3) / 4, nblocks_env > 0 ? nblocks_env : (N <= ((size_t)1 << 25) ? 256 : 128));
+        const int blocks = std::min((waves + 3) / 4, nblocks_env > 0 ? nblocks_env : (sparse_levels ? 256 : 128));
         hipLaunchKernelGGL(k_flow_dataflow, dim3(blocks), dim3(256), 0, st, fc, order.i(), n_reached, (const unsigned short *)mask.p, dcf.i(),
                            down.f(), (unsigned *)acc.p, dtick.i(), dtick.i() + 1, look_through);
         DMG_HIP(hipGetLastError());
