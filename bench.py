@@ -857,15 +857,16 @@ def worker(args):
             roof["shape_ceiling"] = HBM_ROWS_GBS
             roof["frac_of_shape_ceiling"] = roof["achieved"] / HBM_ROWS_GBS
             roof["note"] = ("8 sweeps per launch on chip: `achieved` is the HBM traffic the launch really moves (PMC) over its "
-                            "duration.  It is not what the launch waits for: the one-sweep kernel moves more bytes per second in this "
-                            "same run (`demonstrated_GBps`), and round 5 built a form with HALF the bytes per sweep (16 sweeps per "
-                            "trip, two waves per unit through LDS, bit-identical) that takes the same time.  What it runs into is the "
-                            "package power limit: these launches hold the chip at ~1390 W and the shader clock at ~2.1 GHz (`clock`, sampled "
-                            "beside the timed steps; a device copy runs at 2.4 GHz and 850 W, the one-sweep kernel at 2.4 GHz and 1270 W), "
-                            "with the vector pipe ~70 % occupied at that clock, nine tenths of it by the formula's own instructions (DESIGN.md 4.1b, "
-                            "profiles/r05_clock_power.txt, profiles/r05_deep_form.txt).  The SURVEY 8d model (16 B per cell-sweep) stops bounding a "
-                            "kernel that does 8 sweeps per HBM pass: `algorithmic_x_peak`; the HBM-bound form the 60 % target is stated "
-                            "for is `roofline_single`")
+                            "duration.  It is not what the launch waits for alone: the kernel is CO-LIMITED at the package power limit.  "
+                            "These launches hold the chip at ~1400 W; the shader clock measured INSIDE the kernel (s_memtime / s_memrealtime "
+                            "per unit, profiles/r06_clock_power.txt) is 1.96 GHz (`clock`, rocm-smi sampled beside the timed steps, reads "
+                            "~2.05; a device copy runs at 2.4 GHz and 850 W), at which the vector pipe is 76-80 % occupied, nine tenths of "
+                            "it by the formula's own instructions, 90 % with the launch's tail -- while the launch moves 0.8 of the bytes per "
+                            "second the one-sweep kernel moves in this same run (`demonstrated_GBps`).  Halving the bytes (round 5's deep form: "
+                            "16 sweeps per trip, bit-identical) buys nothing in the exact arithmetic; halving the arithmetic (the `tolerance` "
+                            "rendering, within north_star's 1e-5) buys 9 % with this kernel and 25 % with the deep form (DESIGN.md 4.1b, 4.1c).  "
+                            "The SURVEY 8d model (16 B per cell-sweep) stops bounding a kernel that does 8 sweeps per HBM pass: "
+                            "`algorithmic_x_peak`; the HBM-bound form the 60 % target is stated for is `roofline_single`")
         else:
             roof["achieved"], roof["frac"] = None, None
             roof["note"] = "no PMC traffic for this configuration (%s); see algorithmic_x_peak and fp32" % tsrc
