@@ -518,7 +518,7 @@ __device__ __forceinline__ int flow_sources(const flow_canvas &fc, int p, const 
         if (y < 0 || y >= H) continue;
         src[n++] = y * W + x;
     }
-    const int from = conn_from[p];
+    const int from = conn_from ? conn_from[p] : -1;          // (null: the sums inside the catchments, before the lakes are connected -- phase A below)
     if (from >= 0) src[n++] = from;
     return n;
 }
@@ -533,10 +533,12 @@ __device__ __forceinline__ int flow_sources(const flow_canvas &fc, int p, const 
 // finish the four cells in five that sit within three hops of a source in full-width passes beforehand: 3.43 -> 3.30 ms.)
 __global__ __launch_bounds__(256) void k_flow_dataflow(flow_canvas fc, const int *__restrict__ order, int n_reached,
                                                        const unsigned short *__restrict__ mask, const int *__restrict__ conn_from,
-                                                       const float *__restrict__ own_row, unsigned *acc, int *ticket, int *error, int look_through)
+                                                       const float *__restrict__ own_row, unsigned *acc, int *ticket, int *error, int look_through,
+                                                       const int *__restrict__ n_dev = nullptr)
 {
     const int W = fc.c.W;
     const int lane = threadIdx.x & 63;
+    if (n_dev) n_reached = *n_dev;                           // (a count the host has not read back: phase A is queued before the host knows it)
     for (;;) {
         int base = 0;
         if (lane == 0) base = atomicAdd(ticket, 64);
@@ -606,6 +608,203 @@ __global__ __launch_bounds__(256) void k_flow_dataflow(flow_canvas fc, const int
                 } else __builtin_amdgcn_s_sleep(2);
             }
         }
+    }
+}
+
+// ---- the sums in two phases (round 6) ---------------------------------------------------------------------------------------------
+// A cell's sum is its area, its upstream neighbours' sums and -- where a lake drains into it -- that lake's total.  Which lake drains
+// where is the host's Prim growth: 1.2 ms of a config-2 iteration with the GPU idle, and after it the sums waited for the hops of the
+// longest river THROUGH the lakes (1 830 levels at 4096x2048).  But a lake's total only reaches the cells between the cell it enters and
+// that catchment's sink: a fifteenth of the cells.  Phase A, queued before the host starts the growth and running beside it: every cell's
+// sum inside its own catchment, no lake connected -- cells in order of their distance to their own sink, a few hundred levels.  Phase B,
+// once the connections are known: the cells on the way from a connection's cell to its sink are marked, their sums withdrawn, and only
+// those are formed again, in order of their global depth, from sums that are final (phase A's, of cells nothing drains into) or formed
+// earlier in phase B.  Every sum is formed by the same additions in the same order as in one pass: the same bits.
+// Phase A is not a dataflow: catchments do not talk to each other before the lakes are connected, so ONE WAVE takes ONE catchment and
+// walks its cells level by level, deepest first -- no polling, no ticket, no other wave to wait for; the sums it needs it has stored
+// itself, a step earlier.  (As a dataflow over all cells in order of their local depth phase A took as long as the whole one-pass form,
+// 2.8 ms at 4096x2048: the grid's waves spend their time polling each other, 11 us per level.)
+// keys of phase A: (dense lake id << 10 | 1023 - distance to the lake's sink) for the cells of a catchment, all ones for the rest;
+// *count = how many cells have one, *maxd = the largest distance
+#define FLOW_LOCAL_BITS 10
+__global__ __launch_bounds__(256) void k_flow_local_keys(const int *__restrict__ label, const int *__restrict__ dense, const int *__restrict__ dist,
+                                                         unsigned *__restrict__ key, unsigned *__restrict__ idx, int *count, int *maxd, size_t n)
+{
+    const size_t i0 = (size_t)blockIdx.x * FLOW_ITEMS * 256 + threadIdx.x;
+    int c = 0, m = 0;
+#pragma unroll
+    for (int t = 0; t < FLOW_ITEMS; t++) {
+        const size_t i = i0 + (size_t)t * 256;
+        if (i >= n) continue;
+        const int l = label[i];
+        unsigned k = 0xFFFFFFFFu;
+        if (l >= 0) {
+            const int d = dist[i];
+            k = ((unsigned)dense[l] << FLOW_LOCAL_BITS) | (unsigned)((1 << FLOW_LOCAL_BITS) - 1 - min(d, (1 << FLOW_LOCAL_BITS) - 1));
+            c++; m = max(m, d);
+        }
+        key[i] = k;
+        idx[i] = (unsigned)i;
+    }
+    __shared__ int s_c[4], s_m[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { c += __shfl_xor(c, o); m = max(m, __shfl_xor(m, o)); }
+    if ((threadIdx.x & 63) == 0) { s_c[threadIdx.x >> 6] = c; s_m[threadIdx.x >> 6] = m; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int tc = s_c[0] + s_c[1] + s_c[2] + s_c[3], tm = max(max(s_m[0], s_m[1]), max(s_m[2], s_m[3]));
+        if (tc) atomicAdd(count, tc);
+        if (tm) atomicMax(maxd, tm);
+    }
+}
+// off[l] = where lake l's cells start in the sorted list (every lake has its sink cell at least); off[nlakes] = the cells with a catchment
+// ... and smask[i] = the receiver bits of the i-th cell of the sorted list
+__global__ void k_flow_lake_offsets(const unsigned *__restrict__ skey, const int *__restrict__ order, const unsigned short *__restrict__ mask,
+                                    const int *__restrict__ n_dev, int *__restrict__ off, unsigned short *__restrict__ smask, int nlakes, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nl = *n_dev;
+    if (i == 0) off[nlakes] = nl;
+    if (i >= (size_t)nl) return;
+    smask[i] = mask[order[i]];
+    const unsigned l = skey[i] >> FLOW_LOCAL_BITS;
+    if (i == 0 || (skey[i - 1] >> FLOW_LOCAL_BITS) != l) off[l] = (int)i;
+}
+// one wave per catchment (BLOCK = 0), or one workgroup of 1024 threads for a catchment of more than FLOW_BIG_LAKE cells (BLOCK = 1: the
+// largest catchment decides how long phase A takes -- 250 levels of 800 cells on one wave were 9 ms): its cells in order of their distance
+// to the sink, farthest first, a level at a time.  A sum is only ever added by a cell of the same catchment -- by the same wave or the same
+// workgroup, on one CU -- so the loads and stores are of wavefront / workgroup scope and stay in that CU's caches (at agent scope every one
+// of them went out to the memory side of the eight L2s: 4 us a level); between two levels the wave only has to wait for its own stores
+// (and the workgroup for each other's: a barrier).  The kernel's end publishes the sums to the kernels after it.
+#define FLOW_BIG_LAKE 1024
+#define FLOW_WINDOW 2048
+// what a cell of phase A adds: its area and its upstream neighbours' sums, in FlowFilter::neighbours order (flow_sources without a lake)
+template <int SCOPE>
+__device__ __forceinline__ float flow_catchment_sum(const flow_canvas &fc, int p, unsigned m, const float *__restrict__ own_row, const unsigned *acc)
+{
+    const int W = fc.c.W, H = fc.c.H, x0 = p % W, y0 = p / W;
+    float sum = own_row[y0];
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        if (!(m & (unsigned)c_nbit[q])) continue;
+        int x = x0 + c_ndx[q], y = y0 + c_ndy[q];
+        if (fc.wrap) { if (x < 0) x += W; else if (x >= W) x -= W; } else if (x < 0 || x >= W) continue;
+        if (y < 0 || y >= H) continue;
+        sum = __fadd_rn(sum, __uint_as_float(__hip_atomic_load(acc + (y * W + x), __ATOMIC_RELAXED, SCOPE)));
+    }
+    return sum;
+}
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK ? 1024 : 256) void k_flow_catchment_sums(flow_canvas fc, const unsigned *__restrict__ skey, const int *__restrict__ order,
+                                                                          const int *__restrict__ off, const unsigned short *__restrict__ smask,
+                                                                          const float *__restrict__ own_row, unsigned *acc, int nlakes)
+{
+    const int lane = BLOCK ? (int)threadIdx.x : (int)(threadIdx.x & 63);
+    const int lake = BLOCK ? (int)blockIdx.x : (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (lake >= nlakes) return;
+    int pos = off[lake];
+    const int end = off[lake + 1];
+    if ((end - pos > FLOW_BIG_LAKE) != (BLOCK != 0)) return;         // (the other launch's catchment)
+    if (BLOCK) {
+        // The sorted list is read through a window in the LDS, 2048 entries at a time: a level then waits for the sums it adds and for its
+        // own stores, not for its keys as well (they come from HBM: 4.4 us a level with them, 250 levels in the largest catchment).  The
+        // last cell of a level says how many there were; one barrier a level (the count alternates between two words).
+        __shared__ unsigned w_key[FLOW_WINDOW];
+        __shared__ int w_ord[FLOW_WINDOW];
+        __shared__ unsigned short w_msk[FLOW_WINDOW];
+        __shared__ int s_cnt[2];
+        int wbase = pos - FLOW_WINDOW, par = 0;                      // (nothing loaded yet)
+        while (pos < end) {
+            if (pos + 1024 > wbase + FLOW_WINDOW && wbase + FLOW_WINDOW < end) {
+                wbase = pos;                                         // (everybody has passed the barrier of the last level read from the old window)
+#pragma unroll
+                for (int t = 0; t < FLOW_WINDOW / 1024; t++) {
+                    const int i = wbase + t * 1024 + lane;
+                    if (i < end) { w_key[t * 1024 + lane] = skey[i]; w_ord[t * 1024 + lane] = order[i]; w_msk[t * 1024 + lane] = smask[i]; }
+                }
+                __syncthreads();
+            }
+            const int w = pos - wbase + lane;
+            const unsigned k0 = w_key[pos - wbase];
+            const bool mine = pos + lane < end && w_key[w] == k0;    // (the cells of the level the first cell is on; sorted: a prefix of the batch)
+            if (mine) {
+                const int p = w_ord[w];
+                if (lane == 1023 || pos + lane + 1 >= end || w_key[w + 1] != k0) s_cnt[par] = lane + 1;
+                const float sum = flow_catchment_sum<__HIP_MEMORY_SCOPE_WORKGROUP>(fc, p, (unsigned)w_msk[w], own_row, acc);
+                __hip_atomic_store(acc + p, __float_as_uint(sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's sums of the level have reached the L2
+            __syncthreads();
+            pos += s_cnt[par];
+            par ^= 1;
+        }
+        return;
+    }
+    while (pos < end) {
+        // key, cell and the cell's receiver bits are asked for together (smask: the mask in the sorted order, k_flow_lake_offsets): a level
+        // then waits for three round trips -- these, the sums, its own stores -- not five
+        const bool have = pos + lane < end;
+        const unsigned k = have ? skey[pos + lane] : 0u;
+        const int p = have ? order[pos + lane] : 0;
+        const unsigned m = have ? (unsigned)smask[pos + lane] : 0u;
+        const unsigned k0 = (unsigned)__builtin_amdgcn_readfirstlane((int)k);
+        const bool mine = have && k == k0;
+        if (mine) {
+            const float sum = flow_catchment_sum<__HIP_MEMORY_SCOPE_WAVEFRONT>(fc, p, m, own_row, acc);
+            __hip_atomic_store(acc + p, __float_as_uint(sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        pos += __builtin_popcountll(__builtin_amdgcn_ballot_w64(mine));
+    }
+}
+
+// the cell a cell drains to (k_flow_parent's rule), or -1
+__device__ __forceinline__ int flow_receiver(const flow_canvas &fc, const unsigned char *__restrict__ code, int i)
+{
+    const int W = fc.c.W, H = fc.c.H;
+    const int cd = code[i];
+    if (cd == 0 || cd == 5) return -1;
+    const int dx = (cd - 1) % 3 - 1, dy = (cd - 1) / 3 - 1;
+    int x = i % W + dx, y = i / W + dy;
+    if (fc.wrap) { if (x < 0) x += W; else if (x >= W) x -= W; } else if (x < 0 || x >= W) return -1;
+    if (y < 0 || y >= H) return -1;
+    return y * W + x;
+}
+
+// phase B, marking: from every cell a lake drains into, downstream to the catchment's sink (or to a cell somebody else has marked: the
+// one who marked it goes on from there)
+__global__ __launch_bounds__(256) void k_flow_mark_affected(flow_canvas fc, const unsigned char *__restrict__ code, const int *__restrict__ conn_from,
+                                                            const int *__restrict__ gdepth, int *__restrict__ marked, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || conn_from[i] < 0 || gdepth[i] < 0) return;
+    int q = (int)i;
+    for (int guard = 0; q >= 0 && guard < (1 << 24); guard++) {
+        if (atomicExch(marked + q, 1) != 0) break;
+        q = flow_receiver(fc, code, q);
+    }
+}
+
+// phase B, the list: (global depth, cell) of every marked cell, its sum withdrawn
+__global__ __launch_bounds__(256) void k_flow_collect_affected(const int *__restrict__ marked, const int *__restrict__ gdepth, unsigned *acc,
+                                                               unsigned *__restrict__ key, unsigned *__restrict__ cell, int *count, size_t n)
+{
+    int mine[FLOW_ITEMS];
+    int c = 0;
+#pragma unroll
+    for (int t = 0; t < FLOW_ITEMS; t++) {
+        const size_t i = ((size_t)blockIdx.x * FLOW_ITEMS + t) * 256 + threadIdx.x;
+        mine[t] = (i < n && marked[i] && gdepth[i] >= 0) ? (int)i : -1;
+        c += mine[t] >= 0;
+    }
+    int slot = block_append_base(c, count);
+#pragma unroll
+    for (int t = 0; t < FLOW_ITEMS; t++) {
+        if (mine[t] < 0) continue;
+        acc[mine[t]] = FLOW_NOT_READY;
+        key[slot] = (unsigned)gdepth[mine[t]];
+        cell[slot] = (unsigned)mine[t];
+        slot++;
     }
 }
 
@@ -954,7 +1153,48 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
         DMG_HIP(hipMemcpyAsync(ent.data(), dent.p, (size_t)nuniq * 16, hipMemcpyDeviceToHost, st));
         DMG_HIP(hipMemcpyAsync(span.data(), dspan.p, (size_t)(nlakes + 1) * 8, hipMemcpyDeviceToHost, st));
     }
-    DMG_HIP(hipStreamSynchronize(st));
+    // ---- the upstream sums, phase A (k_flow_local_keys has the story): queued BEFORE the host waits for the entries -- it waits on an
+    // event behind the copies, not on the stream -- so that the sums inside the catchments are formed while the host grows the lake graph
+    static const bool by_levels = dmg_hook("DMG_FLOW_LEVELS") != nullptr;      // experiments: the level-synchronous form
+    static const int two_env = [] { const char *e = dmg_hook("DMG_FLOW_TWO_PHASE"); return e ? atoi(e) : 1; }();   // 0: one pass over all cells in order of their global depth (through round 5)
+    bool two_phase = two_env != 0 && !by_levels;
+    dev_buf acc, keyA, keyA2, idxA, orderA, sortA, tickA, lakeoff, smaskA;
+    DMG_ALLOC(acc, N * 4);
+    DMG_ALLOC(tickA, 32);                                // [0] ticket A, [1] error A, [2] cells with a catchment, [3] their largest distance to their sink, [4] ticket B, [5] error B, [6] cells of phase B
+    DMG_HIP(hipMemsetAsync(tickA.p, 0, 32, st));
+    hipEvent_t ev_copies = nullptr;
+    if (two_phase) {
+        DMG_HIP(hipEventCreateWithFlags(&ev_copies, hipEventDisableTiming));
+        DMG_HIP(hipEventRecord(ev_copies, st));
+        DMG_ALLOC(keyA, N * 4); DMG_ALLOC(keyA2, N * 4); DMG_ALLOC(idxA, N * 4); DMG_ALLOC(orderA, N * 4);
+        DMG_HIP(hipMemsetAsync(acc.p, 0xFF, N * 4, st));                  // FLOW_NOT_READY everywhere
+        if (nlakes > 0) {
+            int lake_bits = 1;
+            while ((1ll << lake_bits) < (long long)nlakes + 1) lake_bits++;
+            const int key_bits = std::min(32, FLOW_LOCAL_BITS + lake_bits);
+            const unsigned nbk = (unsigned)((N + (size_t)256 * FLOW_ITEMS - 1) / ((size_t)256 * FLOW_ITEMS));
+            hipLaunchKernelGGL(k_flow_local_keys, dim3(nbk), dim3(256), 0, st, label.i(), dense.i(), dst[cur].i(), (unsigned *)keyA.p, (unsigned *)idxA.p,
+                               tickA.i() + 2, tickA.i() + 3, N);
+            size_t sb = 0;
+            (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sb, (const unsigned *)keyA.p, (unsigned *)keyA2.p, (const unsigned *)idxA.p, (unsigned *)orderA.p, (int)N, 0, key_bits, st);
+            DMG_ALLOC(sortA, sb + 256);
+            // (cells without a catchment carry all ones: with the key's upper bits left out of the sort they would mix with the last lakes' --
+            // so the sort takes all the bits those keys need, 32 where the lakes need 22)
+            DMG_HIP(hipcub::DeviceRadixSort::SortPairs(sortA.p, sb, (const unsigned *)keyA.p, (unsigned *)keyA2.p, (const unsigned *)idxA.p, (unsigned *)orderA.p, (int)N, 0, 32, st));
+            DMG_ALLOC(lakeoff, (size_t)(nlakes + 1) * 4);
+            DMG_ALLOC(smaskA, N * 2);
+            hipLaunchKernelGGL(k_flow_lake_offsets, dim3(nb), dim3(256), 0, st, (const unsigned *)keyA2.p, orderA.i(), (const unsigned short *)mask.p,
+                               (const int *)(tickA.i() + 2), lakeoff.i(), (unsigned short *)smaskA.p, nlakes, N);
+            hipLaunchKernelGGL(k_flow_catchment_sums<1>, dim3((unsigned)nlakes), dim3(1024), 0, st, fc, (const unsigned *)keyA2.p, orderA.i(), lakeoff.i(),
+                               (const unsigned short *)smaskA.p, down.f(), (unsigned *)acc.p, nlakes);          // the large catchments first: they take longest
+            hipLaunchKernelGGL(k_flow_catchment_sums<0>, dim3((unsigned)((nlakes + 3) / 4)), dim3(256), 0, st, fc, (const unsigned *)keyA2.p, orderA.i(), lakeoff.i(),
+                               (const unsigned short *)smaskA.p, down.f(), (unsigned *)acc.p, nlakes);
+            (void)key_bits;
+        }
+        DMG_HIP(hipGetLastError());
+        DMG_HIP(hipEventSynchronize(ev_copies));
+        (void)hipEventDestroy(ev_copies);
+    } else DMG_HIP(hipStreamSynchronize(st));
     lap("passes: sort/reduce/download");
     if (timing) fprintf(stderr, "[flow] %d lakes, %d pass candidates -> %d lake pairs, %d river mouths\n", nlakes, ncand, nuniq, nmouth);
 
@@ -1229,8 +1469,8 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
     // connections[tolocation] = pass (:588): per tolocation cell the LAST assigned entry survives; its lake hangs one below
     // the cell it drains into (calculateflow's recursion: river mouths at depth 0).  Both on the device: the host only
     // hands over the order in which the growth made its connections
-    dev_buf dlo, dcf, gdepth, dstart, order, acc, dmax, dlevel, dassigned, dpar0, dof0, dlv0, dmo;
-    DMG_ALLOC(dlo, N * 4); DMG_ALLOC(dcf, N * 4); DMG_ALLOC(gdepth, N * 4); DMG_ALLOC(order, N * 4); DMG_ALLOC(acc, N * 4); DMG_ALLOC(dmax, 8);
+    dev_buf dlo, dcf, gdepth, dstart, order, dmax, dlevel, dassigned, dpar0, dof0, dlv0, dmo;
+    DMG_ALLOC(dlo, N * 4); DMG_ALLOC(dcf, N * 4); DMG_ALLOC(gdepth, N * 4); DMG_ALLOC(dmax, 8);
     DMG_HIP(hipMemsetAsync(dlo.p, 0xFF, N * 4, st));         // -1
     DMG_HIP(hipMemsetAsync(dcf.p, 0xFF, N * 4, st));
     DMG_HIP(hipMemsetAsync(dmax.p, 0, 8, st));
@@ -1292,94 +1532,127 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
     }
     hipLaunchKernelGGL(k_flow_gdepth, dim3(nbi), dim3(256), 0, st, label.i(), dst[cur].i(), dlo.i(), gdepth.i(), dmax.i(), N);
     DMG_HIP(hipGetLastError());
-    int max_depth = 0;
+    // phase B's cells: marked from the connections' cells down to the sinks, listed with their global depths, their sums withdrawn
+    if (two_phase) {
+        DMG_HIP(hipMemsetAsync(tmp.p, 0, N * 4, st));
+        hipLaunchKernelGGL(k_flow_mark_affected, dim3(nb), dim3(256), 0, st, fc, (const unsigned char *)code.p, dcf.i(), gdepth.i(), tmp.i(), N);
+        hipLaunchKernelGGL(k_flow_collect_affected, dim3(nbi), dim3(256), 0, st, tmp.i(), gdepth.i(), (unsigned *)acc.p, (unsigned *)keyA.p, (unsigned *)idxA.p, tickA.i() + 6, N);
+        DMG_HIP(hipGetLastError());
+    }
+    int max_depth = 0, tick_host[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
     DMG_HIP(hipMemcpyAsync(&max_depth, dmax.p, 4, hipMemcpyDeviceToHost, st));
+    DMG_HIP(hipMemcpyAsync(tick_host, tickA.p, 32, hipMemcpyDeviceToHost, st));
     DMG_HIP(hipStreamSynchronize(st));
     const int levels = max_depth + 1;
-    // cells in depth order: a radix sort on just the bits a depth needs (was a histogram + scatter with one global
-    // atomic per cell, 3.6 ms at 4096x2048 on a handful of hot counters).  -1 (unreached) has all those bits set and
-    // lands behind every real depth.
     int depth_bits = 1;
     while ((1 << depth_bits) <= levels) depth_bits++;
-    dev_buf sdepth, iota, sorttmp;
-    DMG_ALLOC(sdepth, N * 4); DMG_ALLOC(iota, N * 4);
-    hipLaunchKernelGGL(k_flow_iota, dim3(nb), dim3(256), 0, st, (unsigned *)iota.p, N);
-    size_t sort_bytes = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, (const unsigned *)gdepth.p, (unsigned *)sdepth.p, (const unsigned *)iota.p,
-                                             (unsigned *)order.p, (int)N, 0, depth_bits, st);
-    DMG_ALLOC(sorttmp, sort_bytes + 256);
-    DMG_HIP(hipcub::DeviceRadixSort::SortPairs(sorttmp.p, sort_bytes, (const unsigned *)gdepth.p, (unsigned *)sdepth.p, (const unsigned *)iota.p,
-                                               (unsigned *)order.p, (int)N, 0, depth_bits, st));
-    DMG_ALLOC_VAR(dstart, (size_t)(levels + 1) * 4);
-    hipLaunchKernelGGL(k_flow_level_starts, dim3((levels + 256) / 256), dim3(256), 0, st, (const unsigned *)sdepth.p, N, dstart.i(), levels);
-    DMG_HIP(hipGetLastError());
-    std::vector<int> start(levels + 1, 0);
-    DMG_HIP(hipMemcpyAsync(start.data(), dstart.p, (size_t)(levels + 1) * 4, hipMemcpyDeviceToHost, st));
-    DMG_HIP(hipStreamSynchronize(st));
+    if (two_phase && tick_host[1]) return dmg_fail(DMG_EHIP, "flow: the sums inside the catchments did not complete (a cell waited for a sum that was never published)");
+    if (two_phase && tick_host[3] >= (1 << FLOW_LOCAL_BITS) - 1) {
+        // (a catchment deeper than phase A's keys have bits for: the one-pass form, from scratch)
+        two_phase = false;
+        DMG_HIP(hipMemsetAsync(tickA.p, 0, 32, st));
+    }
     hipLaunchKernelGGL(k_fill_f, dim3(nb), dim3(256), 0, st, d_flow, -1.0f, N);        // unreached cells keep -1 (:598-604)
     DMG_HIP(hipGetLastError());
-    if (timing) {
-        fprintf(stderr, "[flow] %d levels\n", levels);
-        // level populations: how much of the dependency chain is sparse (counted from the deepest level down)
-        const int lim[4] = { 64, 1024, 4096, 16384 };
-        int nlev[4] = { 0, 0, 0, 0 }; long long ncell[4] = { 0, 0, 0, 0 };
-        for (int q = 0; q < 4; q++)
-            for (int l = levels - 1; l >= 0; l--) { const int c = start[l + 1] - start[l]; if (c < lim[q]) { nlev[q]++; ncell[q] += c; } }
-        fprintf(stderr, "[flow] levels with < 64 / 1024 / 4096 / 16384 cells: %d / %d / %d / %d (%lld / %lld / %lld / %lld cells of %d reached)\n", nlev[0], nlev[1], nlev[2],
-                nlev[3], ncell[0], ncell[1], ncell[2], ncell[3], start[levels]);
-    }
-    lap("upload + depth sort");
-    static const bool by_levels = dmg_hook("DMG_FLOW_LEVELS") != nullptr;      // experiments: the level-synchronous form
-    const int n_reached = start[levels];
-    if (by_levels) {
-        for (int l = levels - 1; l >= 0; l--) {
-            int cnt = start[l + 1] - start[l];
-            if (!cnt) continue;
-            hipLaunchKernelGGL(k_flow_level, dim3((cnt + 255) / 256), dim3(256), 0, st, fc, order.i(), start[l], cnt,
-                               (const unsigned short *)mask.p, dcf.i(), down.f(), acc.f());
+    static const int look_env = [] { const char *e = dmg_hook("DMG_FLOW_LOOK_THROUGH"); return e ? atoi(e) : -1; }();      // experiments: 0 = every cell waits for its sums to be published
+    static const int nblocks_env = [] { const char *e = dmg_hook("DMG_FLOW_NBLOCKS"); return e ? atoi(e) : 0; }();
+    if (two_phase) {
+        const int n_aff = tick_host[6];
+        if (timing) fprintf(stderr, "[flow] two phases: %d cells with a catchment (deepest %d from its sink), %d of them behind a connection; %d levels of global depth\n",
+                            tick_host[2], tick_host[3], n_aff, levels);
+        lap("upload + depth sort");
+        if (n_aff > 0) {
+            size_t sb = 0;
+            (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sb, (const unsigned *)keyA.p, (unsigned *)keyA2.p, (const unsigned *)idxA.p, (unsigned *)orderA.p, n_aff, 0, depth_bits, st);
+            dev_buf sortB;
+            DMG_ALLOC(sortB, sb + 256);
+            DMG_HIP(hipcub::DeviceRadixSort::SortPairs(sortB.p, sb, (const unsigned *)keyA.p, (unsigned *)keyA2.p, (const unsigned *)idxA.p, (unsigned *)orderA.p, n_aff, 0, depth_bits, st));
+            // (few cells, a long chain: the small grid and the look-through, as for the sparse levels of the one-pass form)
+            const int waves = (n_aff + 63) / 64;
+            const int blocks = std::min((waves + 3) / 4, nblocks_env > 0 ? nblocks_env : 256);
+            hipLaunchKernelGGL(k_flow_dataflow, dim3(blocks), dim3(256), 0, st, fc, orderA.i(), n_aff, (const unsigned short *)mask.p, dcf.i(),
+                               down.f(), (unsigned *)acc.p, tickA.i() + 4, tickA.i() + 5, look_env >= 0 ? look_env : 1, (const int *)nullptr);
+            DMG_HIP(hipGetLastError());
+            int flow_err = 0;
+            DMG_HIP(hipMemcpyAsync(&flow_err, tickA.i() + 5, 4, hipMemcpyDeviceToHost, st));
+            DMG_HIP(hipStreamSynchronize(st));
+            if (flow_err) return dmg_fail(DMG_EHIP, "flow: the upstream sums did not complete (a cell waited for a sum that was never published)");
         }
-    } else if (n_reached > 0) {
-        dev_buf dtick;
-        DMG_ALLOC(dtick, 8);
-        DMG_HIP(hipMemsetAsync(dtick.p, 0, 8, st));
-        DMG_HIP(hipMemsetAsync(acc.p, 0xFF, N * 4, st));                  // FLOW_NOT_READY everywhere
-        const int waves = (n_reached + 63) / 64;
-        // (Round 5 measured where this kernel's 2.9 ms per config-2 iteration go.  Of ~1830 levels the deepest ~1400 hold fewer than 1024
-        // cells each -- the upper reaches of the longest rivers, 0.3 M of 3.1 M cells -- and looked like 1400 x 1.6 us of latency.  They
-        // are not: with those levels taken over by ONE workgroup (a thread per cell, the level's sums in LDS, a __syncthreads per level,
-        // the additions pre-decoded into 16 bytes per cell: bit-identical, 0.75 ms) this kernel still took 2.28 ms for the rest, and with
-        // levels of up to 4096 cells taken over (1790 levels, 1.05 M cells: 2.18 ms on one CU) 1.52 ms for the last 190 levels.  It
-        // spends ~0.4 us on a sparse level and is bound by THROUGHPUT, ~1.1 G cells/s, on the dense levels near the mouths, where the
-        // cells are: a dozen scattered loads per cell from 512 waves.  The single-workgroup form was dropped.)
-        // The persistent grid is SMALL: 128 blocks = 512 waves.  Every wave that holds a ticket polls, and the polls of waves far
-        // from the front compete with the loads that matter: with what the chip holds at once (8 192 waves) the sums of a
-        // 16384x8192 round took 45 ms, with 512 waves 30 ms (4096x2048: 4.5 -> 3.4 ms; 128 waves are too few: 36 ms).
-        // Measured and dropped in the same sitting: a lane that walks on downstream with the sum it has just published
-        // (computing the next cell itself, one round of loads per hop instead of a store and a poll) -- as many rounds saved as
-        // each round got longer; a round is one coherent load's trip to the memory side, ~1 us, either way.  Nor is there a
-        // shorter trip to be had by keeping the whole grid on ONE XCD (workgroups elsewhere leaving at once) and talking through
-        // that XCD's L2: workgroup-scope loads (sc0) are served by the CU's own L1 and never see another CU's sum, with or
-        // without a `buffer_inv sc0` in front; `buffer_inv sc1` works at 50 ms per solve; agent-scope loads of sums stored at
-        // workgroup scope work, and take as long as before (4.0 ms on one XCD against 3.2 ms on eight).
-        // (Longer sleeps for waves that have polled in vain for a while -- far from the front -- cost a third at 4096x2048 and
-        // gain nothing at 16384x8192, with 128, 256 or 512 blocks: round 5.)
-        static const int look_env = [] { const char *e = dmg_hook("DMG_FLOW_LOOK_THROUGH"); return e ? atoi(e) : -1; }();      // experiments: 0 = every cell waits for its sums to be published
-        // (3.40 -> 3.15 ms at 4096x2048; at 16384x8192, where a level holds ten times the cells, its extra loads cost 5 %)
-        // (chosen by what was measured to decide it -- how many cells a level holds -- not by the grid's size: 1 700 cells per
-        // level at 4096x2048 (3.1 M reached cells, 1 830 levels), 14 700 at 16384x8192 (50 M, 3 400); the line between them at 5 000)
-        const int level_pop = (int)(n_reached / std::max(levels, 1));
-        const bool sparse_levels = level_pop <= 5000;
-        const int look_through = look_env >= 0 ? look_env : (sparse_levels ? 1 : 0);
-        static const int nblocks_env = [] { const char *e = dmg_hook("DMG_FLOW_NBLOCKS"); return e ? atoi(e) : 0; }();
-        // (with a sum asked for only until it has arrived, 4096x2048 takes 256 blocks better than 128: 3.13 -> 2.86 ms; 16384x8192 does not: 32.7 -> 37.0)
-        const int blocks = std::min((waves + 3) / 4, nblocks_env > 0 ? nblocks_env : (sparse_levels ? 256 : 128));
-        hipLaunchKernelGGL(k_flow_dataflow, dim3(blocks), dim3(256), 0, st, fc, order.i(), n_reached, (const unsigned short *)mask.p, dcf.i(),
-                           down.f(), (unsigned *)acc.p, dtick.i(), dtick.i() + 1, look_through);
+    } else {
+        DMG_ALLOC(order, N * 4);
+        dev_buf sdepth, iota, sorttmp;
+        DMG_ALLOC(sdepth, N * 4); DMG_ALLOC(iota, N * 4);
+        hipLaunchKernelGGL(k_flow_iota, dim3(nb), dim3(256), 0, st, (unsigned *)iota.p, N);
+        size_t sort_bytes = 0;
+        (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, (const unsigned *)gdepth.p, (unsigned *)sdepth.p, (const unsigned *)iota.p,
+                                                 (unsigned *)order.p, (int)N, 0, depth_bits, st);
+        DMG_ALLOC(sorttmp, sort_bytes + 256);
+        DMG_HIP(hipcub::DeviceRadixSort::SortPairs(sorttmp.p, sort_bytes, (const unsigned *)gdepth.p, (unsigned *)sdepth.p, (const unsigned *)iota.p,
+                                                   (unsigned *)order.p, (int)N, 0, depth_bits, st));
+        DMG_ALLOC_VAR(dstart, (size_t)(levels + 1) * 4);
+        hipLaunchKernelGGL(k_flow_level_starts, dim3((levels + 256) / 256), dim3(256), 0, st, (const unsigned *)sdepth.p, N, dstart.i(), levels);
         DMG_HIP(hipGetLastError());
-        int flow_err = 0;
-        DMG_HIP(hipMemcpyAsync(&flow_err, dtick.i() + 1, 4, hipMemcpyDeviceToHost, st));
+        std::vector<int> start(levels + 1, 0);
+        DMG_HIP(hipMemcpyAsync(start.data(), dstart.p, (size_t)(levels + 1) * 4, hipMemcpyDeviceToHost, st));
         DMG_HIP(hipStreamSynchronize(st));
-        if (flow_err) return dmg_fail(DMG_EHIP, "flow: the upstream sums did not complete (a cell waited for a sum that was never published)");
+        if (timing) {
+            fprintf(stderr, "[flow] %d levels\n", levels);
+            // level populations: how much of the dependency chain is sparse (counted from the deepest level down)
+            const int lim[4] = { 64, 1024, 4096, 16384 };
+            int nlev[4] = { 0, 0, 0, 0 }; long long ncell[4] = { 0, 0, 0, 0 };
+            for (int q = 0; q < 4; q++)
+                for (int l = levels - 1; l >= 0; l--) { const int c = start[l + 1] - start[l]; if (c < lim[q]) { nlev[q]++; ncell[q] += c; } }
+            fprintf(stderr, "[flow] levels with < 64 / 1024 / 4096 / 16384 cells: %d / %d / %d / %d (%lld / %lld / %lld / %lld cells of %d reached)\n", nlev[0], nlev[1], nlev[2],
+                    nlev[3], ncell[0], ncell[1], ncell[2], ncell[3], start[levels]);
+        }
+        lap("upload + depth sort");
+        const int n_reached = start[levels];
+        if (by_levels) {
+            for (int l = levels - 1; l >= 0; l--) {
+                int cnt = start[l + 1] - start[l];
+                if (!cnt) continue;
+                hipLaunchKernelGGL(k_flow_level, dim3((cnt + 255) / 256), dim3(256), 0, st, fc, order.i(), start[l], cnt,
+                                   (const unsigned short *)mask.p, dcf.i(), down.f(), acc.f());
+            }
+        } else if (n_reached > 0) {
+            int *const dtick_p = tickA.i() + 4;              // (ticket and error words of the one pass: zeroed with the rest)
+            DMG_HIP(hipMemsetAsync(acc.p, 0xFF, N * 4, st));                  // FLOW_NOT_READY everywhere
+            const int waves = (n_reached + 63) / 64;
+            // (Round 5 measured where this kernel's 2.9 ms per config-2 iteration go.  Of ~1830 levels the deepest ~1400 hold fewer than 1024
+            // cells each -- the upper reaches of the longest rivers, 0.3 M of 3.1 M cells -- and looked like 1400 x 1.6 us of latency.  They
+            // are not: with those levels taken over by ONE workgroup (a thread per cell, the level's sums in LDS, a __syncthreads per level,
+            // the additions pre-decoded into 16 bytes per cell: bit-identical, 0.75 ms) this kernel still took 2.28 ms for the rest, and with
+            // levels of up to 4096 cells taken over (1790 levels, 1.05 M cells: 2.18 ms on one CU) 1.52 ms for the last 190 levels.  It
+            // spends ~0.4 us on a sparse level and is bound by THROUGHPUT, ~1.1 G cells/s, on the dense levels near the mouths, where the
+            // cells are: a dozen scattered loads per cell from 512 waves.  The single-workgroup form was dropped.)
+            // The persistent grid is SMALL: 128 blocks = 512 waves.  Every wave that holds a ticket polls, and the polls of waves far
+            // from the front compete with the loads that matter: with what the chip holds at once (8 192 waves) the sums of a
+            // 16384x8192 round took 45 ms, with 512 waves 30 ms (4096x2048: 4.5 -> 3.4 ms; 128 waves are too few: 36 ms).
+            // Measured and dropped in the same sitting: a lane that walks on downstream with the sum it has just published
+            // (computing the next cell itself, one round of loads per hop instead of a store and a poll) -- as many rounds saved as
+            // each round got longer; a round is one coherent load's trip to the memory side, ~1 us, either way.  Nor is there a
+            // shorter trip to be had by keeping the whole grid on ONE XCD (workgroups elsewhere leaving at once) and talking through
+            // that XCD's L2: workgroup-scope loads (sc0) are served by the CU's own L1 and never see another CU's sum, with or
+            // without a `buffer_inv sc0` in front; `buffer_inv sc1` works at 50 ms per solve; agent-scope loads of sums stored at
+            // workgroup scope work, and take as long as before (4.0 ms on one XCD against 3.2 ms on eight).
+            // (Longer sleeps for waves that have polled in vain for a while -- far from the front -- cost a third at 4096x2048 and
+            // gain nothing at 16384x8192, with 128, 256 or 512 blocks: round 5.)
+            // (3.40 -> 3.15 ms at 4096x2048; at 16384x8192, where a level holds ten times the cells, its extra loads cost 5 %)
+            // (chosen by what was measured to decide it -- how many cells a level holds -- not by the grid's size: 1 700 cells per
+            // level at 4096x2048 (3.1 M reached cells, 1 830 levels), 14 700 at 16384x8192 (50 M, 3 400); the line between them at 5 000)
+            const int level_pop = (int)(n_reached / std::max(levels, 1));
+            const bool sparse_levels = level_pop <= 5000;
+            const int look_through = look_env >= 0 ? look_env : (sparse_levels ? 1 : 0);
+            // (with a sum asked for only until it has arrived, 4096x2048 takes 256 blocks better than 128: 3.13 -> 2.86 ms; 16384x8192 does not: 32.7 -> 37.0)
+            const int blocks = std::min((waves + 3) / 4, nblocks_env > 0 ? nblocks_env : (sparse_levels ? 256 : 128));
+            hipLaunchKernelGGL(k_flow_dataflow, dim3(blocks), dim3(256), 0, st, fc, order.i(), n_reached, (const unsigned short *)mask.p, dcf.i(),
+                               down.f(), (unsigned *)acc.p, dtick_p, dtick_p + 1, look_through);
+            DMG_HIP(hipGetLastError());
+            int flow_err = 0;
+            DMG_HIP(hipMemcpyAsync(&flow_err, dtick_p + 1, 4, hipMemcpyDeviceToHost, st));
+            DMG_HIP(hipStreamSynchronize(st));
+            if (flow_err) return dmg_fail(DMG_EHIP, "flow: the upstream sums did not complete (a cell waited for a sum that was never published)");
+        }
     }
     hipLaunchKernelGGL(k_flow_pow, dim3(nb), dim3(256), 0, st, gdepth.i(), acc.f(), d_flow, exponent, N);
     DMG_HIP(hipGetLastError());
