@@ -564,12 +564,13 @@ __global__ __launch_bounds__(256) void k_flow_dataflow(flow_canvas fc, const int
         while (__builtin_amdgcn_ballot_w64(pending)) {
             if (pending) {
                 int missing = 0, which = 0;
+                // (every sum still missing is asked for before the first answer is looked at: one round trip a poll, not one a sum)
 #pragma unroll
                 for (int k = 0; k < 9; k++)
-                    if (k < nsrc) {
-                        if (v[k] == FLOW_NOT_READY) v[k] = __hip_atomic_load(acc + src[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (v[k] == FLOW_NOT_READY) { missing++; which = k; }
-                    }
+                    if (k < nsrc && v[k] == FLOW_NOT_READY) v[k] = __hip_atomic_load(acc + src[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int k = 0; k < 9; k++)
+                    if (k < nsrc && v[k] == FLOW_NOT_READY) { missing++; which = k; }
                 if (missing == 1 && look_through) {
                     int cell = 0;
 #pragma unroll
@@ -581,12 +582,15 @@ __global__ __launch_bounds__(256) void k_flow_dataflow(flow_canvas fc, const int
                     }
                     bool uready = true;
                     float usum = uown;
+                    unsigned uv[9];
+#pragma unroll
+                    for (int k = 0; k < 9; k++)
+                        if (k < unsrc) uv[k] = __hip_atomic_load(acc + usrc[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
                     for (int k = 0; k < 9; k++)
                         if (k < unsrc) {
-                            const unsigned uv = __hip_atomic_load(acc + usrc[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            uready = uready && uv != FLOW_NOT_READY;
-                            usum = __fadd_rn(usum, __uint_as_float(uv));
+                            uready = uready && uv[k] != FLOW_NOT_READY;
+                            usum = __fadd_rn(usum, __uint_as_float(uv[k]));
                         }
                     if (uready) {
 #pragma unroll
@@ -679,19 +683,30 @@ __global__ void k_flow_lake_offsets(const unsigned *__restrict__ skey, const int
 #define FLOW_BIG_LAKE 1024
 #define FLOW_WINDOW 2048
 // what a cell of phase A adds: its area and its upstream neighbours' sums, in FlowFilter::neighbours order (flow_sources without a lake)
+// the q-th neighbour in FlowFilter::neighbours order if it drains into (x0, y0) -- bit q of the cell's receiver mask -- and is on the canvas, or -1
+__device__ __forceinline__ int flow_source_at(const flow_canvas &fc, int x0, int y0, unsigned m, int q)
+{
+    const int W = fc.c.W, H = fc.c.H;
+    int x = x0 + c_ndx[q], y = y0 + c_ndy[q];
+    bool ok = (m & (unsigned)c_nbit[q]) != 0 && y >= 0 && y < H;
+    if (fc.wrap) x = x < 0 ? x + W : (x >= W ? x - W : x); else ok = ok && x >= 0 && x < W;
+    return ok ? y * W + x : -1;
+}
 template <int SCOPE>
 __device__ __forceinline__ float flow_catchment_sum(const flow_canvas &fc, int p, unsigned m, const float *__restrict__ own_row, const unsigned *acc)
 {
     const int W = fc.c.W, H = fc.c.H, x0 = p % W, y0 = p / W;
     float sum = own_row[y0];
-#pragma unroll
-    for (int q = 0; q < 8; q++) {
-        if (!(m & (unsigned)c_nbit[q])) continue;
-        int x = x0 + c_ndx[q], y = y0 + c_ndy[q];
-        if (fc.wrap) { if (x < 0) x += W; else if (x >= W) x -= W; } else if (x < 0 || x >= W) continue;
-        if (y < 0 || y >= H) continue;
-        sum = __fadd_rn(sum, __uint_as_float(__hip_atomic_load(acc + (y * W + x), __ATOMIC_RELAXED, SCOPE)));
-    }
+    // all the sums are asked for before the first is added: one round trip a level, not one a neighbour.  (Eight named values, not an
+    // array: the compiler makes a vector of an array and waits for every load to insert it.)
+#define FLOW_AT(q) flow_source_at(fc, x0, y0, m, q)
+#define FLOW_GET(q) const int a##q = FLOW_AT(q); unsigned v##q = 0; if (a##q >= 0) v##q = __hip_atomic_load(acc + a##q, __ATOMIC_RELAXED, SCOPE);
+#define FLOW_ADD(q) if (a##q >= 0) sum = __fadd_rn(sum, __uint_as_float(v##q));
+    FLOW_GET(0) FLOW_GET(1) FLOW_GET(2) FLOW_GET(3) FLOW_GET(4) FLOW_GET(5) FLOW_GET(6) FLOW_GET(7)
+    FLOW_ADD(0) FLOW_ADD(1) FLOW_ADD(2) FLOW_ADD(3) FLOW_ADD(4) FLOW_ADD(5) FLOW_ADD(6) FLOW_ADD(7)
+#undef FLOW_AT
+#undef FLOW_GET
+#undef FLOW_ADD
     return sum;
 }
 template <int BLOCK>
