@@ -502,6 +502,10 @@ __global__ void k_flow_level(flow_canvas fc, const int *__restrict__ order, int 
 // river times one L2 round trip.  Values cross CUs through sc1 (L2) loads and stores.  A poll budget turns a protocol
 // error into a failed call instead of a hung GPU.
 #define FLOW_NOT_READY 0xFFFFFFFFu
+__device__ __forceinline__ float dpp_prev_lane(float v)      // lane l <- lane l - 1 (wave_shr:1; lane 0 <- 0)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
+}
 // what a cell adds, in the order it adds it: the upstream neighbours in FlowFilter::neighbours order (:614-616), then the lake
 // connected to it (:617-619)
 __device__ __forceinline__ int flow_sources(const flow_canvas &fc, int p, const unsigned short *__restrict__ mask, const int *__restrict__ conn_from, int src[9])
@@ -788,15 +792,20 @@ __device__ __forceinline__ int flow_receiver(const flow_canvas &fc, const unsign
 
 // phase B, marking: from every cell a lake drains into, downstream to the catchment's sink (or to a cell somebody else has marked: the
 // one who marked it goes on from there)
+// ... and where every marked cell's sum goes next: the cell it drains to, or -- for a lake's sink -- the cell the lake drains into (next[],
+// -1 everywhere before; a river mouth keeps -1)
 __global__ __launch_bounds__(256) void k_flow_mark_affected(flow_canvas fc, const unsigned char *__restrict__ code, const int *__restrict__ conn_from,
-                                                            const int *__restrict__ gdepth, int *__restrict__ marked, size_t n)
+                                                            const int *__restrict__ gdepth, int *__restrict__ marked, int *__restrict__ next, size_t n)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n || conn_from[i] < 0 || gdepth[i] < 0) return;
+    next[conn_from[i]] = (int)i;
     int q = (int)i;
     for (int guard = 0; q >= 0 && guard < (1 << 24); guard++) {
         if (atomicExch(marked + q, 1) != 0) break;
-        q = flow_receiver(fc, code, q);
+        const int r = flow_receiver(fc, code, q);
+        if (r >= 0) next[q] = r;
+        q = r;
     }
 }
 
@@ -820,6 +829,178 @@ __global__ __launch_bounds__(256) void k_flow_collect_affected(const int *__rest
         key[slot] = (unsigned)gdepth[mine[t]];
         cell[slot] = (unsigned)mine[t];
         slot++;
+    }
+}
+
+// ---- phase B as a walk along the rivers (round 6) ---------------------------------------------------------------------------------------
+// As a dataflow over its cells in depth order phase B is one coherent store and one poll per cell of the longest river: ~0.57 us x 1 830
+// levels = 1.05 ms of a config-2 iteration, for 35 000 cells.  Here the marked cells are cut into REACHES -- stretches of river, each cell
+// draining into the next, through the lakes' sinks into the cells the lakes drain into (k_reach_choose) -- and every other sum a cell of a
+// reach adds is either final (phase A's) or the sum of the LAST cell of another reach, one level deeper.  So the cells are laid out reach by reach, the reaches in order of the depth of their last
+// cell, deepest first: whatever a cell waits for lies BEFORE it in the list.  A wave takes 64 consecutive cells; every lane collects the
+// sums its cell adds from outside its reach (polling, as in the dataflow) and the wave then runs down the reaches in registers -- lane l
+// takes lane l-1's sum through a DPP shift, adds it where the reference adds it (between the neighbours before it and those after it,
+// FlowFilter::neighbours order, then the connected lake: the same additions in the same order, the same bits) and hands its own on: a
+// few cycles per cell instead of a round trip to the L2.  Only a reach's first lane in a wave waits for another wave.  A sum not there yet
+// is the NaN it is stored as: it runs down its reach as NaN, and what is NaN after the run is not published and tried again.
+// The reaches.  Where several marked cells drain into one, the reach goes on from the one with the LONGEST marked river above it (any choice
+// gives the same sums; this one keeps the longest river -- the one everything waits for -- in as few reaches as its confluences allow, and
+// a reach that ends costs the next one a round trip to the L2).  top[c] = the greatest global depth among the marked cells above c, c
+// included: pointer jumping down next[], synchronous rounds (two copies of top and of the pointers), log2(longest river) of them.
+__global__ void k_reach_init(const unsigned *__restrict__ cell, const int *__restrict__ gdepth, const int *__restrict__ next,
+                             int *__restrict__ top_a, int *__restrict__ top_b, int *__restrict__ hop, int *__restrict__ tail, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned c = cell[i];
+    top_a[c] = top_b[c] = gdepth[c];
+    hop[c] = next[c];
+    tail[c] = (int)c;                                       // (k_reach_choose: the reach goes on, for all but its last cell)
+}
+__global__ void k_reach_height(const unsigned *__restrict__ cell, const int *__restrict__ hop_in, int *__restrict__ hop_out,
+                               const int *__restrict__ top_in, int *top_out, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned c = cell[i];
+    const int t = top_in[c], v = hop_in[c];
+    atomicMax(top_out + c, t);                              // (top_out is two rounds old)
+    if (v >= 0) atomicMax(top_out + v, t);
+    hop_out[c] = v >= 0 ? hop_in[v] : -1;
+}
+// for every marked cell: which of the marked cells draining into it the reach comes from; tail[u] = c for that one (the reach goes on), the
+// others keep tail[u] = u (their reach ends)
+__global__ void k_reach_choose(flow_canvas fc, const unsigned *__restrict__ cell, const unsigned short *__restrict__ mask, const int *__restrict__ conn_from,
+                               const int *__restrict__ marked, const int *__restrict__ top, int *__restrict__ tail, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c = (int)cell[i];
+    int src[9];
+    const int nsrc = flow_sources(fc, c, mask, conn_from, src);
+    int best = -1, best_top = -1;
+#pragma unroll
+    for (int k = 0; k < 9; k++)
+        if (k < nsrc && marked[src[k]]) { const int t = top[src[k]]; if (t > best_top) { best_top = t; best = src[k]; } }
+    if (best >= 0) tail[best] = c;
+}
+// tail[c] = the last cell of c's reach (pointer jumping in place: a pointer only ever moves down its own reach)
+__global__ void k_reach_tail(const unsigned *__restrict__ cell, int *tail, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned c = cell[i];
+    const int t = tail[c];
+    const int tt = __hip_atomic_load(tail + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tt != t) __hip_atomic_store(tail + c, tt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// keys: (depth of the reach's last cell, the reach -- its last cell --, the cell's own depth), all deepest first
+__global__ void k_flow_walk_keys(const unsigned *__restrict__ cell, const int *__restrict__ tail, const int *__restrict__ gdepth,
+                                 unsigned long long *__restrict__ key, int n, int depth_bits, int cell_bits, int max_depth)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned c = cell[i];
+    const unsigned w = (unsigned)tail[c];
+    key[i] = ((unsigned long long)(unsigned)(max_depth - gdepth[w]) << (cell_bits + depth_bits)) | ((unsigned long long)w << depth_bits) |
+             (unsigned long long)(unsigned)(max_depth - gdepth[c]);
+}
+
+__device__ __forceinline__ bool flow_is_nan(float x) { return (__float_as_uint(x) & 0x7FFFFFFFu) > 0x7F800000u; }
+
+__global__ __launch_bounds__(256) void k_flow_walk(flow_canvas fc, const unsigned long long *__restrict__ skey, const int *__restrict__ cells, int n, int depth_bits,
+                                                   const unsigned short *__restrict__ mask, const int *__restrict__ conn_from,
+                                                   const float *__restrict__ own_row, unsigned *acc, int *ticket, int *error)
+{
+    const int W = fc.c.W;
+    const int lane = threadIdx.x & 63;
+    for (;;) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(ticket, 64);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base >= n) return;
+        if (__hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+        const int i = base + lane;
+        const bool valid = i < n;
+        int p = 0, nsrc = 0, src[9], h = 9;                  // h: which of the sums the cell adds is its upstream neighbour in the reach (9: none in this wave)
+        float own = 0.0f;
+        bool linked = false;                                 // the lane before holds the cell before, in the same reach
+        if (valid) {
+            p = cells[i];
+            own = own_row[p / W];
+            nsrc = flow_sources(fc, p, mask, conn_from, src);
+            if (lane > 0 && (skey[i] >> depth_bits) == (skey[i - 1] >> depth_bits)) {
+                const int before = cells[i - 1];
+#pragma unroll
+                for (int k = 0; k < 9; k++) if (k < nsrc && src[k] == before) h = k;
+                linked = h < 9;
+                if (!linked) atomicOr(error, 2);             // (the cell before does not drain into this one: not a reach)
+            }
+        }
+        // how far a sum has to run inside this wave: the longest stretch of linked lanes
+        const unsigned long long heads = __builtin_amdgcn_ballot_w64(!linked);
+        const unsigned long long below = heads & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+        int run = lane - (63 - __builtin_clzll(below));     // (lane 0 is never linked: `below` has a bit)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) run = max(run, __shfl_xor(run, o));
+        const int hops = __builtin_amdgcn_readfirstlane(run);
+        int nafter = linked ? nsrc - 1 - h : 0;
+        int most_after = nafter;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) most_after = max(most_after, __shfl_xor(most_after, o));
+        most_after = __builtin_amdgcn_readfirstlane(most_after);
+
+        unsigned v[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) v[k] = FLOW_NOT_READY;
+        bool done = !valid;
+        float s = __uint_as_float(FLOW_NOT_READY);
+        int polls = 0;
+        const unsigned long long t_wait0 = __builtin_amdgcn_s_memrealtime();
+        while (__builtin_amdgcn_ballot_w64(!done)) {
+            // the sums from outside the reach: every one still missing is asked for, then looked at
+#pragma unroll
+            for (int k = 0; k < 9; k++)
+                if (!done && k < nsrc && k != h && v[k] == FLOW_NOT_READY) v[k] = __hip_atomic_load(acc + src[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bool ready = true;
+#pragma unroll
+            for (int k = 0; k < 9; k++)
+                if (k < nsrc && k != h && v[k] == FLOW_NOT_READY) ready = false;
+            // before: own + the sums added before the reach's (all of them for a cell that heads its reach here); after[j]: those added after it
+            float before = own, after[8];
+#pragma unroll
+            for (int k = 0; k < 9; k++)
+                if (k < nsrc && k < h) before = __fadd_rn(before, __uint_as_float(v[k]));
+            if (!ready) before = __uint_as_float(FLOW_NOT_READY);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                after[j] = 0.0f;
+#pragma unroll
+                for (int k = 1; k < 9; k++) if (k == h + 1 + j) after[j] = __uint_as_float(v[k]);
+            }
+            float cur = done ? s : (linked ? __uint_as_float(FLOW_NOT_READY) : before);
+            for (int hop = 0; hop < hops; hop++) {
+                const float carried = dpp_prev_lane(cur);
+                float t = __fadd_rn(before, carried);
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    if (j < most_after) { if (j < nafter) t = __fadd_rn(t, after[j]); }
+                if (linked && !done) cur = t;
+            }
+            const bool publish = !done && !flow_is_nan(cur);
+            if (publish) {
+                __hip_atomic_store(acc + p, __float_as_uint(cur), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s = cur;
+                done = true;
+            }
+            if (__builtin_amdgcn_ballot_w64(publish) == 0) {
+                if ((++polls & 1023) == 0 &&                 // two seconds without a sum: something upstream was never published
+                    (__builtin_amdgcn_s_memrealtime() - t_wait0 > 200000000ull || __hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                    atomicOr(error, 1);
+                    done = true;
+                } else __builtin_amdgcn_s_sleep(1);
+            }
+        }
     }
 }
 
@@ -1173,7 +1354,7 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
     static const bool by_levels = dmg_hook("DMG_FLOW_LEVELS") != nullptr;      // experiments: the level-synchronous form
     static const int two_env = [] { const char *e = dmg_hook("DMG_FLOW_TWO_PHASE"); return e ? atoi(e) : 1; }();   // 0: one pass over all cells in order of their global depth (through round 5)
     bool two_phase = two_env != 0 && !by_levels;
-    dev_buf acc, keyA, keyA2, idxA, orderA, sortA, tickA, lakeoff, smaskA;
+    dev_buf acc, keyA, keyA2, idxA, orderA, sortA, tickA, lakeoff, smaskA, nextB;
     DMG_ALLOC(acc, N * 4);
     DMG_ALLOC(tickA, 32);                                // [0] ticket A, [1] error A, [2] cells with a catchment, [3] their largest distance to their sink, [4] ticket B, [5] error B, [6] cells of phase B
     DMG_HIP(hipMemsetAsync(tickA.p, 0, 32, st));
@@ -1550,7 +1731,9 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
     // phase B's cells: marked from the connections' cells down to the sinks, listed with their global depths, their sums withdrawn
     if (two_phase) {
         DMG_HIP(hipMemsetAsync(tmp.p, 0, N * 4, st));
-        hipLaunchKernelGGL(k_flow_mark_affected, dim3(nb), dim3(256), 0, st, fc, (const unsigned char *)code.p, dcf.i(), gdepth.i(), tmp.i(), N);
+        DMG_ALLOC(nextB, N * 4);
+        DMG_HIP(hipMemsetAsync(nextB.p, 0xFF, N * 4, st));
+        hipLaunchKernelGGL(k_flow_mark_affected, dim3(nb), dim3(256), 0, st, fc, (const unsigned char *)code.p, dcf.i(), gdepth.i(), tmp.i(), nextB.i(), N);
         hipLaunchKernelGGL(k_flow_collect_affected, dim3(nbi), dim3(256), 0, st, tmp.i(), gdepth.i(), (unsigned *)acc.p, (unsigned *)keyA.p, (unsigned *)idxA.p, tickA.i() + 6, N);
         DMG_HIP(hipGetLastError());
     }
@@ -1576,7 +1759,40 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
         if (timing) fprintf(stderr, "[flow] two phases: %d cells with a catchment (deepest %d from its sink), %d of them behind a connection; %d levels of global depth\n",
                             tick_host[2], tick_host[3], n_aff, levels);
         lap("upload + depth sort");
-        if (n_aff > 0) {
+        static const int walk_env = [] { const char *e = dmg_hook("DMG_FLOW_WALK"); return e ? atoi(e) : 1; }();      // 0: phase B as a dataflow in depth order
+        int cell_bits = 1;
+        while ((1ull << cell_bits) < (unsigned long long)N) cell_bits++;
+        if (n_aff > 0 && walk_env != 0 && 2 * depth_bits + cell_bits <= 64) {
+            // the walk along the reaches (k_flow_walk): keys from the marks, the cells reach by reach, 64 to a wave
+            dev_buf wkey, wkey2, sortB, top[2], hop[2], tail;
+            DMG_ALLOC(wkey, (size_t)n_aff * 8); DMG_ALLOC(wkey2, (size_t)n_aff * 8);
+            DMG_ALLOC(top[0], N * 4); DMG_ALLOC(top[1], N * 4); DMG_ALLOC(hop[0], N * 4); DMG_ALLOC(hop[1], N * 4); DMG_ALLOC(tail, N * 4);
+            const dim3 lb((unsigned)((n_aff + 255) / 256));
+            const unsigned *const list = (const unsigned *)idxA.p;
+            hipLaunchKernelGGL(k_reach_init, lb, dim3(256), 0, st, list, gdepth.i(), nextB.i(), top[0].i(), top[1].i(), hop[0].i(), tail.i(), n_aff);
+            int cur_top = 0;
+            for (int r = 0; r < depth_bits; r++, cur_top ^= 1)      // (2^depth_bits > the longest river)
+                hipLaunchKernelGGL(k_reach_height, lb, dim3(256), 0, st, list, hop[cur_top].i(), hop[cur_top ^ 1].i(), top[cur_top].i(), top[cur_top ^ 1].i(), n_aff);
+            hipLaunchKernelGGL(k_reach_choose, lb, dim3(256), 0, st, fc, list, (const unsigned short *)mask.p, dcf.i(), tmp.i(), top[cur_top].i(), tail.i(), n_aff);
+            for (int r = 0; r < depth_bits; r++) hipLaunchKernelGGL(k_reach_tail, lb, dim3(256), 0, st, list, tail.i(), n_aff);
+            hipLaunchKernelGGL(k_flow_walk_keys, lb, dim3(256), 0, st, list, tail.i(), gdepth.i(), (unsigned long long *)wkey.p, n_aff, depth_bits, cell_bits, max_depth);
+            size_t sb = 0;
+            (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sb, (const unsigned long long *)wkey.p, (unsigned long long *)wkey2.p, (const unsigned *)idxA.p,
+                                                     (unsigned *)orderA.p, n_aff, 0, 2 * depth_bits + cell_bits, st);
+            DMG_ALLOC(sortB, sb + 256);
+            DMG_HIP(hipcub::DeviceRadixSort::SortPairs(sortB.p, sb, (const unsigned long long *)wkey.p, (unsigned long long *)wkey2.p, (const unsigned *)idxA.p,
+                                                       (unsigned *)orderA.p, n_aff, 0, 2 * depth_bits + cell_bits, st));
+            const int waves = (n_aff + 63) / 64;
+            const int blocks = std::min((waves + 3) / 4, nblocks_env > 0 ? nblocks_env : 256);
+            hipLaunchKernelGGL(k_flow_walk, dim3(blocks), dim3(256), 0, st, fc, (const unsigned long long *)wkey2.p, orderA.i(), n_aff, depth_bits,
+                               (const unsigned short *)mask.p, dcf.i(), down.f(), (unsigned *)acc.p, tickA.i() + 4, tickA.i() + 5);
+            DMG_HIP(hipGetLastError());
+            int flow_err = 0;
+            DMG_HIP(hipMemcpyAsync(&flow_err, tickA.i() + 5, 4, hipMemcpyDeviceToHost, st));
+            DMG_HIP(hipStreamSynchronize(st));
+            if (flow_err) return dmg_fail(DMG_EHIP, flow_err & 2 ? "flow: the cells of a reach do not drain into each other (the marks and the sort disagree)"
+                                                                 : "flow: the upstream sums did not complete (a cell waited for a sum that was never published)");
+        } else if (n_aff > 0) {
             size_t sb = 0;
             (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sb, (const unsigned *)keyA.p, (unsigned *)keyA2.p, (const unsigned *)idxA.p, (unsigned *)orderA.p, n_aff, 0, depth_bits, st);
             dev_buf sortB;
