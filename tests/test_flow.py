@@ -296,3 +296,30 @@ def test_flow_parallel_growth_equals_serial_at_size():
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         outs[mode] = [l.split()[:4] for l in r.stdout.strip().splitlines()]
     assert len(outs["serial"]) == 4 and outs["serial"] == outs["parallel"], (outs["serial"], outs["parallel"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"DMG_FLOW_WALK": "0"}, {"DMG_FLOW_TWO_PHASE": "0"}], ids=["phase-B-dataflow", "one-pass"])
+def test_flow_suite_through_the_other_sum_forms(env):
+    """Round 6: the upstream sums are formed in two phases -- inside the catchments beside the host's growth, then along the reaches
+    behind the connections (flow.hip, k_flow_catchment_sums / k_flow_walk).  The forms they replaced stay as fallbacks (a catchment
+    deeper than the keys of phase A have bits for; more levels than the walk's keys hold): this file's oracle comparisons once more
+    through each of them, in a child process."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_flow.py"), "-q", "-m", "gpu", "-x", "-k",
+                        "matches_oracle or mouth_filter or selection or lake_drawing or round_by_round or conservation"],
+                       cwd=root, env=dict(os.environ, **env), capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_flow_sum_forms_equal_at_size():
+    """the same flow fields, bit for bit (SHA-256), from the two-phase sums with the walk along the reaches (the default), with phase B
+    as a dataflow, and from the one pass in depth order, at 4096x2048 and 16384x8192, with and without lake drawing"""
+    outs = {}
+    for name, env in (("walk", {}), ("dataflow", {"DMG_FLOW_WALK": "0"}), ("one pass", {"DMG_FLOW_TWO_PHASE": "0"})):
+        r = _flow_child(_GROWTH_CHILD, env)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        outs[name] = [l.split()[:4] for l in r.stdout.strip().splitlines()]
+    assert len(outs["walk"]) == 4 and outs["walk"] == outs["dataflow"] == outs["one pass"], outs
