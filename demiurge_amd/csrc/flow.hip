@@ -699,7 +699,7 @@ __device__ __forceinline__ int flow_source_at(const flow_canvas &fc, int x0, int
 template <int SCOPE>
 __device__ __forceinline__ float flow_catchment_sum(const flow_canvas &fc, int p, unsigned m, const float *__restrict__ own_row, const unsigned *acc)
 {
-    const int W = fc.c.W, H = fc.c.H, x0 = p % W, y0 = p / W;
+    const int W = fc.c.W, x0 = p % W, y0 = p / W;
     float sum = own_row[y0];
     // all the sums are asked for before the first is added: one round trip a level, not one a neighbour.  (Eight named values, not an
     // array: the compiler makes a vector of an array and waits for every load to insert it.)
@@ -778,10 +778,9 @@ __global__ __launch_bounds__(BLOCK ? 1024 : 256) void k_flow_catchment_sums(flow
 }
 
 // the cell a cell drains to (k_flow_parent's rule), or -1
-__device__ __forceinline__ int flow_receiver(const flow_canvas &fc, const unsigned char *__restrict__ code, int i)
+__device__ __forceinline__ int flow_receiver_of(const flow_canvas &fc, int cd, int i)
 {
     const int W = fc.c.W, H = fc.c.H;
-    const int cd = code[i];
     if (cd == 0 || cd == 5) return -1;
     const int dx = (cd - 1) % 3 - 1, dy = (cd - 1) / 3 - 1;
     int x = i % W + dx, y = i / W + dy;
@@ -800,12 +799,16 @@ __global__ __launch_bounds__(256) void k_flow_mark_affected(flow_canvas fc, cons
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n || conn_from[i] < 0 || gdepth[i] < 0) return;
     next[conn_from[i]] = (int)i;
-    int q = (int)i;
-    for (int guard = 0; q >= 0 && guard < (1 << 24); guard++) {
+    // (a step is one round trip: where the cell drains to is known from its code, fetched a step ahead, so the next cell's code is on its
+    // way while the mark is being set)
+    int q = (int)i, cd = code[q];
+    for (int guard = 0; guard < (1 << 24); guard++) {
+        const int r = flow_receiver_of(fc, cd, q);
+        const int ncd = r >= 0 ? (int)code[r] : 0;
         if (atomicExch(marked + q, 1) != 0) break;
-        const int r = flow_receiver(fc, code, q);
-        if (r >= 0) next[q] = r;
-        q = r;
+        if (r < 0) break;
+        next[q] = r;
+        q = r; cd = ncd;
     }
 }
 
