@@ -125,6 +125,7 @@ int dmg_trim(dmg_ctx *c)
     for (auto &kv : c->scratch_pool) (void)hipFree(kv.second);
     c->scratch_pool.clear();
     c->scratch_pool_bytes = 0;
+    if (c->flow_rows) { (void)hipFree(c->flow_rows); c->flow_rows = nullptr; }      // (the flow solve builds them again)
     return DMG_OK;
 }
 

@@ -56,6 +56,17 @@ struct dmg_ctx {
     // (the count starts at one: the owner's reference, given back by dmg_destroy)
     std::atomic<int> children{1};
     std::atomic<bool> destroy_requested{false};
+    // the flow solve's memory between calls (flow.hip): how many rounds of pointer doubling the last solve of a grid this size needed -- the
+    // next one asks whether anything still moved from that round on, not from the seventh (an erosion run's rivers change slowly, a
+    // question is a synchronisation).  A hint: a wrong one costs a round or a question, never a result.
+    // ... and the flow solve's per-row tables of the last grid (pixel sizes of the direction pass, cell areas of the sums: three floats a
+    // row, the same every erosion round -- recomputed and uploaded per solve they were 2 048 cosines and three synchronisations of an
+    // iteration); device memory of the context, released by dmg_trim
+    dmg_grid flow_rows_grid = {};
+    float *flow_rows = nullptr;         // [3][H]: dx, dy, area
+    size_t flow_hint_cells = 0;
+    int flow_hint_rounds = 0;
+    unsigned flow_hint_age = 0;
 };
 void dmg_ctx_retain(dmg_ctx *ctx);
 void dmg_ctx_release(dmg_ctx *ctx);

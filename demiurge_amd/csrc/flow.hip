@@ -850,64 +850,73 @@ __global__ __launch_bounds__(256) void k_flow_collect_affected(const int *__rest
 // gives the same sums; this one keeps the longest river -- the one everything waits for -- in as few reaches as its confluences allow, and
 // a reach that ends costs the next one a round trip to the L2).  top[c] = the greatest global depth among the marked cells above c, c
 // included: pointer jumping down next[], synchronous rounds (two copies of top and of the pointers), log2(longest river) of them.
-__global__ void k_reach_init(const unsigned *__restrict__ cell, const int *__restrict__ gdepth, const int *__restrict__ next,
-                             int *__restrict__ top_a, int *__restrict__ top_b, int *__restrict__ hop, int *__restrict__ tail, int n)
+// (what another thread of the same launch may have written is read with a coherent load)
+__device__ __forceinline__ int reach_peek(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+struct reach_tables {
+    const unsigned *cell;            // the marked cells, n of them
+    const int *gdepth, *next, *marked;
+    int *top[2], *hop[2], *tail;
+    unsigned long long *key;
+    int n, rounds, depth_bits, cell_bits, max_depth;
+};
+__device__ __forceinline__ void reach_init(const reach_tables &t, int i)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const unsigned c = cell[i];
-    top_a[c] = top_b[c] = gdepth[c];
-    hop[c] = next[c];
-    tail[c] = (int)c;                                       // (k_reach_choose: the reach goes on, for all but its last cell)
+    const unsigned c = t.cell[i];
+    t.top[0][c] = t.top[1][c] = t.gdepth[c];
+    t.hop[0][c] = t.next[c];
+    t.tail[c] = (int)c;                                     // (reach_choose: the reach goes on, for all but its last cell)
 }
-__global__ void k_reach_height(const unsigned *__restrict__ cell, const int *__restrict__ hop_in, int *__restrict__ hop_out,
-                               const int *__restrict__ top_in, int *top_out, int n)
+__device__ __forceinline__ void reach_height(const reach_tables &t, int i, int from)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const unsigned c = cell[i];
-    const int t = top_in[c], v = hop_in[c];
-    atomicMax(top_out + c, t);                              // (top_out is two rounds old)
-    if (v >= 0) atomicMax(top_out + v, t);
-    hop_out[c] = v >= 0 ? hop_in[v] : -1;
+    const unsigned c = t.cell[i];
+    const int h = reach_peek(t.top[from] + c), v = reach_peek(t.hop[from] + c);
+    atomicMax(t.top[from ^ 1] + c, h);                      // (the other copy is two rounds old)
+    if (v >= 0) atomicMax(t.top[from ^ 1] + v, h);
+    t.hop[from ^ 1][c] = v >= 0 ? reach_peek(t.hop[from] + v) : -1;
 }
 // for every marked cell: which of the marked cells draining into it the reach comes from; tail[u] = c for that one (the reach goes on), the
 // others keep tail[u] = u (their reach ends)
-__global__ void k_reach_choose(flow_canvas fc, const unsigned *__restrict__ cell, const unsigned short *__restrict__ mask, const int *__restrict__ conn_from,
-                               const int *__restrict__ marked, const int *__restrict__ top, int *__restrict__ tail, int n)
+__device__ __forceinline__ void reach_choose(const reach_tables &t, const flow_canvas &fc, const unsigned short *__restrict__ mask,
+                                             const int *__restrict__ conn_from, int i, int from)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int c = (int)cell[i];
+    const int c = (int)t.cell[i];
     int src[9];
     const int nsrc = flow_sources(fc, c, mask, conn_from, src);
     int best = -1, best_top = -1;
 #pragma unroll
     for (int k = 0; k < 9; k++)
-        if (k < nsrc && marked[src[k]]) { const int t = top[src[k]]; if (t > best_top) { best_top = t; best = src[k]; } }
-    if (best >= 0) tail[best] = c;
+        if (k < nsrc && t.marked[src[k]]) { const int h = reach_peek(t.top[from] + src[k]); if (h > best_top) { best_top = h; best = src[k]; } }
+    if (best >= 0) t.tail[best] = c;
 }
 // tail[c] = the last cell of c's reach (pointer jumping in place: a pointer only ever moves down its own reach)
-__global__ void k_reach_tail(const unsigned *__restrict__ cell, int *tail, int n)
+__device__ __forceinline__ void reach_tail(const reach_tables &t, int i)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const unsigned c = cell[i];
-    const int t = tail[c];
-    const int tt = __hip_atomic_load(tail + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (tt != t) __hip_atomic_store(tail + c, tt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned c = t.cell[i];
+    const int e = reach_peek(t.tail + c);
+    const int ee = reach_peek(t.tail + e);
+    if (ee != e) __hip_atomic_store(t.tail + c, ee, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // keys: (depth of the reach's last cell, the reach -- its last cell --, the cell's own depth), all deepest first
-__global__ void k_flow_walk_keys(const unsigned *__restrict__ cell, const int *__restrict__ tail, const int *__restrict__ gdepth,
-                                 unsigned long long *__restrict__ key, int n, int depth_bits, int cell_bits, int max_depth)
+__device__ __forceinline__ void reach_key(const reach_tables &t, int i)
+{
+    const unsigned c = t.cell[i];
+    const unsigned w = (unsigned)reach_peek(t.tail + c);
+    t.key[i] = ((unsigned long long)(unsigned)(t.max_depth - t.gdepth[w]) << (t.cell_bits + t.depth_bits)) | ((unsigned long long)w << t.depth_bits) |
+               (unsigned long long)(unsigned)(t.max_depth - t.gdepth[c]);
+}
+// one launch per step (any number of cells) ...
+__global__ void k_reach_init(reach_tables t) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < t.n) reach_init(t, i); }
+__global__ void k_reach_height(reach_tables t, int from) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < t.n) reach_height(t, i, from); }
+__global__ void k_reach_choose(reach_tables t, flow_canvas fc, const unsigned short *__restrict__ mask, const int *__restrict__ conn_from, int from)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const unsigned c = cell[i];
-    const unsigned w = (unsigned)tail[c];
-    key[i] = ((unsigned long long)(unsigned)(max_depth - gdepth[w]) << (cell_bits + depth_bits)) | ((unsigned long long)w << depth_bits) |
-             (unsigned long long)(unsigned)(max_depth - gdepth[c]);
+    if (i < t.n) reach_choose(t, fc, mask, conn_from, i, from);
 }
+__global__ void k_reach_tail(reach_tables t) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < t.n) reach_tail(t, i); }
+__global__ void k_flow_walk_keys(reach_tables t) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < t.n) reach_key(t, i); }
+// (Measured and dropped: ONE workgroup of 1024 threads taking all the steps with a barrier between them instead of 2 x log2(levels) + 3
+// launches -- 35 000 cells are 34 per thread, each a chain of coherent loads and an atomic, one after the other: 1.5 ms against the
+// launches' 0.17 ms.)
 
 __device__ __forceinline__ bool flow_is_nan(float x) { return (__float_as_uint(x) & 0x7FFFFFFFu) > 0x7F800000u; }
 
@@ -1199,19 +1208,29 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
     fc.cm = make_canvas(gm, dmg_topology_of(gm));
     fc.wrap = fabs(grid.coords[3] - grid.coords[2]) > 2 * M_PI - 1e-4;       // :47
 
-    // per-row tables: pixelsize() of the direction pass, cell area of calculateflow (double arithmetic, :608-613)
-    std::vector<float> dxr(H), dyr(H), own(H);
-    float pwx = (float)(grid.circumference * (grid.coords[3] - grid.coords[2]) / (2 * M_PI) / W);
-    float pwy = (float)(grid.circumference * (grid.coords[1] - grid.coords[0]) / (2 * M_PI) / H);
-    for (int y = 0; y < H; y++) {
-        dmg_row_pixelsize(gm, y, &dxr[y], &dyr[y]);
-        float fy = (float)y / H;
-        float geoy = (fy * (grid.coords[1] - grid.coords[0]) + grid.coords[0]);
-        own[y] = (float)(pwy * pwx * cos((double)geoy) * 1e-5);      // unqualified cos(float) = the C double cos there
+    // per-row tables: pixelsize() of the direction pass, cell area of calculateflow (double arithmetic, :608-613); kept with the context
+    // from one solve of a grid to the next (dmg_ctx::flow_rows)
+    if (!ctx->flow_rows || memcmp(&ctx->flow_rows_grid, &grid, sizeof(dmg_grid)) != 0) {
+        std::vector<float> rows((size_t)3 * H);
+        float pwx = (float)(grid.circumference * (grid.coords[3] - grid.coords[2]) / (2 * M_PI) / W);
+        float pwy = (float)(grid.circumference * (grid.coords[1] - grid.coords[0]) / (2 * M_PI) / H);
+        for (int y = 0; y < H; y++) {
+            dmg_row_pixelsize(gm, y, &rows[y], &rows[(size_t)H + y]);
+            float fy = (float)y / H;
+            float geoy = (fy * (grid.coords[1] - grid.coords[0]) + grid.coords[0]);
+            rows[(size_t)2 * H + y] = (float)(pwy * pwx * cos((double)geoy) * 1e-5);      // unqualified cos(float) = the C double cos there
+        }
+        DMG_HIP(hipStreamSynchronize(st));                   // (a solve still using the old tables)
+        if (ctx->flow_rows) { (void)hipFree(ctx->flow_rows); ctx->flow_rows = nullptr; }
+        if (hipMalloc((void **)&ctx->flow_rows, rows.size() * 4) != hipSuccess) { ctx->flow_rows = nullptr; return dmg_fail(DMG_ENOMEM, "hipMalloc(%zu) failed", rows.size() * 4); }
+        DMG_HIP(hipMemcpyAsync(ctx->flow_rows, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, st));
+        DMG_HIP(hipStreamSynchronize(st));                   // `rows` is a host temporary
+        ctx->flow_rows_grid = grid;
     }
-    dev_buf ddx, ddy, down, hb, tmp, code, mask, par[2], dst[2], label, changed, count;
+    struct row_table { const float *p; const float *f() const { return p; } };
+    const row_table ddx{ ctx->flow_rows }, ddy{ ctx->flow_rows + H }, down{ ctx->flow_rows + (size_t)2 * H };
+    dev_buf hb, tmp, code, mask, par[2], dst[2], label, changed, count;
     int rc;
-    if ((rc = upload_vec(ctx, ddx, dxr)) || (rc = upload_vec(ctx, ddy, dyr)) || (rc = upload_vec(ctx, down, own))) return rc;
     DMG_ALLOC(hb, N * 4); DMG_ALLOC(tmp, N * 4); DMG_ALLOC(code, N); DMG_ALLOC(mask, N * 2);
     DMG_ALLOC(par[0], N * 4); DMG_ALLOC(par[1], N * 4); DMG_ALLOC(dst[0], N * 4); DMG_ALLOC(dst[1], N * 4);
     DMG_ALLOC(label, N * 4); DMG_ALLOC(changed, 128 * 4); DMG_ALLOC(count, 4);      // changed: a word per round (cleared once, not once per round)
@@ -1229,17 +1248,21 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
     hipLaunchKernelGGL(k_flow_parent, dim3(nb), dim3(256), 0, st, fc, (const unsigned char *)code.p, par[0].i(), dst[0].i());
     int cur = 0;
     DMG_HIP(hipMemsetAsync(changed.p, 0, 128 * 4, st));
+    // (a round past the last one changes nothing: rivers of 2^8 cells and more are the rule, so the first rounds run without asking; a
+    // readback costs more than the round.  From which round on to ask: the one the last solve of this size ended with -- one question
+    // where the seventh round on were three -- and every 32nd solve two rounds earlier, so that the hint follows rivers that got shorter.)
+    int first_ask = N >= ((size_t)1 << 20) ? 7 : 0;
+    if (ctx->flow_hint_cells == N && ctx->flow_hint_rounds > first_ask)
+        first_ask = std::max(first_ask, ctx->flow_hint_rounds - ((++ctx->flow_hint_age & 31u) == 0 ? 2 : 0));
     for (int it = 0; it < 40; it++) {
         hipLaunchKernelGGL(k_flow_jump, dim3(nb), dim3(256), 0, st, par[cur].i(), dst[cur].i(), par[cur ^ 1].i(), dst[cur ^ 1].i(), N, changed.i() + it, it == 0 ? 1 : 0);
         DMG_HIP(hipGetLastError());
         cur ^= 1;
-        // (a round past the last one changes nothing: rivers of 2^8 cells and more are the rule, so the first rounds run
-        // without asking; a readback costs more than the round)
-        if (it < 7 && N >= ((size_t)1 << 20)) continue;
+        if (it < first_ask) continue;
         int ch = 0;
         DMG_HIP(hipMemcpyAsync(&ch, changed.i() + it, 4, hipMemcpyDeviceToHost, st));
         DMG_HIP(hipStreamSynchronize(st));
-        if (!ch) break;
+        if (!ch) { ctx->flow_hint_cells = N; ctx->flow_hint_rounds = it; break; }
     }
     hipLaunchKernelGGL(k_flow_label, dim3(nb), dim3(256), 0, st, par[cur].i(), (const unsigned char *)code.p, label.i(), N);
 
@@ -1727,7 +1750,8 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
         hipLaunchKernelGGL(k_lake_scatter, dim3(lb), dim3(256), 0, st, dp[b], dof[b], dlv[b], (const unsigned char *)dmo.p, sinkc.i(),
                            dlo.i(), draw_lakes ? dlevel.f() : nullptr, dmax.i() + 1, nlakes);
         DMG_HIP(hipGetLastError());
-        DMG_HIP(hipStreamSynchronize(st));                   // the tables above are released here
+        // (no synchronisation here: the tables above go back to the context's pool, whose reuse is ordered by this stream, and the host
+        // vectors they were filled from live until the solve returns)
     }
     hipLaunchKernelGGL(k_flow_gdepth, dim3(nbi), dim3(256), 0, st, label.i(), dst[cur].i(), dlo.i(), gdepth.i(), dmax.i(), N);
     DMG_HIP(hipGetLastError());
@@ -1771,14 +1795,19 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
             DMG_ALLOC(wkey, (size_t)n_aff * 8); DMG_ALLOC(wkey2, (size_t)n_aff * 8);
             DMG_ALLOC(top[0], N * 4); DMG_ALLOC(top[1], N * 4); DMG_ALLOC(hop[0], N * 4); DMG_ALLOC(hop[1], N * 4); DMG_ALLOC(tail, N * 4);
             const dim3 lb((unsigned)((n_aff + 255) / 256));
-            const unsigned *const list = (const unsigned *)idxA.p;
-            hipLaunchKernelGGL(k_reach_init, lb, dim3(256), 0, st, list, gdepth.i(), nextB.i(), top[0].i(), top[1].i(), hop[0].i(), tail.i(), n_aff);
-            int cur_top = 0;
-            for (int r = 0; r < depth_bits; r++, cur_top ^= 1)      // (2^depth_bits > the longest river)
-                hipLaunchKernelGGL(k_reach_height, lb, dim3(256), 0, st, list, hop[cur_top].i(), hop[cur_top ^ 1].i(), top[cur_top].i(), top[cur_top ^ 1].i(), n_aff);
-            hipLaunchKernelGGL(k_reach_choose, lb, dim3(256), 0, st, fc, list, (const unsigned short *)mask.p, dcf.i(), tmp.i(), top[cur_top].i(), tail.i(), n_aff);
-            for (int r = 0; r < depth_bits; r++) hipLaunchKernelGGL(k_reach_tail, lb, dim3(256), 0, st, list, tail.i(), n_aff);
-            hipLaunchKernelGGL(k_flow_walk_keys, lb, dim3(256), 0, st, list, tail.i(), gdepth.i(), (unsigned long long *)wkey.p, n_aff, depth_bits, cell_bits, max_depth);
+            reach_tables rt;
+            rt.cell = (const unsigned *)idxA.p; rt.gdepth = gdepth.i(); rt.next = nextB.i(); rt.marked = tmp.i();
+            rt.top[0] = top[0].i(); rt.top[1] = top[1].i(); rt.hop[0] = hop[0].i(); rt.hop[1] = hop[1].i(); rt.tail = tail.i();
+            rt.key = (unsigned long long *)wkey.p;
+            rt.n = n_aff; rt.rounds = depth_bits; rt.depth_bits = depth_bits; rt.cell_bits = cell_bits; rt.max_depth = max_depth;      // (2^depth_bits > the longest river)
+            {
+                hipLaunchKernelGGL(k_reach_init, lb, dim3(256), 0, st, rt);
+                int from = 0;
+                for (int r = 0; r < rt.rounds; r++, from ^= 1) hipLaunchKernelGGL(k_reach_height, lb, dim3(256), 0, st, rt, from);
+                hipLaunchKernelGGL(k_reach_choose, lb, dim3(256), 0, st, rt, fc, (const unsigned short *)mask.p, dcf.i(), from);
+                for (int r = 0; r < rt.rounds; r++) hipLaunchKernelGGL(k_reach_tail, lb, dim3(256), 0, st, rt);
+                hipLaunchKernelGGL(k_flow_walk_keys, lb, dim3(256), 0, st, rt);
+            }
             size_t sb = 0;
             (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sb, (const unsigned long long *)wkey.p, (unsigned long long *)wkey2.p, (const unsigned *)idxA.p,
                                                      (unsigned *)orderA.p, n_aff, 0, 2 * depth_bits + cell_bits, st);
