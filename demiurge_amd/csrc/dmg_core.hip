@@ -147,6 +147,9 @@ static void ctx_free(dmg_ctx *c)
 {
     (void)hipSetDevice(c->device);
     (void)dmg_trim(c);
+    if (c->flow_fork) (void)hipEventDestroy(c->flow_fork);
+    if (c->flow_join) (void)hipEventDestroy(c->flow_join);
+    if (c->flow_side) (void)hipStreamDestroy(c->flow_side);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);

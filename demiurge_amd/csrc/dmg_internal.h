@@ -62,6 +62,9 @@ struct dmg_ctx {
     // ... and the flow solve's per-row tables of the last grid (pixel sizes of the direction pass, cell areas of the sums: three floats a
     // row, the same every erosion round -- recomputed and uploaded per solve they were 2 048 cosines and three synchronisations of an
     // iteration); device memory of the context, released by dmg_trim
+    // a second stream and two events for the flow solve (created at its first use): the small catchments' sums run beside the large ones'
+    hipStream_t flow_side = nullptr;
+    hipEvent_t flow_fork = nullptr, flow_join = nullptr;
     dmg_grid flow_rows_grid = {};
     float *flow_rows = nullptr;         // [3][H]: dx, dy, area
     size_t flow_hint_cells = 0;

@@ -1407,10 +1407,21 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
             DMG_ALLOC(smaskA, N * 2);
             hipLaunchKernelGGL(k_flow_lake_offsets, dim3(nb), dim3(256), 0, st, (const unsigned *)keyA2.p, orderA.i(), (const unsigned short *)mask.p,
                                (const int *)(tickA.i() + 2), lakeoff.i(), (unsigned short *)smaskA.p, nlakes, N);
+            // the large catchments (a few hundred workgroups, bound by the steps of the deepest) and the small ones (tens of thousands of
+            // waves) do not wait for each other: the small ones run on a second stream beside the large
+            if (!ctx->flow_side) {
+                DMG_HIP(hipStreamCreateWithFlags(&ctx->flow_side, hipStreamNonBlocking));
+                DMG_HIP(hipEventCreateWithFlags(&ctx->flow_fork, hipEventDisableTiming));
+                DMG_HIP(hipEventCreateWithFlags(&ctx->flow_join, hipEventDisableTiming));
+            }
+            DMG_HIP(hipEventRecord(ctx->flow_fork, st));
+            DMG_HIP(hipStreamWaitEvent(ctx->flow_side, ctx->flow_fork, 0));
             hipLaunchKernelGGL(k_flow_catchment_sums<1>, dim3((unsigned)nlakes), dim3(1024), 0, st, fc, (const unsigned *)keyA2.p, orderA.i(), lakeoff.i(),
-                               (const unsigned short *)smaskA.p, down.f(), (unsigned *)acc.p, nlakes);          // the large catchments first: they take longest
-            hipLaunchKernelGGL(k_flow_catchment_sums<0>, dim3((unsigned)((nlakes + 3) / 4)), dim3(256), 0, st, fc, (const unsigned *)keyA2.p, orderA.i(), lakeoff.i(),
                                (const unsigned short *)smaskA.p, down.f(), (unsigned *)acc.p, nlakes);
+            hipLaunchKernelGGL(k_flow_catchment_sums<0>, dim3((unsigned)((nlakes + 3) / 4)), dim3(256), 0, ctx->flow_side, fc, (const unsigned *)keyA2.p, orderA.i(),
+                               lakeoff.i(), (const unsigned short *)smaskA.p, down.f(), (unsigned *)acc.p, nlakes);
+            DMG_HIP(hipEventRecord(ctx->flow_join, ctx->flow_side));
+            DMG_HIP(hipStreamWaitEvent(st, ctx->flow_join, 0));
             (void)key_bits;
         }
         DMG_HIP(hipGetLastError());
@@ -1647,8 +1658,12 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
     std::vector<int> stat_depth;
     int stat_maxdepth = 0, stat_from = 0, stat_s = 0; long long stat_ncascade = 0, stat_cur = 0, stat_maxcascade = 0, stat_multi = 0, stat_inmulti = 0;
     float stat_h = 0.0f; bool stat_have = false;
+    const auto tg0 = std::chrono::steady_clock::now();
     for (int lake : mouths) push_next(lake, true);
+    const auto tg1 = std::chrono::steady_clock::now();
+    long long npop = 0, npush0 = (long long)candidates.count;
     while (!candidates.empty()) {
+        npop++;
         const Cand top = candidates.top();
         candidates.pop();
         const int c = top.idx;
@@ -1684,6 +1699,8 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
         push_next(top.lake);                                           // (independent of the next line: disjoint lakes)
         push_next(top.from);
     }
+    if (timing) fprintf(stderr, "[flow] growth on the host: the mouths' first passes %.3f ms (%lld pushed), the growth %.3f ms (%lld pops)\n", std::chrono::duration<double, std::milli>(tg1 - tg0).count(), npush0,
+                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tg1).count(), npop);
     if (timing) fprintf(stderr, "[flow] growth: %zu connections, deepest lake %d hops from its river mouth; %lld cascades (a new highest pass = a new cascade), "
                                 "%lld of them with more than one lake holding %lld lakes, the largest %lld lakes\n", assigned.size(), stat_maxdepth, stat_ncascade, stat_multi, stat_inmulti, stat_maxcascade);
     }
