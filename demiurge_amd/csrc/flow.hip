@@ -702,13 +702,24 @@ __device__ __forceinline__ float flow_catchment_sum(const flow_canvas &fc, int p
     const int W = fc.c.W, x0 = p % W, y0 = p / W;
     float sum = own_row[y0];
     // all the sums are asked for before the first is added: one round trip a level, not one a neighbour.  (Eight named values, not an
-    // array: the compiler makes a vector of an array and waits for every load to insert it.)
-#define FLOW_AT(q) flow_source_at(fc, x0, y0, m, q)
-#define FLOW_GET(q) const int a##q = FLOW_AT(q); unsigned v##q = 0; if (a##q >= 0) v##q = __hip_atomic_load(acc + a##q, __ATOMIC_RELAXED, SCOPE);
+    // array: the compiler makes a vector of an array and waits for every load to insert it.)  Where they are: a cell off the canvas' edges
+    // -- all but one in a thousand -- has its q-th neighbour at a fixed distance in memory (a bit test and an add); the general rule
+    // (wrap-around, the rows at the poles: ~45 instructions a neighbour, and the large catchments' kernel is bound by its instructions)
+    // is for the rest.
+    int a0, a1, a2, a3, a4, a5, a6, a7;
+    if (x0 > 0 && x0 < W - 1 && y0 > 0 && y0 < fc.c.H - 1) {
+#define FLOW_NEAR(q, dx, dy, bit) a##q = (m & bit##u) ? p + (dy) * W + (dx) : -1;
+        FLOW_NEAR(0, -1, -1, 1) FLOW_NEAR(1, 0, -1, 2) FLOW_NEAR(2, 1, -1, 4) FLOW_NEAR(3, -1, 0, 8)
+        FLOW_NEAR(4, 1, 0, 32) FLOW_NEAR(5, -1, 1, 64) FLOW_NEAR(6, 0, 1, 128) FLOW_NEAR(7, 1, 1, 256)      // (c_ndx, c_ndy, c_nbit)
+#undef FLOW_NEAR
+    } else {
+        a0 = flow_source_at(fc, x0, y0, m, 0); a1 = flow_source_at(fc, x0, y0, m, 1); a2 = flow_source_at(fc, x0, y0, m, 2); a3 = flow_source_at(fc, x0, y0, m, 3);
+        a4 = flow_source_at(fc, x0, y0, m, 4); a5 = flow_source_at(fc, x0, y0, m, 5); a6 = flow_source_at(fc, x0, y0, m, 6); a7 = flow_source_at(fc, x0, y0, m, 7);
+    }
+#define FLOW_GET(q) unsigned v##q = 0; if (a##q >= 0) v##q = __hip_atomic_load(acc + a##q, __ATOMIC_RELAXED, SCOPE);
 #define FLOW_ADD(q) if (a##q >= 0) sum = __fadd_rn(sum, __uint_as_float(v##q));
     FLOW_GET(0) FLOW_GET(1) FLOW_GET(2) FLOW_GET(3) FLOW_GET(4) FLOW_GET(5) FLOW_GET(6) FLOW_GET(7)
     FLOW_ADD(0) FLOW_ADD(1) FLOW_ADD(2) FLOW_ADD(3) FLOW_ADD(4) FLOW_ADD(5) FLOW_ADD(6) FLOW_ADD(7)
-#undef FLOW_AT
 #undef FLOW_GET
 #undef FLOW_ADD
     return sum;
@@ -716,15 +727,19 @@ __device__ __forceinline__ float flow_catchment_sum(const flow_canvas &fc, int p
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK ? 1024 : 256) void k_flow_catchment_sums(flow_canvas fc, const unsigned *__restrict__ skey, const int *__restrict__ order,
                                                                           const int *__restrict__ off, const unsigned short *__restrict__ smask,
-                                                                          const float *__restrict__ own_row, unsigned *acc, int nlakes)
+                                                                          const float *__restrict__ own_row, unsigned *acc, int nlakes, const int *__restrict__ big)
 {
     const int lane = BLOCK ? (int)threadIdx.x : (int)(threadIdx.x & 63);
-    const int lake = BLOCK ? (int)blockIdx.x : (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    // (BLOCK: the large catchments are listed -- big[1..big[0]], k_flow_big_lakes -- and the workgroups take them in turn: a grid of one
+    // workgroup per lake, 43 000 of 1024 threads of which a few hundred stay, spent its time being dispatched)
+    for (int turn = (int)blockIdx.x; BLOCK == 0 || turn < big[0]; turn += (int)gridDim.x) {
+    const int lake = BLOCK ? big[1 + turn] : (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     if (lake >= nlakes) return;
     int pos = off[lake];
     const int end = off[lake + 1];
-    if ((end - pos > FLOW_BIG_LAKE) != (BLOCK != 0)) return;         // (the other launch's catchment)
+    if (!BLOCK && end - pos > FLOW_BIG_LAKE) return;                 // (the other launch's catchment)
     if (BLOCK) {
+        __syncthreads();                                             // (the window and the counts of the catchment before)
         // The sorted list is read through a window in the LDS, 2048 entries at a time: a level then waits for the sums it adds and for its
         // own stores, not for its keys as well (they come from HBM: 4.4 us a level with them, 250 levels in the largest catchment).  The
         // last cell of a level says how many there were; one barrier a level (the count alternates between two words).
@@ -757,7 +772,7 @@ __global__ __launch_bounds__(BLOCK ? 1024 : 256) void k_flow_catchment_sums(flow
             pos += s_cnt[par];
             par ^= 1;
         }
-        return;
+        continue;
     }
     while (pos < end) {
         // key, cell and the cell's receiver bits are asked for together (smask: the mask in the sorted order, k_flow_lake_offsets): a level
@@ -775,6 +790,14 @@ __global__ __launch_bounds__(BLOCK ? 1024 : 256) void k_flow_catchment_sums(flow
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         pos += __builtin_popcountll(__builtin_amdgcn_ballot_w64(mine));
     }
+    return;
+    }
+}
+// the catchments of more than FLOW_BIG_LAKE cells: big[0] of them, big[1..]
+__global__ void k_flow_big_lakes(const int *__restrict__ off, int nlakes, int *big)
+{
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l < nlakes && off[l + 1] - off[l] > FLOW_BIG_LAKE) big[1 + atomicAdd(big, 1)] = l;
 }
 
 // the cell a cell drains to (k_flow_parent's rule), or -1
@@ -1380,7 +1403,7 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
     static const bool by_levels = dmg_hook("DMG_FLOW_LEVELS") != nullptr;      // experiments: the level-synchronous form
     static const int two_env = [] { const char *e = dmg_hook("DMG_FLOW_TWO_PHASE"); return e ? atoi(e) : 1; }();   // 0: one pass over all cells in order of their global depth (through round 5)
     bool two_phase = two_env != 0 && !by_levels;
-    dev_buf acc, keyA, keyA2, idxA, orderA, sortA, tickA, lakeoff, smaskA, nextB;
+    dev_buf acc, keyA, keyA2, idxA, orderA, sortA, tickA, lakeoff, smaskA, nextB, bigA;
     DMG_ALLOC(acc, N * 4);
     DMG_ALLOC(tickA, 32);                                // [0] ticket A, [1] error A, [2] cells with a catchment, [3] their largest distance to their sink, [4] ticket B, [5] error B, [6] cells of phase B
     DMG_HIP(hipMemsetAsync(tickA.p, 0, 32, st));
@@ -1404,6 +1427,8 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
             // so the sort takes all the bits those keys need, 32 where the lakes need 22)
             DMG_HIP(hipcub::DeviceRadixSort::SortPairs(sortA.p, sb, (const unsigned *)keyA.p, (unsigned *)keyA2.p, (const unsigned *)idxA.p, (unsigned *)orderA.p, (int)N, 0, 32, st));
             DMG_ALLOC(lakeoff, (size_t)(nlakes + 1) * 4);
+            DMG_ALLOC_VAR(bigA, (size_t)(nlakes + 1) * 4);
+            DMG_HIP(hipMemsetAsync(bigA.p, 0, 4, st));
             DMG_ALLOC(smaskA, N * 2);
             hipLaunchKernelGGL(k_flow_lake_offsets, dim3(nb), dim3(256), 0, st, (const unsigned *)keyA2.p, orderA.i(), (const unsigned short *)mask.p,
                                (const int *)(tickA.i() + 2), lakeoff.i(), (unsigned short *)smaskA.p, nlakes, N);
@@ -1416,10 +1441,11 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
             }
             DMG_HIP(hipEventRecord(ctx->flow_fork, st));
             DMG_HIP(hipStreamWaitEvent(ctx->flow_side, ctx->flow_fork, 0));
-            hipLaunchKernelGGL(k_flow_catchment_sums<1>, dim3((unsigned)nlakes), dim3(1024), 0, st, fc, (const unsigned *)keyA2.p, orderA.i(), lakeoff.i(),
-                               (const unsigned short *)smaskA.p, down.f(), (unsigned *)acc.p, nlakes);
+            hipLaunchKernelGGL(k_flow_big_lakes, dim3((unsigned)((nlakes + 255) / 256)), dim3(256), 0, st, lakeoff.i(), nlakes, bigA.i());
+            hipLaunchKernelGGL(k_flow_catchment_sums<1>, dim3((unsigned)std::min(nlakes, 2 * ctx->num_cu)), dim3(1024), 0, st, fc, (const unsigned *)keyA2.p, orderA.i(),
+                               lakeoff.i(), (const unsigned short *)smaskA.p, down.f(), (unsigned *)acc.p, nlakes, (const int *)bigA.i());
             hipLaunchKernelGGL(k_flow_catchment_sums<0>, dim3((unsigned)((nlakes + 3) / 4)), dim3(256), 0, ctx->flow_side, fc, (const unsigned *)keyA2.p, orderA.i(),
-                               lakeoff.i(), (const unsigned short *)smaskA.p, down.f(), (unsigned *)acc.p, nlakes);
+                               lakeoff.i(), (const unsigned short *)smaskA.p, down.f(), (unsigned *)acc.p, nlakes, (const int *)nullptr);
             DMG_HIP(hipEventRecord(ctx->flow_join, ctx->flow_side));
             DMG_HIP(hipStreamWaitEvent(st, ctx->flow_join, 0));
             (void)key_bits;
