@@ -727,17 +727,17 @@ __device__ __forceinline__ float flow_catchment_sum(const flow_canvas &fc, int p
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK ? 1024 : 256) void k_flow_catchment_sums(flow_canvas fc, const unsigned *__restrict__ skey, const int *__restrict__ order,
                                                                           const int *__restrict__ off, const unsigned short *__restrict__ smask,
-                                                                          const float *__restrict__ own_row, unsigned *acc, int nlakes, const int *__restrict__ big)
+                                                                          const float *__restrict__ own_row, unsigned *acc, const int *__restrict__ list)
 {
     const int lane = BLOCK ? (int)threadIdx.x : (int)(threadIdx.x & 63);
-    // (BLOCK: the large catchments are listed -- big[1..big[0]], k_flow_big_lakes -- and the workgroups take them in turn: a grid of one
-    // workgroup per lake, 43 000 of 1024 threads of which a few hundred stay, spent its time being dispatched)
-    for (int turn = (int)blockIdx.x; BLOCK == 0 || turn < big[0]; turn += (int)gridDim.x) {
-    const int lake = BLOCK ? big[1 + turn] : (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-    if (lake >= nlakes) return;
+    // (the catchments of a kind are listed -- list[1..list[0]], k_flow_lake_kinds -- and the workgroups / waves take them in turn: a grid of
+    // one workgroup per lake, 43 000 of 1024 threads of which a few hundred stay, spent its time being dispatched)
+    const int first = BLOCK ? (int)blockIdx.x : (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int stride = BLOCK ? (int)gridDim.x : (int)(((size_t)gridDim.x * blockDim.x) >> 6);
+    for (int turn = first; turn < list[0]; turn += stride) {
+    const int lake = list[1 + turn];
     int pos = off[lake];
     const int end = off[lake + 1];
-    if (!BLOCK && end - pos > FLOW_BIG_LAKE) return;                 // (the other launch's catchment)
     if (BLOCK) {
         __syncthreads();                                             // (the window and the counts of the catchment before)
         // The sorted list is read through a window in the LDS, 2048 entries at a time: a level then waits for the sums it adds and for its
@@ -790,14 +790,45 @@ __global__ __launch_bounds__(BLOCK ? 1024 : 256) void k_flow_catchment_sums(flow
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         pos += __builtin_popcountll(__builtin_amdgcn_ballot_w64(mine));
     }
-    return;
     }
 }
-// the catchments of more than FLOW_BIG_LAKE cells: big[0] of them, big[1..]
-__global__ void k_flow_big_lakes(const int *__restrict__ off, int nlakes, int *big)
+// ... and the smallest catchments, up to FLOW_TINY_LAKE cells -- where every other cell is a lake of its own there are millions of them, and
+// a wave for each is a wave for a cell or two -- one LANE each: the lane goes through its catchment's cells in the list's order, farthest
+// from the sink first; what a cell adds its own lane stored before it
+#define FLOW_TINY_LAKE 8
+__global__ __launch_bounds__(256) void k_flow_tiny_catchment_sums(flow_canvas fc, const int *__restrict__ order, const int *__restrict__ off,
+                                                                  const unsigned short *__restrict__ smask, const float *__restrict__ own_row, unsigned *acc, int nlakes)
+{
+    const int lake = (int)((size_t)blockIdx.x * blockDim.x + threadIdx.x);
+    if (lake >= nlakes) return;
+    int pos = off[lake];
+    const int end = off[lake + 1];
+    if (end - pos > FLOW_TINY_LAKE) return;
+    for (; pos < end; pos++) {
+        const int p = order[pos];
+        const float sum = flow_catchment_sum<__HIP_MEMORY_SCOPE_WAVEFRONT>(fc, p, (unsigned)smask[pos], own_row, acc);
+        __hip_atomic_store(acc + p, __float_as_uint(sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+}
+// the catchments by kind: big[0] of more than FLOW_BIG_LAKE cells, big[1..]; mid[0] of more than FLOW_TINY_LAKE, mid[1..] (a wave counts
+// its lakes and takes its places in a list with one atomic)
+__global__ __launch_bounds__(256) void k_flow_lake_kinds(const int *__restrict__ off, int nlakes, int *big, int *mid)
 {
     const int l = blockIdx.x * blockDim.x + threadIdx.x;
-    if (l < nlakes && off[l + 1] - off[l] > FLOW_BIG_LAKE) big[1 + atomicAdd(big, 1)] = l;
+    const int lane = threadIdx.x & 63;
+    const int size = l < nlakes ? off[l + 1] - off[l] : 0;
+#pragma unroll
+    for (int kind = 0; kind < 2; kind++) {
+        const bool is = kind ? (size > FLOW_TINY_LAKE && size <= FLOW_BIG_LAKE) : size > FLOW_BIG_LAKE;
+        const unsigned long long who = __builtin_amdgcn_ballot_w64(is);
+        if (!who) continue;
+        int *list = kind ? mid : big;
+        int base = 0;
+        if (lane == 0) base = atomicAdd(list, __builtin_popcountll(who));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (is) list[1 + base + __builtin_popcountll(who & ((1ull << lane) - 1ull))] = l;
+    }
 }
 
 // the cell a cell drains to (k_flow_parent's rule), or -1
@@ -1402,8 +1433,10 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
     // event behind the copies, not on the stream -- so that the sums inside the catchments are formed while the host grows the lake graph
     static const bool by_levels = dmg_hook("DMG_FLOW_LEVELS") != nullptr;      // experiments: the level-synchronous form
     static const int two_env = [] { const char *e = dmg_hook("DMG_FLOW_TWO_PHASE"); return e ? atoi(e) : 1; }();   // 0: one pass over all cells in order of their global depth (through round 5)
-    bool two_phase = two_env != 0 && !by_levels;
-    dev_buf acc, keyA, keyA2, idxA, orderA, sortA, tickA, lakeoff, smaskA, nextB, bigA;
+    // (phase A's keys hold a lake's dense id above FLOW_LOCAL_BITS of distance, in 32 bits, all ones being "no catchment": four million lakes.
+    // The terrain the tectonics pass leaves -- every cell a lake of its own, 134 M of them at 16384x8192 -- takes the one pass.)
+    bool two_phase = two_env != 0 && !by_levels && (long long)nlakes < (1ll << (32 - FLOW_LOCAL_BITS)) - 1;
+    dev_buf acc, keyA, keyA2, idxA, orderA, sortA, tickA, lakeoff, smaskA, nextB, bigA, midA;
     DMG_ALLOC(acc, N * 4);
     DMG_ALLOC(tickA, 32);                                // [0] ticket A, [1] error A, [2] cells with a catchment, [3] their largest distance to their sink, [4] ticket B, [5] error B, [6] cells of phase B
     DMG_HIP(hipMemsetAsync(tickA.p, 0, 32, st));
@@ -1427,8 +1460,9 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
             // so the sort takes all the bits those keys need, 32 where the lakes need 22)
             DMG_HIP(hipcub::DeviceRadixSort::SortPairs(sortA.p, sb, (const unsigned *)keyA.p, (unsigned *)keyA2.p, (const unsigned *)idxA.p, (unsigned *)orderA.p, (int)N, 0, 32, st));
             DMG_ALLOC(lakeoff, (size_t)(nlakes + 1) * 4);
-            DMG_ALLOC_VAR(bigA, (size_t)(nlakes + 1) * 4);
+            DMG_ALLOC_VAR(bigA, (size_t)(nlakes + 1) * 4); DMG_ALLOC_VAR(midA, (size_t)(nlakes + 1) * 4);
             DMG_HIP(hipMemsetAsync(bigA.p, 0, 4, st));
+            DMG_HIP(hipMemsetAsync(midA.p, 0, 4, st));
             DMG_ALLOC(smaskA, N * 2);
             hipLaunchKernelGGL(k_flow_lake_offsets, dim3(nb), dim3(256), 0, st, (const unsigned *)keyA2.p, orderA.i(), (const unsigned short *)mask.p,
                                (const int *)(tickA.i() + 2), lakeoff.i(), (unsigned short *)smaskA.p, nlakes, N);
@@ -1439,13 +1473,15 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
                 DMG_HIP(hipEventCreateWithFlags(&ctx->flow_fork, hipEventDisableTiming));
                 DMG_HIP(hipEventCreateWithFlags(&ctx->flow_join, hipEventDisableTiming));
             }
+            hipLaunchKernelGGL(k_flow_lake_kinds, dim3((unsigned)((nlakes + 255) / 256)), dim3(256), 0, st, lakeoff.i(), nlakes, bigA.i(), midA.i());
             DMG_HIP(hipEventRecord(ctx->flow_fork, st));
             DMG_HIP(hipStreamWaitEvent(ctx->flow_side, ctx->flow_fork, 0));
-            hipLaunchKernelGGL(k_flow_big_lakes, dim3((unsigned)((nlakes + 255) / 256)), dim3(256), 0, st, lakeoff.i(), nlakes, bigA.i());
             hipLaunchKernelGGL(k_flow_catchment_sums<1>, dim3((unsigned)std::min(nlakes, 2 * ctx->num_cu)), dim3(1024), 0, st, fc, (const unsigned *)keyA2.p, orderA.i(),
-                               lakeoff.i(), (const unsigned short *)smaskA.p, down.f(), (unsigned *)acc.p, nlakes, (const int *)bigA.i());
-            hipLaunchKernelGGL(k_flow_catchment_sums<0>, dim3((unsigned)((nlakes + 3) / 4)), dim3(256), 0, ctx->flow_side, fc, (const unsigned *)keyA2.p, orderA.i(),
-                               lakeoff.i(), (const unsigned short *)smaskA.p, down.f(), (unsigned *)acc.p, nlakes, (const int *)nullptr);
+                               lakeoff.i(), (const unsigned short *)smaskA.p, down.f(), (unsigned *)acc.p, (const int *)bigA.i());
+            hipLaunchKernelGGL(k_flow_catchment_sums<0>, dim3((unsigned)std::min((nlakes + 3) / 4, 32 * ctx->num_cu)), dim3(256), 0, ctx->flow_side, fc,
+                               (const unsigned *)keyA2.p, orderA.i(), lakeoff.i(), (const unsigned short *)smaskA.p, down.f(), (unsigned *)acc.p, (const int *)midA.i());
+            hipLaunchKernelGGL(k_flow_tiny_catchment_sums, dim3((unsigned)((nlakes + 255) / 256)), dim3(256), 0, ctx->flow_side, fc, orderA.i(), lakeoff.i(),
+                               (const unsigned short *)smaskA.p, down.f(), (unsigned *)acc.p, nlakes);
             DMG_HIP(hipEventRecord(ctx->flow_join, ctx->flow_side));
             DMG_HIP(hipStreamWaitEvent(st, ctx->flow_join, 0));
             (void)key_bits;

@@ -323,3 +323,34 @@ def test_flow_sum_forms_equal_at_size():
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         outs[name] = [l.split()[:4] for l in r.stdout.strip().splitlines()]
     assert len(outs["walk"]) == 4 and outs["walk"] == outs["dataflow"] == outs["one pass"], outs
+
+
+_LAKES_CHILD = """
+import sys, hashlib
+import numpy as np
+sys.path.insert(0, '.')
+from demiurge_amd import capi, synth
+ctx = capi.Context(0)
+for name, W, H in (("noise", 2048, 1024), ("plateaus", 4096, 2048)):
+    if name == "noise":          # a lake every few cells: a million catchments of a handful of cells
+        h = (synth.lcg_uniform(W * H, 17).reshape(H, W) * 50).astype(np.float32)
+    else:                        # a handful of flat values, as the tectonics render pass leaves them: every cell a lake of its own, 8.4 M of them
+        h = np.floor(synth.terrain(W, H) * 6).astype(np.float32)
+    for lakes in (0, 1):
+        f = ctx.flow_accumulate(capi.make_grid(W, H), h, 0.5, 0.5, lakes=lakes)
+        print(name, lakes, hashlib.sha256(f.tobytes()).hexdigest(), flush=True)
+ctx.close()
+"""
+
+
+@pytest.mark.gpu
+def test_flow_sum_forms_equal_on_many_small_lakes():
+    """the two-phase sums give the smallest catchments a LANE each (k_flow_tiny_catchment_sums) and step aside for the one pass where the
+    lakes' ids no longer fit phase A's keys (four million: the plate map the tectonics pass leaves is 8.4 M one-cell lakes at 4096x2048):
+    both cases against the one-pass form, bit for bit"""
+    outs = {}
+    for name, env in (("two phases", {}), ("one pass", {"DMG_FLOW_TWO_PHASE": "0"})):
+        r = _flow_child(_LAKES_CHILD, env)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        outs[name] = r.stdout.strip().splitlines()
+    assert len(outs["two phases"]) == 4 and outs["two phases"] == outs["one pass"], outs
