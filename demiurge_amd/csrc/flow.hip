@@ -1305,18 +1305,21 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
     // (a round past the last one changes nothing: rivers of 2^8 cells and more are the rule, so the first rounds run without asking; a
     // readback costs more than the round.  From which round on to ask: the one the last solve of this size ended with -- one question
     // where the seventh round on were three -- and every 32nd solve two rounds earlier, so that the hint follows rivers that got shorter.)
+    // (The hint works downwards too: the plate map the tectonics pass leaves is a sink per cell -- nothing moves in the first round, and
+    // seven rounds at the HBM roof went by before the first question: 3 ms of config 5's iteration.)
     int first_ask = N >= ((size_t)1 << 20) ? 7 : 0;
-    if (ctx->flow_hint_cells == N && ctx->flow_hint_rounds > first_ask)
-        first_ask = std::max(first_ask, ctx->flow_hint_rounds - ((++ctx->flow_hint_age & 31u) == 0 ? 2 : 0));
+    if (ctx->flow_hint_cells == N) first_ask = std::max(0, ctx->flow_hint_rounds - ((++ctx->flow_hint_age & 31u) == 0 ? 2 : 0));
     for (int it = 0; it < 40; it++) {
         hipLaunchKernelGGL(k_flow_jump, dim3(nb), dim3(256), 0, st, par[cur].i(), dst[cur].i(), par[cur ^ 1].i(), dst[cur ^ 1].i(), N, changed.i() + it, it == 0 ? 1 : 0);
         DMG_HIP(hipGetLastError());
         cur ^= 1;
         if (it < first_ask) continue;
-        int ch = 0;
-        DMG_HIP(hipMemcpyAsync(&ch, changed.i() + it, 4, hipMemcpyDeviceToHost, st));
+        int ch[40];                                          // (every round's word so far: the hint is the FIRST round in which nothing moved)
+        DMG_HIP(hipMemcpyAsync(ch, changed.i(), (size_t)(it + 1) * 4, hipMemcpyDeviceToHost, st));
         DMG_HIP(hipStreamSynchronize(st));
-        if (!ch) { ctx->flow_hint_cells = N; ctx->flow_hint_rounds = it; break; }
+        int still = 0;
+        while (still <= it && ch[still]) still++;
+        if (still <= it) { ctx->flow_hint_cells = N; ctx->flow_hint_rounds = still; break; }
     }
     hipLaunchKernelGGL(k_flow_label, dim3(nb), dim3(256), 0, st, par[cur].i(), (const unsigned char *)code.p, label.i(), N);
 
