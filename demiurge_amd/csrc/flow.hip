@@ -1334,11 +1334,20 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
         DMG_ALLOC(scan_tmp, sb + 256);
         DMG_HIP(hipcub::DeviceScan::ExclusiveSum(scan_tmp.p, sb, sflag.i(), dense.i(), (int)N, st));
     }
-    int nlakes = 0;
+    // river mouths (dense ids), compacted (sorted below, on the device) -- counted with the lakes: without a mouth no pass is ever looked
+    // at (below), and the pass candidates need not be found either (4.5 ms of config 5's iteration at 16384x8192, whose terrain has none)
+    const unsigned nbi = (unsigned)((N + (size_t)256 * FLOW_ITEMS - 1) / ((size_t)256 * FLOW_ITEMS));     // blocks of FLOW_ITEMS x 256 cells (k_flow_mouths, k_flow_gdepth)
+    dev_buf nsel, mouths_d;
+    DMG_ALLOC(nsel, 8);
+    DMG_ALLOC(mouths_d, N * 4);
+    DMG_HIP(hipMemsetAsync(nsel.p, 0, 8, st));
+    hipLaunchKernelGGL(k_flow_mouths, dim3(nbi), dim3(256), 0, st, (const unsigned short *)mask.p, dense.i(), mouths_d.i(), nsel.i(), N);
+    int nlakes = 0, nmouth = 0;
     {
         int last_dense = 0, last_flag = 0;
         DMG_HIP(hipMemcpyAsync(&last_dense, dense.i() + (N - 1), 4, hipMemcpyDeviceToHost, st));
         DMG_HIP(hipMemcpyAsync(&last_flag, sflag.i() + (N - 1), 4, hipMemcpyDeviceToHost, st));
+        DMG_HIP(hipMemcpyAsync(&nmouth, nsel.p, 4, hipMemcpyDeviceToHost, st));
         DMG_HIP(hipStreamSynchronize(st));
         nlakes = last_dense + last_flag;
     }
@@ -1351,25 +1360,20 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
     // boundary cells -> pass candidates; reduce to the lowest pass per lake pair on the device:
     // sort by (height, s), stable sort by (lake, from), keep segment heads, then order each lake's passes by height
     int cap = (int)std::min<size_t>(N, (size_t)1 << 28);
-    dev_buf k0, v0, k1, v1, flags, nsel, tmpst, sdist, mouths_d;
-    DMG_ALLOC_VAR(k0, (size_t)cap * 8); DMG_ALLOC_VAR(v0, (size_t)cap * 8); DMG_ALLOC_VAR(k1, (size_t)cap * 8); DMG_ALLOC_VAR(v1, (size_t)cap * 8);
-    DMG_ALLOC(nsel, 8);
-    DMG_HIP(hipMemsetAsync(count.p, 0, 4, st));
-    const unsigned nbi = (unsigned)((N + (size_t)256 * FLOW_ITEMS - 1) / ((size_t)256 * FLOW_ITEMS));     // blocks of FLOW_ITEMS x 256 cells (k_flow_mouths, k_flow_gdepth)
-    hipLaunchKernelGGL(k_flow_passes, dim3((unsigned)((W + 255) / 256), (unsigned)((H + FLOW_ITEMS - 1) / FLOW_ITEMS)), dim3(256), 0, st, fc, d_h,    // tiles of 256 x FLOW_ITEMS cells
-                       label.i(), dense.i(), (const unsigned short *)mask.p,
-                       (unsigned long long *)k0.p, (unsigned long long *)v0.p, count.i(), cap);
-    DMG_HIP(hipGetLastError());
+    dev_buf k0, v0, k1, v1, flags, tmpst, sdist;
     int ncand = 0;
-    DMG_HIP(hipMemcpyAsync(&ncand, count.p, 4, hipMemcpyDeviceToHost, st));
-    // river mouths (dense ids), compacted (sorted below, on the device)
-    DMG_ALLOC_VAR(mouths_d, (size_t)std::max(nlakes, 1) * 4);
-    DMG_HIP(hipMemsetAsync(nsel.p, 0, 8, st));
-    hipLaunchKernelGGL(k_flow_mouths, dim3(nbi), dim3(256), 0, st, (const unsigned short *)mask.p, dense.i(), mouths_d.i(), nsel.i(), N);
-    int nmouth = 0;
-    DMG_HIP(hipMemcpyAsync(&nmouth, nsel.p, 4, hipMemcpyDeviceToHost, st));
-    DMG_HIP(hipStreamSynchronize(st));
-    if (ncand > cap) return dmg_fail(DMG_ENOMEM, "flow: %d pass candidates exceed the buffer", ncand);
+    if (nmouth) {
+        DMG_ALLOC_VAR(k0, (size_t)cap * 8); DMG_ALLOC_VAR(v0, (size_t)cap * 8); DMG_ALLOC_VAR(k1, (size_t)cap * 8); DMG_ALLOC_VAR(v1, (size_t)cap * 8);
+        DMG_HIP(hipMemsetAsync(count.p, 0, 4, st));
+        hipLaunchKernelGGL(k_flow_passes, dim3((unsigned)((W + 255) / 256), (unsigned)((H + FLOW_ITEMS - 1) / FLOW_ITEMS)), dim3(256), 0, st, fc, d_h,    // tiles of 256 x FLOW_ITEMS cells
+                           label.i(), dense.i(), (const unsigned short *)mask.p,
+                           (unsigned long long *)k0.p, (unsigned long long *)v0.p, count.i(), cap);
+        DMG_HIP(hipGetLastError());
+        DMG_HIP(hipMemcpyAsync(&ncand, count.p, 4, hipMemcpyDeviceToHost, st));
+        DMG_HIP(hipMemsetAsync(nsel.p, 0, 8, st));           // (the select below counts into it)
+        DMG_HIP(hipStreamSynchronize(st));
+        if (ncand > cap) return dmg_fail(DMG_ENOMEM, "flow: %d pass candidates exceed the buffer", ncand);
+    }
     std::vector<int> mouths(nmouth);
     dev_buf mouths_s, mouths_tmp;
     if (nmouth) {
@@ -1811,6 +1815,8 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
         float *dlv[2] = { dlv0.f(), dlv1.f() };
         int rounds = 1;
         while ((1ll << rounds) < nlakes) rounds++;           // paths are at most nlakes long
+        if (assigned.empty()) rounds = -1;                   // (no connection: every lake is its own root, a sweep is the identity -- 134 M lakes on the
+                                                             // tectonics pass' plate map, five sweeps before the first question, 3 ms of config 5's iteration)
         int b = 0;
         const unsigned lb = (unsigned)((nlakes + 255) / 256);
         // The forest is far shallower than it is large (2.6 M lakes at 16384x8192 hang a few hundred deep): where a sweep costs more
