@@ -70,6 +70,7 @@ struct dmg_ctx {
     size_t flow_hint_cells = 0;
     int flow_hint_rounds = 0;
     unsigned flow_hint_age = 0;
+    bool flow_hint_no_mouths = false;   // the last solve of flow_hint_cells cells found no river mouth: the next one looks for one first
 };
 void dmg_ctx_retain(dmg_ctx *ctx);
 void dmg_ctx_release(dmg_ctx *ctx);

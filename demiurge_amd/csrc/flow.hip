@@ -339,6 +339,19 @@ __global__ __launch_bounds__(256) void k_flow_mouths(const unsigned short *__res
         if (hit & (1u << t)) out[slot++] = dense[((size_t)blockIdx.x * FLOW_ITEMS + t) * 256 + threadIdx.x];
 }
 
+// is there a river mouth at all?  (k_flow_mouths' test, counted only)
+__global__ __launch_bounds__(256) void k_flow_any_mouth(const unsigned short *__restrict__ mask, int *__restrict__ found, size_t n)
+{
+    bool hit = false;
+#pragma unroll
+    for (int t = 0; t < FLOW_ITEMS; t++) {
+        const size_t i = ((size_t)blockIdx.x * FLOW_ITEMS + t) * 256 + threadIdx.x;
+        const unsigned m = i < n ? mask[i] : 0u;
+        hit = hit || (m != 0xFFFFu && (m & 16u) && (m & 512u));
+    }
+    if (__builtin_amdgcn_ballot_w64(hit) && (threadIdx.x & 63) == 0) *found = 1;
+}
+
 __global__ void k_flow_scatter_pairs(const int *__restrict__ idx, const int *__restrict__ v, int *__restrict__ dst, int n)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1298,6 +1311,25 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
     DMG_HIP(hipGetLastError());
 
     lap("alloc+blur+direction+mask");
+    // Without a river mouth no lake is ever reached (solvingConnections starts at the mouths, :533-595; calculateflow at what it connected):
+    // the flow is -1 everywhere, whatever the catchments are.  Config 5's iteration meets this every time -- the terrain the tectonics
+    // render pass leaves has no sink beside the sea -- and spent 7 ms of its 34 on catchments nobody reads.  Where the last solve of this
+    // size found no mouth, this one looks for one before anything else (0.2 ms and a synchronisation; a grid that has mouths never pays).
+    if (ctx->flow_hint_no_mouths && ctx->flow_hint_cells == N) {
+        DMG_HIP(hipMemsetAsync(count.p, 0, 4, st));
+        hipLaunchKernelGGL(k_flow_any_mouth, dim3((unsigned)((N + (size_t)256 * FLOW_ITEMS - 1) / ((size_t)256 * FLOW_ITEMS))), dim3(256), 0, st,
+                           (const unsigned short *)mask.p, count.i(), N);
+        int any = 0;
+        DMG_HIP(hipMemcpyAsync(&any, count.p, 4, hipMemcpyDeviceToHost, st));
+        DMG_HIP(hipStreamSynchronize(st));
+        if (!any) {
+            hipLaunchKernelGGL(k_fill_f, dim3(nb), dim3(256), 0, st, d_flow, -1.0f, N);        // unreached cells keep -1 (:598-604)
+            DMG_HIP(hipGetLastError());
+            lap("no river mouth: -1 everywhere");
+            return DMG_OK;
+        }
+        ctx->flow_hint_no_mouths = false;
+    }
     // catchment labels + depth by pointer jumping (log2 of the longest river iterations)
     hipLaunchKernelGGL(k_flow_parent, dim3(nb), dim3(256), 0, st, fc, (const unsigned char *)code.p, par[0].i(), dst[0].i());
     int cur = 0;
@@ -1351,6 +1383,7 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
         DMG_HIP(hipStreamSynchronize(st));
         nlakes = last_dense + last_flag;
     }
+    if (ctx->flow_hint_cells == N || nmouth == 0) { ctx->flow_hint_no_mouths = nmouth == 0; if (nmouth == 0) ctx->flow_hint_cells = N; }
     std::vector<int> sink_cell;                              // on the host only if a growth will read it (below, once the mouths are counted)
     if (nlakes) {
         DMG_ALLOC_VAR(sinkc, (size_t)nlakes * 4);

@@ -80,6 +80,27 @@ def test_flow_matches_oracle(dev, oracle, W, H, exponent):
 
 
 @pytest.mark.gpu
+def test_flow_without_a_river_mouth_and_after(dev, oracle):
+    """no cell at or below the sea: no river mouth, no lake is ever reached, the flow is -1 everywhere (FlowFilter.cpp:533-604).  The
+    second solve of such a grid looks for a mouth first and returns (dmg_ctx::flow_hint_no_mouths); a terrain WITH mouths after it
+    must not be taken for one without.  All three against the oracle."""
+    capi, ctx = dev
+    from demiurge_amd import synth
+    W, H = 192, 96
+    g, og = capi.make_grid(W, H), oracle.grid(W, H)
+    dry = (synth.terrain(W, H) * 100 + synth.lcg_uniform(W * H, 3).reshape(H, W) * 8).astype(np.float32)
+    dry = dry - dry.min() + np.float32(5.0)
+    wet = (synth.terrain(W, H) * 100 + synth.lcg_uniform(W * H, 3).reshape(H, W) * 8).astype(np.float32)
+    ref_dry = oracle.flow_accumulate(og, dry, 0.5, 1.0)["flow"]
+    assert (ref_dry == -1).all()                         # the case is what it says
+    for h, ref in ((dry, ref_dry), (dry, ref_dry), (dry + np.float32(1.0), None), (wet, None), (dry, ref_dry), (wet, None)):
+        if ref is None:
+            ref = oracle.flow_accumulate(og, h, 0.5, 1.0)["flow"]
+        got = ctx.flow_accumulate(g, h, 0.5, 1.0)
+        assert np.array_equal(got, ref), int((got != ref).sum())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("exponent", [0.5, 0.37, 1.0])
 def test_flow_matches_oracle_512(dev, oracle, exponent):
     """131 k cells, rougher terrain (more lakes), the erosion tool's exponent 0.5 and an odd one"""
