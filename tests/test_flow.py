@@ -320,7 +320,8 @@ def test_flow_parallel_growth_equals_serial_at_size():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", [{"DMG_FLOW_WALK": "0"}, {"DMG_FLOW_TWO_PHASE": "0"}], ids=["phase-B-dataflow", "one-pass"])
+@pytest.mark.parametrize("env", [{"DMG_FLOW_WALK": "0"}, {"DMG_FLOW_TWO_PHASE": "0"}, {"DMG_FLOW_LOCAL_LIMIT": "12"}],
+                         ids=["phase-B-dataflow", "one-pass", "one-pass-after-phase-A (a catchment deeper than the keys hold)"])
 def test_flow_suite_through_the_other_sum_forms(env):
     """Round 6: the upstream sums are formed in two phases -- inside the catchments beside the host's growth, then along the reaches
     behind the connections (flow.hip, k_flow_catchment_sums / k_flow_walk).  The forms they replaced stay as fallbacks (a catchment
