@@ -147,9 +147,9 @@ static void ctx_free(dmg_ctx *c)
 {
     (void)hipSetDevice(c->device);
     (void)dmg_trim(c);
-    if (c->flow_fork) (void)hipEventDestroy(c->flow_fork);
-    if (c->flow_join) (void)hipEventDestroy(c->flow_join);
+    for (hipEvent_t e : { c->flow_fork, c->flow_fork2, c->flow_join, c->flow_join2 }) if (e) (void)hipEventDestroy(e);
     if (c->flow_side) (void)hipStreamDestroy(c->flow_side);
+    if (c->flow_side2) (void)hipStreamDestroy(c->flow_side2);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);

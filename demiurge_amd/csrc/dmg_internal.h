@@ -62,9 +62,10 @@ struct dmg_ctx {
     // ... and the flow solve's per-row tables of the last grid (pixel sizes of the direction pass, cell areas of the sums: three floats a
     // row, the same every erosion round -- recomputed and uploaded per solve they were 2 048 cosines and three synchronisations of an
     // iteration); device memory of the context, released by dmg_trim
-    // a second stream and two events for the flow solve (created at its first use): the small catchments' sums run beside the large ones'
-    hipStream_t flow_side = nullptr;
-    hipEvent_t flow_fork = nullptr, flow_join = nullptr;
+    // two streams of the flow solve's own and the events that fork and join them (created at first use): phase A of the upstream sums
+    // runs beside the pass search and the host's growth, its small catchments beside its large ones
+    hipStream_t flow_side = nullptr, flow_side2 = nullptr;
+    hipEvent_t flow_fork = nullptr, flow_fork2 = nullptr, flow_join = nullptr, flow_join2 = nullptr;
     dmg_grid flow_rows_grid = {};
     float *flow_rows = nullptr;         // [3][H]: dx, dy, area
     size_t flow_hint_cells = 0;

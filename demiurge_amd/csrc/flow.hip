@@ -1420,6 +1420,85 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
         hipLaunchKernelGGL(k_flow_sinkcells, dim3(nb), dim3(256), 0, st, label.i(), dense.i(), sinkc.i(), N);
     }
 
+    // ---- the upstream sums, phase A (k_flow_local_keys has the story): every cell's sum inside its own catchment needs the labels, the
+    // distances to the sinks and the receiver bits -- all there once the lakes are counted -- and nothing the pass search or the host's
+    // growth produce.  It runs on two streams of its own (the large catchments on one, the small kinds on the other) beside the pass
+    // candidates' sorts -- small launches that leave most of the chip idle -- and beside the host's growth; the main stream takes its sums
+    // over (phase_a.join) before the first kernel that reads them.
+    static const bool by_levels = dmg_hook("DMG_FLOW_LEVELS") != nullptr;      // experiments: the level-synchronous form
+    static const int two_env = [] { const char *e = dmg_hook("DMG_FLOW_TWO_PHASE"); return e ? atoi(e) : 1; }();   // 0: one pass over all cells in order of their global depth (through round 5)
+    // (phase A's keys hold a lake's dense id above FLOW_LOCAL_BITS of distance, in 32 bits, all ones being "no catchment": four million lakes.
+    // The terrain the tectonics pass leaves -- every cell a lake of its own, 134 M of them at 16384x8192 -- takes the one pass.)
+    bool two_phase = two_env != 0 && !by_levels && nmouth > 0 && (long long)nlakes < (1ll << (32 - FLOW_LOCAL_BITS)) - 1;      // (no mouth: nothing is reached, nothing to sum)
+    dev_buf acc, keyA, keyA2, idxA, orderA, sortA, tickA, lakeoff, smaskA, nextB, bigA, midA;
+    DMG_ALLOC(acc, N * 4);
+    DMG_ALLOC(tickA, 32);                                // [0] ticket A, [1] error A, [2] cells with a catchment, [3] their largest distance to their sink, [4] ticket B, [5] error B, [6] cells of phase B
+    DMG_HIP(hipMemsetAsync(tickA.p, 0, 32, st));
+    // whatever way the solve is left, the side streams are done with the solve's buffers before those go back to the pool
+    struct side_streams {
+        dmg_ctx *ctx; hipStream_t main; bool forked = false, joined = false;
+        int join()
+        {
+            if (!forked || joined) return DMG_OK;
+            joined = true;
+            DMG_HIP(hipStreamWaitEvent(main, ctx->flow_join, 0));
+            DMG_HIP(hipStreamWaitEvent(main, ctx->flow_join2, 0));
+            return DMG_OK;
+        }
+        ~side_streams() { if (forked && !joined) { (void)hipStreamSynchronize(ctx->flow_side); (void)hipStreamSynchronize(ctx->flow_side2); } }
+    } phase_a{ ctx, st };
+    if (two_phase) {
+        DMG_ALLOC(keyA, N * 4); DMG_ALLOC(keyA2, N * 4); DMG_ALLOC(idxA, N * 4); DMG_ALLOC(orderA, N * 4);
+        if (!ctx->flow_side) {
+            DMG_HIP(hipStreamCreateWithFlags(&ctx->flow_side, hipStreamNonBlocking));
+            DMG_HIP(hipStreamCreateWithFlags(&ctx->flow_side2, hipStreamNonBlocking));
+            DMG_HIP(hipEventCreateWithFlags(&ctx->flow_fork, hipEventDisableTiming));
+            DMG_HIP(hipEventCreateWithFlags(&ctx->flow_fork2, hipEventDisableTiming));
+            DMG_HIP(hipEventCreateWithFlags(&ctx->flow_join, hipEventDisableTiming));
+            DMG_HIP(hipEventCreateWithFlags(&ctx->flow_join2, hipEventDisableTiming));
+        }
+        hipStream_t sa = ctx->flow_side, sb2 = ctx->flow_side2;
+        DMG_HIP(hipEventRecord(ctx->flow_fork, st));
+        DMG_HIP(hipStreamWaitEvent(sa, ctx->flow_fork, 0));
+        phase_a.forked = true;
+        DMG_HIP(hipMemsetAsync(acc.p, 0xFF, N * 4, sa));                  // FLOW_NOT_READY everywhere
+        if (nlakes > 0) {
+            const unsigned nbk = (unsigned)((N + (size_t)256 * FLOW_ITEMS - 1) / ((size_t)256 * FLOW_ITEMS));
+            hipLaunchKernelGGL(k_flow_local_keys, dim3(nbk), dim3(256), 0, sa, label.i(), dense.i(), dst[cur].i(), (unsigned *)keyA.p, (unsigned *)idxA.p,
+                               tickA.i() + 2, tickA.i() + 3, N);
+            size_t sb = 0;
+            (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sb, (const unsigned *)keyA.p, (unsigned *)keyA2.p, (const unsigned *)idxA.p, (unsigned *)orderA.p, (int)N, 0, 32, sa);
+            DMG_ALLOC(sortA, sb + 256);
+            // (cells without a catchment carry all ones: with the key's upper bits left out of the sort they would mix with the last lakes' --
+            // so the sort takes all 32 bits where the lakes need 22)
+            DMG_HIP(hipcub::DeviceRadixSort::SortPairs(sortA.p, sb, (const unsigned *)keyA.p, (unsigned *)keyA2.p, (const unsigned *)idxA.p, (unsigned *)orderA.p, (int)N, 0, 32, sa));
+            DMG_ALLOC(lakeoff, (size_t)(nlakes + 1) * 4);
+            DMG_ALLOC_VAR(bigA, (size_t)(nlakes + 1) * 4); DMG_ALLOC_VAR(midA, (size_t)(nlakes + 1) * 4);
+            DMG_HIP(hipMemsetAsync(bigA.p, 0, 4, sa));
+            DMG_HIP(hipMemsetAsync(midA.p, 0, 4, sa));
+            DMG_ALLOC(smaskA, N * 2);
+            hipLaunchKernelGGL(k_flow_lake_offsets, dim3(nb), dim3(256), 0, sa, (const unsigned *)keyA2.p, orderA.i(), (const unsigned short *)mask.p,
+                               (const int *)(tickA.i() + 2), lakeoff.i(), (unsigned short *)smaskA.p, nlakes, N);
+            hipLaunchKernelGGL(k_flow_lake_kinds, dim3((unsigned)((nlakes + 255) / 256)), dim3(256), 0, sa, lakeoff.i(), nlakes, bigA.i(), midA.i());
+            // the large catchments (a few hundred workgroups, bound by the steps of the deepest) and the small ones (tens of thousands of
+            // waves and lanes) do not wait for each other
+            DMG_HIP(hipEventRecord(ctx->flow_fork2, sa));
+            DMG_HIP(hipStreamWaitEvent(sb2, ctx->flow_fork2, 0));
+            hipLaunchKernelGGL(k_flow_catchment_sums<1>, dim3((unsigned)std::min(nlakes, 2 * ctx->num_cu)), dim3(1024), 0, sa, fc, (const unsigned *)keyA2.p, orderA.i(),
+                               lakeoff.i(), (const unsigned short *)smaskA.p, down.f(), (unsigned *)acc.p, (const int *)bigA.i());
+            hipLaunchKernelGGL(k_flow_catchment_sums<0>, dim3((unsigned)std::min((nlakes + 3) / 4, 32 * ctx->num_cu)), dim3(256), 0, sb2, fc,
+                               (const unsigned *)keyA2.p, orderA.i(), lakeoff.i(), (const unsigned short *)smaskA.p, down.f(), (unsigned *)acc.p, (const int *)midA.i());
+            hipLaunchKernelGGL(k_flow_tiny_catchment_sums, dim3((unsigned)((nlakes + 255) / 256)), dim3(256), 0, sb2, fc, orderA.i(), lakeoff.i(),
+                               (const unsigned short *)smaskA.p, down.f(), (unsigned *)acc.p, nlakes);
+        } else {
+            DMG_HIP(hipEventRecord(ctx->flow_fork2, sa));
+            DMG_HIP(hipStreamWaitEvent(sb2, ctx->flow_fork2, 0));
+        }
+        DMG_HIP(hipEventRecord(ctx->flow_join, sa));
+        DMG_HIP(hipEventRecord(ctx->flow_join2, sb2));
+        DMG_HIP(hipGetLastError());
+    }
+
     // boundary cells -> pass candidates; reduce to the lowest pass per lake pair on the device:
     // sort by (height, s), stable sort by (lake, from), keep segment heads, then order each lake's passes by height
     int cap = (int)std::min<size_t>(N, (size_t)1 << 28);
@@ -1499,67 +1578,8 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
         DMG_HIP(hipMemcpyAsync(ent.data(), dent.p, (size_t)nuniq * 16, hipMemcpyDeviceToHost, st));
         DMG_HIP(hipMemcpyAsync(span.data(), dspan.p, (size_t)(nlakes + 1) * 8, hipMemcpyDeviceToHost, st));
     }
-    // ---- the upstream sums, phase A (k_flow_local_keys has the story): queued BEFORE the host waits for the entries -- it waits on an
-    // event behind the copies, not on the stream -- so that the sums inside the catchments are formed while the host grows the lake graph
-    static const bool by_levels = dmg_hook("DMG_FLOW_LEVELS") != nullptr;      // experiments: the level-synchronous form
-    static const int two_env = [] { const char *e = dmg_hook("DMG_FLOW_TWO_PHASE"); return e ? atoi(e) : 1; }();   // 0: one pass over all cells in order of their global depth (through round 5)
-    // (phase A's keys hold a lake's dense id above FLOW_LOCAL_BITS of distance, in 32 bits, all ones being "no catchment": four million lakes.
-    // The terrain the tectonics pass leaves -- every cell a lake of its own, 134 M of them at 16384x8192 -- takes the one pass.)
-    bool two_phase = two_env != 0 && !by_levels && (long long)nlakes < (1ll << (32 - FLOW_LOCAL_BITS)) - 1;
-    dev_buf acc, keyA, keyA2, idxA, orderA, sortA, tickA, lakeoff, smaskA, nextB, bigA, midA;
-    DMG_ALLOC(acc, N * 4);
-    DMG_ALLOC(tickA, 32);                                // [0] ticket A, [1] error A, [2] cells with a catchment, [3] their largest distance to their sink, [4] ticket B, [5] error B, [6] cells of phase B
-    DMG_HIP(hipMemsetAsync(tickA.p, 0, 32, st));
-    hipEvent_t ev_copies = nullptr;
-    if (two_phase) {
-        DMG_HIP(hipEventCreateWithFlags(&ev_copies, hipEventDisableTiming));
-        DMG_HIP(hipEventRecord(ev_copies, st));
-        DMG_ALLOC(keyA, N * 4); DMG_ALLOC(keyA2, N * 4); DMG_ALLOC(idxA, N * 4); DMG_ALLOC(orderA, N * 4);
-        DMG_HIP(hipMemsetAsync(acc.p, 0xFF, N * 4, st));                  // FLOW_NOT_READY everywhere
-        if (nlakes > 0) {
-            int lake_bits = 1;
-            while ((1ll << lake_bits) < (long long)nlakes + 1) lake_bits++;
-            const int key_bits = std::min(32, FLOW_LOCAL_BITS + lake_bits);
-            const unsigned nbk = (unsigned)((N + (size_t)256 * FLOW_ITEMS - 1) / ((size_t)256 * FLOW_ITEMS));
-            hipLaunchKernelGGL(k_flow_local_keys, dim3(nbk), dim3(256), 0, st, label.i(), dense.i(), dst[cur].i(), (unsigned *)keyA.p, (unsigned *)idxA.p,
-                               tickA.i() + 2, tickA.i() + 3, N);
-            size_t sb = 0;
-            (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sb, (const unsigned *)keyA.p, (unsigned *)keyA2.p, (const unsigned *)idxA.p, (unsigned *)orderA.p, (int)N, 0, key_bits, st);
-            DMG_ALLOC(sortA, sb + 256);
-            // (cells without a catchment carry all ones: with the key's upper bits left out of the sort they would mix with the last lakes' --
-            // so the sort takes all the bits those keys need, 32 where the lakes need 22)
-            DMG_HIP(hipcub::DeviceRadixSort::SortPairs(sortA.p, sb, (const unsigned *)keyA.p, (unsigned *)keyA2.p, (const unsigned *)idxA.p, (unsigned *)orderA.p, (int)N, 0, 32, st));
-            DMG_ALLOC(lakeoff, (size_t)(nlakes + 1) * 4);
-            DMG_ALLOC_VAR(bigA, (size_t)(nlakes + 1) * 4); DMG_ALLOC_VAR(midA, (size_t)(nlakes + 1) * 4);
-            DMG_HIP(hipMemsetAsync(bigA.p, 0, 4, st));
-            DMG_HIP(hipMemsetAsync(midA.p, 0, 4, st));
-            DMG_ALLOC(smaskA, N * 2);
-            hipLaunchKernelGGL(k_flow_lake_offsets, dim3(nb), dim3(256), 0, st, (const unsigned *)keyA2.p, orderA.i(), (const unsigned short *)mask.p,
-                               (const int *)(tickA.i() + 2), lakeoff.i(), (unsigned short *)smaskA.p, nlakes, N);
-            // the large catchments (a few hundred workgroups, bound by the steps of the deepest) and the small ones (tens of thousands of
-            // waves) do not wait for each other: the small ones run on a second stream beside the large
-            if (!ctx->flow_side) {
-                DMG_HIP(hipStreamCreateWithFlags(&ctx->flow_side, hipStreamNonBlocking));
-                DMG_HIP(hipEventCreateWithFlags(&ctx->flow_fork, hipEventDisableTiming));
-                DMG_HIP(hipEventCreateWithFlags(&ctx->flow_join, hipEventDisableTiming));
-            }
-            hipLaunchKernelGGL(k_flow_lake_kinds, dim3((unsigned)((nlakes + 255) / 256)), dim3(256), 0, st, lakeoff.i(), nlakes, bigA.i(), midA.i());
-            DMG_HIP(hipEventRecord(ctx->flow_fork, st));
-            DMG_HIP(hipStreamWaitEvent(ctx->flow_side, ctx->flow_fork, 0));
-            hipLaunchKernelGGL(k_flow_catchment_sums<1>, dim3((unsigned)std::min(nlakes, 2 * ctx->num_cu)), dim3(1024), 0, st, fc, (const unsigned *)keyA2.p, orderA.i(),
-                               lakeoff.i(), (const unsigned short *)smaskA.p, down.f(), (unsigned *)acc.p, (const int *)bigA.i());
-            hipLaunchKernelGGL(k_flow_catchment_sums<0>, dim3((unsigned)std::min((nlakes + 3) / 4, 32 * ctx->num_cu)), dim3(256), 0, ctx->flow_side, fc,
-                               (const unsigned *)keyA2.p, orderA.i(), lakeoff.i(), (const unsigned short *)smaskA.p, down.f(), (unsigned *)acc.p, (const int *)midA.i());
-            hipLaunchKernelGGL(k_flow_tiny_catchment_sums, dim3((unsigned)((nlakes + 255) / 256)), dim3(256), 0, ctx->flow_side, fc, orderA.i(), lakeoff.i(),
-                               (const unsigned short *)smaskA.p, down.f(), (unsigned *)acc.p, nlakes);
-            DMG_HIP(hipEventRecord(ctx->flow_join, ctx->flow_side));
-            DMG_HIP(hipStreamWaitEvent(st, ctx->flow_join, 0));
-            (void)key_bits;
-        }
-        DMG_HIP(hipGetLastError());
-        DMG_HIP(hipEventSynchronize(ev_copies));
-        (void)hipEventDestroy(ev_copies);
-    } else DMG_HIP(hipStreamSynchronize(st));
+    // (phase A of the upstream sums has been running on the side streams since the lakes were counted: the host waits for the entries only)
+    DMG_HIP(hipStreamSynchronize(st));
     lap("passes: sort/reduce/download");
     if (timing) fprintf(stderr, "[flow] %d lakes, %d pass candidates -> %d lake pairs, %d river mouths\n", nlakes, ncand, nuniq, nmouth);
 
@@ -1904,6 +1924,7 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
         // (no synchronisation here: the tables above go back to the context's pool, whose reuse is ordered by this stream, and the host
         // vectors they were filled from live until the solve returns)
     }
+    if ((rc = phase_a.join())) return rc;                   // (phase A's sums, counts and lists: the main stream's from here on)
     hipLaunchKernelGGL(k_flow_gdepth, dim3(nbi), dim3(256), 0, st, label.i(), dst[cur].i(), dlo.i(), gdepth.i(), dmax.i(), N);
     DMG_HIP(hipGetLastError());
     // phase B's cells: marked from the connections' cells down to the sinks, listed with their global depths, their sums withdrawn
