@@ -147,7 +147,7 @@ static void ctx_free(dmg_ctx *c)
 {
     (void)hipSetDevice(c->device);
     (void)dmg_trim(c);
-    for (hipEvent_t e : { c->flow_fork, c->flow_fork2, c->flow_join, c->flow_join2 }) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : { c->flow_fork, c->flow_fork2, c->flow_join, c->flow_join2, c->flow_copied }) if (e) (void)hipEventDestroy(e);
     if (c->flow_side) (void)hipStreamDestroy(c->flow_side);
     if (c->flow_side2) (void)hipStreamDestroy(c->flow_side2);
     if (c->ev0) (void)hipEventDestroy(c->ev0);

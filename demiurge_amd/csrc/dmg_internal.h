@@ -65,7 +65,7 @@ struct dmg_ctx {
     // two streams of the flow solve's own and the events that fork and join them (created at first use): phase A of the upstream sums
     // runs beside the pass search and the host's growth, its small catchments beside its large ones
     hipStream_t flow_side = nullptr, flow_side2 = nullptr;
-    hipEvent_t flow_fork = nullptr, flow_fork2 = nullptr, flow_join = nullptr, flow_join2 = nullptr;
+    hipEvent_t flow_fork = nullptr, flow_fork2 = nullptr, flow_join = nullptr, flow_join2 = nullptr, flow_copied = nullptr;
     dmg_grid flow_rows_grid = {};
     float *flow_rows = nullptr;         // [3][H]: dx, dy, area
     size_t flow_hint_cells = 0;

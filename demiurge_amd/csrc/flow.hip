@@ -1578,8 +1578,35 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
         DMG_HIP(hipMemcpyAsync(ent.data(), dent.p, (size_t)nuniq * 16, hipMemcpyDeviceToHost, st));
         DMG_HIP(hipMemcpyAsync(span.data(), dspan.p, (size_t)(nlakes + 1) * 8, hipMemcpyDeviceToHost, st));
     }
-    // (phase A of the upstream sums has been running on the side streams since the lakes were counted: the host waits for the entries only)
-    DMG_HIP(hipStreamSynchronize(st));
+    // (phase A of the upstream sums has been running on the side streams since the lakes were counted.)  The host waits for the entries
+    // only -- an event behind their copies -- and what the stages after the growth need cleared or preset is queued behind that event:
+    // done while the host grows the lake graph, not after it
+    if (!ctx->flow_copied) DMG_HIP(hipEventCreateWithFlags(&ctx->flow_copied, hipEventDisableTiming));
+    DMG_HIP(hipEventRecord(ctx->flow_copied, st));
+    dev_buf dlo, dcf, gdepth, dstart, order, dmax, dlevel, dassigned, dpar0, dof0, dlv0, dmo;
+    DMG_ALLOC(dlo, N * 4); DMG_ALLOC(dcf, N * 4); DMG_ALLOC(gdepth, N * 4); DMG_ALLOC(dmax, 8);
+    DMG_HIP(hipMemsetAsync(dlo.p, 0xFF, N * 4, st));         // -1
+    DMG_HIP(hipMemsetAsync(dcf.p, 0xFF, N * 4, st));
+    DMG_HIP(hipMemsetAsync(dmax.p, 0, 8, st));
+    if (nlakes) {
+        const unsigned lb0 = (unsigned)((nlakes + 255) / 256);
+        DMG_ALLOC_VAR(dpar0, (size_t)nlakes * 4); DMG_ALLOC_VAR(dof0, (size_t)nlakes * 4); DMG_ALLOC_VAR(dlv0, (size_t)nlakes * 4); DMG_ALLOC_VAR(dmo, (size_t)nlakes);
+        hipLaunchKernelGGL(k_flow_lake_init, dim3(lb0), dim3(256), 0, st, dpar0.i(), nlakes);
+        DMG_HIP(hipMemsetAsync(dof0.p, 0, (size_t)nlakes * 4, st));
+        DMG_HIP(hipMemsetAsync(dlv0.p, 0, (size_t)nlakes * 4, st));
+        DMG_HIP(hipMemsetAsync(dmo.p, 0, (size_t)nlakes, st));
+        if (nmouth) hipLaunchKernelGGL(k_flow_mark, dim3((nmouth + 255) / 256), dim3(256), 0, st, mouths_d.i(), (unsigned char *)dmo.p, nmouth);
+    }
+    DMG_HIP(hipMemsetAsync(tmp.p, 0xFF, N * 4, st));         // (k_flow_lastpos: last position per cell, -1)
+    dev_buf marks;
+    if (two_phase) {
+        DMG_ALLOC(marks, N * 4); DMG_ALLOC(nextB, N * 4);
+        DMG_HIP(hipMemsetAsync(marks.p, 0, N * 4, st));
+        DMG_HIP(hipMemsetAsync(nextB.p, 0xFF, N * 4, st));
+    }
+    hipLaunchKernelGGL(k_fill_f, dim3(nb), dim3(256), 0, st, d_flow, -1.0f, N);        // unreached cells keep -1 (:598-604)
+    DMG_HIP(hipGetLastError());
+    DMG_HIP(hipEventSynchronize(ctx->flow_copied));
     lap("passes: sort/reduce/download");
     if (timing) fprintf(stderr, "[flow] %d lakes, %d pass candidates -> %d lake pairs, %d river mouths\n", nlakes, ncand, nuniq, nmouth);
 
@@ -1860,24 +1887,11 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
     // connections[tolocation] = pass (:588): per tolocation cell the LAST assigned entry survives; its lake hangs one below
     // the cell it drains into (calculateflow's recursion: river mouths at depth 0).  Both on the device: the host only
     // hands over the order in which the growth made its connections
-    dev_buf dlo, dcf, gdepth, dstart, order, dmax, dlevel, dassigned, dpar0, dof0, dlv0, dmo;
-    DMG_ALLOC(dlo, N * 4); DMG_ALLOC(dcf, N * 4); DMG_ALLOC(gdepth, N * 4); DMG_ALLOC(dmax, 8);
-    DMG_HIP(hipMemsetAsync(dlo.p, 0xFF, N * 4, st));         // -1
-    DMG_HIP(hipMemsetAsync(dcf.p, 0xFF, N * 4, st));
-    DMG_HIP(hipMemsetAsync(dmax.p, 0, 8, st));
     if (nlakes) {
-        const unsigned lb0 = (unsigned)((nlakes + 255) / 256);
-        DMG_ALLOC_VAR(dpar0, (size_t)nlakes * 4); DMG_ALLOC_VAR(dof0, (size_t)nlakes * 4); DMG_ALLOC_VAR(dlv0, (size_t)nlakes * 4); DMG_ALLOC_VAR(dmo, (size_t)nlakes);
-        hipLaunchKernelGGL(k_flow_lake_init, dim3(lb0), dim3(256), 0, st, dpar0.i(), nlakes);
-        DMG_HIP(hipMemsetAsync(dof0.p, 0, (size_t)nlakes * 4, st));
-        DMG_HIP(hipMemsetAsync(dlv0.p, 0, (size_t)nlakes * 4, st));
-        DMG_HIP(hipMemsetAsync(dmo.p, 0, (size_t)nlakes, st));
-        if (nmouth) hipLaunchKernelGGL(k_flow_mark, dim3((nmouth + 255) / 256), dim3(256), 0, st, mouths_d.i(), (unsigned char *)dmo.p, nmouth);
         const int na = (int)assigned.size();
         if (na) {
             typedef unsigned long long u64;
             if ((rc = upload_vec(ctx, dassigned, assigned))) return rc;
-            DMG_HIP(hipMemsetAsync(tmp.p, 0xFF, N * 4, st));                  // last position per cell: -1
             hipLaunchKernelGGL(k_flow_lastpos, dim3((na + 255) / 256), dim3(256), 0, st, dassigned.i(), (const u64 *)v1.p, tmp.i(), na);
             hipLaunchKernelGGL(k_flow_connect, dim3((na + 255) / 256), dim3(256), 0, st, dassigned.i(), (const u64 *)k1.p, (const u64 *)v1.p, sdist.i(), tmp.i(),
                                sinkc.i(), dcf.i(), dpar0.i(), dof0.i(), dlv0.f(), na);
@@ -1929,11 +1943,8 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
     DMG_HIP(hipGetLastError());
     // phase B's cells: marked from the connections' cells down to the sinks, listed with their global depths, their sums withdrawn
     if (two_phase) {
-        DMG_HIP(hipMemsetAsync(tmp.p, 0, N * 4, st));
-        DMG_ALLOC(nextB, N * 4);
-        DMG_HIP(hipMemsetAsync(nextB.p, 0xFF, N * 4, st));
-        hipLaunchKernelGGL(k_flow_mark_affected, dim3(nb), dim3(256), 0, st, fc, (const unsigned char *)code.p, dcf.i(), gdepth.i(), tmp.i(), nextB.i(), N);
-        hipLaunchKernelGGL(k_flow_collect_affected, dim3(nbi), dim3(256), 0, st, tmp.i(), gdepth.i(), (unsigned *)acc.p, (unsigned *)keyA.p, (unsigned *)idxA.p, tickA.i() + 6, N);
+        hipLaunchKernelGGL(k_flow_mark_affected, dim3(nb), dim3(256), 0, st, fc, (const unsigned char *)code.p, dcf.i(), gdepth.i(), marks.i(), nextB.i(), N);
+        hipLaunchKernelGGL(k_flow_collect_affected, dim3(nbi), dim3(256), 0, st, marks.i(), gdepth.i(), (unsigned *)acc.p, (unsigned *)keyA.p, (unsigned *)idxA.p, tickA.i() + 6, N);
         DMG_HIP(hipGetLastError());
     }
     int max_depth = 0, tick_host[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
@@ -1950,8 +1961,6 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
         two_phase = false;
         DMG_HIP(hipMemsetAsync(tickA.p, 0, 32, st));
     }
-    hipLaunchKernelGGL(k_fill_f, dim3(nb), dim3(256), 0, st, d_flow, -1.0f, N);        // unreached cells keep -1 (:598-604)
-    DMG_HIP(hipGetLastError());
     static const int look_env = [] { const char *e = dmg_hook("DMG_FLOW_LOOK_THROUGH"); return e ? atoi(e) : -1; }();      // experiments: 0 = every cell waits for its sums to be published
     static const int nblocks_env = [] { const char *e = dmg_hook("DMG_FLOW_NBLOCKS"); return e ? atoi(e) : 0; }();
     if (two_phase) {
@@ -1969,7 +1978,7 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
             DMG_ALLOC(top[0], N * 4); DMG_ALLOC(top[1], N * 4); DMG_ALLOC(hop[0], N * 4); DMG_ALLOC(hop[1], N * 4); DMG_ALLOC(tail, N * 4);
             const dim3 lb((unsigned)((n_aff + 255) / 256));
             reach_tables rt;
-            rt.cell = (const unsigned *)idxA.p; rt.gdepth = gdepth.i(); rt.next = nextB.i(); rt.marked = tmp.i();
+            rt.cell = (const unsigned *)idxA.p; rt.gdepth = gdepth.i(); rt.next = nextB.i(); rt.marked = marks.i();
             rt.top[0] = top[0].i(); rt.top[1] = top[1].i(); rt.hop[0] = hop[0].i(); rt.hop[1] = hop[1].i(); rt.tail = tail.i();
             rt.key = (unsigned long long *)wkey.p;
             rt.n = n_aff; rt.rounds = depth_bits; rt.depth_bits = depth_bits; rt.cell_bits = cell_bits; rt.max_depth = max_depth;      // (2^depth_bits > the longest river)
