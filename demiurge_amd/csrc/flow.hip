@@ -298,16 +298,8 @@ __global__ __launch_bounds__(256) void k_flow_passes(flow_canvas fc, const float
     }
 }
 
-// segment heads of the (lake, from)-sorted candidates
-__global__ void k_flow_heads(const unsigned long long *__restrict__ key, unsigned char *__restrict__ flag, int n)
-{
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) flag[i] = (i == 0 || key[i] != key[i - 1]) ? 1 : 0;
-}
-
 // per unique (lake, from) pass: sort key (lake << 32 | height bits), payload (from << 32 | s), depth of s
-__global__ void k_flow_pack(const unsigned long long *__restrict__ ukey, const unsigned long long *__restrict__ uval,
-                            unsigned long long *__restrict__ key2, unsigned long long *__restrict__ pay, int n)
+__global__ void k_flow_pack(const unsigned long long *ukey, const unsigned long long *uval, unsigned long long *key2, unsigned long long *pay, int n)      // (in place)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -1500,9 +1492,9 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
     }
 
     // boundary cells -> pass candidates; reduce to the lowest pass per lake pair on the device:
-    // sort by (height, s), stable sort by (lake, from), keep segment heads, then order each lake's passes by height
+    // sort by (lake, from), keep each run's lowest (height, s), then order each lake's passes by height
     int cap = (int)std::min<size_t>(N, (size_t)1 << 28);
-    dev_buf k0, v0, k1, v1, flags, tmpst, sdist;
+    dev_buf k0, v0, k1, v1, tmpst, sdist;
     int ncand = 0;
     if (nmouth) {
         DMG_ALLOC_VAR(k0, (size_t)cap * 8); DMG_ALLOC_VAR(v0, (size_t)cap * 8); DMG_ALLOC_VAR(k1, (size_t)cap * 8); DMG_ALLOC_VAR(v1, (size_t)cap * 8);
@@ -1549,24 +1541,25 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
     // on which every cell is a lake of its own -- 134 M candidates at 16384x8192, 0.37 s of sorting that led nowhere.
     if (ncand && nmouth) {
         typedef unsigned long long u64;
+        // (keys are lake << 32 | from, both dense ids: the sorts stop at the bits they have)
+        int pair_bits = 33;
+        while (pair_bits < 64 && (1ull << (pair_bits - 32)) < (unsigned long long)nlakes + 1) pair_bits++;
         size_t tb = 0, tb2 = 0;
-        (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb, (u64 *)v0.p, (u64 *)v1.p, (u64 *)k0.p, (u64 *)k1.p, ncand, 0, 64, st);
-        DMG_ALLOC_VAR(flags, (size_t)ncand);
-        (void)hipcub::DeviceSelect::Flagged(nullptr, tb2, (u64 *)k0.p, (unsigned char *)flags.p, (u64 *)k1.p, nsel.i(), ncand, st);
+        (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb, (u64 *)k0.p, (u64 *)k1.p, (u64 *)v0.p, (u64 *)v1.p, ncand, 0, pair_bits, st);
+        (void)hipcub::DeviceReduce::ReduceByKey(nullptr, tb2, (u64 *)k1.p, (u64 *)k0.p, (u64 *)v1.p, (u64 *)v0.p, nsel.i(), hipcub::Min(), ncand, st);
         DMG_ALLOC_VAR(tmpst, std::max(tb, tb2) + 256);
-        // 1) by (height, s): (v0,k0) -> (v1,k1)
-        DMG_HIP(hipcub::DeviceRadixSort::SortPairs(tmpst.p, tb, (u64 *)v0.p, (u64 *)v1.p, (u64 *)k0.p, (u64 *)k1.p, ncand, 0, 64, st));
-        // 2) stable by (lake, from): (k1,v1) -> (k0,v0); within a lake pair the lowest (height, s) comes first
-        DMG_HIP(hipcub::DeviceRadixSort::SortPairs(tmpst.p, tb, (u64 *)k1.p, (u64 *)k0.p, (u64 *)v1.p, (u64 *)v0.p, ncand, 0, 64, st));
-        hipLaunchKernelGGL(k_flow_heads, dim3((ncand + 255) / 256), dim3(256), 0, st, (const u64 *)k0.p, (unsigned char *)flags.p, ncand);
-        DMG_HIP(hipcub::DeviceSelect::Flagged(tmpst.p, tb2, (u64 *)k0.p, (unsigned char *)flags.p, (u64 *)k1.p, nsel.i(), ncand, st));
-        DMG_HIP(hipcub::DeviceSelect::Flagged(tmpst.p, tb2, (u64 *)v0.p, (unsigned char *)flags.p, (u64 *)v1.p, nsel.i(), ncand, st));
+        // 1) by (lake, from): (k0,v0) -> (k1,v1)
+        DMG_HIP(hipcub::DeviceRadixSort::SortPairs(tmpst.p, tb, (u64 *)k0.p, (u64 *)k1.p, (u64 *)v0.p, (u64 *)v1.p, ncand, 0, pair_bits, st));
+        // 2) per lake pair its lowest (height, s) -- the smallest value of the run: (k1,v1) -> (k0,v0), one entry per pair.  (Through round 6
+        // this was a sort by (height, s), a stable sort by (lake, from) over all 64 bits, segment heads and two selects: sixteen radix
+        // passes over the candidates where seven and a reduction do.)
+        DMG_HIP(hipcub::DeviceReduce::ReduceByKey(tmpst.p, tb2, (u64 *)k1.p, (u64 *)k0.p, (u64 *)v1.p, (u64 *)v0.p, nsel.i(), hipcub::Min(), ncand, st));
         DMG_HIP(hipMemcpyAsync(&nuniq, nsel.p, 4, hipMemcpyDeviceToHost, st));
         DMG_HIP(hipStreamSynchronize(st));
-        // 3) (lake, height) order with (from, s) payload; stable, so equal heights stay in `from` order
-        hipLaunchKernelGGL(k_flow_pack, dim3((nuniq + 255) / 256), dim3(256), 0, st, (const u64 *)k1.p, (const u64 *)v1.p,
+        // 3) (lake, height) order with (from, s) payload; stable, so equal heights stay in `from` order: packed in place, (k0,v0) -> (k1,v1)
+        hipLaunchKernelGGL(k_flow_pack, dim3((nuniq + 255) / 256), dim3(256), 0, st, (const u64 *)k0.p, (const u64 *)v0.p,
                            (u64 *)k0.p, (u64 *)v0.p, nuniq);
-        DMG_HIP(hipcub::DeviceRadixSort::SortPairs(tmpst.p, tb, (u64 *)k0.p, (u64 *)k1.p, (u64 *)v0.p, (u64 *)v1.p, nuniq, 0, 64, st));
+        DMG_HIP(hipcub::DeviceRadixSort::SortPairs(tmpst.p, tb, (u64 *)k0.p, (u64 *)k1.p, (u64 *)v0.p, (u64 *)v1.p, nuniq, 0, pair_bits, st));
         DMG_ALLOC_VAR(sdist, (size_t)nuniq * 4);
         hipLaunchKernelGGL(k_flow_gather_dist, dim3((nuniq + 255) / 256), dim3(256), 0, st, (const u64 *)v1.p, dst[cur].i(), sdist.i(), nuniq);
         // the host's view: entries as 16-byte records and every lake's range of them (the sink distances stay on the device)
