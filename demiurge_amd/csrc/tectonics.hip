@@ -165,10 +165,13 @@ __global__ void k_tect_trig(canvas c, int n, int which, float2 *out)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float s = ((float)i + 0.5f) / (float)n;
+    float s = ((float)i + 0.5f) / (float)n;
+    // which 2: of the lon of the column offset(st, vec2(0)) hands back -- st.x through the two wraps of Shader.h:86,97, which
+    // cost it its low bits (unfold's centre tap)
+    if (which == 2 && c.lonwrap) { s = d_mod(s + 1.0f, 1.0f); s = d_mod(s + 1.0f, 1.0f); }
     float lon, lat, sn, cs;
     t_spheric(c, s, s, &lon, &lat);
-    t_sincos(which ? lat : lon, &sn, &cs);
+    t_sincos(which == 1 ? lat : lon, &sn, &cs);
     out[i] = make_float2(sn, cs);
 }
 
@@ -243,8 +246,13 @@ __global__ void __launch_bounds__(256) k_tect_ring_gather(canvas c, const float4
             float nx, ny;
             t_offset(c, sx, sy, tab->ct[i] * radius * factor, tab->sn[i] * radius, (float)S, (float)S, &nx, &ny);
             float4 a = t_fetch(map, S, S, nx, ny);
-            float nz = a.z + t_geodistance(c, nx, ny, sx, sy, (float)S);
-            if ((nz < fc.z || fc.x == 0.0f) && a.x != 0.0f) fc = make_float4(a.x, -1.1f, nz, -1.1e6f);
+            // the shader's `(nz < fc.z || fc.x == 0) && a.x != 0`: a tap that lands in the gap itself (a.x == 0) cannot
+            // change the texel, so its distance -- most of a tap's ~250 instructions -- is not worked out; deep inside a
+            // gap whole waves skip it
+            if (a.x != 0.0f) {
+                float nz = a.z + t_geodistance(c, nx, ny, sx, sy, (float)S);
+                if (nz < fc.z || fc.x == 0.0f) fc = make_float4(a.x, -1.1f, nz, -1.1e6f);
+            }
         }
         newval[k] = fc;
     }
@@ -265,17 +273,15 @@ __global__ void k_tect_ring_scatter(float4 *__restrict__ map, const unsigned *__
 // back to plates (:216-251)
 __global__ void __launch_bounds__(256) k_tect_unfold(canvas c, const float4 *__restrict__ map, int S, ctex4 old, mat3 inv,
                                                      float index, float4 *__restrict__ out, int w, int h,
-                                                     const float2 *__restrict__ trig_lon, const float2 *__restrict__ trig_lat)
+                                                     const float2 *__restrict__ trig_lon, const float2 *__restrict__ trig_lat,
+                                                     const float2 *__restrict__ trig_lon0)
 {
     int x = blockIdx.x * TT_W + (int)(threadIdx.x % TT_W), y = blockIdx.y * TT_H + (int)(threadIdx.x / TT_W);
     if (x >= w || y >= h) return;
     float sx = ((float)x + 0.5f) / (float)w, sy = ((float)y + 0.5f) / (float)h;
-    float lon, phi, u, v;
-    t_spheric(c, sx, sy, &lon, &phi);
-    {
-        const float2 tl = trig_lat[y], to = trig_lon[x];        // (sin, cos) of phi and lon: the row's and the column's
-        t_rotate_cs(c, inv, tl.x, tl.y, to.x, to.y, &u, &v);
-    }
+    float u, v;
+    const float2 tl = trig_lat[y], to = trig_lon[x];            // (sin, cos) of phi and lon: the row's and the column's
+    t_rotate_cs(c, inv, tl.x, tl.y, to.x, to.y, &u, &v);
     float4 a = t_fetch(map, S, S, u, v);
     float4 fc = t_fetch(old.p, old.w, old.h, sx, sy);
     if (fc.y >= 0.0f) fc.y += 0.01f;                               // increment age
@@ -285,9 +291,21 @@ __global__ void __launch_bounds__(256) k_tect_unfold(canvas c, const float4 *__r
     const float4 none = make_float4(0.0f, -1.0f, 0.0f, 0.0f);
     bool is_none = __float_as_uint(fc.x) == 0u && fc.y == -1.0f && __float_as_uint(fc.z) == 0u && __float_as_uint(fc.w) == 0u;
     if (!(a.y <= 0.0f && fc.x > 0.0f) && !is_none) {
-        float factor = 1.0f / t_cos(fabsf(phi));
+        // cos |phi| is the row's cosine (sincos takes |x| first; the sign only goes to the sine): the same bits from the table
+        float factor = 1.0f / tl.y;
+        // The centre tap is offset(st, vec2(0)): st.y itself and st.x through the two wraps -- a value of the column alone, so
+        // its sine and cosine come from a table as well (k_tect_trig, which 2) and the tap is one rotation instead of
+        // offset + two sincos + rotation.  (0 * factor is 0 for every finite factor; a row whose cosine is not a normal number
+        // -- none on a sphere -- takes the loop from its first tap.)
         bool differentIndex = true;
-        for (int k = 0; k < 9 && differentIndex; k++) {
+        int k0 = 0;
+        if (w == S && fabsf(factor) < 3.0e38f) {
+            const float2 t0 = trig_lon0[x];
+            t_rotate_cs(c, inv, tl.x, tl.y, t0.x, t0.y, &u, &v);
+            differentIndex = t_fetch(map, S, S, u, v).x != index;
+            k0 = 1;
+        }
+        for (int k = k0; k < 9 && differentIndex; k++) {
             int q = (k + 4) % 9, i = q / 3 - 1, j = q % 3 - 1;          // (0,0) first, then the reference's order
             float ox, oy, lo, la;
             t_offset(c, sx, sy, (float)i * factor, (float)j, (float)S, (float)S, &ox, &oy);
@@ -353,7 +371,7 @@ struct dmg_tectonics {
     long steps_done = 0;
     // (sin, cos) per column of a texture S wide, per row of one S high and of one H high (k_tect_trig): the storage shuffle
     // (c <-> plate) only ever makes textures of S x S and S x H
-    float2 *trig_lon = nullptr, *trig_lat_S = nullptr, *trig_lat_H = nullptr;
+    float2 *trig_lon = nullptr, *trig_lat_S = nullptr, *trig_lat_H = nullptr, *trig_lon0 = nullptr;   // (trig_lon0: of the centre tap's column, k_tect_trig which 2)
     const float2 *trig_lat(int h) const { return h == S ? trig_lat_S : trig_lat_H; }
 };
 
@@ -397,6 +415,7 @@ int dmg_tectonics_create(dmg_ctx *ctx, const dmg_grid *grid, const float *terrai
     if (e == hipSuccess) e = hipMalloc((void **)&t->trig_lon, (size_t)t->S * sizeof(float2));
     if (e == hipSuccess) e = hipMalloc((void **)&t->trig_lat_S, (size_t)t->S * sizeof(float2));
     if (e == hipSuccess) e = hipMalloc((void **)&t->trig_lat_H, (size_t)grid->H * sizeof(float2));
+    if (e == hipSuccess) e = hipMalloc((void **)&t->trig_lon0, (size_t)t->S * sizeof(float2));
     if (e == hipSuccess) e = hipMalloc((void **)&t->count, sizeof(unsigned));
     if (e != hipSuccess) {
         dmg_tectonics_destroy(t);
@@ -418,6 +437,7 @@ int dmg_tectonics_create(dmg_ctx *ctx, const dmg_grid *grid, const float *terrai
         hipLaunchKernelGGL(k_tect_trig, dim3((unsigned)((t->S + 255) / 256)), dim3(256), 0, ctx->stream, t->cv, t->S, 0, t->trig_lon);
         hipLaunchKernelGGL(k_tect_trig, dim3((unsigned)((t->S + 255) / 256)), dim3(256), 0, ctx->stream, t->cv, t->S, 1, t->trig_lat_S);
         hipLaunchKernelGGL(k_tect_trig, dim3((unsigned)((grid->H + 255) / 256)), dim3(256), 0, ctx->stream, t->cv, grid->H, 1, t->trig_lat_H);
+        hipLaunchKernelGGL(k_tect_trig, dim3((unsigned)((t->S + 255) / 256)), dim3(256), 0, ctx->stream, t->cv, t->S, 2, t->trig_lon0);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);                   // `terrain` is the caller's buffer
@@ -441,7 +461,7 @@ void dmg_tectonics_destroy(dmg_tectonics *t)
     if (t->ring) (void)hipFree(t->ring);
     if (t->active) (void)hipFree(t->active);
     if (t->count) (void)hipFree(t->count);
-    for (void *q : { (void *)t->trig_lon, (void *)t->trig_lat_S, (void *)t->trig_lat_H }) if (q) (void)hipFree(q);
+    for (void *q : { (void *)t->trig_lon, (void *)t->trig_lat_S, (void *)t->trig_lat_H, (void *)t->trig_lon0 }) if (q) (void)hipFree(q);
     dmg_ctx *ctx = t->ctx;
     delete t;
     dmg_ctx_release(ctx);
@@ -513,7 +533,7 @@ int dmg_tectonics_unfold(dmg_tectonics *t)
         std::swap(t->c_h, t->ph[k]);
         hipLaunchKernelGGL(k_tect_unfold, grid_tiles(t->pw[k], t->ph[k]), dim3(256), 0, t->ctx->stream, t->cv,
                            t->map[t->cur], t->S, ctex4{ t->cbuf, t->c_w, t->c_h }, plate_mat3(t, k, true), (float)(k + 1),
-                           t->plate[k], t->pw[k], t->ph[k], t->trig_lon, t->trig_lat(t->ph[k]));
+                           t->plate[k], t->pw[k], t->ph[k], t->trig_lon, t->trig_lat(t->ph[k]), t->trig_lon0);
     }
     DMG_HIP(hipGetLastError());
     t->steps_done++;
