@@ -282,12 +282,198 @@ __global__ __launch_bounds__(256) void k_blur13_axis2(canvas c, const float *__r
     if ((int)(blockIdx.x * 256 + threadIdx.x) < W) dst[(size_t)y * W + x] = color;
 }
 
+// Round 6: the (0, r) pass streamed down the columns.  Along y every tap of a cell reads the SAME column pair with the same weight
+// (blur_x `plain`; the cell's own tap has its own pair, from st.x before the wraps), and a tap's value is
+//     fma(wy, b - a, a)   with   a = fma(wx, T[j0][i1] - T[j0][i0], T[j0][i0]),   b = the same on row j1:
+// a and b are values of a (source row, column) alone -- the row's horizontal lerp.  k_blur13_axis2<1> works each of them out once per
+// tap that reads it: 28 loads and 14 lerps per cell, which is what bound it (200 vector instructions and 28 trips through the vector
+// memory path per cell).  Here a thread owns a column and walks down `rows` rows of it; every source row's lerp is worked out ONCE --
+// four loads, two lerps -- and kept in a ring of the thread's own in LDS (dynamic row index; a thread reads only what it wrote: no
+// barrier on the data), and a tap is two LDS reads and the vertical lerp.  Same operations on the same operands in the same order
+// as k_blur13 (tests/test_gpu_filters.py holds it against k_blur13_axis2, k_blur13 and the goldens).  What is the same for a whole
+// row -- the taps' rows, weights, pole crossings -- is worked out by 56 threads per chunk of eight rows with the statements of
+// k_blur13_axis2 and handed round through LDS.  A tap that crosses a pole (its rows are mirrored and its columns the mirrored pair)
+// is taken the old way, straight from memory; RING rows must hold a row's taps: 2 K + 8 of them, K = ceil(5.18 r) + 2.
+#define BLUR_YT_CHUNK 8
+#define BLUR_YT_RO 16          // ring of the cell's own tap: rows y - 1 .. y + 1 and a chunk
+// a source row's horizontal lerps, CHUNK rows at a time: rows [*jfill, jneed] into ring (loads of a row past jneed repeat jneed's)
+template <int NR, int BT>
+__device__ __forceinline__ void blur_yt_fill(float (*ring)[BT], const float *__restrict__ src, int W, unsigned o0, unsigned o1, float wx,
+                                             int *jfill, int jneed, int tid)
+{
+    while (*jfill <= jneed) {
+        float t0[BLUR_YT_CHUNK], t1[BLUR_YT_CHUNK];
+#pragma unroll
+        for (int q = 0; q < BLUR_YT_CHUNK; q++) {
+            const int j = min(*jfill + q, jneed);
+            const char *row = reinterpret_cast<const char *>(src + (size_t)j * W);
+            t0[q] = *reinterpret_cast<const float *>(row + o0); t1[q] = *reinterpret_cast<const float *>(row + o1);
+        }
+#pragma unroll
+        for (int q = 0; q < BLUR_YT_CHUNK; q++) {       // (a row past jneed goes to the spare slot NR: no branch, so every load is waited for here)
+            const int j = *jfill + q;
+            ring[j <= jneed ? (j & (NR - 1)) : NR][tid] = fmaf(wx, __fsub_rn(t1[q], t0[q]), t0[q]);      // (blur_tap_rows' a and b)
+        }
+        *jfill = min(*jfill + BLUR_YT_CHUNK, jneed + 1);
+    }
+}
+// a tap's rows as k_blur13_axis2 has them, and where the ring keeps those rows (bytes from the ring's start to the row, for a row
+// that crosses no pole); any: some tap of this output row crosses a pole (kept with the cell's own rows, t = 6)
+struct alignas(32) blur_yrec { int j0, j1, crossed, pad; float wy; int o0, o1, any; };
+// ... and the part of a row's seven records the common case reads, in one 64-byte line (ONE s_load_dwordx16 per row): per tap its
+// weight and its two ring offsets in sixteen bits each (a ring is at most 32 KB), then `any`
+struct alignas(64) blur_yfast { struct { float wy; unsigned o01; } t[7]; int any, pad; };
+static_assert(sizeof(blur_yfast) == 64 && sizeof(blur_yrec) == 32, "one cache line; two 16-byte halves");
+// What is the same for a whole row of the (0, r) pass -- the taps' rows, weights, pole crossings: what k_blur13_axis2<1>'s first four
+// threads work out per row, statement for statement -- once per pass into a table the main kernel reads with scalar loads:
+// tab[(y - c.row0) * 7 + t], t = 0..5 the taps in k_blur13's order, 6 the cell's own rows.  ring / pitch: rows and bytes per row of
+// the main kernel's LDS ring.
+__global__ void k_blur13_yrec(canvas c, float r, int nrows, int ring, int pitch, blur_yrec *__restrict__ tab, blur_yfast *__restrict__ fast)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nrows * 7) return;
+    const int yy = c.row0 + i / 7, t = i % 7, H = c.H;
+    const float sy = d_sty(c, yy);
+    blur_yrec rr = {};
+    int any = 0;
+#pragma unroll
+    for (int u = 0; u < 6; u++) {                 // (t = 6 looks at all six taps for `any`; the others at their own)
+        if (t != 6 && t != u) continue;
+        const int k = u >> 1, sgn = u & 1;
+        const float kk = k == 0 ? 1.411764705882353f : (k == 1 ? 3.2941176470588234f : 5.176470588235294f);
+        float o = __fmul_rn(kk, r);
+        o = __fdiv_rn(o, (float)H);
+        float py = __fadd_rn(sy, sgn ? -o : o);
+        int cr = 0;
+        if (c.spole && py < 0.0f) { py = -py; cr++; }
+        if (c.npole && py > 1.0f) { py = __fsub_rn(2.0f, py); cr++; }
+        any |= cr;
+        if (t == u) {
+            const blur_y by = blur_ypart(py, H);
+            rr.j0 = by.j0; rr.j1 = by.j1; rr.crossed = cr; rr.wy = by.wy;
+            rr.o0 = (by.j0 & (ring - 1)) * pitch; rr.o1 = (by.j1 & (ring - 1)) * pitch;
+        }
+    }
+    if (t == 6) {
+        const blur_y by = blur_ypart(sy, H);
+        rr.j0 = by.j0; rr.j1 = by.j1; rr.crossed = 0; rr.wy = by.wy;
+        rr.o0 = (by.j0 & (BLUR_YT_RO - 1)) * pitch; rr.o1 = (by.j1 & (BLUR_YT_RO - 1)) * pitch;
+        rr.any = any;
+    }
+    tab[i] = rr;
+    fast[i / 7].t[t].wy = rr.wy;
+    fast[i / 7].t[t].o01 = (unsigned)rr.o0 | ((unsigned)rr.o1 << 16);
+    if (t == 6) fast[i / 7].any = any;
+}
+template <int RING, int BT>
+__global__ __launch_bounds__(BT) void k_blur13_ytile(canvas c, const float *__restrict__ src, float *__restrict__ dst, float r, int nrows, int rows, int K,
+                                                     const blur_yrec *__restrict__ tab, const blur_yfast *__restrict__ fast)
+{
+    static_assert(RING * BT * 4 <= 65536, "ring offsets in sixteen bits");
+    __shared__ float s_p[RING + 1][BT];                  // lerps with the taps' column pair, row j at j & (RING - 1) (+ a spare slot)
+    __shared__ float s_o[BLUR_YT_RO + 1][BT];            // ... with the cell's own column pair
+    const int W = c.W, H = c.H, tid = (int)threadIdx.x;
+    const int y0 = c.row0 + (int)blockIdx.y * rows, yend = min(y0 + rows, c.row0 + nrows);
+    const int x = min((int)(blockIdx.x * BT) + tid, W - 1);          // (a column past the edge repeats the last: not stored)
+    const bool store = (int)(blockIdx.x * BT) + tid < W;
+    const float sx = d_stx(c, x);
+    const blur_x xo = blur_xpart(sx, W);
+    float px1 = sx;
+    if (c.lonwrap) px1 = d_mod(__fadd_rn(px1, 1.0f), 1.0f);
+    const blur_x plain = blur_xpart(c.lonwrap ? d_mod(__fadd_rn(px1, 1.0f), 1.0f) : px1, W);
+    const float w0 = 0.1964825501511404f, w[3] = { 0.2969069646728344f, 0.09447039785044732f, 0.010381362401148057f };
+    int jfill = max(y0 - K, 0), jfill_o = max(y0 - 1, 0);
+    const char *ringp = reinterpret_cast<const char *>(&s_p[0][tid]), *ringo = reinterpret_cast<const char *>(&s_o[0][tid]);
+    for (int yc = y0; yc < yend; yc += BLUR_YT_CHUNK) {
+        const int ylast = min(yc + BLUR_YT_CHUNK, yend) - 1;
+        // the source rows the chunk needs and the rings do not hold yet: two loads and a lerp each, a chunk's worth in flight
+        blur_yt_fill<RING, BT>(s_p, src, W, (unsigned)plain.i0 * 4u, (unsigned)plain.i1 * 4u, plain.wx, &jfill, min(H - 1, ylast + K), tid);
+        blur_yt_fill<BLUR_YT_RO, BT>(s_o, src, W, (unsigned)xo.i0 * 4u, (unsigned)xo.i1 * 4u, xo.wx, &jfill_o, min(H - 1, ylast + 1), tid);
+        // A row's step is a chain of latencies -- its records from the scalar cache, then its ring reads: the next row's line is asked
+        // for before this row's ring reads, so the two waits are one
+        blur_yfast cur = fast[yc - c.row0];
+        for (int y = yc; y <= ylast; y++) {
+            const blur_yfast nxt = fast[min(y + 1, ylast) - c.row0];
+            const blur_yfast q = cur;
+            cur = nxt;
+            float color;
+            if (q.any == 0) {
+                // no tap of this row crosses a pole: fourteen ring reads at the records' offsets, then the taps in k_blur13's order
+                float a[7], b[7];
+#pragma unroll
+                for (int t = 0; t < 7; t++) {
+                    const char *ring = t == 6 ? ringo : ringp;
+                    a[t] = *reinterpret_cast<const float *>(ring + (q.t[t].o01 & 0xffffu)); b[t] = *reinterpret_cast<const float *>(ring + (q.t[t].o01 >> 16));
+                }
+                color = __fadd_rn(0.0f, __fmul_rn(fmaf(q.t[6].wy, __fsub_rn(b[6], a[6]), a[6]), w0));
+#pragma unroll
+                for (int t = 0; t < 6; t++) color = __fadd_rn(color, __fmul_rn(fmaf(q.t[t].wy, __fsub_rn(b[t], a[t]), a[t]), w[t >> 1]));
+            } else {
+                const blur_yrec *rec = tab + (size_t)(y - c.row0) * 7;
+                const float a0 = *reinterpret_cast<const float *>(ringo + rec[6].o0), b0 = *reinterpret_cast<const float *>(ringo + rec[6].o1);
+                color = __fadd_rn(0.0f, __fmul_rn(fmaf(rec[6].wy, __fsub_rn(b0, a0), a0), w0));
+                float px = d_pole_lon(__fadd_rn(__fmul_rn(px1, __fsub_rn(c.c3, c.c2)), c.c2));
+                px = __fdiv_rn(__fsub_rn(px, c.c2), __fsub_rn(c.c3, c.c2));
+                if (c.lonwrap) px = d_mod(__fadd_rn(px, 1.0f), 1.0f);
+                const blur_x mirrored = blur_xpart(px, W);
+#pragma unroll
+                for (int k = 0; k < 3; k++)
+#pragma unroll
+                    for (int sgn = 0; sgn < 2; sgn++) {
+                        const int t = 2 * k + sgn;
+                        const blur_yrec rt = rec[t];
+                        float v;
+                        if (rt.crossed == 2) {
+                            const float kk = k == 0 ? 1.411764705882353f : (k == 1 ? 3.2941176470588234f : 5.176470588235294f);
+                            v = blur_tap_literal(c, src, sx, d_sty(c, y), sgn ? -0.0f : 0.0f, sgn ? -__fmul_rn(kk, r) : __fmul_rn(kk, r));
+                        } else if (rt.crossed)
+                            v = blur_tap_rows(src + (size_t)rt.j0 * W, src + (size_t)rt.j1 * W, mirrored, rt.wy);
+                        else {
+                            const float a = *reinterpret_cast<const float *>(ringp + rt.o0), b = *reinterpret_cast<const float *>(ringp + rt.o1);
+                            v = fmaf(rt.wy, __fsub_rn(b, a), a);
+                        }
+                        color = __fadd_rn(color, __fmul_rn(v, w[k]));
+                    }
+            }
+            if (store) dst[(size_t)y * W + x] = color;
+        }
+    }
+}
+
 // one pass of blur13 in direction (dirx, diry): the axis forms where they apply
-static void launch_blur13(hipStream_t st, dim3 g, const canvas &c, const float *src, float *dst, const float *pf, float dirx, float diry)
+// yrec: room for a blur_yfast and 7 blur_yrec per row of the launch (BLUR_YREC_BYTES), or null: the (0, r) pass by k_blur13_axis2<1>
+#define BLUR_YREC_BYTES(nrows) ((size_t)(nrows) * (sizeof(blur_yfast) + 7 * sizeof(blur_yrec)))
+static void launch_blur13(hipStream_t st, dim3 g, const canvas &c, const float *src, float *dst, const float *pf, float dirx, float diry, void *yrec = nullptr)
 {
     static const bool literal = dmg_hook("DMG_BLUR_LITERAL") != nullptr;       // tests: the general kernel for every pass
     const dim3 ga((unsigned)((c.W + 256 * BLUR_CPT - 1) / (256 * BLUR_CPT)), g.y);
     static const bool axis_v1 = dmg_hook("DMG_BLUR_AXIS_V1") != nullptr;       // tests, A/B: the round-3 axis kernels
+    static const bool no_ytile = dmg_hook("DMG_BLUR_NO_YTILE") != nullptr;     // tests, A/B: the (0, r) pass by k_blur13_axis2<1> (round 5's form)
+    if (!literal && !axis_v1 && !no_ytile && yrec && dirx == 0.0f && diry > 0.0f) {
+        // the (0, r) pass streamed down the columns where a ring of 16 / 32 / 64 rows holds a row's taps (r up to 5.2)
+        const int K = (int)ceilf(5.1765f * diry) + 1, need = 2 * K + BLUR_YT_CHUNK, nrows = (int)g.y;
+        if (need <= 64 && nrows >= 1) {
+            const int BT = need <= 32 ? 256 : 128;
+            const int bx = (c.W + BT - 1) / BT;
+            // rows per block: enough blocks to fill the chip, as tall as that allows (a block re-reads 2 K rows)
+            int rows = (int)(((long long)nrows * bx + 4095) / 4096);
+            rows = std::min(std::max((rows + BLUR_YT_CHUNK - 1) / BLUR_YT_CHUNK * BLUR_YT_CHUNK, 2 * BLUR_YT_CHUNK), 256);
+            static const int rows_hook = [] { const char *e = dmg_hook("DMG_BLUR_YT_ROWS"); return e ? atoi(e) : 0; }();   // tests: every ring size on small grids
+            if (rows_hook >= BLUR_YT_CHUNK) rows = rows_hook / BLUR_YT_CHUNK * BLUR_YT_CHUNK;
+            const dim3 gt((unsigned)bx, (unsigned)((nrows + rows - 1) / rows));
+            // (a block reads rows + 2 K source rows: on a small grid with a large radius -- 4096 x 2048 from r = 1.2 -- that is
+            // more than twice its rows, and k_blur13_axis2<1> is the faster one: tools/blur_pass_probe.py)
+            if (2 * K <= rows || rows_hook) {
+            blur_yfast *fast = (blur_yfast *)yrec;                      // (a pool block: 256-byte aligned)
+            blur_yrec *tab = (blur_yrec *)(fast + nrows);
+            hipLaunchKernelGGL(k_blur13_yrec, dim3((unsigned)((nrows * 7 + 255) / 256)), dim3(256), 0, st, c, diry, nrows, need <= 16 ? 16 : (need <= 32 ? 32 : 64), BT * 4, tab, fast);
+            if (need <= 16) hipLaunchKernelGGL((k_blur13_ytile<16, 256>), gt, dim3(256), 0, st, c, src, dst, diry, nrows, rows, K, tab, fast);
+            else if (need <= 32) hipLaunchKernelGGL((k_blur13_ytile<32, 256>), gt, dim3(256), 0, st, c, src, dst, diry, nrows, rows, K, tab, fast);
+            else hipLaunchKernelGGL((k_blur13_ytile<64, 128>), gt, dim3(128), 0, st, c, src, dst, diry, nrows, rows, K, tab, fast);
+            return;
+            }
+        }
+    }
     if (!literal && !axis_v1 && diry == 0.0f && dirx > 0.0f) hipLaunchKernelGGL(k_blur13_axis2<0>, ga, dim3(256), 0, st, c, src, dst, pf, dirx);
     else if (!literal && !axis_v1 && dirx == 0.0f && diry > 0.0f) hipLaunchKernelGGL(k_blur13_axis2<1>, ga, dim3(256), 0, st, c, src, dst, pf, diry);
     else if (!literal && diry == 0.0f && dirx > 0.0f) hipLaunchKernelGGL(k_blur13_axis<0>, ga, dim3(256), 0, st, c, src, dst, pf, dirx);
@@ -997,9 +1183,11 @@ int blur_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, fl
     if (rc) return rc;
     std::vector<float> rl = blur_rlist(radius);
     dim3 g((grid.W + 255) / 256, grid.H);
+    dev_buf drec;                                    // the (0, r) passes' per-row records (k_blur13_yrec)
+    if (drec.alloc(ctx, BLUR_YREC_BYTES(grid.H)) != hipSuccess) return dmg_fail(DMG_ENOMEM, "blur: no device memory for the row records");
     size_t i = 0;
     do {                                             // Blur::step (:97-117)
-        launch_blur13(ctx->stream, g, c, d_field, d_tmp, dpf.f(), 0.0f, rl[i]);   // (0, r)
+        launch_blur13(ctx->stream, g, c, d_field, d_tmp, dpf.f(), 0.0f, rl[i], drec.p);   // (0, r)
         launch_blur13(ctx->stream, g, c, d_tmp, d_field, dpf.f(), rl[i], 0.0f);   // (r, 0)
         DMG_HIP(hipGetLastError());
         i++;
@@ -1693,6 +1881,7 @@ struct dmg_field {
     float *d[2] = { nullptr, nullptr };
     int cur = 0;
     dev_buf dpf, ddx, ddy;                           // per-row tables of the whole grid (tiny): blur's cos|lat|, pixelsize x / y
+    dev_buf drec;                                    // the (0, r) blur pass' records of the band's rows (k_blur13_yrec)
     bool tables = false;
     float *virt(int k) const { return d[k] - (size_t)(y0 - gs) * grid.W; }
 };
@@ -1709,6 +1898,7 @@ static int field_tables(dmg_field *f)
     dmg_ctx *ctx = f->ctx;
     int rc;
     if ((rc = upload_rows(ctx, f->dpf, pf)) || (rc = upload_rows(ctx, f->ddx, dxr)) || (rc = upload_rows(ctx, f->ddy, dyr))) return rc;
+    if (f->drec.alloc(ctx, BLUR_YREC_BYTES(f->y1 - f->y0)) != hipSuccess) return dmg_fail(DMG_ENOMEM, "field: no device memory for the blur's row records");
     f->tables = true;
     return DMG_OK;
 }
@@ -1862,7 +2052,7 @@ int dmg_field_blur_pass(dmg_field *f, float r, int vertical)
     canvas c = make_canvas(f->grid, f->topo);
     c.row0 = f->y0;
     dim3 g((f->grid.W + 255) / 256, f->y1 - f->y0);
-    launch_blur13(f->ctx->stream, g, c, (const float *)f->virt(f->cur), f->virt(f->cur ^ 1), f->dpf.f(), vertical ? 0.0f : r, vertical ? r : 0.0f);
+    launch_blur13(f->ctx->stream, g, c, (const float *)f->virt(f->cur), f->virt(f->cur ^ 1), f->dpf.f(), vertical ? 0.0f : r, vertical ? r : 0.0f, f->drec.p);
     DMG_HIP(hipGetLastError());
     f->cur ^= 1;
     return DMG_OK;

@@ -57,7 +57,7 @@ def _blur_cases(capi):
 
 def test_blur_axis_kernels_equal_the_literal_kernel_and_the_oracle(dev, oracle):
     """Blur::step's two directions go through the axis forms of blur13 (k_blur13_axis2: what is the same for a row in scalar
-    registers); DMG_BLUR_LITERAL=1 (read once per process: a child) sends every pass through the general kernel, DMG_BLUR_AXIS_V1=1
+    registers; the (0, r) pass since round 6 k_blur13_ytile: a thread walks down a column with the rows' lerps in an LDS ring); DMG_BLUR_LITERAL=1 (read once per process: a child) sends every pass through the general kernel, DMG_BLUR_AXIS_V1=1
     through the axis kernels of round 3.  Same bits, and the oracle's, on random fields."""
     import hashlib
     import os
@@ -74,8 +74,10 @@ def test_blur_axis_kernels_equal_the_literal_kernel_and_the_oracle(dev, oracle):
             "import test_gpu_filters as t\nctx = capi.Context(0)\n"
             "for W, H, coords, r, f in t._blur_cases(capi):\n    print(hashlib.sha256(ctx.blur(capi.make_grid(W, H, coords), f, r).tobytes()).hexdigest())\n"
             % (str(Path(__file__).resolve().parents[1]), str(Path(__file__).resolve().parent)))
-    for hook in ("DMG_BLUR_LITERAL", "DMG_BLUR_AXIS_V1"):       # the general kernel; the axis kernels before round 5's row-uniform form
-        res = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **{hook: "1"}), capture_output=True, text=True, timeout=600)
+    # the general kernel; the axis kernels before round 5's row-uniform form; round 5's (0, r) pass instead of the one streamed down the columns
+    # ... and the streamed pass with blocks of 8 and of 40 rows whatever the radius (every ring size, pole crossings inside the rings' rows)
+    for hook, val in (("DMG_BLUR_LITERAL", "1"), ("DMG_BLUR_AXIS_V1", "1"), ("DMG_BLUR_NO_YTILE", "1"), ("DMG_BLUR_YT_ROWS", "8"), ("DMG_BLUR_YT_ROWS", "40")):
+        res = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **{hook: val}), capture_output=True, text=True, timeout=600)
         assert res.returncode == 0, res.stderr[-2000:]
         assert res.stdout.split() == mine, hook
 
