@@ -24,6 +24,7 @@ kernels = [  # substring, what, unavoidable bytes per cell and launch
     ("k_flow_jump", "pointer jumping", 16),
     ("k_blur13_axis2<0>", "blur13 x", 8),
     ("k_blur13_axis2<1>", "blur13 y", 8),
+    ("k_blur13_ytile", "blur13 y, streamed", 8),
     ("k_flow_passes", "flow: pass candidates", 12),
     # (round 6: the map is W x W texels of 16 B -- two per cell of the W x H canvas: written once = 32 B per cell -- and each of the
     # two plates' 16-byte texels is gathered about once = 32 B; round 4's 16 B per cell made the fold look 4.6 x over its bytes)

@@ -18,6 +18,7 @@ table = [  # kernel substring, what, unavoidable bytes per cell and launch, cell
     ("k_erosion(", "erosion / uplift pass: h 4 + flow 4 + uplift 4 in, h 4 out", 16, N),
     ("k_blur13_axis<0>", "blur13 along x: 4 in, 4 out", 8, N),
     ("k_blur13_axis<1>", "blur13 along y: 4 in, 4 out", 8, N),
+    ("k_blur13_ytile", "blur13 along y, streamed down the columns: 4 in, 4 out", 8, N),
     ("k_flow_direction", "flow direction codes: h 4 in, code 1 out", 5, N),
     ("k_flow_jump", "pointer jumping round: parent 4 + dist 4 in (+ gathers), 8 out", 16, N),
     ("k_tect_fold", "tectonics fold: map 16 out (+ plate gathers)", 16, N),
