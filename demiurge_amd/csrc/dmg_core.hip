@@ -126,6 +126,7 @@ int dmg_trim(dmg_ctx *c)
     c->scratch_pool.clear();
     c->scratch_pool_bytes = 0;
     if (c->flow_rows) { (void)hipFree(c->flow_rows); c->flow_rows = nullptr; }      // (the flow solve builds them again)
+    if (c->blur_rows) { (void)hipFree(c->blur_rows); c->blur_rows = nullptr; }      // (... and the blur)
     return DMG_OK;
 }
 

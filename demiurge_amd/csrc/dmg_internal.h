@@ -68,6 +68,10 @@ struct dmg_ctx {
     hipEvent_t flow_fork = nullptr, flow_fork2 = nullptr, flow_join = nullptr, flow_join2 = nullptr, flow_copied = nullptr;
     dmg_grid flow_rows_grid = {};
     float *flow_rows = nullptr;         // [3][H]: dx, dy, area
+    // ... and the blur's: cos|lat| per row of the last grid and room for the (0, r) passes' row records (blur_device: recomputed and
+    // uploaded per call they were a host loop, a copy and a synchronisation of every erosion round); released by dmg_trim
+    dmg_grid blur_rows_grid = {};
+    void *blur_rows = nullptr;          // [H] floats, then BLUR_YREC_BYTES(H) of records (256-byte aligned)
     size_t flow_hint_cells = 0;
     int flow_hint_rounds = 0;
     unsigned flow_hint_age = 0;

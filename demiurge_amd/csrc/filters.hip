@@ -452,13 +452,14 @@ static void launch_blur13(hipStream_t st, dim3 g, const canvas &c, const float *
     if (!literal && !axis_v1 && !no_ytile && yrec && dirx == 0.0f && diry > 0.0f) {
         // the (0, r) pass streamed down the columns where a ring of 16 / 32 / 64 rows holds a row's taps (r up to 5.2)
         const int K = (int)ceilf(5.1765f * diry) + 1, need = 2 * K + BLUR_YT_CHUNK, nrows = (int)g.y;
-        if (need <= 64 && nrows >= 1) {
+        static const int rows_hook = [] { const char *e = dmg_hook("DMG_BLUR_YT_ROWS"); return e ? atoi(e) : 0; }();   // tests: every ring size on small grids
+        // (below two million cells a pass is its launches: the records' pre-kernel would be a seventh more of them -- 1024 x 512, config 1)
+        if (need <= 64 && nrows >= 1 && ((size_t)nrows * c.W >= ((size_t)1 << 21) || rows_hook)) {
             const int BT = need <= 32 ? 256 : 128;
             const int bx = (c.W + BT - 1) / BT;
             // rows per block: enough blocks to fill the chip, as tall as that allows (a block re-reads 2 K rows)
             int rows = (int)(((long long)nrows * bx + 4095) / 4096);
             rows = std::min(std::max((rows + BLUR_YT_CHUNK - 1) / BLUR_YT_CHUNK * BLUR_YT_CHUNK, 2 * BLUR_YT_CHUNK), 256);
-            static const int rows_hook = [] { const char *e = dmg_hook("DMG_BLUR_YT_ROWS"); return e ? atoi(e) : 0; }();   // tests: every ring size on small grids
             if (rows_hook >= BLUR_YT_CHUNK) rows = rows_hook / BLUR_YT_CHUNK * BLUR_YT_CHUNK;
             const dim3 gt((unsigned)bx, (unsigned)((nrows + rows - 1) / rows));
             // (a block reads rows + 2 K source rows: on a small grid with a large radius -- 4096 x 2048 from r = 1.2 -- that is
@@ -1176,24 +1177,31 @@ static int upload_rows(dmg_ctx *ctx, dev_buf &d, const std::vector<float> &v) { 
 int blur_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, float *d_field, float *d_tmp, float radius)
 {
     canvas c = make_canvas(grid, topo);
-    std::vector<float> pf(grid.H);
-    for (int y = 0; y < grid.H; y++) pf[y] = glsl::cos(fabsf(dmg_row_lat(grid, y)));   // BlurMenu.cpp:49
-    dev_buf dpf;
-    int rc = upload_rows(ctx, dpf, pf);
-    if (rc) return rc;
+    // cos|lat| per row (BlurMenu.cpp:49) and room for the (0, r) passes' row records (k_blur13_yrec): kept with the context from one
+    // call on a grid to the next (dmg_ctx::blur_rows) -- an erosion round's pre-blur is the same grid every round
+    const size_t pf_bytes = ((size_t)grid.H * 4 + 255) & ~(size_t)255;
+    if (!ctx->blur_rows || memcmp(&ctx->blur_rows_grid, &grid, sizeof(dmg_grid)) != 0) {
+        std::vector<float> pf(grid.H);
+        for (int y = 0; y < grid.H; y++) pf[y] = glsl::cos(fabsf(dmg_row_lat(grid, y)));
+        DMG_HIP(hipStreamSynchronize(ctx->stream));      // (passes of an earlier grid may still read the old tables)
+        if (ctx->blur_rows) { (void)hipFree(ctx->blur_rows); ctx->blur_rows = nullptr; }
+        if (hipMalloc(&ctx->blur_rows, pf_bytes + BLUR_YREC_BYTES(grid.H)) != hipSuccess) { ctx->blur_rows = nullptr; return dmg_fail(DMG_ENOMEM, "blur: no device memory for the row tables"); }
+        DMG_HIP(hipMemcpyAsync(ctx->blur_rows, pf.data(), (size_t)grid.H * 4, hipMemcpyHostToDevice, ctx->stream));
+        DMG_HIP(hipStreamSynchronize(ctx->stream));      // `pf` is a host temporary
+        ctx->blur_rows_grid = grid;
+    }
+    const float *dpf = (const float *)ctx->blur_rows;
+    void *drec = (char *)ctx->blur_rows + pf_bytes;
     std::vector<float> rl = blur_rlist(radius);
     dim3 g((grid.W + 255) / 256, grid.H);
-    dev_buf drec;                                    // the (0, r) passes' per-row records (k_blur13_yrec)
-    if (drec.alloc(ctx, BLUR_YREC_BYTES(grid.H)) != hipSuccess) return dmg_fail(DMG_ENOMEM, "blur: no device memory for the row records");
     size_t i = 0;
     do {                                             // Blur::step (:97-117)
-        launch_blur13(ctx->stream, g, c, d_field, d_tmp, dpf.f(), 0.0f, rl[i], drec.p);   // (0, r)
-        launch_blur13(ctx->stream, g, c, d_tmp, d_field, dpf.f(), rl[i], 0.0f);   // (r, 0)
+        launch_blur13(ctx->stream, g, c, d_field, d_tmp, dpf, 0.0f, rl[i], drec);   // (0, r)
+        launch_blur13(ctx->stream, g, c, d_tmp, d_field, dpf, rl[i], 0.0f);         // (r, 0)
         DMG_HIP(hipGetLastError());
         i++;
     } while (!(i > rl.size() - 1));                  // `i>rlist.size()-1` (:111)
-    DMG_HIP(hipStreamSynchronize(ctx->stream));      // dpf is released on return
-    return DMG_OK;
+    return DMG_OK;                                   // (nothing of this call's to release: no synchronisation)
 }
 
 int erosion_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, const float *d_h, const float *d_flow,

@@ -45,6 +45,7 @@ def test_blur_config1_size(dev, oracle):
 BLUR_CASES = [  # (W, H, canvas, radius): full globe (pole crossings at the large radii), a belt, a polar cap, a window
     (256, 128, None, 1.0), (256, 128, None, 7.5), (200, 100, None, 40.0), (334, 111, None, 3.0), (128, 64, None, 300.0),
     (256, 128, (-1.0, 1.2, -np.pi, np.pi), 5.0), (192, 96, (0.9, np.pi / 2, -np.pi, np.pi), 12.0), (160, 120, (-0.4, 0.3, 0.2, 1.4), 6.0),
+    (2048, 1024, None, 3.0),   # two million cells: from here on the (0, r) pass is the streamed one by default
 ]
 
 
