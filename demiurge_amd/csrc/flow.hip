@@ -1164,7 +1164,7 @@ __global__ void k_growth_seed(const int *__restrict__ mouths, int nm, unsigned *
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < nm) { d[mouths[i]] = 0u; frontier[i] = mouths[i]; }
-    if (i == 0) { count[0] = nm; count[1] = 0; }
+    if (i == 0) { count[0] = nm; count[1] = 0; count[2] = 0; }
 }
 // one relaxation round: every lake of the frontier offers max(d(L), rank) to the lakes behind its passes.  A lake whose d
 // falls joins the next round's frontier once: `stamp` holds the last round a lake was queued for, and only the thread that
@@ -1175,8 +1175,12 @@ __global__ void k_growth_seed(const int *__restrict__ mouths, int nm, unsigned *
 // fewer threads to hide them behind.)
 __global__ __launch_bounds__(256) void k_growth_relax(const int *__restrict__ fin, const int *__restrict__ nin, int *__restrict__ fout, int *__restrict__ nout,
                                                        unsigned *__restrict__ d, const int2 *__restrict__ span, const int *__restrict__ vstart,
-                                                       const int4 *__restrict__ ent, const unsigned *__restrict__ rank, int *__restrict__ stamp, int round)
+                                                       const int4 *__restrict__ ent, const unsigned *__restrict__ rank, int *__restrict__ stamp, int round,
+                                                       int *__restrict__ nclear)
 {
+    // (three counters in turn: this round reads one, fills the next and clears the third -- the one the round before read and the
+    // round after fills -- so no launch stands between two rounds)
+    if (blockIdx.x == 0 && threadIdx.x == 0) *nclear = 0;
     // the next frontier is collected per block in LDS and appended with ONE add on the global counter (block_append_base's
     // reason: an add per lake on one address costs ~5 ns per wave-instruction, serialised; the order inside a frontier
     // does not matter, the levels are a fixed point)
@@ -1209,8 +1213,6 @@ __global__ __launch_bounds__(256) void k_growth_relax(const int *__restrict__ fi
     __syncthreads();
     for (int i = threadIdx.x; i < m; i += blockDim.x) fout[qbase + i] = q[i];
 }
-// between two rounds: the frontier just written becomes the one to read, the other one's counter is cleared
-__global__ void k_growth_flip(int *__restrict__ count, int from) { count[from] = 0; }
 __global__ void k_growth_iota(int *__restrict__ v, int n) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) v[i] = i; }
 // the pass that opens the cascade of every lake in sorted order (only read at a cascade's first lake)
 __global__ void k_growth_heads(const unsigned *__restrict__ dsorted, const int *__restrict__ order, int *__restrict__ head, int n, int nent)
@@ -1647,21 +1649,20 @@ int flow_device(dmg_ctx *ctx, const dmg_grid &grid, const dmg_topology &topo, co
         }
         if ((rc = upload_vec(ctx, gvs, vstart))) return rc;
         // (3) minimax levels: frontier relaxation from the mouths until nothing falls any more
-        DMG_ALLOC_VAR(gd, (size_t)nlakes * 4); DMG_ALLOC_VAR(gq, (size_t)nlakes * 4); DMG_ALLOC_VAR(gfa, (size_t)nlakes * 4); DMG_ALLOC_VAR(gfb, (size_t)nlakes * 4); DMG_ALLOC(gcnt, 8);
+        DMG_ALLOC_VAR(gd, (size_t)nlakes * 4); DMG_ALLOC_VAR(gq, (size_t)nlakes * 4); DMG_ALLOC_VAR(gfa, (size_t)nlakes * 4); DMG_ALLOC_VAR(gfb, (size_t)nlakes * 4); DMG_ALLOC(gcnt, 12);
         hipLaunchKernelGGL(k_growth_init, dim3(lb), dim3(256), 0, st, (unsigned *)gd.p, gq.i(), nlakes);
         hipLaunchKernelGGL(k_growth_seed, dim3((unsigned)((nmouth + 255) / 256)), dim3(256), 0, st, mouths_d.i(), nmouth, (unsigned *)gd.p, gfa.i(), gcnt.i());
         int rounds = 0;
         for (bool more = true; more;) {
             for (int k = 0; k < 16; k++, rounds++) {
-                const int in = rounds & 1;
-                hipLaunchKernelGGL(k_growth_relax, dim3(1024), dim3(256), 0, st, in ? gfb.i() : gfa.i(), gcnt.i() + in, in ? gfa.i() : gfb.i(), gcnt.i() + (in ^ 1),
-                                   (unsigned *)gd.p, (const int2 *)dspan.p, gvs.i(), (const int4 *)dent.p, (const unsigned *)grank.p, gq.i(), rounds);
-                hipLaunchKernelGGL(k_growth_flip, dim3(1), dim3(1), 0, st, gcnt.i(), in);
+                const int in = rounds & 1;                                     // (the frontier lists alternate, the counters go round in threes)
+                hipLaunchKernelGGL(k_growth_relax, dim3(1024), dim3(256), 0, st, in ? gfb.i() : gfa.i(), gcnt.i() + rounds % 3, in ? gfa.i() : gfb.i(), gcnt.i() + (rounds + 1) % 3,
+                                   (unsigned *)gd.p, (const int2 *)dspan.p, gvs.i(), (const int4 *)dent.p, (const unsigned *)grank.p, gq.i(), rounds, gcnt.i() + (rounds + 2) % 3);
             }
-            int cnt[2] = { 0, 0 };
-            DMG_HIP(hipMemcpyAsync(cnt, gcnt.p, 8, hipMemcpyDeviceToHost, st));
+            int cnt[3] = { 0, 0, 0 };
+            DMG_HIP(hipMemcpyAsync(cnt, gcnt.p, 12, hipMemcpyDeviceToHost, st));
             DMG_HIP(hipStreamSynchronize(st));
-            more = cnt[rounds & 1] != 0;
+            more = cnt[rounds % 3] != 0;
             if (rounds > 4 * nlakes + 64) return dmg_fail(DMG_ESTATE, "flow: the minimax levels of the lake graph did not settle");
         }
         // (4) lakes in order of their level; the pass that opens each lake's cascade
