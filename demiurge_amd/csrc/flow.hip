@@ -173,7 +173,9 @@ __global__ void k_flow_jump(const int *__restrict__ pin, const int *__restrict__
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    int p = pin[i], pp = pin[p];
+    int p = pin[i];
+    if (p == (int)i && !first) return;                 // (a root -- every sea cell is one: both tables hold (i, 0) since the first round; not even read)
+    int pp = pin[p];
     if (pp == p && !first && pout[i] == p) return;
     dout[i] = din[i] + din[p];
     pout[i] = pp;
