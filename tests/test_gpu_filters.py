@@ -83,6 +83,27 @@ def test_blur_axis_kernels_equal_the_literal_kernel_and_the_oracle(dev, oracle):
         assert res.stdout.split() == mine, hook
 
 
+def test_blur_streamed_pass_equals_round5_kernel_at_size():
+    """The (0, r) pass streamed down the columns (k_blur13_ytile, round 6) against round 5's k_blur13_axis2<1> at 16384x8192 and at config 2's
+    4096x2048: the same passes on the same field in two processes (DMG_BLUR_NO_YTILE is read once per process), SHA-256 of what they
+    leave -- every ring size (radii up to 5) with the block heights the sizes really get, and a radius beyond the rings (7.5: both take
+    the old kernel)."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    outs = []
+    for extra in ({}, {"DMG_BLUR_NO_YTILE": "1"}):
+        res = subprocess.run([sys.executable, str(root / "tools" / "blur_pass_probe.py")], cwd=str(root), env=dict(os.environ, DMG_TEST_HOOKS="1", **extra),
+                             capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-2000:]
+        shas = [l.split("sha")[-1].strip() for l in res.stdout.splitlines() if " sha " in l]
+        assert len(shas) == 2, res.stdout[-2000:]
+        outs.append(shas)
+    assert outs[0] == outs[1], outs
+
+
 def test_temperature(dev, oracle):
     capi, ctx = dev
     G = load_golden("temperature_128x64_full")
