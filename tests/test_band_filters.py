@@ -49,6 +49,22 @@ def test_band_blur_is_bitwise(dev, bands, radius):
         assert np.array_equal(got, ref), (bands, radius)
 
 
+def test_band_blur_is_bitwise_through_the_streamed_pass():
+    """The same with the (0, r) pass streamed down the columns (k_blur13_ytile), which grids of this size do not get by themselves:
+    DMG_BLUR_YT_ROWS forces it (read once per process: a child runs the test above), so its loads stay inside a band's ghost rows
+    and its row records follow a band's first row."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    for rows in ("8", "24"):
+        res = subprocess.run([sys.executable, "-m", "pytest", str(Path(__file__).resolve()), "-q", "-m", "gpu", "-k", "test_band_blur_is_bitwise and not streamed",
+                              "-p", "no:cacheprovider"], cwd=str(root), env=dict(os.environ, DMG_TEST_HOOKS="1", DMG_BLUR_YT_ROWS=rows),
+                             capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0 and "3 passed" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
+
+
 @pytest.mark.parametrize("bands", [2, 3])
 def test_band_erosion_pass_is_bitwise(dev, bands):
     capi, ctx = dev
